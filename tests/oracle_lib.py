@@ -1,0 +1,224 @@
+"""ctypes binding of oracle/liboracle.so for the tests, smoke() and bench.py's cpu_baseline leg.
+
+TEST INFRASTRUCTURE: the product package (humanoid_mujoco_amd/) never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+HUMANOID_HBM = os.path.join(GOLDEN, "humanoid27.hbm")
+
+_lib = None
+
+
+def build_oracle(force=False):
+    src = os.path.join(ORACLE_DIR, "mjstep_oracle.c")
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return ORACLE_SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        L = ctypes.CDLL(ORACLE_SO)
+        vp, cp, ci, cd = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_double
+        pd, pi = ctypes.POINTER(cd), ctypes.POINTER(ci)
+        L.om_load.restype = vp; L.om_load.argtypes = [cp, cp, ci]
+        L.om_make_data.restype = vp; L.om_make_data.argtypes = [vp]
+        L.om_free_data.argtypes = [vp]
+        L.om_reset.argtypes = [vp, vp, ci]
+        L.om_forward.argtypes = [vp, vp]
+        L.om_step.argtypes = [vp, vp]
+        L.om_data_ptr.restype = pd; L.om_data_ptr.argtypes = [vp, vp, cp, pi]
+        L.om_model_ptr.restype = pd; L.om_model_ptr.argtypes = [vp, cp, pi]
+        L.om_model_int.restype = ci; L.om_model_int.argtypes = [vp, cp]
+        L.om_model_set_int.argtypes = [vp, cp, ci]
+        L.om_model_set_dbl.argtypes = [vp, cp, cd]
+        L.om_model_dbl.restype = cd; L.om_model_dbl.argtypes = [vp, cp]
+        L.om_data_int.restype = ci; L.om_data_int.argtypes = [vp, cp]
+        L.om_data_time.restype = cd; L.om_data_time.argtypes = [vp]
+        L.om_data_set_time.argtypes = [vp, cd]
+        L.om_contact_get.argtypes = [vp, ci, pd]
+        L.om_efc_types.argtypes = [vp, pi, pi]
+        L.om_stats.argtypes = [vp, pd]
+        L.om_halton.restype = cd; L.om_halton.argtypes = [ci, ci]
+        L.om_init_env.argtypes = [vp, vp, ci]
+        L.om_ctrl_env.argtypes = [vp, pd, ci, ci]
+        L.om_rollout_threads.restype = ctypes.c_longlong
+        L.om_rollout_threads.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+        _lib = L
+    return _lib
+
+
+def parse_hbm(path):
+    """Independent (Python) reader of the .hbm text model: dict name -> int/float/np.ndarray/list."""
+    out = {}
+    with open(path) as f:
+        first = f.readline()
+        assert first.startswith("HBM1"), "not an HBM1 file"
+        for line in f:
+            line = line.strip()
+            if line == "END":
+                break
+            if not line or line[0] == "#":
+                continue
+            tok = line.split()
+            kind, name = tok[0], tok[1]
+            if kind == "i":
+                out[name] = int(tok[2])
+            elif kind == "d":
+                out[name] = float(tok[2])
+            elif kind == "I":
+                out[name] = np.array([int(x) for x in tok[3:]], dtype=np.int64)
+            elif kind == "D":
+                out[name] = np.array([float(x) for x in tok[3:]], dtype=np.float64)
+            elif kind == "S":
+                out[name] = ["" if x == "-" else x for x in tok[3:]]
+    return out
+
+
+class Oracle:
+    """One model + one data block of the fp64 oracle."""
+
+    def __init__(self, hbm_path=HUMANOID_HBM):
+        self.L = lib()
+        err = ctypes.create_string_buffer(512)
+        self.m = self.L.om_load(hbm_path.encode(), err, 512)
+        if not self.m:
+            raise RuntimeError("oracle: " + err.value.decode())
+        self.d = self.L.om_make_data(self.m)
+        self.info = parse_hbm(hbm_path)
+        for k in ("nq", "nv", "nu", "nbody", "njnt", "ngeom", "ntendon", "nM"):
+            setattr(self, k, self.L.om_model_int(self.m, k.encode()))
+
+    def __del__(self):
+        try:
+            if self.d:
+                self.L.om_free_data(self.d)
+        except Exception:
+            pass
+
+    # ---- arrays are live views into the oracle's memory
+    def arr(self, name):
+        n = ctypes.c_int()
+        p = self.L.om_data_ptr(self.m, self.d, name.encode(), ctypes.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, (max(n.value, 0),))
+
+    def marr(self, name):
+        n = ctypes.c_int()
+        p = self.L.om_model_ptr(self.m, name.encode(), ctypes.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, (n.value,))
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name in ("L", "m", "d", "info"):
+            raise AttributeError(name)
+        try:
+            return self.arr(name)
+        except KeyError:
+            raise AttributeError(name)
+
+    def dint(self, name):
+        return self.L.om_data_int(self.d, name.encode())
+
+    @property
+    def ncon(self):
+        return self.dint("ncon")
+
+    @property
+    def nefc(self):
+        return self.dint("nefc")
+
+    @property
+    def time(self):
+        return self.L.om_data_time(self.d)
+
+    def set_opt(self, **kw):
+        for k, v in kw.items():
+            if k in ("iterations", "disableflags"):
+                self.L.om_model_set_int(self.m, k.encode(), int(v))
+            else:
+                self.L.om_model_set_dbl(self.m, k.encode(), float(v))
+
+    def opt(self, name):
+        if name in ("iterations", "disableflags", "solver"):
+            return self.L.om_model_int(self.m, name.encode())
+        return self.L.om_model_dbl(self.m, name.encode())
+
+    def reset(self, key=-1):
+        self.L.om_reset(self.m, self.d, key)
+
+    def forward(self):
+        self.L.om_forward(self.m, self.d)
+
+    def step(self, n=1):
+        for _ in range(n):
+            self.L.om_step(self.m, self.d)
+
+    def init_env(self, e):
+        self.L.om_init_env(self.m, self.d, e)
+
+    def ctrl_env(self, t, e):
+        c = np.zeros(self.nu)
+        self.L.om_ctrl_env(self.m, c.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), t, e)
+        return c
+
+    def contacts(self):
+        out = []
+        buf = (ctypes.c_double * 18)()
+        for k in range(self.ncon):
+            self.L.om_contact_get(self.d, k, buf)
+            a = np.array(buf[:])
+            out.append(dict(dist=a[0], pos=a[1:4].copy(), frame=a[4:13].reshape(3, 3).copy(), dim=int(a[13]),
+                            geom1=int(a[14]), geom2=int(a[15]), efc_address=int(a[16]), friction=a[17]))
+        return out
+
+    def efc_types(self):
+        n = self.nefc
+        t = (ctypes.c_int * max(n, 1))()
+        i = (ctypes.c_int * max(n, 1))()
+        self.L.om_efc_types(self.d, t, i)
+        return np.array(t[:n]), np.array(i[:n])
+
+    def dense_M(self):
+        """Dense mass matrix from the ancestor-chain sparse qM."""
+        nv = self.nv
+        M = np.zeros((nv, nv))
+        qM = self.arr("qM")
+        par, madr = self.info["dof_parentid"], self.info["dof_Madr"]
+        for i in range(nv):
+            a = madr[i]
+            j = i
+            while j >= 0:
+                M[i, j] = M[j, i] = qM[a]
+                a += 1
+                j = par[j]
+        return M
+
+    def rollout_threads(self, n_env, nstep, nthread, env_offset=0, want_qpos=False):
+        q = np.zeros((n_env, self.nq)) if want_qpos else None
+        st = (ctypes.c_double * 5)()
+        n = self.L.om_rollout_threads(self.m, n_env, nstep, nthread, env_offset,
+                                      q.ctypes.data if q is not None else None, ctypes.addressof(st))
+        return n, q, dict(mean_ncon=st[0], mean_nefc=st[1], mean_iter=st[2], max_ncon=st[3], max_nefc=st[4])
+
+
+def halton(index, base):
+    """Python restatement of the radical inverse (mju_Halton, mujoco.h:1231), for cross-checks."""
+    f, r = 1.0 / base, 0.0
+    while index > 0:
+        r += f * (index % base)
+        index //= base
+        f /= base
+    return r

@@ -1,0 +1,17 @@
+// hb_compile — compile an MJCF file to the .hbm text model (host only, no GPU needed).
+// usage: hb_compile in.xml out.hbm
+#include "../humanoid_mujoco_amd/csrc/hb_model.hpp"
+#include <cstdio>
+int main(int argc, char** argv) {
+  if (argc < 3) { fprintf(stderr, "usage: %s in.xml|in.hbm out.hbm\n", argv[0]); return 2; }
+  hb::Model m;
+  std::string err, in = argv[1];
+  bool ok = in.size() > 4 && in.substr(in.size() - 4) == ".hbm" ? hb::load_hbm(in, m, err) : hb::compile_mjcf_file(in, m, err);
+  if (!ok) { fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
+  if (!hb::save_hbm(m, argv[2], err)) { fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
+  double mass = 0;
+  for (int b = 0; b < m.nbody; b++) mass += m.body_mass[b];
+  printf("nq=%d nv=%d nu=%d nbody=%d njnt=%d ngeom=%d ntendon=%d nM=%d npair=%d nkey=%d mass=%.6f meaninertia=%.6f\n",
+         m.nq, m.nv, m.nu, m.nbody, m.njnt, m.ngeom, m.ntendon, m.nM, m.npair, m.nkey, mass, m.meaninertia);
+  return 0;
+}

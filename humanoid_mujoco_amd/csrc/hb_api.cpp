@@ -1,0 +1,683 @@
+// hb_api.cpp — the C-ABI of libhb.so (include/hb.h): model handles, device model tables,
+// batches of environments on one GPU, and the launch plumbing around hb_kernels.hip.
+//
+// Host C++ only; no PyTorch.  One hb_batch owns one HIP stream and all device memory of its
+// envs; the model is immutable and shareable (reference ownership rules: SURVEY.md §8b).
+#include "../../include/hb.h"
+#include "hb_device.hpp"
+#include "hb_launch.hpp"
+#include "hb_model.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hb;
+
+struct hb_model {
+  Model m;
+};
+
+namespace {
+
+void set_err(char* err, int err_sz, const std::string& s) {
+  if (err && err_sz > 0) { snprintf(err, err_sz, "%s", s.c_str()); }
+}
+
+// flat table builder: ints and floats pushed into two arrays; offsets resolved after upload
+struct TableBuilder {
+  std::vector<int> iv;
+  std::vector<float> fv;
+  std::vector<unsigned long long> uv;
+  size_t addi(const std::vector<int>& v) { size_t o = iv.size(); iv.insert(iv.end(), v.begin(), v.end()); if (v.empty()) iv.push_back(0); return o; }
+  size_t addf(const std::vector<double>& v) { size_t o = fv.size(); for (double x : v) fv.push_back((float)x); if (v.empty()) fv.push_back(0.f); return o; }
+  size_t addu(const std::vector<unsigned long long>& v) { size_t o = uv.size(); uv.insert(uv.end(), v.begin(), v.end()); if (v.empty()) uv.push_back(0); return o; }
+};
+
+struct DeviceModel {
+  DevModel dm;
+  int* d_int = nullptr;
+  float* d_flt = nullptr;
+  unsigned long long* d_u64 = nullptr;
+  float* d_qpos_src = nullptr;  // qpos0 followed by keyframes, fp32
+  ~DeviceModel() {
+    if (d_int) (void)hipFree(d_int);
+    if (d_flt) (void)hipFree(d_flt);
+    if (d_u64) (void)hipFree(d_u64);
+    if (d_qpos_src) (void)hipFree(d_qpos_src);
+  }
+};
+
+// contact parameter mixing per candidate pair (mj_contactParam restatement; static per pair)
+void mix_pair(const Model& m, int g1, int g2, int& dim, double* fr, double* solref, double* solimp, double& margin, double& gap) {
+  dim = std::max(m.geom_condim[g1], m.geom_condim[g2]);
+  int p1 = m.geom_priority[g1], p2 = m.geom_priority[g2];
+  if (p1 != p2) {
+    int g = p1 > p2 ? g1 : g2;
+    dim = m.geom_condim[g];
+    for (int i = 0; i < 3; i++) fr[i] = m.geom_friction[3 * g + i];
+    for (int i = 0; i < 2; i++) solref[i] = m.geom_solref[2 * g + i];
+    for (int i = 0; i < 5; i++) solimp[i] = m.geom_solimp[5 * g + i];
+  } else {
+    for (int i = 0; i < 3; i++) fr[i] = std::max(m.geom_friction[3 * g1 + i], m.geom_friction[3 * g2 + i]);
+    double s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2], mix;
+    const double MINVAL = 1e-15;
+    if (s1 >= MINVAL && s2 >= MINVAL) mix = s1 / (s1 + s2);
+    else if (s1 < MINVAL && s2 < MINVAL) mix = 0.5;
+    else mix = s1 < MINVAL ? 0.0 : 1.0;
+    const double *r1 = &m.geom_solref[2 * g1], *r2 = &m.geom_solref[2 * g2];
+    if (r1[0] > 0 && r2[0] > 0) for (int i = 0; i < 2; i++) solref[i] = mix * r1[i] + (1 - mix) * r2[i];
+    else for (int i = 0; i < 2; i++) solref[i] = std::min(r1[i], r2[i]);
+    for (int i = 0; i < 5; i++) solimp[i] = mix * m.geom_solimp[5 * g1 + i] + (1 - mix) * m.geom_solimp[5 * g2 + i];
+  }
+  margin = std::max(m.geom_margin[g1], m.geom_margin[g2]);
+  gap = std::max(m.geom_gap[g1], m.geom_gap[g2]);
+}
+
+bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
+  if (m.nv > 32) { err = "this build supports nv <= 32 degrees of freedom"; return false; }
+  if (m.nbody > 64 || m.ngeom > 64) { err = "this build supports at most 64 bodies and 64 geoms"; return false; }
+  for (int g = 0; g < m.ngeom; g++)
+    if (m.geom_type[g] == GEOM_HFIELD) { err = "height-field collision is not implemented on the device path yet"; return false; }
+  for (int j = 0; j < m.njnt; j++)
+    if (m.jnt_type[j] == JNT_BALL) { err = "ball joints are not supported"; return false; }
+  TableBuilder T;
+  DevModel& dm = D.dm;
+  memset(&dm, 0, sizeof dm);
+  int nb = m.nbody, nv = m.nv;
+  dm.nq = m.nq; dm.nv = nv; dm.nu = m.nu; dm.nbody = nb; dm.njnt = m.njnt; dm.ngeom = m.ngeom; dm.ntendon = m.ntendon; dm.nM = m.nM; dm.npair = m.npair;
+  dm.nstate = 1 + m.nq + 2 * nv;
+  dm.timestep = (float)m.timestep;
+  for (int i = 0; i < 3; i++) dm.gravity[i] = (float)m.gravity[i];
+  dm.inv_sqrt_impratio = (float)(1.0 / std::sqrt(m.impratio));
+  dm.tolerance = (float)m.tolerance;
+  dm.pgs_scale = (float)(1.0 / (m.meaninertia * std::max(1, nv)));
+  dm.iterations = m.iterations;
+  dm.disableflags = m.disableflags;
+
+  // trees, levels, children, dof masks
+  std::vector<int> treeid(nb, 0), roots;
+  for (int b = 1; b < nb; b++) {
+    if (m.body_parentid[b] == 0) { treeid[b] = (int)roots.size(); roots.push_back(b); }
+    else treeid[b] = treeid[m.body_parentid[b]];
+  }
+  dm.ntree = (int)roots.size();
+  std::vector<double> tree_invmass;
+  for (int r : roots) tree_invmass.push_back(m.body_subtreemass[r] > 1e-15 ? 1.0 / m.body_subtreemass[r] : 0.0);
+  int maxdepth = 0;
+  for (int b = 0; b < nb; b++) maxdepth = std::max(maxdepth, m.body_depth[b]);
+  dm.nlevel = maxdepth + 1;
+  std::vector<int> level_adr(dm.nlevel, 0), level_num(dm.nlevel, 0), level_body;
+  for (int L = 0; L <= maxdepth; L++) {
+    level_adr[L] = (int)level_body.size();
+    for (int b = 0; b < nb; b++) if (m.body_depth[b] == L) { level_body.push_back(b); level_num[L]++; }
+  }
+  std::vector<int> childadr(nb, 0), childnum(nb, 0), child_list;
+  for (int b = 0; b < nb; b++) {
+    childadr[b] = (int)child_list.size();
+    for (int c = 1; c < nb; c++) if (m.body_parentid[c] == b && c != b) { child_list.push_back(c); childnum[b]++; }
+  }
+  std::vector<unsigned long long> dofmask(nb, 0);
+  for (int b = 1; b < nb; b++)
+    for (int a = b; a > 0; a = m.body_parentid[a])
+      for (int k = 0; k < m.body_dofnum[a]; k++) dofmask[b] |= 1ull << (m.body_dofadr[a] + k);
+  // dof ancestry
+  std::vector<int> nanc(nv, 0), dof_qposadr(nv, 0), Mi(m.nM), Mj(m.nM);
+  for (int i = 0; i < nv; i++) {
+    int adr = m.dof_Madr[i];
+    for (int j = i; j >= 0; j = m.dof_parentid[j]) { Mi[adr] = i; Mj[adr] = j; adr++; }
+    nanc[i] = adr - m.dof_Madr[i] - 1;
+    int jn = m.dof_jntid[i];
+    dof_qposadr[i] = m.jnt_qposadr[jn] + (i - m.jnt_dofadr[jn]);
+  }
+  std::vector<int> fac_adr(nv + 1, 0), fac_dst, fac_src, fac_tmp;
+  for (int k = 0; k < nv; k++) {
+    fac_adr[k] = (int)fac_dst.size();
+    int Mki = m.dof_Madr[k] + 1, i = m.dof_parentid[k];
+    while (i >= 0) {
+      int cnt = nanc[i] + 1;
+      for (int t = 0; t < cnt; t++) { fac_dst.push_back(m.dof_Madr[i] + t); fac_src.push_back(Mki + t); fac_tmp.push_back(Mki); }
+      i = m.dof_parentid[i];
+      Mki++;
+    }
+  }
+  fac_adr[nv] = (int)fac_dst.size();
+  dm.nfac = (int)fac_dst.size();
+  std::vector<int> desc_adr(nv + 1, 0), desc_k, desc_M;
+  for (int i = 0; i < nv; i++) {
+    desc_adr[i] = (int)desc_k.size();
+    for (int k = i + 1; k < nv; k++) {
+      int pos = 1;
+      for (int a = m.dof_parentid[k]; a >= 0; a = m.dof_parentid[a], pos++)
+        if (a == i) { desc_k.push_back(k); desc_M.push_back(m.dof_Madr[k] + pos); break; }
+    }
+  }
+  desc_adr[nv] = (int)desc_k.size();
+  // pairs
+  std::vector<int> pair_dim;
+  std::vector<double> pair_fr, pair_solref, pair_solimp, pair_margin, pair_gap;
+  for (int p = 0; p < m.npair; p++) {
+    int dim; double fr[3], sr[2], si[5], mg, gp;
+    mix_pair(m, m.pair_geom1[p], m.pair_geom2[p], dim, fr, sr, si, mg, gp);
+    if (dim != 1 && dim != 3) { err = "contact dimension " + std::to_string(dim) + " is not implemented (condim 1 and 3 only)"; return false; }
+    pair_dim.push_back(dim);
+    for (double v : fr) pair_fr.push_back(v);
+    for (double v : sr) pair_solref.push_back(v);
+    for (double v : si) pair_solimp.push_back(v);
+    pair_margin.push_back(mg); pair_gap.push_back(gp);
+  }
+  // limit candidates
+  std::vector<int> lim_kind, lim_id, lim_side;
+  std::vector<double> lim_range, lim_margin, lim_solref, lim_solimp, lim_invw;
+  for (int j = 0; j < m.njnt; j++) {
+    if (!m.jnt_limited[j] || (m.jnt_type[j] != JNT_HINGE && m.jnt_type[j] != JNT_SLIDE)) continue;
+    for (int side = -1; side <= 1; side += 2) {
+      lim_kind.push_back(0); lim_id.push_back(j); lim_side.push_back(side);
+      lim_range.push_back(m.jnt_range[2 * j + (side + 1) / 2]); lim_margin.push_back(m.jnt_margin[j]);
+      for (int i = 0; i < 2; i++) lim_solref.push_back(m.jnt_solref[2 * j + i]);
+      for (int i = 0; i < 5; i++) lim_solimp.push_back(m.jnt_solimp[5 * j + i]);
+      lim_invw.push_back(m.dof_invweight0[m.jnt_dofadr[j]]);
+    }
+  }
+  for (int t = 0; t < m.ntendon; t++) {
+    if (!m.tendon_limited[t]) continue;
+    for (int side = -1; side <= 1; side += 2) {
+      lim_kind.push_back(1); lim_id.push_back(t); lim_side.push_back(side);
+      lim_range.push_back(m.tendon_range[2 * t + (side + 1) / 2]); lim_margin.push_back(m.tendon_margin[t]);
+      for (int i = 0; i < 2; i++) lim_solref.push_back(m.tendon_solref_lim[2 * t + i]);
+      for (int i = 0; i < 5; i++) lim_solimp.push_back(m.tendon_solimp_lim[5 * t + i]);
+      lim_invw.push_back(m.tendon_invweight0[t]);
+    }
+  }
+  dm.nlimcand = (int)lim_kind.size();
+  std::vector<int> wrap_dofadr, wrap_qposadr;
+  for (int w = 0; w < m.nwrap; w++) { wrap_dofadr.push_back(m.jnt_dofadr[m.wrap_objid[w]]); wrap_qposadr.push_back(m.jnt_qposadr[m.wrap_objid[w]]); }
+  std::vector<int> act_qposadr, act_dofadr;
+  for (int a = 0; a < m.nu; a++) { act_qposadr.push_back(m.jnt_qposadr[m.actuator_trnid[a]]); act_dofadr.push_back(m.jnt_dofadr[m.actuator_trnid[a]]); }
+  // env adapter
+  dm.obs_root_body = -1; dm.obs_root_dofadr = -1;
+  int nscalar = 0;
+  for (int j = 0; j < m.njnt; j++) {
+    if (m.jnt_type[j] == JNT_FREE && dm.obs_root_dofadr < 0) { dm.obs_root_dofadr = m.jnt_dofadr[j]; dm.obs_root_body = m.jnt_bodyid[j]; }
+    if (m.jnt_type[j] == JNT_HINGE || m.jnt_type[j] == JNT_SLIDE) nscalar++;
+  }
+  dm.nobs = 2 * nscalar + 6;
+
+  // ---- offsets into the flat tables
+  struct IO { const int** p; size_t o; };
+  struct FO { const float** p; size_t o; };
+  std::vector<IO> io;
+  std::vector<FO> fo;
+#define TI(field, vec) io.push_back({&dm.field, T.addi(vec)})
+#define TF(field, vec) fo.push_back({&dm.field, T.addf(vec)})
+  TI(body_parentid, m.body_parentid); TI(body_treeid, treeid); TI(body_jntnum, m.body_jntnum); TI(body_jntadr, m.body_jntadr);
+  TI(body_dofnum, m.body_dofnum); TI(body_dofadr, m.body_dofadr); TI(body_childadr, childadr); TI(body_childnum, childnum); TI(child_list, child_list);
+  TI(level_adr, level_adr); TI(level_num, level_num); TI(level_body, level_body);
+  TF(body_pos, m.body_pos); TF(body_quat, m.body_quat); TF(body_ipos, m.body_ipos); TF(body_iquat, m.body_iquat); TF(body_mass, m.body_mass);
+  TF(body_inertia, m.body_inertia); TF(body_invweight0, m.body_invweight0); TF(tree_invmass, tree_invmass);
+  TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TI(jnt_bodyid, m.jnt_bodyid);
+  TF(jnt_pos, m.jnt_pos); TF(jnt_axis, m.jnt_axis); TF(jnt_stiffness, m.jnt_stiffness); TF(qpos0, m.qpos0); TF(qpos_spring, m.qpos_spring);
+  TI(dof_bodyid, m.dof_bodyid); TI(dof_jntid, m.dof_jntid); TI(dof_parentid, m.dof_parentid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TI(dof_qposadr, dof_qposadr);
+  TF(dof_armature, m.dof_armature); TF(dof_damping, m.dof_damping);
+  TI(M_i, Mi); TI(M_j, Mj);
+  TI(fac_adr, fac_adr); TI(fac_dst, fac_dst); TI(fac_src, fac_src); TI(fac_tmp, fac_tmp);
+  TI(desc_adr, desc_adr); TI(desc_k, desc_k); TI(desc_M, desc_M);
+  TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid);
+  TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
+  TI(pair_geom1, m.pair_geom1); TI(pair_geom2, m.pair_geom2); TI(pair_dim, pair_dim);
+  TF(pair_friction, pair_fr); TF(pair_solref, pair_solref); TF(pair_solimp, pair_solimp); TF(pair_margin, pair_margin); TF(pair_gap, pair_gap);
+  TI(lim_kind, lim_kind); TI(lim_id, lim_id); TI(lim_side, lim_side);
+  TF(lim_range, lim_range); TF(lim_margin, lim_margin); TF(lim_solref, lim_solref); TF(lim_solimp, lim_solimp); TF(lim_invweight, lim_invw);
+  TI(tendon_adr, m.tendon_adr); TI(tendon_num, m.tendon_num); TI(wrap_dofadr, wrap_dofadr); TI(wrap_qposadr, wrap_qposadr);
+  TF(wrap_prm, m.wrap_prm);
+  TI(act_qposadr, act_qposadr); TI(act_dofadr, act_dofadr); TI(act_ctrllimited, m.actuator_ctrllimited); TI(act_forcelimited, m.actuator_forcelimited);
+  TF(act_gear, m.actuator_gear); TF(act_ctrlrange, m.actuator_ctrlrange); TF(act_forcerange, m.actuator_forcerange); TF(act_gain, m.actuator_gainprm);
+  TF(act_bias, m.actuator_biasprm);
+#undef TI
+#undef TF
+  size_t o_mask = T.addu(dofmask);
+
+  // ---- LDS layout
+  int off = 0;
+  auto take = [&](int n) { int o = off; off += (n + 3) & ~3; return o; };
+  dm.cstride = 33;
+  dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
+  dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(6 * nv);
+  dm.o_qM = take(m.nM); dm.o_qLD = take(m.nM); dm.o_dinv = take(nv); dm.o_dsqrtinv = take(nv); dm.o_smooth = take(nv);
+  dm.o_vec0 = take(nv); dm.o_vec1 = take(nv); dm.o_vec2 = take(nv); dm.o_tenlen = take(std::max(1, m.ntendon));
+  int region = off;
+  dm.o_xpos = take(3 * nb); dm.o_xquat = take(4 * nb); dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
+  dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(10 * nb);
+  dm.o_cdofdot = take(6 * nv); dm.o_cvel = take(6 * nb); dm.o_cacc = take(6 * nb); dm.o_cfrc = take(6 * nb);
+  int endA = off;
+  off = region;
+  dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride); dm.o_efc = take(13 * kNefcMax);
+  dm.o_AR = take(kNefcMax * (kNefcMax | 1));
+  int endB = off;
+  // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
+  dm.lds_floats = std::max(endA, endB);
+  if (dm.lds_floats * 4 > 160 * 1024) { err = "model needs more LDS than one CU has"; return false; }
+
+  // ---- upload
+  if (hipMalloc((void**)&D.d_int, T.iv.size() * sizeof(int)) != hipSuccess || hipMalloc((void**)&D.d_flt, T.fv.size() * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&D.d_u64, T.uv.size() * sizeof(unsigned long long)) != hipSuccess) { err = "hipMalloc failed for model tables"; return false; }
+  if (hipMemcpy(D.d_int, T.iv.data(), T.iv.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(D.d_flt, T.fv.data(), T.fv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(D.d_u64, T.uv.data(), T.uv.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy failed for model tables"; return false; }
+  for (auto& x : io) *x.p = D.d_int + x.o;
+  for (auto& x : fo) *x.p = D.d_flt + x.o;
+  dm.body_dofmask = D.d_u64 + o_mask;
+  std::vector<float> qsrc;
+  for (double v : m.qpos0) qsrc.push_back((float)v);
+  for (double v : m.key_qpos) qsrc.push_back((float)v);
+  if (hipMalloc((void**)&D.d_qpos_src, qsrc.size() * sizeof(float)) != hipSuccess ||
+      hipMemcpy(D.d_qpos_src, qsrc.data(), qsrc.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMalloc failed for qpos sources"; return false; }
+  return true;
+}
+
+}  // namespace
+
+struct hb_batch {
+  const hb_model* model = nullptr;
+  DeviceModel D;
+  int n_env = 0, device = 0;
+  hipStream_t stream = nullptr;
+  float *d_state = nullptr, *d_ctrl = nullptr, *d_xfrc = nullptr, *d_diag_qacc = nullptr, *d_diag_force = nullptr, *d_diag_contact = nullptr;
+  float *d_obs = nullptr, *d_reward = nullptr;
+  uint8_t *d_term = nullptr, *d_trunc = nullptr, *d_mask = nullptr;
+  int *d_status = nullptr, *d_counts = nullptr;
+  size_t ctrl_cap = 0;  // floats
+  float* d_qpos_out = nullptr;
+  size_t qpos_out_cap = 0;
+  bool diag = false;
+};
+
+namespace {
+
+#define HB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { return HB_ENODEVICE; } } while (0)
+
+int ensure_ctrl(hb_batch* b, size_t floats) {
+  if (floats <= b->ctrl_cap) return HB_OK;
+  if (b->d_ctrl) (void)hipFree(b->d_ctrl);
+  b->d_ctrl = nullptr; b->ctrl_cap = 0;
+  if (hipMalloc((void**)&b->d_ctrl, floats * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+  b->ctrl_cap = floats;
+  return HB_OK;
+}
+
+BatchPtrs make_ptrs(hb_batch* b) {
+  BatchPtrs P;
+  memset(&P, 0, sizeof P);
+  P.state = b->d_state; P.status = b->d_status; P.counts = b->d_counts; P.xfrc = b->d_xfrc;
+  if (b->diag) { P.diag_qacc = b->d_diag_qacc; P.diag_force = b->d_diag_force; P.diag_contact = b->d_diag_contact; }
+  P.n_env = b->n_env;
+  P.integrate = 1;
+  return P;
+}
+
+// field offsets of the per-env state record for a state spec
+struct SpecLayout { int total; };
+int spec_size(const Model& m, unsigned spec) {
+  int n = 0;
+  if (spec & HB_STATE_TIME) n += 1;
+  if (spec & HB_STATE_QPOS) n += m.nq;
+  if (spec & HB_STATE_QVEL) n += m.nv;
+  if (spec & HB_STATE_WARMSTART) n += m.nv;
+  if (spec & HB_STATE_XFRC_APPLIED) n += 6 * m.nbody;
+  return n;
+}
+const unsigned kSupportedSpec = HB_STATE_TIME | HB_STATE_QPOS | HB_STATE_QVEL | HB_STATE_WARMSTART | HB_STATE_XFRC_APPLIED;
+
+template <class T>
+int get_state_impl(hb_batch* b, unsigned spec, T* out) {
+  if (!b || !out || (spec & ~kSupportedSpec) || !spec) return HB_EINVAL;
+  const Model& m = b->model->m;
+  int ns = b->D.dm.nstate, n = b->n_env, w = spec_size(m, spec);
+  std::vector<float> host((size_t)n * ns), xf;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipMemcpy(host.data(), b->d_state, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+  if (spec & HB_STATE_XFRC_APPLIED) {
+    xf.assign((size_t)n * 6 * m.nbody, 0.f);
+    if (b->d_xfrc) HB_HIP(hipMemcpy(xf.data(), b->d_xfrc, xf.size() * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  for (int e = 0; e < n; e++) {
+    const float* s = &host[(size_t)e * ns];
+    T* o = out + (size_t)e * w;
+    if (spec & HB_STATE_TIME) *o++ = (T)s[0];
+    if (spec & HB_STATE_QPOS) for (int i = 0; i < m.nq; i++) *o++ = (T)s[1 + i];
+    if (spec & HB_STATE_QVEL) for (int i = 0; i < m.nv; i++) *o++ = (T)s[1 + m.nq + i];
+    if (spec & HB_STATE_WARMSTART) for (int i = 0; i < m.nv; i++) *o++ = (T)s[1 + m.nq + m.nv + i];
+    if (spec & HB_STATE_XFRC_APPLIED) for (int i = 0; i < 6 * m.nbody; i++) *o++ = (T)xf[(size_t)e * 6 * m.nbody + i];
+  }
+  return HB_OK;
+}
+
+template <class T>
+int set_state_impl(hb_batch* b, unsigned spec, const T* in) {
+  if (!b || !in || (spec & ~kSupportedSpec) || !spec) return HB_EINVAL;
+  const Model& m = b->model->m;
+  int ns = b->D.dm.nstate, n = b->n_env, w = spec_size(m, spec);
+  std::vector<float> host((size_t)n * ns);
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipMemcpy(host.data(), b->d_state, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<float> xf;
+  if (spec & HB_STATE_XFRC_APPLIED) xf.assign((size_t)n * 6 * m.nbody, 0.f);
+  for (int e = 0; e < n; e++) {
+    float* s = &host[(size_t)e * ns];
+    const T* o = in + (size_t)e * w;
+    if (spec & HB_STATE_TIME) s[0] = (float)*o++;
+    if (spec & HB_STATE_QPOS) for (int i = 0; i < m.nq; i++) s[1 + i] = (float)*o++;
+    if (spec & HB_STATE_QVEL) for (int i = 0; i < m.nv; i++) s[1 + m.nq + i] = (float)*o++;
+    if (spec & HB_STATE_WARMSTART) for (int i = 0; i < m.nv; i++) s[1 + m.nq + m.nv + i] = (float)*o++;
+    if (spec & HB_STATE_XFRC_APPLIED) for (int i = 0; i < 6 * m.nbody; i++) xf[(size_t)e * 6 * m.nbody + i] = (float)*o++;
+  }
+  HB_HIP(hipMemcpy(b->d_state, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (spec & HB_STATE_XFRC_APPLIED) {
+    if (!b->d_xfrc) { if (hipMalloc((void**)&b->d_xfrc, xf.size() * sizeof(float)) != hipSuccess) return HB_ENOMEM; }
+    HB_HIP(hipMemcpy(b->d_xfrc, xf.data(), xf.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return HB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hb_version(void) { return "hb 0.1 (gfx950)"; }
+
+hb_model* hb_model_load(const char* path, char* err, int err_sz) {
+  if (!path) { set_err(err, err_sz, "null path"); return nullptr; }
+  hb_model* h = new hb_model;
+  std::string e, p = path;
+  bool ok = (p.size() > 4 && p.substr(p.size() - 4) == ".hbm") ? load_hbm(p, h->m, e) : compile_mjcf_file(p, h->m, e);
+  if (!ok) { set_err(err, err_sz, e); delete h; return nullptr; }
+  return h;
+}
+
+hb_model* hb_model_load_xml_string(const char* xml, char* err, int err_sz) {
+  if (!xml) { set_err(err, err_sz, "null xml"); return nullptr; }
+  hb_model* h = new hb_model;
+  std::string e;
+  if (!compile_mjcf_string(xml, h->m, e)) { set_err(err, err_sz, e); delete h; return nullptr; }
+  return h;
+}
+
+int hb_model_save(const hb_model* m, const char* path, char* err, int err_sz) {
+  if (!m || !path) return HB_EINVAL;
+  std::string e;
+  if (!save_hbm(m->m, path, e)) { set_err(err, err_sz, e); return HB_EIO; }
+  return HB_OK;
+}
+
+void hb_model_free(hb_model* m) { delete m; }
+
+int hb_model_sizes(const hb_model* h, hb_sizes* out) {
+  if (!h || !out) return HB_EINVAL;
+  const Model& m = h->m;
+  out->nq = m.nq; out->nv = m.nv; out->nu = m.nu; out->nbody = m.nbody; out->njnt = m.njnt; out->ngeom = m.ngeom; out->ntendon = m.ntendon;
+  out->nM = m.nM; out->nkey = m.nkey; out->npair = m.npair;
+  int nscalar = 0;
+  for (int j = 0; j < m.njnt; j++) if (m.jnt_type[j] >= JNT_SLIDE) nscalar++;
+  out->nobs = 2 * nscalar + 6;
+  out->ncon_max = kNconMax; out->nefc_max = kNefcMax;
+  return HB_OK;
+}
+
+int hb_options_get(const hb_model* h, hb_options* o) {
+  if (!h || !o) return HB_EINVAL;
+  const Model& m = h->m;
+  o->timestep = m.timestep; memcpy(o->gravity, m.gravity, sizeof o->gravity); o->impratio = m.impratio; o->tolerance = m.tolerance;
+  o->iterations = m.iterations; o->solver = m.solver; o->cone = m.cone; o->integrator = m.integrator; o->disableflags = m.disableflags;
+  return HB_OK;
+}
+
+int hb_options_set(hb_model* h, const hb_options* o) {
+  if (!h || !o) return HB_EINVAL;
+  if (o->solver != SOL_PGS || o->cone != 0 || o->integrator != 0) return HB_EUNSUPPORTED;
+  if (!(o->timestep > 0) || !(o->impratio > 0) || o->iterations < 0) return HB_EINVAL;
+  Model& m = h->m;
+  m.timestep = o->timestep; memcpy(m.gravity, o->gravity, sizeof o->gravity); m.impratio = o->impratio; m.tolerance = o->tolerance;
+  m.iterations = o->iterations; m.disableflags = o->disableflags;
+  return HB_OK;
+}
+
+int hb_model_name2id(const hb_model* h, const char* kind, const char* name) {
+  if (!h || !kind || !name) return -1;
+  const Model& m = h->m;
+  const std::vector<std::string>* v = nullptr;
+  std::string k = kind;
+  if (k == "body") v = &m.body_name; else if (k == "joint") v = &m.jnt_name; else if (k == "geom") v = &m.geom_name;
+  else if (k == "actuator") v = &m.actuator_name; else if (k == "tendon") v = &m.tendon_name; else if (k == "key") v = &m.key_name;
+  if (!v) return -1;
+  for (size_t i = 0; i < v->size(); i++) if ((*v)[i] == name) return (int)i;
+  return -1;
+}
+
+int hb_model_get_array(const hb_model* h, const char* field, double* out, int cap) {
+  if (!h || !field) return HB_EINVAL;
+  struct Finder {
+    const char* want; const vecd* found = nullptr; const veci* foundi = nullptr;
+    void operator()(const char* n, vecd& v) { if (!strcmp(n, want)) found = &v; }
+    void operator()(const char* n, veci& v) { if (!strcmp(n, want)) foundi = &v; }
+    void operator()(const char*, int&) {}
+    void operator()(const char*, double&) {}
+    void operator()(const char*, double*, int) {}
+    void operator()(const char*, std::vector<std::string>&) {}
+  } f;
+  f.want = field;
+  const_cast<Model&>(h->m).visit(f);
+  if (f.found) { int n = (int)f.found->size(); if (out) for (int i = 0; i < n && i < cap; i++) out[i] = (*f.found)[i]; return n; }
+  if (f.foundi) { int n = (int)f.foundi->size(); if (out) for (int i = 0; i < n && i < cap; i++) out[i] = (*f.foundi)[i]; return n; }
+  return HB_EINVAL;
+}
+
+hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, int err_sz) {
+  if (!m || n_env <= 0) { set_err(err, err_sz, "bad arguments"); return nullptr; }
+  int ndev = 0;
+  if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
+    set_err(err, err_sz, "no HIP device available: this engine has no CPU backend (device=" + std::to_string(device) + ", visible=" + std::to_string(ndev) + ")");
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) { set_err(err, err_sz, "hipSetDevice failed"); return nullptr; }
+  hb_batch* b = new hb_batch;
+  b->model = m; b->n_env = n_env; b->device = device;
+  std::string e;
+  if (!build_device_model(m->m, b->D, e)) { set_err(err, err_sz, e); delete b; return nullptr; }
+  const DevModel& dm = b->D.dm;
+  bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipMalloc((void**)&b->d_state, (size_t)n_env * dm.nstate * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&b->d_status, (size_t)n_env * sizeof(int)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&b->d_counts, (size_t)n_env * 4 * sizeof(int)) == hipSuccess;
+  ok = ok && hipMemset(b->d_counts, 0, (size_t)n_env * 4 * sizeof(int)) == hipSuccess;
+  ok = ok && ensure_ctrl(b, (size_t)n_env * std::max(1, dm.nu)) == HB_OK;
+  if (ok && dm.lds_floats * 4 > 64 * 1024) ok = set_step_lds_limit(dm.lds_floats * 4) == hipSuccess;
+  if (!ok) { set_err(err, err_sz, "device allocation failed"); hb_batch_free(b); return nullptr; }
+  if (hb_reset(b, nullptr, -1, 0, 0) != HB_OK) { set_err(err, err_sz, "initial reset failed"); hb_batch_free(b); return nullptr; }
+  return b;
+}
+
+void hb_batch_free(hb_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+  void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
+                  b->d_status, b->d_counts, b->d_qpos_out};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete b;
+}
+
+int hb_batch_n_env(const hb_batch* b) { return b ? b->n_env : HB_EINVAL; }
+void* hb_batch_stream(const hb_batch* b) { return b ? (void*)b->stream : nullptr; }
+int hb_batch_sync(hb_batch* b) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+
+int hb_reset(hb_batch* b, const uint8_t* mask, int keyframe, int perturb, int env_offset) {
+  if (!b) return HB_EINVAL;
+  const Model& m = b->model->m;
+  if (keyframe >= m.nkey) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  const uint8_t* dmask = nullptr;
+  if (mask) {
+    if (!b->d_mask && hipMalloc((void**)&b->d_mask, b->n_env) != hipSuccess) return HB_ENOMEM;
+    HB_HIP(hipMemcpyAsync(b->d_mask, mask, b->n_env, hipMemcpyHostToDevice, b->stream));
+    dmask = b->d_mask;
+  }
+  const float* src = b->D.d_qpos_src + (keyframe < 0 ? 0 : (size_t)(1 + keyframe) * m.nq);
+  HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, dmask, src, b->n_env, perturb, env_offset, b->stream));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+
+int hb_step_dev(hb_batch* b, const float* ctrl_dev, int n_substeps) {
+  if (!b || n_substeps < 1 || (!ctrl_dev && b->D.dm.nu > 0)) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  BatchPtrs P = make_ptrs(b);
+  P.ctrl = ctrl_dev; P.ctrl_mode = 0;
+  HB_HIP(launch_step(b->D.dm, P, n_substeps, b->stream));
+  return HB_OK;
+}
+
+int hb_step(hb_batch* b, const float* ctrl, int n_substeps) {
+  if (!b || n_substeps < 1 || (!ctrl && b->D.dm.nu > 0)) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  size_t n = (size_t)b->n_env * b->D.dm.nu;
+  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  int rc = hb_step_dev(b, b->d_ctrl, n_substeps);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+
+int hb_forward(hb_batch* b, const float* ctrl) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  size_t n = (size_t)b->n_env * b->D.dm.nu;
+  if (ctrl && n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  else if (n) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * sizeof(float), b->stream));
+  BatchPtrs P = make_ptrs(b);
+  P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
+  HB_HIP(launch_step(b->D.dm, P, 1, b->stream));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+
+int hb_rollout_dev(hb_batch* b, const float* ctrl_dev, int T, float* qpos_out_dev) {
+  if (!b || T < 1 || (!ctrl_dev && b->D.dm.nu > 0)) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  BatchPtrs P = make_ptrs(b);
+  P.ctrl = ctrl_dev; P.ctrl_mode = 1; P.qpos_out = qpos_out_dev;
+  HB_HIP(launch_step(b->D.dm, P, T, b->stream));
+  return HB_OK;
+}
+
+int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out) {
+  if (!b || T < 1 || (!ctrl && b->D.dm.nu > 0)) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  size_t n = (size_t)T * b->n_env * b->D.dm.nu;
+  int rc = ensure_ctrl(b, std::max<size_t>(n, 1));
+  if (rc != HB_OK) return rc;
+  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  size_t nq_out = (size_t)T * b->n_env * b->D.dm.nq;
+  if (qpos_out && nq_out > b->qpos_out_cap) {
+    if (b->d_qpos_out) (void)hipFree(b->d_qpos_out);
+    b->d_qpos_out = nullptr; b->qpos_out_cap = 0;
+    if (hipMalloc((void**)&b->d_qpos_out, nq_out * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+    b->qpos_out_cap = nq_out;
+  }
+  rc = hb_rollout_dev(b, b->d_ctrl, T, qpos_out ? b->d_qpos_out : nullptr);
+  if (rc != HB_OK) return rc;
+  if (qpos_out) HB_HIP(hipMemcpyAsync(qpos_out, b->d_qpos_out, nq_out * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+
+int hb_rollout_halton(hb_batch* b, int T, int t0, int env_offset, float* qpos_out_dev) {
+  if (!b || T < 1) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  BatchPtrs P = make_ptrs(b);
+  P.ctrl = nullptr; P.ctrl_mode = 2; P.t0 = t0; P.env_offset = env_offset; P.qpos_out = qpos_out_dev;
+  HB_HIP(launch_step(b->D.dm, P, T, b->stream));
+  return HB_OK;
+}
+
+int hb_state_size(const hb_batch* b, unsigned spec) {
+  if (!b || (spec & ~kSupportedSpec)) return HB_EINVAL;
+  return spec_size(b->model->m, spec);
+}
+int hb_get_state(hb_batch* b, unsigned spec, float* out) { return get_state_impl<float>(b, spec, out); }
+int hb_set_state(hb_batch* b, unsigned spec, const float* in) { return set_state_impl<float>(b, spec, in); }
+int hb_get_state_f64(hb_batch* b, unsigned spec, double* out) { return get_state_impl<double>(b, spec, out); }
+int hb_set_state_f64(hb_batch* b, unsigned spec, const double* in) { return set_state_impl<double>(b, spec, in); }
+
+int hb_get_obs(hb_batch* b, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated) {
+  if (!b || !obs) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  int n = b->n_env, nobs = b->D.dm.nobs;
+  if (!b->d_obs) {
+    if (hipMalloc((void**)&b->d_obs, (size_t)n * nobs * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_reward, (size_t)n * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&b->d_term, n) != hipSuccess || hipMalloc((void**)&b->d_trunc, n) != hipSuccess) return HB_ENOMEM;
+  }
+  HB_HIP(launch_obs(b->D.dm, b->d_state, b->d_obs, b->d_reward, b->d_term, b->d_trunc, n, b->stream));
+  HB_HIP(hipMemcpyAsync(obs, b->d_obs, (size_t)n * nobs * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  if (reward) HB_HIP(hipMemcpyAsync(reward, b->d_reward, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  if (terminated) HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, b->stream));
+  if (truncated) HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, b->stream));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+
+int hb_get_status(hb_batch* b, int* status) {
+  if (!b || !status) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipMemcpy(status, b->d_status, (size_t)b->n_env * sizeof(int), hipMemcpyDeviceToHost));
+  return HB_OK;
+}
+
+int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  std::vector<int> h((size_t)b->n_env * 4);
+  HB_HIP(hipMemcpy(h.data(), b->d_counts, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (int e = 0; e < b->n_env; e++) {
+    if (ncon) ncon[e] = h[4 * e];
+    if (nefc) nefc[e] = h[4 * e + 1];
+    if (niter) niter[e] = h[4 * e + 2];
+  }
+  return HB_OK;
+}
+
+int hb_diag_enable(hb_batch* b, int on) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  if (on && !b->d_diag_qacc) {
+    size_t n = b->n_env;
+    if (hipMalloc((void**)&b->d_diag_qacc, n * b->D.dm.nv * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_diag_force, n * kNefcMax * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&b->d_diag_contact, n * kNconMax * kDiagConStride * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+  }
+  b->diag = on != 0;
+  return HB_OK;
+}
+
+static int copy_out(hb_batch* b, float* out, const float* dev, size_t n) {
+  if (!b || !out) return HB_EINVAL;
+  if (!b->diag || !dev) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipMemcpy(out, dev, n * sizeof(float), hipMemcpyDeviceToHost));
+  return HB_OK;
+}
+int hb_get_qacc(hb_batch* b, float* qacc) { return copy_out(b, qacc, b ? b->d_diag_qacc : nullptr, b ? (size_t)b->n_env * b->D.dm.nv : 0); }
+int hb_get_efc_force(hb_batch* b, float* f) { return copy_out(b, f, b ? b->d_diag_force : nullptr, b ? (size_t)b->n_env * kNefcMax : 0); }
+int hb_get_contacts(hb_batch* b, float* c) { return copy_out(b, c, b ? b->d_diag_contact : nullptr, b ? (size_t)b->n_env * kNconMax * kDiagConStride : 0); }
+
+}  // extern "C"

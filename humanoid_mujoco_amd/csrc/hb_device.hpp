@@ -1,0 +1,87 @@
+// hb_device.hpp — device-side model tables and batch buffers (fp32), shared by the host
+// runtime (hb_api.cpp) and the kernels (hb_kernels.hip).
+//
+// The model is replicated read-only per device as two flat arrays (int, float); DevModel holds
+// typed pointers into them plus the per-env LDS layout.  All tables are small (a few KB) and
+// identical for every env, so lane-indexed reads hit L1/L2 and uniform reads go through the
+// scalar cache.
+#pragma once
+#include <stdint.h>
+
+namespace hb {
+
+constexpr int kGroup = 64;      // lanes cooperating on one env (one wavefront)
+constexpr int kNconMax = 24;    // contact capacity per env (overflow -> HB_WARN_CONTACTFULL)
+constexpr int kNefcMax = 63;    // constraint-row capacity per env (overflow -> HB_WARN_CNSTRFULL); lane 63 / row 63 of C carries the extra right-hand side
+constexpr int kConStride = 20;  // floats per contact record in LDS
+constexpr int kDiagConStride = 16;
+
+// contact record layout in LDS (floats)
+enum { C_DIST = 0, C_POS = 1, C_FRAME = 4, C_PAIR = 13, C_ROW = 14, C_DIM = 15, C_FRIC = 16 };
+
+struct DevModel {
+  // sizes
+  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, npair, nlevel, ntree, nfac, nlimcand;
+  int nstate;   // floats per env in the global state record: time, qpos, qvel, qacc_warmstart
+  int nobs;
+  // options
+  float timestep, gravity[3], inv_sqrt_impratio, tolerance, pgs_scale;
+  int iterations, disableflags;
+  // body tables
+  const int *body_parentid, *body_treeid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_childadr, *body_childnum, *child_list;
+  const int *level_adr, *level_num, *level_body;
+  const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *tree_invmass;
+  const unsigned long long* body_dofmask;  // bit d set: dof d moves this body
+  // joint tables
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
+  const float *jnt_pos, *jnt_axis, *jnt_stiffness, *qpos0, *qpos_spring;
+  // dof tables
+  const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_nanc, *dof_qposadr;
+  const float *dof_armature, *dof_damping;
+  const int *M_i, *M_j;                                  // dof pair of each sparse mass-matrix entry
+  const int *fac_adr, *fac_dst, *fac_src, *fac_tmp;      // L^T D L update triples per pivot dof
+  const int *desc_adr, *desc_k, *desc_M;                 // descendants of each dof: (k, address of L[k,i])
+  // geoms
+  const int *geom_type, *geom_bodyid;
+  const float *geom_size, *geom_pos, *geom_quat, *geom_rbound;
+  // collision candidates with pre-mixed contact parameters
+  const int *pair_geom1, *pair_geom2, *pair_dim;
+  const float *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
+  // limit candidates: 2 per limited joint/tendon in constraint order (lower, upper)
+  const int *lim_kind, *lim_id, *lim_side;  // kind 0 = joint, 1 = tendon
+  const float *lim_range, *lim_margin, *lim_solref, *lim_solimp, *lim_invweight;
+  // tendons (fixed)
+  const int *tendon_adr, *tendon_num, *wrap_dofadr, *wrap_qposadr;
+  const float* wrap_prm;
+  // actuators
+  const int *act_qposadr, *act_dofadr, *act_ctrllimited, *act_forcelimited;
+  const float *act_gear, *act_ctrlrange, *act_forcerange, *act_gain, *act_bias;
+  // env adapter
+  int obs_root_body, obs_root_dofadr;
+  // LDS layout (float offsets per env) — persistent region
+  int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qM, o_qLD, o_dinv, o_dsqrtinv, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
+  // region A (dynamics scratch)
+  int o_xpos, o_xquat, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cdofdot, o_cvel, o_cacc, o_cfrc;
+  // region B (constraints), aliases region A
+  int o_con, o_C, o_efc, o_AR;
+  int lds_floats;  // total floats per env
+  int cstride;     // row stride of C (odd, >= nv+1; column nv holds the extra right-hand side)
+};
+
+struct BatchPtrs {
+  float* state;        // [n_env][nstate]
+  const float* ctrl;   // [n_env][nu] or [T][n_env][nu]
+  float* qpos_out;     // nullable, [T][n_env][nq]
+  float* xfrc;         // nullable, [n_env][nbody][6]
+  int* status;         // [n_env] accumulated HB_WARN_* bits
+  int* counts;         // [n_env][4] ncon, nefc, niter, spare
+  float* diag_qacc;    // nullable [n_env][nv]
+  float* diag_force;   // nullable [n_env][kNefcMax]
+  float* diag_contact; // nullable [n_env][kNconMax][kDiagConStride]
+  int n_env;
+  int ctrl_mode;       // 0: ctrl[e][nu] held for all steps; 1: ctrl[t][e][nu]; 2: on-device Halton
+  int t0, env_offset;  // Halton indexing
+  int integrate;       // 1: mj_step, 0: mj_forward only
+};
+
+}  // namespace hb

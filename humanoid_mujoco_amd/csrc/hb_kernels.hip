@@ -1,0 +1,1042 @@
+// hb_kernels.hip — the fused physics-step kernel for gfx950 (MI355X).
+//
+// One 64-lane wavefront advances ONE environment through the whole mj_step pipeline
+// (reference API: simulation/mujoco/include/mujoco/mujoco.h:120 mj_step; stage list
+// mujoco.h:247-372; oracle: oracle/mjstep_oracle.c) with every intermediate resident in LDS
+// or registers.  HBM traffic per env-step is the state record in and out (plus ctrl), i.e. the
+// algorithmic bytes of SURVEY.md §8(d).  A multi-step rollout keeps the state on chip between
+// steps.  See DESIGN.md for the lane mappings of each stage and the LDS map.
+//
+// Lane mappings (G = 64 lanes per env):
+//   tree passes (kinematics, comVel/RNE forward)  lanes = bodies of one depth level
+//   backward passes (crb, cfrc)                   lanes = (body, component), pull from children
+//   qM                                            lanes = sparse mass-matrix entries
+//   L^T D L                                       lanes = update triples of one pivot dof
+//   collision                                     lanes = candidate geom pairs
+//   constraint rows, half-solve, AR, PGS          lane  = constraint row
+//   dof vectors                                   lanes = dofs
+#include <hip/hip_runtime.h>
+#include "hb_device.hpp"
+
+namespace hb {
+
+#define HB_MINVAL 1e-15f
+#define HB_MAXVAL 1e10f
+#define HB_MINIMP 0.0001f
+#define HB_MAXIMP 0.9999f
+
+// wave-level ordering point for LDS traffic between lanes of one wavefront.  A wavefront's DS
+// instructions execute in issue order, so no s_barrier is needed; the fences stop the compiler
+// from moving LDS accesses across this point.
+__device__ __forceinline__ void gsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ float rdlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 normalized(V3 v, float* n_out = nullptr) {
+  float n = sqrtf(dot(v, v));
+  if (n_out) *n_out = n;
+  if (n < HB_MINVAL) return {1.f, 0.f, 0.f};
+  float inv = 1.f / n;
+  return v * inv;
+}
+
+struct Q4 { float w, x, y, z; };
+__device__ __forceinline__ Q4 ldq(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void stq(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q4 qnormalize(Q4 q) {
+  float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n < HB_MINVAL) return {1.f, 0.f, 0.f, 0.f};
+  float inv = 1.f / n;
+  return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+}
+__device__ __forceinline__ void q2mat(float* m, Q4 q) {
+  float q00 = q.w * q.w, q11 = q.x * q.x, q22 = q.y * q.y, q33 = q.z * q.z;
+  float q01 = q.w * q.x, q02 = q.w * q.y, q03 = q.w * q.z, q12 = q.x * q.y, q13 = q.x * q.z, q23 = q.y * q.z;
+  m[0] = q00 + q11 - q22 - q33; m[1] = 2.f * (q12 - q03); m[2] = 2.f * (q13 + q02);
+  m[3] = 2.f * (q12 + q03); m[4] = q00 - q11 + q22 - q33; m[5] = 2.f * (q23 - q01);
+  m[6] = 2.f * (q13 - q02); m[7] = 2.f * (q23 + q01); m[8] = q00 - q11 - q22 + q33;
+}
+__device__ __forceinline__ V3 mrot(const float* m, V3 v) {
+  return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
+  float m[9];
+  q2mat(m, q);
+  return mrot(m, v);
+}
+__device__ __forceinline__ Q4 axisangle(V3 axis, float ang) {
+  float s, c;
+  sincosf(0.5f * ang, &s, &c);
+  return {c, axis.x * s, axis.y * s, axis.z * s};
+}
+
+// spatial algebra on 6-vectors (rotation, translation); cinert layout as mjData.cinert (mjdata.h:269)
+__device__ __forceinline__ void mul_inert_vec(float* r, const float* i, const float* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+__device__ __forceinline__ void cross_motion(float* r, const float* vel, const float* v) {
+  r[0] = -vel[2] * v[1] + vel[1] * v[2];
+  r[1] = vel[2] * v[0] - vel[0] * v[2];
+  r[2] = -vel[1] * v[0] + vel[0] * v[1];
+  r[3] = -vel[2] * v[4] + vel[1] * v[5] - vel[5] * v[1] + vel[4] * v[2];
+  r[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
+  r[5] = -vel[1] * v[3] + vel[0] * v[4] - vel[4] * v[0] + vel[3] * v[1];
+}
+__device__ __forceinline__ void cross_force(float* r, const float* vel, const float* f) {
+  r[0] = -vel[2] * f[1] + vel[1] * f[2] - vel[5] * f[4] + vel[4] * f[5];
+  r[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
+  r[2] = -vel[1] * f[0] + vel[0] * f[1] - vel[4] * f[3] + vel[3] * f[4];
+  r[3] = -vel[2] * f[4] + vel[1] * f[5];
+  r[4] = vel[2] * f[3] - vel[0] * f[5];
+  r[5] = -vel[1] * f[3] + vel[0] * f[4];
+}
+
+// radical inverse, mju_Halton (mujoco.h:1231); used by simulation/mujoco/sample/testspeed.cc:76
+__device__ __forceinline__ float halton(int index, int base) {
+  float f = 1.f / (float)base, fb = f, hn = 0.f;
+  while (index > 0) {
+    int n1 = index / base, r = index - n1 * base;
+    hn += f * (float)r;
+    f *= fb;
+    index = n1;
+  }
+  return hn;
+}
+
+// ------------------------------------------------------------------------------------------
+// narrowphase helpers (engine_collision_primitive restatement, see oracle)
+struct ConOut { float dist; V3 pos; V3 n; };
+
+__device__ __forceinline__ bool plane_sphere(ConOut& c, float margin, V3 ppos, V3 normal, V3 spos, float radius) {
+  float cdist = dot(spos - ppos, normal);
+  if (cdist > margin + radius) return false;
+  c.dist = cdist - radius;
+  c.pos = spos + normal * (-c.dist * 0.5f - radius);
+  c.n = normal;
+  return true;
+}
+__device__ __forceinline__ bool sphere_sphere(ConOut& c, float margin, V3 p1, float r1, V3 p2, float r2) {
+  V3 dif = p2 - p1;
+  float cdist = sqrtf(dot(dif, dif));
+  if (cdist > margin + r1 + r2) return false;
+  c.dist = cdist - r1 - r2;
+  V3 n = cdist < HB_MINVAL ? V3{1.f, 0.f, 0.f} : dif * (1.f / cdist);
+  c.pos = p1 + n * (r1 + c.dist * 0.5f);
+  c.n = n;
+  return true;
+}
+__device__ __forceinline__ int capsule_capsule(ConOut* c, float margin, V3 pos1, V3 axis1, float r1, float len1, V3 pos2, V3 axis2, float r2, float len2) {
+  V3 dif = pos1 - pos2;
+  float ma = dot(axis1, axis1), mb = -dot(axis1, axis2), mc = dot(axis2, axis2);
+  float u = -dot(axis1, dif), v = dot(axis2, dif);
+  float det = ma * mc - mb * mb;
+  if (fabsf(det) >= HB_MINVAL) {
+    float x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > len1) { x1 = len1; x2 = (v - mb * len1) / mc; }
+    else if (x1 < -len1) { x1 = -len1; x2 = (v + mb * len1) / mc; }
+    if (x2 > len2) { x2 = len2; x1 = clampf((u - mb * len2) / ma, -len1, len1); }
+    else if (x2 < -len2) { x2 = -len2; x1 = clampf((u + mb * len2) / ma, -len1, len1); }
+    return sphere_sphere(c[0], margin, pos1 + axis1 * x1, r1, pos2 + axis2 * x2, r2) ? 1 : 0;
+  }
+  int n = 0;
+  float x2 = clampf((v - mb * len1) / mc, -len2, len2);
+  n += sphere_sphere(c[n], margin, pos1 + axis1 * len1, r1, pos2 + axis2 * x2, r2) ? 1 : 0;
+  x2 = clampf((v + mb * len1) / mc, -len2, len2);
+  n += sphere_sphere(c[n], margin, pos1 - axis1 * len1, r1, pos2 + axis2 * x2, r2) ? 1 : 0;
+  if (n >= 2) return n;
+  float x1 = clampf((u - mb * len2) / ma, -len1, len1);
+  n += sphere_sphere(c[n], margin, pos1 + axis1 * x1, r1, pos2 + axis2 * len2, r2) ? 1 : 0;
+  if (n >= 2) return n;
+  x1 = clampf((u + mb * len2) / ma, -len1, len1);
+  n += sphere_sphere(c[n], margin, pos1 + axis1 * x1, r1, pos2 - axis2 * len2, r2) ? 1 : 0;
+  return n;
+}
+
+// complete a contact frame from its normal and an optional tangent hint (mju_makeFrame)
+__device__ __forceinline__ void make_frame(float* f, V3 n, V3 hint) {
+  n = normalized(n);
+  V3 t = hint;
+  if (dot(t, t) < 0.25f) t = (n.y < 0.5f && n.y > -0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
+  t = t - n * dot(n, t);
+  t = normalized(t);
+  V3 b = cross(n, t);
+  st3(f, n); st3(f + 3, t); st3(f + 6, b);
+}
+
+// impedance sigmoid (getimpedance restatement); solimp = d0, dmax, width, midpoint, power
+__device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
+  float d0 = clampf(solimp[0], HB_MINIMP, HB_MAXIMP), d1 = clampf(solimp[1], HB_MINIMP, HB_MAXIMP);
+  float width = fmaxf(0.f, solimp[2]), mid = clampf(solimp[3], HB_MINIMP, HB_MAXIMP), power = fmaxf(1.f, solimp[4]);
+  if (d0 == d1 || width <= HB_MINVAL) return 0.5f * (d0 + d1);
+  float x = fabsf((pos - margin) / width);
+  if (x >= 1.f) return d1;
+  if (x <= 0.f) return d0;
+  float y;
+  if (power == 1.f) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
+  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  return d0 + y * (d1 - d0);
+}
+
+// L^T D L factorisation of the sparse mass matrix held in LD (LDS), lanes = update triples.
+__device__ __forceinline__ void factor_ld(const DevModel& M, float* LD, float* dinv, float* dsqrtinv, int lane) {
+  for (int k = M.nv - 1; k >= 0; k--) {
+    int nanc = M.dof_nanc[k];
+    if (nanc == 0) continue;
+    int Mkk = M.dof_Madr[k];
+    float dkk = fmaxf(LD[Mkk], HB_MINVAL);
+    float inv = 1.f / dkk;
+    int t0 = M.fac_adr[k], t1 = M.fac_adr[k + 1];
+    for (int t = t0 + lane; t < t1; t += kGroup) {
+      int dst = M.fac_dst[t], src = M.fac_src[t], ti = M.fac_tmp[t];
+      LD[dst] -= LD[src] * (LD[ti] * inv);
+    }
+    gsync();
+    for (int a = lane; a < nanc; a += kGroup) LD[Mkk + 1 + a] *= inv;
+    gsync();
+  }
+  for (int i = lane; i < M.nv; i += kGroup) {
+    float d = fmaxf(LD[M.dof_Madr[i]], HB_MINVAL);
+    dinv[i] = 1.f / d;
+    dsqrtinv[i] = rsqrtf(d);
+  }
+  gsync();
+}
+
+// x <- L^-T x (single vector in LDS): pivots descending, push to ancestors
+__device__ __forceinline__ void solve_lt_push(const DevModel& M, const float* LD, float* x, int lane) {
+  for (int k = M.nv - 1; k >= 0; k--) {
+    int nanc = M.dof_nanc[k];
+    if (nanc == 0) continue;
+    int Mkk = M.dof_Madr[k];
+    float xk = x[k];
+    if (lane < nanc) {
+      // a-th ancestor of k: walk the parent chain (uniform, short)
+      int i = M.dof_parentid[k];
+      for (int a = 0; a < lane; a++) i = M.dof_parentid[i];
+      x[i] -= LD[Mkk + 1 + lane] * xk;
+    }
+    gsync();
+  }
+}
+// x <- L^-1 x (single vector in LDS): dofs ascending, push to descendants
+__device__ __forceinline__ void solve_l_push(const DevModel& M, const float* LD, float* x, int lane) {
+  for (int i = 0; i < M.nv; i++) {
+    int t0 = M.desc_adr[i], t1 = M.desc_adr[i + 1];
+    if (t0 == t1) continue;
+    float xi = x[i];
+    for (int t = t0 + lane; t < t1; t += kGroup) x[M.desc_k[t]] -= LD[M.desc_M[t]] * xi;
+    gsync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const BatchPtrs P, int nsteps) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int env = blockIdx.x;
+  if (env >= P.n_env) return;
+  const int nv = M.nv, nq = M.nq, nb = M.nbody, cs = M.cstride;
+
+  float* s_qpos = lds + M.o_qpos;
+  float* s_qvel = lds + M.o_qvel;
+  float* s_warm = lds + M.o_warm;
+  float* s_ctrl = lds + M.o_ctrl;
+  float* s_gpos = lds + M.o_gpos;
+  float* s_gaxis = lds + M.o_gaxis;
+  float* s_scom = lds + M.o_scom;
+  float* s_cdof = lds + M.o_cdof;
+  float* s_qM = lds + M.o_qM;
+  float* s_qLD = lds + M.o_qLD;
+  float* s_dinv = lds + M.o_dinv;
+  float* s_dsqrtinv = lds + M.o_dsqrtinv;
+  float* s_smooth = lds + M.o_smooth;  // qfrc_smooth
+  float* s_v0 = lds + M.o_vec0;        // scratch dof vectors
+  float* s_v1 = lds + M.o_vec1;
+  float* s_v2 = lds + M.o_vec2;
+  float* s_tenlen = lds + M.o_tenlen;
+  float* s_xpos = lds + M.o_xpos;
+  float* s_xquat = lds + M.o_xquat;
+  float* s_xmat = lds + M.o_xmat;
+  float* s_xipos = lds + M.o_xipos;
+  float* s_xanchor = lds + M.o_xanchor;
+  float* s_xaxis = lds + M.o_xaxis;
+  float* s_cinert = lds + M.o_cinert;
+  float* s_crb = lds + M.o_crb;
+  float* s_cdofdot = lds + M.o_cdofdot;
+  float* s_cvel = lds + M.o_cvel;
+  float* s_cacc = lds + M.o_cacc;
+  float* s_cfrc = lds + M.o_cfrc;
+  float* s_con = lds + M.o_con;
+  float* s_C = lds + M.o_C;
+  float* s_efc = lds + M.o_efc;  // per-row meta, stride kNefcMax
+  float* s_AR = lds + M.o_AR;
+  constexpr int ARS = kNefcMax | 1;  // odd row stride of AR
+  static_assert(kNefcMax == kGroup - 1, "row kNefcMax of C is handled by the last lane");
+  // per-row meta slots
+  enum { E_POS = 0, E_MARGIN, E_SOLREF0, E_SOLREF1, E_IMP0, E_IMP1, E_IMP2, E_IMP3, E_IMP4, E_DA, E_DAFIRST, E_MU2, E_FORCE, E_NSLOT };
+
+  float* gstate = P.state + (size_t)env * M.nstate;
+  float time = gstate[0];
+  for (int i = lane; i < nq; i += kGroup) s_qpos[i] = gstate[1 + i];
+  for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = gstate[1 + nq + i]; s_warm[i] = gstate[1 + nq + nv + i]; }
+  int status = 0;
+  gsync();
+
+  for (int step = 0; step < nsteps; step++) {
+    // ---------------------------------------------------------------- controls
+    if (P.ctrl_mode == 2) {
+      int idx = 1 + P.t0 + step + 1000 * (P.env_offset + env);
+      for (int i = lane; i < M.nu; i += kGroup) s_ctrl[i] = 2.f * halton(idx, i + 2) - 1.f;
+    } else {
+      const float* c = P.ctrl + (P.ctrl_mode == 1 ? (size_t)step * P.n_env * M.nu : 0) + (size_t)env * M.nu;
+      for (int i = lane; i < M.nu; i += kGroup) s_ctrl[i] = c[i];
+    }
+    // ---------------------------------------------------------------- mj_checkPos / mj_checkVel
+    {
+      bool badp = false, badv = false;
+      for (int i = lane; i < nq; i += kGroup) { float v = s_qpos[i]; badp |= !(fabsf(v) <= HB_MAXVAL); }
+      for (int i = lane; i < nv; i += kGroup) { float v = s_qvel[i]; badv |= !(fabsf(v) <= HB_MAXVAL); }
+      bool anyp = __any(badp), anyv = __any(badv);
+      if (anyp || anyv) {
+        status |= anyp ? (1 << 4) : (1 << 5);
+        for (int i = lane; i < nq; i += kGroup) s_qpos[i] = M.qpos0[i];
+        for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; }
+        time = 0.f;
+      }
+    }
+    gsync();
+
+    // ---------------------------------------------------------------- mj_kinematics
+    if (lane == 0) {
+      st3(s_xpos, {0.f, 0.f, 0.f}); stq(s_xquat, {1.f, 0.f, 0.f, 0.f}); st3(s_xipos, {0.f, 0.f, 0.f});
+      for (int i = 0; i < 9; i++) s_xmat[i] = (i % 4 == 0) ? 1.f : 0.f;
+    }
+    gsync();
+    for (int L = 1; L < M.nlevel; L++) {
+      int n = M.level_num[L], adr = M.level_adr[L];
+      for (int idx = lane; idx < n; idx += kGroup) {
+        int b = M.level_body[adr + idx];
+        int p = M.body_parentid[b];
+        int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
+        V3 pos;
+        Q4 quat;
+        if (jn == 1 && M.jnt_type[ja] == 0) {
+          int qa = M.jnt_qposadr[ja];
+          pos = ld3(s_qpos + qa);
+          quat = qnormalize(ldq(s_qpos + qa + 3));
+          st3(s_xanchor + 3 * ja, pos);
+          st3(s_xaxis + 3 * ja, ld3(M.jnt_axis + 3 * ja));
+        } else {
+          pos = mrot(s_xmat + 9 * p, ld3(M.body_pos + 3 * b)) + ld3(s_xpos + 3 * p);
+          quat = qmul(ldq(s_xquat + 4 * p), ldq(M.body_quat + 4 * b));
+          for (int jj = 0; jj < jn; jj++) {
+            int j = ja + jj, qa = M.jnt_qposadr[j];
+            V3 laxis = ld3(M.jnt_axis + 3 * j), lpos = ld3(M.jnt_pos + 3 * j);
+            V3 axis = qrot(quat, laxis);
+            V3 anchor = qrot(quat, lpos) + pos;
+            st3(s_xaxis + 3 * j, axis);
+            st3(s_xanchor + 3 * j, anchor);
+            float dq = s_qpos[qa] - M.qpos0[qa];
+            if (M.jnt_type[j] == 2) pos = pos + axis * dq;
+            else {
+              quat = qmul(quat, axisangle(laxis, dq));
+              pos = anchor - qrot(quat, lpos);
+            }
+          }
+          quat = qnormalize(quat);
+        }
+        st3(s_xpos + 3 * b, pos);
+        stq(s_xquat + 4 * b, quat);
+        float mat[9];
+        q2mat(mat, quat);
+        for (int i = 0; i < 9; i++) s_xmat[9 * b + i] = mat[i];
+        st3(s_xipos + 3 * b, pos + mrot(mat, ld3(M.body_ipos + 3 * b)));
+      }
+      gsync();
+    }
+    // geoms: world position and z axis
+    for (int g = lane; g < M.ngeom; g += kGroup) {
+      int b = M.geom_bodyid[g];
+      st3(s_gpos + 3 * g, ld3(s_xpos + 3 * b) + mrot(s_xmat + 9 * b, ld3(M.geom_pos + 3 * g)));
+      Q4 q = qmul(ldq(s_xquat + 4 * b), ldq(M.geom_quat + 4 * g));
+      st3(s_gaxis + 3 * g, {2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z});
+    }
+    // ---------------------------------------------------------------- mj_comPos
+    for (int t = 0; t < M.ntree; t++) {
+      V3 acc = {0.f, 0.f, 0.f};
+      for (int b = 1 + lane; b < nb; b += kGroup)
+        if (M.body_treeid[b] == t) acc = acc + ld3(s_xipos + 3 * b) * M.body_mass[b];
+      float im = M.tree_invmass[t];
+      float sx = wave_sum(acc.x) * im, sy = wave_sum(acc.y) * im, sz = wave_sum(acc.z) * im;
+      if (lane == 0) st3(s_scom + 3 * t, {sx, sy, sz});
+    }
+    gsync();
+    for (int b = 1 + lane; b < nb; b += kGroup) {
+      V3 com = ld3(s_scom + 3 * M.body_treeid[b]);
+      V3 dif = ld3(s_xipos + 3 * b) - com;
+      float mat[9];
+      q2mat(mat, qmul(ldq(s_xquat + 4 * b), ldq(M.body_iquat + 4 * b)));
+      float in0 = M.body_inertia[3 * b], in1 = M.body_inertia[3 * b + 1], in2 = M.body_inertia[3 * b + 2], mass = M.body_mass[b];
+      float t[9];
+      for (int r = 0; r < 3; r++) { t[3 * r] = mat[3 * r] * in0; t[3 * r + 1] = mat[3 * r + 1] * in1; t[3 * r + 2] = mat[3 * r + 2] * in2; }
+      float* res = s_cinert + 10 * b;
+      res[0] = t[0] * mat[0] + t[1] * mat[1] + t[2] * mat[2] + mass * (dif.y * dif.y + dif.z * dif.z);
+      res[1] = t[3] * mat[3] + t[4] * mat[4] + t[5] * mat[5] + mass * (dif.x * dif.x + dif.z * dif.z);
+      res[2] = t[6] * mat[6] + t[7] * mat[7] + t[8] * mat[8] + mass * (dif.x * dif.x + dif.y * dif.y);
+      res[3] = t[0] * mat[3] + t[1] * mat[4] + t[2] * mat[5] - mass * dif.x * dif.y;
+      res[4] = t[0] * mat[6] + t[1] * mat[7] + t[2] * mat[8] - mass * dif.x * dif.z;
+      res[5] = t[3] * mat[6] + t[4] * mat[7] + t[5] * mat[8] - mass * dif.y * dif.z;
+      res[6] = mass * dif.x; res[7] = mass * dif.y; res[8] = mass * dif.z; res[9] = mass;
+    }
+    if (lane < 10) s_cinert[lane] = 0.f;
+    for (int d = lane; d < nv; d += kGroup) {
+      int j = M.dof_jntid[d], b = M.dof_bodyid[d], type = M.jnt_type[j], k = d - M.jnt_dofadr[j];
+      V3 off = ld3(s_scom + 3 * M.body_treeid[b]) - ld3(s_xanchor + 3 * j);
+      V3 ang = {0.f, 0.f, 0.f}, lin = {0.f, 0.f, 0.f};
+      if (type == 0) {
+        if (k < 3) { lin = {k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f}; }
+        else {
+          int c = k - 3;
+          ang = {s_xmat[9 * b + c], s_xmat[9 * b + 3 + c], s_xmat[9 * b + 6 + c]};
+          lin = cross(ang, off);
+        }
+      } else if (type == 2) {
+        lin = ld3(s_xaxis + 3 * j);
+      } else {
+        ang = ld3(s_xaxis + 3 * j);
+        lin = cross(ang, off);
+      }
+      st3(s_cdof + 6 * d, ang);
+      st3(s_cdof + 6 * d + 3, lin);
+    }
+    // fixed tendon lengths
+    for (int t = lane; t < M.ntendon; t += kGroup) {
+      float len = 0.f;
+      for (int w = 0; w < M.tendon_num[t]; w++) len += M.wrap_prm[M.tendon_adr[t] + w] * s_qpos[M.wrap_qposadr[M.tendon_adr[t] + w]];
+      s_tenlen[t] = len;
+    }
+    gsync();
+    // ---------------------------------------------------------------- mj_crb
+    for (int i = lane; i < 10 * nb; i += kGroup) s_crb[i] = s_cinert[i];
+    gsync();
+    for (int L = M.nlevel - 2; L >= 1; L--) {
+      int n = M.level_num[L] * 10, adr = M.level_adr[L];
+      for (int idx = lane; idx < n; idx += kGroup) {
+        int b = M.level_body[adr + idx / 10], c = idx % 10;
+        int ca = M.body_childadr[b], cn = M.body_childnum[b];
+        float acc = s_crb[10 * b + c];
+        for (int k = 0; k < cn; k++) acc += s_crb[10 * M.child_list[ca + k] + c];
+        s_crb[10 * b + c] = acc;
+      }
+      gsync();
+    }
+    for (int e = lane; e < M.nM; e += kGroup) {
+      int i = M.M_i[e], j = M.M_j[e];
+      float buf[6], cd[6];
+      for (int t = 0; t < 6; t++) cd[t] = s_cdof[6 * i + t];
+      float in[10];
+      for (int t = 0; t < 10; t++) in[t] = s_crb[10 * M.dof_bodyid[i] + t];
+      mul_inert_vec(buf, in, cd);
+      float s = 0.f;
+      for (int t = 0; t < 6; t++) s += s_cdof[6 * j + t] * buf[t];
+      if (i == j) s += M.dof_armature[i];
+      s_qM[e] = s;
+      s_qLD[e] = s;
+    }
+    gsync();
+    // ---------------------------------------------------------------- mj_factorM
+    factor_ld(M, s_qLD, s_dinv, s_dsqrtinv, lane);
+
+    // ---------------------------------------------------------------- mj_comVel + mj_rne forward pass
+    if (lane < 6) {
+      s_cvel[lane] = 0.f;
+      s_cacc[lane] = (lane >= 3 && !(M.disableflags & (1 << 6))) ? -M.gravity[lane - 3] : 0.f;
+      s_cfrc[lane] = 0.f;
+    }
+    gsync();
+    for (int L = 1; L < M.nlevel; L++) {
+      int n = M.level_num[L], adr = M.level_adr[L];
+      for (int idx = lane; idx < n; idx += kGroup) {
+        int b = M.level_body[adr + idx], p = M.body_parentid[b];
+        float cvel[6], cacc[6], t[6], cd[6];
+        for (int i = 0; i < 6; i++) { cvel[i] = s_cvel[6 * p + i]; cacc[i] = s_cacc[6 * p + i]; }
+        int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
+        for (int jj = 0; jj < jn; jj++) {
+          int j = ja + jj, da = M.jnt_dofadr[j];
+          if (M.jnt_type[j] == 0) {
+            for (int k = 0; k < 3; k++) {
+              float qv = s_qvel[da + k];
+              for (int i = 0; i < 6; i++) { s_cdofdot[6 * (da + k) + i] = 0.f; cvel[i] += s_cdof[6 * (da + k) + i] * qv; }
+            }
+            float dots[3][6];
+            for (int k = 0; k < 3; k++) {
+              for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * (da + 3 + k) + i];
+              cross_motion(dots[k], cvel, cd);
+            }
+            for (int k = 0; k < 3; k++) {
+              float qv = s_qvel[da + 3 + k];
+              for (int i = 0; i < 6; i++) {
+                s_cdofdot[6 * (da + 3 + k) + i] = dots[k][i];
+                cacc[i] += dots[k][i] * qv;
+                cvel[i] += s_cdof[6 * (da + 3 + k) + i] * qv;
+              }
+            }
+          } else {
+            float qv = s_qvel[da];
+            for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * da + i];
+            cross_motion(t, cvel, cd);
+            for (int i = 0; i < 6; i++) { s_cdofdot[6 * da + i] = t[i]; cacc[i] += t[i] * qv; cvel[i] += cd[i] * qv; }
+          }
+        }
+        float in[10], f0[6], f1[6], f2[6];
+        for (int i = 0; i < 10; i++) in[i] = s_cinert[10 * b + i];
+        mul_inert_vec(f0, in, cacc);
+        mul_inert_vec(f1, in, cvel);
+        cross_force(f2, cvel, f1);
+        for (int i = 0; i < 6; i++) { s_cvel[6 * b + i] = cvel[i]; s_cacc[6 * b + i] = cacc[i]; s_cfrc[6 * b + i] = f0[i] + f2[i]; }
+      }
+      gsync();
+    }
+    // rne backward pass: accumulate child forces into parents (pull form)
+    for (int L = M.nlevel - 2; L >= 1; L--) {
+      int n = M.level_num[L] * 6, adr = M.level_adr[L];
+      for (int idx = lane; idx < n; idx += kGroup) {
+        int b = M.level_body[adr + idx / 6], c = idx % 6;
+        int ca = M.body_childadr[b], cn = M.body_childnum[b];
+        float acc = s_cfrc[6 * b + c];
+        for (int k = 0; k < cn; k++) acc += s_cfrc[6 * M.child_list[ca + k] + c];
+        s_cfrc[6 * b + c] = acc;
+      }
+      gsync();
+    }
+    // ---------------------------------------------------------------- qfrc_bias, mj_passive, mj_fwdActuation -> qfrc_smooth
+    for (int d = lane; d < nv; d += kGroup) {
+      float bias = 0.f;
+      int b = M.dof_bodyid[d];
+      for (int t = 0; t < 6; t++) bias += s_cdof[6 * d + t] * s_cfrc[6 * b + t];
+      float passive = 0.f;
+      if (!(M.disableflags & (1 << 5))) {
+        int j = M.dof_jntid[d];
+        if (M.jnt_type[j] >= 2) { int qa = M.jnt_qposadr[j]; passive -= M.jnt_stiffness[j] * (s_qpos[qa] - M.qpos_spring[qa]); }
+        passive -= M.dof_damping[d] * s_qvel[d];
+      }
+      s_smooth[d] = passive - bias;
+    }
+    gsync();
+    if (!(M.disableflags & (1 << 10))) {
+      for (int a = lane; a < M.nu; a += kGroup) {
+        float ctrl = s_ctrl[a];
+        if (M.act_ctrllimited[a] && !(M.disableflags & (1 << 7))) ctrl = clampf(ctrl, M.act_ctrlrange[2 * a], M.act_ctrlrange[2 * a + 1]);
+        float gear = M.act_gear[a];
+        float force = M.act_gain[a] * ctrl + M.act_bias[3 * a] + M.act_bias[3 * a + 1] * gear * s_qpos[M.act_qposadr[a]] + M.act_bias[3 * a + 2] * gear * s_qvel[M.act_dofadr[a]];
+        if (M.act_forcelimited[a]) force = clampf(force, M.act_forcerange[2 * a], M.act_forcerange[2 * a + 1]);
+        atomicAdd(&s_smooth[M.act_dofadr[a]], gear * force);
+      }
+    }
+    gsync();
+    // xfrc_applied: Cartesian wrench at each body com (mj_xfrcAccumulate)
+    if (P.xfrc) {
+      const float* xf = P.xfrc + (size_t)env * nb * 6;
+      for (int b = 1; b < nb; b++) {
+        float f[6];
+        bool nz = false;
+        for (int i = 0; i < 6; i++) { f[i] = xf[6 * b + i]; nz |= (f[i] != 0.f); }
+        if (!nz) continue;  // uniform: every lane reads the same values
+        V3 off = ld3(s_xipos + 3 * b) - ld3(s_scom + 3 * M.body_treeid[b]);
+        unsigned long long mask = M.body_dofmask[b];
+        for (int d = lane; d < nv; d += kGroup) {
+          if (!((mask >> d) & 1ull)) continue;
+          V3 ang = ld3(s_cdof + 6 * d), lin = ld3(s_cdof + 6 * d + 3);
+          V3 jp = lin + cross(ang, off);
+          s_smooth[d] += jp.x * f[0] + jp.y * f[1] + jp.z * f[2] + ang.x * f[3] + ang.y * f[4] + ang.z * f[5];
+        }
+      }
+      gsync();
+    }
+
+    // ================================================================ region B from here on (aliases the dynamics scratch)
+    // ---------------------------------------------------------------- mj_collision
+    int ncon = 0;
+    const bool contacts_on = !(M.disableflags & ((1 << 0) | (1 << 4)));
+    if (contacts_on) {
+      for (int p0 = 0; p0 < M.npair; p0 += kGroup) {
+        int p = p0 + lane;
+        ConOut co[2];
+        int n = 0;
+        V3 hint = {0.f, 0.f, 0.f};
+        float margin = 0.f;
+        if (p < M.npair) {
+          int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+          int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+          margin = M.pair_margin[p];
+          V3 pos1 = ld3(s_gpos + 3 * g1), pos2 = ld3(s_gpos + 3 * g2), ax2 = ld3(s_gaxis + 3 * g2);
+          float r2 = M.geom_size[3 * g2], l2 = M.geom_size[3 * g2 + 1];
+          if (t1 == 0) {
+            V3 normal = ld3(s_gaxis + 3 * g1);
+            if (dot(pos2 - pos1, normal) <= margin + M.geom_rbound[g2]) {
+              if (t2 == 2) n = plane_sphere(co[0], margin, pos1, normal, pos2, r2) ? 1 : 0;
+              else {
+                int n1 = plane_sphere(co[0], margin, pos1, normal, pos2 + ax2 * l2, r2) ? 1 : 0;
+                int n2 = plane_sphere(co[n1], margin, pos1, normal, pos2 - ax2 * l2, r2) ? 1 : 0;
+                n = n1 + n2;
+                hint = ax2;
+              }
+            }
+          } else if (t1 >= 2) {
+            V3 dp = pos2 - pos1;
+            float bound = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
+            if (dot(dp, dp) <= bound * bound) {
+              float r1 = M.geom_size[3 * g1], l1 = M.geom_size[3 * g1 + 1];
+              if (t1 == 2 && t2 == 2) n = sphere_sphere(co[0], margin, pos1, r1, pos2, r2) ? 1 : 0;
+              else if (t1 == 2) {
+                float x = clampf(dot(ax2, pos1 - pos2), -l2, l2);
+                n = sphere_sphere(co[0], margin, pos1, r1, pos2 + ax2 * x, r2) ? 1 : 0;
+              } else {
+                n = capsule_capsule(co, margin, pos1, ld3(s_gaxis + 3 * g1), r1, l1, pos2, ax2, r2, l2);
+              }
+            }
+          }
+        }
+        // ordered append: slot = ncon + (# contacts of lower lanes)
+        unsigned long long b1 = __ballot(n >= 1), b2 = __ballot(n >= 2);
+        unsigned long long lt = (1ull << lane) - 1ull;
+        int slot = ncon + __popcll(b1 & lt) + __popcll(b2 & lt);
+        for (int k = 0; k < n; k++) {
+          int s = slot + k;
+          if (s < kNconMax) {
+            float* c = s_con + s * kConStride;
+            c[C_DIST] = co[k].dist;
+            st3(c + C_POS, co[k].pos);
+            make_frame(c + C_FRAME, co[k].n, hint);
+            c[C_PAIR] = __int_as_float(p);
+          }
+        }
+        ncon += __popcll(b1) + __popcll(b2);
+      }
+      if (ncon > kNconMax) { status |= (1 << 1); ncon = kNconMax; }
+    }
+    gsync();
+
+    // ---------------------------------------------------------------- mj_makeConstraint
+    int nefc = 0;
+    const bool constraints_on = !(M.disableflags & (1 << 0));
+    // (a) limits: 2 candidates (lower, upper) per limited joint / tendon, in constraint order
+    if (constraints_on && !(M.disableflags & (1 << 3))) {
+      for (int c0 = 0; c0 < M.nlimcand; c0 += kGroup) {
+        int c = c0 + lane;
+        bool active = false;
+        float dist = 0.f, margin = 0.f;
+        int side = 0, kind = 0, id = 0;
+        if (c < M.nlimcand) {
+          kind = M.lim_kind[c]; id = M.lim_id[c]; side = M.lim_side[c];
+          margin = M.lim_margin[c];
+          float value = kind == 0 ? s_qpos[M.jnt_qposadr[id]] : s_tenlen[id];
+          dist = (float)side * (M.lim_range[c] - value);
+          active = dist < margin;
+        }
+        unsigned long long bal = __ballot(active);
+        int row = nefc + __popcll(bal & ((1ull << lane) - 1ull));
+        if (active && row < kNefcMax) {
+          float* Jr = s_C + row * cs;
+          for (int k = 0; k < cs; k++) Jr[k] = 0.f;
+          if (kind == 0) Jr[M.jnt_dofadr[id]] = (float)(-side);
+          else for (int w = 0; w < M.tendon_num[id]; w++) Jr[M.wrap_dofadr[M.tendon_adr[id] + w]] = (float)(-side) * M.wrap_prm[M.tendon_adr[id] + w];
+          float* e = s_efc + row;
+          e[E_POS * kNefcMax] = dist; e[E_MARGIN * kNefcMax] = margin;
+          e[E_SOLREF0 * kNefcMax] = M.lim_solref[2 * c]; e[E_SOLREF1 * kNefcMax] = M.lim_solref[2 * c + 1];
+          for (int i = 0; i < 5; i++) e[(E_IMP0 + i) * kNefcMax] = M.lim_solimp[5 * c + i];
+          e[E_DA * kNefcMax] = M.lim_invweight[c]; e[E_DAFIRST * kNefcMax] = M.lim_invweight[c]; e[E_MU2 * kNefcMax] = 0.f;
+        }
+        nefc += __popcll(bal);
+      }
+      if (nefc > kNefcMax) { status |= (1 << 2); nefc = kNefcMax; }
+    }
+    // (b) contacts: row base by prefix sum over contacts (1 row for condim 1, 4 for condim 3)
+    if (constraints_on && contacts_on) {
+      int myrows = 0, pairid = 0;
+      bool incl = false;
+      if (lane < ncon) {
+        const float* c = s_con + lane * kConStride;
+        pairid = __float_as_int(c[C_PAIR]);
+        float includemargin = M.pair_margin[pairid] - M.pair_gap[pairid];
+        incl = c[C_DIST] < includemargin;
+        myrows = incl ? (M.pair_dim[pairid] == 1 ? 1 : 4) : 0;
+      }
+      int scan = myrows;  // inclusive scan
+#pragma unroll
+      for (int o = 1; o < kGroup; o <<= 1) { int v = __shfl_up(scan, o, kGroup); if (lane >= o) scan += v; }
+      int base = nefc + scan - myrows;
+      bool fits = base + myrows <= kNefcMax;
+      if (lane < ncon) {
+        float* c = s_con + lane * kConStride;
+        c[C_ROW] = __int_as_float((incl && fits) ? base : -1);
+        c[C_DIM] = __int_as_float(M.pair_dim[pairid] == 1 ? 1 : 3);
+        c[C_FRIC] = fmaxf(1e-5f, M.pair_friction[3 * pairid]);
+      }
+      if (__ballot(lane < ncon && incl && !fits)) status |= (1 << 2);
+      // contacts are materialised in order; once one does not fit, none of the later ones does
+      int endrow = (lane < ncon && incl && fits) ? base + myrows : nefc;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) endrow = max(endrow, __shfl_xor(endrow, m, kGroup));
+      const int nefc_after = endrow;
+      gsync();
+      // Jacobian rows: uniform loop over contacts, lanes over dofs
+      for (int ci = 0; ci < ncon; ci++) {
+        const float* c = s_con + ci * kConStride;
+        int row = __float_as_int(c[C_ROW]);
+        if (row < 0) continue;
+        int pid = __float_as_int(c[C_PAIR]);
+        int dim = __float_as_int(c[C_DIM]);
+        int g1 = M.pair_geom1[pid], g2 = M.pair_geom2[pid];
+        int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
+        unsigned long long m1 = M.body_dofmask[b1], m2 = M.body_dofmask[b2];
+        V3 cpos = ld3(c + C_POS);
+        V3 off1 = cpos - ld3(s_scom + 3 * M.body_treeid[b1]), off2 = cpos - ld3(s_scom + 3 * M.body_treeid[b2]);
+        V3 fn = ld3(c + C_FRAME), ft1 = ld3(c + C_FRAME + 3), ft2 = ld3(c + C_FRAME + 6);
+        float mu = c[C_FRIC];
+        for (int d = lane; d < cs; d += kGroup) {
+          V3 jd = {0.f, 0.f, 0.f};
+          if (d < nv) {
+            V3 ang = ld3(s_cdof + 6 * d), lin = ld3(s_cdof + 6 * d + 3);
+            if ((m2 >> d) & 1ull) jd = jd + lin + cross(ang, off2);
+            if ((m1 >> d) & 1ull) jd = jd - (lin + cross(ang, off1));
+          }
+          float j0 = dot(fn, jd);
+          if (dim == 1) s_C[row * cs + d] = j0;
+          else {
+            float j1 = mu * dot(ft1, jd), j2 = mu * dot(ft2, jd);
+            s_C[row * cs + d] = j0 + j1;
+            s_C[(row + 1) * cs + d] = j0 - j1;
+            s_C[(row + 2) * cs + d] = j0 + j2;
+            s_C[(row + 3) * cs + d] = j0 - j2;
+          }
+        }
+        int nr = dim == 1 ? 1 : 4;
+        if (lane < nr) {
+          float tran = M.body_invweight0[2 * b1] + M.body_invweight0[2 * b2];
+          float* e = s_efc + row + lane;
+          e[E_POS * kNefcMax] = c[C_DIST];
+          e[E_MARGIN * kNefcMax] = M.pair_margin[pid] - M.pair_gap[pid];
+          e[E_SOLREF0 * kNefcMax] = M.pair_solref[2 * pid]; e[E_SOLREF1 * kNefcMax] = M.pair_solref[2 * pid + 1];
+          for (int i = 0; i < 5; i++) e[(E_IMP0 + i) * kNefcMax] = M.pair_solimp[5 * pid + i];
+          float da = dim == 1 ? tran : tran + mu * mu * tran;
+          e[E_DA * kNefcMax] = da; e[E_DAFIRST * kNefcMax] = da;
+          float mus = mu * M.inv_sqrt_impratio;
+          e[E_MU2 * kNefcMax] = dim == 1 ? 0.f : 2.f * mus * mus;
+        }
+      }
+      nefc = nefc_after;
+    }
+    // extra right-hand side: row kNefcMax of C holds qfrc_smooth (half-solved below into y)
+    for (int d = lane; d < cs; d += kGroup) s_C[kNefcMax * cs + d] = d < nv ? s_smooth[d] : 0.f;
+    gsync();
+
+    // ---------------------------------------------------------------- per-row quantities (lane = row)
+    const bool rowact = lane < nefc;
+    float R = 1.f, Dd = 1.f, aref = 0.f, jw = 0.f, force = 0.f, bvec = 0.f;
+    if (rowact) {
+      const float* Jr = s_C + lane * cs;
+      float vel = 0.f;
+      for (int k = 0; k < nv; k++) { float j = Jr[k]; vel += j * s_qvel[k]; jw += j * s_warm[k]; }
+      const float* e = s_efc + lane;
+      float pos = e[E_POS * kNefcMax], margin = e[E_MARGIN * kNefcMax];
+      float solref0 = e[E_SOLREF0 * kNefcMax], solref1 = e[E_SOLREF1 * kNefcMax];
+      float solimp[5];
+      for (int i = 0; i < 5; i++) solimp[i] = e[(E_IMP0 + i) * kNefcMax];
+      float imp = clampf(impedance(solimp, pos, margin), HB_MINIMP, HB_MAXIMP);
+      float mu2 = e[E_MU2 * kNefcMax];
+      float Rown = fmaxf(HB_MINVAL, (1.f - imp) * e[E_DA * kNefcMax] / imp);
+      R = mu2 > 0.f ? mu2 * Rown : Rown;  // pyramidal: all rows share 2 mu^2 R(first); first row's diagApprox == own
+      Dd = 1.f / R;
+      float dmax = clampf(solimp[1], HB_MINIMP, HB_MAXIMP), K, Bc;
+      if (solref0 > 0.f) {
+        float tc = solref0;
+        if (!(M.disableflags & (1 << 11))) tc = fmaxf(tc, 2.f * M.timestep);
+        K = 1.f / fmaxf(HB_MINVAL, dmax * dmax * tc * tc * solref1 * solref1);
+        Bc = 2.f / fmaxf(HB_MINVAL, dmax * tc);
+      } else { K = -solref0 / fmaxf(HB_MINVAL, dmax * dmax); Bc = -solref1 / fmaxf(HB_MINVAL, dmax); }
+      aref = -Bc * vel - K * imp * (pos - margin);
+    }
+    gsync();
+    // ---------------------------------------------------------------- half solve: C_i = D^-1/2 L^-T J_i (mj_solveM2), rows and the extra RHS together
+    {
+      const bool solverow = rowact || lane == kGroup - 1;
+      float* x = s_C + lane * cs;  // lane 63 owns row kNefcMax == 63 (the extra right-hand side)
+      if (solverow) {
+        for (int k = nv - 1; k >= 0; k--) {
+          int nanc = M.dof_nanc[k];
+          if (nanc == 0) continue;
+          float xk = x[k];
+          int Mki = M.dof_Madr[k] + 1, i = M.dof_parentid[k];
+          for (int a = 0; a < nanc; a++) { x[i] -= s_qLD[Mki + a] * xk; i = M.dof_parentid[i]; }
+        }
+        for (int k = 0; k < nv; k++) x[k] *= s_dsqrtinv[k];
+      }
+    }
+    gsync();
+    // ---------------------------------------------------------------- efc_b, AR = C C^T + diag(R) (mj_projectConstraint)
+    const float* yv = s_C + kNefcMax * cs;
+    if (rowact) {
+      const float* Cr = s_C + lane * cs;
+      float jas = 0.f;
+      for (int k = 0; k < nv; k++) jas += Cr[k] * yv[k];
+      bvec = jas - aref;
+      for (int j = 0; j < nefc; j++) {
+        const float* Cj = s_C + j * cs;
+        float s = 0.f;
+        for (int k = 0; k < nv; k++) s += Cr[k] * Cj[k];
+        if (j == lane) s += R;
+        s_AR[lane * ARS + j] = s;
+      }
+    }
+    gsync();
+    // ---------------------------------------------------------------- mj_fwdConstraint: warm start + PGS
+    int niter = 0;
+    if (nefc > 0) {
+      float Aii = rowact ? s_AR[lane * ARS + lane] : 1.f;
+      if (!(M.disableflags & (1 << 8))) {
+        float jar = jw - aref;
+        force = (rowact && jar < 0.f) ? -Dd * jar : 0.f;
+        // cost(f) = 0.5 f'AR f + f'b; keep the warm start only if it beats zero
+        float arf = 0.f;
+        for (int j = 0; j < nefc; j++) arf += s_AR[j * ARS + lane] * rdlane(force, j);
+        float cost = wave_sum(rowact ? force * (0.5f * arf + bvec) : 0.f);
+        if (cost > 0.f) force = 0.f;
+      }
+      float res = bvec;
+      for (int j = 0; j < nefc; j++) res += s_AR[j * ARS + lane] * rdlane(force, j);
+      if (!rowact) res = 0.f;
+      while (niter < M.iterations) {
+        float improvement = 0.f;
+        for (int i = 0; i < nefc; i++) {
+          float ri = rdlane(res, i), fi = rdlane(force, i), aii = rdlane(Aii, i);
+          float fnew = fmaxf(0.f, fi - ri / aii);
+          float delta = fnew - fi;
+          float change = 0.5f * delta * delta * aii + delta * ri;
+          if (change > 1e-10f) { delta = 0.f; change = 0.f; }
+          improvement -= change;
+          res += s_AR[i * ARS + lane] * delta;
+          if (lane == i) force += delta;
+        }
+        niter++;
+        if (improvement * M.pgs_scale < M.tolerance) break;
+      }
+    }
+    if (lane < kNefcMax) s_efc[E_FORCE * kNefcMax + lane] = rowact ? force : 0.f;
+    gsync();
+    // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = L^-1 D^-1/2 (y + s) ; qfrc_constraint = L^T D^1/2 s
+    for (int k = lane; k < nv; k += kGroup) {
+      float s = 0.f;
+      for (int i = 0; i < nefc; i++) s += s_efc[E_FORCE * kNefcMax + i] * s_C[i * cs + k];
+      float dsi = s_dsqrtinv[k];
+      s_v0[k] = (yv[k] + s) * dsi;  // -> qacc after L^-1
+      s_v1[k] = s / dsi;            // D^1/2 s
+    }
+    gsync();
+    solve_l_push(M, s_qLD, s_v0, lane);
+    for (int i = lane; i < nv; i += kGroup) {
+      float acc = s_v1[i];
+      for (int t = M.desc_adr[i]; t < M.desc_adr[i + 1]; t++) acc += s_qLD[M.desc_M[t]] * s_v1[M.desc_k[t]];
+      s_v2[i] = s_smooth[i] + acc;  // qfrc_smooth + qfrc_constraint: right-hand side of the Euler solve
+    }
+    gsync();
+    // mj_checkAcc
+    {
+      bool bad = false;
+      for (int i = lane; i < nv; i += kGroup) bad |= !(fabsf(s_v0[i]) <= HB_MAXVAL);
+      if (__any(bad)) {
+        status |= (1 << 6);
+        for (int i = lane; i < nq; i += kGroup) s_qpos[i] = M.qpos0[i];
+        for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; s_v0[i] = 0.f; s_v2[i] = 0.f; }
+        time = 0.f;
+        gsync();
+      }
+    }
+    // diagnostics of this step (parity tests)
+    if (P.diag_qacc) for (int i = lane; i < nv; i += kGroup) P.diag_qacc[(size_t)env * nv + i] = s_v0[i];
+    if (P.diag_force && lane < kNefcMax) P.diag_force[(size_t)env * kNefcMax + lane] = rowact ? force : 0.f;
+    if (P.diag_contact) {
+      for (int idx = lane; idx < kNconMax * kDiagConStride; idx += kGroup) {
+        int ci = idx / kDiagConStride, f = idx % kDiagConStride;
+        float v = 0.f;
+        if (ci < ncon) {
+          const float* c = s_con + ci * kConStride;
+          if (f < 13) v = c[f];
+          else {
+            int pid = __float_as_int(c[C_PAIR]);
+            v = f == 13 ? (float)__float_as_int(c[C_DIM]) : (f == 14 ? (float)M.pair_geom1[pid] : (float)M.pair_geom2[pid]);
+          }
+        }
+        P.diag_contact[((size_t)env * kNconMax) * kDiagConStride + idx] = v;
+      }
+    }
+    if (lane == 0) { int* c = P.counts + 4 * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; }
+
+    if (P.integrate) {
+      // ---------------------------------------------------------------- mj_Euler: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint
+      bool damp = false;
+      if (!(M.disableflags & (1 << 14))) {
+        bool d = false;
+        for (int i = lane; i < nv; i += kGroup) d |= M.dof_damping[i] > 0.f;
+        damp = __any(d);
+      }
+      for (int i = lane; i < nv; i += kGroup) s_warm[i] = s_v0[i];  // qacc_warmstart <- qacc
+      if (damp) {
+        for (int e = lane; e < M.nM; e += kGroup) {
+          float v = s_qM[e];
+          if (M.M_i[e] == M.M_j[e]) v += M.timestep * M.dof_damping[M.M_i[e]];
+          s_qLD[e] = v;
+        }
+        gsync();
+        factor_ld(M, s_qLD, s_dinv, s_dsqrtinv, lane);
+        solve_lt_push(M, s_qLD, s_v2, lane);
+        for (int i = lane; i < nv; i += kGroup) s_v2[i] *= s_dinv[i];
+        gsync();
+        solve_l_push(M, s_qLD, s_v2, lane);
+      } else {
+        for (int i = lane; i < nv; i += kGroup) s_v2[i] = s_v0[i];
+        gsync();
+      }
+      // mj_advance
+      const float h = M.timestep;
+      for (int i = lane; i < nv; i += kGroup) s_qvel[i] += h * s_v2[i];
+      gsync();
+      for (int j = lane; j < M.njnt; j += kGroup) {
+        int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
+        if (M.jnt_type[j] == 0) {
+          for (int i = 0; i < 3; i++) s_qpos[qa + i] += h * s_qvel[da + i];
+          float n;
+          V3 w = normalized(ld3(s_qvel + da + 3), &n);
+          Q4 q = qnormalize(ldq(s_qpos + qa + 3));
+          stq(s_qpos + qa + 3, qmul(q, axisangle(w, h * n)));
+        } else s_qpos[qa] += h * s_qvel[da];
+      }
+      time += h;
+      gsync();
+      if (P.qpos_out) {
+        float* o = P.qpos_out + ((size_t)step * P.n_env + env) * nq;
+        for (int i = lane; i < nq; i += kGroup) o[i] = s_qpos[i];
+      }
+    }
+  }
+
+  if (P.integrate) {
+    if (lane == 0) gstate[0] = time;
+    for (int i = lane; i < nq; i += kGroup) gstate[1 + i] = s_qpos[i];
+    for (int i = lane; i < nv; i += kGroup) { gstate[1 + nq + i] = s_qvel[i]; gstate[1 + nq + nv + i] = s_warm[i]; }
+  }
+  if (status && lane == 0) atomicOr(P.status + env, status);
+}
+
+// ------------------------------------------------------------------------------------------
+// reset: qpos0/keyframe (+ Halton perturbation), zero velocity/warmstart/time/status
+__global__ void hb_reset_kernel(const DevModel M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, int perturb, int env_offset) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env) return;
+  if (mask && !mask[e]) return;
+  float* s = state + (size_t)e * M.nstate;
+  s[0] = 0.f;
+  for (int i = 0; i < M.nq; i++) s[1 + i] = qpos_src[i];
+  for (int i = 0; i < 2 * M.nv; i++) s[1 + M.nq + i] = 0.f;
+  if (perturb) {
+    for (int j = 0; j < M.njnt; j++) {
+      int qa = M.jnt_qposadr[j];
+      if (M.jnt_type[j] == 0) s[1 + qa + 2] += 0.1f * halton(env_offset + e + 1, 3);
+      else s[1 + qa] += 0.2f * (2.f * halton(env_offset + e + 1, 2 + j) - 1.f);
+    }
+  }
+  status[e] = 0;
+}
+
+// env adapter: observation / reward / done, the 27-DoF analogue of CPUEnv._get_obs (cpu_env.py:465-571)
+__global__ void hb_obs_kernel(const DevModel M, const float* state, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env) return;
+  const float* s = state + (size_t)e * M.nstate;
+  const float* qpos = s + 1;
+  const float* qvel = s + 1 + M.nq;
+  float* o = obs + (size_t)e * M.nobs;
+  int nh = 0;
+  for (int j = 0; j < M.njnt; j++)
+    if (M.jnt_type[j] >= 2) { o[nh++] = qpos[M.jnt_qposadr[j]]; }
+  int k = nh;
+  for (int j = 0; j < M.njnt; j++)
+    if (M.jnt_type[j] >= 2) { o[k++] = qvel[M.jnt_dofadr[j]]; }
+  int da = M.obs_root_dofadr;
+  Q4 q = {1.f, 0.f, 0.f, 0.f};
+  if (da >= 0) {
+    for (int i = 0; i < 3; i++) o[k++] = qvel[da + 3 + i];
+    int qa = M.jnt_qposadr[M.dof_jntid[da]];
+    q = qnormalize(ldq(qpos + qa + 3));
+  } else {
+    for (int i = 0; i < 3; i++) o[k++] = 0.f;
+  }
+  // gravity direction in the torso frame: R(q)^T (0,0,-1)  (cpu_env.py:510-519)
+  float m[9];
+  q2mat(m, q);
+  o[k++] = -m[6]; o[k++] = -m[7]; o[k++] = -m[8];
+  if (reward) {
+    // upright + height shaping in the spirit of standupReward (reward_functions.py:247-374); see DESIGN.md
+    float up = -(-m[8]);  // cos of tilt
+    float z = da >= 0 ? qpos[M.jnt_qposadr[M.dof_jntid[da]] + 2] : 0.f;
+    reward[e] = 10.f * expf(-(1.f - up) / 0.5f) + z;
+  }
+  if (terminated) terminated[e] = 0;
+  if (truncated) truncated[e] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-callable launchers (declared in hb_launch.hpp)
+}  // namespace hb
+
+#include "hb_launch.hpp"
+
+namespace hb {
+
+hipError_t launch_step(const DevModel& M, const BatchPtrs& P, int nsteps, hipStream_t stream) {
+  size_t shmem = (size_t)M.lds_floats * sizeof(float);
+  hipLaunchKernelGGL(hb_step_kernel, dim3(P.n_env), dim3(kGroup), shmem, stream, M, P, nsteps);
+  return hipGetLastError();
+}
+hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, int perturb, int env_offset, hipStream_t stream) {
+  hipLaunchKernelGGL(hb_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, status, mask, qpos_src, n_env, perturb, env_offset);
+  return hipGetLastError();
+}
+hipError_t launch_obs(const DevModel& M, const float* state, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env, hipStream_t stream) {
+  hipLaunchKernelGGL(hb_obs_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, obs, reward, terminated, truncated, n_env);
+  return hipGetLastError();
+}
+hipError_t set_step_lds_limit(int bytes) {
+  return hipFuncSetAttribute((const void*)hb_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace hb

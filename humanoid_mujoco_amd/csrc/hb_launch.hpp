@@ -1,0 +1,10 @@
+// hb_launch.hpp — host-callable launchers implemented in hb_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hb_device.hpp"
+namespace hb {
+hipError_t launch_step(const DevModel& M, const BatchPtrs& P, int nsteps, hipStream_t stream);
+hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, int perturb, int env_offset, hipStream_t stream);
+hipError_t launch_obs(const DevModel& M, const float* state, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env, hipStream_t stream);
+hipError_t set_step_lds_limit(int bytes);
+}  // namespace hb

@@ -1,0 +1,289 @@
+"""ctypes host binding of libhb.so (include/hb.h) — the Python side of the drop-in boundary.
+
+Mirrors how the reference's Python reaches its physics step: ``mujoco.MjModel.from_xml_path`` /
+``mujoco.MjData`` / ``mujoco.mj_step`` in simulation/cpu_env.py:86,397,684 become
+``Model.load`` / ``Batch`` / ``Batch.step``.  All compute happens in the HIP kernels behind the
+C-ABI; this module only moves pointers.  There is no CPU fallback: creating a Batch without a
+GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhb.so")
+
+HB_OK = 0
+WARN_CONTACTFULL, WARN_CNSTRFULL, WARN_BADQPOS, WARN_BADQVEL, WARN_BADQACC = 1 << 1, 1 << 2, 1 << 4, 1 << 5, 1 << 6
+STATE_TIME, STATE_QPOS, STATE_QVEL, STATE_WARMSTART, STATE_XFRC_APPLIED = 1 << 0, 1 << 1, 1 << 2, 1 << 4, 1 << 7
+STATE_PHYSICS = STATE_QPOS | STATE_QVEL
+STATE_INTEGRATION = STATE_TIME | STATE_QPOS | STATE_QVEL | STATE_WARMSTART
+
+# mjtDisableBit (simulation/mujoco/include/mujoco/mjmodel.h:50-68)
+DSBL_CONSTRAINT, DSBL_LIMIT, DSBL_CONTACT, DSBL_PASSIVE, DSBL_GRAVITY = 1 << 0, 1 << 3, 1 << 4, 1 << 5, 1 << 6
+DSBL_CLAMPCTRL, DSBL_WARMSTART, DSBL_FILTERPARENT, DSBL_ACTUATION, DSBL_REFSAFE, DSBL_EULERDAMP = 1 << 7, 1 << 8, 1 << 9, 1 << 10, 1 << 11, 1 << 14
+
+
+class HbOptions(ctypes.Structure):
+    _fields_ = [("timestep", ctypes.c_double), ("gravity", ctypes.c_double * 3), ("impratio", ctypes.c_double),
+                ("tolerance", ctypes.c_double), ("iterations", ctypes.c_int), ("solver", ctypes.c_int),
+                ("cone", ctypes.c_int), ("integrator", ctypes.c_int), ("disableflags", ctypes.c_int)]
+
+
+class HbSizes(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("nq", "nv", "nu", "nbody", "njnt", "ngeom", "ntendon", "nM", "nkey",
+                                            "npair", "nobs", "ncon_max", "nefc_max")]
+
+
+class HbError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libhb.so; fails loudly when the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HbError("libhb.so is missing (%s): build it with `make` or __graft_entry__.build(); "
+                      "this package has no fallback path" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, cp, ci, cu = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint
+    L.hb_version.restype = cp
+    L.hb_model_load.restype = vp; L.hb_model_load.argtypes = [cp, cp, ci]
+    L.hb_model_load_xml_string.restype = vp; L.hb_model_load_xml_string.argtypes = [cp, cp, ci]
+    L.hb_model_save.argtypes = [vp, cp, cp, ci]
+    L.hb_model_free.argtypes = [vp]; L.hb_model_free.restype = None
+    L.hb_model_sizes.argtypes = [vp, ctypes.POINTER(HbSizes)]
+    L.hb_options_get.argtypes = [vp, ctypes.POINTER(HbOptions)]
+    L.hb_options_set.argtypes = [vp, ctypes.POINTER(HbOptions)]
+    L.hb_model_name2id.argtypes = [vp, cp, cp]
+    L.hb_model_get_array.argtypes = [vp, cp, vp, ci]
+    L.hb_batch_create.restype = vp; L.hb_batch_create.argtypes = [vp, ci, ci, cp, ci]
+    L.hb_batch_free.argtypes = [vp]; L.hb_batch_free.restype = None
+    L.hb_batch_n_env.argtypes = [vp]
+    L.hb_batch_stream.restype = vp; L.hb_batch_stream.argtypes = [vp]
+    L.hb_batch_sync.argtypes = [vp]
+    L.hb_reset.argtypes = [vp, vp, ci, ci, ci]
+    L.hb_step.argtypes = [vp, vp, ci]
+    L.hb_step_dev.argtypes = [vp, vp, ci]
+    L.hb_rollout.argtypes = [vp, vp, ci, vp]
+    L.hb_rollout_dev.argtypes = [vp, vp, ci, vp]
+    L.hb_rollout_halton.argtypes = [vp, ci, ci, ci, vp]
+    L.hb_forward.argtypes = [vp, vp]
+    L.hb_state_size.argtypes = [vp, cu]
+    L.hb_get_state.argtypes = [vp, cu, vp]; L.hb_set_state.argtypes = [vp, cu, vp]
+    L.hb_get_state_f64.argtypes = [vp, cu, vp]; L.hb_set_state_f64.argtypes = [vp, cu, vp]
+    L.hb_get_obs.argtypes = [vp, vp, vp, vp, vp]
+    L.hb_get_status.argtypes = [vp, vp]
+    L.hb_get_counts.argtypes = [vp, vp, vp, vp]
+    L.hb_diag_enable.argtypes = [vp, ci]
+    L.hb_get_qacc.argtypes = [vp, vp]; L.hb_get_efc_force.argtypes = [vp, vp]; L.hb_get_contacts.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != HB_OK:
+        raise HbError("%s failed with code %d" % (what, rc))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Model:
+    """Compiled model (replaces mujoco.MjModel for this path)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        s = HbSizes()
+        _check(lib().hb_model_sizes(self._h, ctypes.byref(s)), "hb_model_sizes")
+        for name, _ in HbSizes._fields_:
+            setattr(self, name, getattr(s, name))
+
+    @classmethod
+    def load(cls, path):
+        err = ctypes.create_string_buffer(1024)
+        h = lib().hb_model_load(os.fsencode(path), err, len(err))
+        if not h:
+            raise HbError("hb_model_load(%s): %s" % (path, err.value.decode()))
+        return cls(h)
+
+    @classmethod
+    def from_xml_string(cls, xml):
+        err = ctypes.create_string_buffer(1024)
+        h = lib().hb_model_load_xml_string(xml.encode(), err, len(err))
+        if not h:
+            raise HbError("hb_model_load_xml_string: %s" % err.value.decode())
+        return cls(h)
+
+    def save(self, path):
+        err = ctypes.create_string_buffer(1024)
+        if lib().hb_model_save(self._h, os.fsencode(path), err, len(err)) != HB_OK:
+            raise HbError("hb_model_save: %s" % err.value.decode())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().hb_model_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def opt(self):
+        o = HbOptions()
+        _check(lib().hb_options_get(self._h, ctypes.byref(o)), "hb_options_get")
+        return o
+
+    def set_opt(self, **kw):
+        o = self.opt
+        for k, v in kw.items():
+            if k == "gravity":
+                for i in range(3):
+                    o.gravity[i] = v[i]
+            else:
+                setattr(o, k, v)
+        _check(lib().hb_options_set(self._h, ctypes.byref(o)), "hb_options_set")
+
+    def name2id(self, kind, name):
+        return lib().hb_model_name2id(self._h, kind.encode(), name.encode())
+
+    def array(self, field):
+        n = lib().hb_model_get_array(self._h, field.encode(), None, 0)
+        if n < 0:
+            raise KeyError(field)
+        out = np.zeros(n, dtype=np.float64)
+        lib().hb_model_get_array(self._h, field.encode(), _ptr(out), n)
+        return out
+
+
+class Batch:
+    """n_env environments resident on one GPU (replaces n_env mujoco.MjData blocks)."""
+
+    def __init__(self, model, n_env, device=0):
+        self.model = model
+        self.n_env = int(n_env)
+        err = ctypes.create_string_buffer(1024)
+        self._h = lib().hb_batch_create(model._h, self.n_env, int(device), err, len(err))
+        if not self._h:
+            raise HbError("hb_batch_create: %s" % err.value.decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hb_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return lib().hb_batch_stream(self._h)
+
+    def sync(self):
+        _check(lib().hb_batch_sync(self._h), "hb_batch_sync")
+
+    def reset(self, mask=None, keyframe=-1, perturb=False, env_offset=0):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        _check(lib().hb_reset(self._h, _ptr(m), int(keyframe), int(bool(perturb)), int(env_offset)), "hb_reset")
+
+    def step(self, ctrl, n_substeps=1):
+        c = np.ascontiguousarray(ctrl, dtype=np.float32)
+        assert c.shape == (self.n_env, self.model.nu), c.shape
+        _check(lib().hb_step(self._h, _ptr(c), int(n_substeps)), "hb_step")
+
+    def step_dev(self, ctrl_ptr, n_substeps=1):
+        """ctrl_ptr: device address (int) of a float32 [n_env, nu] array; asynchronous."""
+        _check(lib().hb_step_dev(self._h, ctypes.c_void_p(ctrl_ptr), int(n_substeps)), "hb_step_dev")
+
+    def forward(self, ctrl=None):
+        c = None if ctrl is None else np.ascontiguousarray(ctrl, dtype=np.float32)
+        _check(lib().hb_forward(self._h, _ptr(c)), "hb_forward")
+
+    def rollout(self, ctrl, want_qpos=False):
+        c = np.ascontiguousarray(ctrl, dtype=np.float32)
+        T = c.shape[0]
+        assert c.shape == (T, self.n_env, self.model.nu), c.shape
+        q = np.zeros((T, self.n_env, self.model.nq), dtype=np.float32) if want_qpos else None
+        _check(lib().hb_rollout(self._h, _ptr(c), T, _ptr(q)), "hb_rollout")
+        return q
+
+    def rollout_dev(self, ctrl_ptr, T, qpos_out_ptr=None):
+        _check(lib().hb_rollout_dev(self._h, ctypes.c_void_p(ctrl_ptr), int(T), ctypes.c_void_p(qpos_out_ptr or 0)), "hb_rollout_dev")
+
+    def rollout_halton(self, T, t0=0, env_offset=0, qpos_out_ptr=None):
+        _check(lib().hb_rollout_halton(self._h, int(T), int(t0), int(env_offset), ctypes.c_void_p(qpos_out_ptr or 0)), "hb_rollout_halton")
+
+    def state_size(self, spec):
+        return lib().hb_state_size(self._h, spec)
+
+    def get_state(self, spec=STATE_INTEGRATION, dtype=np.float32):
+        w = self.state_size(spec)
+        out = np.zeros((self.n_env, w), dtype=dtype)
+        fn = lib().hb_get_state if dtype == np.float32 else lib().hb_get_state_f64
+        _check(fn(self._h, spec, _ptr(out)), "hb_get_state")
+        return out
+
+    def set_state(self, spec, values):
+        dt = np.float64 if np.asarray(values).dtype == np.float64 else np.float32
+        v = np.ascontiguousarray(values, dtype=dt)
+        assert v.shape == (self.n_env, self.state_size(spec)), v.shape
+        fn = lib().hb_set_state if dt == np.float32 else lib().hb_set_state_f64
+        _check(fn(self._h, spec, _ptr(v)), "hb_set_state")
+
+    @property
+    def qpos(self):
+        return self.get_state(STATE_QPOS)
+
+    @property
+    def qvel(self):
+        return self.get_state(STATE_QVEL)
+
+    @property
+    def time(self):
+        return self.get_state(STATE_TIME)[:, 0]
+
+    def obs(self, want_reward=True):
+        o = np.zeros((self.n_env, self.model.nobs), dtype=np.float32)
+        r = np.zeros(self.n_env, dtype=np.float32) if want_reward else None
+        te = np.zeros(self.n_env, dtype=np.uint8)
+        tr = np.zeros(self.n_env, dtype=np.uint8)
+        _check(lib().hb_get_obs(self._h, _ptr(o), _ptr(r), _ptr(te), _ptr(tr)), "hb_get_obs")
+        return o, r, te.astype(bool), tr.astype(bool)
+
+    def status(self):
+        s = np.zeros(self.n_env, dtype=np.int32)
+        _check(lib().hb_get_status(self._h, _ptr(s)), "hb_get_status")
+        return s
+
+    def counts(self):
+        a, b, c = (np.zeros(self.n_env, dtype=np.int32) for _ in range(3))
+        _check(lib().hb_get_counts(self._h, _ptr(a), _ptr(b), _ptr(c)), "hb_get_counts")
+        return a, b, c
+
+    def diag_enable(self, on=True):
+        _check(lib().hb_diag_enable(self._h, int(on)), "hb_diag_enable")
+
+    def qacc(self):
+        out = np.zeros((self.n_env, self.model.nv), dtype=np.float32)
+        _check(lib().hb_get_qacc(self._h, _ptr(out)), "hb_get_qacc")
+        return out
+
+    def efc_force(self):
+        out = np.zeros((self.n_env, self.model.nefc_max), dtype=np.float32)
+        _check(lib().hb_get_efc_force(self._h, _ptr(out)), "hb_get_efc_force")
+        return out
+
+    def contacts(self):
+        out = np.zeros((self.n_env, self.model.ncon_max, 16), dtype=np.float32)
+        _check(lib().hb_get_contacts(self._h, _ptr(out)), "hb_get_contacts")
+        return out

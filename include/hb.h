@@ -1,0 +1,167 @@
+/* hb.h — C-ABI of the MI355X batched humanoid physics-step / rollout engine (libhb.so).
+ *
+ * Drop-in boundary for the reference's physics-step path.  Every entry point
+ * cites the reference interface it replaces; paths are relative to the reference repository
+ * (mcgill-robotics/Humanoid-MuJoCo), MuJoCo C API = simulation/mujoco/include/mujoco/mujoco.h.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in any signature.
+ *   - every function returns an int status (HB_OK == 0, negative = error) or a handle
+ *     (NULL on failure, message in the caller's err buffer).  Nothing aborts the process
+ *     (the reference's mju_error would, mujoco.h:810).
+ *   - "env-major" arrays are [n_env][width], row e belonging to environment e.
+ *   - *_dev variants take DEVICE pointers (hipMalloc / torch tensor data_ptr) on the batch's
+ *     device and enqueue on the batch's stream without synchronising; the plain variants take
+ *     HOST pointers, copy, and synchronise before returning.
+ *   - there is no CPU backend: hb_batch_create fails (HB_ENODEVICE) without a HIP device.
+ */
+#ifndef HB_H_
+#define HB_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HB_OK 0
+#define HB_EINVAL (-1)    /* bad argument */
+#define HB_ENODEVICE (-2) /* no usable HIP device / HIP call failed */
+#define HB_ENOMEM (-3)
+#define HB_EUNSUPPORTED (-4)
+#define HB_EIO (-5)
+
+/* per-env status bits, the batched counterpart of mjData.warning[] (mjdata.h:54-65,185) */
+#define HB_WARN_CONTACTFULL (1 << 1) /* mjWARN_CONTACTFULL: contact buffer overflow, extras dropped */
+#define HB_WARN_CNSTRFULL (1 << 2)   /* mjWARN_CNSTRFULL: constraint rows overflow, extras dropped */
+#define HB_WARN_BADQPOS (1 << 4)     /* mjWARN_BADQPOS: NaN/huge qpos, env was reset (mujoco.h:301) */
+#define HB_WARN_BADQVEL (1 << 5)     /* mjWARN_BADQVEL (mujoco.h:304) */
+#define HB_WARN_BADQACC (1 << 6)     /* mjWARN_BADQACC (mujoco.h:307) */
+
+/* state specification bits — identical to mjtState (mjdata.h:27-50); hb_get_state/hb_set_state
+ * concatenate the selected components per env in ascending bit order, as mj_getState does. */
+#define HB_STATE_TIME (1 << 0)
+#define HB_STATE_QPOS (1 << 1)
+#define HB_STATE_QVEL (1 << 2)
+#define HB_STATE_WARMSTART (1 << 4)
+#define HB_STATE_CTRL (1 << 5)
+#define HB_STATE_XFRC_APPLIED (1 << 7)
+#define HB_STATE_PHYSICS (HB_STATE_QPOS | HB_STATE_QVEL)
+#define HB_STATE_INTEGRATION (HB_STATE_TIME | HB_STATE_QPOS | HB_STATE_QVEL | HB_STATE_WARMSTART)
+
+typedef struct hb_model hb_model; /* immutable compiled model; shareable across batches/devices */
+typedef struct hb_batch hb_batch; /* n_env independent simulations resident on one GPU */
+
+/* The fields of mjOption this engine honours (mjmodel.h:403-445). */
+typedef struct hb_options {
+  double timestep;
+  double gravity[3];
+  double impratio;
+  double tolerance;  /* PGS early-exit threshold on the scaled cost improvement */
+  int iterations;    /* PGS sweep cap */
+  int solver;        /* 0 = PGS (mjSOL_PGS); the only solver implemented */
+  int cone;          /* 0 = pyramidal; the only cone implemented */
+  int integrator;    /* 0 = Euler (semi-implicit, implicit joint damping) */
+  int disableflags;  /* mjtDisableBit (mjmodel.h:50-68) */
+} hb_options;
+
+/* sizes a caller needs to allocate buffers (mjModel.nq/nv/nu/..., mjmodel.h:560-620) */
+typedef struct hb_sizes {
+  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, nkey, npair;
+  int nobs;     /* width of the env observation (hb_get_obs) */
+  int ncon_max; /* contact capacity per env */
+  int nefc_max; /* constraint-row capacity per env */
+} hb_sizes;
+
+/* ---- model --------------------------------------------------------------------------------- */
+
+/* Replaces mj_loadXML (mujoco.h:103) / mj_loadModel (mujoco.h:163).  `path` ends in ".xml"
+ * (MJCF subset, compiled on the host) or ".hbm" (this engine's compiled text model). */
+hb_model* hb_model_load(const char* path, char* err, int err_sz);
+/* Replaces mj_loadXML with an in-memory string (mjVFS use in the reference). */
+hb_model* hb_model_load_xml_string(const char* xml, char* err, int err_sz);
+/* Replaces mj_saveModel (mujoco.h:159). */
+int hb_model_save(const hb_model* m, const char* path, char* err, int err_sz);
+/* Replaces mj_deleteModel (mujoco.h:166). */
+void hb_model_free(hb_model* m);
+int hb_model_sizes(const hb_model* m, hb_sizes* out);
+/* mjOption get/set (model->opt in the reference, e.g. simulation/cpu_env.py:87 sets
+ * opt.timestep).  Options are copied into a batch at hb_batch_create. */
+int hb_options_get(const hb_model* m, hb_options* out);
+int hb_options_set(hb_model* m, const hb_options* in);
+/* mj_name2id (mujoco.h:516) for kind in {"body","joint","geom","actuator","tendon","key"}; -1 if absent. */
+int hb_model_name2id(const hb_model* m, const char* kind, const char* name);
+/* Copies a named fp64 model array (mjModel field name, e.g. "body_mass", "qpos0") into out[cap];
+ * returns its length, or HB_EINVAL. */
+int hb_model_get_array(const hb_model* m, const char* field, double* out, int cap);
+
+/* ---- batch --------------------------------------------------------------------------------- */
+
+/* Replaces n_env calls of mj_makeData (mujoco.h:173).  device = HIP ordinal (>= 0). */
+hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, int err_sz);
+/* Replaces mj_deleteData (mujoco.h:206). */
+void hb_batch_free(hb_batch* b);
+int hb_batch_n_env(const hb_batch* b);
+/* The HIP stream (hipStream_t as void*) all work of this batch is enqueued on. */
+void* hb_batch_stream(const hb_batch* b);
+int hb_batch_sync(hb_batch* b);
+
+/* Replaces mj_resetData (keyframe < 0) / mj_resetDataKeyframe (mujoco.h:180,186) for the envs
+ * whose mask byte is non-zero (mask == NULL: all).  perturb != 0 adds the deterministic
+ * Halton perturbation of SURVEY.md §8(d) (hinges +-0.2 rad, root z +0.1 m) indexed by
+ * env_offset + e, mirroring CPUEnv.reset's joint/height randomisation (cpu_env.py:282-328). */
+int hb_reset(hb_batch* b, const uint8_t* mask, int keyframe, int perturb, int env_offset);
+
+/* Replaces `for e: mju_copy(d->ctrl, ...); mj_step(m, d)` (mujoco.h:120; call sites
+ * simulation/cpu_env.py:683-684, simulation/mujoco/sample/testspeed.cc:93-96).
+ * ctrl: env-major [n_env][nu] float32, applied for n_substeps consecutive steps. */
+int hb_step(hb_batch* b, const float* ctrl, int n_substeps);
+int hb_step_dev(hb_batch* b, const float* ctrl_dev, int n_substeps);
+
+/* Replaces the open-loop rollout loops (mujoco_mpc/mjpc/trajectory.cc:141-179,
+ * simulation/mujoco/sample/testspeed.cc:84-103): T steps in ONE launch with state resident
+ * on chip; ctrl is [T][n_env][nu]; qpos_out (nullable) receives [T][n_env][nq] after each step. */
+int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out);
+int hb_rollout_dev(hb_batch* b, const float* ctrl_dev, int T, float* qpos_out_dev);
+/* Same rollout with controls generated on device from the Halton sequence of
+ * testspeed.cc:64-80 (ctrl[t,e,i] = 2*H(1+t0+t+1000*(env_offset+e), i+2)-1): the benchmark
+ * workload of SURVEY.md §8(d), no control tensor in HBM. */
+int hb_rollout_halton(hb_batch* b, int T, int t0, int env_offset, float* qpos_out_dev);
+
+/* Replaces mj_forward (mujoco.h:129): recompute everything up to qacc without integrating. */
+int hb_forward(hb_batch* b, const float* ctrl);
+
+/* Replaces mj_stateSize / mj_getState / mj_setState (mujoco.h:378-384). */
+int hb_state_size(const hb_batch* b, unsigned spec);
+int hb_get_state(hb_batch* b, unsigned spec, float* out);
+int hb_set_state(hb_batch* b, unsigned spec, const float* in);
+/* fp64 variants for bit-exact hand-over of oracle/CPU states */
+int hb_get_state_f64(hb_batch* b, unsigned spec, double* out);
+int hb_set_state_f64(hb_batch* b, unsigned spec, const double* in);
+
+/* Env adapter outputs, the 27-DoF analogue of CPUEnv._get_obs/_get_reward (cpu_env.py:465-616):
+ * obs[n_env][nobs] = [hinge qpos (nv-6), hinge qvel (nv-6), root angular velocity (3),
+ * gravity direction in the torso frame (3)]; reward/terminated/truncated may be NULL. */
+int hb_get_obs(hb_batch* b, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated);
+
+/* Per-env status bits (HB_WARN_*), accumulated since the last hb_reset; replaces polling
+ * mjData.warning (mujoco_mpc/mjpc/utilities.cc:787-799 CheckWarnings). */
+int hb_get_status(hb_batch* b, int* status);
+/* Per-env counters of the last step: ncon, nefc, solver iterations (mjData.ncon/nefc/
+ * solver_niter, mjdata.h:196-201) — what testspeed.cc:97-98 accumulates. */
+int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter);
+
+/* Diagnostics of the last step for parity tests (mjData.qacc, efc_force, contact[]; mjdata.h:
+ * 362,376,427): enable once, then read after a step.  efc_force is [n_env][nefc_max];
+ * contact is [n_env][ncon_max][16] = dist, pos[3], frame[9], dim, geom1, geom2. */
+int hb_diag_enable(hb_batch* b, int on);
+int hb_get_qacc(hb_batch* b, float* qacc);
+int hb_get_efc_force(hb_batch* b, float* efc_force);
+int hb_get_contacts(hb_batch* b, float* contact);
+
+const char* hb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HB_H_ */

@@ -10,8 +10,27 @@ FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-result
 
 all: $(LIB) build/hb_compile build/hb_testspeed oracle
 
-$(LIB): $(HOST_SRCS) $(HIP_SRCS) $(HDRS)
-	$(HIPCC) $(FLAGS) -shared -o $@ -x hip $(HOST_SRCS) $(HIP_SRCS)
+# host sources are plain C++ (HIP runtime API only); only the kernels are compiled for the device
+HOSTFLAGS := -O2 -std=c++17 -fPIC -Wall -Wno-unused-result -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
+HOST_OBJS := $(patsubst $(CSRC)/%.cpp,build/obj/%.o,$(HOST_SRCS))
+
+build/obj/%.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p build/obj
+	g++ $(HOSTFLAGS) -c $< -o $@
+
+build/obj/hb_kernels.o: $(HIP_SRCS) $(HDRS)
+	@mkdir -p build/obj
+	$(HIPCC) $(FLAGS) -c -x hip $(HIP_SRCS) -o $@
+
+$(LIB): $(HOST_OBJS) build/obj/hb_kernels.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
+
+# diagnostic build with per-phase cycle stamps (never used for timing or by the product)
+build/libhb_stamps.so: $(HOST_SRCS) $(HIP_SRCS) $(HDRS)
+	@mkdir -p build/obj_stamps
+	for f in $(HOST_SRCS); do g++ $(HOSTFLAGS) -DHB_STAMPS -c $$f -o build/obj_stamps/$$(basename $$f .cpp).o || exit 1; done
+	$(HIPCC) $(FLAGS) -DHB_STAMPS -c -x hip $(HIP_SRCS) -o build/obj_stamps/hb_kernels.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ build/obj_stamps/*.o
 
 build/hb_compile: tools/hb_compile.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp $(HDRS)
 	@mkdir -p build

@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: env-steps/s of the batched mj_step path, 27-DoF humanoid,
+4096 envs per GPU, Halton random actions (BASELINE.json configs[1]).
+
+One "step" = one hb_step_dev launch = one physics step of every env of this rank's batch, with
+state and controls already resident in HBM.  N>1: one process per GPU (torch.distributed over
+RCCL for the barrier and the max-over-ranks reduction only — the path has no data collective;
+envs shard by env_offset = rank * 4096), weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+ALGO_BYTES_PER_ENV_STEP = 748  # fp32 x [read qpos 28 + qvel 27 + warmstart 27 + ctrl 21 + time 1; write 28+27+27+1]
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def shard_range(n_total, world, rank):
+    """Contiguous block partition of env indices: env e lives on rank floor(e*G/N)."""
+    lo = n_total * rank // world
+    hi = n_total * (rank + 1) // world
+    return lo, hi
+
+
+def cpu_baseline(target_seconds=12.0):
+    """The oracle (kind "port") on this box's host cores, on a bounded sample of the same workload.
+    Shape of simulation/mujoco/sample/testspeed.cc:203-210: shared model, a chunk of envs per thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    o = Oracle()
+    t0 = time.perf_counter()
+    n, _, _ = o.rollout_threads(cores * 2, 100, cores)
+    rate = n / (time.perf_counter() - t0)
+    # ~target_seconds of CPU work on the benchmark's own batch size, scaled in steps
+    n_env = max(cores, (ENVS_PER_GPU // cores) * cores)
+    steps = int(max(50, min(1000, rate * target_seconds / n_env)))
+    t0 = time.perf_counter()
+    n, _, st = o.rollout_threads(n_env, steps, cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d steps of the same Halton workload, fp64 oracle/mjstep_oracle.c (CPU restatement, not libmujoco), %d threads, %.1f s"
+                      % (n_env, steps, cores, dt),
+            "mean_nefc": st["mean_nefc"]}
+
+
+def load_traffic():
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (or None)."""
+    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_
+
+    import humanoid_mujoco_amd as hb
+    model = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm"))
+    n_env = args.envs_per_gpu
+    lo, hi = shard_range(n_env * world, world, rank)
+    assert hi - lo == n_env
+    batch = hb.Batch(model, n_env, local_rank)  # raises without a GPU: no CPU fallback
+    K, W = args.steps, args.warmup
+    nu = model.nu
+    # controls for every timed step live in HBM, generated there (testspeed.cc:64-80)
+    ctrl = batch.dev_alloc((K + W) * n_env * nu * 4)
+    batch.halton_ctrl_dev(K + W, 0, lo, ctrl)
+    batch.reset(perturb=True, env_offset=lo)
+    stride = n_env * nu * 4
+
+    def barrier():
+        batch.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for t in range(W):
+        batch.step_dev(ctrl + t * stride)
+    barrier()
+    batch.timer_start()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        batch.step_dev(ctrl + t * stride)
+    kernel_ms = batch.timer_stop()  # HIP events on the launch stream; also drains it
+    batch.sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.barrier()
+
+    status = batch.status()
+    nc, ne, ni = batch.counts()
+    if rank == 0:
+        value = n_env * world * K / elapsed
+        launch_us = 1e3 * kernel_ms / K
+        achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (launch_us * 1e-6) / 1e9
+        traffic = load_traffic()
+        out = {
+            "metric": "env-steps/sec (whole node), 27-DoF humanoid, 4096 envs/GPU",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d parallel humanoid envs per GPU, Halton random actions, fp32, PGS<=50 iters tol 1e-8, dt 0.005, one mj_step per launch"
+                                   % n_env,
+                       "model": "27-DoF humanoid (assets/humanoid27.hbm)", "envs_per_gpu": n_env, "global_envs": n_env * world,
+                       "sharding": "env blocks by rank, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+                         "kernel": "hb_step_kernel", "avg_launch_us": launch_us,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_env,
+                         "note": "path is latency/VALU bound, not HBM bound (SURVEY.md §8d); see DESIGN.md"},
+            "state_check": {"envs_with_warnings": int((status != 0).sum()), "mean_ncon": float(nc.mean()), "mean_nefc": float(ne.mean()),
+                            "mean_pgs_iters": float(ni.mean())},
+        }
+        if traffic:
+            out["roofline"]["traffic_source"] = traffic.get("source")
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    batch.dev_free(ctrl)
+    batch.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

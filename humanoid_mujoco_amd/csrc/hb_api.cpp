@@ -42,11 +42,13 @@ struct DeviceModel {
   float* d_flt = nullptr;
   unsigned long long* d_u64 = nullptr;
   float* d_qpos_src = nullptr;  // qpos0 followed by keyframes, fp32
+  DevModel* d_dm = nullptr;     // device copy of dm (the step kernel reads the tables through it)
   ~DeviceModel() {
     if (d_int) (void)hipFree(d_int);
     if (d_flt) (void)hipFree(d_flt);
     if (d_u64) (void)hipFree(d_u64);
     if (d_qpos_src) (void)hipFree(d_qpos_src);
+    if (d_dm) (void)hipFree(d_dm);
   }
 };
 
@@ -132,29 +134,36 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     int jn = m.dof_jntid[i];
     dof_qposadr[i] = m.jnt_qposadr[jn] + (i - m.jnt_dofadr[jn]);
   }
-  std::vector<int> fac_adr(nv + 1, 0), fac_dst, fac_src, fac_tmp;
+  if (m.nM > 1023) { err = "sparse mass matrix too large for the packed index tables"; return false; }
+  std::vector<int> fac_pack, piv4;
   for (int k = 0; k < nv; k++) {
-    fac_adr[k] = (int)fac_dst.size();
+    int t0 = (int)fac_pack.size();
     int Mki = m.dof_Madr[k] + 1, i = m.dof_parentid[k];
     while (i >= 0) {
       int cnt = nanc[i] + 1;
-      for (int t = 0; t < cnt; t++) { fac_dst.push_back(m.dof_Madr[i] + t); fac_src.push_back(Mki + t); fac_tmp.push_back(Mki); }
+      for (int t = 0; t < cnt; t++) fac_pack.push_back((m.dof_Madr[i] + t) | ((Mki + t) << 10) | (Mki << 20));
       i = m.dof_parentid[i];
       Mki++;
     }
+    piv4.push_back(nanc[k]); piv4.push_back(m.dof_Madr[k]); piv4.push_back(t0); piv4.push_back((int)fac_pack.size());
   }
-  fac_adr[nv] = (int)fac_dst.size();
-  dm.nfac = (int)fac_dst.size();
-  std::vector<int> desc_adr(nv + 1, 0), desc_k, desc_M;
+  dm.nfac = (int)fac_pack.size();
+  std::vector<int> desc_adr(nv + 1, 0), desc_pack;
   for (int i = 0; i < nv; i++) {
-    desc_adr[i] = (int)desc_k.size();
+    desc_adr[i] = (int)desc_pack.size();
     for (int k = i + 1; k < nv; k++) {
       int pos = 1;
       for (int a = m.dof_parentid[k]; a >= 0; a = m.dof_parentid[a], pos++)
-        if (a == i) { desc_k.push_back(k); desc_M.push_back(m.dof_Madr[k] + pos); break; }
+        if (a == i) { desc_pack.push_back(k | ((m.dof_Madr[k] + pos) << 8)); break; }
     }
   }
-  desc_adr[nv] = (int)desc_k.size();
+  desc_adr[nv] = (int)desc_pack.size();
+  std::vector<int> hs_pack;
+  for (int k = nv - 1; k >= 0; k--) {
+    int e = m.dof_Madr[k] + 1;
+    for (int i = m.dof_parentid[k]; i >= 0; i = m.dof_parentid[i], e++) hs_pack.push_back(e | (k << 10) | (i << 16));
+  }
+  dm.nhs = (int)hs_pack.size();
   // pairs
   std::vector<int> pair_dim;
   std::vector<double> pair_fr, pair_solref, pair_solimp, pair_margin, pair_gap;
@@ -222,8 +231,9 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(dof_bodyid, m.dof_bodyid); TI(dof_jntid, m.dof_jntid); TI(dof_parentid, m.dof_parentid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TI(dof_qposadr, dof_qposadr);
   TF(dof_armature, m.dof_armature); TF(dof_damping, m.dof_damping);
   TI(M_i, Mi); TI(M_j, Mj);
-  TI(fac_adr, fac_adr); TI(fac_dst, fac_dst); TI(fac_src, fac_src); TI(fac_tmp, fac_tmp);
-  TI(desc_adr, desc_adr); TI(desc_k, desc_k); TI(desc_M, desc_M);
+  while (T.iv.size() % 4) T.iv.push_back(0);  // int4 alignment of the pivot table
+  size_t o_piv = T.addi(piv4);
+  TI(fac_pack, fac_pack); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(hs_pack, hs_pack);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
   TI(pair_geom1, m.pair_geom1); TI(pair_geom2, m.pair_geom2); TI(pair_dim, pair_dim);
@@ -246,15 +256,19 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
   dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(6 * nv);
   dm.o_qM = take(m.nM); dm.o_qLD = take(m.nM); dm.o_dinv = take(nv); dm.o_dsqrtinv = take(nv); dm.o_smooth = take(nv);
-  dm.o_vec0 = take(nv); dm.o_vec1 = take(nv); dm.o_vec2 = take(nv); dm.o_tenlen = take(std::max(1, m.ntendon));
+  dm.o_vec0 = take(nv); dm.o_vec1 = take(nv); dm.o_vec2 = take(nv); dm.o_tenlen = take(std::max(1, m.ntendon)); dm.o_hdinv = take(nv);
   int region = off;
   dm.o_xpos = take(3 * nb); dm.o_xquat = take(4 * nb); dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
   dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(10 * nb);
   dm.o_cdofdot = take(6 * nv); dm.o_cvel = take(6 * nb); dm.o_cacc = take(6 * nb); dm.o_cfrc = take(6 * nb);
   int endA = off;
   off = region;
-  dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride); dm.o_efc = take(13 * kNefcMax);
-  dm.o_AR = take(kNefcMax * (kNefcMax | 1));
+  dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);
+  // per-row meta (13 slots x kNefcMax) is dead once the row quantities are in registers; the AR
+  // staging buffer (16 x 64 floats), live only between the half-solve and PGS, aliases it, and the
+  // force slot is written after PGS
+  dm.o_efc = take(std::max(13 * kNefcMax, 16 * kGroup));
+  dm.o_stage = dm.o_efc;
   int endB = off;
   // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
   dm.lds_floats = std::max(endA, endB);
@@ -269,11 +283,13 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   for (auto& x : io) *x.p = D.d_int + x.o;
   for (auto& x : fo) *x.p = D.d_flt + x.o;
   dm.body_dofmask = D.d_u64 + o_mask;
+  dm.piv = reinterpret_cast<const int4*>(D.d_int + o_piv);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);
   for (double v : m.key_qpos) qsrc.push_back((float)v);
   if (hipMalloc((void**)&D.d_qpos_src, qsrc.size() * sizeof(float)) != hipSuccess ||
       hipMemcpy(D.d_qpos_src, qsrc.data(), qsrc.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMalloc failed for qpos sources"; return false; }
+  if (hipMalloc((void**)&D.d_dm, sizeof(DevModel)) != hipSuccess || hipMemcpy(D.d_dm, &dm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMalloc failed for the device model"; return false; }
   return true;
 }
 
@@ -292,6 +308,8 @@ struct hb_batch {
   float* d_qpos_out = nullptr;
   size_t qpos_out_cap = 0;
   bool diag = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned long long* d_stamps = nullptr;
 };
 
 namespace {
@@ -314,6 +332,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
   if (b->diag) { P.diag_qacc = b->d_diag_qacc; P.diag_force = b->d_diag_force; P.diag_contact = b->d_diag_contact; }
   P.n_env = b->n_env;
   P.integrate = 1;
+  P.stamps = b->d_stamps;
   return P;
 }
 
@@ -504,6 +523,8 @@ void hb_batch_free(hb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
   void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
                   b->d_status, b->d_counts, b->d_qpos_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -541,7 +562,7 @@ int hb_step_dev(hb_batch* b, const float* ctrl_dev, int n_substeps) {
   HB_HIP(hipSetDevice(b->device));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = ctrl_dev; P.ctrl_mode = 0;
-  HB_HIP(launch_step(b->D.dm, P, n_substeps, b->stream));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, n_substeps, b->stream));
   return HB_OK;
 }
 
@@ -564,7 +585,7 @@ int hb_forward(hb_batch* b, const float* ctrl) {
   else if (n) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * sizeof(float), b->stream));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
-  HB_HIP(launch_step(b->D.dm, P, 1, b->stream));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, 1, b->stream));
   HB_HIP(hipStreamSynchronize(b->stream));
   return HB_OK;
 }
@@ -574,7 +595,7 @@ int hb_rollout_dev(hb_batch* b, const float* ctrl_dev, int T, float* qpos_out_de
   HB_HIP(hipSetDevice(b->device));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = ctrl_dev; P.ctrl_mode = 1; P.qpos_out = qpos_out_dev;
-  HB_HIP(launch_step(b->D.dm, P, T, b->stream));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, T, b->stream));
   return HB_OK;
 }
 
@@ -604,7 +625,7 @@ int hb_rollout_halton(hb_batch* b, int T, int t0, int env_offset, float* qpos_ou
   HB_HIP(hipSetDevice(b->device));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = nullptr; P.ctrl_mode = 2; P.t0 = t0; P.env_offset = env_offset; P.qpos_out = qpos_out_dev;
-  HB_HIP(launch_step(b->D.dm, P, T, b->stream));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, T, b->stream));
   return HB_OK;
 }
 
@@ -679,5 +700,70 @@ static int copy_out(hb_batch* b, float* out, const float* dev, size_t n) {
 int hb_get_qacc(hb_batch* b, float* qacc) { return copy_out(b, qacc, b ? b->d_diag_qacc : nullptr, b ? (size_t)b->n_env * b->D.dm.nv : 0); }
 int hb_get_efc_force(hb_batch* b, float* f) { return copy_out(b, f, b ? b->d_diag_force : nullptr, b ? (size_t)b->n_env * kNefcMax : 0); }
 int hb_get_contacts(hb_batch* b, float* c) { return copy_out(b, c, b ? b->d_diag_contact : nullptr, b ? (size_t)b->n_env * kNconMax * kDiagConStride : 0); }
+
+void* hb_dev_alloc(hb_batch* b, uint64_t bytes) {
+  if (!b || hipSetDevice(b->device) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  return p;
+}
+void hb_dev_free(hb_batch* b, void* p) {
+  if (!b || !p) return;
+  (void)hipSetDevice(b->device);
+  (void)hipStreamSynchronize(b->stream);
+  (void)hipFree(p);
+}
+int hb_memcpy_h2d(hb_batch* b, void* dst_dev, const void* src, uint64_t bytes) {
+  if (!b || !dst_dev || !src) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, b->stream));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+int hb_memcpy_d2h(hb_batch* b, void* dst, const void* src_dev, uint64_t bytes) {
+  if (!b || !dst || !src_dev) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, b->stream));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+int hb_halton_ctrl_dev(hb_batch* b, int T, int t0, int env_offset, float* out_dev) {
+  if (!b || T < 1 || !out_dev) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(launch_halton_ctrl(out_dev, T, b->n_env, b->D.dm.nu, t0, env_offset, b->stream));
+  return HB_OK;
+}
+int hb_get_stamps(hb_batch* b, unsigned long long* out) {
+#ifdef HB_STAMPS
+  if (!b || !out) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  if (!b->d_stamps) {
+    if (hipMalloc((void**)&b->d_stamps, (size_t)b->n_env * 16 * sizeof(unsigned long long)) != hipSuccess) return HB_ENOMEM;
+    HB_HIP(hipMemset(b->d_stamps, 0, (size_t)b->n_env * 16 * sizeof(unsigned long long)));
+    return HB_OK;  // first call arms the stamps; call again after a step to read them
+  }
+  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipMemcpy(out, b->d_stamps, (size_t)b->n_env * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return HB_OK;
+#else
+  (void)b; (void)out;
+  return HB_EUNSUPPORTED;
+#endif
+}
+int hb_timer_start(hb_batch* b) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  if (!b->ev0) { HB_HIP(hipEventCreate(&b->ev0)); HB_HIP(hipEventCreate(&b->ev1)); }
+  HB_HIP(hipEventRecord(b->ev0, b->stream));
+  return HB_OK;
+}
+int hb_timer_stop(hb_batch* b, float* elapsed_ms) {
+  if (!b || !elapsed_ms || !b->ev0) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipEventRecord(b->ev1, b->stream));
+  HB_HIP(hipEventSynchronize(b->ev1));
+  HB_HIP(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+  return HB_OK;
+}
 
 }  // extern "C"

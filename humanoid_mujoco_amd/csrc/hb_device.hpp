@@ -7,6 +7,16 @@
 // scalar cache.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
+
+// Model tables are immutable for the lifetime of a batch: device code addresses them through the
+// constant address space so that wave-uniform reads become scalar (s_load) instructions served by
+// the scalar cache, even though the kernel also writes global memory.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HB_CONST __attribute__((address_space(4)))
+#else
+#define HB_CONST
+#endif
 
 namespace hb {
 
@@ -28,45 +38,50 @@ struct DevModel {
   float timestep, gravity[3], inv_sqrt_impratio, tolerance, pgs_scale;
   int iterations, disableflags;
   // body tables
-  const int *body_parentid, *body_treeid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_childadr, *body_childnum, *child_list;
-  const int *level_adr, *level_num, *level_body;
-  const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *tree_invmass;
-  const unsigned long long* body_dofmask;  // bit d set: dof d moves this body
+  const int HB_CONST *body_parentid, *body_treeid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_childadr, *body_childnum, *child_list;
+  const int HB_CONST *level_adr, *level_num, *level_body;
+  const float HB_CONST *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *tree_invmass;
+  const unsigned long long HB_CONST* body_dofmask;  // bit d set: dof d moves this body
   // joint tables
-  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
-  const float *jnt_pos, *jnt_axis, *jnt_stiffness, *qpos0, *qpos_spring;
+  const int HB_CONST *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
+  const float HB_CONST *jnt_pos, *jnt_axis, *jnt_stiffness, *qpos0, *qpos_spring;
   // dof tables
-  const int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_nanc, *dof_qposadr;
-  const float *dof_armature, *dof_damping;
-  const int *M_i, *M_j;                                  // dof pair of each sparse mass-matrix entry
-  const int *fac_adr, *fac_dst, *fac_src, *fac_tmp;      // L^T D L update triples per pivot dof
-  const int *desc_adr, *desc_k, *desc_M;                 // descendants of each dof: (k, address of L[k,i])
+  const int HB_CONST *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_nanc, *dof_qposadr;
+  const float HB_CONST *dof_armature, *dof_damping;
+  const int HB_CONST *M_i, *M_j;                                  // dof pair of each sparse mass-matrix entry
+  const int4 HB_CONST* piv;                                       // per pivot dof: {#strict ancestors, Madr, first triple, end triple}
+  const int HB_CONST* fac_pack;                                   // L^T D L update triples: dst | src << 10 | tmp << 20
+  const int HB_CONST *desc_adr, *desc_pack;                       // descendants of each dof: k | address of L[k,i] << 8
+  const int HB_CONST* hs_pack;                                    // half-solve schedule: e | k << 10 | i << 16, pivots descending
+  int nhs;
   // geoms
-  const int *geom_type, *geom_bodyid;
-  const float *geom_size, *geom_pos, *geom_quat, *geom_rbound;
+  const int HB_CONST *geom_type, *geom_bodyid;
+  const float HB_CONST *geom_size, *geom_pos, *geom_quat, *geom_rbound;
   // collision candidates with pre-mixed contact parameters
-  const int *pair_geom1, *pair_geom2, *pair_dim;
-  const float *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
+  const int HB_CONST *pair_geom1, *pair_geom2, *pair_dim;
+  const float HB_CONST *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
   // limit candidates: 2 per limited joint/tendon in constraint order (lower, upper)
-  const int *lim_kind, *lim_id, *lim_side;  // kind 0 = joint, 1 = tendon
-  const float *lim_range, *lim_margin, *lim_solref, *lim_solimp, *lim_invweight;
+  const int HB_CONST *lim_kind, *lim_id, *lim_side;  // kind 0 = joint, 1 = tendon
+  const float HB_CONST *lim_range, *lim_margin, *lim_solref, *lim_solimp, *lim_invweight;
   // tendons (fixed)
-  const int *tendon_adr, *tendon_num, *wrap_dofadr, *wrap_qposadr;
-  const float* wrap_prm;
+  const int HB_CONST *tendon_adr, *tendon_num, *wrap_dofadr, *wrap_qposadr;
+  const float HB_CONST* wrap_prm;
   // actuators
-  const int *act_qposadr, *act_dofadr, *act_ctrllimited, *act_forcelimited;
-  const float *act_gear, *act_ctrlrange, *act_forcerange, *act_gain, *act_bias;
+  const int HB_CONST *act_qposadr, *act_dofadr, *act_ctrllimited, *act_forcelimited;
+  const float HB_CONST *act_gear, *act_ctrlrange, *act_forcerange, *act_gain, *act_bias;
   // env adapter
   int obs_root_body, obs_root_dofadr;
   // LDS layout (float offsets per env) — persistent region
-  int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qM, o_qLD, o_dinv, o_dsqrtinv, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
+  int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qM, o_qLD, o_dinv, o_dsqrtinv, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen, o_hdinv;
   // region A (dynamics scratch)
   int o_xpos, o_xquat, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cdofdot, o_cvel, o_cacc, o_cfrc;
   // region B (constraints), aliases region A
-  int o_con, o_C, o_efc, o_AR;
+  int o_con, o_C, o_efc, o_stage;
   int lds_floats;  // total floats per env
   int cstride;     // row stride of C (odd, >= nv+1; column nv holds the extra right-hand side)
 };
+
+typedef const DevModel HB_CONST& DevModelRef;
 
 struct BatchPtrs {
   float* state;        // [n_env][nstate]
@@ -82,6 +97,7 @@ struct BatchPtrs {
   int ctrl_mode;       // 0: ctrl[e][nu] held for all steps; 1: ctrl[t][e][nu]; 2: on-device Halton
   int t0, env_offset;  // Halton indexing
   int integrate;       // 1: mj_step, 0: mj_forward only
+  unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
 };
 
 }  // namespace hb

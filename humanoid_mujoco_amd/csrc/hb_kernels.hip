@@ -20,6 +20,13 @@
 
 namespace hb {
 
+// Diagnostic build only (-DHB_STAMPS): per-phase cycle stamps of the last step, written to
+// BatchPtrs::diag_contact's tail is NOT used; stamps go to their own buffer P.stamps.
+#ifdef HB_STAMPS
+#define HB_STAMP(i) do { if (lane == 0 && P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps_[i] = t_; } } while (0)
+#else
+#define HB_STAMP(i) do {} while (0)
+#endif
 #define HB_MINVAL 1e-15f
 #define HB_MAXVAL 1e10f
 #define HB_MINIMP 0.0001f
@@ -29,9 +36,9 @@ namespace hb {
 // instructions execute in issue order, so no s_barrier is needed; the fences stop the compiler
 // from moving LDS accesses across this point.
 __device__ __forceinline__ void gsync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 __device__ __forceinline__ float rdlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
@@ -40,10 +47,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
+// value known to be identical in every lane -> tell the compiler (scalar register, scalar branches)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniformf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ V3 ld3(const float HB_CONST* p) { return {p[0], p[1], p[2]}; }
+#endif
 __device__ __forceinline__ void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -60,6 +73,9 @@ __device__ __forceinline__ V3 normalized(V3 v, float* n_out = nullptr) {
 
 struct Q4 { float w, x, y, z; };
 __device__ __forceinline__ Q4 ldq(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ Q4 ldq(const float HB_CONST* p) { return {p[0], p[1], p[2], p[3]}; }
+#endif
 __device__ __forceinline__ void stq(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
 __device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
   return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
@@ -152,7 +168,7 @@ __device__ __forceinline__ bool sphere_sphere(ConOut& c, float margin, V3 p1, fl
   c.n = n;
   return true;
 }
-__device__ __forceinline__ int capsule_capsule(ConOut* c, float margin, V3 pos1, V3 axis1, float r1, float len1, V3 pos2, V3 axis2, float r2, float len2) {
+__device__ __forceinline__ int capsule_capsule(ConOut& c0, ConOut& c1, float margin, V3 pos1, V3 axis1, float r1, float len1, V3 pos2, V3 axis2, float r2, float len2) {
   V3 dif = pos1 - pos2;
   float ma = dot(axis1, axis1), mb = -dot(axis1, axis2), mc = dot(axis2, axis2);
   float u = -dot(axis1, dif), v = dot(axis2, dif);
@@ -163,19 +179,24 @@ __device__ __forceinline__ int capsule_capsule(ConOut* c, float margin, V3 pos1,
     else if (x1 < -len1) { x1 = -len1; x2 = (v + mb * len1) / mc; }
     if (x2 > len2) { x2 = len2; x1 = clampf((u - mb * len2) / ma, -len1, len1); }
     else if (x2 < -len2) { x2 = -len2; x1 = clampf((u + mb * len2) / ma, -len1, len1); }
-    return sphere_sphere(c[0], margin, pos1 + axis1 * x1, r1, pos2 + axis2 * x2, r2) ? 1 : 0;
+    return sphere_sphere(c0, margin, pos1 + axis1 * x1, r1, pos2 + axis2 * x2, r2) ? 1 : 0;
   }
-  int n = 0;
+  // parallel axes: up to two contacts from the segment ends (first two hits in this order)
+  ConOut t0, t1, t2, t3;
   float x2 = clampf((v - mb * len1) / mc, -len2, len2);
-  n += sphere_sphere(c[n], margin, pos1 + axis1 * len1, r1, pos2 + axis2 * x2, r2) ? 1 : 0;
+  const bool h0 = sphere_sphere(t0, margin, pos1 + axis1 * len1, r1, pos2 + axis2 * x2, r2);
   x2 = clampf((v + mb * len1) / mc, -len2, len2);
-  n += sphere_sphere(c[n], margin, pos1 - axis1 * len1, r1, pos2 + axis2 * x2, r2) ? 1 : 0;
-  if (n >= 2) return n;
+  const bool h1 = sphere_sphere(t1, margin, pos1 - axis1 * len1, r1, pos2 + axis2 * x2, r2);
   float x1 = clampf((u - mb * len2) / ma, -len1, len1);
-  n += sphere_sphere(c[n], margin, pos1 + axis1 * x1, r1, pos2 + axis2 * len2, r2) ? 1 : 0;
-  if (n >= 2) return n;
+  const bool h2 = sphere_sphere(t2, margin, pos1 + axis1 * x1, r1, pos2 + axis2 * len2, r2);
   x1 = clampf((u + mb * len2) / ma, -len1, len1);
-  n += sphere_sphere(c[n], margin, pos1 + axis1 * x1, r1, pos2 - axis2 * len2, r2) ? 1 : 0;
+  const bool h3 = sphere_sphere(t3, margin, pos1 + axis1 * x1, r1, pos2 - axis2 * len2, r2);
+  // first two hits in order
+  int n = 0;
+  if (h0) { c0 = t0; n = 1; }
+  if (h1) { if (n == 0) c0 = t1; else c1 = t1; n++; }
+  if (h2 && n < 2) { if (n == 0) c0 = t2; else c1 = t2; n++; }
+  if (h3 && n < 2) { if (n == 0) c0 = t3; else c1 = t3; n++; }
   return n;
 }
 
@@ -205,61 +226,78 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   return d0 + y * (d1 - d0);
 }
 
-// L^T D L factorisation of the sparse mass matrix held in LD (LDS), lanes = update triples.
-__device__ __forceinline__ void factor_ld(const DevModel& M, float* LD, float* dinv, float* dsqrtinv, int lane) {
+// L^T D L factorisation of the sparse matrices held in LD and (optionally) LD2 (LDS), lanes =
+// update triples of one pivot dof.  M and H = M + h*diag(damping) share their sparsity, so both
+// are factorised in lockstep: same index traffic, twice the independent arithmetic per lane.
+template <bool TWO>
+__device__ __forceinline__ void factor_ld(DevModelRef M, float* LD, float* dinv, float* dsqrtinv, float* LD2, float* dinv2, int lane) {
   for (int k = M.nv - 1; k >= 0; k--) {
-    int nanc = M.dof_nanc[k];
+    const int4 pv = M.piv[k];  // nanc, Madr, t0, t1
+    const int nanc = pv.x;
     if (nanc == 0) continue;
-    int Mkk = M.dof_Madr[k];
-    float dkk = fmaxf(LD[Mkk], HB_MINVAL);
-    float inv = 1.f / dkk;
-    int t0 = M.fac_adr[k], t1 = M.fac_adr[k + 1];
-    for (int t = t0 + lane; t < t1; t += kGroup) {
-      int dst = M.fac_dst[t], src = M.fac_src[t], ti = M.fac_tmp[t];
+    const int Mkk = pv.y;
+    const float inv = 1.f / fmaxf(LD[Mkk], HB_MINVAL);
+    float inv2 = 0.f;
+    if (TWO) inv2 = 1.f / fmaxf(LD2[Mkk], HB_MINVAL);
+    for (int t = pv.z + lane; t < pv.w; t += kGroup) {
+      const int pk = M.fac_pack[t];
+      const int dst = pk & 1023, src = (pk >> 10) & 1023, ti = pk >> 20;
       LD[dst] -= LD[src] * (LD[ti] * inv);
+      if (TWO) LD2[dst] -= LD2[src] * (LD2[ti] * inv2);
     }
     gsync();
-    for (int a = lane; a < nanc; a += kGroup) LD[Mkk + 1 + a] *= inv;
+    for (int a = lane; a < nanc; a += kGroup) {
+      LD[Mkk + 1 + a] *= inv;
+      if (TWO) LD2[Mkk + 1 + a] *= inv2;
+    }
     gsync();
   }
   for (int i = lane; i < M.nv; i += kGroup) {
-    float d = fmaxf(LD[M.dof_Madr[i]], HB_MINVAL);
+    const int a = M.dof_Madr[i];
+    float d = fmaxf(LD[a], HB_MINVAL);
     dinv[i] = 1.f / d;
     dsqrtinv[i] = rsqrtf(d);
+    if (TWO) dinv2[i] = 1.f / fmaxf(LD2[a], HB_MINVAL);
   }
   gsync();
 }
 
 // x <- L^-T x (single vector in LDS): pivots descending, push to ancestors
-__device__ __forceinline__ void solve_lt_push(const DevModel& M, const float* LD, float* x, int lane) {
+__device__ __forceinline__ void solve_lt_push(DevModelRef M, const float* LD, float* x, int lane) {
   for (int k = M.nv - 1; k >= 0; k--) {
-    int nanc = M.dof_nanc[k];
+    const int4 pv = M.piv[k];
+    const int nanc = pv.x;
     if (nanc == 0) continue;
-    int Mkk = M.dof_Madr[k];
-    float xk = x[k];
+    const int Mkk = pv.y;
+    const float xk = x[k];
     if (lane < nanc) {
-      // a-th ancestor of k: walk the parent chain (uniform, short)
-      int i = M.dof_parentid[k];
-      for (int a = 0; a < lane; a++) i = M.dof_parentid[i];
+      const int i = M.M_j[Mkk + 1 + lane];  // the lane-th ancestor of k
       x[i] -= LD[Mkk + 1 + lane] * xk;
     }
     gsync();
   }
 }
 // x <- L^-1 x (single vector in LDS): dofs ascending, push to descendants
-__device__ __forceinline__ void solve_l_push(const DevModel& M, const float* LD, float* x, int lane) {
+__device__ __forceinline__ void solve_l_push(DevModelRef M, const float* LD, float* x, int lane) {
   for (int i = 0; i < M.nv; i++) {
-    int t0 = M.desc_adr[i], t1 = M.desc_adr[i + 1];
+    const int t0 = M.desc_adr[i], t1 = M.desc_adr[i + 1];
     if (t0 == t1) continue;
-    float xi = x[i];
-    for (int t = t0 + lane; t < t1; t += kGroup) x[M.desc_k[t]] -= LD[M.desc_M[t]] * xi;
+    const float xi = x[i];
+    for (int t = t0 + lane; t < t1; t += kGroup) {
+      const int pk = M.desc_pack[t];  // k | address of L[k,i] << 8
+      x[pk & 255] -= LD[pk >> 8] * xi;
+    }
     gsync();
   }
 }
 
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const BatchPtrs P, int nsteps) {
+__global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) {
+  // the model tables are read through a constant-address-space pointer (not by-value kernel
+  // arguments): the ~100 table pointers and every wave-uniform table entry are fetched on demand by
+  // scalar loads through the scalar cache instead of living in (and spilling from) SGPRs
+  DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   const int env = blockIdx.x;
@@ -274,7 +312,8 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
   float* s_gaxis = lds + M.o_gaxis;
   float* s_scom = lds + M.o_scom;
   float* s_cdof = lds + M.o_cdof;
-  float* s_qM = lds + M.o_qM;
+  float* s_qH = lds + M.o_qM;    // H = M + h*diag(damping), factorised in place
+  float* s_hdinv = lds + M.o_hdinv;
   float* s_qLD = lds + M.o_qLD;
   float* s_dinv = lds + M.o_dinv;
   float* s_dsqrtinv = lds + M.o_dsqrtinv;
@@ -298,8 +337,8 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
   float* s_con = lds + M.o_con;
   float* s_C = lds + M.o_C;
   float* s_efc = lds + M.o_efc;  // per-row meta, stride kNefcMax
-  float* s_AR = lds + M.o_AR;
-  constexpr int ARS = kNefcMax | 1;  // odd row stride of AR
+  float* s_stage = lds + M.o_stage;  // 16 x 64 staging buffer of the AR build
+  constexpr int kCs = 33;            // row stride of C (odd: conflict-free lane-strided access; column 32 is zero padding)
   static_assert(kNefcMax == kGroup - 1, "row kNefcMax of C is handled by the last lane");
   // per-row meta slots
   enum { E_POS = 0, E_MARGIN, E_SOLREF0, E_SOLREF1, E_IMP0, E_IMP1, E_IMP2, E_IMP3, E_IMP4, E_DA, E_DAFIRST, E_MU2, E_FORCE, E_NSLOT };
@@ -309,9 +348,20 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
   for (int i = lane; i < nq; i += kGroup) s_qpos[i] = gstate[1 + i];
   for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = gstate[1 + nq + i]; s_warm[i] = gstate[1 + nq + nv + i]; }
   int status = 0;
+  bool eulerdamp = false;
+  if (!(M.disableflags & (1 << 14))) {
+    bool d = false;
+    for (int i = lane; i < nv; i += kGroup) d |= M.dof_damping[i] > 0.f;
+    eulerdamp = __any(d);
+  }
+#ifdef HB_STAMPS
+  unsigned long long stamps_[16] = {0};
+#endif
   gsync();
 
   for (int step = 0; step < nsteps; step++) {
+    asm volatile("" ::: "memory");  // keep model-table loads inside the step (no hoisting out of the rollout loop)
+    HB_STAMP(0);
     // ---------------------------------------------------------------- controls
     if (P.ctrl_mode == 2) {
       int idx = 1 + P.t0 + step + 1000 * (P.env_offset + env);
@@ -335,6 +385,7 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
     }
     gsync();
 
+    HB_STAMP(1);
     // ---------------------------------------------------------------- mj_kinematics
     if (lane == 0) {
       st3(s_xpos, {0.f, 0.f, 0.f}); stq(s_xquat, {1.f, 0.f, 0.f, 0.f}); st3(s_xipos, {0.f, 0.f, 0.f});
@@ -383,6 +434,7 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
       }
       gsync();
     }
+    HB_STAMP(2);
     // geoms: world position and z axis
     for (int g = lane; g < M.ngeom; g += kGroup) {
       int b = M.geom_bodyid[g];
@@ -445,6 +497,7 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
       s_tenlen[t] = len;
     }
     gsync();
+    HB_STAMP(3);
     // ---------------------------------------------------------------- mj_crb
     for (int i = lane; i < 10 * nb; i += kGroup) s_crb[i] = s_cinert[i];
     gsync();
@@ -469,13 +522,17 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
       float s = 0.f;
       for (int t = 0; t < 6; t++) s += s_cdof[6 * j + t] * buf[t];
       if (i == j) s += M.dof_armature[i];
-      s_qM[e] = s;
       s_qLD[e] = s;
+      // H = M + h diag(damping): matrix of the implicit-damping Euler solve (mj_Euler), factorised alongside M
+      s_qH[e] = (i == j) ? s + M.timestep * M.dof_damping[i] : s;
     }
     gsync();
+    HB_STAMP(4);
     // ---------------------------------------------------------------- mj_factorM
-    factor_ld(M, s_qLD, s_dinv, s_dsqrtinv, lane);
+    if (eulerdamp) factor_ld<true>(M, s_qLD, s_dinv, s_dsqrtinv, s_qH, s_hdinv, lane);
+    else factor_ld<false>(M, s_qLD, s_dinv, s_dsqrtinv, nullptr, nullptr, lane);
 
+    HB_STAMP(5);
     // ---------------------------------------------------------------- mj_comVel + mj_rne forward pass
     if (lane < 6) {
       s_cvel[lane] = 0.f;
@@ -538,6 +595,7 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
       }
       gsync();
     }
+    HB_STAMP(6);
     // ---------------------------------------------------------------- qfrc_bias, mj_passive, mj_fwdActuation -> qfrc_smooth
     for (int d = lane; d < nv; d += kGroup) {
       float bias = 0.f;
@@ -584,13 +642,14 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
     }
 
     // ================================================================ region B from here on (aliases the dynamics scratch)
+    HB_STAMP(7);
     // ---------------------------------------------------------------- mj_collision
     int ncon = 0;
     const bool contacts_on = !(M.disableflags & ((1 << 0) | (1 << 4)));
     if (contacts_on) {
       for (int p0 = 0; p0 < M.npair; p0 += kGroup) {
         int p = p0 + lane;
-        ConOut co[2];
+        ConOut co0, co1;
         int n = 0;
         V3 hint = {0.f, 0.f, 0.f};
         float margin = 0.f;
@@ -603,11 +662,14 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
           if (t1 == 0) {
             V3 normal = ld3(s_gaxis + 3 * g1);
             if (dot(pos2 - pos1, normal) <= margin + M.geom_rbound[g2]) {
-              if (t2 == 2) n = plane_sphere(co[0], margin, pos1, normal, pos2, r2) ? 1 : 0;
+              if (t2 == 2) n = plane_sphere(co0, margin, pos1, normal, pos2, r2) ? 1 : 0;
               else {
-                int n1 = plane_sphere(co[0], margin, pos1, normal, pos2 + ax2 * l2, r2) ? 1 : 0;
-                int n2 = plane_sphere(co[n1], margin, pos1, normal, pos2 - ax2 * l2, r2) ? 1 : 0;
-                n = n1 + n2;
+                ConOut ca, cb;
+                const bool h1 = plane_sphere(ca, margin, pos1, normal, pos2 + ax2 * l2, r2);
+                const bool h2 = plane_sphere(cb, margin, pos1, normal, pos2 - ax2 * l2, r2);
+                co0 = h1 ? ca : cb;
+                co1 = cb;
+                n = (h1 ? 1 : 0) + (h2 ? 1 : 0);
                 hint = ax2;
               }
             }
@@ -616,12 +678,12 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
             float bound = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
             if (dot(dp, dp) <= bound * bound) {
               float r1 = M.geom_size[3 * g1], l1 = M.geom_size[3 * g1 + 1];
-              if (t1 == 2 && t2 == 2) n = sphere_sphere(co[0], margin, pos1, r1, pos2, r2) ? 1 : 0;
+              if (t1 == 2 && t2 == 2) n = sphere_sphere(co0, margin, pos1, r1, pos2, r2) ? 1 : 0;
               else if (t1 == 2) {
                 float x = clampf(dot(ax2, pos1 - pos2), -l2, l2);
-                n = sphere_sphere(co[0], margin, pos1, r1, pos2 + ax2 * x, r2) ? 1 : 0;
+                n = sphere_sphere(co0, margin, pos1, r1, pos2 + ax2 * x, r2) ? 1 : 0;
               } else {
-                n = capsule_capsule(co, margin, pos1, ld3(s_gaxis + 3 * g1), r1, l1, pos2, ax2, r2, l2);
+                n = capsule_capsule(co0, co1, margin, pos1, ld3(s_gaxis + 3 * g1), r1, l1, pos2, ax2, r2, l2);
               }
             }
           }
@@ -630,22 +692,28 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
         unsigned long long b1 = __ballot(n >= 1), b2 = __ballot(n >= 2);
         unsigned long long lt = (1ull << lane) - 1ull;
         int slot = ncon + __popcll(b1 & lt) + __popcll(b2 & lt);
-        for (int k = 0; k < n; k++) {
-          int s = slot + k;
-          if (s < kNconMax) {
-            float* c = s_con + s * kConStride;
-            c[C_DIST] = co[k].dist;
-            st3(c + C_POS, co[k].pos);
-            make_frame(c + C_FRAME, co[k].n, hint);
-            c[C_PAIR] = __int_as_float(p);
-          }
+        if (n >= 1 && slot < kNconMax) {
+          float* c = s_con + slot * kConStride;
+          c[C_DIST] = co0.dist;
+          st3(c + C_POS, co0.pos);
+          make_frame(c + C_FRAME, co0.n, hint);
+          c[C_PAIR] = __int_as_float(p);
+        }
+        if (n >= 2 && slot + 1 < kNconMax) {
+          float* c = s_con + (slot + 1) * kConStride;
+          c[C_DIST] = co1.dist;
+          st3(c + C_POS, co1.pos);
+          make_frame(c + C_FRAME, co1.n, hint);
+          c[C_PAIR] = __int_as_float(p);
         }
         ncon += __popcll(b1) + __popcll(b2);
       }
       if (ncon > kNconMax) { status |= (1 << 1); ncon = kNconMax; }
     }
+    ncon = uniform(ncon);
     gsync();
 
+    HB_STAMP(8);
     // ---------------------------------------------------------------- mj_makeConstraint
     int nefc = 0;
     const bool constraints_on = !(M.disableflags & (1 << 0));
@@ -707,7 +775,7 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
       int endrow = (lane < ncon && incl && fits) ? base + myrows : nefc;
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) endrow = max(endrow, __shfl_xor(endrow, m, kGroup));
-      const int nefc_after = endrow;
+      const int nefc_after = uniform(endrow);
       gsync();
       // Jacobian rows: uniform loop over contacts, lanes over dofs
       for (int ci = 0; ci < ncon; ci++) {
@@ -756,10 +824,12 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
       }
       nefc = nefc_after;
     }
+    nefc = uniform(nefc);
     // extra right-hand side: row kNefcMax of C holds qfrc_smooth (half-solved below into y)
     for (int d = lane; d < cs; d += kGroup) s_C[kNefcMax * cs + d] = d < nv ? s_smooth[d] : 0.f;
     gsync();
 
+    HB_STAMP(9);
     // ---------------------------------------------------------------- per-row quantities (lane = row)
     const bool rowact = lane < nefc;
     float R = 1.f, Dd = 1.f, aref = 0.f, jw = 0.f, force = 0.f, bvec = 0.f;
@@ -787,72 +857,119 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
       aref = -Bc * vel - K * imp * (pos - margin);
     }
     gsync();
+    HB_STAMP(10);
     // ---------------------------------------------------------------- half solve: C_i = D^-1/2 L^-T J_i (mj_solveM2), rows and the extra RHS together
     {
       const bool solverow = rowact || lane == kGroup - 1;
       float* x = s_C + lane * cs;  // lane 63 owns row kNefcMax == 63 (the extra right-hand side)
       if (solverow) {
-        for (int k = nv - 1; k >= 0; k--) {
-          int nanc = M.dof_nanc[k];
-          if (nanc == 0) continue;
-          float xk = x[k];
-          int Mki = M.dof_Madr[k] + 1, i = M.dof_parentid[k];
-          for (int a = 0; a < nanc; a++) { x[i] -= s_qLD[Mki + a] * xk; i = M.dof_parentid[i]; }
+        // off-diagonal entries of L in pivot-descending order: x[i] -= L[k,i] * x[k]
+        for (int t = 0; t < M.nhs; t++) {
+          const int pk = M.hs_pack[t];  // e | k << 10 | i << 16
+          x[pk >> 16] -= s_qLD[pk & 1023] * x[(pk >> 10) & 63];
         }
         for (int k = 0; k < nv; k++) x[k] *= s_dsqrtinv[k];
       }
     }
     gsync();
+    HB_STAMP(11);
     // ---------------------------------------------------------------- efc_b, AR = C C^T + diag(R) (mj_projectConstraint)
     const float* yv = s_C + kNefcMax * cs;
-    if (rowact) {
+    // AR lives in registers: lane j holds ar[i] = AR[i][j] (= AR[j][i]) for every row i.  It is
+    // produced 16 rows at a time through a small LDS staging buffer so that the row loop can stay
+    // a run-time loop while the register indices stay compile-time constants.
+    float ar[kNefcMax];
+    float Aii = 1.f;
+    {
+      float cj[kCs];
       const float* Cr = s_C + lane * cs;
-      float jas = 0.f;
-      for (int k = 0; k < nv; k++) jas += Cr[k] * yv[k];
+#pragma unroll
+      for (int k = 0; k < kCs; k++) cj[k] = rowact ? Cr[k] : 0.f;
+      float jas = 0.f, diag = 0.f;
+#pragma unroll
+      for (int k = 0; k < kCs; k++) { jas += cj[k] * yv[k]; diag += cj[k] * cj[k]; }
       bvec = jas - aref;
-      for (int j = 0; j < nefc; j++) {
-        const float* Cj = s_C + j * cs;
-        float s = 0.f;
-        for (int k = 0; k < nv; k++) s += Cr[k] * Cj[k];
-        if (j == lane) s += R;
-        s_AR[lane * ARS + j] = s;
+      Aii = rowact ? diag + R : 1.f;
+      float* stage = s_stage + lane;
+#pragma unroll
+      for (int c = 0; c < (kNefcMax + 15) / 16; c++) {
+        if (c * 16 < nefc) {
+          const int iend = min(nefc, c * 16 + 16);
+          for (int i = c * 16; i < iend; i++) {
+            const float* Ci = s_C + i * cs;
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < kCs - 1; k++) sacc += cj[k] * Ci[k];
+            stage[(i - c * 16) * kGroup] = (i == lane) ? sacc + R : sacc;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            if (c * 16 + r < kNefcMax) ar[c * 16 + r] = (c * 16 + r < nefc) ? stage[r * kGroup] : 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            if (c * 16 + r < kNefcMax) ar[c * 16 + r] = 0.f;
+        }
       }
     }
-    gsync();
+    HB_STAMP(12);
     // ---------------------------------------------------------------- mj_fwdConstraint: warm start + PGS
     int niter = 0;
     if (nefc > 0) {
-      float Aii = rowact ? s_AR[lane * ARS + lane] : 1.f;
+      const float Ainv = 1.f / Aii;
       if (!(M.disableflags & (1 << 8))) {
         float jar = jw - aref;
         force = (rowact && jar < 0.f) ? -Dd * jar : 0.f;
         // cost(f) = 0.5 f'AR f + f'b; keep the warm start only if it beats zero
         float arf = 0.f;
-        for (int j = 0; j < nefc; j++) arf += s_AR[j * ARS + lane] * rdlane(force, j);
-        float cost = wave_sum(rowact ? force * (0.5f * arf + bvec) : 0.f);
+#pragma unroll
+        for (int j = 0; j < kNefcMax; j++)
+          if (j < nefc) arf += ar[j] * rdlane(force, j);
+        const float cost = uniformf(wave_sum(rowact ? force * (0.5f * arf + bvec) : 0.f));
         if (cost > 0.f) force = 0.f;
       }
       float res = bvec;
-      for (int j = 0; j < nefc; j++) res += s_AR[j * ARS + lane] * rdlane(force, j);
+#pragma unroll
+      for (int j = 0; j < kNefcMax; j++)
+        if (j < nefc) res += ar[j] * rdlane(force, j);
       if (!rowact) res = 0.f;
+      // Gauss-Seidel sweeps.  Every lane proposes the update of its own row from its current
+      // residual; the proposal of lane i is the valid one when row i's turn comes, and its delta is
+      // broadcast so that all residuals follow (column form of the reference's row update).
+      // The row loop is unrolled (ar[i] must be a compile-time register index) in 8-row chunks with
+      // scalar guards; nefc and the lane id are re-materialised every sweep so that the 63 guard
+      // conditions are cheap scalar compares instead of hoisted, spilled masks.
       while (niter < M.iterations) {
-        float improvement = 0.f;
-        for (int i = 0; i < nefc; i++) {
-          float ri = rdlane(res, i), fi = rdlane(force, i), aii = rdlane(Aii, i);
-          float fnew = fmaxf(0.f, fi - ri / aii);
-          float delta = fnew - fi;
-          float change = 0.5f * delta * delta * aii + delta * ri;
-          if (change > 1e-10f) { delta = 0.f; change = 0.f; }
-          improvement -= change;
-          res += s_AR[i * ARS + lane] * delta;
-          if (lane == i) force += delta;
+        int ne, ln;
+        asm volatile("s_mov_b32 %0, %1" : "=s"(ne) : "s"(nefc));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
+        float improvement = 0.f;  // identical in every lane
+#pragma unroll
+        for (int c = 0; c < (kNefcMax + 7) / 8; c++) {
+          if (c * 8 < ne) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+              const int i = c * 8 + r;
+              if (i < kNefcMax && i < ne) {
+                float fnew = fmaxf(0.f, force - res * Ainv);
+                float delta = fnew - force;
+                float change = delta * (0.5f * delta * Aii + res);
+                if (change > 1e-10f) { delta = 0.f; change = 0.f; }
+                const float di = rdlane(delta, i);
+                improvement -= rdlane(change, i);
+                if (ln == i) force += delta;
+                res += ar[i] * di;
+              }
+            }
+          }
         }
         niter++;
-        if (improvement * M.pgs_scale < M.tolerance) break;
+        if (uniformf(improvement) * M.pgs_scale < M.tolerance) break;
       }
     }
     if (lane < kNefcMax) s_efc[E_FORCE * kNefcMax + lane] = rowact ? force : 0.f;
     gsync();
+    HB_STAMP(13);
     // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = L^-1 D^-1/2 (y + s) ; qfrc_constraint = L^T D^1/2 s
     for (int k = lane; k < nv; k += kGroup) {
       float s = 0.f;
@@ -865,7 +982,7 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
     solve_l_push(M, s_qLD, s_v0, lane);
     for (int i = lane; i < nv; i += kGroup) {
       float acc = s_v1[i];
-      for (int t = M.desc_adr[i]; t < M.desc_adr[i + 1]; t++) acc += s_qLD[M.desc_M[t]] * s_v1[M.desc_k[t]];
+      for (int t = M.desc_adr[i]; t < M.desc_adr[i + 1]; t++) { const int pk = M.desc_pack[t]; acc += s_qLD[pk >> 8] * s_v1[pk & 255]; }
       s_v2[i] = s_smooth[i] + acc;  // qfrc_smooth + qfrc_constraint: right-hand side of the Euler solve
     }
     gsync();
@@ -901,27 +1018,15 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
     }
     if (lane == 0) { int* c = P.counts + 4 * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; }
 
+    HB_STAMP(14);
     if (P.integrate) {
       // ---------------------------------------------------------------- mj_Euler: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint
-      bool damp = false;
-      if (!(M.disableflags & (1 << 14))) {
-        bool d = false;
-        for (int i = lane; i < nv; i += kGroup) d |= M.dof_damping[i] > 0.f;
-        damp = __any(d);
-      }
       for (int i = lane; i < nv; i += kGroup) s_warm[i] = s_v0[i];  // qacc_warmstart <- qacc
-      if (damp) {
-        for (int e = lane; e < M.nM; e += kGroup) {
-          float v = s_qM[e];
-          if (M.M_i[e] == M.M_j[e]) v += M.timestep * M.dof_damping[M.M_i[e]];
-          s_qLD[e] = v;
-        }
+      if (eulerdamp) {
+        solve_lt_push(M, s_qH, s_v2, lane);
+        for (int i = lane; i < nv; i += kGroup) s_v2[i] *= s_hdinv[i];
         gsync();
-        factor_ld(M, s_qLD, s_dinv, s_dsqrtinv, lane);
-        solve_lt_push(M, s_qLD, s_v2, lane);
-        for (int i = lane; i < nv; i += kGroup) s_v2[i] *= s_dinv[i];
-        gsync();
-        solve_l_push(M, s_qLD, s_v2, lane);
+        solve_l_push(M, s_qH, s_v2, lane);
       } else {
         for (int i = lane; i < nv; i += kGroup) s_v2[i] = s_v0[i];
         gsync();
@@ -949,6 +1054,10 @@ __global__ __launch_bounds__(kGroup) void hb_step_kernel(const DevModel M, const
     }
   }
 
+#ifdef HB_STAMPS
+  HB_STAMP(15);
+  if (lane == 0 && P.stamps) for (int i = 0; i < 16; i++) P.stamps[(size_t)env * 16 + i] = stamps_[i];
+#endif
   if (P.integrate) {
     if (lane == 0) gstate[0] = time;
     for (int i = lane; i < nq; i += kGroup) gstate[1 + i] = s_qpos[i];
@@ -1014,6 +1123,18 @@ __global__ void hb_obs_kernel(const DevModel M, const float* state, float* obs, 
   if (truncated) truncated[e] = 0;
 }
 
+
+// benchmark controls: ctrl[t][e][i] = 2*H(1+t0+t+1000*(env_offset+e), i+2) - 1  (testspeed.cc:64-80)
+__global__ void hb_halton_ctrl_kernel(float* out, int T, int n_env, int nu, int t0, int env_offset) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)T * n_env * nu;
+  if (idx >= total) return;
+  int i = (int)(idx % nu);
+  size_t r = idx / nu;
+  int e = (int)(r % n_env), t = (int)(r / n_env);
+  out[idx] = 2.f * halton(1 + t0 + t + 1000 * (env_offset + e), i + 2) - 1.f;
+}
+
 // ------------------------------------------------------------------------------------------
 // host-callable launchers (declared in hb_launch.hpp)
 }  // namespace hb
@@ -1022,9 +1143,9 @@ __global__ void hb_obs_kernel(const DevModel M, const float* state, float* obs, 
 
 namespace hb {
 
-hipError_t launch_step(const DevModel& M, const BatchPtrs& P, int nsteps, hipStream_t stream) {
-  size_t shmem = (size_t)M.lds_floats * sizeof(float);
-  hipLaunchKernelGGL(hb_step_kernel, dim3(P.n_env), dim3(kGroup), shmem, stream, M, P, nsteps);
+hipError_t launch_step(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
+  size_t shmem = (size_t)lds_floats * sizeof(float);
+  hipLaunchKernelGGL(hb_step_kernel, dim3(P.n_env), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   return hipGetLastError();
 }
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, int perturb, int env_offset, hipStream_t stream) {
@@ -1033,6 +1154,11 @@ hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint
 }
 hipError_t launch_obs(const DevModel& M, const float* state, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env, hipStream_t stream) {
   hipLaunchKernelGGL(hb_obs_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, obs, reward, terminated, truncated, n_env);
+  return hipGetLastError();
+}
+hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream) {
+  size_t total = (size_t)T * n_env * nu;
+  hipLaunchKernelGGL(hb_halton_ctrl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, out, T, n_env, nu, t0, env_offset);
   return hipGetLastError();
 }
 hipError_t set_step_lds_limit(int bytes) {

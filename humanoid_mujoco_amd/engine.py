@@ -83,6 +83,11 @@ def lib():
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
     L.hb_diag_enable.argtypes = [vp, ci]
     L.hb_get_qacc.argtypes = [vp, vp]; L.hb_get_efc_force.argtypes = [vp, vp]; L.hb_get_contacts.argtypes = [vp, vp]
+    L.hb_dev_alloc.restype = vp; L.hb_dev_alloc.argtypes = [vp, ctypes.c_uint64]
+    L.hb_dev_free.restype = None; L.hb_dev_free.argtypes = [vp, vp]
+    L.hb_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_uint64]; L.hb_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_uint64]
+    L.hb_halton_ctrl_dev.argtypes = [vp, ci, ci, ci, vp]
+    L.hb_timer_start.argtypes = [vp]; L.hb_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     _lib = L
     return L
 
@@ -287,3 +292,33 @@ class Batch:
         out = np.zeros((self.n_env, self.model.ncon_max, 16), dtype=np.float32)
         _check(lib().hb_get_contacts(self._h, _ptr(out)), "hb_get_contacts")
         return out
+
+    # ---- device buffers / timing helpers (no HIP headers or torch needed on the caller's side)
+    def dev_alloc(self, nbytes):
+        p = lib().hb_dev_alloc(self._h, int(nbytes))
+        if not p:
+            raise HbError("hb_dev_alloc(%d) failed" % nbytes)
+        return p
+
+    def dev_free(self, p):
+        lib().hb_dev_free(self._h, ctypes.c_void_p(p))
+
+    def to_dev(self, p, arr):
+        a = np.ascontiguousarray(arr)
+        _check(lib().hb_memcpy_h2d(self._h, ctypes.c_void_p(p), _ptr(a), a.nbytes), "hb_memcpy_h2d")
+
+    def from_dev(self, p, shape, dtype=np.float32):
+        out = np.zeros(shape, dtype=dtype)
+        _check(lib().hb_memcpy_d2h(self._h, _ptr(out), ctypes.c_void_p(p), out.nbytes), "hb_memcpy_d2h")
+        return out
+
+    def halton_ctrl_dev(self, T, t0, env_offset, out_ptr):
+        _check(lib().hb_halton_ctrl_dev(self._h, int(T), int(t0), int(env_offset), ctypes.c_void_p(out_ptr)), "hb_halton_ctrl_dev")
+
+    def timer_start(self):
+        _check(lib().hb_timer_start(self._h), "hb_timer_start")
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        _check(lib().hb_timer_stop(self._h, ctypes.byref(ms)), "hb_timer_stop")
+        return ms.value

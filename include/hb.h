@@ -159,6 +159,24 @@ int hb_get_qacc(hb_batch* b, float* qacc);
 int hb_get_efc_force(hb_batch* b, float* efc_force);
 int hb_get_contacts(hb_batch* b, float* contact);
 
+/* ---- host-side helpers so a C/C++/ctypes caller needs no HIP headers ---------------------------- */
+
+/* Device buffer on the batch's GPU (hipMalloc / hipFree). */
+void* hb_dev_alloc(hb_batch* b, uint64_t bytes);
+void hb_dev_free(hb_batch* b, void* p);
+int hb_memcpy_h2d(hb_batch* b, void* dst_dev, const void* src, uint64_t bytes);
+int hb_memcpy_d2h(hb_batch* b, void* dst, const void* src_dev, uint64_t bytes);
+/* Fills out_dev[T][n_env][nu] with the benchmark's deterministic controls, the generator of
+ * simulation/mujoco/sample/testspeed.cc:64-80 (CtrlNoise) with ctrlnoise = 1:
+ * ctrl[t,e,i] = 2*Halton(1 + t0 + t + 1000*(env_offset+e), i+2) - 1. */
+int hb_halton_ctrl_dev(hb_batch* b, int T, int t0, int env_offset, float* out_dev);
+/* HIP-event stopwatch on the batch's stream (hipEventRecord on that stream; hipEventElapsedTime). */
+int hb_timer_start(hb_batch* b);
+int hb_timer_stop(hb_batch* b, float* elapsed_ms);
+/* Diagnostic builds only (libhb_stamps.so, -DHB_STAMPS): per-env s_memtime stamps at the 16 phase
+ * boundaries of the last step; the first call arms the buffer.  HB_EUNSUPPORTED in the product build. */
+int hb_get_stamps(hb_batch* b, unsigned long long* out);
+
 const char* hb_version(void);
 
 #ifdef __cplusplus

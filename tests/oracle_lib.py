@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-HUMANOID_HBM = os.path.join(GOLDEN, "humanoid27.hbm")
+HUMANOID_HBM = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm")
 
 _lib = None
 

@@ -1,0 +1,369 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libhb.so) against the fp64 oracle.
+
+Tolerances (fp32 device arithmetic vs fp64 oracle, stated per SURVEY.md §8(c)/(d)):
+  one step, teacher-forced from identical states
+      qpos   : |d| <= 1e-4 * max(1, |qpos|)            (measured: median 7e-8, max 1.1e-5..2.6e-5 on one stiff 6-limit-row impact state)
+      qvel   : |d| <= 1e-3 * max(1, max|qvel|)         (measured: median 8e-7, max 1.2e-4; qvel' = qvel + h*qacc, |qacc| up to 4e3)
+      qacc   : |d| <= 2e-3 * max(1, max|qacc|)         (measured: median 2e-6, max 1.2e-4)
+      contact: dist/pos 1e-5; frame 1e-3 (a capsule-capsule normal is (p2-p1)/|p2-p1| of two nearly coincident
+               closest points under deep penetration: ill-conditioned in fp32, measured max 2.3e-4, median 1e-7);
+               counts (ncon, nefc) identical
+      forces : |d| <= 2e-3 * max(1, max|efc_force|)   (measured: median 4e-6, max 8e-5; PGS sweep counts identical)
+  (measurements: tools/gpu_parity_report.py on the 128 golden states, profiles/r01_parity_report.txt)
+  free-running, contact-free segment: relative qpos drift <= 1e-4 (the north-star bar);
+  free-running through contacts: chaotic, reported not asserted beyond sanity.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import GOLDEN, HUMANOID_HBM, Oracle, halton
+
+pytestmark = pytest.mark.gpu
+MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "humanoid27_steps.npz"))
+
+
+def pack_state(g, idx):
+    return np.concatenate([g["time"][idx, None], g["qpos"][idx], g["qvel"][idx], g["warm"][idx]], axis=1)
+
+
+def test_one_step_parity_on_golden_states(hbmod, humanoid_model, gpu, golden):
+    g = golden
+    n = len(g["env"])
+    b = hbmod.Batch(humanoid_model, n, gpu)
+    b.diag_enable(True)
+    b.set_state(hbmod.STATE_INTEGRATION, pack_state(g, np.arange(n)))
+    b.step(g["ctrl"].astype(np.float32))
+    q, v, a = b.qpos.astype(np.float64), b.qvel.astype(np.float64), b.qacc().astype(np.float64)
+    ncon, nefc, niter = b.counts()
+    assert not b.status().any()
+    assert np.array_equal(ncon, g["ncon"]) and np.array_equal(nefc, g["nefc"])
+    dq = np.abs(q - g["qpos1"]) / np.maximum(1.0, np.abs(g["qpos1"]))
+    assert dq.max() <= 1e-4, dq.max()
+    assert np.median(dq.max(axis=1)) <= 1e-6
+    vs = np.maximum(1.0, np.abs(g["qvel1"]).max(axis=1, keepdims=True))
+    assert (np.abs(v - g["qvel1"]) / vs).max() <= 1e-3
+    as_ = np.maximum(1.0, np.abs(g["qacc"]).max(axis=1, keepdims=True))
+    assert (np.abs(a - g["qacc"]) / as_).max() <= 2e-3
+    # time advanced by one timestep
+    assert np.allclose(b.time, g["time"] + 0.005, atol=1e-5)
+    # contact geometry
+    con = b.contacts().astype(np.float64)
+    for k in range(n):
+        nc = int(g["ncon"][k])
+        assert np.abs(con[k, :nc, 0] - g["con_dist"][k, :nc]).max(initial=0) <= 1e-5
+        assert np.abs(con[k, :nc, 1:4] - g["con_pos"][k, :nc]).max(initial=0) <= 1e-5
+        assert np.abs(con[k, :nc, 4:13] - g["con_frame"][k, :nc]).max(initial=0) <= 1e-3
+        assert np.array_equal(con[k, :nc, 14:16], g["con_geom"][k, :nc])
+    # constraint forces
+    f = b.efc_force().astype(np.float64)
+    fs = np.maximum(1.0, np.abs(g["efc_force"]).max(axis=1, keepdims=True))
+    assert (np.abs(f - g["efc_force"]) / fs).max() <= 2e-3
+
+
+def test_forward_matches_oracle_and_leaves_state(hbmod, humanoid_model, gpu, golden):
+    g = golden
+    idx = np.arange(0, len(g["env"]), 4)
+    b = hbmod.Batch(humanoid_model, len(idx), gpu)
+    b.diag_enable(True)
+    st = pack_state(g, idx)
+    b.set_state(hbmod.STATE_INTEGRATION, st)
+    b.forward(g["ctrl"][idx].astype(np.float32))
+    assert np.allclose(b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64), st.astype(np.float32), atol=0)
+    a = b.qacc()
+    as_ = np.maximum(1.0, np.abs(g["qacc"][idx]).max(axis=1, keepdims=True))
+    assert (np.abs(a - g["qacc"][idx]) / as_).max() <= 2e-3
+
+
+def test_contact_free_drift_within_north_star_bar(hbmod, humanoid_model, gpu):
+    """Free-running GPU vs oracle over the contact-free opening of the benchmark workload."""
+    envs = [0, 1, 2, 3, 4, 5, 6, 7]
+    n = len(envs)
+    b = hbmod.Batch(humanoid_model, n, gpu)
+    b.reset(perturb=True)
+    oracles = []
+    for e in envs:
+        o = Oracle()
+        o.init_env(e)
+        oracles.append(o)
+    # initial state identical (fp32 rounding of the Halton perturbation aside)
+    q0 = b.qpos
+    for i, o in enumerate(oracles):
+        assert np.abs(q0[i] - o.qpos).max() < 1e-6
+    T = 50
+    worst = 0.0
+    for t in range(T):
+        ctrl = np.stack([o.ctrl_env(t, e) for o, e in zip(oracles, envs)]).astype(np.float32)
+        b.step(ctrl)
+        for o, c in zip(oracles, ctrl):
+            o.ctrl[:] = c
+            o.step()
+        q = b.qpos
+        for i, o in enumerate(oracles):
+            if o.ncon == 0:
+                worst = max(worst, float((np.abs(q[i] - o.qpos) / np.maximum(1.0, np.abs(o.qpos))).max()))
+    assert worst <= 1e-4, worst
+
+
+def test_long_rollout_statistics_match_oracle(hbmod, humanoid_model, gpu):
+    """1000 free-running steps: trajectories decorrelate (chaos), so compare ensemble statistics and
+    check physical sanity instead of per-env drift."""
+    n, T = 256, 1000
+    b = hbmod.Batch(humanoid_model, n, gpu)
+    b.reset(perturb=True)
+    b.rollout_halton(T)
+    b.sync()
+    q = b.qpos
+    assert np.isfinite(q).all() and np.isfinite(b.qvel).all()
+    assert not b.status().any()
+    assert np.allclose(np.linalg.norm(q[:, 3:7], axis=1), 1.0, atol=1e-4)
+    assert q[:, 2].min() > -0.02 and q[:, 2].max() < 1.0  # everybody is lying on the floor, nobody below it
+    o = Oracle()
+    _, qo, st = o.rollout_threads(n, T, os.cpu_count() or 4, 0, True)
+    assert abs(q[:, 2].mean() - qo[:, 2].mean()) < 0.02
+    nc, ne, ni = b.counts()
+    assert abs(ne.mean() - st["mean_nefc"]) < 4.0
+    assert abs(np.abs(q[:, 7:]).mean() - np.abs(qo[:, 7:]).mean()) < 0.05
+    assert np.allclose(b.time, T * 0.005, rtol=1e-4)
+
+
+def test_rollout_equals_repeated_steps_bitwise(hbmod, humanoid_model, gpu):
+    n, T = 64, 40
+    rng = np.random.default_rng(3)
+    ctrl = rng.uniform(-1, 1, size=(T, n, humanoid_model.nu)).astype(np.float32)
+    a = hbmod.Batch(humanoid_model, n, gpu)
+    c = hbmod.Batch(humanoid_model, n, gpu)
+    a.reset(perturb=True)
+    c.reset(perturb=True)
+    qs = a.rollout(ctrl, want_qpos=True)
+    for t in range(T):
+        c.step(ctrl[t])
+        if t in (0, 17, T - 1):
+            assert np.array_equal(qs[t], c.qpos)
+    assert np.array_equal(a.get_state(hbmod.STATE_INTEGRATION), c.get_state(hbmod.STATE_INTEGRATION))
+    # n_substeps: same control held
+    d = hbmod.Batch(humanoid_model, n, gpu)
+    e = hbmod.Batch(humanoid_model, n, gpu)
+    d.reset(perturb=True); e.reset(perturb=True)
+    d.step(ctrl[0], n_substeps=5)
+    for _ in range(5):
+        e.step(ctrl[0])
+    assert np.array_equal(d.get_state(hbmod.STATE_INTEGRATION), e.get_state(hbmod.STATE_INTEGRATION))
+
+
+def test_device_halton_controls_and_determinism(hbmod, humanoid_model, gpu):
+    n, T, off = 32, 12, 4096
+    b = hbmod.Batch(humanoid_model, n, gpu)
+    nu = humanoid_model.nu
+    buf = b.dev_alloc(T * n * nu * 4)
+    b.halton_ctrl_dev(T, 3, off, buf)
+    got = b.from_dev(buf, (T, n, nu))
+    want = np.array([[[2 * halton(1 + 3 + t + 1000 * (off + e), i + 2) - 1 for i in range(nu)] for e in range(n)] for t in range(T)])
+    assert np.abs(got - want).max() < 2e-6
+    # rollout with the control tensor in HBM == rollout generating the same controls on chip
+    b.reset(perturb=True, env_offset=off)
+    b.rollout_dev(buf, T)
+    s1 = b.get_state(hbmod.STATE_INTEGRATION)
+    b.reset(perturb=True, env_offset=off)
+    b.rollout_halton(T, t0=3, env_offset=off)
+    s2 = b.get_state(hbmod.STATE_INTEGRATION)
+    assert np.array_equal(s1, s2)
+    # and again: bitwise reproducible
+    b.reset(perturb=True, env_offset=off)
+    b.rollout_halton(T, t0=3, env_offset=off)
+    assert np.array_equal(s2, b.get_state(hbmod.STATE_INTEGRATION))
+    b.dev_free(buf)
+
+
+def test_sharding_by_env_offset_is_exact(hbmod, humanoid_model, gpu):
+    """Envs are independent: one batch of 2N envs == two batches of N with env_offset (multi-GPU split)."""
+    n, T = 128, 30
+    whole = hbmod.Batch(humanoid_model, 2 * n, gpu)
+    whole.reset(perturb=True)
+    whole.rollout_halton(T)
+    sw = whole.get_state(hbmod.STATE_INTEGRATION)
+    for r in range(2):
+        part = hbmod.Batch(humanoid_model, n, gpu)
+        part.reset(perturb=True, env_offset=r * n)
+        part.rollout_halton(T, env_offset=r * n)
+        assert np.array_equal(part.get_state(hbmod.STATE_INTEGRATION), sw[r * n:(r + 1) * n])
+
+
+def test_state_io_reset_and_keyframes(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n = 16
+    b = hbmod.Batch(m, n, gpu)
+    assert b.state_size(hbmod.STATE_INTEGRATION) == 1 + m.nq + 2 * m.nv
+    assert b.state_size(hbmod.STATE_QPOS | hbmod.STATE_QVEL) == m.nq + m.nv
+    qpos0 = m.array("qpos0")
+    assert np.allclose(b.qpos, qpos0.astype(np.float32)[None])
+    assert not b.qvel.any() and not b.time.any()
+    # set / get round trip in mjtState bit order
+    rng = np.random.default_rng(1)
+    st = rng.normal(size=(n, b.state_size(hbmod.STATE_INTEGRATION))).astype(np.float32)
+    b.set_state(hbmod.STATE_INTEGRATION, st)
+    assert np.array_equal(b.get_state(hbmod.STATE_INTEGRATION), st)
+    assert np.array_equal(b.get_state(hbmod.STATE_QVEL), st[:, 1 + m.nq:1 + m.nq + m.nv])
+    part = rng.normal(size=(n, m.nv)).astype(np.float32)
+    b.set_state(hbmod.STATE_QVEL, part)
+    st[:, 1 + m.nq:1 + m.nq + m.nv] = part
+    assert np.array_equal(b.get_state(hbmod.STATE_INTEGRATION), st)
+    # masked reset to a keyframe
+    key = m.array("key_qpos").reshape(m.nkey, m.nq)
+    mask = np.zeros(n, np.uint8)
+    mask[::2] = 1
+    b.reset(mask=mask, keyframe=m.name2id("key", "squat"))
+    q = b.qpos
+    assert np.allclose(q[::2], key[0].astype(np.float32)[None])
+    assert np.array_equal(q[1::2], st[1::2, 1:1 + m.nq])
+    with pytest.raises(hbmod.HbError):
+        b.reset(keyframe=7)
+
+
+def test_bad_state_is_flagged_and_reset(hbmod, humanoid_model, gpu):
+    """mj_checkPos / mj_checkVel semantics (mujoco.h:301-307): NaN or |x|>1e10 resets the env and
+    raises the warning; other envs are untouched."""
+    m = humanoid_model
+    n = 8
+    b = hbmod.Batch(m, n, gpu)
+    b.reset(perturb=True)
+    st = b.get_state(hbmod.STATE_INTEGRATION)
+    st[2, 5] = np.nan
+    st[5, 1 + m.nq + 3] = 1e12
+    b.set_state(hbmod.STATE_INTEGRATION, st)
+    b.step(np.zeros((n, m.nu), np.float32))
+    s = b.status()
+    assert s[2] & hbmod.WARN_BADQPOS and s[5] & hbmod.WARN_BADQVEL
+    assert not s[[0, 1, 3, 4, 6, 7]].any()
+    assert np.isfinite(b.qpos).all() and np.isfinite(b.qvel).all()
+    b.reset()
+    assert not b.status().any()
+
+
+def test_disable_flags_and_options(hbmod, gpu):
+    from humanoid_mujoco_amd import engine
+    m = hbmod.Model.load(HUMANOID_HBM)
+    m.set_opt(disableflags=engine.DSBL_CONTACT | engine.DSBL_LIMIT)
+    b = hbmod.Batch(m, 8, gpu)
+    b.reset(keyframe=0)
+    for _ in range(20):
+        b.step(np.ones((8, m.nu), np.float32))
+    nc, ne, _ = b.counts()
+    assert not nc.any() and not ne.any()
+    # gravity off + everything passive off: free body keeps its velocity exactly
+    m2 = hbmod.Model.load(HUMANOID_HBM)
+    m2.set_opt(disableflags=engine.DSBL_CONTACT | engine.DSBL_LIMIT | engine.DSBL_GRAVITY | engine.DSBL_PASSIVE | engine.DSBL_ACTUATION)
+    b2 = hbmod.Batch(m2, 2, gpu)
+    st = b2.get_state(hbmod.STATE_INTEGRATION)
+    st[:, 1 + m2.nq + 0] = 1.5  # root x velocity
+    b2.set_state(hbmod.STATE_INTEGRATION, st)
+    b2.step(np.zeros((2, m2.nu), np.float32), n_substeps=10)
+    assert np.allclose(b2.qvel[:, 0], 1.5, atol=1e-5)
+    assert np.allclose(b2.qpos[:, 0], 1.5 * 10 * 0.005, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,steps", [("ball_plane", 400), ("capsules", 300), ("chain", 300), ("pendulum_limit", 500)])
+def test_other_models_one_step_parity_along_oracle_trajectory(hbmod, gpu, tmp_path, name, steps):
+    """Multi-tree models, slide joints, tendon limits, affine actuators, condim-1 pairs: teacher-forced
+    one-step parity at states sampled along an oracle rollout."""
+    xml = os.path.join(MODELS, name + ".xml")
+    m = hbmod.Model.load(xml)
+    p = str(tmp_path / (name + ".hbm"))
+    m.save(p)
+    o = Oracle(p)
+    o.reset(0 if name == "chain" else -1)
+    rng = np.random.default_rng(11)
+    states, ctrls, outs = [], [], []
+    for t in range(steps):
+        c = rng.uniform(-1, 1, size=max(o.nu, 1))[:o.nu]
+        o.ctrl[:] = c
+        if t % 10 == 0:
+            states.append(np.concatenate([[o.time], o.qpos, o.qvel, o.qacc_warmstart]))
+            ctrls.append(c.copy())
+        o.step()
+        if t % 10 == 0:
+            outs.append((o.qpos.copy(), o.qvel.copy(), o.ncon, o.nefc))
+    n = len(states)
+    b = hbmod.Batch(m, n, gpu)
+    b.set_state(hbmod.STATE_INTEGRATION, np.array(states))
+    b.step(np.array(ctrls, dtype=np.float32).reshape(n, m.nu))
+    q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
+    nc, ne, _ = b.counts()
+    assert not b.status().any()
+    for k, (qo, vo, nco, neo) in enumerate(outs):
+        assert (nc[k], ne[k]) == (nco, neo), (k, nc[k], ne[k], nco, neo)
+        assert (np.abs(q[k] - qo) / np.maximum(1, np.abs(qo))).max() <= 1e-4
+        assert np.abs(v[k] - vo).max() <= 1e-3 * max(1.0, np.abs(vo).max())
+
+
+def test_xfrc_applied(hbmod, humanoid_model, gpu):
+    """Cartesian push on a body (CPUEnv._apply_external_forces, cpu_env.py:618-654) vs the oracle."""
+    m = humanoid_model
+    n = 4
+    b = hbmod.Batch(m, n, gpu)
+    b.reset(perturb=True)
+    st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+    xf = np.zeros((n, m.nbody, 6))
+    xf[:, 1, 0] = [10, -5, 0, 3]
+    xf[:, 7, 1] = [0, 8, -8, 1]
+    xf[2, 12, 3:6] = [0.5, -0.25, 1.0]
+    b.set_state(hbmod.STATE_XFRC_APPLIED, xf.reshape(n, -1))
+    b.step(np.zeros((n, m.nu), np.float32))
+    v = b.qvel
+    for e in range(n):
+        o = Oracle()
+        o.reset()
+        o.qpos[:] = st[e, 1:1 + m.nq]
+        o.xfrc_applied[:] = xf[e].ravel()
+        o.step()
+        assert np.abs(v[e] - o.qvel).max() <= 1e-3 * max(1.0, np.abs(o.qvel).max())
+    assert np.array_equal(b.get_state(hbmod.STATE_XFRC_APPLIED).reshape(n, m.nbody, 6), xf.astype(np.float32))
+
+
+def test_observation_layout(hbmod, humanoid_model, gpu):
+    """obs[48] = hinge qpos (21), hinge qvel (21), root angular velocity (3), gravity in torso frame (3):
+    the 27-DoF analogue of CPUEnv._get_obs (cpu_env.py:554-571), SURVEY.md §8(a) a18."""
+    m = humanoid_model
+    n = 8
+    b = hbmod.Batch(m, n, gpu)
+    b.reset(perturb=True)
+    b.rollout_halton(80)
+    obs, rew, term, trunc = b.obs()
+    q, v = b.qpos, b.qvel
+    assert obs.shape == (n, 48)
+    assert np.array_equal(obs[:, :21], q[:, 7:]) and np.array_equal(obs[:, 21:42], v[:, 6:])
+    assert np.array_equal(obs[:, 42:45], v[:, 3:6])
+    for e in range(n):
+        w, x, y, z = q[e, 3:7] / np.linalg.norm(q[e, 3:7])
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        assert np.allclose(obs[e, 45:48], R.T @ np.array([0, 0, -1.0]), atol=1e-5)
+    assert np.isfinite(rew).all() and not term.any() and not trunc.any()
+
+
+def test_full_size_batch_properties(hbmod, humanoid_model, gpu):
+    """BASELINE config 2 size (4096 envs): size-independent properties after 300 steps."""
+    n, T = 4096, 300
+    b = hbmod.Batch(humanoid_model, n, gpu)
+    b.reset(perturb=True)
+    b.rollout_halton(T)
+    q, v = b.qpos, b.qvel
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert not b.status().any()
+    assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max() < 1e-4
+    assert q[:, 2].min() > -0.02
+    nc, ne, ni = b.counts()
+    assert nc.max() <= humanoid_model.ncon_max and ne.max() <= humanoid_model.nefc_max and ni.max() <= 50
+    # joint limits are soft but hold to within a few degrees
+    rng_ = humanoid_model.array("jnt_range").reshape(-1, 2)[1:]
+    viol = np.maximum(q[:, 7:] - rng_[None, :, 1], rng_[None, :, 0] - q[:, 7:]).max()
+    assert viol < 0.35
+    # distinct environments really are distinct, identical ones identical
+    assert len(np.unique(q[:, 2])) > n // 2

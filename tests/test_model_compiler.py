@@ -1,0 +1,174 @@
+"""Host-side model compiler (csrc/mjcf.cpp, setconst.cpp, model_io.cpp) — no GPU needed.
+
+Replaces mj_loadXML / mj_setConst for the hot path's models; checked against hand-derived facts
+about the reference's benchmark model and closed forms.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REF_HUMANOID_XML
+from oracle_lib import HUMANOID_HBM, Oracle, parse_hbm
+
+MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+
+
+def test_humanoid_sizes_and_layout(humanoid_model):
+    m = humanoid_model
+    # simulation/mujoco/model/humanoid/README.md:4-5 (27 DoF, 21 actuators); SURVEY.md Appendix A.1
+    assert (m.nq, m.nv, m.nu, m.nbody, m.njnt, m.ngeom, m.ntendon, m.nM, m.nkey) == (28, 27, 21, 17, 22, 20, 2, 243, 2)
+    assert m.nobs == 48
+    info = parse_hbm(HUMANOID_HBM)
+    assert info["body_name"][1] == "torso" and info["body_name"][6] == "shin_right"
+    # dof order per Appendix A.1: 6 root, abdomen_z,y,x, right leg (6), left leg (6), arms
+    assert info["jnt_name"][:4] == ["root", "abdomen_z", "abdomen_y", "abdomen_x"]
+    assert info["jnt_name"][4:10] == ["hip_x_right", "hip_z_right", "hip_y_right", "knee_right", "ankle_y_right", "ankle_x_right"]
+    # actuator order differs from dof order (humanoid.xml:203-223): abdomen_y first, gears 40/40/40/40/40/120/80/20/20
+    assert info["actuator_name"][:3] == ["abdomen_y", "abdomen_z", "abdomen_x"]
+    assert list(info["actuator_gear"][:9]) == [40, 40, 40, 40, 40, 120, 80, 20, 20]
+    assert m.name2id("joint", "knee_left") == 13 and m.name2id("body", "nope") == -1
+    # chain depths: feet 15 ancestors incl. self (Appendix A.1)
+    madr = info["dof_Madr"]
+    assert madr[15] - madr[14] == 15
+    # degrees were converted: knee range -160..2 deg
+    k = info["jnt_name"].index("knee_right")
+    assert np.allclose(info["jnt_range"][2 * k:2 * k + 2], np.radians([-160, 2]))
+    # keyframe squat: root z = 0.596 (humanoid.xml:236)
+    assert abs(info["key_qpos"][2] - 0.596) < 1e-12
+    # 8x floor contact params: condim 3 from the plane, friction max(1,.7)=1, solref mix (.02+.015)/2
+    assert info["geom_condim"][0] == 3 and info["geom_condim"][1] == 1
+
+
+def test_humanoid_mass_properties():
+    info = parse_hbm(HUMANOID_HBM)
+    mass = info["body_mass"]
+    # head: sphere r=.09 at density 1000
+    assert abs(mass[2] - 1000 * 4 / 3 * math.pi * 0.09 ** 3) < 1e-9
+    # shin: capsule r=.049, half length .15
+    r, h = 0.049, 0.15
+    assert abs(mass[6] - 1000 * (math.pi * r * r * 2 * h + 4 / 3 * math.pi * r ** 3)) < 1e-9
+    # left/right symmetry
+    assert np.allclose(mass[5:8], mass[8:11]) and np.allclose(mass[11:14], mass[14:17])
+    assert abs(mass.sum() - info["body_subtreemass"][1]) < 1e-9
+    inertia = info["body_inertia"].reshape(-1, 3)
+    assert (inertia[1:] > 0).all()
+    # triangle inequality of principal inertias
+    for I in inertia[1:]:
+        assert I[0] <= I[1] + I[2] + 1e-12 and I[1] <= I[0] + I[2] + 1e-12 and I[2] <= I[0] + I[1] + 1e-12
+    # capsule inertia against numerical integration (shin)
+    n = 200000
+    rng = np.random.default_rng(0)
+    pts = rng.uniform([-r, -r, -h - r], [r, r, h + r], size=(n, 3))
+    zc = np.clip(pts[:, 2], -h, h)
+    inside = (pts[:, 0] ** 2 + pts[:, 1] ** 2 + (pts[:, 2] - zc) ** 2) <= r * r
+    vol_box = (2 * r) * (2 * r) * (2 * h + 2 * r)
+    dens = 1000 * vol_box / n
+    p = pts[inside]
+    Ixx = dens * (p[:, 1] ** 2 + p[:, 2] ** 2).sum()
+    Izz = dens * (p[:, 0] ** 2 + p[:, 1] ** 2).sum()
+    got = np.sort(inertia[6])
+    assert abs(got[2] - Ixx) / Ixx < 0.02 and abs(got[0] - Izz) / Izz < 0.03
+
+
+def test_setconst_products_match_oracle_recomputation(oracle):
+    """dof_M0 / invweight0 / meaninertia (product, setconst.cpp) vs the oracle's own M at qpos0."""
+    info = parse_hbm(HUMANOID_HBM)
+    oracle.reset()
+    oracle.forward()
+    M = oracle.dense_M()
+    assert np.allclose(np.diag(M), info["dof_M0"], rtol=1e-12)
+    assert abs(np.diag(M).mean() - info["meaninertia"]) < 1e-12
+    Minv = np.linalg.inv(M)
+    dinv = np.diag(Minv)
+    w = info["dof_invweight0"]
+    assert np.allclose(w[:3], dinv[:3].mean()) and np.allclose(w[3:6], dinv[3:6].mean())
+    assert np.allclose(w[6:], dinv[6:], rtol=1e-9)
+    # tendon: J M^-1 J^T with J = 0.5 hip_y - 0.5 knee
+    J = np.zeros(27)
+    J[11], J[12] = 0.5, -0.5
+    assert abs(J @ Minv @ J - info["tendon_invweight0"][0]) < 1e-9
+    # body_invweight0 of the torso: translational block of J M^-1 J^T at its com
+    bw = info["body_invweight0"].reshape(-1, 2)
+    assert bw[0].tolist() == [0, 0]
+    assert (bw[1:] > 0).all()
+    # hands are welded to the lower arms: same rotational weight
+    assert np.isclose(bw[12, 1], bw[13, 1])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HUMANOID_XML), reason="reference tree not present (GPU box)")
+def test_fixture_reproduced_from_reference_xml(hbmod, tmp_path):
+    """The committed humanoid27.hbm is exactly what the compiler produces from the reference's MJCF."""
+    p = str(tmp_path / "h.hbm")
+    hbmod.Model.load(REF_HUMANOID_XML).save(p)
+    assert open(p).read() == open(HUMANOID_HBM).read()
+
+
+def test_hbm_roundtrip_bit_exact(hbmod, tmp_path):
+    for name in ("chain", "capsules"):
+        a, b = str(tmp_path / (name + "_a.hbm")), str(tmp_path / (name + "_b.hbm"))
+        hbmod.Model.load(os.path.join(MODELS, name + ".xml")).save(a)
+        hbmod.Model.load(a).save(b)
+        assert open(a).read() == open(b).read()
+
+
+def test_defaults_fromto_and_pairs(hbmod, tmp_path):
+    p = str(tmp_path / "chain.hbm")
+    m = hbmod.Model.load(os.path.join(MODELS, "chain.xml"))
+    m.save(p)
+    info = parse_hbm(p)
+    # class "link": capsule from fromto, half length .2, radius .03, z axis along -z..+z
+    assert info["geom_type"][2] == 3 and np.allclose(info["geom_size"][6:8], [0.03, 0.2])
+    assert np.allclose(info["geom_pos"][6:9], [0, 0, -0.2])
+    # nested default inheritance: damping/armature from main, stiffness/range from class
+    assert np.allclose(info["dof_damping"], 0.1) and np.allclose(info["dof_armature"], 0.01)
+    assert np.allclose(info["jnt_stiffness"], [0, 0.5, 0.5, 0.5])
+    assert np.allclose(info["jnt_range"][6:8], np.radians([-60, 60]))
+    # slide joint range is not an angle
+    assert np.allclose(info["jnt_range"][0:2], [-1, 1])
+    # parent-child geoms are filtered; cart sphere is on the same body chain as l1 (parent-child)
+    pairs = set(zip(info["pair_geom1"], info["pair_geom2"]))
+    assert (1, 2) not in pairs and (2, 3) not in pairs and (2, 4) in pairs and (0, 4) in pairs
+    # position actuator: gain kp, bias -kp*q
+    assert np.allclose(info["actuator_gainprm"], [1, 5, 2])
+    assert np.allclose(info["actuator_biasprm"].reshape(3, 3)[1], [0, -5, 0])
+    opt = m.opt
+    assert opt.timestep == 0.002 and opt.iterations == 50 and opt.solver == 0
+
+
+def test_multi_tree_weld_and_options(hbmod, tmp_path):
+    p = str(tmp_path / "c.hbm")
+    m = hbmod.Model.load(os.path.join(MODELS, "capsules.xml"))
+    m.save(p)
+    info = parse_hbm(p)
+    assert list(info["body_rootid"]) == [0, 1, 2, 3]
+    assert info["npair"] == 6  # 3 with the plane + 3 among the bodies
+    m.set_opt(timestep=0.001, iterations=10, disableflags=16)
+    assert m.opt.timestep == 0.001 and m.opt.iterations == 10 and m.opt.disableflags == 16
+    with pytest.raises(hbmod.HbError):
+        m.set_opt(solver=2)  # Newton is not implemented: refused, not silently ignored
+
+
+@pytest.mark.parametrize("xml,frag", [
+    ("<mujoco><worldbody><body><geom type='box' size='1 1 1'/></body></worldbody></mujoco>", "not supported"),
+    ("<mujoco><worldbody><body><joint type='ball'/><geom size='1'/></body></worldbody></mujoco>", "not supported"),
+    ("<mujoco><worldbody><body><joint/><geom type='sphere'/></body></worldbody></mujoco>", "size"),
+    ("<mujoco><worldbody><body><joint/></body></worldbody></mujoco>", "no mass"),
+    ("<mujoco><worldbody><body></worldbody></mujoco>", "mismatched"),
+    ("<mujoco><option solver='Newton'/><worldbody/></mujoco>", "PGS"),
+    ("<notmujoco/>", "root element"),
+])
+def test_compile_errors_are_reported_not_fatal(hbmod, xml, frag):
+    with pytest.raises(hbmod.HbError) as e:
+        hbmod.Model.from_xml_string(xml)
+    assert frag in str(e.value)
+
+
+def test_load_errors(hbmod, tmp_path):
+    with pytest.raises(hbmod.HbError):
+        hbmod.Model.load(str(tmp_path / "missing.xml"))
+    bad = tmp_path / "bad.hbm"
+    bad.write_text("HBM1\ni nq 3\n")  # truncated: no END
+    with pytest.raises(hbmod.HbError):
+        hbmod.Model.load(str(bad))

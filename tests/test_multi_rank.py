@@ -1,0 +1,74 @@
+"""N>1 path on CPU: world_size-2 gloo run of bench.py's sharding logic.
+
+The hot path has no data collective (independent envs): ranks own contiguous env
+blocks selected by env_offset, and only the timing (MAX) and a state checksum are reduced.  The
+oracle plays the stepper here (CPU, test-only) to prove that sharded results equal the unsharded
+ones bit for bit and that the reductions bench.py relies on behave.
+"""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, steps, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from bench import shard_range
+    from oracle_lib import Oracle
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    lo, hi = shard_range(n_total, world, rank)
+    o = Oracle()
+    _, qpos, _ = o.rollout_threads(hi - lo, steps, 2, env_offset=lo, want_qpos=True)
+    # what bench.py reduces: max elapsed over ranks, plus here a gather of the shard results
+    t = torch.tensor([0.5 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    parts = [torch.zeros((n_total // world, qpos.shape[1]), dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(qpos))
+    dist.barrier()
+    if rank == 0:
+        q.put((float(t.item()), torch.cat(parts).numpy(), (lo, hi)))
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    sys.path.insert(0, ROOT)
+    from bench import shard_range
+    for n, w in ((32768, 8), (8192, 2), (4096, 1), (10, 3)):
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+    assert shard_range(32768, 8, 3) == (3 * 4096, 4 * 4096)  # config 3: env e on GPU floor(e/4096)
+
+
+def test_two_rank_gloo_sharded_equals_unsharded():
+    world, n_total, steps = 2, 8, 120
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tmax, gathered, span0 = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert tmax == 1.5 and span0 == (0, 4)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    _, whole, _ = Oracle().rollout_threads(n_total, steps, 2, env_offset=0, want_qpos=True)
+    assert np.array_equal(gathered, whole)

@@ -1,0 +1,320 @@
+"""Known-answer and invariant tests that pin the fp64 oracle (oracle/mjstep_oracle.c).
+
+The reference holds no golden vectors for mj_step and MuJoCo itself is unavailable (SURVEY.md
+§8c: "parity unpinned"), so the oracle is validated the way SURVEY.md §8(c) prescribes:
+closed-form cases and structural invariants.  All CPU, no GPU.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import HUMANOID_HBM, Oracle, halton
+
+MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+CONTACT, LIMIT, PASSIVE, ACT, EULERDAMP, GRAVITY, WARMSTART = 16, 8, 32, 1024, 16384, 64, 256
+
+
+@pytest.fixture(scope="module")
+def compiled(tmp_path_factory, ):
+    """Compile the test MJCF models with the product's compiler into .hbm files the oracle reads."""
+    import humanoid_mujoco_amd as hb
+    out = {}
+    d = tmp_path_factory.mktemp("hbm")
+    for name in ("pendulum", "pendulum_limit", "ball_plane", "capsules", "chain"):
+        p = str(d / (name + ".hbm"))
+        hb.Model.load(os.path.join(MODELS, name + ".xml")).save(p)
+        out[name] = p
+    return out
+
+
+def test_halton_matches_python():
+    o = Oracle()
+    for idx in (1, 2, 7, 1000, 123457, 4096000):
+        for base in (2, 3, 5, 22):
+            assert abs(o.L.om_halton(idx, base) - halton(idx, base)) < 1e-15
+    # first terms of the base-2 van der Corput sequence
+    assert [o.L.om_halton(i, 2) for i in range(1, 5)] == [0.5, 0.25, 0.75, 0.125]
+
+
+def test_free_fall_closed_form():
+    """No contacts, no passive forces: the tree's com follows semi-implicit Euler free fall exactly:
+    z_n = z_0 - g h^2 n(n+1)/2."""
+    o = Oracle()
+    o.set_opt(disableflags=CONTACT | LIMIT | PASSIVE | ACT)
+    o.reset()
+    o.qpos[2] += 10.0
+    o.forward()
+    z0 = o.subtree_com.reshape(-1, 3)[1, 2]
+    h, g, n = o.opt("timestep"), 9.81, 200
+    o.step(n)
+    o.forward()
+    z = o.subtree_com.reshape(-1, 3)[1, 2]
+    assert abs(z - (z0 - g * h * h * n * (n + 1) / 2)) < 1e-9
+    assert abs(o.time - n * h) < 1e-12
+
+
+def test_energy_and_momentum_conservation():
+    """Tumbling humanoid in free flight: total energy drifts only O(h); spatial momentum about the
+    com is conserved in zero gravity.  Exercises kinematics, CRB, RNE (Coriolis) together."""
+    o = Oracle()
+    o.set_opt(disableflags=CONTACT | LIMIT | PASSIVE | ACT | EULERDAMP, timestep=1e-4)
+    o.reset()
+    rng = np.random.default_rng(0)
+    o.qvel[:] = rng.normal(size=o.nv)
+    o.qpos[2] += 5
+    mass = o.marr("body_mass")
+
+    def energy():
+        o.forward()
+        M = o.dense_M()
+        return 0.5 * o.qvel @ M @ o.qvel + 9.81 * (mass * o.xipos.reshape(-1, 3)[:, 2]).sum()
+
+    e0 = energy()
+    o.step(3000)
+    e1 = energy()
+    assert abs(e1 - e0) / abs(e0) < 1e-4
+
+    # zero gravity: momentum about the com (sum of cinert * cvel) is conserved
+    o.set_opt(disableflags=CONTACT | LIMIT | PASSIVE | ACT | EULERDAMP | GRAVITY)
+
+    def momentum():
+        o.forward()
+        ci, cv = o.cinert.reshape(-1, 10), o.cvel.reshape(-1, 6)
+        tot = np.zeros(6)
+        for b in range(1, o.nbody):
+            i, v = ci[b], cv[b]
+            tot += np.array([
+                i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5],
+                i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5],
+                i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4],
+                i[8] * v[1] - i[7] * v[2] + i[9] * v[3],
+                i[6] * v[2] - i[8] * v[0] + i[9] * v[4],
+                i[7] * v[0] - i[6] * v[1] + i[9] * v[5]])
+        return tot
+
+    p0 = momentum()
+    o.step(2000)
+    p1 = momentum()
+    assert np.abs(p1 - p0).max() < 2e-3 * max(1.0, np.abs(p0).max())
+
+
+def test_mass_matrix_and_factorisation():
+    o = Oracle()
+    o.init_env(3)
+    o.forward()
+    M = o.dense_M()
+    assert np.allclose(M, M.T)
+    assert np.linalg.eigvalsh(M).min() > 0
+    # M * qacc_smooth == qfrc_smooth (L^T D L solve)
+    assert np.abs(M @ o.qacc_smooth - o.qfrc_smooth).max() < 1e-9 * max(1, np.abs(o.qfrc_smooth).max())
+    # total mass on the translational block
+    total = o.marr("body_mass").sum()
+    assert np.allclose(np.diag(M)[:3], total)
+    # M qacc = qfrc_smooth + qfrc_constraint
+    assert np.abs(M @ o.qacc - o.qfrc_smooth - o.qfrc_constraint).max() < 1e-8 * max(1, np.abs(o.qfrc_smooth).max())
+
+
+def test_bias_force_is_gravity_at_rest():
+    """With zero velocity the RNE bias force is pure gravity: its root translational part is (0,0,m g)."""
+    o = Oracle()
+    o.init_env(1)
+    o.forward()
+    total = o.marr("body_mass").sum()
+    assert np.allclose(o.qfrc_bias[:3], [0, 0, 9.81 * total], atol=1e-9)
+
+
+def test_pendulum_period(compiled):
+    o = Oracle(compiled["pendulum"])
+    o.reset()
+    theta0 = 0.05
+    o.qpos[0] = theta0
+    # physical pendulum: T = 2 pi sqrt(I / (m g l)), sphere bob radius r at distance l
+    m, r, l = 1000 * 4 / 3 * math.pi * 0.05 ** 3, 0.05, 1.0
+    inertia = m * l * l + 0.4 * m * r * r
+    period = 2 * math.pi * math.sqrt(inertia / (m * 9.81 * l))
+    h = o.opt("timestep")
+    prev, crossings = o.qpos[0], []
+    for n in range(int(2.6 * period / h)):
+        o.step()
+        cur = o.qpos[0]
+        if prev > 0 >= cur:  # downward zero crossing
+            crossings.append((n + 1 - cur / (cur - prev)) * h if cur != prev else (n + 1) * h)
+        prev = cur
+    assert len(crossings) >= 2
+    measured = crossings[1] - crossings[0]
+    assert abs(measured - period) / period < 2e-3
+
+
+def test_joint_limit_holds(compiled):
+    o = Oracle(compiled["pendulum_limit"])
+    o.reset()
+    o.qpos[0] = 0.25
+    lo, hi = o.marr("jnt_range")
+    worst = 0.0
+    for n in range(4000):
+        o.ctrl[0] = 1.0 if (n // 500) % 2 == 0 else -1.0
+        o.step()
+        worst = max(worst, o.qpos[0] - hi, lo - o.qpos[0])
+    assert worst < 0.02  # soft limit: small violation only
+    assert worst > 0     # and it was actually reached
+
+
+def test_ball_rests_on_plane(compiled):
+    o = Oracle(compiled["ball_plane"])
+    o.reset()
+    o.step(1500)
+    o.forward()  # contacts of the final state
+    # at rest: tiny velocity, centre just below one radius, one contact with 4 pyramid rows
+    assert np.abs(o.qvel).max() < 1e-4
+    assert 0.09 < o.qpos[2] < 0.1
+    assert o.ncon == 1 and o.nefc == 4
+    c = o.contacts()[0]
+    assert np.allclose(c["frame"][0], [0, 0, 1])
+    assert abs(c["dist"] - (o.qpos[2] - 0.1)) < 1e-12
+    # contact position: midway between the two surfaces
+    assert abs(c["pos"][2] - 0.5 * (o.qpos[2] - 0.1)) < 1e-12
+    # normal force balances weight: each pyramid row contributes its force along the normal
+    m = o.marr("body_mass")[1]
+    assert abs(o.efc_force.sum() - m * 9.81) < 1e-3 * m * 9.81
+    # pyramid rows are J_n +- mu J_t: rows 0+1 and 2+3 both equal 2 J_n
+    J = o.efc_J.reshape(4, -1)
+    assert np.allclose(J[0] + J[1], J[2] + J[3])
+
+
+def test_pgs_kkt(compiled):
+    """After many sweeps the PGS solution satisfies the LCP: f >= 0, AR f + b >= 0, complementarity."""
+    o = Oracle(compiled["capsules"])
+    o.set_opt(iterations=2000, tolerance=0)
+    o.reset()
+    o.step(400)
+    o.forward()
+    n = o.nefc
+    assert n > 0
+    AR, b, f = o.efc_AR.reshape(n, n), o.efc_b, o.efc_force
+    assert np.allclose(AR, AR.T)
+    w = AR @ f + b
+    scale = max(1.0, np.abs(b).max())
+    assert f.min() >= 0
+    assert w.min() > -1e-6 * scale
+    assert np.abs(f * w).max() < 1e-6 * scale * max(1.0, f.max())
+
+
+def test_contact_frames_orthonormal_and_normal_direction(compiled):
+    o = Oracle(compiled["capsules"])
+    o.reset()
+    seen_types = set()
+    for _ in range(300):
+        o.step()
+        for c in o.contacts():
+            F = c["frame"]
+            assert np.allclose(F @ F.T, np.eye(3), atol=1e-12)
+            assert np.isclose(np.linalg.det(F), 1.0)
+            seen_types.add((c["geom1"], c["geom2"]))
+            # normal points from geom1 to geom2: moving geom2 along it increases the distance
+            p1, p2 = o.geom_xpos.reshape(-1, 3)[c["geom1"]], o.geom_xpos.reshape(-1, 3)[c["geom2"]]
+            if c["geom1"] != 0:
+                assert F[0] @ (p2 - p1) > -0.35  # centres roughly ordered along the normal (capsules are long)
+    assert len(seen_types) >= 3  # plane-capsule, capsule-capsule, plane/capsule-sphere all occurred
+
+
+def test_capsule_capsule_distance_bruteforce(compiled):
+    """Closest-point routine vs dense sampling of both segments."""
+    o = Oracle(compiled["capsules"])
+    rng = np.random.default_rng(5)
+    ts = np.linspace(-1, 1, 401)
+    checked = 0
+    for trial in range(60):
+        o.reset()
+        qa = o.qpos
+        qa[0:3] = [0, 0, 1.0]
+        qa[7:10] = rng.normal(size=3) * 0.12 + [0, 0, 1.0]
+        q = rng.normal(size=4)
+        qa[10:14] = q / np.linalg.norm(q)
+        qa[14:17] = [5, 5, 5]  # sphere far away
+        o.forward()
+        gp, gm = o.geom_xpos.reshape(-1, 3), o.geom_xmat.reshape(-1, 3, 3)
+        a1, a2 = gm[1][:, 2], gm[2][:, 2]
+        P1 = gp[1][None] + ts[:, None] * 0.3 * a1[None]
+        P2 = gp[2][None] + ts[:, None] * 0.25 * a2[None]
+        dmin = np.sqrt(((P1[:, None, :] - P2[None, :, :]) ** 2).sum(-1)).min() - 0.06 - 0.05
+        cc = [c for c in o.contacts() if (c["geom1"], c["geom2"]) == (1, 2)]
+        if dmin < -1e-3:
+            assert len(cc) == 1
+            assert abs(cc[0]["dist"] - dmin) < 2e-3
+            checked += 1
+        elif dmin > 1e-3:
+            assert len(cc) == 0
+    assert checked > 5
+
+
+def test_step_is_forward_plus_euler_and_deterministic():
+    """mj_step == mj_forward + mj_Euler (the reference's own test pattern, mjpc/test/simulation.cc:59-73),
+    and two identical runs agree bit for bit."""
+    a, b = Oracle(), Oracle()
+    for o in (a, b):
+        o.init_env(7)
+    for t in range(120):
+        c = a.ctrl_env(t, 7)
+        a.ctrl[:] = c
+        b.ctrl[:] = c
+        a.step()
+        b.step()
+    assert np.array_equal(a.qpos, b.qpos) and np.array_equal(a.qvel, b.qvel)
+    # without damping, the velocity update is exactly h * qacc
+    o = Oracle()
+    o.set_opt(disableflags=EULERDAMP)
+    o.init_env(2)
+    v0 = o.qvel.copy()
+    o.step()
+    assert np.allclose(o.qvel - v0, o.opt("timestep") * o.qacc, atol=1e-12)
+    assert np.array_equal(o.qacc_warmstart, o.qacc)
+
+
+def test_warmstart_reduces_iterations(compiled):
+    """A body at rest: the warm-started PGS converges in a sweep or two, the cold one needs the cap."""
+    its = {}
+    for flags in (0, WARMSTART):
+        o = Oracle(compiled["ball_plane"])
+        o.set_opt(disableflags=flags)
+        o.reset()
+        n = []
+        for t in range(1200):
+            o.step()
+            n.append(o.dint("solver_niter"))
+        its[flags] = np.mean(n[-300:])
+    assert its[0] < 3 and its[WARMSTART] > 20
+
+
+def test_humanoid_workload_statistics():
+    """Contact/constraint counts under the benchmark workload stay inside the device capacities
+    (hb_device.hpp: 24 contacts, 63 rows) — the sizing evidence quoted in DESIGN.md."""
+    o = Oracle()
+    n, q, st = o.rollout_threads(32, 400, 4, 0, True)
+    assert n == 32 * 400
+    assert st["max_ncon"] <= 24 and st["max_nefc"] <= 63
+    assert np.isfinite(q).all()
+    assert q[:, 2].min() > -0.05  # nobody fell through the floor
+    quat = q[:, 3:7]
+    assert np.allclose(np.linalg.norm(quat, axis=1), 1.0, atol=1e-9)
+
+
+def test_tendon_and_chain_model(compiled):
+    o = Oracle(compiled["chain"])
+    o.reset(0)  # keyframe "bent"
+    assert np.allclose(o.qpos, [0.2, 0.5, -0.7, 0.3])
+    o.forward()
+    assert abs(o.ten_length[0] - (0.5 + 0.35)) < 1e-12  # 1*h1 - 0.5*h2
+    # tendon length 0.85 > upper limit 0.5 -> one tendon-limit row with J = -coef
+    types, ids = o.efc_types()
+    assert 4 in types
+    row = list(types).index(4)
+    J = o.efc_J.reshape(o.nefc, -1)[row]
+    assert np.allclose(J, [0, -1, 0.5, 0])
+    # position servo force = kp*ctrl - kp*q ; general: clip(2*ctrl + 0.1 - q - 0.05*qd, +-3)
+    o.ctrl[:] = [0.5, 0.2, 1.0]
+    o.forward()
+    assert abs(o.actuator_force[0] - 0.5) < 1e-12
+    assert abs(o.actuator_force[1] - (5 * 0.2 - 5 * (-0.7))) < 1e-12
+    assert abs(o.actuator_force[2] - (2.0 + 0.1 - 0.3)) < 1e-12

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-phase cycle shares of hb_step_kernel from the diagnostic build (build/libhb_stamps.so).
+Shares only — never quote this build's run time (stamps serialise)."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import humanoid_mujoco_amd.engine as eng
+eng.LIB_PATH = os.path.join(ROOT, "build", "libhb_stamps.so")
+import humanoid_mujoco_amd as hb
+L = eng.lib()
+L.hb_get_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+m = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm"))
+b = hb.Batch(m, N, 0)
+b.reset(perturb=True)
+b.rollout_halton(400)
+st = np.zeros((N, 16), dtype=np.uint64)
+assert L.hb_get_stamps(b._h, st.ctypes.data_as(ctypes.c_void_p)) == 0  # arm
+b.rollout_halton(1, t0=400)
+assert L.hb_get_stamps(b._h, st.ctypes.data_as(ctypes.c_void_p)) == 0
+d = np.diff(st.astype(np.int64), axis=1).astype(np.float64)
+names = ["ctrl+check", "kinematics", "geoms/com/cinert/cdof", "crb+qM", "factorM", "comVel+rne", "bias/passive/act", "collision", "makeConstraint",
+         "row quantities", "half-solve", "b + AR", "PGS", "dual finish", "Euler+advance"]
+tot = d.sum(1)
+print("envs %d; mean cycles per env-step (one wave) %.0f, median %.0f" % (N, tot.mean(), np.median(tot)))
+nc, ne, ni = b.counts()
+print("mean nefc %.1f niter %.1f" % (ne.mean(), ni.mean()))
+for i, n in enumerate(names):
+    print("%-24s %9.0f cycles  %5.1f %%" % (n, d[:, i].mean(), 100 * d[:, i].mean() / tot.mean()))

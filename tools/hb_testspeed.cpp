@@ -1,0 +1,56 @@
+// hb_testspeed — host C++ rollout driver over the C-ABI, in the shape of the reference's
+// simulation/mujoco/sample/testspeed.cc (load model, make data, Halton control noise, step loop,
+// print steps/s, contacts/step, constraints/step) but for n_env environments on one GPU.
+// usage: hb_testspeed model.{xml,hbm} [nstep=1000] [n_env=4096] [device=0]
+#include "hb.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s model.{xml,hbm} [nstep] [n_env] [device]\n", argv[0]); return 2; }
+  int nstep = argc > 2 ? atoi(argv[2]) : 1000, n_env = argc > 3 ? atoi(argv[3]) : 4096, device = argc > 4 ? atoi(argv[4]) : 0;
+  char err[1024] = "";
+  hb_model* m = hb_model_load(argv[1], err, sizeof err);
+  if (!m) { fprintf(stderr, "could not load model: %s\n", err); return 1; }
+  hb_sizes sz;
+  hb_model_sizes(m, &sz);
+  hb_batch* b = hb_batch_create(m, n_env, device, err, sizeof err);
+  if (!b) { fprintf(stderr, "could not create batch: %s\n", err); return 1; }
+  hb_reset(b, nullptr, -1, /*perturb=*/1, /*env_offset=*/0);
+  // controls for the whole run live in HBM, generated there (testspeed.cc:64-80)
+  float* ctrl = (float*)hb_dev_alloc(b, (uint64_t)nstep * n_env * sz.nu * sizeof(float));
+  if (!ctrl) { fprintf(stderr, "out of device memory\n"); return 1; }
+  hb_halton_ctrl_dev(b, nstep, 0, 0, ctrl);
+  hb_step_dev(b, ctrl, 1);  // warm-up launch
+  hb_reset(b, nullptr, -1, 1, 0);
+  hb_batch_sync(b);
+  long long contacts = 0, constraints = 0;
+  std::vector<int> ncon(n_env), nefc(n_env);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < nstep; t++) hb_step_dev(b, ctrl + (size_t)t * n_env * sz.nu, 1);
+  hb_batch_sync(b);
+  double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  hb_get_counts(b, ncon.data(), nefc.data(), nullptr);
+  for (int e = 0; e < n_env; e++) { contacts += ncon[e]; constraints += nefc[e]; }
+  std::vector<int> status(n_env);
+  hb_get_status(b, status.data());
+  int flagged = 0;
+  for (int s : status) flagged += s != 0;
+  hb_options opt;
+  hb_options_get(m, &opt);
+  printf("\nSimulation time      : %.3f s\n", sec);
+  printf("Environments         : %d on device %d\n", n_env, device);
+  printf("Steps per second     : %.0f (env-steps/s)\n", (double)nstep * n_env / sec);
+  printf("Realtime factor      : %.1f x per env\n", nstep * opt.timestep / sec);
+  printf("Time per batch step  : %.1f us\n", 1e6 * sec / nstep);
+  printf("Contacts / env (last): %.3f\n", (double)contacts / n_env);
+  printf("Constraints / env    : %.3f\n", (double)constraints / n_env);
+  printf("Degrees of freedom   : %d\n", sz.nv);
+  printf("Envs with warnings   : %d\n", flagged);
+  hb_dev_free(b, ctrl);
+  hb_batch_free(b);
+  hb_model_free(m);
+  return 0;
+}

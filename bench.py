@@ -42,9 +42,10 @@ def cpu_baseline(target_seconds=12.0):
     t0 = time.perf_counter()
     n, _, _ = o.rollout_threads(cores * 2, 100, cores)
     rate = n / (time.perf_counter() - t0)
-    # ~target_seconds of CPU work on the benchmark's own batch size, scaled in steps
-    n_env = max(cores, (ENVS_PER_GPU // cores) * cores)
-    steps = int(max(50, min(1000, rate * target_seconds / n_env)))
+    # ~target_seconds of CPU work: the benchmark's batch (or a multiple of it on many-core hosts), up to 1000 steps
+    steps = int(max(50, min(1000, rate * target_seconds / ENVS_PER_GPU)))
+    mult = max(1, int(round(rate * target_seconds / (ENVS_PER_GPU * steps))))
+    n_env = max(cores, (ENVS_PER_GPU * mult // cores) * cores)
     t0 = time.perf_counter()
     n, _, st = o.rollout_threads(n_env, steps, cores)
     dt = time.perf_counter() - t0

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of a tools/gpu_round.sh run from gpurun_out/<tag>/ into profiles/.
+
+usage: tools/collect_profiles.py <tag> <round-label>   e.g. r01f r01
+Writes profiles/<round>_kernel_stats.csv, <round>_counters.json, <round>_bench.json, <round>_testspeed.txt and
+profiles/traffic_latest.json (read by bench.py for roofline.traffic).
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: separate --pmc passes for FETCH_SIZE and
+WRITE_SIZE, bytes = counter * 1024, and FETCH_SIZE doubled (gfx950 reports half of a streaming read).
+"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, rnd = sys.argv[1], sys.argv[2]
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "prof_trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, rnd + "_kernel_stats.csv"))
+avg_ns = None
+for row in csv.DictReader(open(stats)):
+    if "hb_step_kernel" in row["Name"]:
+        avg_ns = float(row["AverageNs"]); calls = int(row["Calls"])
+counters = {}
+meta = {}
+for d in ("prof_fetch", "prof_write", "prof_sq", "prof_lds"):
+    fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    if not fs:
+        continue
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(fs[0])):
+        if "hb_step_kernel" in row["Kernel_Name"]:
+            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            meta = {k: row[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+    for k, v in agg.items():
+        counters[k] = {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "dispatches": len(v)}
+n_env = 4096
+out = {"kernel": "hb_step_kernel", "launch": "4096 envs (one wave each), 1 step per launch, bench.py workload",
+       "avg_launch_ns_kernel_trace": avg_ns, "kernel_trace_calls": calls, "dispatch_meta": meta, "counters_per_launch": counters}
+if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+    fetch, write = counters["FETCH_SIZE"]["mean"] * 1024, counters["WRITE_SIZE"]["mean"] * 1024
+    hbm = 2 * fetch + write
+    out["hbm"] = {"fetch_bytes_raw": fetch, "write_bytes": write, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 748 * n_env,
+                  "note": "FETCH_SIZE doubled per the gfx950 correction (calibrated for 16 B/lane streams; this kernel reads dwords, so this is an upper estimate)"}
+    json.dump({"hbm_bytes_per_launch": hbm, "source": "profiles/%s_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_round.sh)" % rnd},
+              open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+if "SQ_INSTS_VALU" in counters:
+    w = counters["SQ_WAVES"]["mean"]
+    out["per_wave"] = {k: counters[k]["mean"] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                                                               "SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE") if k in counters}
+    if avg_ns:
+        # fp32 VALU utilisation: wave64 VALU instruction = 64 lanes; peak 157.3 TFLOP/s = 78.6e12 lane-FMA/s
+        out["valu_lane_ops_per_s"] = counters["SQ_INSTS_VALU"]["mean"] * 64 / (avg_ns * 1e-9)
+        out["valu_issue_frac_of_peak"] = out["valu_lane_ops_per_s"] / 78.6e12
+json.dump(out, open(os.path.join(dst, rnd + "_counters.json"), "w"), indent=1)
+for f, name in (("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt")):
+    p = os.path.join(src, f)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, name))
+print(json.dumps({k: out[k] for k in out if k in ("avg_launch_ns_kernel_trace", "hbm", "per_wave", "valu_issue_frac_of_peak")}, indent=1))

@@ -123,6 +123,23 @@ def main():
         elapsed = float(tt.item())
         dist.barrier()
 
+    # Second measurement, reported beside `value`: the same K steps as ONE hb_rollout_dev launch (state
+    # resident on chip, each env advancing through its own K steps without a per-step batch barrier) —
+    # the shape of the reference's C++ harness simulation/mujoco/sample/testspeed.cc:84-103,203-210.
+    batch.reset(perturb=True, env_offset=lo)
+    batch.rollout_dev(ctrl, W)
+    barrier()
+    t1 = time.perf_counter()
+    batch.rollout_dev(ctrl + W * stride, K)
+    batch.sync()
+    elapsed_rollout = time.perf_counter() - t1
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed_rollout], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_rollout = float(tt.item())
+        dist.barrier()
+
     status = batch.status()
     nc, ne, ni = batch.counts()
     if rank == 0:
@@ -144,6 +161,8 @@ def main():
                          "kernel": "hb_step_kernel", "avg_launch_us": launch_us,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_env,
                          "note": "path is latency/VALU bound, not HBM bound (SURVEY.md §8d); see DESIGN.md"},
+            "rollout": {"value": n_env * world * K / elapsed_rollout, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed_rollout / K,
+                        "what": "same K steps as one hb_rollout_dev launch per GPU (no per-step batch barrier; testspeed.cc shape)"},
             "state_check": {"envs_with_warnings": int((status != 0).sum()), "mean_ncon": float(nc.mean()), "mean_nefc": float(ne.mean()),
                             "mean_pgs_iters": float(ni.mean())},
         }

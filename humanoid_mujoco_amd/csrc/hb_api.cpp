@@ -33,6 +33,7 @@ struct TableBuilder {
   std::vector<unsigned long long> uv;
   size_t addi(const std::vector<int>& v) { size_t o = iv.size(); iv.insert(iv.end(), v.begin(), v.end()); if (v.empty()) iv.push_back(0); return o; }
   size_t addf(const std::vector<double>& v) { size_t o = fv.size(); for (double x : v) fv.push_back((float)x); if (v.empty()) fv.push_back(0.f); return o; }
+  size_t addraw(const std::vector<float>& v) { while (fv.size() % 4) fv.push_back(0.f); size_t o = fv.size(); fv.insert(fv.end(), v.begin(), v.end()); return o; }
   size_t addu(const std::vector<unsigned long long>& v) { size_t o = uv.size(); uv.insert(uv.end(), v.begin(), v.end()); if (v.empty()) uv.push_back(0); return o; }
 };
 
@@ -158,6 +159,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     }
   }
   desc_adr[nv] = (int)desc_pack.size();
+  for (int i = 0; i < 4; i++) desc_pack.push_back(0);  // the half-solve reads four entries at a time
   std::vector<int> hs_pack;
   for (int k = nv - 1; k >= 0; k--) {
     int e = m.dof_Madr[k] + 1;
@@ -214,6 +216,43 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   }
   dm.nobs = 2 * nscalar + 6;
 
+  // level-ordered body records, dof records, packed M entries (layouts in hb_device.hpp)
+  std::vector<float> brec((size_t)nb * kBrecQuads * 4, 0.f);
+  auto fi = [](int v) { float f; memcpy(&f, &v, 4); return f; };
+  for (int sl = 0; sl < nb; sl++) {
+    int b = level_body[sl];
+    float* r = &brec[(size_t)sl * kBrecQuads * 4];
+    if (m.body_jntnum[b] > 3) { err = "at most 3 joints per body are supported (body '" + m.body_name[b] + "')"; return false; }
+    if (childnum[b] > 8) { err = "at most 8 child bodies per body are supported (body '" + m.body_name[b] + "')"; return false; }
+    r[0] = fi(b); r[1] = fi(m.body_parentid[b]); r[2] = fi(m.body_jntnum[b]); r[3] = fi(m.body_jntadr[b]);
+    r[4] = fi(m.body_dofadr[b]); r[5] = fi(treeid[b]); r[6] = (float)m.body_mass[b]; r[7] = fi(childnum[b]);
+    for (int i = 0; i < 3; i++) { r[8 + i] = (float)m.body_pos[3 * b + i]; r[16 + i] = (float)m.body_ipos[3 * b + i]; r[24 + i] = (float)m.body_inertia[3 * b + i]; }
+    for (int i = 0; i < 4; i++) { r[12 + i] = (float)m.body_quat[4 * b + i]; r[20 + i] = (float)m.body_iquat[4 * b + i]; }
+    for (int c = 0; c < 8; c++) r[28 + c] = fi(c < childnum[b] ? child_list[childadr[b] + c] : 0);
+    for (int jj = 0; jj < m.body_jntnum[b]; jj++) {
+      int j = m.body_jntadr[b] + jj;
+      float* q = r + 36 + 12 * jj;
+      q[0] = fi(m.jnt_type[j]); q[1] = fi(m.jnt_qposadr[j]); q[2] = fi(m.jnt_dofadr[j]); q[3] = (float)m.qpos0[m.jnt_qposadr[j]];
+      for (int i = 0; i < 3; i++) { q[4 + i] = (float)m.jnt_axis[3 * j + i]; q[8 + i] = (float)m.jnt_pos[3 * j + i]; }
+    }
+  }
+  std::vector<float> drec((size_t)nv * 12, 0.f);
+  for (int d = 0; d < nv; d++) {
+    int j = m.dof_jntid[d], b = m.dof_bodyid[d];
+    float* r = &drec[(size_t)d * 12];
+    r[0] = fi(j); r[1] = fi(b); r[2] = fi(m.jnt_type[j]); r[3] = fi(d - m.jnt_dofadr[j]);
+    r[4] = fi(treeid[b]); r[5] = (float)m.dof_armature[d]; r[6] = (float)m.dof_damping[d]; r[7] = (float)m.jnt_stiffness[j];
+    r[8] = fi(m.jnt_qposadr[j]); r[9] = (float)m.qpos_spring[m.jnt_qposadr[j]];
+  }
+  std::vector<int> mrec(m.nM);
+  std::vector<float> mdiag((size_t)m.nM * 2, 0.f);
+  for (int e = 0; e < m.nM; e++) {
+    mrec[e] = Mi[e] | (Mj[e] << 8) | (m.dof_bodyid[Mi[e]] << 16);
+    if (Mi[e] == Mj[e]) { mdiag[2 * e] = (float)m.dof_armature[Mi[e]]; mdiag[2 * e + 1] = (float)m.dof_damping[Mi[e]]; }
+  }
+  for (int i = 0; i < nv; i++)
+    if (nanc[i] > kMaxAnc) { err = "kinematic chains deeper than " + std::to_string(kMaxAnc + 1) + " dofs are not supported"; return false; }
+
   // ---- offsets into the flat tables
   struct IO { const int** p; size_t o; };
   struct FO { const float** p; size_t o; };
@@ -230,7 +269,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TF(jnt_pos, m.jnt_pos); TF(jnt_axis, m.jnt_axis); TF(jnt_stiffness, m.jnt_stiffness); TF(qpos0, m.qpos0); TF(qpos_spring, m.qpos_spring);
   TI(dof_bodyid, m.dof_bodyid); TI(dof_jntid, m.dof_jntid); TI(dof_parentid, m.dof_parentid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TI(dof_qposadr, dof_qposadr);
   TF(dof_armature, m.dof_armature); TF(dof_damping, m.dof_damping);
-  TI(M_i, Mi); TI(M_j, Mj);
+  TI(M_i, Mi); TI(M_j, Mj); TI(mrec, mrec);
   while (T.iv.size() % 4) T.iv.push_back(0);  // int4 alignment of the pivot table
   size_t o_piv = T.addi(piv4);
   TI(fac_pack, fac_pack); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(hs_pack, hs_pack);
@@ -248,6 +287,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
 #undef TI
 #undef TF
   size_t o_mask = T.addu(dofmask);
+  size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag);
 
   // ---- LDS layout
   int off = 0;
@@ -284,6 +324,9 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   for (auto& x : fo) *x.p = D.d_flt + x.o;
   dm.body_dofmask = D.d_u64 + o_mask;
   dm.piv = reinterpret_cast<const int4*>(D.d_int + o_piv);
+  dm.brec = reinterpret_cast<const float4*>(D.d_flt + o_brec);
+  dm.drec = reinterpret_cast<const float4*>(D.d_flt + o_drec);
+  dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);
   for (double v : m.key_qpos) qsrc.push_back((float)v);
@@ -310,6 +353,9 @@ struct hb_batch {
   bool diag = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_stamps = nullptr;
+  int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
+  bool order_valid = false;
+  bool schedule = true;
 };
 
 namespace {
@@ -332,8 +378,19 @@ BatchPtrs make_ptrs(hb_batch* b) {
   if (b->diag) { P.diag_qacc = b->d_diag_qacc; P.diag_force = b->d_diag_force; P.diag_contact = b->d_diag_contact; }
   P.n_env = b->n_env;
   P.integrate = 1;
-  P.stamps = b->d_stamps;
+  if (b->schedule && b->order_valid) P.order = b->d_order;
   return P;
+}
+
+
+// launch the step kernel, then (heavy-first scheduling) the tiny kernel that orders the next launch's blocks
+int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, nsteps, b->stream));
+  if (b->schedule) {  // sort the envs by the cost of the step just enqueued, for the next launch
+    HB_HIP(launch_order(b->d_counts, b->d_order, b->n_env, b->stream));
+    b->order_valid = true;
+  }
+  return HB_OK;
 }
 
 // field offsets of the per-env state record for a state spec
@@ -513,6 +570,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
   ok = ok && hipMalloc((void**)&b->d_counts, (size_t)n_env * 4 * sizeof(int)) == hipSuccess;
   ok = ok && hipMemset(b->d_counts, 0, (size_t)n_env * 4 * sizeof(int)) == hipSuccess;
   ok = ok && ensure_ctrl(b, (size_t)n_env * std::max(1, dm.nu)) == HB_OK;
+  ok = ok && hipMalloc((void**)&b->d_order, (size_t)n_env * sizeof(int)) == hipSuccess;
   if (ok && dm.lds_floats * 4 > 64 * 1024) ok = set_step_lds_limit(dm.lds_floats * 4) == hipSuccess;
   if (!ok) { set_err(err, err_sz, "device allocation failed"); hb_batch_free(b); return nullptr; }
   if (hb_reset(b, nullptr, -1, 0, 0) != HB_OK) { set_err(err, err_sz, "initial reset failed"); hb_batch_free(b); return nullptr; }
@@ -526,7 +584,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
-                  b->d_status, b->d_counts, b->d_qpos_out};
+                  b->d_status, b->d_counts, b->d_qpos_out, b->d_order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete b;
 }
@@ -562,8 +620,7 @@ int hb_step_dev(hb_batch* b, const float* ctrl_dev, int n_substeps) {
   HB_HIP(hipSetDevice(b->device));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = ctrl_dev; P.ctrl_mode = 0;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, n_substeps, b->stream));
-  return HB_OK;
+  return launch_steps(b, P, n_substeps);
 }
 
 int hb_step(hb_batch* b, const float* ctrl, int n_substeps) {
@@ -595,8 +652,7 @@ int hb_rollout_dev(hb_batch* b, const float* ctrl_dev, int T, float* qpos_out_de
   HB_HIP(hipSetDevice(b->device));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = ctrl_dev; P.ctrl_mode = 1; P.qpos_out = qpos_out_dev;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, T, b->stream));
-  return HB_OK;
+  return launch_steps(b, P, T);
 }
 
 int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out) {
@@ -625,8 +681,7 @@ int hb_rollout_halton(hb_batch* b, int T, int t0, int env_offset, float* qpos_ou
   HB_HIP(hipSetDevice(b->device));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = nullptr; P.ctrl_mode = 2; P.t0 = t0; P.env_offset = env_offset; P.qpos_out = qpos_out_dev;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, T, b->stream));
-  return HB_OK;
+  return launch_steps(b, P, T);
 }
 
 int hb_state_size(const hb_batch* b, unsigned spec) {

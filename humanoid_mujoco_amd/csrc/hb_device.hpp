@@ -25,6 +25,8 @@ constexpr int kNconMax = 24;    // contact capacity per env (overflow -> HB_WARN
 constexpr int kNefcMax = 63;    // constraint-row capacity per env (overflow -> HB_WARN_CNSTRFULL); lane 63 / row 63 of C carries the extra right-hand side
 constexpr int kConStride = 20;  // floats per contact record in LDS
 constexpr int kDiagConStride = 16;
+constexpr int kMaxAnc = 16;     // deepest dof chain the batched half-solve handles (strict ancestors per dof)
+constexpr int kBrecQuads = 18;  // float4s per level-ordered body record (see build_device_model)
 
 // contact record layout in LDS (floats)
 enum { C_DIST = 0, C_POS = 1, C_FRAME = 4, C_PAIR = 13, C_ROW = 14, C_DIM = 15, C_FRIC = 16 };
@@ -48,6 +50,12 @@ struct DevModel {
   // dof tables
   const int HB_CONST *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_nanc, *dof_qposadr;
   const float HB_CONST *dof_armature, *dof_damping;
+  // level-ordered body records: [0] b,parent,jntnum,jntadr  [1] dofadr,treeid,mass,childnum  [2] pos  [3] quat  [4] ipos
+  // [5] iquat  [6] inertia  [7..8] children[8]  [9+3j] joint j: (type,qposadr,dofadr,qpos0) (axis) (pos)
+  const float4 HB_CONST* brec;
+  const float4 HB_CONST* drec;   // per dof: (jntid,bodyid,type,k) (treeid,armature,damping,stiffness) (qposadr,qpos_spring,-,-)
+  const int HB_CONST* mrec;      // per sparse M entry: i | j << 8 | body(i) << 16
+  const float2 HB_CONST* mdiag;  // per sparse M entry: (armature, damping) on the diagonal, 0 elsewhere
   const int HB_CONST *M_i, *M_j;                                  // dof pair of each sparse mass-matrix entry
   const int4 HB_CONST* piv;                                       // per pivot dof: {#strict ancestors, Madr, first triple, end triple}
   const int HB_CONST* fac_pack;                                   // L^T D L update triples: dst | src << 10 | tmp << 20
@@ -97,6 +105,9 @@ struct BatchPtrs {
   int ctrl_mode;       // 0: ctrl[e][nu] held for all steps; 1: ctrl[t][e][nu]; 2: on-device Halton
   int t0, env_offset;  // Halton indexing
   int integrate;       // 1: mj_step, 0: mj_forward only
+  // heavy-first block scheduling (nullable): blocks take env = order[blockIdx.x], a permutation sorted by
+  // the cost of each env's previous step (counts[4*e+3]) so the most expensive envs are dispatched first
+  const int* order;    // [n_env]
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
 };
 

@@ -229,26 +229,42 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 // L^T D L factorisation of the sparse matrices held in LD and (optionally) LD2 (LDS), lanes =
 // update triples of one pivot dof.  M and H = M + h*diag(damping) share their sparsity, so both
 // are factorised in lockstep: same index traffic, twice the independent arithmetic per lane.
+// The pivot row is read unscaled and never touched again after its pivot, so the division of
+// the off-diagonal entries by D is deferred to one pass at the end (one wave-sync per pivot instead
+// of two); the index words of the next pivot are fetched while the current one is processed.
 template <bool TWO>
 __device__ __forceinline__ void factor_ld(DevModelRef M, float* LD, float* dinv, float* dsqrtinv, float* LD2, float* dinv2, int lane) {
+  int4 pv = M.piv[M.nv - 1];  // nanc, Madr, t0, t1
+  int p0 = (pv.z + lane < pv.w) ? M.fac_pack[pv.z + lane] : -1;
+  int p1 = (pv.z + lane + kGroup < pv.w) ? M.fac_pack[pv.z + lane + kGroup] : -1;
   for (int k = M.nv - 1; k >= 0; k--) {
-    const int4 pv = M.piv[k];  // nanc, Madr, t0, t1
-    const int nanc = pv.x;
-    if (nanc == 0) continue;
-    const int Mkk = pv.y;
+    const int4 cur = pv;
+    const int c0 = p0, c1 = p1;
+    if (k > 0) {
+      pv = M.piv[k - 1];
+      p0 = (pv.z + lane < pv.w) ? M.fac_pack[pv.z + lane] : -1;
+      p1 = (pv.z + lane + kGroup < pv.w) ? M.fac_pack[pv.z + lane + kGroup] : -1;
+    }
+    if (cur.x == 0) continue;
+    const int Mkk = cur.y;
     const float inv = 1.f / fmaxf(LD[Mkk], HB_MINVAL);
     float inv2 = 0.f;
     if (TWO) inv2 = 1.f / fmaxf(LD2[Mkk], HB_MINVAL);
-    for (int t = pv.z + lane; t < pv.w; t += kGroup) {
+    if (c0 >= 0) {
+      const int dst = c0 & 1023, src = (c0 >> 10) & 1023, ti = c0 >> 20;
+      LD[dst] -= LD[src] * (LD[ti] * inv);
+      if (TWO) LD2[dst] -= LD2[src] * (LD2[ti] * inv2);
+    }
+    if (c1 >= 0) {
+      const int dst = c1 & 1023, src = (c1 >> 10) & 1023, ti = c1 >> 20;
+      LD[dst] -= LD[src] * (LD[ti] * inv);
+      if (TWO) LD2[dst] -= LD2[src] * (LD2[ti] * inv2);
+    }
+    for (int t = cur.z + lane + 2 * kGroup; t < cur.w; t += kGroup) {  // pivots with more than 128 triples (deep trees)
       const int pk = M.fac_pack[t];
       const int dst = pk & 1023, src = (pk >> 10) & 1023, ti = pk >> 20;
       LD[dst] -= LD[src] * (LD[ti] * inv);
       if (TWO) LD2[dst] -= LD2[src] * (LD2[ti] * inv2);
-    }
-    gsync();
-    for (int a = lane; a < nanc; a += kGroup) {
-      LD[Mkk + 1 + a] *= inv;
-      if (TWO) LD2[Mkk + 1 + a] *= inv2;
     }
     gsync();
   }
@@ -260,32 +276,50 @@ __device__ __forceinline__ void factor_ld(DevModelRef M, float* LD, float* dinv,
     if (TWO) dinv2[i] = 1.f / fmaxf(LD2[a], HB_MINVAL);
   }
   gsync();
+  for (int e = lane; e < M.nM; e += kGroup) {  // L[k,i] = M'[k,i] / D[k]
+    const int pk = M.mrec[e];
+    const int i = pk & 255, j = (pk >> 8) & 255;
+    if (i != j) {
+      LD[e] *= dinv[i];
+      if (TWO) LD2[e] *= dinv2[i];
+    }
+  }
+  gsync();
 }
 
-// x <- L^-T x (single vector in LDS): pivots descending, push to ancestors
+// x <- L^-T x (single vector in LDS): pivots descending, push to ancestors (lane a = a-th ancestor)
 __device__ __forceinline__ void solve_lt_push(DevModelRef M, const float* LD, float* x, int lane) {
+  int4 pv = M.piv[M.nv - 1];
+  int anc = (lane < pv.x) ? M.M_j[pv.y + 1 + lane] : 0;
   for (int k = M.nv - 1; k >= 0; k--) {
-    const int4 pv = M.piv[k];
-    const int nanc = pv.x;
-    if (nanc == 0) continue;
-    const int Mkk = pv.y;
-    const float xk = x[k];
-    if (lane < nanc) {
-      const int i = M.M_j[Mkk + 1 + lane];  // the lane-th ancestor of k
-      x[i] -= LD[Mkk + 1 + lane] * xk;
+    const int4 cur = pv;
+    const int i = anc;
+    if (k > 0) {
+      pv = M.piv[k - 1];
+      anc = (lane < pv.x) ? M.M_j[pv.y + 1 + lane] : 0;
     }
+    if (cur.x == 0) continue;
+    const float xk = x[k];
+    if (lane < cur.x) x[i] -= LD[cur.y + 1 + lane] * xk;
     gsync();
   }
 }
 // x <- L^-1 x (single vector in LDS): dofs ascending, push to descendants
 __device__ __forceinline__ void solve_l_push(DevModelRef M, const float* LD, float* x, int lane) {
+  int t0 = M.desc_adr[0], t1 = M.desc_adr[1];
+  int pk = (t0 + lane < t1) ? M.desc_pack[t0 + lane] : -1;
   for (int i = 0; i < M.nv; i++) {
-    const int t0 = M.desc_adr[i], t1 = M.desc_adr[i + 1];
-    if (t0 == t1) continue;
+    const int c0 = t0, c1 = t1, cpk = pk;
+    if (i + 1 < M.nv) {
+      t0 = c1; t1 = M.desc_adr[i + 2];
+      pk = (t0 + lane < t1) ? M.desc_pack[t0 + lane] : -1;
+    }
+    if (c0 == c1) continue;
     const float xi = x[i];
-    for (int t = t0 + lane; t < t1; t += kGroup) {
-      const int pk = M.desc_pack[t];  // k | address of L[k,i] << 8
-      x[pk & 255] -= LD[pk >> 8] * xi;
+    if (cpk >= 0) x[cpk & 255] -= LD[cpk >> 8] * xi;  // k | address of L[k,i] << 8
+    for (int t = c0 + lane + kGroup; t < c1; t += kGroup) {
+      const int q = M.desc_pack[t];
+      x[q & 255] -= LD[q >> 8] * xi;
     }
     gsync();
   }
@@ -299,9 +333,10 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   // scalar loads through the scalar cache instead of living in (and spilling from) SGPRs
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
   extern __shared__ float lds[];
-  const int lane = threadIdx.x;
-  const int env = blockIdx.x;
-  if (env >= P.n_env) return;
+  const int lane0 = threadIdx.x;
+  int lane = lane0;
+  if ((int)blockIdx.x >= P.n_env) return;
+  const int env = P.order ? P.order[blockIdx.x] : (int)blockIdx.x;
   const int nv = M.nv, nq = M.nq, nb = M.nbody, cs = M.cstride;
 
   float* s_qpos = lds + M.o_qpos;
@@ -360,7 +395,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   gsync();
 
   for (int step = 0; step < nsteps; step++) {
-    asm volatile("" ::: "memory");  // keep model-table loads inside the step (no hoisting out of the rollout loop)
+    // re-materialise the lane id every step: keeps per-lane table addresses and loads inside the step
+    // instead of hoisted out of the rollout loop into long-lived (spilled) registers
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0) : "memory");
     HB_STAMP(0);
     // ---------------------------------------------------------------- controls
     if (P.ctrl_mode == 2) {
@@ -387,40 +424,48 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
 
     HB_STAMP(1);
     // ---------------------------------------------------------------- mj_kinematics
+    // Tree passes read one level-ordered record per body (M.brec: parent, joints, frames, children
+    // in kBrecQuads float4s) so that all table loads of a lane are independent of each other.
     if (lane == 0) {
       st3(s_xpos, {0.f, 0.f, 0.f}); stq(s_xquat, {1.f, 0.f, 0.f, 0.f}); st3(s_xipos, {0.f, 0.f, 0.f});
       for (int i = 0; i < 9; i++) s_xmat[i] = (i % 4 == 0) ? 1.f : 0.f;
     }
     gsync();
     for (int L = 1; L < M.nlevel; L++) {
-      int n = M.level_num[L], adr = M.level_adr[L];
+      const int n = M.level_num[L], adr = M.level_adr[L];
       for (int idx = lane; idx < n; idx += kGroup) {
-        int b = M.level_body[adr + idx];
-        int p = M.body_parentid[b];
-        int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
+        const float4 HB_CONST* R = M.brec + (size_t)(adr + idx) * kBrecQuads;
+        const float4 q0 = R[0], bp = R[2], bq = R[3], ip = R[4];
+        const int b = __float_as_int(q0.x), p = __float_as_int(q0.y), jn = __float_as_int(q0.z), ja = __float_as_int(q0.w);
+        float4 JA[3], JB[3], JC[3];
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) { JA[jj] = R[9 + 3 * jj]; JB[jj] = R[10 + 3 * jj]; JC[jj] = R[11 + 3 * jj]; }
         V3 pos;
         Q4 quat;
-        if (jn == 1 && M.jnt_type[ja] == 0) {
-          int qa = M.jnt_qposadr[ja];
+        if (jn == 1 && __float_as_int(JA[0].x) == 0) {
+          const int qa = __float_as_int(JA[0].y);
           pos = ld3(s_qpos + qa);
           quat = qnormalize(ldq(s_qpos + qa + 3));
           st3(s_xanchor + 3 * ja, pos);
-          st3(s_xaxis + 3 * ja, ld3(M.jnt_axis + 3 * ja));
+          st3(s_xaxis + 3 * ja, {JB[0].x, JB[0].y, JB[0].z});
         } else {
-          pos = mrot(s_xmat + 9 * p, ld3(M.body_pos + 3 * b)) + ld3(s_xpos + 3 * p);
-          quat = qmul(ldq(s_xquat + 4 * p), ldq(M.body_quat + 4 * b));
-          for (int jj = 0; jj < jn; jj++) {
-            int j = ja + jj, qa = M.jnt_qposadr[j];
-            V3 laxis = ld3(M.jnt_axis + 3 * j), lpos = ld3(M.jnt_pos + 3 * j);
-            V3 axis = qrot(quat, laxis);
-            V3 anchor = qrot(quat, lpos) + pos;
-            st3(s_xaxis + 3 * j, axis);
-            st3(s_xanchor + 3 * j, anchor);
-            float dq = s_qpos[qa] - M.qpos0[qa];
-            if (M.jnt_type[j] == 2) pos = pos + axis * dq;
-            else {
-              quat = qmul(quat, axisangle(laxis, dq));
-              pos = anchor - qrot(quat, lpos);
+          pos = mrot(s_xmat + 9 * p, {bp.x, bp.y, bp.z}) + ld3(s_xpos + 3 * p);
+          quat = qmul(ldq(s_xquat + 4 * p), {bq.x, bq.y, bq.z, bq.w});
+#pragma unroll
+          for (int jj = 0; jj < 3; jj++) {
+            if (jj < jn) {
+              const int j = ja + jj, qa = __float_as_int(JA[jj].y);
+              const V3 laxis = {JB[jj].x, JB[jj].y, JB[jj].z}, lpos = {JC[jj].x, JC[jj].y, JC[jj].z};
+              const V3 axis = qrot(quat, laxis);
+              const V3 anchor = qrot(quat, lpos) + pos;
+              st3(s_xaxis + 3 * j, axis);
+              st3(s_xanchor + 3 * j, anchor);
+              const float dq = s_qpos[qa] - JA[jj].w;
+              if (__float_as_int(JA[jj].x) == 2) pos = pos + axis * dq;
+              else {
+                quat = qmul(quat, axisangle(laxis, dq));
+                pos = anchor - qrot(quat, lpos);
+              }
             }
           }
           quat = qnormalize(quat);
@@ -430,7 +475,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         float mat[9];
         q2mat(mat, quat);
         for (int i = 0; i < 9; i++) s_xmat[9 * b + i] = mat[i];
-        st3(s_xipos + 3 * b, pos + mrot(mat, ld3(M.body_ipos + 3 * b)));
+        st3(s_xipos + 3 * b, pos + mrot(mat, {ip.x, ip.y, ip.z}));
       }
       gsync();
     }
@@ -445,19 +490,25 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     // ---------------------------------------------------------------- mj_comPos
     for (int t = 0; t < M.ntree; t++) {
       V3 acc = {0.f, 0.f, 0.f};
-      for (int b = 1 + lane; b < nb; b += kGroup)
-        if (M.body_treeid[b] == t) acc = acc + ld3(s_xipos + 3 * b) * M.body_mass[b];
+      for (int sl = 1 + lane; sl < nb; sl += kGroup) {
+        const float4 HB_CONST* R = M.brec + (size_t)sl * kBrecQuads;
+        const float4 q0 = R[0], q1 = R[1];
+        if (__float_as_int(q1.y) == t) acc = acc + ld3(s_xipos + 3 * __float_as_int(q0.x)) * q1.z;
+      }
       float im = M.tree_invmass[t];
       float sx = wave_sum(acc.x) * im, sy = wave_sum(acc.y) * im, sz = wave_sum(acc.z) * im;
       if (lane == 0) st3(s_scom + 3 * t, {sx, sy, sz});
     }
     gsync();
-    for (int b = 1 + lane; b < nb; b += kGroup) {
-      V3 com = ld3(s_scom + 3 * M.body_treeid[b]);
+    for (int sl = 1 + lane; sl < nb; sl += kGroup) {
+      const float4 HB_CONST* R = M.brec + (size_t)sl * kBrecQuads;
+      const float4 q0 = R[0], q1 = R[1], iq = R[5], in4 = R[6];
+      const int b = __float_as_int(q0.x);
+      V3 com = ld3(s_scom + 3 * __float_as_int(q1.y));
       V3 dif = ld3(s_xipos + 3 * b) - com;
       float mat[9];
-      q2mat(mat, qmul(ldq(s_xquat + 4 * b), ldq(M.body_iquat + 4 * b)));
-      float in0 = M.body_inertia[3 * b], in1 = M.body_inertia[3 * b + 1], in2 = M.body_inertia[3 * b + 2], mass = M.body_mass[b];
+      q2mat(mat, qmul(ldq(s_xquat + 4 * b), {iq.x, iq.y, iq.z, iq.w}));
+      const float in0 = in4.x, in1 = in4.y, in2 = in4.z, mass = q1.z;
       float t[9];
       for (int r = 0; r < 3; r++) { t[3 * r] = mat[3 * r] * in0; t[3 * r + 1] = mat[3 * r + 1] * in1; t[3 * r + 2] = mat[3 * r + 2] * in2; }
       float* res = s_cinert + 10 * b;
@@ -471,8 +522,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     if (lane < 10) s_cinert[lane] = 0.f;
     for (int d = lane; d < nv; d += kGroup) {
-      int j = M.dof_jntid[d], b = M.dof_bodyid[d], type = M.jnt_type[j], k = d - M.jnt_dofadr[j];
-      V3 off = ld3(s_scom + 3 * M.body_treeid[b]) - ld3(s_xanchor + 3 * j);
+      const float4 dA = M.drec[3 * d], dB = M.drec[3 * d + 1];
+      const int j = __float_as_int(dA.x), b = __float_as_int(dA.y), type = __float_as_int(dA.z), k = __float_as_int(dA.w);
+      V3 off = ld3(s_scom + 3 * __float_as_int(dB.x)) - ld3(s_xanchor + 3 * j);
       V3 ang = {0.f, 0.f, 0.f}, lin = {0.f, 0.f, 0.f};
       if (type == 0) {
         if (k < 3) { lin = {k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f}; }
@@ -502,29 +554,35 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     for (int i = lane; i < 10 * nb; i += kGroup) s_crb[i] = s_cinert[i];
     gsync();
     for (int L = M.nlevel - 2; L >= 1; L--) {
-      int n = M.level_num[L] * 10, adr = M.level_adr[L];
+      const int n = M.level_num[L] * 10, adr = M.level_adr[L];
       for (int idx = lane; idx < n; idx += kGroup) {
-        int b = M.level_body[adr + idx / 10], c = idx % 10;
-        int ca = M.body_childadr[b], cn = M.body_childnum[b];
+        const float4 HB_CONST* R = M.brec + (size_t)(adr + idx / 10) * kBrecQuads;
+        const float4 q0 = R[0], q1 = R[1], c0 = R[7], c1 = R[8];
+        const int b = __float_as_int(q0.x), c = idx % 10, cn = __float_as_int(q1.w);
+        const int ch[8] = {__float_as_int(c0.x), __float_as_int(c0.y), __float_as_int(c0.z), __float_as_int(c0.w),
+                           __float_as_int(c1.x), __float_as_int(c1.y), __float_as_int(c1.z), __float_as_int(c1.w)};
         float acc = s_crb[10 * b + c];
-        for (int k = 0; k < cn; k++) acc += s_crb[10 * M.child_list[ca + k] + c];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < cn) acc += s_crb[10 * ch[k] + c];
         s_crb[10 * b + c] = acc;
       }
       gsync();
     }
     for (int e = lane; e < M.nM; e += kGroup) {
-      int i = M.M_i[e], j = M.M_j[e];
+      const int pk = M.mrec[e];  // i | j << 8 | body(i) << 16
+      const float2 ad = M.mdiag[e];  // (armature, damping) on diagonal entries, 0 elsewhere
+      const int i = pk & 255, j = (pk >> 8) & 255, bi = pk >> 16;
       float buf[6], cd[6];
       for (int t = 0; t < 6; t++) cd[t] = s_cdof[6 * i + t];
       float in[10];
-      for (int t = 0; t < 10; t++) in[t] = s_crb[10 * M.dof_bodyid[i] + t];
+      for (int t = 0; t < 10; t++) in[t] = s_crb[10 * bi + t];
       mul_inert_vec(buf, in, cd);
-      float s = 0.f;
-      for (int t = 0; t < 6; t++) s += s_cdof[6 * j + t] * buf[t];
-      if (i == j) s += M.dof_armature[i];
-      s_qLD[e] = s;
+      float sacc = 0.f;
+      for (int t = 0; t < 6; t++) sacc += s_cdof[6 * j + t] * buf[t];
+      sacc += ad.x;
+      s_qLD[e] = sacc;
       // H = M + h diag(damping): matrix of the implicit-damping Euler solve (mj_Euler), factorised alongside M
-      s_qH[e] = (i == j) ? s + M.timestep * M.dof_damping[i] : s;
+      s_qH[e] = sacc + M.timestep * ad.y;
     }
     gsync();
     HB_STAMP(4);
@@ -541,37 +599,43 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     gsync();
     for (int L = 1; L < M.nlevel; L++) {
-      int n = M.level_num[L], adr = M.level_adr[L];
+      const int n = M.level_num[L], adr = M.level_adr[L];
       for (int idx = lane; idx < n; idx += kGroup) {
-        int b = M.level_body[adr + idx], p = M.body_parentid[b];
+        const float4 HB_CONST* R = M.brec + (size_t)(adr + idx) * kBrecQuads;
+        const float4 q0 = R[0];
+        const float4 JA[3] = {R[9], R[12], R[15]};
+        const int b = __float_as_int(q0.x), p = __float_as_int(q0.y), jn = __float_as_int(q0.z);
         float cvel[6], cacc[6], t[6], cd[6];
         for (int i = 0; i < 6; i++) { cvel[i] = s_cvel[6 * p + i]; cacc[i] = s_cacc[6 * p + i]; }
-        int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
-        for (int jj = 0; jj < jn; jj++) {
-          int j = ja + jj, da = M.jnt_dofadr[j];
-          if (M.jnt_type[j] == 0) {
-            for (int k = 0; k < 3; k++) {
-              float qv = s_qvel[da + k];
-              for (int i = 0; i < 6; i++) { s_cdofdot[6 * (da + k) + i] = 0.f; cvel[i] += s_cdof[6 * (da + k) + i] * qv; }
+        if (jn == 1 && __float_as_int(JA[0].x) == 0) {
+          const int da = __float_as_int(JA[0].z);
+          for (int k = 0; k < 3; k++) {
+            float qv = s_qvel[da + k];
+            for (int i = 0; i < 6; i++) { s_cdofdot[6 * (da + k) + i] = 0.f; cvel[i] += s_cdof[6 * (da + k) + i] * qv; }
+          }
+          float dots[3][6];
+          for (int k = 0; k < 3; k++) {
+            for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * (da + 3 + k) + i];
+            cross_motion(dots[k], cvel, cd);
+          }
+          for (int k = 0; k < 3; k++) {
+            float qv = s_qvel[da + 3 + k];
+            for (int i = 0; i < 6; i++) {
+              s_cdofdot[6 * (da + 3 + k) + i] = dots[k][i];
+              cacc[i] += dots[k][i] * qv;
+              cvel[i] += s_cdof[6 * (da + 3 + k) + i] * qv;
             }
-            float dots[3][6];
-            for (int k = 0; k < 3; k++) {
-              for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * (da + 3 + k) + i];
-              cross_motion(dots[k], cvel, cd);
+          }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 3; jj++) {
+            if (jj < jn) {
+              const int da = __float_as_int(JA[jj].z);
+              float qv = s_qvel[da];
+              for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * da + i];
+              cross_motion(t, cvel, cd);
+              for (int i = 0; i < 6; i++) { s_cdofdot[6 * da + i] = t[i]; cacc[i] += t[i] * qv; cvel[i] += cd[i] * qv; }
             }
-            for (int k = 0; k < 3; k++) {
-              float qv = s_qvel[da + 3 + k];
-              for (int i = 0; i < 6; i++) {
-                s_cdofdot[6 * (da + 3 + k) + i] = dots[k][i];
-                cacc[i] += dots[k][i] * qv;
-                cvel[i] += s_cdof[6 * (da + 3 + k) + i] * qv;
-              }
-            }
-          } else {
-            float qv = s_qvel[da];
-            for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * da + i];
-            cross_motion(t, cvel, cd);
-            for (int i = 0; i < 6; i++) { s_cdofdot[6 * da + i] = t[i]; cacc[i] += t[i] * qv; cvel[i] += cd[i] * qv; }
           }
         }
         float in[10], f0[6], f1[6], f2[6];
@@ -585,12 +649,16 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     // rne backward pass: accumulate child forces into parents (pull form)
     for (int L = M.nlevel - 2; L >= 1; L--) {
-      int n = M.level_num[L] * 6, adr = M.level_adr[L];
+      const int n = M.level_num[L] * 6, adr = M.level_adr[L];
       for (int idx = lane; idx < n; idx += kGroup) {
-        int b = M.level_body[adr + idx / 6], c = idx % 6;
-        int ca = M.body_childadr[b], cn = M.body_childnum[b];
+        const float4 HB_CONST* R = M.brec + (size_t)(adr + idx / 6) * kBrecQuads;
+        const float4 q0 = R[0], q1 = R[1], c0 = R[7], c1 = R[8];
+        const int b = __float_as_int(q0.x), c = idx % 6, cn = __float_as_int(q1.w);
+        const int ch[8] = {__float_as_int(c0.x), __float_as_int(c0.y), __float_as_int(c0.z), __float_as_int(c0.w),
+                           __float_as_int(c1.x), __float_as_int(c1.y), __float_as_int(c1.z), __float_as_int(c1.w)};
         float acc = s_cfrc[6 * b + c];
-        for (int k = 0; k < cn; k++) acc += s_cfrc[6 * M.child_list[ca + k] + c];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < cn) acc += s_cfrc[6 * ch[k] + c];
         s_cfrc[6 * b + c] = acc;
       }
       gsync();
@@ -598,14 +666,14 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     HB_STAMP(6);
     // ---------------------------------------------------------------- qfrc_bias, mj_passive, mj_fwdActuation -> qfrc_smooth
     for (int d = lane; d < nv; d += kGroup) {
+      const float4 dA = M.drec[3 * d], dB = M.drec[3 * d + 1], dC = M.drec[3 * d + 2];
       float bias = 0.f;
-      int b = M.dof_bodyid[d];
+      const int b = __float_as_int(dA.y);
       for (int t = 0; t < 6; t++) bias += s_cdof[6 * d + t] * s_cfrc[6 * b + t];
       float passive = 0.f;
       if (!(M.disableflags & (1 << 5))) {
-        int j = M.dof_jntid[d];
-        if (M.jnt_type[j] >= 2) { int qa = M.jnt_qposadr[j]; passive -= M.jnt_stiffness[j] * (s_qpos[qa] - M.qpos_spring[qa]); }
-        passive -= M.dof_damping[d] * s_qvel[d];
+        if (__float_as_int(dA.z) >= 2) passive -= dB.w * (s_qpos[__float_as_int(dC.x)] - dC.y);
+        passive -= dB.z * s_qvel[d];
       }
       s_smooth[d] = passive - bias;
     }
@@ -863,10 +931,21 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       const bool solverow = rowact || lane == kGroup - 1;
       float* x = s_C + lane * cs;  // lane 63 owns row kNefcMax == 63 (the extra right-hand side)
       if (solverow) {
-        // off-diagonal entries of L in pivot-descending order: x[i] -= L[k,i] * x[k]
-        for (int t = 0; t < M.nhs; t++) {
-          const int pk = M.hs_pack[t];  // e | k << 10 | i << 16
-          x[pk >> 16] -= s_qLD[pk & 1023] * x[(pk >> 10) & 63];
+        // pull form, dofs descending: z_i = x_i - sum over descendants k of L[k,i] z_k.  Only finished
+        // values are read, so the LDS reads of one dof are independent and issued four at a time.
+        for (int i = nv - 1; i >= 0; i--) {
+          const int t0 = M.desc_adr[i], t1 = M.desc_adr[i + 1];
+          float acc = x[i];
+          for (int t = t0; t < t1; t += 4) {
+            const int q0 = M.desc_pack[t], q1 = M.desc_pack[t + 1], q2 = M.desc_pack[t + 2], q3 = M.desc_pack[t + 3];  // table is padded
+            const float l0 = s_qLD[q0 >> 8], l1 = s_qLD[q1 >> 8], l2 = s_qLD[q2 >> 8], l3 = s_qLD[q3 >> 8];
+            const float v0 = x[q0 & 255], v1 = x[q1 & 255], v2 = x[q2 & 255], v3 = x[q3 & 255];
+            acc -= l0 * v0;
+            if (t + 1 < t1) acc -= l1 * v1;
+            if (t + 2 < t1) acc -= l2 * v2;
+            if (t + 3 < t1) acc -= l3 * v3;
+          }
+          x[i] = acc;
         }
         for (int k = 0; k < nv; k++) x[k] *= s_dsqrtinv[k];
       }
@@ -1016,7 +1095,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         P.diag_contact[((size_t)env * kNconMax) * kDiagConStride + idx] = v;
       }
     }
-    if (lane == 0) { int* c = P.counts + 4 * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; }
+    if (lane == 0) { int* c = P.counts + 4 * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; c[3] = nefc * (niter + 4); }
 
     HB_STAMP(14);
     if (P.integrate) {
@@ -1124,6 +1203,33 @@ __global__ void hb_obs_kernel(const DevModel M, const float* state, float* obs, 
 }
 
 
+
+// Heavy-first dispatch order for the next launch: counting sort of the envs by the cost proxy of their
+// last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
+// the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
+// which cannot change results (envs are independent).
+__global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int n_env) {
+  __shared__ int hist[256];
+  __shared__ int base[256];
+  const int tid = threadIdx.x;
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  for (int e = tid; e < n_env; e += blockDim.x) {
+    int key = min(255, counts[4 * e + 3] >> 3);
+    atomicAdd(&hist[255 - key], 1);  // bin 0 = most expensive
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < 256; i++) { base[i] = acc; acc += hist[i]; }
+  }
+  __syncthreads();
+  for (int e = tid; e < n_env; e += blockDim.x) {
+    int key = min(255, counts[4 * e + 3] >> 3);
+    order[atomicAdd(&base[255 - key], 1)] = e;
+  }
+}
+
 // benchmark controls: ctrl[t][e][i] = 2*H(1+t0+t+1000*(env_offset+e), i+2) - 1  (testspeed.cc:64-80)
 __global__ void hb_halton_ctrl_kernel(float* out, int T, int n_env, int nu, int t0, int env_offset) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1154,6 +1260,10 @@ hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint
 }
 hipError_t launch_obs(const DevModel& M, const float* state, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env, hipStream_t stream) {
   hipLaunchKernelGGL(hb_obs_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, obs, reward, terminated, truncated, n_env);
+  return hipGetLastError();
+}
+hipError_t launch_order(const int* counts, int* order, int n_env, hipStream_t stream) {
+  hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, n_env);
   return hipGetLastError();
 }
 hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream) {

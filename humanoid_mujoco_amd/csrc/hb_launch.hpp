@@ -6,6 +6,7 @@ namespace hb {
 hipError_t launch_step(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream);
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, int perturb, int env_offset, hipStream_t stream);
 hipError_t launch_obs(const DevModel& M, const float* state, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env, hipStream_t stream);
+hipError_t launch_order(const int* counts, int* order, int n_env, hipStream_t stream);
 hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream);
 hipError_t set_step_lds_limit(int bytes);
 }  // namespace hb

@@ -1018,11 +1018,19 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       // The row loop is unrolled (ar[i] must be a compile-time register index) in 8-row chunks with
       // scalar guards; nefc and the lane id are re-materialised every sweep so that the 63 guard
       // conditions are cheap scalar compares instead of hoisted, spilled masks.
+      //
+      // The reference reverts a row update whose cost change comes out positive (> 1e-10), which
+      // exact 1-D minimisation never produces.  The fast sweep keeps that test off the dependency
+      // chain (residual -> proposal -> broadcast -> residual): it only records the largest change
+      // seen; if a sweep ever records a positive one, it is replayed from its saved start by the
+      // literal (slow) sweep, so the result is the reference's in every case.
       while (niter < M.iterations) {
         int ne, ln;
         asm volatile("s_mov_b32 %0, %1" : "=s"(ne) : "s"(nefc));
         asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
+        const float force0 = force, res0 = res;
         float improvement = 0.f;  // identical in every lane
+        float worst = 0.f;        // largest cost change of the sweep (identical in every lane)
 #pragma unroll
         for (int c = 0; c < (kNefcMax + 7) / 8; c++) {
           if (c * 8 < ne) {
@@ -1030,15 +1038,32 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
             for (int r = 0; r < 8; r++) {
               const int i = c * 8 + r;
               if (i < kNefcMax && i < ne) {
-                float fnew = fmaxf(0.f, force - res * Ainv);
-                float delta = fnew - force;
-                float change = delta * (0.5f * delta * Aii + res);
-                if (change > 1e-10f) { delta = 0.f; change = 0.f; }
+                const float fnew = fmaxf(0.f, force - res * Ainv);
+                const float delta = fnew - force;
                 const float di = rdlane(delta, i);
-                improvement -= rdlane(change, i);
-                if (ln == i) force += delta;
+                const float change = delta * (0.5f * delta * Aii + res);
                 res += ar[i] * di;
+                const float ci = rdlane(change, i);
+                improvement -= ci;
+                worst = fmaxf(worst, ci);
+                if (ln == i) force = fnew;
               }
+            }
+          }
+        }
+        if (uniformf(worst) > 1e-10f) {  // never taken in practice; literal replay of this sweep
+          force = force0; res = res0; improvement = 0.f;
+#pragma unroll
+          for (int i = 0; i < kNefcMax; i++) {
+            if (i < ne) {
+              float fnew = fmaxf(0.f, force - res * Ainv);
+              float delta = fnew - force;
+              float change = delta * (0.5f * delta * Aii + res);
+              if (change > 1e-10f) { delta = 0.f; change = 0.f; }
+              const float di = rdlane(delta, i);
+              improvement -= rdlane(change, i);
+              if (ln == i) force += delta;
+              res += ar[i] * di;
             }
           }
         }

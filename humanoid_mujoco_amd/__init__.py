@@ -8,4 +8,6 @@ from .engine import (Batch, HbError, Model, lib, LIB_PATH, STATE_INTEGRATION, ST
                      STATE_TIME, STATE_WARMSTART, STATE_XFRC_APPLIED, WARN_BADQACC, WARN_BADQPOS, WARN_BADQVEL,
                      WARN_CNSTRFULL, WARN_CONTACTFULL)
 
-__all__ = ["Batch", "Model", "HbError", "lib", "LIB_PATH"]
+from .vecenv import VecEnv  # noqa: E402,F401
+
+__all__ = ["Batch", "Model", "VecEnv", "HbError", "lib", "LIB_PATH"]

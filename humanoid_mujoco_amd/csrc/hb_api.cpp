@@ -353,6 +353,12 @@ struct hb_batch {
   bool diag = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_stamps = nullptr;
+  // env adapter (hb_env_*)
+  EnvConfig env_cfg;
+  bool env_ready = false;
+  float *d_prev = nullptr, *d_latest = nullptr, *d_qfrc = nullptr, *d_action = nullptr;
+  int* d_episode = nullptr;
+  int env_offset = 0;
   int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
   bool order_valid = false;
   bool schedule = true;
@@ -374,7 +380,7 @@ int ensure_ctrl(hb_batch* b, size_t floats) {
 BatchPtrs make_ptrs(hb_batch* b) {
   BatchPtrs P;
   memset(&P, 0, sizeof P);
-  P.state = b->d_state; P.status = b->d_status; P.counts = b->d_counts; P.xfrc = b->d_xfrc;
+  P.state = b->d_state; P.status = b->d_status; P.counts = b->d_counts; P.xfrc = b->d_xfrc; P.qfrc_out = b->d_qfrc;
   if (b->diag) { P.diag_qacc = b->d_diag_qacc; P.diag_force = b->d_diag_force; P.diag_contact = b->d_diag_contact; }
   P.n_env = b->n_env;
   P.integrate = 1;
@@ -567,8 +573,8 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
   bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&b->d_state, (size_t)n_env * dm.nstate * sizeof(float)) == hipSuccess;
   ok = ok && hipMalloc((void**)&b->d_status, (size_t)n_env * sizeof(int)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&b->d_counts, (size_t)n_env * 4 * sizeof(int)) == hipSuccess;
-  ok = ok && hipMemset(b->d_counts, 0, (size_t)n_env * 4 * sizeof(int)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&b->d_counts, (size_t)n_env * kCountStride * sizeof(int)) == hipSuccess;
+  ok = ok && hipMemset(b->d_counts, 0, (size_t)n_env * kCountStride * sizeof(int)) == hipSuccess;
   ok = ok && ensure_ctrl(b, (size_t)n_env * std::max(1, dm.nu)) == HB_OK;
   ok = ok && hipMalloc((void**)&b->d_order, (size_t)n_env * sizeof(int)) == hipSuccess;
   if (ok && dm.lds_floats * 4 > 64 * 1024) ok = set_step_lds_limit(dm.lds_floats * 4) == hipSuccess;
@@ -584,7 +590,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
-                  b->d_status, b->d_counts, b->d_qpos_out, b->d_order};
+                  b->d_status, b->d_counts, b->d_qpos_out, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete b;
 }
@@ -598,7 +604,7 @@ int hb_batch_sync(hb_batch* b) {
   return HB_OK;
 }
 
-int hb_reset(hb_batch* b, const uint8_t* mask, int keyframe, int perturb, int env_offset) {
+static int reset_impl(hb_batch* b, const uint8_t* mask, int keyframe, float perturb_scale, int env_offset) {
   if (!b) return HB_EINVAL;
   const Model& m = b->model->m;
   if (keyframe >= m.nkey) return HB_EINVAL;
@@ -609,10 +615,15 @@ int hb_reset(hb_batch* b, const uint8_t* mask, int keyframe, int perturb, int en
     HB_HIP(hipMemcpyAsync(b->d_mask, mask, b->n_env, hipMemcpyHostToDevice, b->stream));
     dmask = b->d_mask;
   }
+  b->env_offset = env_offset;
   const float* src = b->D.d_qpos_src + (keyframe < 0 ? 0 : (size_t)(1 + keyframe) * m.nq);
-  HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, dmask, src, b->n_env, perturb, env_offset, b->stream));
+  HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, dmask, src, b->n_env, perturb_scale, env_offset, b->stream));
   HB_HIP(hipStreamSynchronize(b->stream));
   return HB_OK;
+}
+
+int hb_reset(hb_batch* b, const uint8_t* mask, int keyframe, int perturb, int env_offset) {
+  return reset_impl(b, mask, keyframe, perturb ? 1.f : 0.f, env_offset);
 }
 
 int hb_step_dev(hb_batch* b, const float* ctrl_dev, int n_substeps) {
@@ -693,19 +704,141 @@ int hb_set_state(hb_batch* b, unsigned spec, const float* in) { return set_state
 int hb_get_state_f64(hb_batch* b, unsigned spec, double* out) { return get_state_impl<double>(b, spec, out); }
 int hb_set_state_f64(hb_batch* b, unsigned spec, const double* in) { return set_state_impl<double>(b, spec, in); }
 
-int hb_get_obs(hb_batch* b, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated) {
-  if (!b || !obs) return HB_EINVAL;
+static int env_alloc(hb_batch* b) {
+  if (b->env_ready) return HB_OK;
+  const DevModel& dm = b->D.dm;
+  size_t n = b->n_env;
   HB_HIP(hipSetDevice(b->device));
-  int n = b->n_env, nobs = b->D.dm.nobs;
   if (!b->d_obs) {
-    if (hipMalloc((void**)&b->d_obs, (size_t)n * nobs * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_reward, (size_t)n * sizeof(float)) != hipSuccess ||
+    if (hipMalloc((void**)&b->d_obs, n * dm.nobs * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_reward, n * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&b->d_term, n) != hipSuccess || hipMalloc((void**)&b->d_trunc, n) != hipSuccess) return HB_ENOMEM;
   }
-  HB_HIP(launch_obs(b->D.dm, b->d_state, b->d_obs, b->d_reward, b->d_term, b->d_trunc, n, b->stream));
+  size_t nu = std::max(1, dm.nu);
+  if (hipMalloc((void**)&b->d_prev, n * nu * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_latest, n * nu * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&b->d_action, n * nu * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_qfrc, n * dm.nv * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&b->d_episode, n * sizeof(int)) != hipSuccess) return HB_ENOMEM;
+  HB_HIP(hipMemset(b->d_prev, 0, n * nu * sizeof(float)));
+  HB_HIP(hipMemset(b->d_latest, 0, n * nu * sizeof(float)));
+  HB_HIP(hipMemset(b->d_qfrc, 0, n * dm.nv * sizeof(float)));
+  HB_HIP(hipMemset(b->d_episode, 0, n * sizeof(int)));
+  hb_env_config def;
+  hb_env_default_config(b->model, &def);
+  static_assert(sizeof(hb_env_config) == sizeof(EnvConfig), "hb_env_config and EnvConfig must have the same layout");
+  memcpy(&b->env_cfg, &def, sizeof def);
+  b->env_ready = true;
+  return HB_OK;
+}
+
+static int env_eval(hb_batch* b, bool allow_reset, float* d_obs, float* d_reward, uint8_t* d_term, uint8_t* d_trunc) {
+  EnvConfig cfg = b->env_cfg;
+  if (!allow_reset) cfg.auto_reset = 0;
+  const Model& m = b->model->m;
+  const float* src = b->D.d_qpos_src + (cfg.reset_keyframe < 0 || cfg.reset_keyframe >= m.nkey ? 0 : (size_t)(1 + cfg.reset_keyframe) * m.nq);
+  HB_HIP(launch_env(b->D.dm, cfg, b->d_state, b->d_qfrc, b->d_counts, b->d_prev, b->d_latest, src, b->d_episode, b->d_status, d_obs, d_reward, d_term, d_trunc,
+                    b->n_env, b->env_offset, b->stream));
+  return HB_OK;
+}
+
+int hb_get_obs(hb_batch* b, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated) {
+  if (!b || !obs) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  int n = b->n_env, nobs = b->D.dm.nobs;
+  if (reward || terminated || truncated) {
+    rc = env_eval(b, false, b->d_obs, b->d_reward, b->d_term, b->d_trunc);  // pure evaluation: no reset, no bookkeeping
+    if (rc != HB_OK) return rc;
+  } else {
+    HB_HIP(launch_obs(b->D.dm, b->d_state, b->d_obs, n, b->stream));
+  }
   HB_HIP(hipMemcpyAsync(obs, b->d_obs, (size_t)n * nobs * sizeof(float), hipMemcpyDeviceToHost, b->stream));
   if (reward) HB_HIP(hipMemcpyAsync(reward, b->d_reward, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
   if (terminated) HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, b->stream));
   if (truncated) HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, b->stream));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+
+int hb_env_default_config(const hb_model* h, hb_env_config* c) {
+  if (!h || !c) return HB_EINVAL;
+  const Model& m = h->m;
+  memset(c, 0, sizeof *c);
+  double z0 = 1.0;
+  for (int j = 0; j < m.njnt; j++) if (m.jnt_type[j] == JNT_FREE) { z0 = m.qpos0[m.jnt_qposadr[j] + 2]; break; }
+  c->target_z = (float)(0.94 * z0);  // the reference targets its standing height (Z_INITIAL_POS); 6 % slack for the soft stance
+  c->min_z = (float)(0.3 * z0);
+  c->max_time = 10.f;                 // MAX_SIM_TIME_STANDUP
+  double gear = 0;
+  for (int a = 0; a < m.nu; a++) gear += std::fabs(m.actuator_gear[a]);
+  c->safe_torque = (float)(m.nu ? 0.05 * gear / m.nu : 1.0);  // reference: 1.0 N m = 5 % of its 20 N m motors
+  c->control_frequency = (float)(1.0 / m.timestep);
+  c->action_scale = 1.5707963267948966f;
+  c->w_hvel = 5.f; c->w_upright = 10.f; c->w_height = 15.f; c->w_torque = 2.5f; c->w_ctrl_change = 2.f; c->w_ctrl_reg = 0.5f; c->w_symmetry = 1.f;
+  c->self_collision_penalty = -20.f; c->terminal_reward = -100.f; c->upright_tol = 0.7f;
+  // symmetry pairs: actuators named <x>_right / <x>_left (mirrored joint axes in the model => equal controls)
+  for (int a = 0; a < m.nu && c->n_equal < HB_ENV_MAX_PAIRS; a++) {
+    const std::string& n = m.actuator_name[a];
+    const std::string suf = "_right";
+    if (n.size() > suf.size() && n.compare(n.size() - suf.size(), suf.size(), suf) == 0) {
+      std::string other = n.substr(0, n.size() - suf.size()) + "_left";
+      for (int k = 0; k < m.nu; k++) if (m.actuator_name[k] == other) { c->equal_pairs[c->n_equal][0] = k; c->equal_pairs[c->n_equal][1] = a; c->n_equal++; break; }
+    }
+  }
+  c->auto_reset = 1; c->reset_keyframe = -1; c->reset_perturb = 1.f;
+  return HB_OK;
+}
+
+int hb_env_configure(hb_batch* b, const hb_env_config* cfg) {
+  if (!b || !cfg) return HB_EINVAL;
+  if (cfg->n_equal < 0 || cfg->n_equal > HB_ENV_MAX_PAIRS || cfg->n_opposite < 0 || cfg->n_opposite > HB_ENV_MAX_PAIRS || !(cfg->action_scale > 0)) return HB_EINVAL;
+  int nu = b->D.dm.nu;
+  for (int k = 0; k < cfg->n_equal; k++) for (int t = 0; t < 2; t++) if (cfg->equal_pairs[k][t] < 0 || cfg->equal_pairs[k][t] >= nu) return HB_EINVAL;
+  for (int k = 0; k < cfg->n_opposite; k++) for (int t = 0; t < 2; t++) if (cfg->opposite_pairs[k][t] < 0 || cfg->opposite_pairs[k][t] >= nu) return HB_EINVAL;
+  if (cfg->reset_keyframe >= b->model->m.nkey) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  memcpy(&b->env_cfg, cfg, sizeof *cfg);
+  return HB_OK;
+}
+
+int hb_env_reset(hb_batch* b, float* obs) {
+  if (!b || !obs) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  const EnvConfig& c = b->env_cfg;
+  size_t nu = std::max(1, b->D.dm.nu);
+  HB_HIP(hipMemsetAsync(b->d_prev, 0, (size_t)b->n_env * nu * sizeof(float), b->stream));
+  HB_HIP(hipMemsetAsync(b->d_latest, 0, (size_t)b->n_env * nu * sizeof(float), b->stream));
+  HB_HIP(hipMemsetAsync(b->d_episode, 0, (size_t)b->n_env * sizeof(int), b->stream));
+  rc = reset_impl(b, nullptr, c.reset_keyframe, c.reset_perturb, b->env_offset);
+  if (rc != HB_OK) return rc;
+  return hb_get_obs(b, obs, nullptr, nullptr, nullptr);
+}
+
+int hb_env_step_dev(hb_batch* b, const float* action_dev, int n_substeps, float* obs_dev, float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev) {
+  if (!b || !action_dev || n_substeps < 1 || !obs_dev || !reward_dev || !terminated_dev || !truncated_dev) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  int n = b->n_env * b->D.dm.nu;
+  if (n) HB_HIP(launch_action(action_dev, b->d_prev, b->d_latest, b->d_ctrl, n, b->stream));
+  BatchPtrs P = make_ptrs(b);
+  P.ctrl = b->d_ctrl; P.ctrl_mode = 0;
+  rc = launch_steps(b, P, n_substeps);
+  if (rc != HB_OK) return rc;
+  return env_eval(b, true, obs_dev, reward_dev, terminated_dev, truncated_dev);
+}
+
+int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated) {
+  if (!b || !action || !obs || !reward || !terminated || !truncated) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  int n = b->n_env, nu = b->D.dm.nu, nobs = b->D.dm.nobs;
+  if (nu) HB_HIP(hipMemcpyAsync(b->d_action, action, (size_t)n * nu * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  rc = hb_env_step_dev(b, b->d_action, n_substeps, b->d_obs, b->d_reward, b->d_term, b->d_trunc);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipMemcpyAsync(obs, b->d_obs, (size_t)n * nobs * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  HB_HIP(hipMemcpyAsync(reward, b->d_reward, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, b->stream));
+  HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, b->stream));
   HB_HIP(hipStreamSynchronize(b->stream));
   return HB_OK;
 }
@@ -722,12 +855,12 @@ int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   HB_HIP(hipStreamSynchronize(b->stream));
-  std::vector<int> h((size_t)b->n_env * 4);
+  std::vector<int> h((size_t)b->n_env * kCountStride);
   HB_HIP(hipMemcpy(h.data(), b->d_counts, h.size() * sizeof(int), hipMemcpyDeviceToHost));
   for (int e = 0; e < b->n_env; e++) {
-    if (ncon) ncon[e] = h[4 * e];
-    if (nefc) nefc[e] = h[4 * e + 1];
-    if (niter) niter[e] = h[4 * e + 2];
+    if (ncon) ncon[e] = h[kCountStride * e];
+    if (nefc) nefc[e] = h[kCountStride * e + 1];
+    if (niter) niter[e] = h[kCountStride * e + 2];
   }
   return HB_OK;
 }

@@ -25,6 +25,7 @@ constexpr int kNconMax = 24;    // contact capacity per env (overflow -> HB_WARN
 constexpr int kNefcMax = 63;    // constraint-row capacity per env (overflow -> HB_WARN_CNSTRFULL); lane 63 / row 63 of C carries the extra right-hand side
 constexpr int kConStride = 20;  // floats per contact record in LDS
 constexpr int kDiagConStride = 16;
+constexpr int kCountStride = 8;  // ints per env in BatchPtrs::counts: ncon, nefc, niter, cost, self-collision flag, spare
 constexpr int kMaxAnc = 16;     // deepest dof chain the batched half-solve handles (strict ancestors per dof)
 constexpr int kBrecQuads = 18;  // float4s per level-ordered body record (see build_device_model)
 
@@ -91,13 +92,28 @@ struct DevModel {
 
 typedef const DevModel HB_CONST& DevModelRef;
 
+// device copy of hb_env_config (include/hb.h), same field order
+constexpr int kEnvMaxPairs = 16;
+struct EnvConfig {
+  float target_velocity[2];
+  float target_z, min_z, max_time, safe_torque, control_frequency, action_scale;
+  float w_hvel, w_upright, w_height, w_torque, w_ctrl_change, w_ctrl_reg, w_symmetry;
+  float self_collision_penalty, terminal_reward, upright_tol;
+  int n_equal, n_opposite;
+  int equal_pairs[kEnvMaxPairs][2];
+  int opposite_pairs[kEnvMaxPairs][2];
+  int auto_reset, reset_keyframe;
+  float reset_perturb;
+};
+
 struct BatchPtrs {
   float* state;        // [n_env][nstate]
   const float* ctrl;   // [n_env][nu] or [T][n_env][nu]
   float* qpos_out;     // nullable, [T][n_env][nq]
   float* xfrc;         // nullable, [n_env][nbody][6]
   int* status;         // [n_env] accumulated HB_WARN_* bits
-  int* counts;         // [n_env][4] ncon, nefc, niter, spare
+  int* counts;         // [n_env][kCountStride]
+  float* qfrc_out;     // nullable [n_env][nv]: qfrc_smooth + qfrc_constraint of the last step (env adapter's joint torques)
   float* diag_qacc;    // nullable [n_env][nv]
   float* diag_force;   // nullable [n_env][kNefcMax]
   float* diag_contact; // nullable [n_env][kNconMax][kDiagConStride]

@@ -779,6 +779,13 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       if (ncon > kNconMax) { status |= (1 << 1); ncon = kNconMax; }
     }
     ncon = uniform(ncon);
+    // self collision (CPUEnv._check_self_collision, cpu_env.py:576-584): a contact whose geoms both belong to the robot
+    int selfcol = 0;
+    {
+      bool sc = false;
+      if (lane < ncon) sc = M.geom_bodyid[M.pair_geom1[__float_as_int(s_con[lane * kConStride + C_PAIR])]] != 0;
+      selfcol = __any(sc) ? 1 : 0;
+    }
     gsync();
 
     HB_STAMP(8);
@@ -1088,6 +1095,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       float acc = s_v1[i];
       for (int t = M.desc_adr[i]; t < M.desc_adr[i + 1]; t++) { const int pk = M.desc_pack[t]; acc += s_qLD[pk >> 8] * s_v1[pk & 255]; }
       s_v2[i] = s_smooth[i] + acc;  // qfrc_smooth + qfrc_constraint: right-hand side of the Euler solve
+      if (P.qfrc_out) P.qfrc_out[(size_t)env * nv + i] = s_v2[i];
     }
     gsync();
     // mj_checkAcc
@@ -1120,7 +1128,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         P.diag_contact[((size_t)env * kNconMax) * kDiagConStride + idx] = v;
       }
     }
-    if (lane == 0) { int* c = P.counts + 4 * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; c[3] = nefc * (niter + 4); }
+    if (lane == 0) { int* c = P.counts + kCountStride * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; c[3] = nefc * (niter + 4); c[4] = selfcol; }
 
     HB_STAMP(14);
     if (P.integrate) {
@@ -1172,7 +1180,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
 
 // ------------------------------------------------------------------------------------------
 // reset: qpos0/keyframe (+ Halton perturbation), zero velocity/warmstart/time/status
-__global__ void hb_reset_kernel(const DevModel M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, int perturb, int env_offset) {
+__global__ void hb_reset_kernel(const DevModel M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, float perturb, int env_offset) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_env) return;
   if (mask && !mask[e]) return;
@@ -1180,54 +1188,145 @@ __global__ void hb_reset_kernel(const DevModel M, float* state, int* status, con
   s[0] = 0.f;
   for (int i = 0; i < M.nq; i++) s[1 + i] = qpos_src[i];
   for (int i = 0; i < 2 * M.nv; i++) s[1 + M.nq + i] = 0.f;
-  if (perturb) {
+  if (perturb > 0.f) {
     for (int j = 0; j < M.njnt; j++) {
       int qa = M.jnt_qposadr[j];
-      if (M.jnt_type[j] == 0) s[1 + qa + 2] += 0.1f * halton(env_offset + e + 1, 3);
-      else s[1 + qa] += 0.2f * (2.f * halton(env_offset + e + 1, 2 + j) - 1.f);
+      if (M.jnt_type[j] == 0) s[1 + qa + 2] += perturb * 0.1f * halton(env_offset + e + 1, 3);
+      else s[1 + qa] += perturb * 0.2f * (2.f * halton(env_offset + e + 1, 2 + j) - 1.f);
     }
   }
   status[e] = 0;
 }
 
-// env adapter: observation / reward / done, the 27-DoF analogue of CPUEnv._get_obs (cpu_env.py:465-571)
-__global__ void hb_obs_kernel(const DevModel M, const float* state, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_env) return;
-  const float* s = state + (size_t)e * M.nstate;
+// env adapter: observation, the 27-DoF analogue of CPUEnv._get_obs (cpu_env.py:465-571):
+// [hinge/slide qpos, hinge/slide qvel, root angular velocity, gravity direction in the root body frame]
+__device__ __forceinline__ void compute_obs(const DevModel& M, const float* s, float* o, float* g_local, float* root_z) {
   const float* qpos = s + 1;
   const float* qvel = s + 1 + M.nq;
-  float* o = obs + (size_t)e * M.nobs;
-  int nh = 0;
+  int k = 0;
   for (int j = 0; j < M.njnt; j++)
-    if (M.jnt_type[j] >= 2) { o[nh++] = qpos[M.jnt_qposadr[j]]; }
-  int k = nh;
+    if (M.jnt_type[j] >= 2) o[k++] = qpos[M.jnt_qposadr[j]];
   for (int j = 0; j < M.njnt; j++)
-    if (M.jnt_type[j] >= 2) { o[k++] = qvel[M.jnt_dofadr[j]]; }
-  int da = M.obs_root_dofadr;
+    if (M.jnt_type[j] >= 2) o[k++] = qvel[M.jnt_dofadr[j]];
+  const int da = M.obs_root_dofadr;
   Q4 q = {1.f, 0.f, 0.f, 0.f};
+  float z = 0.f;
   if (da >= 0) {
     for (int i = 0; i < 3; i++) o[k++] = qvel[da + 3 + i];
-    int qa = M.jnt_qposadr[M.dof_jntid[da]];
+    const int qa = M.jnt_qposadr[M.dof_jntid[da]];
     q = qnormalize(ldq(qpos + qa + 3));
+    z = qpos[qa + 2];
   } else {
     for (int i = 0; i < 3; i++) o[k++] = 0.f;
   }
   // gravity direction in the torso frame: R(q)^T (0,0,-1)  (cpu_env.py:510-519)
   float m[9];
   q2mat(m, q);
-  o[k++] = -m[6]; o[k++] = -m[7]; o[k++] = -m[8];
-  if (reward) {
-    // upright + height shaping in the spirit of standupReward (reward_functions.py:247-374); see DESIGN.md
-    float up = -(-m[8]);  // cos of tilt
-    float z = da >= 0 ? qpos[M.jnt_qposadr[M.dof_jntid[da]] + 2] : 0.f;
-    reward[e] = 10.f * expf(-(1.f - up) / 0.5f) + z;
-  }
-  if (terminated) terminated[e] = 0;
-  if (truncated) truncated[e] = 0;
+  g_local[0] = -m[6]; g_local[1] = -m[7]; g_local[2] = -m[8];
+  o[k++] = g_local[0]; o[k++] = g_local[1]; o[k++] = g_local[2];
+  *root_z = z;
 }
 
+__global__ void hb_obs_kernel(const DevModel M, const float* state, float* obs, int n_env) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env) return;
+  float g[3], z;
+  compute_obs(M, state + (size_t)e * M.nstate, obs + (size_t)e * M.nobs, g, &z);
+}
 
+// CPUEnv._apply_action bookkeeping (cpu_env.py:656-674): previous <- latest, latest <- action, ctrl <- action
+__global__ void hb_action_kernel(const float* action, float* prev, float* latest, float* ctrl, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  prev[i] = latest[i];
+  float a = action[i];
+  latest[i] = a;
+  ctrl[i] = a;
+}
+
+__device__ __forceinline__ float scaled_exp(float x) { return expf(-x / 0.5f); }  // reward_functions.py:17-19
+
+// standupReward (reward_functions.py:247-374) + observation + termination + auto-reset, one thread per env
+__global__ void hb_env_kernel(const DevModel M, const EnvConfig cfg, float* state, const float* qfrc, const int* counts, float* prev, float* latest,
+                              const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env,
+                              int env_offset) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env) return;
+  float* s = state + (size_t)e * M.nstate;
+  float* o = obs + (size_t)e * M.nobs;
+  float g[3], z;
+  compute_obs(M, s, o, g, &z);
+  const float* qvel = s + 1 + M.nq;
+  const int da = M.obs_root_dofadr;
+  float r = 0.f;
+  // horizontal velocity
+  float vx = da >= 0 ? qvel[da] : 0.f, vy = da >= 0 ? qvel[da + 1] : 0.f;
+  float dvx = vx - cfg.target_velocity[0], dvy = vy - cfg.target_velocity[1];
+  r += cfg.w_hvel * scaled_exp(dvx * dvx + dvy * dvy);
+  // upright: |g_local - (0,0,-1)|^2
+  r += cfg.w_upright * scaled_exp(g[0] * g[0] + g[1] * g[1] + (g[2] + 1.f) * (g[2] + 1.f));
+  // torso height: linear ramp min_z -> target_z, clamped (numpy.interp)
+  float t = (z - cfg.min_z) / fmaxf(cfg.target_z - cfg.min_z, 1e-9f);
+  r += cfg.w_height * fminf(fmaxf(t, 0.f), 1.f);
+  // joint torques on the scalar joints' dofs
+  {
+    float acc = 0.f;
+    int n = 0;
+    for (int j = 0; j < M.njnt; j++)
+      if (M.jnt_type[j] >= 2) {
+        float x = fmaxf(fabsf(qfrc[(size_t)e * M.nv + M.jnt_dofadr[j]]) - cfg.safe_torque, 0.f);
+        acc += scaled_exp(x * x);
+        n++;
+      }
+    if (n) r += cfg.w_torque * acc / (float)n;
+  }
+  // control change / regularisation / symmetry on the (scaled) actions
+  const float* pa = prev + (size_t)e * M.nu;
+  const float* la = latest + (size_t)e * M.nu;
+  const float inv = 1.f / cfg.action_scale;
+  if (M.nu > 0) {
+    float chg = 0.f, reg = 0.f;
+    for (int i = 0; i < M.nu; i++) {
+      float d = (la[i] - pa[i]) * inv * cfg.control_frequency;
+      chg += scaled_exp(d * d);
+      float a = la[i] * inv;
+      reg += scaled_exp(a * a);
+    }
+    r += cfg.w_ctrl_change * chg / (float)M.nu + cfg.w_ctrl_reg * reg / (float)M.nu;
+  }
+  if (cfg.n_equal + cfg.n_opposite > 0) {
+    float sym = 0.f;
+    for (int k = 0; k < cfg.n_equal; k++) { float d = (la[cfg.equal_pairs[k][0]] - la[cfg.equal_pairs[k][1]]) * inv; sym += scaled_exp(d * d); }
+    for (int k = 0; k < cfg.n_opposite; k++) { float d = (la[cfg.opposite_pairs[k][0]] + la[cfg.opposite_pairs[k][1]]) * inv; sym += scaled_exp(d * d); }
+    r += cfg.w_symmetry * sym / (float)(cfg.n_equal + cfg.n_opposite);
+  }
+  if (counts[kCountStride * e + 4]) r += cfg.self_collision_penalty;
+  const bool term = cfg.max_time > 0.f && s[0] >= cfg.max_time;
+  if (term) r = cfg.terminal_reward;
+  const bool upright = fmaxf(fabsf(g[0]), fabsf(g[1])) < cfg.upright_tol;
+  const bool trunc = z >= cfg.target_z && upright;
+  reward[e] = r;
+  terminated[e] = term ? 1 : 0;
+  truncated[e] = trunc ? 1 : 0;
+  if ((term || trunc) && cfg.auto_reset) {
+    // CPUEnv.reset for this env; the perturbation index advances with the episode count
+    const int ep = ++episode[e];
+    s[0] = 0.f;
+    for (int i = 0; i < M.nq; i++) s[1 + i] = qpos_src[i];
+    for (int i = 0; i < 2 * M.nv; i++) s[1 + M.nq + i] = 0.f;
+    if (cfg.reset_perturb > 0.f) {
+      const int idx = env_offset + e + 1 + ep * 7919;
+      for (int j = 0; j < M.njnt; j++) {
+        int qa = M.jnt_qposadr[j];
+        if (M.jnt_type[j] == 0) s[1 + qa + 2] += cfg.reset_perturb * 0.1f * halton(idx, 3);
+        else s[1 + qa] += cfg.reset_perturb * 0.2f * (2.f * halton(idx, 2 + j) - 1.f);
+      }
+    }
+    for (int i = 0; i < M.nu; i++) { prev[(size_t)e * M.nu + i] = 0.f; latest[(size_t)e * M.nu + i] = 0.f; }
+    status[e] = 0;
+    compute_obs(M, s, o, g, &z);
+  }
+}
 
 // Heavy-first dispatch order for the next launch: counting sort of the envs by the cost proxy of their
 // last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
@@ -1240,7 +1339,7 @@ __global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* 
   if (tid < 256) hist[tid] = 0;
   __syncthreads();
   for (int e = tid; e < n_env; e += blockDim.x) {
-    int key = min(255, counts[4 * e + 3] >> 3);
+    int key = min(255, counts[kCountStride * e + 3] >> 3);
     atomicAdd(&hist[255 - key], 1);  // bin 0 = most expensive
   }
   __syncthreads();
@@ -1250,7 +1349,7 @@ __global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* 
   }
   __syncthreads();
   for (int e = tid; e < n_env; e += blockDim.x) {
-    int key = min(255, counts[4 * e + 3] >> 3);
+    int key = min(255, counts[kCountStride * e + 3] >> 3);
     order[atomicAdd(&base[255 - key], 1)] = e;
   }
 }
@@ -1279,12 +1378,22 @@ hipError_t launch_step(const DevModel* M_dev, int lds_floats, const BatchPtrs& P
   hipLaunchKernelGGL(hb_step_kernel, dim3(P.n_env), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   return hipGetLastError();
 }
-hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, int perturb, int env_offset, hipStream_t stream) {
+hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, float perturb, int env_offset, hipStream_t stream) {
   hipLaunchKernelGGL(hb_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, status, mask, qpos_src, n_env, perturb, env_offset);
   return hipGetLastError();
 }
-hipError_t launch_obs(const DevModel& M, const float* state, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env, hipStream_t stream) {
-  hipLaunchKernelGGL(hb_obs_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, obs, reward, terminated, truncated, n_env);
+hipError_t launch_obs(const DevModel& M, const float* state, float* obs, int n_env, hipStream_t stream) {
+  hipLaunchKernelGGL(hb_obs_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, obs, n_env);
+  return hipGetLastError();
+}
+hipError_t launch_action(const float* action, float* prev, float* latest, float* ctrl, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(hb_action_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, action, prev, latest, ctrl, n);
+  return hipGetLastError();
+}
+hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, float* state, const float* qfrc, const int* counts, float* prev, float* latest, const float* qpos_src,
+                      int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env, int env_offset, hipStream_t stream) {
+  hipLaunchKernelGGL(hb_env_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, cfg, state, qfrc, counts, prev, latest, qpos_src, episode, status, obs, reward,
+                     terminated, truncated, n_env, env_offset);
   return hipGetLastError();
 }
 hipError_t launch_order(const int* counts, int* order, int n_env, hipStream_t stream) {

@@ -36,6 +36,18 @@ class HbSizes(ctypes.Structure):
                                             "npair", "nobs", "ncon_max", "nefc_max")]
 
 
+class HbEnvConfig(ctypes.Structure):
+    """hb_env_config (include/hb.h): reward / termination parameters of the env adapter."""
+    _fields_ = [("target_velocity", ctypes.c_float * 2), ("target_z", ctypes.c_float), ("min_z", ctypes.c_float),
+                ("max_time", ctypes.c_float), ("safe_torque", ctypes.c_float), ("control_frequency", ctypes.c_float),
+                ("action_scale", ctypes.c_float), ("w_hvel", ctypes.c_float), ("w_upright", ctypes.c_float),
+                ("w_height", ctypes.c_float), ("w_torque", ctypes.c_float), ("w_ctrl_change", ctypes.c_float),
+                ("w_ctrl_reg", ctypes.c_float), ("w_symmetry", ctypes.c_float), ("self_collision_penalty", ctypes.c_float),
+                ("terminal_reward", ctypes.c_float), ("upright_tol", ctypes.c_float), ("n_equal", ctypes.c_int),
+                ("n_opposite", ctypes.c_int), ("equal_pairs", (ctypes.c_int * 2) * 16), ("opposite_pairs", (ctypes.c_int * 2) * 16),
+                ("auto_reset", ctypes.c_int), ("reset_keyframe", ctypes.c_int), ("reset_perturb", ctypes.c_float)]
+
+
 class HbError(RuntimeError):
     pass
 
@@ -83,6 +95,11 @@ def lib():
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
     L.hb_diag_enable.argtypes = [vp, ci]
     L.hb_get_qacc.argtypes = [vp, vp]; L.hb_get_efc_force.argtypes = [vp, vp]; L.hb_get_contacts.argtypes = [vp, vp]
+    L.hb_env_default_config.argtypes = [vp, ctypes.POINTER(HbEnvConfig)]
+    L.hb_env_configure.argtypes = [vp, ctypes.POINTER(HbEnvConfig)]
+    L.hb_env_reset.argtypes = [vp, vp]
+    L.hb_env_step.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    L.hb_env_step_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.hb_dev_alloc.restype = vp; L.hb_dev_alloc.argtypes = [vp, ctypes.c_uint64]
     L.hb_dev_free.restype = None; L.hb_dev_free.argtypes = [vp, vp]
     L.hb_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_uint64]; L.hb_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_uint64]
@@ -292,6 +309,30 @@ class Batch:
         out = np.zeros((self.n_env, self.model.ncon_max, 16), dtype=np.float32)
         _check(lib().hb_get_contacts(self._h, _ptr(out)), "hb_get_contacts")
         return out
+
+    # ---- env adapter (CPUEnv.step/reset analogue)
+    def env_default_config(self):
+        c = HbEnvConfig()
+        _check(lib().hb_env_default_config(self.model._h, ctypes.byref(c)), "hb_env_default_config")
+        return c
+
+    def env_configure(self, cfg):
+        _check(lib().hb_env_configure(self._h, ctypes.byref(cfg)), "hb_env_configure")
+
+    def env_reset(self):
+        o = np.zeros((self.n_env, self.model.nobs), dtype=np.float32)
+        _check(lib().hb_env_reset(self._h, _ptr(o)), "hb_env_reset")
+        return o
+
+    def env_step(self, action, n_substeps=1):
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        assert a.shape == (self.n_env, self.model.nu), a.shape
+        o = np.zeros((self.n_env, self.model.nobs), dtype=np.float32)
+        r = np.zeros(self.n_env, dtype=np.float32)
+        te = np.zeros(self.n_env, dtype=np.uint8)
+        tr = np.zeros(self.n_env, dtype=np.uint8)
+        _check(lib().hb_env_step(self._h, _ptr(a), int(n_substeps), _ptr(o), _ptr(r), _ptr(te), _ptr(tr)), "hb_env_step")
+        return o, r, te.astype(bool), tr.astype(bool)
 
     # ---- device buffers / timing helpers (no HIP headers or torch needed on the caller's side)
     def dev_alloc(self, nbytes):

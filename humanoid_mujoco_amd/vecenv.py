@@ -1,0 +1,52 @@
+"""VecEnv-shaped adapter over the env entry points of libhb.so.
+
+Replaces the stack ``DummyVecEnv([CPUEnv, ...])`` the reference trains and benchmarks with
+(rl/train.py:123-136, simulation/benchmark.py:37-53, env contract simulation/cpu_env.py:374-416,676-693):
+``reset() -> obs[N, nobs]`` and ``step(actions[N, nu]) -> (obs, reward[N], terminated[N], truncated[N], infos)``
+with finished envs reset in place (SB3 VecEnv semantics) and ``set_attr("randomization_factor", x)``
+(rl/randomization_adaptation_callback.py:53-54).  All arithmetic is in the HIP kernels.
+"""
+import numpy as np
+
+from .engine import Batch, Model
+
+
+class VecEnv:
+    def __init__(self, model, n_envs, device=0, n_substeps=1, randomization_factor=1.0, **reward_overrides):
+        self.model = model if isinstance(model, Model) else Model.load(model)
+        self.batch = Batch(self.model, n_envs, device)
+        self.num_envs = int(n_envs)
+        self.n_substeps = int(n_substeps)
+        self.cfg = self.batch.env_default_config()
+        self.cfg.reset_perturb = float(randomization_factor)
+        for k, v in reward_overrides.items():
+            if not hasattr(self.cfg, k):
+                raise AttributeError("unknown env parameter %r" % k)
+            setattr(self.cfg, k, v)
+        self.batch.env_configure(self.cfg)
+        # gymnasium-style space descriptions (cpu_env.py:56-63: Box(-1,1,(nu,)), Box(-10,10,(nobs,)))
+        self.action_shape = (self.model.nu,)
+        self.observation_shape = (self.model.nobs,)
+        self.action_low, self.action_high = -1.0, 1.0
+
+    @property
+    def randomization_factor(self):
+        return float(self.cfg.reset_perturb)
+
+    def set_attr(self, name, value):
+        if name != "randomization_factor":
+            raise AttributeError(name)
+        self.cfg.reset_perturb = float(np.clip(value, 0.0, 1.0))
+        self.batch.env_configure(self.cfg)
+
+    def reset(self):
+        return self.batch.env_reset()
+
+    def step(self, actions):
+        obs, rew, term, trunc = self.batch.env_step(actions, self.n_substeps)
+        done = term | trunc
+        infos = {"is_success": trunc.copy(), "done": done}  # cpu_env.py:688-689
+        return obs, rew, term, trunc, infos
+
+    def close(self):
+        self.batch.close()

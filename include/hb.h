@@ -159,6 +159,41 @@ int hb_get_qacc(hb_batch* b, float* qacc);
 int hb_get_efc_force(hb_batch* b, float* efc_force);
 int hb_get_contacts(hb_batch* b, float* contact);
 
+/* ---- env adapter: the 27-DoF analogue of CPUEnv.step/reset (simulation/cpu_env.py:374-416,656-693) --------- */
+
+#define HB_ENV_MAX_PAIRS 16
+/* Reward / termination parameters of standupReward (simulation/reward_functions.py:247-374), made explicit.
+ * hb_env_default_config fills the reference's weights and model-derived heights. */
+typedef struct hb_env_config {
+  float target_velocity[2];     /* control_input_velocity (cpu_env.py:593) */
+  float target_z, min_z;        /* TARGET_Z_POS / MIN_Z_POS_FOR_REWARD (reward_functions.py:303-305) */
+  float max_time;               /* MAX_SIM_TIME_STANDUP; <= 0 disables the time limit */
+  float safe_torque;            /* MAX__SAFE_JOINT_TORQUE */
+  float control_frequency;      /* CONTROL_FREQUENCY (simulation_parameters.py:51) */
+  float action_scale;           /* previous/latest action are divided by this (pi/2 at cpu_env.py:601-602) */
+  float w_hvel, w_upright, w_height, w_torque, w_ctrl_change, w_ctrl_reg, w_symmetry;
+  float self_collision_penalty; /* SELF_COLLISION_PENALTY */
+  float terminal_reward;        /* TERMINAL_REWARD (overrides the step reward at the time limit) */
+  float upright_tol;            /* success needs max|g_local[0:2]| below this (0.7) */
+  int n_equal, n_opposite;      /* actuator index pairs of symmetry_reward (reward_functions.py:98-113) */
+  int equal_pairs[HB_ENV_MAX_PAIRS][2];
+  int opposite_pairs[HB_ENV_MAX_PAIRS][2];
+  int auto_reset;               /* 1: envs that terminate/truncate are reset inside hb_env_step (VecEnv semantics) */
+  int reset_keyframe;           /* -1 = qpos0 */
+  float reset_perturb;          /* 0..1 scale of the Halton joint/height perturbation (randomization_factor) */
+} hb_env_config;
+
+int hb_env_default_config(const hb_model* m, hb_env_config* out);
+int hb_env_configure(hb_batch* b, const hb_env_config* cfg);
+/* CPUEnv.reset for every env: returns obs[n_env][nobs]. */
+int hb_env_reset(hb_batch* b, float* obs);
+/* CPUEnv.step: action[n_env][nu] -> ctrl (unscaled; the physics clamps to ctrlrange), n_substeps x mj_step,
+ * reward, termination, observation; finished envs are reset when auto_reset is set and then report the
+ * observation of their new episode. Host pointers. */
+int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated);
+/* Same with device pointers, asynchronous on the batch's stream (policy on the same GPU). */
+int hb_env_step_dev(hb_batch* b, const float* action_dev, int n_substeps, float* obs_dev, float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev);
+
 /* ---- host-side helpers so a C/C++/ctypes caller needs no HIP headers ---------------------------- */
 
 /* Device buffer on the batch's GPU (hipMalloc / hipFree). */

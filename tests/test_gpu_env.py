@@ -1,0 +1,93 @@
+"""Env adapter on the GPU (hb_env_step / hb_env_reset) against a numpy restatement of
+the reference's standupReward fed with oracle quantities."""
+import numpy as np
+import pytest
+
+from env_ref import obs_from_state, standup_reward
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_env_step_matches_reference_reward(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n = 12
+    env = hbmod.VecEnv(m, n, gpu, auto_reset=0, max_time=0.0)
+    cfg = env.cfg
+    assert cfg.n_equal == 9 and cfg.n_opposite == 0  # nine right/left actuator pairs in the 27-DoF model
+    obs = env.reset()
+    b = env.batch
+    st0 = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+    for e in range(n):
+        o_ref, _ = obs_from_state(st0[e, 1:1 + m.nq], st0[e, 1 + m.nq:1 + m.nq + m.nv])
+        assert np.allclose(obs[e], o_ref, atol=1e-6)
+    rng = np.random.default_rng(2)
+    prev = np.zeros((n, m.nu))
+    o = Oracle()
+    worst = 0.0
+    for t in range(60):
+        act = rng.uniform(-1.2, 1.2, size=(n, m.nu)).astype(np.float32)
+        st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+        obs, rew, term, trunc, info = env.step(act)
+        st1 = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+        assert not term.any()
+        for e in range(n):
+            # oracle forward at the pre-step state gives the joint torques and the self-collision flag
+            o.reset()
+            o.qpos[:] = st[e, 1:1 + m.nq]; o.qvel[:] = st[e, 1 + m.nq:1 + m.nq + m.nv]; o.qacc_warmstart[:] = st[e, 1 + m.nq + m.nv:]
+            o.ctrl[:] = act[e]
+            o.forward()
+            torques = (o.qfrc_smooth + o.qfrc_constraint)[6:]
+            selfcol = any(c["geom1"] != 0 for c in o.contacts())
+            q1, v1 = st1[e, 1:1 + m.nq], st1[e, 1 + m.nq:1 + m.nq + m.nv]
+            r_ref, te, tr = standup_reward(cfg, st1[e, 0], q1, v1, torques, prev[e], act[e].astype(np.float64), selfcol)
+            worst = max(worst, abs(rew[e] - r_ref))
+            assert abs(rew[e] - r_ref) <= 2e-3 * max(1.0, abs(r_ref)), (t, e, rew[e], r_ref)
+            assert bool(trunc[e]) == tr
+            o_ref, _ = obs_from_state(q1, v1)
+            assert np.allclose(obs[e], o_ref, atol=1e-5)
+        prev = act.astype(np.float64)
+    assert worst < 2e-2
+
+
+def test_time_limit_terminates_and_auto_resets(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n = 8
+    env = hbmod.VecEnv(m, n, gpu, max_time=0.0249, target_z=10.0)  # 5 steps of 5 ms; success unreachable
+    env.reset()
+    zeros = np.zeros((n, m.nu), np.float32)
+    for t in range(4):
+        obs, rew, term, trunc, info = env.step(zeros)
+        assert not term.any() and not trunc.any()
+    q_before = env.batch.qpos
+    obs, rew, term, trunc, info = env.step(zeros)
+    assert term.all() and np.allclose(rew, -100.0)
+    # reset in place: time back to zero, a fresh perturbed start, and the returned obs belongs to the new episode
+    assert np.allclose(env.batch.time, 0.0)
+    q = env.batch.qpos
+    assert not np.allclose(q, q_before)
+    assert np.abs(q[:, 7:] - 0).max() <= 0.2 + 1e-6 and (q[:, 2] >= 1.282 - 1e-6).all()
+    assert np.allclose(obs[:, :21], q[:, 7:])
+    # a second episode starts from a different perturbation than the first
+    first = env.batch.qpos.copy()
+    for t in range(5):
+        obs, rew, term, trunc, info = env.step(zeros)
+    assert term.all()
+    assert not np.allclose(env.batch.qpos, first)
+
+
+def test_success_truncation_and_randomization_factor(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    env = hbmod.VecEnv(m, 4, gpu, randomization_factor=0.0, max_time=0.0)
+    env.reset()
+    assert np.allclose(env.batch.qpos, m.array("qpos0").astype(np.float32)[None])  # no perturbation at factor 0
+    obs, rew, term, trunc, info = env.step(np.zeros((4, m.nu), np.float32))
+    assert trunc.all() and info["is_success"].all()  # standing upright above target height == success (reward_functions.py:371-372)
+    env.set_attr("randomization_factor", 0.5)
+    env.reset()
+    q = env.batch.qpos
+    assert 0 < np.abs(q[:, 7:]).max() <= 0.1 + 1e-6
+    with pytest.raises(AttributeError):
+        env.set_attr("nope", 1)
+    with pytest.raises(AttributeError):
+        hbmod.VecEnv(m, 2, gpu, not_a_parameter=1)

@@ -304,10 +304,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   int endA = off;
   off = region;
   dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);
-  // per-row meta (13 slots x kNefcMax) is dead once the row quantities are in registers; the AR
-  // staging buffer (16 x 64 floats), live only between the half-solve and PGS, aliases it, and the
-  // force slot is written after PGS
-  dm.o_efc = take(std::max(13 * kNefcMax, 16 * kGroup));
+  dm.o_efc = take(13 * kNefcMax);
   dm.o_stage = dm.o_efc;
   int endB = off;
   // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
@@ -385,6 +382,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
   P.n_env = b->n_env;
   P.integrate = 1;
   if (b->schedule && b->order_valid) P.order = b->d_order;
+  P.stamps = b->d_stamps;
   return P;
 }
 

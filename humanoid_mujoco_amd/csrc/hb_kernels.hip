@@ -52,6 +52,9 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 __device__ __forceinline__ float uniformf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -372,7 +375,6 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   float* s_con = lds + M.o_con;
   float* s_C = lds + M.o_C;
   float* s_efc = lds + M.o_efc;  // per-row meta, stride kNefcMax
-  float* s_stage = lds + M.o_stage;  // 16 x 64 staging buffer of the AR build
   constexpr int kCs = 33;            // row stride of C (odd: conflict-free lane-strided access; column 32 is zero padding)
   static_assert(kNefcMax == kGroup - 1, "row kNefcMax of C is handled by the last lane");
   // per-row meta slots
@@ -961,41 +963,66 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     HB_STAMP(11);
     // ---------------------------------------------------------------- efc_b, AR = C C^T + diag(R) (mj_projectConstraint)
     const float* yv = s_C + kNefcMax * cs;
-    // AR lives in registers: lane j holds ar[i] = AR[i][j] (= AR[j][i]) for every row i.  It is
-    // produced 16 rows at a time through a small LDS staging buffer so that the row loop can stay
-    // a run-time loop while the register indices stay compile-time constants.
+    // AR lives in registers: lane j holds ar[i] = AR[i][j] (= AR[j][i]) for every row i.
+    // AR = C C^T is formed on the matrix cores: v_mfma_f32_32x32x2_f32 (exact f32) accumulates 32x32
+    // tiles over K = 32 dof columns, operands read straight from the LDS rows of C, the regulariser R
+    // injected through the accumulator input of the diagonal tiles.  A 32x32 result has its column on
+    // the lane and half of its rows in each 32-lane half; v_permlane32_swap pairs tile (I,0) with
+    // tile (I,1) so that every lane ends up with the full column it owns, with no LDS round trip.
     float ar[kNefcMax];
     float Aii = 1.f;
     {
-      float cj[kCs];
       const float* Cr = s_C + lane * cs;
-#pragma unroll
-      for (int k = 0; k < kCs; k++) cj[k] = rowact ? Cr[k] : 0.f;
       float jas = 0.f, diag = 0.f;
 #pragma unroll
-      for (int k = 0; k < kCs; k++) { jas += cj[k] * yv[k]; diag += cj[k] * cj[k]; }
+      for (int k = 0; k < kCs; k++) {
+        const float c = rowact ? Cr[k] : 0.f;
+        jas += c * yv[k];
+        diag += c * c;
+      }
       bvec = jas - aref;
       Aii = rowact ? diag + R : 1.f;
-      float* stage = s_stage + lane;
+      const int col = lane & 31, half = lane >> 5;
+      const bool two = nefc > 32;  // rows 32..62 in use: all four tiles, else only tile (0,0)
+      const bool v0 = col < nefc, v1 = 32 + col < nefc;
+      const float* A0p = s_C + col * cs + half;
+      const float* A1p = s_C + (32 + col) * cs + half;
+      const float R0 = __shfl(R, col, kGroup), R1 = __shfl(R, 32 + col, kGroup);
+      f32x16 X0, Y0, X1, Y1;
 #pragma unroll
-      for (int c = 0; c < (kNefcMax + 15) / 16; c++) {
-        if (c * 16 < nefc) {
-          const int iend = min(nefc, c * 16 + 16);
-          for (int i = c * 16; i < iend; i++) {
-            const float* Ci = s_C + i * cs;
-            float sacc = 0.f;
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;  // C/D layout: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+        X0[r] = (row == col && v0) ? R0 : 0.f;
+        Y1[r] = (row == col && v1) ? R1 : 0.f;
+        Y0[r] = 0.f;
+        X1[r] = 0.f;
+      }
+      if (!two) {
 #pragma unroll
-            for (int k = 0; k < kCs - 1; k++) sacc += cj[k] * Ci[k];
-            stage[(i - c * 16) * kGroup] = (i == lane) ? sacc + R : sacc;
-          }
-#pragma unroll
-          for (int r = 0; r < 16; r++)
-            if (c * 16 + r < kNefcMax) ar[c * 16 + r] = (c * 16 + r < nefc) ? stage[r * kGroup] : 0.f;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; r++)
-            if (c * 16 + r < kNefcMax) ar[c * 16 + r] = 0.f;
+        for (int kk = 0; kk < 16; kk++) {
+          const float a0 = v0 ? A0p[2 * kk] : 0.f;
+          X0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a0, X0, 0, 0, 0);
         }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+          const float a0 = v0 ? A0p[2 * kk] : 0.f;
+          const float a1 = v1 ? A1p[2 * kk] : 0.f;
+          X0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a0, X0, 0, 0, 0);  // AR[0:32, 0:32]
+          Y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a1, Y0, 0, 0, 0);  // AR[0:32, 32:64]
+          X1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a0, X1, 0, 0, 0);  // AR[32:64, 0:32]
+          Y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1, Y1, 0, 0, 0);  // AR[32:64, 32:64]
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int ra = (r & 3) + 8 * (r >> 2);
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(X0[r]), __float_as_uint(Y0[r]), false, false);
+        ar[ra] = __uint_as_float(s0.x);
+        ar[ra + 4] = __uint_as_float(s0.y);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(X1[r]), __float_as_uint(Y1[r]), false, false);
+        if (32 + ra < kNefcMax) ar[32 + ra] = __uint_as_float(s1.x);
+        if (32 + ra + 4 < kNefcMax) ar[32 + ra + 4] = __uint_as_float(s1.y);
       }
     }
     HB_STAMP(12);

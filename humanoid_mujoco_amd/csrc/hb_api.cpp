@@ -166,6 +166,11 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (int i = m.dof_parentid[k]; i >= 0; i = m.dof_parentid[i], e++) hs_pack.push_back(e | (k << 10) | (i << 16));
   }
   dm.nhs = (int)hs_pack.size();
+  std::vector<int> chain((size_t)32 * (kMaxAnc + 1), 0);
+  for (int i = 0; i < nv; i++) {
+    int t = 0;
+    for (int c = i; c >= 0 && t <= kMaxAnc; c = m.dof_parentid[c], t++) chain[(size_t)i * (kMaxAnc + 1) + t] = c | (m.dof_Madr[c] << 8);
+  }
   // pairs
   std::vector<int> pair_dim;
   std::vector<double> pair_fr, pair_solref, pair_solimp, pair_margin, pair_gap;
@@ -272,7 +277,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(M_i, Mi); TI(M_j, Mj); TI(mrec, mrec);
   while (T.iv.size() % 4) T.iv.push_back(0);  // int4 alignment of the pivot table
   size_t o_piv = T.addi(piv4);
-  TI(fac_pack, fac_pack); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(hs_pack, hs_pack);
+  TI(fac_pack, fac_pack); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(hs_pack, hs_pack); TI(chain, chain);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
   TI(pair_geom1, m.pair_geom1); TI(pair_geom2, m.pair_geom2); TI(pair_dim, pair_dim);
@@ -304,8 +309,11 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   int endA = off;
   off = region;
   dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);
-  dm.o_efc = take(13 * kNefcMax);
+  // per-row meta (13 slots x kNefcMax) is dead once the row quantities are in registers; W = L^-1 D^-1/2
+  // ([32][33]) is built over it before the J W product and lives until the dual finish
+  dm.o_efc = take(std::max(13 * kNefcMax, 32 * 33));
   dm.o_stage = dm.o_efc;
+  dm.o_force = take(kGroup);
   int endB = off;
   // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
   dm.lds_floats = std::max(endA, endB);

@@ -61,6 +61,7 @@ struct DevModel {
   const int4 HB_CONST* piv;                                       // per pivot dof: {#strict ancestors, Madr, first triple, end triple}
   const int HB_CONST* fac_pack;                                   // L^T D L update triples: dst | src << 10 | tmp << 20
   const int HB_CONST *desc_adr, *desc_pack;                       // descendants of each dof: k | address of L[k,i] << 8
+  const int HB_CONST* chain;                             // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)
   const int HB_CONST* hs_pack;                                    // half-solve schedule: e | k << 10 | i << 16, pivots descending
   int nhs;
   // geoms
@@ -85,7 +86,7 @@ struct DevModel {
   // region A (dynamics scratch)
   int o_xpos, o_xquat, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cdofdot, o_cvel, o_cacc, o_cfrc;
   // region B (constraints), aliases region A
-  int o_con, o_C, o_efc, o_stage;
+  int o_con, o_C, o_efc, o_stage, o_force;
   int lds_floats;  // total floats per env
   int cstride;     // row stride of C (odd, >= nv+1; column nv holds the extra right-hand side)
 };

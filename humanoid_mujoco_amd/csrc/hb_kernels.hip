@@ -328,6 +328,43 @@ __device__ __forceinline__ void solve_l_push(DevModelRef M, const float* LD, flo
   }
 }
 
+
+// W = L^-1 D^-1/2 (so that M^-1 = W W^T), dense row-major [32][kWs] in LDS.  L^-1 has the sparsity of L
+// (row i is supported on the ancestor chain of dof i) and from L^-1 L = I row i follows from its own
+// earlier entries and L along that chain:  Linv[i][c_t] = - sum_{s<t} Linv[i][c_s] L[c_s, c_t],
+// c_0 = i, c_1 = parent dof, ...  One lane per row, no cross-lane dependency; the chain (dof id and
+// address of its L row) comes packed from M.chain.  SQRT_OF_INV: dscale holds 1/D instead of D^-1/2.
+constexpr int kWs = 33;
+template <bool SQRT_OF_INV>
+__device__ __forceinline__ void build_w(DevModelRef M, const float* LD, const float* dscale, float* W, int lane) {
+  for (int idx = lane; idx < 32 * kWs; idx += kGroup) W[idx] = 0.f;
+  gsync();
+  if (lane < M.nv) {
+    const int i = lane;
+    const int n = M.dof_nanc[i];
+    const int HB_CONST* ch = M.chain + i * (kMaxAnc + 1);
+    int c[kMaxAnc + 1], ca[kMaxAnc + 1];
+    float u[kMaxAnc + 1];
+#pragma unroll
+    for (int t = 0; t <= kMaxAnc; t++) { const int pk = ch[t]; c[t] = pk & 255; ca[t] = pk >> 8; }
+    u[0] = 1.f;
+#pragma unroll
+    for (int t = 1; t <= kMaxAnc; t++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int sx = 0; sx < t; sx++) acc += LD[ca[sx] + (t - sx)] * u[sx];
+      u[t] = (t <= n) ? -acc : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t <= kMaxAnc; t++)
+      if (t <= n) {
+        const float d = dscale[c[t]];
+        W[i * kWs + c[t]] = u[t] * (SQRT_OF_INV ? sqrtf(d) : d);
+      }
+  }
+  gsync();
+}
+
 // ------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) {
@@ -374,9 +411,11 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   float* s_cfrc = lds + M.o_cfrc;
   float* s_con = lds + M.o_con;
   float* s_C = lds + M.o_C;
-  float* s_efc = lds + M.o_efc;  // per-row meta, stride kNefcMax
+  float* s_efc = lds + M.o_efc;  // per-row meta, stride kNefcMax; dead once the row quantities are in registers
+  float* s_W = lds + M.o_efc;    // W = L^-1 D^-1/2, [32][33], aliases the row meta
+  float* s_force = lds + M.o_force;
   constexpr int kCs = 33;            // row stride of C (odd: conflict-free lane-strided access; column 32 is zero padding)
-  static_assert(kNefcMax == kGroup - 1, "row kNefcMax of C is handled by the last lane");
+  static_assert(kNefcMax == kGroup - 1, "C holds kNefcMax constraint rows plus the qfrc_smooth row");
   // per-row meta slots
   enum { E_POS = 0, E_MARGIN, E_SOLREF0, E_SOLREF1, E_IMP0, E_IMP1, E_IMP2, E_IMP3, E_IMP4, E_DA, E_DAFIRST, E_MU2, E_FORCE, E_NSLOT };
 
@@ -902,8 +941,8 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       nefc = nefc_after;
     }
     nefc = uniform(nefc);
-    // extra right-hand side: row kNefcMax of C holds qfrc_smooth (half-solved below into y)
-    for (int d = lane; d < cs; d += kGroup) s_C[kNefcMax * cs + d] = d < nv ? s_smooth[d] : 0.f;
+    // extra right-hand side: row nefc of C holds qfrc_smooth (transformed below, with the rows, into y)
+    for (int d = lane; d < cs; d += kGroup) s_C[nefc * cs + d] = d < nv ? s_smooth[d] : 0.f;
     gsync();
 
     HB_STAMP(9);
@@ -935,34 +974,39 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     gsync();
     HB_STAMP(10);
-    // ---------------------------------------------------------------- half solve: C_i = D^-1/2 L^-T J_i (mj_solveM2), rows and the extra RHS together
+    // ---------------------------------------------------------------- C = J W, W = L^-1 D^-1/2 (the half solve of mj_solveM2 as one GEMM)
+    // rows 0..nefc-1 are constraint rows, row nefc is qfrc_smooth (-> y = D^-1/2 L^-T qfrc_smooth).
+    // 32-row tiles x 32 dof columns x K = 32 on the matrix cores; A operands are preloaded so the
+    // product can be written back over J in place.
+    build_w<false>(M, s_qLD, s_dsqrtinv, s_W, lane);
     {
-      const bool solverow = rowact || lane == kGroup - 1;
-      float* x = s_C + lane * cs;  // lane 63 owns row kNefcMax == 63 (the extra right-hand side)
-      if (solverow) {
-        // pull form, dofs descending: z_i = x_i - sum over descendants k of L[k,i] z_k.  Only finished
-        // values are read, so the LDS reads of one dof are independent and issued four at a time.
-        for (int i = nv - 1; i >= 0; i--) {
-          const int t0 = M.desc_adr[i], t1 = M.desc_adr[i + 1];
-          float acc = x[i];
-          for (int t = t0; t < t1; t += 4) {
-            const int q0 = M.desc_pack[t], q1 = M.desc_pack[t + 1], q2 = M.desc_pack[t + 2], q3 = M.desc_pack[t + 3];  // table is padded
-            const float l0 = s_qLD[q0 >> 8], l1 = s_qLD[q1 >> 8], l2 = s_qLD[q2 >> 8], l3 = s_qLD[q3 >> 8];
-            const float v0 = x[q0 & 255], v1 = x[q1 & 255], v2 = x[q2 & 255], v3 = x[q3 & 255];
-            acc -= l0 * v0;
-            if (t + 1 < t1) acc -= l1 * v1;
-            if (t + 2 < t1) acc -= l2 * v2;
-            if (t + 3 < t1) acc -= l3 * v3;
+      const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+      for (int I = 0; I < 2; I++) {
+        if (I == 0 || nefc >= 32) {
+          const int arow = 32 * I + col;
+          const float* Ap = s_C + arow * cs + half;
+          const bool av = arow <= nefc;
+          float a[16];
+#pragma unroll
+          for (int kk = 0; kk < 16; kk++) a[kk] = av ? Ap[2 * kk] : 0.f;
+          f32x16 D;
+#pragma unroll
+          for (int r = 0; r < 16; r++) D[r] = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < 16; kk++) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], s_W[(2 * kk + half) * kWs + col], D, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = 32 * I + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row <= nefc) s_C[row * cs + col] = D[r];
           }
-          x[i] = acc;
         }
-        for (int k = 0; k < nv; k++) x[k] *= s_dsqrtinv[k];
       }
     }
     gsync();
     HB_STAMP(11);
     // ---------------------------------------------------------------- efc_b, AR = C C^T + diag(R) (mj_projectConstraint)
-    const float* yv = s_C + kNefcMax * cs;
+    const float* yv = s_C + nefc * cs;
     // AR lives in registers: lane j holds ar[i] = AR[i][j] (= AR[j][i]) for every row i.
     // AR = C C^T is formed on the matrix cores: v_mfma_f32_32x32x2_f32 (exact f32) accumulates 32x32
     // tiles over K = 32 dof columns, operands read straight from the LDS rows of C, the regulariser R
@@ -1105,24 +1149,29 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         if (uniformf(improvement) * M.pgs_scale < M.tolerance) break;
       }
     }
-    if (lane < kNefcMax) s_efc[E_FORCE * kNefcMax + lane] = rowact ? force : 0.f;
+    if (lane < kNefcMax) s_force[lane] = rowact ? force : 0.f;
     gsync();
     HB_STAMP(13);
-    // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = L^-1 D^-1/2 (y + s) ; qfrc_constraint = L^T D^1/2 s
+    // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = W (y + s) ; qfrc_constraint = L^T D^1/2 s
     for (int k = lane; k < nv; k += kGroup) {
-      float s = 0.f;
-      for (int i = 0; i < nefc; i++) s += s_efc[E_FORCE * kNefcMax + i] * s_C[i * cs + k];
-      float dsi = s_dsqrtinv[k];
-      s_v0[k] = (yv[k] + s) * dsi;  // -> qacc after L^-1
-      s_v1[k] = s / dsi;            // D^1/2 s
+      float sacc = 0.f;
+      for (int i = 0; i < nefc; i++) sacc += s_force[i] * s_C[i * cs + k];
+      s_v1[k] = sacc / s_dsqrtinv[k];  // D^1/2 s
+      s_v2[k] = yv[k] + sacc;          // y + s
     }
     gsync();
-    solve_l_push(M, s_qLD, s_v0, lane);
-    for (int i = lane; i < nv; i += kGroup) {
-      float acc = s_v1[i];
-      for (int t = M.desc_adr[i]; t < M.desc_adr[i + 1]; t++) { const int pk = M.desc_pack[t]; acc += s_qLD[pk >> 8] * s_v1[pk & 255]; }
-      s_v2[i] = s_smooth[i] + acc;  // qfrc_smooth + qfrc_constraint: right-hand side of the Euler solve
-      if (P.qfrc_out) P.qfrc_out[(size_t)env * nv + i] = s_v2[i];
+    {
+      float qacc_i = 0.f, rhs_i = 0.f;
+      if (lane < nv) {
+        const float* Wr = s_W + lane * kWs;
+        for (int n = 0; n < nv; n++) qacc_i += Wr[n] * s_v2[n];
+        float acc = s_v1[lane];
+        for (int t = M.desc_adr[lane]; t < M.desc_adr[lane + 1]; t++) { const int pk = M.desc_pack[t]; acc += s_qLD[pk >> 8] * s_v1[pk & 255]; }
+        rhs_i = s_smooth[lane] + acc;  // qfrc_smooth + qfrc_constraint: right-hand side of the Euler solve
+        if (P.qfrc_out) P.qfrc_out[(size_t)env * nv + lane] = rhs_i;
+      }
+      gsync();
+      if (lane < nv) { s_v0[lane] = qacc_i; s_v2[lane] = rhs_i; }
     }
     gsync();
     // mj_checkAcc
@@ -1162,10 +1211,19 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       // ---------------------------------------------------------------- mj_Euler: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint
       for (int i = lane; i < nv; i += kGroup) s_warm[i] = s_v0[i];  // qacc_warmstart <- qacc
       if (eulerdamp) {
-        solve_lt_push(M, s_qH, s_v2, lane);
-        for (int i = lane; i < nv; i += kGroup) s_v2[i] *= s_hdinv[i];
+        // qacc' = H^-1 (qfrc_smooth + qfrc_constraint), H^-1 = W_H W_H^T; W_H is built in the (now dead) C rows
+        float* WH = s_C;
+        build_w<true>(M, s_qH, s_hdinv, WH, lane);
+        float p = 0.f;
+        if (lane < nv) for (int k = 0; k < nv; k++) p += WH[k * kWs + lane] * s_v2[k];  // p = W_H^T rhs
         gsync();
-        solve_l_push(M, s_qH, s_v2, lane);
+        if (lane < nv) s_v1[lane] = p;
+        gsync();
+        float q = 0.f;
+        if (lane < nv) { const float* Wr = WH + lane * kWs; for (int n = 0; n < nv; n++) q += Wr[n] * s_v1[n]; }
+        gsync();
+        if (lane < nv) s_v2[lane] = q;
+        gsync();
       } else {
         for (int i = lane; i < nv; i += kGroup) s_v2[i] = s_v0[i];
         gsync();

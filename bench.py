@@ -39,12 +39,13 @@ def cpu_baseline(target_seconds=12.0):
     from oracle_lib import Oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     o = Oracle()
+    # calibration on a sample large enough to load every core, including the contact-rich later steps
     t0 = time.perf_counter()
-    n, _, _ = o.rollout_threads(cores * 2, 100, cores)
+    n, _, _ = o.rollout_threads(max(cores * 8, 256), 300, cores)
     rate = n / (time.perf_counter() - t0)
-    # ~target_seconds of CPU work: the benchmark's batch (or a multiple of it on many-core hosts), up to 1000 steps
+    # ~target_seconds of CPU work: the benchmark's batch (or a small multiple of it on many-core hosts), up to 1000 steps
     steps = int(max(50, min(1000, rate * target_seconds / ENVS_PER_GPU)))
-    mult = max(1, int(round(rate * target_seconds / (ENVS_PER_GPU * steps))))
+    mult = int(min(4, max(1, rate * target_seconds // (ENVS_PER_GPU * steps))))
     n_env = max(cores, (ENVS_PER_GPU * mult // cores) * cores)
     t0 = time.perf_counter()
     n, _, st = o.rollout_threads(n_env, steps, cores)
@@ -73,6 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the second (single-launch rollout) measurement, e.g. under rocprofv3")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,11 +111,14 @@ def main():
     for t in range(W):
         batch.step_dev(ctrl + t * stride)
     barrier()
+    batch.step_timing(True)  # HIP events around every 8th hb_step_kernel launch, on its stream
     batch.timer_start()
     t0 = time.perf_counter()
     for t in range(W, W + K):
         batch.step_dev(ctrl + t * stride)
-    kernel_ms = batch.timer_stop()  # HIP events on the launch stream; also drains it
+    region_ms = batch.timer_stop()  # HIP events around the whole timed region on the launch stream; also drains it
+    kernel_us, kernel_samples = batch.step_timing_read()
+    batch.step_timing(False)
     batch.sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -126,14 +131,16 @@ def main():
     # Second measurement, reported beside `value`: the same K steps as ONE hb_rollout_dev launch (state
     # resident on chip, each env advancing through its own K steps without a per-step batch barrier) —
     # the shape of the reference's C++ harness simulation/mujoco/sample/testspeed.cc:84-103,203-210.
-    batch.reset(perturb=True, env_offset=lo)
-    batch.rollout_dev(ctrl, W)
-    barrier()
-    t1 = time.perf_counter()
-    batch.rollout_dev(ctrl + W * stride, K)
-    batch.sync()
-    elapsed_rollout = time.perf_counter() - t1
-    if dist is not None:
+    elapsed_rollout = None
+    if not args.no_rollout:
+        batch.reset(perturb=True, env_offset=lo)
+        batch.rollout_dev(ctrl, W)
+        barrier()
+        t1 = time.perf_counter()
+        batch.rollout_dev(ctrl + W * stride, K)
+        batch.sync()
+        elapsed_rollout = time.perf_counter() - t1
+    if dist is not None and elapsed_rollout is not None:
         import torch
         tt = torch.tensor([elapsed_rollout], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -144,7 +151,7 @@ def main():
     nc, ne, ni = batch.counts()
     if rank == 0:
         value = n_env * world * K / elapsed
-        launch_us = 1e3 * kernel_ms / K
+        launch_us = kernel_us if kernel_samples else 1e3 * region_ms / K
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (launch_us * 1e-6) / 1e9
         traffic = load_traffic()
         out = {
@@ -158,16 +165,18 @@ def main():
                        "sharding": "env blocks by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                         "kernel": "hb_step_kernel", "avg_launch_us": launch_us,
+                         "kernel": "hb_step_kernel", "avg_launch_us": launch_us, "launch_samples": kernel_samples,
+                         "region_us_per_step": 1e3 * region_ms / K,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_env,
                          "note": "path is latency/VALU bound, not HBM bound (SURVEY.md §8d); see DESIGN.md"},
-            "rollout": {"value": n_env * world * K / elapsed_rollout, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed_rollout / K,
-                        "what": "same K steps as one hb_rollout_dev launch per GPU (no per-step batch barrier; testspeed.cc shape)"},
             "state_check": {"envs_with_warnings": int((status != 0).sum()), "mean_ncon": float(nc.mean()), "mean_nefc": float(ne.mean()),
                             "mean_pgs_iters": float(ni.mean())},
         }
         if traffic:
             out["roofline"]["traffic_source"] = traffic.get("source")
+        if elapsed_rollout is not None:
+            out["rollout"] = {"value": n_env * world * K / elapsed_rollout, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed_rollout / K,
+                              "what": "same K steps as one hb_rollout_dev launch per GPU (no per-step batch barrier; testspeed.cc shape)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

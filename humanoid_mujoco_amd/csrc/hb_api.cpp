@@ -364,6 +364,17 @@ struct hb_batch {
   float *d_prev = nullptr, *d_latest = nullptr, *d_qfrc = nullptr, *d_action = nullptr;
   int* d_episode = nullptr;
   int env_offset = 0;
+  // policy MLP (hb_policy_*)
+  int mlp_layers = 0;
+  int mlp_sizes[5] = {0, 0, 0, 0, 0};
+  float* d_mlp_w[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* d_mlp_b[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* d_mlp_h[2] = {nullptr, nullptr};  // hidden activations, ping-pong
+  // optional per-kernel timing of the step kernel (hb_step_timing)
+  bool time_steps = false;
+  std::vector<hipEvent_t> tev;  // pairs
+  int tev_used = 0;
+  long long launch_count = 0;
   int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
   bool order_valid = false;
   bool schedule = true;
@@ -397,11 +408,17 @@ BatchPtrs make_ptrs(hb_batch* b) {
 
 // launch the step kernel, then (heavy-first scheduling) the tiny kernel that orders the next launch's blocks
 int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
+  const bool sample = b->time_steps && (b->launch_count % 8 == 0) && b->tev_used + 2 <= (int)b->tev.size();
+  if (sample) HB_HIP(hipEventRecord(b->tev[b->tev_used], b->stream));
   HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, nsteps, b->stream));
-  if (b->schedule) {  // sort the envs by the cost of the step just enqueued, for the next launch
+  if (sample) { HB_HIP(hipEventRecord(b->tev[b->tev_used + 1], b->stream)); b->tev_used += 2; }
+  // heavy-first scheduling: re-sort the envs by the cost of the step just enqueued; costs change slowly, so
+  // every 4th launch is enough (the sort kernel sits on the critical path of the stream)
+  if (b->schedule && (b->launch_count % 4 == 0)) {
     HB_HIP(launch_order(b->d_counts, b->d_order, b->n_env, b->stream));
     b->order_valid = true;
   }
+  b->launch_count++;
   return HB_OK;
 }
 
@@ -593,6 +610,9 @@ void hb_batch_free(hb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+  for (auto e : b->tev) (void)hipEventDestroy(e);
+  for (int i = 0; i < 4; i++) { if (b->d_mlp_w[i]) (void)hipFree(b->d_mlp_w[i]); if (b->d_mlp_b[i]) (void)hipFree(b->d_mlp_b[i]); }
+  for (int i = 0; i < 2; i++) if (b->d_mlp_h[i]) (void)hipFree(b->d_mlp_h[i]);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
@@ -849,6 +869,72 @@ int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, fl
   return HB_OK;
 }
 
+int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* const* weights, const float* const* biases) {
+  if (!b || !sizes || !weights || !biases || n_layers < 1 || n_layers > 4) return HB_EINVAL;
+  if (sizes[0] != b->D.dm.nobs || sizes[n_layers] != b->D.dm.nu) return HB_EINVAL;
+  for (int l = 0; l <= n_layers; l++) if (sizes[l] < 1 || sizes[l] > 512) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  int maxh = 1;
+  for (int l = 0; l < n_layers; l++) {
+    if (!weights[l] || !biases[l]) return HB_EINVAL;
+    if (b->d_mlp_w[l]) { (void)hipFree(b->d_mlp_w[l]); b->d_mlp_w[l] = nullptr; }
+    if (b->d_mlp_b[l]) { (void)hipFree(b->d_mlp_b[l]); b->d_mlp_b[l] = nullptr; }
+    size_t nw = (size_t)sizes[l] * sizes[l + 1];
+    if (hipMalloc((void**)&b->d_mlp_w[l], nw * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_mlp_b[l], sizes[l + 1] * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+    HB_HIP(hipMemcpy(b->d_mlp_w[l], weights[l], nw * sizeof(float), hipMemcpyHostToDevice));
+    HB_HIP(hipMemcpy(b->d_mlp_b[l], biases[l], sizes[l + 1] * sizeof(float), hipMemcpyHostToDevice));
+    if (l + 1 < n_layers) maxh = std::max(maxh, sizes[l + 1]);
+  }
+  for (int i = 0; i < 2; i++) {
+    if (b->d_mlp_h[i]) { (void)hipFree(b->d_mlp_h[i]); b->d_mlp_h[i] = nullptr; }
+    if (hipMalloc((void**)&b->d_mlp_h[i], (size_t)b->n_env * maxh * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+  }
+  b->mlp_layers = n_layers;
+  for (int l = 0; l <= n_layers; l++) b->mlp_sizes[l] = sizes[l];
+  return HB_OK;
+}
+
+// observation -> MLP -> b->d_ctrl, all on the batch's stream
+static int policy_forward(hb_batch* b) {
+  if (b->mlp_layers < 1) return HB_EINVAL;
+  HB_HIP(launch_obs(b->D.dm, b->d_state, b->d_obs, b->n_env, b->stream));
+  const float* x = b->d_obs;
+  for (int l = 0; l < b->mlp_layers; l++) {
+    float* y = (l + 1 == b->mlp_layers) ? b->d_ctrl : b->d_mlp_h[l & 1];
+    HB_HIP(launch_mlp_layer(x, b->d_mlp_w[l], b->d_mlp_b[l], y, b->n_env, b->mlp_sizes[l], b->mlp_sizes[l + 1], 1, b->stream));
+    x = y;
+  }
+  return HB_OK;
+}
+
+int hb_policy_eval(hb_batch* b, float* ctrl_out) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  int rc = policy_forward(b);
+  if (rc != HB_OK) return rc;
+  if (ctrl_out) HB_HIP(hipMemcpyAsync(ctrl_out, b->d_ctrl, (size_t)b->n_env * b->D.dm.nu * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  return HB_OK;
+}
+
+int hb_rollout_policy(hb_batch* b, int T, float* qpos_out_dev) {
+  if (!b || T < 1) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  for (int t = 0; t < T; t++) {
+    int rc = policy_forward(b);
+    if (rc != HB_OK) return rc;
+    BatchPtrs P = make_ptrs(b);
+    P.ctrl = b->d_ctrl; P.ctrl_mode = 0;
+    P.qpos_out = qpos_out_dev ? qpos_out_dev + (size_t)t * b->n_env * b->D.dm.nq : nullptr;
+    rc = launch_steps(b, P, 1);
+    if (rc != HB_OK) return rc;
+  }
+  return HB_OK;
+}
+
 int hb_get_status(hb_batch* b, int* status) {
   if (!b || !status) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
@@ -943,6 +1029,33 @@ int hb_get_stamps(hb_batch* b, unsigned long long* out) {
   (void)b; (void)out;
   return HB_EUNSUPPORTED;
 #endif
+}
+int hb_step_timing(hb_batch* b, int enable) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  if (enable && b->tev.empty()) {
+    b->tev.resize(512);
+    for (auto& e : b->tev) HB_HIP(hipEventCreate(&e));
+  }
+  b->time_steps = enable != 0;
+  b->tev_used = 0;
+  return HB_OK;
+}
+int hb_step_timing_read(hb_batch* b, float* mean_us, int* samples) {
+  if (!b || !mean_us) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(b->stream));
+  double tot = 0;
+  int n = 0;
+  for (int i = 0; i + 1 < b->tev_used; i += 2) {
+    float ms = 0;
+    HB_HIP(hipEventElapsedTime(&ms, b->tev[i], b->tev[i + 1]));
+    tot += ms; n++;
+  }
+  *mean_us = n ? (float)(1e3 * tot / n) : 0.f;
+  if (samples) *samples = n;
+  b->tev_used = 0;
+  return HB_OK;
 }
 int hb_timer_start(hb_batch* b) {
   if (!b) return HB_EINVAL;

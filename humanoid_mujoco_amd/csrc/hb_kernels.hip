@@ -1413,6 +1413,41 @@ __global__ void hb_env_kernel(const DevModel M, const EnvConfig cfg, float* stat
   }
 }
 
+
+// One dense layer of the policy MLP on the matrix cores: Y[M][N] = act(X[M][K] W[K][N] + b[N]).
+// One wave per 32x32 output tile, K swept two columns per v_mfma_f32_32x32x2_f32 (exact f32); the X tile
+// is staged through LDS (row stride K+1: conflict-free A-operand reads), W streams from L2 coalesced.
+__global__ __launch_bounds__(kGroup) void hb_mlp_layer_kernel(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act) {
+  extern __shared__ float xs[];
+  const int lane = threadIdx.x, m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int ks = K + 1;
+  for (int idx = lane; idx < 32 * K; idx += kGroup) {
+    const int r = idx / K, c = idx - r * K;
+    xs[r * ks + c] = (m0 + r < Mrows) ? X[(size_t)(m0 + r) * K + c] : 0.f;
+  }
+  __syncthreads();
+  const int col = lane & 31, half = lane >> 5;
+  const bool nvld = n0 + col < N;
+  f32x16 D;
+#pragma unroll
+  for (int r = 0; r < 16; r++) D[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 2) {
+    const int k = k0 + half;
+    const float a = k < K ? xs[col * ks + k] : 0.f;
+    const float bv = (nvld && k < K) ? W[(size_t)k * N + n0 + col] : 0.f;
+    D = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, D, 0, 0, 0);
+  }
+  const float bn = nvld ? bias[n0 + col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (row < Mrows && nvld) {
+      float v = D[r] + bn;
+      Y[(size_t)row * N + n0 + col] = act ? tanhf(v) : v;
+    }
+  }
+}
+
 // Heavy-first dispatch order for the next launch: counting sort of the envs by the cost proxy of their
 // last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
 // the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
@@ -1483,6 +1518,10 @@ hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, float* state, con
 }
 hipError_t launch_order(const int* counts, int* order, int n_env, hipStream_t stream) {
   hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, n_env);
+  return hipGetLastError();
+}
+hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream) {
+  hipLaunchKernelGGL(hb_mlp_layer_kernel, dim3((Mrows + 31) / 32, (N + 31) / 32), dim3(kGroup), (size_t)32 * (K + 1) * sizeof(float), stream, X, W, bias, Y, Mrows, K, N, act);
   return hipGetLastError();
 }
 hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream) {

@@ -100,11 +100,15 @@ def lib():
     L.hb_env_reset.argtypes = [vp, vp]
     L.hb_env_step.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.hb_env_step_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    L.hb_policy_set_mlp.argtypes = [vp, ci, vp, vp, vp]
+    L.hb_policy_eval.argtypes = [vp, vp]
+    L.hb_rollout_policy.argtypes = [vp, ci, vp]
     L.hb_dev_alloc.restype = vp; L.hb_dev_alloc.argtypes = [vp, ctypes.c_uint64]
     L.hb_dev_free.restype = None; L.hb_dev_free.argtypes = [vp, vp]
     L.hb_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_uint64]; L.hb_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_uint64]
     L.hb_halton_ctrl_dev.argtypes = [vp, ci, ci, ci, vp]
     L.hb_timer_start.argtypes = [vp]; L.hb_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.hb_step_timing.argtypes = [vp, ci]; L.hb_step_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ci)]
     _lib = L
     return L
 
@@ -334,6 +338,24 @@ class Batch:
         _check(lib().hb_env_step(self._h, _ptr(a), int(n_substeps), _ptr(o), _ptr(r), _ptr(te), _ptr(tr)), "hb_env_step")
         return o, r, te.astype(bool), tr.astype(bool)
 
+    # ---- policy in the loop (BASELINE config 4)
+    def set_policy_mlp(self, weights, biases):
+        """weights[l]: [in, out] float32 (transpose of torch.nn.Linear.weight); tanh after every layer."""
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        bs = [np.ascontiguousarray(x, dtype=np.float32) for x in biases]
+        sizes = (ctypes.c_int * (len(ws) + 1))(*([ws[0].shape[0]] + [w.shape[1] for w in ws]))
+        wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+        bp = (ctypes.c_void_p * len(bs))(*[x.ctypes.data for x in bs])
+        _check(lib().hb_policy_set_mlp(self._h, len(ws), sizes, wp, bp), "hb_policy_set_mlp")
+
+    def policy_eval(self):
+        out = np.zeros((self.n_env, self.model.nu), dtype=np.float32)
+        _check(lib().hb_policy_eval(self._h, _ptr(out)), "hb_policy_eval")
+        return out
+
+    def rollout_policy(self, T, qpos_out_ptr=None):
+        _check(lib().hb_rollout_policy(self._h, int(T), ctypes.c_void_p(qpos_out_ptr or 0)), "hb_rollout_policy")
+
     # ---- device buffers / timing helpers (no HIP headers or torch needed on the caller's side)
     def dev_alloc(self, nbytes):
         p = lib().hb_dev_alloc(self._h, int(nbytes))
@@ -363,3 +385,11 @@ class Batch:
         ms = ctypes.c_float()
         _check(lib().hb_timer_stop(self._h, ctypes.byref(ms)), "hb_timer_stop")
         return ms.value
+
+    def step_timing(self, enable=True):
+        _check(lib().hb_step_timing(self._h, int(enable)), "hb_step_timing")
+
+    def step_timing_read(self):
+        us, n = ctypes.c_float(), ctypes.c_int()
+        _check(lib().hb_step_timing_read(self._h, ctypes.byref(us), ctypes.byref(n)), "hb_step_timing_read")
+        return us.value, n.value

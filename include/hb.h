@@ -194,6 +194,19 @@ int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, fl
 /* Same with device pointers, asynchronous on the batch's stream (policy on the same GPU). */
 int hb_env_step_dev(hb_batch* b, const float* action_dev, int n_substeps, float* obs_dev, float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev);
 
+/* ---- policy in the loop (BASELINE.json configs[3]: MLP policy inference fused into the rollout loop) ---------- */
+
+/* Installs an MLP policy obs[nobs] -> sizes[1] -> ... -> sizes[n_layers] == nu with tanh after every layer
+ * (sizes and activation of simulation/hyperparam_config.py:21-27, rl/train.py:163-167).  weights[l] is row-major
+ * [sizes[l]][sizes[l+1]] float32 (the transpose of torch.nn.Linear.weight), biases[l] is [sizes[l+1]].  Host pointers;
+ * copied to the device.  n_layers <= 4, every size <= 512. */
+int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* const* weights, const float* const* biases);
+/* One policy evaluation on the current states: ctrl_out[n_env][nu] (host, nullable) and the batch's control buffer. */
+int hb_policy_eval(hb_batch* b, float* ctrl_out);
+/* T closed-loop steps on the device: observation -> MLP (f32 MFMA GEMMs) -> mj_step, no host round trip.
+ * qpos_out_dev (nullable, device) receives [T][n_env][nq]. */
+int hb_rollout_policy(hb_batch* b, int T, float* qpos_out_dev);
+
 /* ---- host-side helpers so a C/C++/ctypes caller needs no HIP headers ---------------------------- */
 
 /* Device buffer on the batch's GPU (hipMalloc / hipFree). */
@@ -208,6 +221,10 @@ int hb_halton_ctrl_dev(hb_batch* b, int T, int t0, int env_offset, float* out_de
 /* HIP-event stopwatch on the batch's stream (hipEventRecord on that stream; hipEventElapsedTime). */
 int hb_timer_start(hb_batch* b);
 int hb_timer_stop(hb_batch* b, float* elapsed_ms);
+/* Per-kernel timing of the step kernel alone: when enabled, every 8th step launch is bracketed by its own pair
+ * of HIP events on the launch stream (up to 256 samples); hb_step_timing_read synchronises and returns their mean. */
+int hb_step_timing(hb_batch* b, int enable);
+int hb_step_timing_read(hb_batch* b, float* mean_us, int* samples);
 /* Diagnostic builds only (libhb_stamps.so, -DHB_STAMPS): per-env s_memtime stamps at the 16 phase
  * boundaries of the last step; the first call arms the buffer.  HB_EUNSUPPORTED in the product build. */
 int hb_get_stamps(hb_batch* b, unsigned long long* out);

@@ -1,0 +1,75 @@
+"""BASELINE config 4: 2-hidden-layer tanh MLP policy (48 -> 256 -> 256 -> 21, sizes from
+simulation/hyperparam_config.py:21-27) evaluated on the GPU inside the rollout loop, against numpy."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_policy(nobs, nu, hidden=256, seed=0):
+    """torch.manual_seed(0) default nn.Linear initialisation, exported as [in, out]."""
+    import torch
+    torch.manual_seed(seed)
+    layers = [torch.nn.Linear(nobs, hidden), torch.nn.Linear(hidden, hidden), torch.nn.Linear(hidden, nu)]
+    ws = [l.weight.detach().numpy().T.copy() for l in layers]
+    bs = [l.bias.detach().numpy().copy() for l in layers]
+    return ws, bs
+
+
+def mlp_ref(obs, ws, bs):
+    x = obs.astype(np.float64)
+    for w, b in zip(ws, bs):
+        x = np.tanh(x @ w.astype(np.float64) + b.astype(np.float64))
+    return x
+
+
+def test_policy_eval_matches_numpy(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n = 1000  # not a multiple of 32: exercises the tile edge
+    b = hbmod.Batch(m, n, gpu)
+    b.reset(perturb=True)
+    b.rollout_halton(120)
+    ws, bs = make_policy(m.nobs, m.nu)
+    b.set_policy_mlp(ws, bs)
+    ctrl = b.policy_eval()
+    obs, _, _, _ = b.obs(want_reward=False)
+    ref = mlp_ref(obs, ws, bs)
+    assert ctrl.shape == (n, m.nu)
+    assert np.abs(ctrl - ref).max() < 2e-5
+    assert np.abs(ctrl).max() < 1.0 and np.abs(ctrl).std() > 0.01
+
+
+def test_closed_loop_rollout_matches_host_loop(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n, T = 64, 25
+    ws, bs = make_policy(m.nobs, m.nu)
+    a = hbmod.Batch(m, n, gpu)
+    c = hbmod.Batch(m, n, gpu)
+    for x in (a, c):
+        x.reset(perturb=True)
+        x.set_policy_mlp(ws, bs)
+    a.rollout_policy(T)
+    a.sync()
+    for t in range(T):  # same loop driven from the host: policy_eval then step
+        c.step(c.policy_eval())
+    assert np.array_equal(a.get_state(hbmod.STATE_INTEGRATION), c.get_state(hbmod.STATE_INTEGRATION))
+    # and against the numpy policy in the loop (fp32 tanh vs fp64: tiny control differences only)
+    d = hbmod.Batch(m, n, gpu)
+    d.reset(perturb=True)
+    for t in range(5):
+        obs, _, _, _ = d.obs(want_reward=False)
+        d.step(mlp_ref(obs, ws, bs).astype(np.float32))
+    e = hbmod.Batch(m, n, gpu)
+    e.reset(perturb=True)
+    e.set_policy_mlp(ws, bs)
+    e.rollout_policy(5)
+    assert np.abs(d.qpos - e.qpos).max() < 1e-4
+
+
+def test_policy_argument_checks(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    b = hbmod.Batch(m, 8, gpu)
+    with pytest.raises(hbmod.HbError):
+        b.rollout_policy(3)  # no policy installed
+    with pytest.raises(hbmod.HbError):
+        b.set_policy_mlp([np.zeros((m.nobs + 1, m.nu), np.float32)], [np.zeros(m.nu, np.float32)])  # wrong input width

@@ -83,7 +83,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   if (m.nv > 32) { err = "this build supports nv <= 32 degrees of freedom"; return false; }
   if (m.nbody > 64 || m.ngeom > 64) { err = "this build supports at most 64 bodies and 64 geoms"; return false; }
   for (int g = 0; g < m.ngeom; g++)
-    if (m.geom_type[g] == GEOM_HFIELD) { err = "height-field collision is not implemented on the device path yet"; return false; }
+    if (m.geom_type[g] == GEOM_HFIELD && m.geom_bodyid[g] != 0) { err = "height fields must be attached to the world body"; return false; }
   for (int j = 0; j < m.njnt; j++)
     if (m.jnt_type[j] == JNT_BALL) { err = "ball joints are not supported"; return false; }
   TableBuilder T;
@@ -278,7 +278,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   while (T.iv.size() % 4) T.iv.push_back(0);  // int4 alignment of the pivot table
   size_t o_piv = T.addi(piv4);
   TI(fac_pack, fac_pack); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(hs_pack, hs_pack); TI(chain, chain);
-  TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid);
+  TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
+  TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
   TI(pair_geom1, m.pair_geom1); TI(pair_geom2, m.pair_geom2); TI(pair_dim, pair_dim);
   TF(pair_friction, pair_fr); TF(pair_solref, pair_solref); TF(pair_solimp, pair_solimp); TF(pair_margin, pair_margin); TF(pair_gap, pair_gap);

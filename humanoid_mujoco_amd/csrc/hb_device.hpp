@@ -67,6 +67,9 @@ struct DevModel {
   // geoms
   const int HB_CONST *geom_type, *geom_bodyid;
   const float HB_CONST *geom_size, *geom_pos, *geom_quat, *geom_rbound;
+  // height fields (static terrain on the world body): per geom the field id (-1 otherwise)
+  const int HB_CONST *geom_dataid, *hfield_nrow, *hfield_ncol, *hfield_adr;
+  const float HB_CONST *hfield_size, *hfield_data;
   // collision candidates with pre-mixed contact parameters
   const int HB_CONST *pair_geom1, *pair_geom2, *pair_dim;
   const float HB_CONST *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;

@@ -574,9 +574,11 @@ static int capsule_capsule(om_contact* c, double margin, const double* pos1, con
   return n;
 }
 
-/* height field vs sphere: closest point on the triangulated surface inside the sphere's
- * footprint (restates the prism decomposition of mjc_ConvexHField for the sphere case as an
- * exact sphere-triangle test; one contact per geom = deepest triangle) */
+/* height field vs sphere.  NOT a restatement of MuJoCo's algorithm (mjc_ConvexHField decomposes the
+ * field into prisms and runs its convex collider on each): this engine's own terrain contact model,
+ * used by BASELINE config 5 — closest point on the triangulated surface (each cell split along the
+ * A-D diagonal) inside the sphere's footprint, one contact per sphere, normal out of the terrain.
+ * The device kernel implements exactly this; parity for config 5 is GPU-vs-this-model only. */
 static void closest_on_triangle(double* out, const double* p, const double* a, const double* b, const double* c) {
   double ab[3], ac[3], ap[3];
   for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
@@ -611,7 +613,7 @@ static int hfield_sphere(const om_model* m, om_contact* c, double margin, int hi
   int cmin = (int)floor((p[0] - reach + hs[0]) / dx), cmax = (int)ceil((p[0] + reach + hs[0]) / dx);
   int rmin = (int)floor((p[1] - reach + hs[1]) / dy), rmax = (int)ceil((p[1] + reach + hs[1]) / dy);
   if (cmin < 0) cmin = 0; if (rmin < 0) rmin = 0; if (cmax > ncol - 1) cmax = ncol - 1; if (rmax > nrow - 1) rmax = nrow - 1;
-  double best = 1e300, bestpt[3] = {0, 0, 0};
+  double best = 1e300, bestpt[3] = {0, 0, 0}, bestn[3] = {0, 0, 1};
   for (int r = rmin; r < rmax; r++)
     for (int cc = cmin; cc < cmax; cc++) {
       double x0 = cc * dx - hs[0], x1 = x0 + dx, y0 = r * dy - hs[1], y1 = y0 + dy;
@@ -623,18 +625,28 @@ static int hfield_sphere(const om_model* m, om_contact* c, double margin, int hi
         closest_on_triangle(q, p, tris[t][0], tris[t][1], tris[t][2]);
         double e[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
         double dd = dot3(e, e);
-        if (dd < best) { best = dd; memcpy(bestpt, q, sizeof q); }
+        if (dd < best) {
+          best = dd; memcpy(bestpt, q, sizeof q);
+          double e1[3] = {tris[t][1][0] - tris[t][0][0], tris[t][1][1] - tris[t][0][1], tris[t][1][2] - tris[t][0][2]};
+          double e2[3] = {tris[t][2][0] - tris[t][0][0], tris[t][2][1] - tris[t][0][1], tris[t][2][2] - tris[t][0][2]};
+          cross3(bestn, e1, e2);  /* counter-clockwise triangles: upward normal */
+        }
       }
     }
   if (best > 1e299) return 0;
   double dist = sqrt(best);
   double nrm[3] = {p[0] - bestpt[0], p[1] - bestpt[1], p[2] - bestpt[2]};
-  /* centre below the surface: push up along the surface side */
-  if (dist < MINVAL) { nrm[0] = 0; nrm[1] = 0; nrm[2] = 1; } else for (int i = 0; i < 3; i++) nrm[i] /= dist;
+  normalize3(bestn);
+  if (dist < MINVAL) { memcpy(nrm, bestn, sizeof nrm); }
+  else {
+    for (int i = 0; i < 3; i++) nrm[i] /= dist;
+    /* centre under the surface: the contact normal keeps pointing out of the terrain, the distance turns negative */
+    if (dot3(nrm, bestn) < 0) { for (int i = 0; i < 3; i++) nrm[i] = -nrm[i]; dist = -dist; }
+  }
   if (dist - radius > margin) return 0;
   c->dist = dist - radius;
   double lp[3], ln[3] = {nrm[0], nrm[1], nrm[2]};
-  for (int i = 0; i < 3; i++) lp[i] = bestpt[i] + nrm[i] * (c->dist / 2 + 0) ;
+  for (int i = 0; i < 3; i++) lp[i] = p[i] - nrm[i] * (radius + c->dist / 2);  /* midway between the surfaces */
   /* back to the world frame; normal points from hfield (geom1) to sphere (geom2) */
   for (int i = 0; i < 3; i++) {
     c->pos[i] = hpos[i] + hmat[3 * i] * lp[0] + hmat[3 * i + 1] * lp[1] + hmat[3 * i + 2] * lp[2];

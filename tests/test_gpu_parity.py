@@ -268,7 +268,7 @@ def test_disable_flags_and_options(hbmod, gpu):
     assert np.allclose(b2.qpos[:, 0], 1.5 * 10 * 0.005, atol=1e-5)
 
 
-@pytest.mark.parametrize("name,steps", [("ball_plane", 400), ("capsules", 300), ("chain", 300), ("pendulum_limit", 500)])
+@pytest.mark.parametrize("name,steps", [("ball_plane", 400), ("capsules", 300), ("chain", 300), ("pendulum_limit", 500), ("ball_hfield", 900)])
 def test_other_models_one_step_parity_along_oracle_trajectory(hbmod, gpu, tmp_path, name, steps):
     """Multi-tree models, slide joints, tendon limits, affine actuators, condim-1 pairs: teacher-forced
     one-step parity at states sampled along an oracle rollout."""
@@ -367,3 +367,51 @@ def test_full_size_batch_properties(hbmod, humanoid_model, gpu):
     assert viol < 0.35
     # distinct environments really are distinct, identical ones identical
     assert len(np.unique(q[:, 2])) > n // 2
+
+
+def test_heightfield_terrain_humanoid_config5(hbmod, gpu):
+    """BASELINE config 5 (terrain humanoid, PGS exactly 50 sweeps): teacher-forced one-step parity along an
+    oracle trajectory on the height-field model, then an 8192-env sanity rollout.  The terrain contact model
+    is this engine's own (oracle header: not MuJoCo's prism algorithm), so parity here is GPU vs that model."""
+    import os
+    from oracle_lib import ROOT
+    path = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27_hfield.hbm")
+    m = hbmod.Model.load(path)
+    assert m.opt.tolerance == 0.0 and m.opt.iterations == 50
+    o = Oracle(path)
+    states, ctrls, outs = [], [], []
+    for e in (0, 3):
+        o.init_env(e)
+        for t in range(420):
+            c = o.ctrl_env(t, e)
+            o.ctrl[:] = c
+            take = t % 20 == 0
+            if take:
+                states.append(np.concatenate([[o.time], o.qpos, o.qvel, o.qacc_warmstart]))
+                ctrls.append(c.copy())
+            o.step()
+            if take:
+                outs.append((o.qpos.copy(), o.qvel.copy(), o.ncon, o.nefc, o.dint("solver_niter")))
+    n = len(states)
+    b = hbmod.Batch(m, n, gpu)
+    b.set_state(hbmod.STATE_INTEGRATION, np.array(states))
+    b.step(np.array(ctrls, dtype=np.float32))
+    q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
+    nc, ne, ni = b.counts()
+    assert not b.status().any()
+    seen_contacts = 0
+    for k, (qo, vo, nco, neo, nio) in enumerate(outs):
+        assert (nc[k], ne[k]) == (nco, neo)
+        assert ni[k] == nio  # exactly 50 sweeps whenever there are constraints
+        seen_contacts += nco
+        assert (np.abs(q[k] - qo) / np.maximum(1, np.abs(qo))).max() <= 1e-4
+        assert np.abs(v[k] - vo).max() <= 1e-3 * max(1.0, np.abs(vo).max())
+    assert seen_contacts > 20
+    big = hbmod.Batch(m, 8192, gpu)
+    big.reset(perturb=True)
+    big.rollout_halton(300)
+    qq = big.qpos
+    assert np.isfinite(qq).all() and not big.status().any()
+    assert qq[:, 2].min() > -0.15 and qq[:, 2].max() < 1.5
+    _, _, it = big.counts()
+    assert set(np.unique(it)) <= {0, 50}

@@ -172,3 +172,23 @@ def test_load_errors(hbmod, tmp_path):
     bad.write_text("HBM1\ni nq 3\n")  # truncated: no END
     with pytest.raises(hbmod.HbError):
         hbmod.Model.load(str(bad))
+
+
+def test_heightfield_asset_and_config5_model(hbmod, tmp_path):
+    p = str(tmp_path / "bh.hbm")
+    hbmod.Model.load(os.path.join(MODELS, "ball_hfield.xml")).save(p)
+    info = parse_hbm(p)
+    assert info["nhfield"] == 1 and list(info["hfield_nrow"]) == [3] and list(info["hfield_ncol"]) == [4]
+    d = info["hfield_data"].reshape(3, 4)
+    assert d.min() == 0.0 and d.max() == 1.0          # normalised like mjModel.hfield_data
+    assert np.allclose(d[1], [1.0, 0.7, 0.4, 0.1])   # middle row of the MJCF listing
+    assert info["geom_type"][0] == 1 and info["geom_dataid"][0] == 0
+    assert set(zip(info["pair_geom1"], info["pair_geom2"])) == {(0, 1), (0, 2), (1, 2)}
+    # config-5 model: same humanoid, plane replaced by the 8x8 field of SURVEY.md 8(d), PGS exactly 50 sweeps
+    from oracle_lib import ROOT
+    h = parse_hbm(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27_hfield.hbm"))
+    base = parse_hbm(HUMANOID_HBM)
+    assert h["geom_type"][0] == 1 and list(h["hfield_size"]) == [10, 10, 1, 1] and h["tolerance"] == 0 and h["iterations"] == 50
+    assert np.array_equal(h["body_mass"], base["body_mass"]) and np.array_equal(h["pair_geom1"], base["pair_geom1"])
+    assert abs((h["hfield_data"] * 1.0).mean() + h["geom_pos"][2]) < 1e-12  # mean terrain height 0
+    assert h["hfield_data"].max() <= 0.1

@@ -22,7 +22,7 @@ def compiled(tmp_path_factory, ):
     import humanoid_mujoco_amd as hb
     out = {}
     d = tmp_path_factory.mktemp("hbm")
-    for name in ("pendulum", "pendulum_limit", "ball_plane", "capsules", "chain"):
+    for name in ("pendulum", "pendulum_limit", "ball_plane", "capsules", "chain", "ball_hfield"):
         p = str(d / (name + ".hbm"))
         hb.Model.load(os.path.join(MODELS, name + ".xml")).save(p)
         out[name] = p
@@ -318,3 +318,24 @@ def test_tendon_and_chain_model(compiled):
     assert abs(o.actuator_force[0] - 0.5) < 1e-12
     assert abs(o.actuator_force[1] - (5 * 0.2 - 5 * (-0.7))) < 1e-12
     assert abs(o.actuator_force[2] - (2.0 + 0.1 - 0.3)) < 1e-12
+
+
+def test_heightfield_contact_model(compiled):
+    """Terrain contact (this engine's own model, not MuJoCo's prisms): a ball dropped on a sloped field rolls
+    downhill, the contact normal is the facet normal, the contact point lies midway between the surfaces."""
+    o = Oracle(compiled["ball_hfield"])
+    o.reset()
+    o.step(400)
+    o.forward()
+    ball = [c for c in o.contacts() if c["geom2"] == 1]
+    assert len(ball) == 1
+    c = ball[0]
+    # facet under the ball: elevation falls 0.15 m per 1.333 m in +x -> normal ~ (0.112, +-0.033, 0.993)
+    assert abs(c["frame"][0][0] - 0.112) < 5e-3 and c["frame"][0][2] > 0.99
+    centre = o.qpos[0:3]
+    assert abs(np.linalg.norm(centre - c["pos"]) - (0.12 + c["dist"] / 2)) < 1e-9
+    assert -0.01 < c["dist"] < 0
+    x0 = o.qpos[0]
+    o.step(400)
+    assert o.qpos[0] > x0 + 0.2  # rolled downhill
+    assert np.isfinite(o.qpos).all()

@@ -81,12 +81,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    backend = os.environ.get("HB_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on a box with fewer GPUs than ranks
+    red_dev = "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            red_dev = "cuda"
+        else:
+            dist_.init_process_group(backend=backend)
         dist = dist_
 
     import humanoid_mujoco_amd as hb
@@ -94,7 +100,13 @@ def main():
     n_env = args.envs_per_gpu
     lo, hi = shard_range(n_env * world, world, rank)
     assert hi - lo == n_env
-    batch = hb.Batch(model, n_env, local_rank)  # raises without a GPU: no CPU fallback
+    device = local_rank
+    if backend != "nccl":
+        import ctypes
+        ndev = ctypes.c_int(0)
+        ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(ndev))
+        device = local_rank % max(1, ndev.value)
+    batch = hb.Batch(model, n_env, device)  # raises without a GPU: no CPU fallback
     K, W = args.steps, args.warmup
     nu = model.nu
     # controls for every timed step live in HBM, generated there (testspeed.cc:64-80)
@@ -123,7 +135,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         dist.barrier()
@@ -142,7 +154,7 @@ def main():
         elapsed_rollout = time.perf_counter() - t1
     if dist is not None and elapsed_rollout is not None:
         import torch
-        tt = torch.tensor([elapsed_rollout], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed_rollout], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed_rollout = float(tt.item())
         dist.barrier()

@@ -81,7 +81,7 @@ void mix_pair(const Model& m, int g1, int g2, int& dim, double* fr, double* solr
 
 bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   if (m.nv > 32) { err = "this build supports nv <= 32 degrees of freedom"; return false; }
-  if (m.nbody > 64 || m.ngeom > 64) { err = "this build supports at most 64 bodies and 64 geoms"; return false; }
+  if (m.nbody > 65 || m.ngeom > 64) { err = "this build supports at most 64 bodies and 64 geoms"; return false; }
   for (int g = 0; g < m.ngeom; g++)
     if (m.geom_type[g] == GEOM_HFIELD && m.geom_bodyid[g] != 0) { err = "height fields must be attached to the world body"; return false; }
   for (int j = 0; j < m.njnt; j++)
@@ -230,7 +230,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     if (m.body_jntnum[b] > 3) { err = "at most 3 joints per body are supported (body '" + m.body_name[b] + "')"; return false; }
     if (childnum[b] > 8) { err = "at most 8 child bodies per body are supported (body '" + m.body_name[b] + "')"; return false; }
     r[0] = fi(b); r[1] = fi(m.body_parentid[b]); r[2] = fi(m.body_jntnum[b]); r[3] = fi(m.body_jntadr[b]);
-    r[4] = fi(m.body_dofadr[b]); r[5] = fi(treeid[b]); r[6] = (float)m.body_mass[b]; r[7] = fi(childnum[b]);
+    r[4] = fi(m.body_depth[b]); r[5] = fi(treeid[b]); r[6] = (float)m.body_mass[b]; r[7] = fi(childnum[b]);
     for (int i = 0; i < 3; i++) { r[8 + i] = (float)m.body_pos[3 * b + i]; r[16 + i] = (float)m.body_ipos[3 * b + i]; r[24 + i] = (float)m.body_inertia[3 * b + i]; }
     for (int i = 0; i < 4; i++) { r[12 + i] = (float)m.body_quat[4 * b + i]; r[20 + i] = (float)m.body_iquat[4 * b + i]; }
     for (int c = 0; c < 8; c++) r[28 + c] = fi(c < childnum[b] ? child_list[childadr[b] + c] : 0);

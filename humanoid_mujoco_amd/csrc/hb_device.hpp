@@ -51,7 +51,7 @@ struct DevModel {
   // dof tables
   const int HB_CONST *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_nanc, *dof_qposadr;
   const float HB_CONST *dof_armature, *dof_damping;
-  // level-ordered body records: [0] b,parent,jntnum,jntadr  [1] dofadr,treeid,mass,childnum  [2] pos  [3] quat  [4] ipos
+  // level-ordered body records: [0] b,parent,jntnum,jntadr  [1] depth,treeid,mass,childnum  [2] pos  [3] quat  [4] ipos
   // [5] iquat  [6] inertia  [7..8] children[8]  [9+3j] joint j: (type,qposadr,dofadr,qpos0) (axis) (pos)
   const float4 HB_CONST* brec;
   const float4 HB_CONST* drec;   // per dof: (jntid,bodyid,type,k) (treeid,armature,damping,stiffness) (qposadr,qpos_spring,-,-)

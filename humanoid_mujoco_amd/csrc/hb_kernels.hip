@@ -542,15 +542,26 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       for (int i = 0; i < 9; i++) s_xmat[i] = (i % 4 == 0) ? 1.f : 0.f;
     }
     gsync();
-    for (int L = 1; L < M.nlevel; L++) {
-      const int n = M.level_num[L], adr = M.level_adr[L];
-      for (int idx = lane; idx < n; idx += kGroup) {
-        const float4 HB_CONST* R = M.brec + (size_t)(adr + idx) * kBrecQuads;
-        const float4 q0 = R[0], bp = R[2], bq = R[3], ip = R[4];
-        const int b = __float_as_int(q0.x), p = __float_as_int(q0.y), jn = __float_as_int(q0.z), ja = __float_as_int(q0.w);
-        float4 JA[3], JB[3], JC[3];
+    // Lane l owns body slot l+1 (level order) for the whole step: its record is fetched once, here,
+    // and stays in registers through the tree passes (no table loads inside the level loops).
+    const bool bl = lane + 1 < nb;
+    float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, bp = q0, bq = q0, ip = q0, ch0 = q0, ch1 = q0;
+    float4 JA[3], JB[3], JC[3];
 #pragma unroll
-        for (int jj = 0; jj < 3; jj++) { JA[jj] = R[9 + 3 * jj]; JB[jj] = R[10 + 3 * jj]; JC[jj] = R[11 + 3 * jj]; }
+    for (int jj = 0; jj < 3; jj++) { JA[jj] = q0; JB[jj] = q0; JC[jj] = q0; }
+    if (bl) {
+      const float4 HB_CONST* R = M.brec + (size_t)(lane + 1) * kBrecQuads;
+      q0 = R[0]; q1 = R[1]; bp = R[2]; bq = R[3]; ip = R[4]; ch0 = R[7]; ch1 = R[8];
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) { JA[jj] = R[9 + 3 * jj]; JB[jj] = R[10 + 3 * jj]; JC[jj] = R[11 + 3 * jj]; }
+    }
+    const int myb = __float_as_int(q0.x), myp = __float_as_int(q0.y), myjn = __float_as_int(q0.z), myja = __float_as_int(q0.w);
+    const int mylevel = bl ? __float_as_int(q1.x) : -1, mycn = __float_as_int(q1.w);
+    const int mych[8] = {__float_as_int(ch0.x), __float_as_int(ch0.y), __float_as_int(ch0.z), __float_as_int(ch0.w),
+                         __float_as_int(ch1.x), __float_as_int(ch1.y), __float_as_int(ch1.z), __float_as_int(ch1.w)};
+    for (int L = 1; L < M.nlevel; L++) {
+      if (mylevel == L) {
+        const int b = myb, p = myp, jn = myjn, ja = myja;
         V3 pos;
         Q4 quat;
         if (jn == 1 && __float_as_int(JA[0].x) == 0) {
@@ -601,20 +612,16 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     // ---------------------------------------------------------------- mj_comPos
     for (int t = 0; t < M.ntree; t++) {
       V3 acc = {0.f, 0.f, 0.f};
-      for (int sl = 1 + lane; sl < nb; sl += kGroup) {
-        const float4 HB_CONST* R = M.brec + (size_t)sl * kBrecQuads;
-        const float4 q0 = R[0], q1 = R[1];
-        if (__float_as_int(q1.y) == t) acc = acc + ld3(s_xipos + 3 * __float_as_int(q0.x)) * q1.z;
-      }
+      if (bl && __float_as_int(q1.y) == t) acc = ld3(s_xipos + 3 * myb) * q1.z;
       float im = M.tree_invmass[t];
       float sx = wave_sum(acc.x) * im, sy = wave_sum(acc.y) * im, sz = wave_sum(acc.z) * im;
       if (lane == 0) st3(s_scom + 3 * t, {sx, sy, sz});
     }
     gsync();
-    for (int sl = 1 + lane; sl < nb; sl += kGroup) {
-      const float4 HB_CONST* R = M.brec + (size_t)sl * kBrecQuads;
-      const float4 q0 = R[0], q1 = R[1], iq = R[5], in4 = R[6];
-      const int b = __float_as_int(q0.x);
+    if (bl) {
+      const float4 HB_CONST* R = M.brec + (size_t)(lane + 1) * kBrecQuads;
+      const float4 iq = R[5], in4 = R[6];
+      const int b = myb;
       V3 com = ld3(s_scom + 3 * __float_as_int(q1.y));
       V3 dif = ld3(s_xipos + 3 * b) - com;
       float mat[9];
@@ -665,17 +672,18 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     for (int i = lane; i < 10 * nb; i += kGroup) s_crb[i] = s_cinert[i];
     gsync();
     for (int L = M.nlevel - 2; L >= 1; L--) {
-      const int n = M.level_num[L] * 10, adr = M.level_adr[L];
-      for (int idx = lane; idx < n; idx += kGroup) {
-        const float4 HB_CONST* R = M.brec + (size_t)(adr + idx / 10) * kBrecQuads;
-        const float4 q0 = R[0], q1 = R[1], c0 = R[7], c1 = R[8];
-        const int b = __float_as_int(q0.x), c = idx % 10, cn = __float_as_int(q1.w);
-        const int ch[8] = {__float_as_int(c0.x), __float_as_int(c0.y), __float_as_int(c0.z), __float_as_int(c0.w),
-                           __float_as_int(c1.x), __float_as_int(c1.y), __float_as_int(c1.z), __float_as_int(c1.w)};
-        float acc = s_crb[10 * b + c];
+      if (mylevel == L && mycn > 0) {
+        float acc[10];
 #pragma unroll
-        for (int k = 0; k < 8; k++) if (k < cn) acc += s_crb[10 * ch[k] + c];
-        s_crb[10 * b + c] = acc;
+        for (int c = 0; c < 10; c++) acc[c] = s_crb[10 * myb + c];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (k < mycn) {
+#pragma unroll
+            for (int c = 0; c < 10; c++) acc[c] += s_crb[10 * mych[k] + c];
+          }
+#pragma unroll
+        for (int c = 0; c < 10; c++) s_crb[10 * myb + c] = acc[c];
       }
       gsync();
     }
@@ -710,12 +718,8 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     gsync();
     for (int L = 1; L < M.nlevel; L++) {
-      const int n = M.level_num[L], adr = M.level_adr[L];
-      for (int idx = lane; idx < n; idx += kGroup) {
-        const float4 HB_CONST* R = M.brec + (size_t)(adr + idx) * kBrecQuads;
-        const float4 q0 = R[0];
-        const float4 JA[3] = {R[9], R[12], R[15]};
-        const int b = __float_as_int(q0.x), p = __float_as_int(q0.y), jn = __float_as_int(q0.z);
+      if (mylevel == L) {
+        const int b = myb, p = myp, jn = myjn;
         float cvel[6], cacc[6], t[6], cd[6];
         for (int i = 0; i < 6; i++) { cvel[i] = s_cvel[6 * p + i]; cacc[i] = s_cacc[6 * p + i]; }
         if (jn == 1 && __float_as_int(JA[0].x) == 0) {
@@ -760,17 +764,18 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     // rne backward pass: accumulate child forces into parents (pull form)
     for (int L = M.nlevel - 2; L >= 1; L--) {
-      const int n = M.level_num[L] * 6, adr = M.level_adr[L];
-      for (int idx = lane; idx < n; idx += kGroup) {
-        const float4 HB_CONST* R = M.brec + (size_t)(adr + idx / 6) * kBrecQuads;
-        const float4 q0 = R[0], q1 = R[1], c0 = R[7], c1 = R[8];
-        const int b = __float_as_int(q0.x), c = idx % 6, cn = __float_as_int(q1.w);
-        const int ch[8] = {__float_as_int(c0.x), __float_as_int(c0.y), __float_as_int(c0.z), __float_as_int(c0.w),
-                           __float_as_int(c1.x), __float_as_int(c1.y), __float_as_int(c1.z), __float_as_int(c1.w)};
-        float acc = s_cfrc[6 * b + c];
+      if (mylevel == L && mycn > 0) {
+        float acc[6];
 #pragma unroll
-        for (int k = 0; k < 8; k++) if (k < cn) acc += s_cfrc[6 * ch[k] + c];
-        s_cfrc[6 * b + c] = acc;
+        for (int c = 0; c < 6; c++) acc[c] = s_cfrc[6 * myb + c];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (k < mycn) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[c] += s_cfrc[6 * mych[k] + c];
+          }
+#pragma unroll
+        for (int c = 0; c < 6; c++) s_cfrc[6 * myb + c] = acc[c];
       }
       gsync();
     }

@@ -149,6 +149,9 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     piv4.push_back(nanc[k]); piv4.push_back(m.dof_Madr[k]); piv4.push_back(t0); piv4.push_back((int)fac_pack.size());
   }
   dm.nfac = (int)fac_pack.size();
+  std::vector<int> fac2((size_t)std::max(nv, 1) * 128, -1);
+  for (int k = 0; k < nv; k++)
+    for (int t = piv4[4 * k + 2]; t < piv4[4 * k + 3] && t - piv4[4 * k + 2] < 128; t++) fac2[(size_t)k * 128 + (t - piv4[4 * k + 2])] = fac_pack[t];
   std::vector<int> desc_adr(nv + 1, 0), desc_pack;
   for (int i = 0; i < nv; i++) {
     desc_adr[i] = (int)desc_pack.size();
@@ -277,7 +280,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(M_i, Mi); TI(M_j, Mj); TI(mrec, mrec);
   while (T.iv.size() % 4) T.iv.push_back(0);  // int4 alignment of the pivot table
   size_t o_piv = T.addi(piv4);
-  TI(fac_pack, fac_pack); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(hs_pack, hs_pack); TI(chain, chain);
+  TI(fac_pack, fac_pack); TI(fac2, fac2); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(hs_pack, hs_pack); TI(chain, chain);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);

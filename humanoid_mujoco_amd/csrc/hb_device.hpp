@@ -59,6 +59,7 @@ struct DevModel {
   const float2 HB_CONST* mdiag;  // per sparse M entry: (armature, damping) on the diagonal, 0 elsewhere
   const int HB_CONST *M_i, *M_j;                                  // dof pair of each sparse mass-matrix entry
   const int4 HB_CONST* piv;                                       // per pivot dof: {#strict ancestors, Madr, first triple, end triple}
+  const int HB_CONST* fac2;                              // fixed-stride copy: [pivot][128] packed triples, -1 = none
   const int HB_CONST* fac_pack;                                   // L^T D L update triples: dst | src << 10 | tmp << 20
   const int HB_CONST *desc_adr, *desc_pack;                       // descendants of each dof: k | address of L[k,i] << 8
   const int HB_CONST* chain;                             // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)

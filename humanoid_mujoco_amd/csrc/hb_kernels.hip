@@ -307,17 +307,19 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 // of two); the index words of the next pivot are fetched while the current one is processed.
 template <bool TWO>
 __device__ __forceinline__ void factor_ld(DevModelRef M, float* LD, float* dinv, float* dsqrtinv, float* LD2, float* dinv2, int lane) {
-  int4 pv = M.piv[M.nv - 1];  // nanc, Madr, t0, t1
-  int p0 = (pv.z + lane < pv.w) ? M.fac_pack[pv.z + lane] : -1;
-  int p1 = (pv.z + lane + kGroup < pv.w) ? M.fac_pack[pv.z + lane + kGroup] : -1;
-  for (int k = M.nv - 1; k >= 0; k--) {
+  // fac2 is a fixed-stride copy of the update triples: pivot k, lane l -> fac2[k*128 + l] and [k*128 + 64 + l]
+  // (-1 = none), so the index words of later pivots can be fetched without waiting for anything
+  const int nv = M.nv;
+  const int HB_CONST* f2 = M.fac2;
+  int pa0 = f2[(nv - 1) * 128 + lane], pa1 = f2[(nv - 1) * 128 + 64 + lane];                          // pivot k
+  int pb0 = nv > 1 ? f2[(nv - 2) * 128 + lane] : -1, pb1 = nv > 1 ? f2[(nv - 2) * 128 + 64 + lane] : -1;  // pivot k-1
+  int4 pv = M.piv[nv - 1];  // nanc, Madr, t0, t1
+  for (int k = nv - 1; k >= 0; k--) {
     const int4 cur = pv;
-    const int c0 = p0, c1 = p1;
-    if (k > 0) {
-      pv = M.piv[k - 1];
-      p0 = (pv.z + lane < pv.w) ? M.fac_pack[pv.z + lane] : -1;
-      p1 = (pv.z + lane + kGroup < pv.w) ? M.fac_pack[pv.z + lane + kGroup] : -1;
-    }
+    const int c0 = pa0, c1 = pa1;
+    pa0 = pb0; pa1 = pb1;
+    if (k > 0) pv = M.piv[k - 1];
+    if (k > 1) { pb0 = f2[(k - 2) * 128 + lane]; pb1 = f2[(k - 2) * 128 + 64 + lane]; }
     if (cur.x == 0) continue;
     const int Mkk = cur.y;
     const float inv = 1.f / fmaxf(LD[Mkk], HB_MINVAL);

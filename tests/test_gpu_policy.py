@@ -7,12 +7,15 @@ pytestmark = pytest.mark.gpu
 
 
 def make_policy(nobs, nu, hidden=256, seed=0):
-    """torch.manual_seed(0) default nn.Linear initialisation, exported as [in, out]."""
-    import torch
-    torch.manual_seed(seed)
-    layers = [torch.nn.Linear(nobs, hidden), torch.nn.Linear(hidden, hidden), torch.nn.Linear(hidden, nu)]
-    ws = [l.weight.detach().numpy().T.copy() for l in layers]
-    bs = [l.bias.detach().numpy().copy() for l in layers]
+    """nn.Linear-style initialisation U(-1/sqrt(fan_in), 1/sqrt(fan_in)) from a fixed numpy seed, as [in, out]
+    (numpy rather than torch so the GPU suite does not pay a torch import on a fresh box)."""
+    rng = np.random.default_rng(seed)
+    sizes = [nobs, hidden, hidden, nu]
+    ws, bs = [], []
+    for a, b in zip(sizes[:-1], sizes[1:]):
+        k = 1.0 / np.sqrt(a)
+        ws.append(rng.uniform(-k, k, size=(a, b)).astype(np.float32))
+        bs.append(rng.uniform(-k, k, size=b).astype(np.float32))
     return ws, bs
 
 

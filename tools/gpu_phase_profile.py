@@ -25,6 +25,6 @@ names = ["ctrl+check", "kinematics", "geoms/com/cinert/cdof", "crb+qM", "factorM
 tot = d.sum(1)
 print("envs %d; mean cycles per env-step (one wave) %.0f, median %.0f" % (N, tot.mean(), np.median(tot)))
 nc, ne, ni = b.counts()
-print("mean nefc %.1f niter %.1f" % (ne.mean(), ni.mean()))
+print("mean nefc %.1f niter %.1f; mean row updates per step (nefc x sweeps) %.0f" % (ne.mean(), ni.mean(), (ne * ni).mean()))
 for i, n in enumerate(names):
     print("%-24s %9.0f cycles  %5.1f %%" % (n, d[:, i].mean(), 100 * d[:, i].mean() / tot.mean()))

@@ -127,13 +127,11 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (int a = b; a > 0; a = m.body_parentid[a])
       for (int k = 0; k < m.body_dofnum[a]; k++) dofmask[b] |= 1ull << (m.body_dofadr[a] + k);
   // dof ancestry
-  std::vector<int> nanc(nv, 0), dof_qposadr(nv, 0), Mi(m.nM), Mj(m.nM);
+  std::vector<int> nanc(nv, 0), Mi(m.nM), Mj(m.nM);
   for (int i = 0; i < nv; i++) {
     int adr = m.dof_Madr[i];
     for (int j = i; j >= 0; j = m.dof_parentid[j]) { Mi[adr] = i; Mj[adr] = j; adr++; }
     nanc[i] = adr - m.dof_Madr[i] - 1;
-    int jn = m.dof_jntid[i];
-    dof_qposadr[i] = m.jnt_qposadr[jn] + (i - m.jnt_dofadr[jn]);
   }
   if (m.nM > 1023) { err = "sparse mass matrix too large for the packed index tables"; return false; }
   std::vector<int> fac_pack, piv4;
@@ -163,12 +161,6 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   }
   desc_adr[nv] = (int)desc_pack.size();
   for (int i = 0; i < 4; i++) desc_pack.push_back(0);  // the half-solve reads four entries at a time
-  std::vector<int> hs_pack;
-  for (int k = nv - 1; k >= 0; k--) {
-    int e = m.dof_Madr[k] + 1;
-    for (int i = m.dof_parentid[k]; i >= 0; i = m.dof_parentid[i], e++) hs_pack.push_back(e | (k << 10) | (i << 16));
-  }
-  dm.nhs = (int)hs_pack.size();
   std::vector<int> chain((size_t)32 * (kMaxAnc + 1), 0);
   for (int i = 0; i < nv; i++) {
     int t = 0;
@@ -268,19 +260,11 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   std::vector<FO> fo;
 #define TI(field, vec) io.push_back({&dm.field, T.addi(vec)})
 #define TF(field, vec) fo.push_back({&dm.field, T.addf(vec)})
-  TI(body_parentid, m.body_parentid); TI(body_treeid, treeid); TI(body_jntnum, m.body_jntnum); TI(body_jntadr, m.body_jntadr);
-  TI(body_dofnum, m.body_dofnum); TI(body_dofadr, m.body_dofadr); TI(body_childadr, childadr); TI(body_childnum, childnum); TI(child_list, child_list);
-  TI(level_adr, level_adr); TI(level_num, level_num); TI(level_body, level_body);
-  TF(body_pos, m.body_pos); TF(body_quat, m.body_quat); TF(body_ipos, m.body_ipos); TF(body_iquat, m.body_iquat); TF(body_mass, m.body_mass);
-  TF(body_inertia, m.body_inertia); TF(body_invweight0, m.body_invweight0); TF(tree_invmass, tree_invmass);
-  TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TI(jnt_bodyid, m.jnt_bodyid);
-  TF(jnt_pos, m.jnt_pos); TF(jnt_axis, m.jnt_axis); TF(jnt_stiffness, m.jnt_stiffness); TF(qpos0, m.qpos0); TF(qpos_spring, m.qpos_spring);
-  TI(dof_bodyid, m.dof_bodyid); TI(dof_jntid, m.dof_jntid); TI(dof_parentid, m.dof_parentid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TI(dof_qposadr, dof_qposadr);
-  TF(dof_armature, m.dof_armature); TF(dof_damping, m.dof_damping);
-  TI(M_i, Mi); TI(M_j, Mj); TI(mrec, mrec);
+  TI(body_treeid, treeid); TF(body_invweight0, m.body_invweight0); TF(tree_invmass, tree_invmass);
+  TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TF(qpos0, m.qpos0); TI(dof_jntid, m.dof_jntid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TF(dof_damping, m.dof_damping); TI(M_j, Mj); TI(mrec, mrec);
   while (T.iv.size() % 4) T.iv.push_back(0);  // int4 alignment of the pivot table
   size_t o_piv = T.addi(piv4);
-  TI(fac_pack, fac_pack); TI(fac2, fac2); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(hs_pack, hs_pack); TI(chain, chain);
+  TI(fac_pack, fac_pack); TI(fac2, fac2); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(chain, chain);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
@@ -316,7 +300,6 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   // per-row meta (13 slots x kNefcMax) is dead once the row quantities are in registers; W = L^-1 D^-1/2
   // ([32][33]) is built over it before the J W product and lives until the dual finish
   dm.o_efc = take(std::max(13 * kNefcMax, 32 * 33));
-  dm.o_stage = dm.o_efc;
   dm.o_force = take(kGroup);
   int endB = off;
   // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias

@@ -40,31 +40,29 @@ struct DevModel {
   // options
   float timestep, gravity[3], inv_sqrt_impratio, tolerance, pgs_scale;
   int iterations, disableflags;
-  // body tables
-  const int HB_CONST *body_parentid, *body_treeid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_childadr, *body_childnum, *child_list;
-  const int HB_CONST *level_adr, *level_num, *level_body;
-  const float HB_CONST *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *tree_invmass;
-  const unsigned long long HB_CONST* body_dofmask;  // bit d set: dof d moves this body
-  // joint tables
-  const int HB_CONST *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
-  const float HB_CONST *jnt_pos, *jnt_axis, *jnt_stiffness, *qpos0, *qpos_spring;
-  // dof tables
-  const int HB_CONST *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr, *dof_nanc, *dof_qposadr;
-  const float HB_CONST *dof_armature, *dof_damping;
-  // level-ordered body records: [0] b,parent,jntnum,jntadr  [1] depth,treeid,mass,childnum  [2] pos  [3] quat  [4] ipos
-  // [5] iquat  [6] inertia  [7..8] children[8]  [9+3j] joint j: (type,qposadr,dofadr,qpos0) (axis) (pos)
+  // bodies.  Level-ordered records, kBrecQuads float4 each (slot 0 = world, slot s = lane s-1 of the tree passes):
+  // [0] b,parent,jntnum,jntadr  [1] depth,treeid,mass,childnum  [2] pos  [3] quat  [4] ipos  [5] iquat  [6] inertia
+  // [7..8] children[8]  [9+3j] joint j: (type,qposadr,dofadr,qpos0) (axis) (pos)
   const float4 HB_CONST* brec;
+  const int HB_CONST* body_treeid;
+  const float HB_CONST *body_invweight0, *tree_invmass;
+  const unsigned long long HB_CONST* body_dofmask;  // bit d set: dof d moves this body
+  // joints
+  const int HB_CONST *jnt_type, *jnt_qposadr, *jnt_dofadr;
+  const float HB_CONST* qpos0;
+  // dofs
   const float4 HB_CONST* drec;   // per dof: (jntid,bodyid,type,k) (treeid,armature,damping,stiffness) (qposadr,qpos_spring,-,-)
-  const int HB_CONST* mrec;      // per sparse M entry: i | j << 8 | body(i) << 16
-  const float2 HB_CONST* mdiag;  // per sparse M entry: (armature, damping) on the diagonal, 0 elsewhere
-  const int HB_CONST *M_i, *M_j;                                  // dof pair of each sparse mass-matrix entry
-  const int4 HB_CONST* piv;                                       // per pivot dof: {#strict ancestors, Madr, first triple, end triple}
-  const int HB_CONST* fac2;                              // fixed-stride copy: [pivot][128] packed triples, -1 = none
-  const int HB_CONST* fac_pack;                                   // L^T D L update triples: dst | src << 10 | tmp << 20
-  const int HB_CONST *desc_adr, *desc_pack;                       // descendants of each dof: k | address of L[k,i] << 8
-  const int HB_CONST* chain;                             // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)
-  const int HB_CONST* hs_pack;                                    // half-solve schedule: e | k << 10 | i << 16, pivots descending
-  int nhs;
+  const int HB_CONST *dof_jntid, *dof_Madr, *dof_nanc;
+  const float HB_CONST* dof_damping;
+  // sparse mass matrix (ancestor-chain layout of mjModel.dof_Madr)
+  const int HB_CONST* mrec;      // per entry: i | j << 8 | body(i) << 16
+  const float2 HB_CONST* mdiag;  // per entry: (armature, damping) on the diagonal, 0 elsewhere
+  const int HB_CONST* M_j;       // column dof of each entry (= the ancestors of the row dof, in chain order)
+  const int4 HB_CONST* piv;      // per pivot dof: {#strict ancestors, Madr, first triple, end triple}
+  const int HB_CONST* fac2;      // L^T D L update triples, fixed stride: [pivot][128] of dst | src << 10 | tmp << 20, -1 = none
+  const int HB_CONST* fac_pack;  // the same triples contiguous (pivots with more than 128)
+  const int HB_CONST *desc_adr, *desc_pack;  // descendants of each dof: k | address of L[k,i] << 8
+  const int HB_CONST* chain;     // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)
   // geoms
   const int HB_CONST *geom_type, *geom_bodyid;
   const float HB_CONST *geom_size, *geom_pos, *geom_quat, *geom_rbound;
@@ -89,10 +87,10 @@ struct DevModel {
   int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qM, o_qLD, o_dinv, o_dsqrtinv, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen, o_hdinv;
   // region A (dynamics scratch)
   int o_xpos, o_xquat, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cdofdot, o_cvel, o_cacc, o_cfrc;
-  // region B (constraints), aliases region A
-  int o_con, o_C, o_efc, o_stage, o_force;
+  // region B (constraints), aliases region A: contacts, C rows, row meta (later W), forces
+  int o_con, o_C, o_efc, o_force;
   int lds_floats;  // total floats per env
-  int cstride;     // row stride of C (odd, >= nv+1; column nv holds the extra right-hand side)
+  int cstride;     // row stride of C (odd: conflict-free lane-strided access; the last column is zero padding)
 };
 
 typedef const DevModel HB_CONST& DevModelRef;

@@ -362,45 +362,6 @@ __device__ __forceinline__ void factor_ld(DevModelRef M, float* LD, float* dinv,
   gsync();
 }
 
-// x <- L^-T x (single vector in LDS): pivots descending, push to ancestors (lane a = a-th ancestor)
-__device__ __forceinline__ void solve_lt_push(DevModelRef M, const float* LD, float* x, int lane) {
-  int4 pv = M.piv[M.nv - 1];
-  int anc = (lane < pv.x) ? M.M_j[pv.y + 1 + lane] : 0;
-  for (int k = M.nv - 1; k >= 0; k--) {
-    const int4 cur = pv;
-    const int i = anc;
-    if (k > 0) {
-      pv = M.piv[k - 1];
-      anc = (lane < pv.x) ? M.M_j[pv.y + 1 + lane] : 0;
-    }
-    if (cur.x == 0) continue;
-    const float xk = x[k];
-    if (lane < cur.x) x[i] -= LD[cur.y + 1 + lane] * xk;
-    gsync();
-  }
-}
-// x <- L^-1 x (single vector in LDS): dofs ascending, push to descendants
-__device__ __forceinline__ void solve_l_push(DevModelRef M, const float* LD, float* x, int lane) {
-  int t0 = M.desc_adr[0], t1 = M.desc_adr[1];
-  int pk = (t0 + lane < t1) ? M.desc_pack[t0 + lane] : -1;
-  for (int i = 0; i < M.nv; i++) {
-    const int c0 = t0, c1 = t1, cpk = pk;
-    if (i + 1 < M.nv) {
-      t0 = c1; t1 = M.desc_adr[i + 2];
-      pk = (t0 + lane < t1) ? M.desc_pack[t0 + lane] : -1;
-    }
-    if (c0 == c1) continue;
-    const float xi = x[i];
-    if (cpk >= 0) x[cpk & 255] -= LD[cpk >> 8] * xi;  // k | address of L[k,i] << 8
-    for (int t = c0 + lane + kGroup; t < c1; t += kGroup) {
-      const int q = M.desc_pack[t];
-      x[q & 255] -= LD[q >> 8] * xi;
-    }
-    gsync();
-  }
-}
-
-
 // W = L^-1 D^-1/2 (so that M^-1 = W W^T), dense row-major [32][kWs] in LDS.  L^-1 has the sparsity of L
 // (row i is supported on the ancestor chain of dof i) and from L^-1 L = I row i follows from its own
 // earlier entries and L along that chain:  Linv[i][c_t] = - sum_{s<t} Linv[i][c_s] L[c_s, c_t],

@@ -141,7 +141,8 @@ int hb_set_state_f64(hb_batch* b, unsigned spec, const double* in);
 
 /* Env adapter outputs, the 27-DoF analogue of CPUEnv._get_obs/_get_reward (cpu_env.py:465-616):
  * obs[n_env][nobs] = [hinge qpos (nv-6), hinge qvel (nv-6), root angular velocity (3),
- * gravity direction in the torso frame (3)]; reward/terminated/truncated may be NULL. */
+ * gravity direction in the torso frame (3)]; reward/terminated/truncated may be NULL; when requested they are
+ * evaluated with the current hb_env_config without resetting anything (pure query). */
 int hb_get_obs(hb_batch* b, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated);
 
 /* Per-env status bits (HB_WARN_*), accumulated since the last hb_reset; replaces polling

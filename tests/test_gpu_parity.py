@@ -415,3 +415,20 @@ def test_heightfield_terrain_humanoid_config5(hbmod, gpu):
     assert qq[:, 2].min() > -0.15 and qq[:, 2].max() < 1.5
     _, _, it = big.counts()
     assert set(np.unique(it)) <= {0, 50}
+
+
+def test_capacity_overflow_is_flagged_not_fatal(hbmod, gpu):
+    """More contacts / constraint rows than the device buffers hold: the extras are dropped and the env is
+    flagged (mjWARN_CONTACTFULL / mjWARN_CNSTRFULL semantics, mjdata.h:54-65), nothing crashes or goes NaN,
+    and other batches are unaffected."""
+    m = hbmod.Model.load(os.path.join(MODELS, "overflow.xml"))
+    assert m.nv == 30 and m.ngeom == 31
+    b = hbmod.Batch(m, 4, gpu)
+    b.step(np.zeros((4, 0), np.float32), n_substeps=3)
+    s = b.status()
+    assert (s & hbmod.WARN_CONTACTFULL).all() and (s & hbmod.WARN_CNSTRFULL).all()
+    nc, ne, _ = b.counts()
+    assert (nc == m.ncon_max).all() and (ne <= m.nefc_max).all() and (ne >= 60).all()
+    assert np.isfinite(b.qpos).all() and np.isfinite(b.qvel).all()
+    b.reset()
+    assert not b.status().any()

@@ -18,7 +18,7 @@ echo "== testspeed (C++ host)" | tee -a $OUT/progress.log
 timeout -k 10 300 ./build/hb_testspeed humanoid_mujoco_amd/assets/humanoid27.hbm 1000 4096 > $OUT/testspeed.log 2>&1; echo "testspeed rc=$?" | tee -a $OUT/progress.log
 cat $OUT/testspeed.log
 echo "== rocprofv3 kernel trace" | tee -a $OUT/progress.log
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-rollout > $OUT/prof_trace.log 2>&1; echo "trace rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- python3 bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-rollout > $OUT/prof_trace.log 2>&1; echo "trace rc=$?" | tee -a $OUT/progress.log
 echo "== rocprofv3 pmc FETCH" | tee -a $OUT/progress.log
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout > $OUT/prof_fetch.log 2>&1; echo "fetch rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout > $OUT/prof_write.log 2>&1; echo "write rc=$?" | tee -a $OUT/progress.log

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -134,22 +135,38 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     nanc[i] = adr - m.dof_Madr[i] - 1;
   }
   if (m.nM > 1023) { err = "sparse mass matrix too large for the packed index tables"; return false; }
-  std::vector<int> fac_pack, piv4;
-  for (int k = 0; k < nv; k++) {
-    int t0 = (int)fac_pack.size();
-    int Mki = m.dof_Madr[k] + 1, i = m.dof_parentid[k];
-    while (i >= 0) {
-      int cnt = nanc[i] + 1;
-      for (int t = 0; t < cnt; t++) fac_pack.push_back((m.dof_Madr[i] + t) | ((Mki + t) << 10) | (Mki << 20));
-      i = m.dof_parentid[i];
-      Mki++;
+  // L^T D L schedule by levels of the elimination tree (a dof is ready once all its descendant dofs are done)
+  std::vector<int> height(nv, 0);
+  for (int k = nv - 1; k >= 0; k--) { int p = m.dof_parentid[k]; if (p >= 0) height[p] = std::max(height[p], height[k] + 1); }
+  int maxh = 0;
+  for (int k = 0; k < nv; k++) maxh = std::max(maxh, height[k]);
+  std::vector<int> flev_adr, flev_ent;
+  for (int L = 0; L <= maxh; L++) {
+    std::map<int, std::vector<int>> by_dst;  // dst -> contributions of this level's pivots
+    for (int k = 0; k < nv; k++) {
+      if (height[k] != L) continue;
+      int Mki = m.dof_Madr[k] + 1, i = m.dof_parentid[k];
+      while (i >= 0) {
+        int cnt = nanc[i] + 1;
+        for (int t = 0; t < cnt; t++) by_dst[m.dof_Madr[i] + t].push_back((Mki + t) | (Mki << 10) | (m.dof_Madr[k] << 20));
+        i = m.dof_parentid[i];
+        Mki++;
+      }
     }
-    piv4.push_back(nanc[k]); piv4.push_back(m.dof_Madr[k]); piv4.push_back(t0); piv4.push_back((int)fac_pack.size());
+    if (by_dst.empty()) continue;
+    flev_adr.push_back((int)flev_ent.size() / 8);
+    for (auto& kv : by_dst) {
+      // more than four pivots of one level reaching the same entry: split into several records of the same dst
+      // is not allowed (two lanes would write it), so chain them through extra levels instead
+      if (kv.second.size() > 4) { err = "more than four sibling subtrees under one dof are not supported by the factorisation schedule"; return false; }
+      flev_ent.push_back(kv.first);
+      for (int q = 0; q < 4; q++) flev_ent.push_back(q < (int)kv.second.size() ? kv.second[q] : -1);
+      for (int q = 0; q < 3; q++) flev_ent.push_back(-1);  // pad to two int4
+    }
   }
-  dm.nfac = (int)fac_pack.size();
-  std::vector<int> fac2((size_t)std::max(nv, 1) * 128, -1);
-  for (int k = 0; k < nv; k++)
-    for (int t = piv4[4 * k + 2]; t < piv4[4 * k + 3] && t - piv4[4 * k + 2] < 128; t++) fac2[(size_t)k * 128 + (t - piv4[4 * k + 2])] = fac_pack[t];
+  flev_adr.push_back((int)flev_ent.size() / 8);
+  dm.nflev = (int)flev_adr.size() - 1;
+  dm.nfac = (int)flev_ent.size() / 8;
   std::vector<int> desc_adr(nv + 1, 0), desc_pack;
   for (int i = 0; i < nv; i++) {
     desc_adr[i] = (int)desc_pack.size();
@@ -262,9 +279,10 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
 #define TF(field, vec) fo.push_back({&dm.field, T.addf(vec)})
   TI(body_treeid, treeid); TF(body_invweight0, m.body_invweight0); TF(tree_invmass, tree_invmass);
   TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TF(qpos0, m.qpos0); TI(dof_jntid, m.dof_jntid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TF(dof_damping, m.dof_damping); TI(M_j, Mj); TI(mrec, mrec);
-  while (T.iv.size() % 4) T.iv.push_back(0);  // int4 alignment of the pivot table
-  size_t o_piv = T.addi(piv4);
-  TI(fac_pack, fac_pack); TI(fac2, fac2); TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(chain, chain);
+  TI(flev_adr, flev_adr);
+  while (T.iv.size() % 4) T.iv.push_back(0);  // int4 alignment
+  size_t o_flev = T.addi(flev_ent);
+  TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(chain, chain);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
@@ -315,7 +333,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   for (auto& x : io) *x.p = D.d_int + x.o;
   for (auto& x : fo) *x.p = D.d_flt + x.o;
   dm.body_dofmask = D.d_u64 + o_mask;
-  dm.piv = reinterpret_cast<const int4*>(D.d_int + o_piv);
+  dm.flev_ent = reinterpret_cast<const int4*>(D.d_int + o_flev);
   dm.brec = reinterpret_cast<const float4*>(D.d_flt + o_brec);
   dm.drec = reinterpret_cast<const float4*>(D.d_flt + o_drec);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);

@@ -58,9 +58,11 @@ struct DevModel {
   const int HB_CONST* mrec;      // per entry: i | j << 8 | body(i) << 16
   const float2 HB_CONST* mdiag;  // per entry: (armature, damping) on the diagonal, 0 elsewhere
   const int HB_CONST* M_j;       // column dof of each entry (= the ancestors of the row dof, in chain order)
-  const int4 HB_CONST* piv;      // per pivot dof: {#strict ancestors, Madr, first triple, end triple}
-  const int HB_CONST* fac2;      // L^T D L update triples, fixed stride: [pivot][128] of dst | src << 10 | tmp << 20, -1 = none
-  const int HB_CONST* fac_pack;  // the same triples contiguous (pivots with more than 128)
+  // L^T D L schedule by elimination-tree level: flev_adr[nflev+1] into flev_ent, two int4 per destination entry:
+  // {dst, c0, c1, c2} {c3, -, -, -} with contributions c = src | tmp << 10 | Mkk << 20 (-1 = none)
+  const int HB_CONST* flev_adr;
+  const int4 HB_CONST* flev_ent;
+  int nflev;
   const int HB_CONST *desc_adr, *desc_pack;  // descendants of each dof: k | address of L[k,i] << 8
   const int HB_CONST* chain;     // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)
   // geoms

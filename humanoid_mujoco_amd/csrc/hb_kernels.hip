@@ -302,44 +302,42 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
 // L^T D L factorisation of the sparse matrices held in LD and (optionally) LD2 (LDS), lanes =
 // update triples of one pivot dof.  M and H = M + h*diag(damping) share their sparsity, so both
 // are factorised in lockstep: same index traffic, twice the independent arithmetic per lane.
-// The pivot row is read unscaled and never touched again after its pivot, so the division of
-// the off-diagonal entries by D is deferred to one pass at the end (one wave-sync per pivot instead
-// of two); the index words of the next pivot are fetched while the current one is processed.
 template <bool TWO>
 __device__ __forceinline__ void factor_ld(DevModelRef M, float* LD, float* dinv, float* dsqrtinv, float* LD2, float* dinv2, int lane) {
-  // fac2 is a fixed-stride copy of the update triples: pivot k, lane l -> fac2[k*128 + l] and [k*128 + 64 + l]
-  // (-1 = none), so the index words of later pivots can be fetched without waiting for anything
-  const int nv = M.nv;
-  const int HB_CONST* f2 = M.fac2;
-  int pa0 = f2[(nv - 1) * 128 + lane], pa1 = f2[(nv - 1) * 128 + 64 + lane];                          // pivot k
-  int pb0 = nv > 1 ? f2[(nv - 2) * 128 + lane] : -1, pb1 = nv > 1 ? f2[(nv - 2) * 128 + 64 + lane] : -1;  // pivot k-1
-  int4 pv = M.piv[nv - 1];  // nanc, Madr, t0, t1
-  for (int k = nv - 1; k >= 0; k--) {
-    const int4 cur = pv;
-    const int c0 = pa0, c1 = pa1;
-    pa0 = pb0; pa1 = pb1;
-    if (k > 0) pv = M.piv[k - 1];
-    if (k > 1) { pb0 = f2[(k - 2) * 128 + lane]; pb1 = f2[(k - 2) * 128 + 64 + lane]; }
-    if (cur.x == 0) continue;
-    const int Mkk = cur.y;
-    const float inv = 1.f / fmaxf(LD[Mkk], HB_MINVAL);
-    float inv2 = 0.f;
-    if (TWO) inv2 = 1.f / fmaxf(LD2[Mkk], HB_MINVAL);
-    if (c0 >= 0) {
-      const int dst = c0 & 1023, src = (c0 >> 10) & 1023, ti = c0 >> 20;
-      LD[dst] -= LD[src] * (LD[ti] * inv);
-      if (TWO) LD2[dst] -= LD2[src] * (LD2[ti] * inv2);
+  // Elimination by levels of the dof tree: pivots whose descendants are all done (both legs, both arms, ...)
+  // are eliminated together.  The work item is a destination entry of an ancestor row; it gathers the (up to
+  // four) contributions  M'[k,j] M'[k,i] / D[k]  of the pivots k of this level that reach it, so no two lanes
+  // write the same entry (deterministic, no atomics).  Pivot rows are read unscaled and are final when read;
+  // the division of L by D is one pass at the end.
+  const int nlev = M.nflev;
+  // records are two int4: {dst, c0, c1, c2}, {c3, -, -, -}; the first record of the next level is fetched
+  // while the current level is processed
+  int e0 = M.flev_adr[0], e1 = M.flev_adr[1];
+  int4 ra = {-1, -1, -1, -1}, rb = ra;
+  if (e0 + lane < e1) { ra = M.flev_ent[2 * (size_t)(e0 + lane)]; rb = M.flev_ent[2 * (size_t)(e0 + lane) + 1]; }
+  for (int L = 0; L < nlev; L++) {
+    const int c0 = e0, c1 = e1;
+    int4 qa = ra, qb = rb;
+    if (L + 1 < nlev) {
+      e0 = c1; e1 = M.flev_adr[L + 2];
+      ra = {-1, -1, -1, -1}; rb = ra;
+      if (e0 + lane < e1) { ra = M.flev_ent[2 * (size_t)(e0 + lane)]; rb = M.flev_ent[2 * (size_t)(e0 + lane) + 1]; }
     }
-    if (c1 >= 0) {
-      const int dst = c1 & 1023, src = (c1 >> 10) & 1023, ti = c1 >> 20;
-      LD[dst] -= LD[src] * (LD[ti] * inv);
-      if (TWO) LD2[dst] -= LD2[src] * (LD2[ti] * inv2);
-    }
-    for (int t = cur.z + lane + 2 * kGroup; t < cur.w; t += kGroup) {  // pivots with more than 128 triples (deep trees)
-      const int pk = M.fac_pack[t];
-      const int dst = pk & 1023, src = (pk >> 10) & 1023, ti = pk >> 20;
-      LD[dst] -= LD[src] * (LD[ti] * inv);
-      if (TWO) LD2[dst] -= LD2[src] * (LD2[ti] * inv2);
+    for (int e = c0 + lane; e < c1; e += kGroup) {
+      if (e != c0 + lane) { qa = M.flev_ent[2 * (size_t)e]; qb = M.flev_ent[2 * (size_t)e + 1]; }
+      const int dst = qa.x;
+      const int c[4] = {qa.y, qa.z, qa.w, qb.x};
+      float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (c[q] >= 0) {
+          const int src = c[q] & 1023, ti = (c[q] >> 10) & 1023, kk = c[q] >> 20;
+          acc += LD[src] * (LD[ti] * __builtin_amdgcn_rcpf(fmaxf(LD[kk], HB_MINVAL)));
+          if (TWO) acc2 += LD2[src] * (LD2[ti] * __builtin_amdgcn_rcpf(fmaxf(LD2[kk], HB_MINVAL)));
+        }
+      }
+      LD[dst] -= acc;
+      if (TWO) LD2[dst] -= acc2;
     }
     gsync();
   }

@@ -42,10 +42,21 @@ __device__ __forceinline__ void gsync() {
 }
 
 __device__ __forceinline__ float rdlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+// v_writelane_b32 (clang has no builtin for it; bind the LLVM intrinsic by name)
+extern "C" __device__ int hb_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 64 lanes, identical (and scalar) in every lane: four DPP steps inside each row of 16,
+// then the four row sums through scalar registers; no LDS traffic.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
 }
 // value known to be identical in every lane -> tell the compiler (scalar register, scalar branches)
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -1123,80 +1134,66 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     // ---------------------------------------------------------------- mj_fwdConstraint: warm start + PGS
     int niter = 0;
     if (nefc > 0) {
-      const float Ainv = 1.f / Aii;
+      // Rows >= nefc are inert by construction (zero AR entries, zero residual and force), so the
+      // unrolled row loops below run in unguarded 4-row chunks up to nefc rounded up.
+      const float nAinv = -1.f / Aii;
+      float arf = 0.f;  // (AR force)_lane
       if (!(M.disableflags & (1 << 8))) {
-        float jar = jw - aref;
+        const float jar = jw - aref;
         force = (rowact && jar < 0.f) ? -Dd * jar : 0.f;
+#pragma unroll
+        for (int c = 0; c < (kNefcMax + 3) / 4; c++) {
+          if (c * 4 < nefc) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (c * 4 + r < kNefcMax) arf += ar[c * 4 + r] * rdlane(force, c * 4 + r);
+          }
+        }
         // cost(f) = 0.5 f'AR f + f'b; keep the warm start only if it beats zero
-        float arf = 0.f;
-#pragma unroll
-        for (int j = 0; j < kNefcMax; j++)
-          if (j < nefc) arf += ar[j] * rdlane(force, j);
-        const float cost = uniformf(wave_sum(rowact ? force * (0.5f * arf + bvec) : 0.f));
-        if (cost > 0.f) force = 0.f;
+        const float cost = wave_sum(rowact ? force * (0.5f * arf + bvec) : 0.f);
+        if (cost > 0.f) { force = 0.f; arf = 0.f; }
       }
-      float res = bvec;
-#pragma unroll
-      for (int j = 0; j < kNefcMax; j++)
-        if (j < nefc) res += ar[j] * rdlane(force, j);
-      if (!rowact) res = 0.f;
-      // Gauss-Seidel sweeps.  Every lane proposes the update of its own row from its current
-      // residual; the proposal of lane i is the valid one when row i's turn comes, and its delta is
-      // broadcast so that all residuals follow (column form of the reference's row update).
-      // The row loop is unrolled (ar[i] must be a compile-time register index) in 8-row chunks with
-      // scalar guards; nefc and the lane id are re-materialised every sweep so that the 63 guard
-      // conditions are cheap scalar compares instead of hoisted, spilled masks.
+      float res = rowact ? bvec + arf : 0.f;
+      // Gauss-Seidel sweeps in column form.  Every lane proposes the step of its own row from its
+      // current residual, delta = max(-res/AR_ii, -force) (= max(0, force - res/AR_ii) - force); when
+      // row i's turn comes the proposal of lane i is the valid one: it is broadcast (v_readlane), all
+      // residuals follow (one fma with the lane's AR column entry) and v_writelane records it in the
+      // owner's lane.  The dependency chain per row is mul - max - readlane - fma.
       //
-      // The reference reverts a row update whose cost change comes out positive (> 1e-10), which
-      // exact 1-D minimisation never produces.  The fast sweep keeps that test off the dependency
-      // chain (residual -> proposal -> broadcast -> residual): it only records the largest change
-      // seen; if a sweep ever records a positive one, it is replayed from its saved start by the
-      // literal (slow) sweep, so the result is the reference's in every case.
+      // Cost change of the sweep: sum_i delta_i (0.5 delta_i AR_ii + res_i at its turn) telescopes to
+      // 0.5 delta . (res_before + res_after), one wave reduction per sweep instead of per-row terms.
+      //
+      // The reference reverts a row whose cost change is > 1e-10.  For scalar rows that is unreachable:
+      // the unclamped step gives -0.5 res^2 / AR_ii, the clamped one -f (res - 0.5 f AR_ii) with
+      // res > f AR_ii, both <= 0; the oracle counts its reverts and the tests assert zero.
       while (niter < M.iterations) {
-        int ne, ln;
+        int ne;
         asm volatile("s_mov_b32 %0, %1" : "=s"(ne) : "s"(nefc));
-        asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
-        const float force0 = force, res0 = res;
-        float improvement = 0.f;  // identical in every lane
-        float worst = 0.f;        // largest cost change of the sweep (identical in every lane)
-#pragma unroll
-        for (int c = 0; c < (kNefcMax + 7) / 8; c++) {
-          if (c * 8 < ne) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-              const int i = c * 8 + r;
-              if (i < kNefcMax && i < ne) {
-                const float fnew = fmaxf(0.f, force - res * Ainv);
-                const float delta = fnew - force;
-                const float di = rdlane(delta, i);
-                const float change = delta * (0.5f * delta * Aii + res);
-                res += ar[i] * di;
-                const float ci = rdlane(change, i);
-                improvement -= ci;
-                worst = fmaxf(worst, ci);
-                if (ln == i) force = fnew;
-              }
-            }
-          }
-        }
-        if (uniformf(worst) > 1e-10f) {  // never taken in practice; literal replay of this sweep
-          force = force0; res = res0; improvement = 0.f;
-#pragma unroll
-          for (int i = 0; i < kNefcMax; i++) {
-            if (i < ne) {
-              float fnew = fmaxf(0.f, force - res * Ainv);
-              float delta = fnew - force;
-              float change = delta * (0.5f * delta * Aii + res);
-              if (change > 1e-10f) { delta = 0.f; change = 0.f; }
-              const float di = rdlane(delta, i);
-              improvement -= rdlane(change, i);
-              if (ln == i) force += delta;
-              res += ar[i] * di;
-            }
-          }
-        }
+        const float nforce = -force, res0 = res;
+        int dl = 0;
+        // hand-unrolled (ar[i] needs a compile-time register index) with one scalar exit test per 4 rows
+#define HB_PGS_ROW(i)                                                              \
+  if ((i) < kNefcMax) {                                                            \
+    const float d_ = fmaxf(res * nAinv, nforce);                                   \
+    const int di_ = __builtin_amdgcn_readlane(__float_as_int(d_), (i));            \
+    res = __builtin_fmaf(ar[(i) < kNefcMax ? (i) : 0], __int_as_float(di_), res);  \
+    dl = hb_writelane(di_, (i), dl);                                               \
+  }
+#define HB_PGS_CHUNK(c) \
+  if ((c) * 4 >= ne) break; \
+  HB_PGS_ROW((c) * 4) HB_PGS_ROW((c) * 4 + 1) HB_PGS_ROW((c) * 4 + 2) HB_PGS_ROW((c) * 4 + 3)
+        do {
+          HB_PGS_CHUNK(0) HB_PGS_CHUNK(1) HB_PGS_CHUNK(2) HB_PGS_CHUNK(3) HB_PGS_CHUNK(4) HB_PGS_CHUNK(5) HB_PGS_CHUNK(6) HB_PGS_CHUNK(7)
+          HB_PGS_CHUNK(8) HB_PGS_CHUNK(9) HB_PGS_CHUNK(10) HB_PGS_CHUNK(11) HB_PGS_CHUNK(12) HB_PGS_CHUNK(13) HB_PGS_CHUNK(14) HB_PGS_CHUNK(15)
+        } while (0);
+#undef HB_PGS_CHUNK
+#undef HB_PGS_ROW
+        static_assert(kNefcMax <= 64, "PGS sweep is unrolled for at most 64 rows");
+        const float delta = __int_as_float(dl);
+        force += delta;  // a clamped row lands on exactly 0
+        const float improvement = -0.5f * wave_sum(delta * (res0 + res));
         niter++;
-        if (uniformf(improvement) * M.pgs_scale < M.tolerance) break;
+        if (improvement * M.pgs_scale < M.tolerance) break;
       }
     }
     if (lane < kNefcMax) s_force[lane] = rowact ? force : 0.f;

@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+static long g_pgs_reverts = 0;
+
 #define MINVAL 1E-15   /* mjMINVAL */
 #define MAXVAL 1E+10   /* mjmodel.h:23 mjMAXVAL */
 #define MINIMP 0.0001  /* mjmodel.h:25 */
@@ -1077,7 +1079,7 @@ static void fwd_constraint(const om_model* m, om_data* d) {
       if (f < 0) f = 0;
       double delta = f - old;
       double change = 0.5 * delta * delta * row[i] + delta * res;
-      if (change > 1e-10) { f = old; change = 0; }
+      if (change > 1e-10) { f = old; change = 0; __atomic_fetch_add(&g_pgs_reverts, 1, __ATOMIC_RELAXED); }
       d->efc_force[i] = f;
       improvement -= change;
     }
@@ -1094,6 +1096,10 @@ static void fwd_constraint(const om_model* m, om_data* d) {
   solve_ld(m, d->qacc, d->qLD, d->qLDiagInv);
   for (int k = 0; k < nv; k++) d->qacc[k] += d->qacc_smooth[k];
 }
+
+/* number of PGS row updates undone by the cost-change test since load (test evidence that the
+   device path may leave that test out: it never fires for scalar rows) */
+long om_pgs_reverts(void) { return __atomic_load_n(&g_pgs_reverts, __ATOMIC_RELAXED); }
 
 /* ------------------------------------------------------------------ top level ------------ */
 

@@ -52,6 +52,7 @@ def lib():
         L.om_halton.restype = cd; L.om_halton.argtypes = [ci, ci]
         L.om_init_env.argtypes = [vp, vp, ci]
         L.om_ctrl_env.argtypes = [vp, pd, ci, ci]
+        L.om_pgs_reverts.restype = ctypes.c_long; L.om_pgs_reverts.argtypes = []
         L.om_rollout_threads.restype = ctypes.c_longlong
         L.om_rollout_threads.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         _lib = L
@@ -205,6 +206,10 @@ class Oracle:
                 a += 1
                 j = par[j]
         return M
+
+    def pgs_reverts(self):
+        """PGS row updates undone by the reference's cost-change test since the library was loaded."""
+        return int(self.L.om_pgs_reverts())
 
     def rollout_threads(self, n_env, nstep, nthread, env_offset=0, want_qpos=False):
         q = np.zeros((n_env, self.nq)) if want_qpos else None

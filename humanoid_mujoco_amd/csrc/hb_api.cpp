@@ -306,8 +306,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.cstride = 33;
   dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
   dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(6 * nv);
-  dm.o_qM = take(m.nM); dm.o_qLD = take(m.nM); dm.o_dinv = take(nv); dm.o_dsqrtinv = take(nv); dm.o_smooth = take(nv);
-  dm.o_vec0 = take(nv); dm.o_vec1 = take(nv); dm.o_vec2 = take(nv); dm.o_tenlen = take(std::max(1, m.ntendon)); dm.o_hdinv = take(nv);
+  dm.o_qLD = take(2 * m.nM); dm.o_dinv = take(2 * nv); dm.o_dsqrtinv = take(nv); dm.o_smooth = take(nv);  // qLD, dinv: {M, H} pairs
+  dm.o_vec0 = take(nv); dm.o_vec1 = take(nv); dm.o_vec2 = take(nv); dm.o_tenlen = take(std::max(1, m.ntendon));
   int region = off;
   dm.o_xpos = take(3 * nb); dm.o_xquat = take(4 * nb); dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
   dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(10 * nb);

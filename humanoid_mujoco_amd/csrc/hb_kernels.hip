@@ -64,6 +64,7 @@ __device__ __forceinline__ float uniformf(float v) { return __int_as_float(__bui
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct V3 { float x, y, z; };
@@ -310,11 +311,14 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   return d0 + y * (d1 - d0);
 }
 
-// L^T D L factorisation of the sparse matrices held in LD and (optionally) LD2 (LDS), lanes =
-// update triples of one pivot dof.  M and H = M + h*diag(damping) share their sparsity, so both
-// are factorised in lockstep: same index traffic, twice the independent arithmetic per lane.
-template <bool TWO>
-__device__ __forceinline__ void factor_ld(DevModelRef M, float* LD, float* dinv, float* dsqrtinv, float* LD2, float* dinv2, int lane) {
+__device__ __forceinline__ f32x2 floor2(f32x2 v, float lo) {  // max(v, lo) per component, one v_med3_f32 each
+  return {__builtin_amdgcn_fmed3f(v.x, lo, __builtin_inff()), __builtin_amdgcn_fmed3f(v.y, lo, __builtin_inff())};
+}
+
+__device__ __forceinline__ void factor_ld(DevModelRef M, f32x2* LD, f32x2* dinv, float* dsqrtinv, int lane) {
+  // LD[e] = {entry of M, entry of H}: the two matrices share every index and ride the packed fp32
+  // instructions (v_pk_mul/v_pk_fma_f32, ds_read_b64) as one.
+  //
   // Elimination by levels of the dof tree: pivots whose descendants are all done (both legs, both arms, ...)
   // are eliminated together.  The work item is a destination entry of an ancestor row; it gathers the (up to
   // four) contributions  M'[k,j] M'[k,i] / D[k]  of the pivots k of this level that reach it, so no two lanes
@@ -338,35 +342,30 @@ __device__ __forceinline__ void factor_ld(DevModelRef M, float* LD, float* dinv,
       if (e != c0 + lane) { qa = M.flev_ent[2 * (size_t)e]; qb = M.flev_ent[2 * (size_t)e + 1]; }
       const int dst = qa.x;
       const int c[4] = {qa.y, qa.z, qa.w, qb.x};
-      float acc = 0.f, acc2 = 0.f;
+      f32x2 acc = {0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         if (c[q] >= 0) {
           const int src = c[q] & 1023, ti = (c[q] >> 10) & 1023, kk = c[q] >> 20;
-          acc += LD[src] * (LD[ti] * __builtin_amdgcn_rcpf(fmaxf(LD[kk], HB_MINVAL)));
-          if (TWO) acc2 += LD2[src] * (LD2[ti] * __builtin_amdgcn_rcpf(fmaxf(LD2[kk], HB_MINVAL)));
+          const f32x2 d = floor2(LD[kk], HB_MINVAL);
+          const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+          acc += LD[src] * (LD[ti] * r);
         }
       }
       LD[dst] -= acc;
-      if (TWO) LD2[dst] -= acc2;
     }
     gsync();
   }
   for (int i = lane; i < M.nv; i += kGroup) {
-    const int a = M.dof_Madr[i];
-    float d = fmaxf(LD[a], HB_MINVAL);
-    dinv[i] = 1.f / d;
-    dsqrtinv[i] = rsqrtf(d);
-    if (TWO) dinv2[i] = 1.f / fmaxf(LD2[a], HB_MINVAL);
+    const f32x2 d = floor2(LD[M.dof_Madr[i]], HB_MINVAL);
+    dinv[i] = {1.f / d.x, 1.f / d.y};
+    dsqrtinv[i] = rsqrtf(d.x);
   }
   gsync();
   for (int e = lane; e < M.nM; e += kGroup) {  // L[k,i] = M'[k,i] / D[k]
     const int pk = M.mrec[e];
     const int i = pk & 255, j = (pk >> 8) & 255;
-    if (i != j) {
-      LD[e] *= dinv[i];
-      if (TWO) LD2[e] *= dinv2[i];
-    }
+    if (i != j) LD[e] *= dinv[i];
   }
   gsync();
 }
@@ -375,10 +374,13 @@ __device__ __forceinline__ void factor_ld(DevModelRef M, float* LD, float* dinv,
 // (row i is supported on the ancestor chain of dof i) and from L^-1 L = I row i follows from its own
 // earlier entries and L along that chain:  Linv[i][c_t] = - sum_{s<t} Linv[i][c_s] L[c_s, c_t],
 // c_0 = i, c_1 = parent dof, ...  One lane per row, no cross-lane dependency; the chain (dof id and
-// address of its L row) comes packed from M.chain.  SQRT_OF_INV: dscale holds 1/D instead of D^-1/2.
+// address of its L row) comes packed from M.chain.  WHICH selects the M (0) or H (1) half of the
+// interleaved factor; this pass is bound by its 136 LDS reads per lane, so the halves are built when
+// needed (dword reads) rather than together (qword reads cost twice the LDS cycles).
 constexpr int kWs = 33;
-template <bool SQRT_OF_INV>
-__device__ __forceinline__ void build_w(DevModelRef M, const float* LD, const float* dscale, float* W, int lane) {
+template <int WHICH>
+__device__ __forceinline__ void build_w(DevModelRef M, const f32x2* LD2, const f32x2* dinv, const float* dsqrtinv, float* W, int lane) {
+  const float* LD = reinterpret_cast<const float*>(LD2) + WHICH;
   for (int idx = lane; idx < 32 * kWs; idx += kGroup) W[idx] = 0.f;
   gsync();
   if (lane < M.nv) {
@@ -388,21 +390,18 @@ __device__ __forceinline__ void build_w(DevModelRef M, const float* LD, const fl
     int c[kMaxAnc + 1], ca[kMaxAnc + 1];
     float u[kMaxAnc + 1];
 #pragma unroll
-    for (int t = 0; t <= kMaxAnc; t++) { const int pk = ch[t]; c[t] = pk & 255; ca[t] = pk >> 8; }
+    for (int t = 0; t <= kMaxAnc; t++) { const int pk = ch[t]; c[t] = pk & 255; ca[t] = 2 * (pk >> 8); }
     u[0] = 1.f;
 #pragma unroll
     for (int t = 1; t <= kMaxAnc; t++) {
       float acc = 0.f;
 #pragma unroll
-      for (int sx = 0; sx < t; sx++) acc += LD[ca[sx] + (t - sx)] * u[sx];
+      for (int sx = 0; sx < t; sx++) acc += LD[ca[sx] + 2 * (t - sx)] * u[sx];
       u[t] = (t <= n) ? -acc : 0.f;
     }
 #pragma unroll
     for (int t = 0; t <= kMaxAnc; t++)
-      if (t <= n) {
-        const float d = dscale[c[t]];
-        W[i * kWs + c[t]] = u[t] * (SQRT_OF_INV ? sqrtf(d) : d);
-      }
+      if (t <= n) W[i * kWs + c[t]] = u[t] * (WHICH ? sqrtf(dinv[c[t]].y) : dsqrtinv[c[t]]);
   }
   gsync();
 }
@@ -429,10 +428,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   float* s_gaxis = lds + M.o_gaxis;
   float* s_scom = lds + M.o_scom;
   float* s_cdof = lds + M.o_cdof;
-  float* s_qH = lds + M.o_qM;    // H = M + h*diag(damping), factorised in place
-  float* s_hdinv = lds + M.o_hdinv;
-  float* s_qLD = lds + M.o_qLD;
-  float* s_dinv = lds + M.o_dinv;
+  // {M, H = M + h*diag(damping)} interleaved: assembled, factorised in place (L and D), later L | W_H
+  f32x2* s_qLD = reinterpret_cast<f32x2*>(lds + M.o_qLD);
+  f32x2* s_dinv = reinterpret_cast<f32x2*>(lds + M.o_dinv);  // {1/D, 1/D_H}
   float* s_dsqrtinv = lds + M.o_dsqrtinv;
   float* s_smooth = lds + M.o_smooth;  // qfrc_smooth
   float* s_v0 = lds + M.o_vec0;        // scratch dof vectors
@@ -671,15 +669,13 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       float sacc = 0.f;
       for (int t = 0; t < 6; t++) sacc += s_cdof[6 * j + t] * buf[t];
       sacc += ad.x;
-      s_qLD[e] = sacc;
       // H = M + h diag(damping): matrix of the implicit-damping Euler solve (mj_Euler), factorised alongside M
-      s_qH[e] = sacc + M.timestep * ad.y;
+      s_qLD[e] = {sacc, sacc + (eulerdamp ? M.timestep * ad.y : 0.f)};
     }
     gsync();
     HB_STAMP(4);
     // ---------------------------------------------------------------- mj_factorM
-    if (eulerdamp) factor_ld<true>(M, s_qLD, s_dinv, s_dsqrtinv, s_qH, s_hdinv, lane);
-    else factor_ld<false>(M, s_qLD, s_dinv, s_dsqrtinv, nullptr, nullptr, lane);
+    factor_ld(M, s_qLD, s_dinv, s_dsqrtinv, lane);
 
     HB_STAMP(5);
     // ---------------------------------------------------------------- mj_comVel + mj_rne forward pass
@@ -1039,7 +1035,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     // rows 0..nefc-1 are constraint rows, row nefc is qfrc_smooth (-> y = D^-1/2 L^-T qfrc_smooth).
     // 32-row tiles x 32 dof columns x K = 32 on the matrix cores; A operands are preloaded so the
     // product can be written back over J in place.
-    build_w<false>(M, s_qLD, s_dsqrtinv, s_W, lane);
+    build_w<0>(M, s_qLD, s_dinv, s_dsqrtinv, s_W, lane);
     {
       const int col = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -1213,7 +1209,16 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         const float* Wr = s_W + lane * kWs;
         for (int n = 0; n < nv; n++) qacc_i += Wr[n] * s_v2[n];
         float acc = s_v1[lane];
-        for (int t = M.desc_adr[lane]; t < M.desc_adr[lane + 1]; t++) { const int pk = M.desc_pack[t]; acc += s_qLD[pk >> 8] * s_v1[pk & 255]; }
+        // descendants of this dof, four table entries in flight at a time (the table is padded by four)
+        const int t1 = M.desc_adr[lane + 1];
+        for (int t = M.desc_adr[lane]; t < t1; t += 4) {
+          int pk[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) pk[q] = M.desc_pack[t + q];
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (t + q < t1) acc += s_qLD[pk[q] >> 8].x * s_v1[pk[q] & 255];
+        }
         rhs_i = s_smooth[lane] + acc;  // qfrc_smooth + qfrc_constraint: right-hand side of the Euler solve
         if (P.qfrc_out) P.qfrc_out[(size_t)env * nv + lane] = rhs_i;
       }
@@ -1260,7 +1265,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       if (eulerdamp) {
         // qacc' = H^-1 (qfrc_smooth + qfrc_constraint), H^-1 = W_H W_H^T; W_H is built in the (now dead) C rows
         float* WH = s_C;
-        build_w<true>(M, s_qH, s_hdinv, WH, lane);
+        build_w<1>(M, s_qLD, s_dinv, s_dsqrtinv, WH, lane);
         float p = 0.f;
         if (lane < nv) for (int k = 0; k < nv; k++) p += WH[k * kWs + lane] * s_v2[k];  // p = W_H^T rhs
         gsync();

@@ -2,8 +2,12 @@
 """bench.py — headline benchmark: env-steps/s of the batched mj_step path, 27-DoF humanoid,
 4096 envs per GPU, Halton random actions (BASELINE.json configs[1]).
 
-One "step" = one hb_step_dev launch = one physics step of every env of this rank's batch, with
-state and controls already resident in HBM.  N>1: one process per GPU (torch.distributed over
+One "step" = one hb_step_dev call = one physics step of every env of this rank's batch, with
+state and controls already resident in HBM.  The timed loop runs with hb_batch_pipeline on: each call
+enqueues the batch as two env segments on two streams, so the slow tail of one step overlaps the
+next (same results, tests/test_gpu_parity.py::test_pipelined_stepping_is_bit_identical).  The roofline
+object is measured on a second, unpipelined leg (one 4096-block launch per step, HIP events on the
+launch stream) so that it is a per-launch figure comparable with the rocprofv3 kernel trace.  N>1: one process per GPU (torch.distributed over
 RCCL for the barrier and the max-over-ranks reduction only — the path has no data collective;
 envs shard by env_offset = rank * 4096), weak scaling.
 
@@ -75,6 +79,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the second (single-launch rollout) measurement, e.g. under rocprofv3")
+    ap.add_argument("--no-pipeline", action="store_true", help="time the unpipelined step API (one launch per step) as `value`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +125,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    pipelined = not args.no_pipeline
+    batch.pipeline(pipelined)
     for t in range(W):
         batch.step_dev(ctrl + t * stride)
     barrier()
@@ -127,7 +134,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(W, W + K):
         batch.step_dev(ctrl + t * stride)
-    region_ms = batch.timer_stop()  # HIP events around the whole timed region on the launch stream; also drains it
+    region_ms = batch.timer_stop()  # HIP events around the whole timed region on the batch's stream (joins the segments); also drains it
     batch.sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -136,6 +143,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         dist.barrier()
+    status = batch.status()
+    nc, ne, ni = batch.counts()
+
+    # Roofline leg: the dominant kernel as ONE launch per step (all 4096 envs), unpipelined, continuing from
+    # the state the timed loop left; HIP events around KR back-to-back launches on the launch stream.
+    batch.pipeline(False)
+    KR = min(K, 200)
+    for t in range(5):
+        batch.step_dev(ctrl + (W + t) * stride)
+    batch.sync()
+    batch.timer_start()
+    for t in range(KR):
+        batch.step_dev(ctrl + (W + t) * stride)
+    launch_us = 1e3 * batch.timer_stop() / KR
 
     # Second measurement, reported beside `value`: the same K steps as ONE hb_rollout_dev launch (state
     # resident on chip, each env advancing through its own K steps without a per-step batch barrier) —
@@ -156,11 +177,8 @@ def main():
         elapsed_rollout = float(tt.item())
         dist.barrier()
 
-    status = batch.status()
-    nc, ne, ni = batch.counts()
     if rank == 0:
         value = n_env * world * K / elapsed
-        launch_us = 1e3 * region_ms / K  # HIP events around the timed region on the launch stream / K launches (includes launch gaps)
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (launch_us * 1e-6) / 1e9
         traffic = load_traffic()
         out = {
@@ -168,13 +186,15 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d parallel humanoid envs per GPU, Halton random actions, fp32, PGS<=50 iters tol 1e-8, dt 0.005, one mj_step per launch"
-                                   % n_env,
+            "config": {"workload": "configs[1]: %d parallel humanoid envs per GPU, Halton random actions, fp32, PGS<=50 iters tol 1e-8, dt 0.005, one mj_step of every env per hb_step_dev call%s"
+                                   % (n_env, " (pipelined: 2 env segments on 2 streams)" if pipelined else ""),
                        "model": "27-DoF humanoid (assets/humanoid27.hbm)", "envs_per_gpu": n_env, "global_envs": n_env * world,
                        "sharding": "env blocks by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                         "kernel": "hb_step_kernel", "avg_launch_us": launch_us,
+                         "kernel": "hb_step_kernel", "avg_launch_us": launch_us, "launches": KR,
+                         "launch_shape": "%d blocks x 64 lanes, one env per block, unpipelined leg" % n_env,
+                         "timed_region_ms_per_step": region_ms / K,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_env,
                          "note": "path is latency/VALU bound, not HBM bound (SURVEY.md §8d); see DESIGN.md"},
             "state_check": {"envs_with_warnings": int((status != 0).sum()), "mean_ncon": float(nc.mean()), "mean_nefc": float(ne.mean()),

@@ -381,8 +381,19 @@ struct hb_batch {
   int tev_used = 0;
   long long launch_count = 0;
   int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
-  bool order_valid = false;
+  int order_mode = 0;       // 0: none yet, 1: one permutation of the whole batch, 2: one permutation per pipe segment
   bool schedule = true;
+  // Pipelined stepping (hb_batch_pipeline): the batch is cut into npipe fixed env segments, each stepped by
+  // its own launch on its own stream.  Envs are independent, so segment c of step t+1 only has to follow
+  // segment c of step t: the tail of one step (its slowest envs) overlaps the head of the next.  `stream`
+  // stays the batch's ordering point: pipes fork from it at every step call and are joined back into it
+  // before anything else is enqueued on it.
+  static constexpr int kPipes = 4;  // streams created; npipe of them in use
+  int npipe = 0;                    // 0: unpipelined
+  bool forked = false;
+  hipStream_t pipe[kPipes] = {};
+  hipEvent_t ev_fork = nullptr, ev_pipe[kPipes] = {};
+  int join_error = 0;
 };
 
 namespace {
@@ -405,25 +416,71 @@ BatchPtrs make_ptrs(hb_batch* b) {
   if (b->diag) { P.diag_qacc = b->d_diag_qacc; P.diag_force = b->d_diag_force; P.diag_contact = b->d_diag_contact; }
   P.n_env = b->n_env;
   P.integrate = 1;
-  if (b->schedule && b->order_valid) P.order = b->d_order;
+  if (b->schedule && b->order_mode) P.order = b->d_order;
+  P.blk0 = 0; P.nblk = b->n_env;
   P.stamps = b->d_stamps;
   return P;
 }
 
 
-// launch the step kernel, then (heavy-first scheduling) the tiny kernel that orders the next launch's blocks
-int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
-  const bool sample = b->time_steps && (b->launch_count % 8 == 0) && b->tev_used + 2 <= (int)b->tev.size();
-  if (sample) HB_HIP(hipEventRecord(b->tev[b->tev_used], b->stream));
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, nsteps, b->stream));
-  if (sample) { HB_HIP(hipEventRecord(b->tev[b->tev_used + 1], b->stream)); b->tev_used += 2; }
-  // heavy-first scheduling: re-sort the envs by the cost of the step just enqueued; costs change slowly, so
-  // every 4th launch is enough (the sort kernel sits on the critical path of the stream)
-  if (b->schedule && (b->launch_count % 4 == 0)) {
-    HB_HIP(launch_order(b->d_counts, b->d_order, b->n_env, b->stream));
-    b->order_valid = true;
+// order `stream` behind every pipe (no-op unless steps are in flight on the pipes)
+void join_pipes(hb_batch* b) {
+  if (!b->forked) return;
+  for (int c = 0; c < b->npipe; c++) {
+    if (hipEventRecord(b->ev_pipe[c], b->pipe[c]) != hipSuccess || hipStreamWaitEvent(b->stream, b->ev_pipe[c], 0) != hipSuccess) b->join_error = 1;
   }
+  b->forked = false;
+}
+// the batch's stream, ordered behind all enqueued steps: every use of the stream outside launch_steps goes through here
+hipStream_t main_stream(hb_batch* b) {
+  join_pipes(b);
+  return b->stream;
+}
+
+// number of segments the next step call is cut into (1: one launch on the batch's stream)
+int segment_count(const hb_batch* b) { return (b->npipe > 1 && !b->time_steps && b->n_env >= 64 * b->npipe) ? b->npipe : 1; }
+struct Segment { int lo, hi; hipStream_t st; };
+Segment segment(hb_batch* b, int c, int nseg) {
+  if (nseg == 1) return {0, b->n_env, b->stream};
+  return {(int)((long long)b->n_env * c / nseg), (int)((long long)b->n_env * (c + 1) / nseg), b->pipe[c]};
+}
+// fork: the pipes see everything enqueued on the batch's stream so far (controls written there, resets, ...)
+int fork_pipes(hb_batch* b, int nseg) {
+  if (nseg == 1) { join_pipes(b); return HB_OK; }
+  HB_HIP(hipEventRecord(b->ev_fork, b->stream));
+  for (int c = 0; c < nseg; c++) HB_HIP(hipStreamWaitEvent(b->pipe[c], b->ev_fork, 0));
+  b->forked = true;
+  return HB_OK;
+}
+// one segment's launch of the step kernel, then (heavy-first scheduling, every 4th call) the tiny kernel that
+// orders the segment's next launch by the cost of this one; costs change slowly, and the sort sits on the
+// critical path of its stream
+int launch_segment(hb_batch* b, BatchPtrs P, int nsteps, const Segment& sg, int nseg, bool reorder) {
+  P.blk0 = sg.lo; P.nblk = sg.hi - sg.lo;
+  // a whole-batch permutation would mix segments: a segment only uses the order of its own envs
+  P.order = (b->schedule && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2)) ? b->d_order : nullptr;
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, nsteps, sg.st));
+  if (reorder) HB_HIP(launch_order(b->d_counts, b->d_order, sg.lo, sg.hi - sg.lo, sg.st));
+  return HB_OK;
+}
+void steps_enqueued(hb_batch* b, int nseg, bool reorder) {
+  if (reorder) b->order_mode = nseg == 1 ? 1 : 2;
   b->launch_count++;
+}
+
+int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
+  const int nseg = segment_count(b);
+  const bool sample = nseg == 1 && b->time_steps && (b->launch_count % 8 == 0) && b->tev_used + 2 <= (int)b->tev.size();
+  const bool reorder = b->schedule && (b->launch_count % 4 == 0);
+  int rc = fork_pipes(b, nseg);
+  if (rc != HB_OK) return rc;
+  if (sample) HB_HIP(hipEventRecord(b->tev[b->tev_used], b->stream));
+  for (int c = 0; c < nseg; c++) {
+    rc = launch_segment(b, P, nsteps, segment(b, c, nseg), nseg, reorder);
+    if (rc != HB_OK) return rc;
+  }
+  if (sample) { HB_HIP(hipEventRecord(b->tev[b->tev_used + 1], b->stream)); b->tev_used += 2; }
+  steps_enqueued(b, nseg, reorder);
   return HB_OK;
 }
 
@@ -447,7 +504,7 @@ int get_state_impl(hb_batch* b, unsigned spec, T* out) {
   int ns = b->D.dm.nstate, n = b->n_env, w = spec_size(m, spec);
   std::vector<float> host((size_t)n * ns), xf;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   HB_HIP(hipMemcpy(host.data(), b->d_state, host.size() * sizeof(float), hipMemcpyDeviceToHost));
   if (spec & HB_STATE_XFRC_APPLIED) {
     xf.assign((size_t)n * 6 * m.nbody, 0.f);
@@ -472,7 +529,7 @@ int set_state_impl(hb_batch* b, unsigned spec, const T* in) {
   int ns = b->D.dm.nstate, n = b->n_env, w = spec_size(m, spec);
   std::vector<float> host((size_t)n * ns);
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   HB_HIP(hipMemcpy(host.data(), b->d_state, host.size() * sizeof(float), hipMemcpyDeviceToHost));
   std::vector<float> xf;
   if (spec & HB_STATE_XFRC_APPLIED) xf.assign((size_t)n * 6 * m.nbody, 0.f);
@@ -599,6 +656,9 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
   if (!build_device_model(m->m, b->D, e)) { set_err(err, err_sz, e); delete b; return nullptr; }
   const DevModel& dm = b->D.dm;
   bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (int c = 0; c < hb_batch::kPipes && ok; c++)
+    ok = hipStreamCreateWithFlags(&b->pipe[c], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&b->ev_pipe[c], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc((void**)&b->d_state, (size_t)n_env * dm.nstate * sizeof(float)) == hipSuccess;
   ok = ok && hipMalloc((void**)&b->d_status, (size_t)n_env * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&b->d_counts, (size_t)n_env * kCountStride * sizeof(int)) == hipSuccess;
@@ -614,6 +674,11 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
 void hb_batch_free(hb_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
+  for (int c = 0; c < hb_batch::kPipes; c++) {
+    if (b->pipe[c]) { (void)hipStreamSynchronize(b->pipe[c]); (void)hipStreamDestroy(b->pipe[c]); }
+    if (b->ev_pipe[c]) (void)hipEventDestroy(b->ev_pipe[c]);
+  }
+  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
   for (auto e : b->tev) (void)hipEventDestroy(e);
   for (int i = 0; i < 4; i++) { if (b->d_mlp_w[i]) (void)hipFree(b->d_mlp_w[i]); if (b->d_mlp_b[i]) (void)hipFree(b->d_mlp_b[i]); }
@@ -627,12 +692,30 @@ void hb_batch_free(hb_batch* b) {
 }
 
 int hb_batch_n_env(const hb_batch* b) { return b ? b->n_env : HB_EINVAL; }
-void* hb_batch_stream(const hb_batch* b) { return b ? (void*)b->stream : nullptr; }
+void* hb_batch_stream(hb_batch* b) { return b ? (void*)main_stream(b) : nullptr; }
 int hb_batch_sync(hb_batch* b) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  if (b->join_error) { b->join_error = 0; return HB_ENODEVICE; }
   return HB_OK;
+}
+int hb_batch_pipeline(hb_batch* b, int on) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  join_pipes(b);
+  if (on < 0 || on > hb_batch::kPipes) return HB_EINVAL;
+  // 1: default segment count.  Two segments of 2048 envs each fill the chip on their own (2048 resident
+  // waves) and measured best on MI355X; more segments than hardware queues serialise (tools/gpu_pipeline_sweep.py)
+  b->npipe = on == 1 ? 2 : on;
+  b->order_mode = 0;            // segment boundaries changed: per-segment permutations are stale
+  return HB_OK;
+}
+int hb_batch_join(hb_batch* b) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  join_pipes(b);
+  return b->join_error ? HB_ENODEVICE : HB_OK;
 }
 
 static int reset_impl(hb_batch* b, const uint8_t* mask, int keyframe, float perturb_scale, int env_offset) {
@@ -643,13 +726,13 @@ static int reset_impl(hb_batch* b, const uint8_t* mask, int keyframe, float pert
   const uint8_t* dmask = nullptr;
   if (mask) {
     if (!b->d_mask && hipMalloc((void**)&b->d_mask, b->n_env) != hipSuccess) return HB_ENOMEM;
-    HB_HIP(hipMemcpyAsync(b->d_mask, mask, b->n_env, hipMemcpyHostToDevice, b->stream));
+    HB_HIP(hipMemcpyAsync(b->d_mask, mask, b->n_env, hipMemcpyHostToDevice, main_stream(b)));
     dmask = b->d_mask;
   }
   b->env_offset = env_offset;
   const float* src = b->D.d_qpos_src + (keyframe < 0 ? 0 : (size_t)(1 + keyframe) * m.nq);
-  HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, dmask, src, b->n_env, perturb_scale, env_offset, b->stream));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, dmask, src, b->n_env, perturb_scale, env_offset, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 
@@ -669,10 +752,10 @@ int hb_step(hb_batch* b, const float* ctrl, int n_substeps) {
   if (!b || n_substeps < 1 || (!ctrl && b->D.dm.nu > 0)) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   size_t n = (size_t)b->n_env * b->D.dm.nu;
-  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
   int rc = hb_step_dev(b, b->d_ctrl, n_substeps);
   if (rc != HB_OK) return rc;
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 
@@ -680,12 +763,12 @@ int hb_forward(hb_batch* b, const float* ctrl) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   size_t n = (size_t)b->n_env * b->D.dm.nu;
-  if (ctrl && n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
-  else if (n) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * sizeof(float), b->stream));
+  if (ctrl && n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  else if (n) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * sizeof(float), main_stream(b)));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, 1, b->stream));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, 1, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 
@@ -703,7 +786,7 @@ int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out) {
   size_t n = (size_t)T * b->n_env * b->D.dm.nu;
   int rc = ensure_ctrl(b, std::max<size_t>(n, 1));
   if (rc != HB_OK) return rc;
-  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
   size_t nq_out = (size_t)T * b->n_env * b->D.dm.nq;
   if (qpos_out && nq_out > b->qpos_out_cap) {
     if (b->d_qpos_out) (void)hipFree(b->d_qpos_out);
@@ -713,8 +796,8 @@ int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out) {
   }
   rc = hb_rollout_dev(b, b->d_ctrl, T, qpos_out ? b->d_qpos_out : nullptr);
   if (rc != HB_OK) return rc;
-  if (qpos_out) HB_HIP(hipMemcpyAsync(qpos_out, b->d_qpos_out, nq_out * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  if (qpos_out) HB_HIP(hipMemcpyAsync(qpos_out, b->d_qpos_out, nq_out * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 
@@ -766,7 +849,7 @@ static int env_eval(hb_batch* b, bool allow_reset, float* d_obs, float* d_reward
   const Model& m = b->model->m;
   const float* src = b->D.d_qpos_src + (cfg.reset_keyframe < 0 || cfg.reset_keyframe >= m.nkey ? 0 : (size_t)(1 + cfg.reset_keyframe) * m.nq);
   HB_HIP(launch_env(b->D.dm, cfg, b->d_state, b->d_qfrc, b->d_counts, b->d_prev, b->d_latest, src, b->d_episode, b->d_status, d_obs, d_reward, d_term, d_trunc,
-                    b->n_env, b->env_offset, b->stream));
+                    b->n_env, b->env_offset, main_stream(b)));
   return HB_OK;
 }
 
@@ -779,13 +862,13 @@ int hb_get_obs(hb_batch* b, float* obs, float* reward, uint8_t* terminated, uint
     rc = env_eval(b, false, b->d_obs, b->d_reward, b->d_term, b->d_trunc);  // pure evaluation: no reset, no bookkeeping
     if (rc != HB_OK) return rc;
   } else {
-    HB_HIP(launch_obs(b->D.dm, b->d_state, b->d_obs, n, b->stream));
+    HB_HIP(launch_obs(b->D.dm, b->d_state, b->d_obs, n, main_stream(b)));
   }
-  HB_HIP(hipMemcpyAsync(obs, b->d_obs, (size_t)n * nobs * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  if (reward) HB_HIP(hipMemcpyAsync(reward, b->d_reward, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  if (terminated) HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, b->stream));
-  if (truncated) HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, b->stream));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipMemcpyAsync(obs, b->d_obs, (size_t)n * nobs * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  if (reward) HB_HIP(hipMemcpyAsync(reward, b->d_reward, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  if (terminated) HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, main_stream(b)));
+  if (truncated) HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 
@@ -837,9 +920,9 @@ int hb_env_reset(hb_batch* b, float* obs) {
   if (rc != HB_OK) return rc;
   const EnvConfig& c = b->env_cfg;
   size_t nu = std::max(1, b->D.dm.nu);
-  HB_HIP(hipMemsetAsync(b->d_prev, 0, (size_t)b->n_env * nu * sizeof(float), b->stream));
-  HB_HIP(hipMemsetAsync(b->d_latest, 0, (size_t)b->n_env * nu * sizeof(float), b->stream));
-  HB_HIP(hipMemsetAsync(b->d_episode, 0, (size_t)b->n_env * sizeof(int), b->stream));
+  HB_HIP(hipMemsetAsync(b->d_prev, 0, (size_t)b->n_env * nu * sizeof(float), main_stream(b)));
+  HB_HIP(hipMemsetAsync(b->d_latest, 0, (size_t)b->n_env * nu * sizeof(float), main_stream(b)));
+  HB_HIP(hipMemsetAsync(b->d_episode, 0, (size_t)b->n_env * sizeof(int), main_stream(b)));
   rc = reset_impl(b, nullptr, c.reset_keyframe, c.reset_perturb, b->env_offset);
   if (rc != HB_OK) return rc;
   return hb_get_obs(b, obs, nullptr, nullptr, nullptr);
@@ -850,7 +933,7 @@ int hb_env_step_dev(hb_batch* b, const float* action_dev, int n_substeps, float*
   int rc = env_alloc(b);
   if (rc != HB_OK) return rc;
   int n = b->n_env * b->D.dm.nu;
-  if (n) HB_HIP(launch_action(action_dev, b->d_prev, b->d_latest, b->d_ctrl, n, b->stream));
+  if (n) HB_HIP(launch_action(action_dev, b->d_prev, b->d_latest, b->d_ctrl, n, main_stream(b)));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0;
   rc = launch_steps(b, P, n_substeps);
@@ -863,14 +946,14 @@ int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, fl
   int rc = env_alloc(b);
   if (rc != HB_OK) return rc;
   int n = b->n_env, nu = b->D.dm.nu, nobs = b->D.dm.nobs;
-  if (nu) HB_HIP(hipMemcpyAsync(b->d_action, action, (size_t)n * nu * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  if (nu) HB_HIP(hipMemcpyAsync(b->d_action, action, (size_t)n * nu * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
   rc = hb_env_step_dev(b, b->d_action, n_substeps, b->d_obs, b->d_reward, b->d_term, b->d_trunc);
   if (rc != HB_OK) return rc;
-  HB_HIP(hipMemcpyAsync(obs, b->d_obs, (size_t)n * nobs * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  HB_HIP(hipMemcpyAsync(reward, b->d_reward, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, b->stream));
-  HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, b->stream));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipMemcpyAsync(obs, b->d_obs, (size_t)n * nobs * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipMemcpyAsync(reward, b->d_reward, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 
@@ -881,7 +964,7 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
   int rc = env_alloc(b);
   if (rc != HB_OK) return rc;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   int maxh = 1;
   for (int l = 0; l < n_layers; l++) {
     if (!weights[l] || !biases[l]) return HB_EINVAL;
@@ -903,13 +986,15 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
 }
 
 // observation -> MLP -> b->d_ctrl, all on the batch's stream
-static int policy_forward(hb_batch* b) {
+// obs -> MLP -> ctrl for envs [lo, hi) on `st`
+static int policy_forward(hb_batch* b, int lo, int hi, hipStream_t st) {
   if (b->mlp_layers < 1) return HB_EINVAL;
-  HB_HIP(launch_obs(b->D.dm, b->d_state, b->d_obs, b->n_env, b->stream));
-  const float* x = b->d_obs;
+  const DevModel& dm = b->D.dm;
+  HB_HIP(launch_obs(dm, b->d_state + (size_t)lo * dm.nstate, b->d_obs + (size_t)lo * b->mlp_sizes[0], hi - lo, st));
+  const float* x = b->d_obs + (size_t)lo * b->mlp_sizes[0];
   for (int l = 0; l < b->mlp_layers; l++) {
-    float* y = (l + 1 == b->mlp_layers) ? b->d_ctrl : b->d_mlp_h[l & 1];
-    HB_HIP(launch_mlp_layer(x, b->d_mlp_w[l], b->d_mlp_b[l], y, b->n_env, b->mlp_sizes[l], b->mlp_sizes[l + 1], 1, b->stream));
+    float* y = ((l + 1 == b->mlp_layers) ? b->d_ctrl : b->d_mlp_h[l & 1]) + (size_t)lo * b->mlp_sizes[l + 1];
+    HB_HIP(launch_mlp_layer(x, b->d_mlp_w[l], b->d_mlp_b[l], y, hi - lo, b->mlp_sizes[l], b->mlp_sizes[l + 1], 1, st));
     x = y;
   }
   return HB_OK;
@@ -918,24 +1003,32 @@ static int policy_forward(hb_batch* b) {
 int hb_policy_eval(hb_batch* b, float* ctrl_out) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  int rc = policy_forward(b);
+  int rc = policy_forward(b, 0, b->n_env, main_stream(b));
   if (rc != HB_OK) return rc;
-  if (ctrl_out) HB_HIP(hipMemcpyAsync(ctrl_out, b->d_ctrl, (size_t)b->n_env * b->D.dm.nu * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  if (ctrl_out) HB_HIP(hipMemcpyAsync(ctrl_out, b->d_ctrl, (size_t)b->n_env * b->D.dm.nu * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 
 int hb_rollout_policy(hb_batch* b, int T, float* qpos_out_dev) {
   if (!b || T < 1) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
+  // every segment is its own obs -> MLP -> mj_step chain: with pipelining on, the chains run side by side
+  const int nseg = segment_count(b);
+  int rc = fork_pipes(b, nseg);
+  if (rc != HB_OK) return rc;
   for (int t = 0; t < T; t++) {
-    int rc = policy_forward(b);
-    if (rc != HB_OK) return rc;
+    const bool reorder = b->schedule && (b->launch_count % 4 == 0);
     BatchPtrs P = make_ptrs(b);
     P.ctrl = b->d_ctrl; P.ctrl_mode = 0;
     P.qpos_out = qpos_out_dev ? qpos_out_dev + (size_t)t * b->n_env * b->D.dm.nq : nullptr;
-    rc = launch_steps(b, P, 1);
-    if (rc != HB_OK) return rc;
+    for (int c = 0; c < nseg; c++) {
+      const Segment sg = segment(b, c, nseg);
+      rc = policy_forward(b, sg.lo, sg.hi, sg.st);
+      if (rc == HB_OK) rc = launch_segment(b, P, 1, sg, nseg, reorder);
+      if (rc != HB_OK) return rc;
+    }
+    steps_enqueued(b, nseg, reorder);
   }
   return HB_OK;
 }
@@ -943,7 +1036,7 @@ int hb_rollout_policy(hb_batch* b, int T, float* qpos_out_dev) {
 int hb_get_status(hb_batch* b, int* status) {
   if (!b || !status) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   HB_HIP(hipMemcpy(status, b->d_status, (size_t)b->n_env * sizeof(int), hipMemcpyDeviceToHost));
   return HB_OK;
 }
@@ -951,7 +1044,7 @@ int hb_get_status(hb_batch* b, int* status) {
 int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   std::vector<int> h((size_t)b->n_env * kCountStride);
   HB_HIP(hipMemcpy(h.data(), b->d_counts, h.size() * sizeof(int), hipMemcpyDeviceToHost));
   for (int e = 0; e < b->n_env; e++) {
@@ -978,7 +1071,7 @@ static int copy_out(hb_batch* b, float* out, const float* dev, size_t n) {
   if (!b || !out) return HB_EINVAL;
   if (!b->diag || !dev) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   HB_HIP(hipMemcpy(out, dev, n * sizeof(float), hipMemcpyDeviceToHost));
   return HB_OK;
 }
@@ -995,27 +1088,27 @@ void* hb_dev_alloc(hb_batch* b, uint64_t bytes) {
 void hb_dev_free(hb_batch* b, void* p) {
   if (!b || !p) return;
   (void)hipSetDevice(b->device);
-  (void)hipStreamSynchronize(b->stream);
+  (void)hipStreamSynchronize(main_stream(b));
   (void)hipFree(p);
 }
 int hb_memcpy_h2d(hb_batch* b, void* dst_dev, const void* src, uint64_t bytes) {
   if (!b || !dst_dev || !src) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, b->stream));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 int hb_memcpy_d2h(hb_batch* b, void* dst, const void* src_dev, uint64_t bytes) {
   if (!b || !dst || !src_dev) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, b->stream));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 int hb_halton_ctrl_dev(hb_batch* b, int T, int t0, int env_offset, float* out_dev) {
   if (!b || T < 1 || !out_dev) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(launch_halton_ctrl(out_dev, T, b->n_env, b->D.dm.nu, t0, env_offset, b->stream));
+  HB_HIP(launch_halton_ctrl(out_dev, T, b->n_env, b->D.dm.nu, t0, env_offset, main_stream(b)));
   return HB_OK;
 }
 int hb_get_stamps(hb_batch* b, unsigned long long* out) {
@@ -1027,7 +1120,7 @@ int hb_get_stamps(hb_batch* b, unsigned long long* out) {
     HB_HIP(hipMemset(b->d_stamps, 0, (size_t)b->n_env * 16 * sizeof(unsigned long long)));
     return HB_OK;  // first call arms the stamps; call again after a step to read them
   }
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   HB_HIP(hipMemcpy(out, b->d_stamps, (size_t)b->n_env * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return HB_OK;
 #else
@@ -1049,7 +1142,7 @@ int hb_step_timing(hb_batch* b, int enable) {
 int hb_step_timing_read(hb_batch* b, float* mean_us, int* samples) {
   if (!b || !mean_us) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipStreamSynchronize(b->stream));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   double tot = 0;
   int n = 0;
   for (int i = 0; i + 1 < b->tev_used; i += 2) {
@@ -1066,13 +1159,13 @@ int hb_timer_start(hb_batch* b) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   if (!b->ev0) { HB_HIP(hipEventCreate(&b->ev0)); HB_HIP(hipEventCreate(&b->ev1)); }
-  HB_HIP(hipEventRecord(b->ev0, b->stream));
+  HB_HIP(hipEventRecord(b->ev0, main_stream(b)));
   return HB_OK;
 }
 int hb_timer_stop(hb_batch* b, float* elapsed_ms) {
   if (!b || !elapsed_ms || !b->ev0) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipEventRecord(b->ev1, b->stream));
+  HB_HIP(hipEventRecord(b->ev1, main_stream(b)));
   HB_HIP(hipEventSynchronize(b->ev1));
   HB_HIP(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
   return HB_OK;

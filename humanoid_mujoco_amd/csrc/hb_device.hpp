@@ -123,10 +123,11 @@ struct BatchPtrs {
   float* diag_force;   // nullable [n_env][kNefcMax]
   float* diag_contact; // nullable [n_env][kNconMax][kDiagConStride]
   int n_env;
+  int blk0, nblk;      // this launch covers dispatch slots blk0 .. blk0+nblk-1 (one block each) of the batch
   int ctrl_mode;       // 0: ctrl[e][nu] held for all steps; 1: ctrl[t][e][nu]; 2: on-device Halton
   int t0, env_offset;  // Halton indexing
   int integrate;       // 1: mj_step, 0: mj_forward only
-  // heavy-first block scheduling (nullable): blocks take env = order[blockIdx.x], a permutation sorted by
+  // heavy-first block scheduling (nullable): slot s takes env = order[s], a permutation sorted by
   // the cost of each env's previous step (counts[4*e+3]) so the most expensive envs are dispatched first
   const int* order;    // [n_env]
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step

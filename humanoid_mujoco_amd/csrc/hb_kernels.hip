@@ -416,8 +416,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   extern __shared__ float lds[];
   const int lane0 = threadIdx.x;
   int lane = lane0;
-  if ((int)blockIdx.x >= P.n_env) return;
-  const int env = P.order ? P.order[blockIdx.x] : (int)blockIdx.x;
+  if ((int)blockIdx.x >= P.nblk) return;
+  const int slot = P.blk0 + (int)blockIdx.x;
+  const int env = P.order ? P.order[slot] : slot;
   const int nv = M.nv, nq = M.nq, nb = M.nbody, cs = M.cstride;
 
   float* s_qpos = lds + M.o_qpos;
@@ -1504,23 +1505,24 @@ __global__ __launch_bounds__(kGroup) void hb_mlp_layer_kernel(const float* X, co
 // last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
 // the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
 // which cannot change results (envs are independent).
-__global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int n_env) {
+__global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int e0, int n) {
+  // sorts envs e0 .. e0+n-1 into order[e0 .. e0+n-1]
   __shared__ int hist[256];
   __shared__ int base[256];
   const int tid = threadIdx.x;
   if (tid < 256) hist[tid] = 0;
   __syncthreads();
-  for (int e = tid; e < n_env; e += blockDim.x) {
+  for (int e = e0 + tid; e < e0 + n; e += blockDim.x) {
     int key = min(255, counts[kCountStride * e + 3] >> 3);
     atomicAdd(&hist[255 - key], 1);  // bin 0 = most expensive
   }
   __syncthreads();
   if (tid == 0) {
-    int acc = 0;
+    int acc = e0;
     for (int i = 0; i < 256; i++) { base[i] = acc; acc += hist[i]; }
   }
   __syncthreads();
-  for (int e = tid; e < n_env; e += blockDim.x) {
+  for (int e = e0 + tid; e < e0 + n; e += blockDim.x) {
     int key = min(255, counts[kCountStride * e + 3] >> 3);
     order[atomicAdd(&base[255 - key], 1)] = e;
   }
@@ -1547,7 +1549,7 @@ namespace hb {
 
 hipError_t launch_step(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   size_t shmem = (size_t)lds_floats * sizeof(float);
-  hipLaunchKernelGGL(hb_step_kernel, dim3(P.n_env), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   return hipGetLastError();
 }
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, float perturb, int env_offset, hipStream_t stream) {
@@ -1568,8 +1570,8 @@ hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, float* state, con
                      terminated, truncated, n_env, env_offset);
   return hipGetLastError();
 }
-hipError_t launch_order(const int* counts, int* order, int n_env, hipStream_t stream) {
-  hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, n_env);
+hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, e0, n);
   return hipGetLastError();
 }
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream) {

@@ -80,6 +80,8 @@ def lib():
     L.hb_batch_n_env.argtypes = [vp]
     L.hb_batch_stream.restype = vp; L.hb_batch_stream.argtypes = [vp]
     L.hb_batch_sync.argtypes = [vp]
+    L.hb_batch_pipeline.argtypes = [vp, ci]
+    L.hb_batch_join.argtypes = [vp]
     L.hb_reset.argtypes = [vp, vp, ci, ci, ci]
     L.hb_step.argtypes = [vp, vp, ci]
     L.hb_step_dev.argtypes = [vp, vp, ci]
@@ -217,6 +219,14 @@ class Batch:
 
     def sync(self):
         _check(lib().hb_batch_sync(self._h), "hb_batch_sync")
+
+    def pipeline(self, on=True):
+        """Pipelined stepping (hb_batch_pipeline): env segments (two by default) on their own streams, so the slow tail of
+        one step overlaps the next step.  Results are identical; see include/hb.h for the stream contract."""
+        _check(lib().hb_batch_pipeline(self._h, int(on)), "hb_batch_pipeline")  # True: 2 segments; 2..4: that many
+
+    def join(self):
+        _check(lib().hb_batch_join(self._h), "hb_batch_join")
 
     def reset(self, mask=None, keyframe=-1, perturb=False, env_offset=0):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)

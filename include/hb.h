@@ -102,9 +102,20 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
 /* Replaces mj_deleteData (mujoco.h:206). */
 void hb_batch_free(hb_batch* b);
 int hb_batch_n_env(const hb_batch* b);
-/* The HIP stream (hipStream_t as void*) all work of this batch is enqueued on. */
-void* hb_batch_stream(const hb_batch* b);
+/* The HIP stream (hipStream_t as void*) that orders all work of this batch.  Work the caller enqueues on
+ * it before a step call (e.g. a policy writing the controls) is seen by that step; every hb_* call is
+ * ordered after the steps enqueued before it.  The call itself performs hb_batch_join. */
+void* hb_batch_stream(hb_batch* b);
 int hb_batch_sync(hb_batch* b);
+/* Pipelined stepping (off by default; on = 1: two segments, on = 2..4: that many).  When on, hb_step_dev /
+ * hb_rollout*_dev cut the batch into fixed env segments and step each with its own launch on an internal stream: segment c of step t+1
+ * follows only segment c of step t, so the slowest envs of one step overlap the start of the next
+ * (envs are independent: results are identical to the unpipelined launch).  The internal streams fork
+ * from the batch's stream at every step call and are joined back by the next hb_* call of any other
+ * kind.  A caller that enqueues its OWN work on hb_batch_stream() after step calls must call
+ * hb_batch_join first (or fetch the stream again); callers that only use hb_* functions need nothing. */
+int hb_batch_pipeline(hb_batch* b, int on);
+int hb_batch_join(hb_batch* b);
 
 /* Replaces mj_resetData (keyframe < 0) / mj_resetDataKeyframe (mujoco.h:180,186) for the envs
  * whose mask byte is non-zero (mask == NULL: all).  perturb != 0 adds the deterministic

@@ -195,6 +195,35 @@ def test_sharding_by_env_offset_is_exact(hbmod, humanoid_model, gpu):
         assert np.array_equal(part.get_state(hbmod.STATE_INTEGRATION), sw[r * n:(r + 1) * n])
 
 
+def test_pipelined_stepping_is_bit_identical(hbmod, humanoid_model, gpu):
+    """hb_batch_pipeline: env segments on their own streams, each step following only its own
+    segment's previous step.  Same states, bit for bit, as the single launch per step — including
+    across a mid-run reset of some envs, a host state read and a switch back to unpipelined stepping."""
+    n, T = 1000, 40  # not a multiple of the segment count's natural sizes
+    ref = hbmod.Batch(humanoid_model, n, gpu)
+    pip = hbmod.Batch(humanoid_model, n, gpu)
+    pip.pipeline(3)  # three uneven segments
+    mask = (np.arange(n) % 7 == 0).astype(np.uint8)
+    for b in (ref, pip):
+        b.reset(perturb=True)
+        for t in range(T):
+            b.rollout_halton(1, t0=t)
+        mid = b.get_state(hbmod.STATE_INTEGRATION)     # joins the pipes
+        b.reset(mask=mask, perturb=True)
+        for t in range(T, 2 * T):
+            b.rollout_halton(1, t0=t)
+        if b is pip:
+            b.pipeline(False)
+        b.rollout_halton(5, t0=2 * T)
+        b.final = b.get_state(hbmod.STATE_INTEGRATION)
+        b.mid = mid
+    assert np.array_equal(ref.mid, pip.mid)
+    assert np.array_equal(ref.final, pip.final)
+    assert np.array_equal(ref.status(), pip.status())
+    for a, c in zip(ref.counts(), pip.counts()):
+        assert np.array_equal(a, c)
+
+
 def test_state_io_reset_and_keyframes(hbmod, humanoid_model, gpu):
     m = humanoid_model
     n = 16

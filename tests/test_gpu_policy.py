@@ -69,6 +69,25 @@ def test_closed_loop_rollout_matches_host_loop(hbmod, humanoid_model, gpu):
     assert np.abs(d.qpos - e.qpos).max() < 1e-4
 
 
+def test_pipelined_policy_rollout_is_bit_identical(hbmod, humanoid_model, gpu):
+    """With hb_batch_pipeline on, every env segment runs its own obs -> MLP -> mj_step chain on its own
+    stream; the closed-loop result is the unpipelined one bit for bit."""
+    m = humanoid_model
+    n, T = 600, 30
+    ws, bs = make_policy(m.nobs, m.nu)
+    out = []
+    for segs in (0, 2, 3):
+        b = hbmod.Batch(m, n, gpu)
+        b.reset(perturb=True)
+        b.set_policy_mlp(ws, bs)
+        b.pipeline(segs)
+        b.rollout_policy(T)
+        b.rollout_policy(3)
+        out.append(b.get_state(hbmod.STATE_INTEGRATION))
+    assert np.array_equal(out[0], out[1])
+    assert np.array_equal(out[0], out[2])
+
+
 def test_policy_argument_checks(hbmod, humanoid_model, gpu):
     m = humanoid_model
     b = hbmod.Batch(m, 8, gpu)

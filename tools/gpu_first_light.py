@@ -48,3 +48,13 @@ for i in range(100): b2.rollout_halton(1, t0=110+i)
 b2.sync(); dt = time.time()-t0
 print('100 single-step launches: %.4f s -> %.3e env-steps/s' % (dt, N*100/dt))
 nc, ne, ni = b2.counts(); print('mean ncon', nc.mean(), 'nefc', ne.mean(), 'niter', ni.mean(), 'max nefc', ne.max(), 'status nonzero', (b2.status()!=0).sum())
+b3 = hb.Batch(m, N, 0)
+b3.reset(perturb=True); b3.pipeline(True)  # two segments
+b3.rollout_halton(10); b3.sync()
+b3.rollout_halton(100, t0=10); b3.sync()
+t0 = time.time()
+for i in range(100): b3.rollout_halton(1, t0=110+i)
+b3.sync(); dt = time.time()-t0
+print('100 single-step launches, pipelined: %.4f s -> %.3e env-steps/s' % (dt, N*100/dt))
+s2 = b2.get_state(hb.STATE_INTEGRATION); s3 = b3.get_state(hb.STATE_INTEGRATION)
+print('pipelined state identical:', np.array_equal(s2, s3))

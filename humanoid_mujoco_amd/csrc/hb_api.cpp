@@ -373,6 +373,8 @@ struct hb_batch {
   int mlp_layers = 0;
   int mlp_sizes[5] = {0, 0, 0, 0, 0};
   float* d_mlp_w[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* d_mlp_wp[4] = {nullptr, nullptr, nullptr, nullptr};  // packed for hb_policy_kernel (all widths <= 256), else null
+  bool mlp_fused = false;
   float* d_mlp_b[4] = {nullptr, nullptr, nullptr, nullptr};
   float* d_mlp_h[2] = {nullptr, nullptr};  // hidden activations, ping-pong
   // optional per-kernel timing of the step kernel (hb_step_timing)
@@ -681,7 +683,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
   for (auto e : b->tev) (void)hipEventDestroy(e);
-  for (int i = 0; i < 4; i++) { if (b->d_mlp_w[i]) (void)hipFree(b->d_mlp_w[i]); if (b->d_mlp_b[i]) (void)hipFree(b->d_mlp_b[i]); }
+  for (int i = 0; i < 4; i++) { if (b->d_mlp_w[i]) (void)hipFree(b->d_mlp_w[i]); if (b->d_mlp_b[i]) (void)hipFree(b->d_mlp_b[i]); if (b->d_mlp_wp[i]) (void)hipFree(b->d_mlp_wp[i]); }
   for (int i = 0; i < 2; i++) if (b->d_mlp_h[i]) (void)hipFree(b->d_mlp_h[i]);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -966,8 +968,24 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
   HB_HIP(hipSetDevice(b->device));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   int maxh = 1;
+  bool fused = true;  // one-launch policy kernel: every width fits its LDS tiles
+  for (int l = 0; l <= n_layers; l++) fused = fused && sizes[l] <= 256;
   for (int l = 0; l < n_layers; l++) {
     if (!weights[l] || !biases[l]) return HB_EINVAL;
+    if (b->d_mlp_wp[l]) { (void)hipFree(b->d_mlp_wp[l]); b->d_mlp_wp[l] = nullptr; }
+    if (fused) {
+      // B-operand order of v_mfma_f32_32x32x2_f32: wp[tile][k/2][lane] = W[2(k/2) + lane/32][32 tile + lane%32], zero padded
+      const int K = sizes[l], N = sizes[l + 1], KK = (K + 1) / 2, ntile = (N + 31) / 32;
+      std::vector<float> wp((size_t)ntile * KK * 64, 0.f);
+      for (int nt = 0; nt < ntile; nt++)
+        for (int kk = 0; kk < KK; kk++)
+          for (int ln = 0; ln < 64; ln++) {
+            const int k = 2 * kk + (ln >> 5), n = 32 * nt + (ln & 31);
+            if (k < K && n < N) wp[((size_t)nt * KK + kk) * 64 + ln] = weights[l][(size_t)k * N + n];
+          }
+      if (hipMalloc((void**)&b->d_mlp_wp[l], wp.size() * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+      HB_HIP(hipMemcpy(b->d_mlp_wp[l], wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (b->d_mlp_w[l]) { (void)hipFree(b->d_mlp_w[l]); b->d_mlp_w[l] = nullptr; }
     if (b->d_mlp_b[l]) { (void)hipFree(b->d_mlp_b[l]); b->d_mlp_b[l] = nullptr; }
     size_t nw = (size_t)sizes[l] * sizes[l + 1];
@@ -981,15 +999,27 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
     if (hipMalloc((void**)&b->d_mlp_h[i], (size_t)b->n_env * maxh * sizeof(float)) != hipSuccess) return HB_ENOMEM;
   }
   b->mlp_layers = n_layers;
+  b->mlp_fused = fused;
   for (int l = 0; l <= n_layers; l++) b->mlp_sizes[l] = sizes[l];
   return HB_OK;
 }
 
-// observation -> MLP -> b->d_ctrl, all on the batch's stream
 // obs -> MLP -> ctrl for envs [lo, hi) on `st`
 static int policy_forward(hb_batch* b, int lo, int hi, hipStream_t st) {
   if (b->mlp_layers < 1) return HB_EINVAL;
   const DevModel& dm = b->D.dm;
+  if (b->mlp_fused) {
+    PolicyDesc pd;
+    memset(&pd, 0, sizeof pd);
+    pd.nl = b->mlp_layers;
+    int widest = 1;
+    for (int l = 0; l <= b->mlp_layers; l++) { pd.sizes[l] = b->mlp_sizes[l]; widest = std::max(widest, b->mlp_sizes[l]); }
+    for (int l = 0; l < b->mlp_layers; l++) { pd.w[l] = b->d_mlp_wp[l]; pd.b[l] = b->d_mlp_b[l]; }
+    pd.ldx = widest + 1;
+    HB_HIP(launch_policy(dm, pd, b->d_state + (size_t)lo * dm.nstate, b->d_ctrl + (size_t)lo * dm.nu, hi - lo, st));
+    return HB_OK;
+  }
+  // wide layers: one launch per layer, activations through HBM
   HB_HIP(launch_obs(dm, b->d_state + (size_t)lo * dm.nstate, b->d_obs + (size_t)lo * b->mlp_sizes[0], hi - lo, st));
   const float* x = b->d_obs + (size_t)lo * b->mlp_sizes[0];
   for (int l = 0; l < b->mlp_layers; l++) {

@@ -111,6 +111,15 @@ struct EnvConfig {
   float reset_perturb;
 };
 
+// fused policy kernel (hb_policy_kernel): layer sizes, host-packed weights (MFMA B-operand order) and biases
+struct PolicyDesc {
+  int nl;
+  int sizes[5];
+  const float* w[4];
+  const float* b[4];
+  int ldx;  // LDS row stride of an activation tile: widest layer + 1 (odd or not, + 1 keeps the K pad column)
+};
+
 struct BatchPtrs {
   float* state;        // [n_env][nstate]
   const float* ctrl;   // [n_env][nu] or [T][n_env][nu]

@@ -1501,6 +1501,93 @@ __global__ __launch_bounds__(kGroup) void hb_mlp_layer_kernel(const float* X, co
   }
 }
 
+// The whole policy in one launch: observation -> every MLP layer -> controls, for 32 envs per block.
+// Activations never leave LDS (two ping-pong tiles of 32 rows); eight waves share the 32-column output tiles
+// of a layer, each sweeping K two columns per v_mfma_f32_32x32x2_f32 (exact f32) with the A operand from LDS
+// and the B operand from weights pre-packed on the host in operand order (one coalesced 256-byte wave load
+// per MFMA: wp[tile][k/2][lane] = W[2(k/2) + lane/32][32 tile + lane%32]).  A layer with fewer than eight
+// tiles (the nu-wide output layer) splits K across the idle waves instead; the partial tiles are summed in
+// a fixed order (deterministic, no atomics).
+__global__ __launch_bounds__(512) void hb_policy_kernel(const DevModel M, const PolicyDesc pd, const float* state, float* ctrl, int n_env) {
+  extern __shared__ float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 32, ldx = pd.ldx;
+  float* cur = sm;
+  float* nxt = sm + 32 * ldx;
+  float* part = sm + 64 * ldx;  // [8][32][32] partial tiles
+  if (tid < 32) {
+    float* o = cur + tid * ldx;
+    if (m0 + tid < n_env) {
+      float g[3], z;
+      compute_obs(M, state + (size_t)(m0 + tid) * M.nstate, o, g, &z);
+    } else {
+      for (int j = 0; j < M.nobs; j++) o[j] = 0.f;
+    }
+    o[M.nobs] = 0.f;  // K is swept in pairs: the pad column must be finite
+  }
+  __syncthreads();
+  const int col = lane & 31, half = lane >> 5;
+  for (int l = 0; l < pd.nl; l++) {
+    const int K = pd.sizes[l], N = pd.sizes[l + 1], KK = (K + 1) / 2, ntile = (N + 31) / 32;
+    const bool last = l + 1 == pd.nl;
+    int S = 1;  // K slices per tile
+    while (S * 2 * ntile <= 8) S *= 2;
+    const float* wp = pd.w[l];
+    const float* bias = pd.b[l];
+    if (!last && tid < 32) nxt[tid * ldx + N] = 0.f;
+    for (int it = wave; it < ntile * S; it += 8) {
+      const int nt = it / S, sl = it - nt * S;
+      const int kb = KK * sl / S, ke = KK * (sl + 1) / S;
+      f32x16 D;
+#pragma unroll
+      for (int r = 0; r < 16; r++) D[r] = 0.f;
+      const float* ap = cur + col * ldx + half;
+      const float* bp = wp + (size_t)nt * KK * 64 + lane;
+      int kk = kb;
+      for (; kk + 8 <= ke; kk += 8) {  // eight operand pairs in flight per batch of MFMAs
+        float a[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a[u] = ap[2 * (kk + u)]; w[u] = bp[(size_t)(kk + u) * 64]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], w[u], D, 0, 0, 0);
+      }
+      for (; kk < ke; kk++) D = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bp[(size_t)kk * 64], D, 0, 0, 0);
+      const int n = nt * 32 + col;
+      if (S == 1) {
+        const float bn = n < N ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (n < N) {
+            const float v = tanhf(D[r] + bn);
+            if (!last) nxt[row * ldx + n] = v;
+            else if (m0 + row < n_env) ctrl[(size_t)(m0 + row) * N + n] = v;
+          }
+        }
+      } else {
+        float* pp = part + it * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; r++) pp[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = D[r];
+      }
+    }
+    __syncthreads();
+    if (S > 1) {
+      for (int idx = tid; idx < ntile * 1024; idx += 512) {
+        const int nt = idx >> 10, rc = idx & 1023, row = rc >> 5, n = nt * 32 + (rc & 31);
+        if (n < N) {
+          float v = bias[n];
+          for (int sl = 0; sl < S; sl++) v += part[(nt * S + sl) * 1024 + rc];
+          v = tanhf(v);
+          if (!last) nxt[row * ldx + n] = v;
+          else if (m0 + row < n_env) ctrl[(size_t)(m0 + row) * N + n] = v;
+        }
+      }
+      __syncthreads();
+    }
+    float* t = cur; cur = nxt; nxt = t;
+  }
+}
+
 // Heavy-first dispatch order for the next launch: counting sort of the envs by the cost proxy of their
 // last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
 // the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
@@ -1576,6 +1663,17 @@ hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_
 }
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream) {
   hipLaunchKernelGGL(hb_mlp_layer_kernel, dim3((Mrows + 31) / 32, (N + 31) / 32), dim3(kGroup), (size_t)32 * (K + 1) * sizeof(float), stream, X, W, bias, Y, Mrows, K, N, act);
+  return hipGetLastError();
+}
+hipError_t launch_policy(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, int n_env, hipStream_t stream) {
+  const size_t shmem = ((size_t)64 * pd.ldx + 8 * 1024) * sizeof(float);
+  static bool raised = false;  // > 64 KiB of dynamic LDS needs the attribute once per process
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)hb_policy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(hb_policy_kernel, dim3((n_env + 31) / 32), dim3(512), shmem, stream, M, pd, state, ctrl, n_env);
   return hipGetLastError();
 }
 hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream) {

@@ -42,6 +42,25 @@ def test_policy_eval_matches_numpy(hbmod, humanoid_model, gpu):
     assert np.abs(ctrl).max() < 1.0 and np.abs(ctrl).std() > 0.01
 
 
+@pytest.mark.parametrize("hidden", [(33,), (64, 17, 130), (300, 64), (512,)])
+def test_policy_shapes(hbmod, humanoid_model, gpu, hidden):
+    """Odd widths (K swept in pairs: pad column), fewer than eight output tiles (K split over waves), up to
+    four layers — the one-launch kernel; a layer wider than 256 takes the layer-by-layer path.  Both against numpy."""
+    m = humanoid_model
+    n = 77
+    rng = np.random.default_rng(5)
+    sizes = [m.nobs, *hidden, m.nu]
+    ws = [rng.uniform(-0.3, 0.3, size=(a, c)).astype(np.float32) for a, c in zip(sizes[:-1], sizes[1:])]
+    bs = [rng.uniform(-0.3, 0.3, size=c).astype(np.float32) for c in sizes[1:]]
+    b = hbmod.Batch(m, n, gpu)
+    b.reset(perturb=True)
+    b.rollout_halton(50)
+    b.set_policy_mlp(ws, bs)
+    ctrl = b.policy_eval()
+    obs, _, _, _ = b.obs(want_reward=False)
+    assert np.abs(ctrl - mlp_ref(obs, ws, bs)).max() < 5e-5
+
+
 def test_closed_loop_rollout_matches_host_loop(hbmod, humanoid_model, gpu):
     m = humanoid_model
     n, T = 64, 25

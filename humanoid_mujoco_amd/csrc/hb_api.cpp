@@ -311,7 +311,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   int region = off;
   dm.o_xpos = take(3 * nb); dm.o_xquat = take(4 * nb); dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
   dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(10 * nb);
-  dm.o_cdofdot = take(6 * nv); dm.o_cvel = take(6 * nb); dm.o_cacc = take(6 * nb); dm.o_cfrc = take(6 * nb);
+  dm.o_cvel = take(6 * nb); dm.o_cacc = take(6 * nb); dm.o_cfrc = take(6 * nb);
   int endA = off;
   off = region;
   dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);

@@ -446,7 +446,6 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   float* s_xaxis = lds + M.o_xaxis;
   float* s_cinert = lds + M.o_cinert;
   float* s_crb = lds + M.o_crb;
-  float* s_cdofdot = lds + M.o_cdofdot;
   float* s_cvel = lds + M.o_cvel;
   float* s_cacc = lds + M.o_cacc;
   float* s_cfrc = lds + M.o_cfrc;
@@ -530,48 +529,72 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     const int mylevel = bl ? __float_as_int(q1.x) : -1, mycn = __float_as_int(q1.w);
     const int mych[8] = {__float_as_int(ch0.x), __float_as_int(ch0.y), __float_as_int(ch0.z), __float_as_int(ch0.w),
                          __float_as_int(ch1.x), __float_as_int(ch1.y), __float_as_int(ch1.z), __float_as_int(ch1.w)};
+    // The pose of a body relative to its parent (body frame, then its joints in order) does not depend on
+    // the parent's world pose, so all of it - the sin/cos of every joint included - is done here for every
+    // body at once; the level loop that follows only composes parent and local pose (mj_kinematics does the
+    // same products in world coordinates, body by body).
+    const bool isfree = bl && myjn == 1 && __float_as_int(JA[0].x) == 0;
+    V3 posl = {bp.x, bp.y, bp.z};
+    Q4 quatl = {bq.x, bq.y, bq.z, bq.w};
+    V3 axl[3], ancl[3];  // joint axes and anchors in the parent frame
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) { axl[jj] = {0.f, 0.f, 0.f}; ancl[jj] = {0.f, 0.f, 0.f}; }
+    if (isfree) {
+      const int qa = __float_as_int(JA[0].y);
+      posl = ld3(s_qpos + qa);
+      quatl = qnormalize(ldq(s_qpos + qa + 3));
+    } else if (bl) {
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) {
+        if (jj < myjn) {
+          const int qa = __float_as_int(JA[jj].y);
+          const V3 laxis = {JB[jj].x, JB[jj].y, JB[jj].z}, lpos = {JC[jj].x, JC[jj].y, JC[jj].z};
+          axl[jj] = qrot(quatl, laxis);
+          ancl[jj] = qrot(quatl, lpos) + posl;
+          const float dq = s_qpos[qa] - JA[jj].w;
+          if (__float_as_int(JA[jj].x) == 2) posl = posl + axl[jj] * dq;
+          else {
+            quatl = qmul(quatl, axisangle(laxis, dq));
+            posl = ancl[jj] - qrot(quatl, lpos);
+          }
+        }
+      }
+    }
+    V3 mypos = posl;
+    Q4 myquat = quatl;
     for (int L = 1; L < M.nlevel; L++) {
       if (mylevel == L) {
-        const int b = myb, p = myp, jn = myjn, ja = myja;
-        V3 pos;
-        Q4 quat;
-        if (jn == 1 && __float_as_int(JA[0].x) == 0) {
-          const int qa = __float_as_int(JA[0].y);
-          pos = ld3(s_qpos + qa);
-          quat = qnormalize(ldq(s_qpos + qa + 3));
-          st3(s_xanchor + 3 * ja, pos);
-          st3(s_xaxis + 3 * ja, {JB[0].x, JB[0].y, JB[0].z});
-        } else {
-          pos = mrot(s_xmat + 9 * p, {bp.x, bp.y, bp.z}) + ld3(s_xpos + 3 * p);
-          quat = qmul(ldq(s_xquat + 4 * p), {bq.x, bq.y, bq.z, bq.w});
-#pragma unroll
-          for (int jj = 0; jj < 3; jj++) {
-            if (jj < jn) {
-              const int j = ja + jj, qa = __float_as_int(JA[jj].y);
-              const V3 laxis = {JB[jj].x, JB[jj].y, JB[jj].z}, lpos = {JC[jj].x, JC[jj].y, JC[jj].z};
-              const V3 axis = qrot(quat, laxis);
-              const V3 anchor = qrot(quat, lpos) + pos;
-              st3(s_xaxis + 3 * j, axis);
-              st3(s_xanchor + 3 * j, anchor);
-              const float dq = s_qpos[qa] - JA[jj].w;
-              if (__float_as_int(JA[jj].x) == 2) pos = pos + axis * dq;
-              else {
-                quat = qmul(quat, axisangle(laxis, dq));
-                pos = anchor - qrot(quat, lpos);
-              }
-            }
-          }
-          quat = qnormalize(quat);
+        if (!isfree) {
+          const Q4 pq = ldq(s_xquat + 4 * myp);
+          mypos = ld3(s_xpos + 3 * myp) + qrot(pq, posl);
+          myquat = qnormalize(qmul(pq, quatl));
         }
-        st3(s_xpos + 3 * b, pos);
-        stq(s_xquat + 4 * b, quat);
-        float mat[9];
-        q2mat(mat, quat);
-        for (int i = 0; i < 9; i++) s_xmat[9 * b + i] = mat[i];
-        st3(s_xipos + 3 * b, pos + mrot(mat, {ip.x, ip.y, ip.z}));
+        st3(s_xpos + 3 * myb, mypos);
+        stq(s_xquat + 4 * myb, myquat);
       }
       gsync();
     }
+    if (bl) {  // everything that hangs off the world poses, all bodies at once
+      if (isfree) {
+        st3(s_xanchor + 3 * myja, mypos);
+        st3(s_xaxis + 3 * myja, {JB[0].x, JB[0].y, JB[0].z});
+      } else {
+        const Q4 pq = ldq(s_xquat + 4 * myp);
+        const V3 pp = ld3(s_xpos + 3 * myp);
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+          if (jj < myjn) {
+            st3(s_xaxis + 3 * (myja + jj), qrot(pq, axl[jj]));
+            st3(s_xanchor + 3 * (myja + jj), qrot(pq, ancl[jj]) + pp);
+          }
+        }
+      }
+      float mat[9];
+      q2mat(mat, myquat);
+      for (int i = 0; i < 9; i++) s_xmat[9 * myb + i] = mat[i];
+      st3(s_xipos + 3 * myb, mypos + mrot(mat, {ip.x, ip.y, ip.z}));
+    }
+    gsync();
     HB_STAMP(2);
     // geoms: world position and z axis
     for (int g = lane; g < M.ngeom; g += kGroup) {
@@ -639,25 +662,100 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     gsync();
     HB_STAMP(3);
-    // ---------------------------------------------------------------- mj_crb
-    for (int i = lane; i < 10 * nb; i += kGroup) s_crb[i] = s_cinert[i];
+    // ---------------------------------------------------------------- mj_comVel + mj_rne forward pass
+    // A body's velocity is its parent's plus a local term lv = sum_j cdof_j qvel_j, and its bias
+    // acceleration is the parent's plus sum_j (cvel before dof j) x cdof_j qvel_j.  The cross product is
+    // linear in both arguments, so that sum splits into  cvel_parent x lv  plus a purely local part la
+    // (the partial sums of this body's own dofs); lv and la are formed for all bodies at once and the
+    // level loop is reduced to two 6-vector updates per body.
+    float lv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, la[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bl) {
+      float cd[6], t[6];
+      if (isfree) {
+        const int da = __float_as_int(JA[0].z);
+        for (int k = 0; k < 3; k++) {
+          const float qv = s_qvel[da + k];
+          for (int i = 0; i < 6; i++) lv[i] += s_cdof[6 * (da + k) + i] * qv;
+        }
+        // the three rotational dofs all see the velocity after the translational ones (mj_comVel, free joint)
+        float rot[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 3; k++) {
+          const float qv = s_qvel[da + 3 + k];
+          for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * (da + 3 + k) + i];
+          cross_motion(t, lv, cd);
+          for (int i = 0; i < 6; i++) { la[i] += t[i] * qv; rot[i] += cd[i] * qv; }
+        }
+        for (int i = 0; i < 6; i++) lv[i] += rot[i];
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+          if (jj < myjn) {
+            const int da = __float_as_int(JA[jj].z);
+            const float qv = s_qvel[da];
+            for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * da + i];
+            cross_motion(t, lv, cd);
+            for (int i = 0; i < 6; i++) { la[i] += t[i] * qv; lv[i] += cd[i] * qv; }
+          }
+        }
+      }
+    }
+    if (lane < 6) {
+      s_cvel[lane] = 0.f;
+      s_cacc[lane] = (lane >= 3 && !(M.disableflags & (1 << 6))) ? -M.gravity[lane - 3] : 0.f;
+      s_cfrc[lane] = 0.f;
+    }
     gsync();
+    float mycvel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mycacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int L = 1; L < M.nlevel; L++) {
+      if (mylevel == L) {
+        float pv[6], t[6];
+        for (int i = 0; i < 6; i++) { pv[i] = s_cvel[6 * myp + i]; mycacc[i] = s_cacc[6 * myp + i]; }
+        cross_motion(t, pv, lv);
+        for (int i = 0; i < 6; i++) {
+          mycvel[i] = pv[i] + lv[i];
+          mycacc[i] += t[i] + la[i];
+          s_cvel[6 * myb + i] = mycvel[i];
+          s_cacc[6 * myb + i] = mycacc[i];
+        }
+      }
+      gsync();
+    }
+    // body-local force cinert cacc + cvel x* (cinert cvel), and the composite inertia seeds, all bodies at once
+    if (bl) {
+      float in[10], f0[6], f1[6], f2[6];
+      for (int i = 0; i < 10; i++) { in[i] = s_cinert[10 * myb + i]; s_crb[10 * myb + i] = in[i]; }
+      mul_inert_vec(f0, in, mycacc);
+      mul_inert_vec(f1, in, mycvel);
+      cross_force(f2, mycvel, f1);
+      for (int i = 0; i < 6; i++) s_cfrc[6 * myb + i] = f0[i] + f2[i];
+    }
+    if (lane < 10) s_crb[lane] = s_cinert[lane];
+    gsync();
+    // mj_crb and the mj_rne backward pass share one sweep up the tree: children into parents (pull form)
     for (int L = M.nlevel - 2; L >= 1; L--) {
       if (mylevel == L && mycn > 0) {
-        float acc[10];
+        float acc[16];
 #pragma unroll
         for (int c = 0; c < 10; c++) acc[c] = s_crb[10 * myb + c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[10 + c] = s_cfrc[6 * myb + c];
 #pragma unroll
         for (int k = 0; k < 8; k++)
           if (k < mycn) {
 #pragma unroll
             for (int c = 0; c < 10; c++) acc[c] += s_crb[10 * mych[k] + c];
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[10 + c] += s_cfrc[6 * mych[k] + c];
           }
 #pragma unroll
         for (int c = 0; c < 10; c++) s_crb[10 * myb + c] = acc[c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) s_cfrc[6 * myb + c] = acc[10 + c];
       }
       gsync();
     }
+    HB_STAMP(4);
+    // ---------------------------------------------------------------- qM from the composite inertias
     for (int e = lane; e < M.nM; e += kGroup) {
       const int pk = M.mrec[e];  // i | j << 8 | body(i) << 16
       const float2 ad = M.mdiag[e];  // (armature, damping) on diagonal entries, 0 elsewhere
@@ -674,80 +772,10 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       s_qLD[e] = {sacc, sacc + (eulerdamp ? M.timestep * ad.y : 0.f)};
     }
     gsync();
-    HB_STAMP(4);
+    HB_STAMP(5);
     // ---------------------------------------------------------------- mj_factorM
     factor_ld(M, s_qLD, s_dinv, s_dsqrtinv, lane);
 
-    HB_STAMP(5);
-    // ---------------------------------------------------------------- mj_comVel + mj_rne forward pass
-    if (lane < 6) {
-      s_cvel[lane] = 0.f;
-      s_cacc[lane] = (lane >= 3 && !(M.disableflags & (1 << 6))) ? -M.gravity[lane - 3] : 0.f;
-      s_cfrc[lane] = 0.f;
-    }
-    gsync();
-    for (int L = 1; L < M.nlevel; L++) {
-      if (mylevel == L) {
-        const int b = myb, p = myp, jn = myjn;
-        float cvel[6], cacc[6], t[6], cd[6];
-        for (int i = 0; i < 6; i++) { cvel[i] = s_cvel[6 * p + i]; cacc[i] = s_cacc[6 * p + i]; }
-        if (jn == 1 && __float_as_int(JA[0].x) == 0) {
-          const int da = __float_as_int(JA[0].z);
-          for (int k = 0; k < 3; k++) {
-            float qv = s_qvel[da + k];
-            for (int i = 0; i < 6; i++) { s_cdofdot[6 * (da + k) + i] = 0.f; cvel[i] += s_cdof[6 * (da + k) + i] * qv; }
-          }
-          float dots[3][6];
-          for (int k = 0; k < 3; k++) {
-            for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * (da + 3 + k) + i];
-            cross_motion(dots[k], cvel, cd);
-          }
-          for (int k = 0; k < 3; k++) {
-            float qv = s_qvel[da + 3 + k];
-            for (int i = 0; i < 6; i++) {
-              s_cdofdot[6 * (da + 3 + k) + i] = dots[k][i];
-              cacc[i] += dots[k][i] * qv;
-              cvel[i] += s_cdof[6 * (da + 3 + k) + i] * qv;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int jj = 0; jj < 3; jj++) {
-            if (jj < jn) {
-              const int da = __float_as_int(JA[jj].z);
-              float qv = s_qvel[da];
-              for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * da + i];
-              cross_motion(t, cvel, cd);
-              for (int i = 0; i < 6; i++) { s_cdofdot[6 * da + i] = t[i]; cacc[i] += t[i] * qv; cvel[i] += cd[i] * qv; }
-            }
-          }
-        }
-        float in[10], f0[6], f1[6], f2[6];
-        for (int i = 0; i < 10; i++) in[i] = s_cinert[10 * b + i];
-        mul_inert_vec(f0, in, cacc);
-        mul_inert_vec(f1, in, cvel);
-        cross_force(f2, cvel, f1);
-        for (int i = 0; i < 6; i++) { s_cvel[6 * b + i] = cvel[i]; s_cacc[6 * b + i] = cacc[i]; s_cfrc[6 * b + i] = f0[i] + f2[i]; }
-      }
-      gsync();
-    }
-    // rne backward pass: accumulate child forces into parents (pull form)
-    for (int L = M.nlevel - 2; L >= 1; L--) {
-      if (mylevel == L && mycn > 0) {
-        float acc[6];
-#pragma unroll
-        for (int c = 0; c < 6; c++) acc[c] = s_cfrc[6 * myb + c];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-          if (k < mycn) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) acc[c] += s_cfrc[6 * mych[k] + c];
-          }
-#pragma unroll
-        for (int c = 0; c < 6; c++) s_cfrc[6 * myb + c] = acc[c];
-      }
-      gsync();
-    }
     HB_STAMP(6);
     // ---------------------------------------------------------------- qfrc_bias, mj_passive, mj_fwdActuation -> qfrc_smooth
     for (int d = lane; d < nv; d += kGroup) {

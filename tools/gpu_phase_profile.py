@@ -20,7 +20,7 @@ assert L.hb_get_stamps(b._h, st.ctypes.data_as(ctypes.c_void_p)) == 0  # arm
 b.rollout_halton(1, t0=400)
 assert L.hb_get_stamps(b._h, st.ctypes.data_as(ctypes.c_void_p)) == 0
 d = np.diff(st.astype(np.int64), axis=1).astype(np.float64)
-names = ["ctrl+check", "kinematics", "geoms/com/cinert/cdof", "crb+qM", "factorM", "comVel+rne", "bias/passive/act", "collision", "makeConstraint",
+names = ["ctrl+check", "kinematics", "geoms/com/cinert/cdof", "comVel+crb+rne tree passes", "qM", "factorM", "bias/passive/act", "collision", "makeConstraint",
          "row quantities", "half-solve", "b + AR", "PGS", "dual finish", "Euler+advance"]
 tot = d.sum(1)
 print("envs %d; mean cycles per env-step (one wave) %.0f, median %.0f" % (N, tot.mean(), np.median(tot)))

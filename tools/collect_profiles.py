@@ -17,10 +17,25 @@ os.makedirs(dst, exist_ok=True)
 
 stats = glob.glob(os.path.join(src, "prof_trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, rnd + "_kernel_stats.csv"))
+# The bench command runs the step kernel in two shapes: 2048-block launches (pipelined `value` leg, two per step,
+# overlapping) and 4096-block launches (the unpipelined roofline leg + its warm-up).  The per-dispatch trace
+# separates them by grid size; the 4096-block average is the one bench.py's roofline.avg_launch_us must agree with.
 avg_ns = None
-for row in csv.DictReader(open(stats)):
-    if "hb_step_kernel" in row["Name"]:
-        avg_ns = float(row["AverageNs"]); calls = int(row["Calls"])
+calls = 0
+by_grid = collections.defaultdict(list)
+trace = glob.glob(os.path.join(src, "prof_trace", "*", "*_kernel_trace.csv"))
+if trace:
+    for row in csv.DictReader(open(trace[0])):
+        if "hb_step_kernel" in row["Kernel_Name"]:
+            by_grid[int(row.get("Grid_Size") or row["Grid_Size_X"])].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    shutil.copy(trace[0], os.path.join(src, "kernel_trace_full.csv"))
+full = 4096 * 64
+if by_grid.get(full):
+    avg_ns = sum(by_grid[full]) / len(by_grid[full]); calls = len(by_grid[full])
+else:
+    for row in csv.DictReader(open(stats)):
+        if "hb_step_kernel" in row["Name"]:
+            avg_ns = float(row["AverageNs"]); calls = int(row["Calls"])
 counters = {}
 meta = {}
 for d in ("prof_fetch", "prof_write", "prof_sq", "prof_lds", "prof_mfma"):
@@ -29,14 +44,16 @@ for d in ("prof_fetch", "prof_write", "prof_sq", "prof_lds", "prof_mfma"):
         continue
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(fs[0])):
-        if "hb_step_kernel" in row["Kernel_Name"]:
+        if "hb_step_kernel" in row["Kernel_Name"] and int(row["Grid_Size"]) == 4096 * 64:
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
             meta = {k: row[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
     for k, v in agg.items():
         counters[k] = {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "dispatches": len(v)}
 n_env = 4096
 out = {"kernel": "hb_step_kernel", "launch": "4096 envs (one wave each), 1 step per launch, bench.py workload",
-       "avg_launch_ns_kernel_trace": avg_ns, "kernel_trace_calls": calls, "dispatch_meta": meta, "counters_per_launch": counters}
+       "avg_launch_ns_kernel_trace": avg_ns, "kernel_trace_calls": calls,
+       "kernel_trace_by_grid": {str(g): {"calls": len(v), "avg_ns": sum(v) / len(v)} for g, v in by_grid.items()},
+       "dispatch_meta": meta, "counters_per_launch": counters}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     fetch, write = counters["FETCH_SIZE"]["mean"] * 1024, counters["WRITE_SIZE"]["mean"] * 1024
     hbm = 2 * fetch + write
@@ -53,7 +70,7 @@ if "SQ_INSTS_VALU" in counters:
         out["valu_lane_ops_per_s"] = counters["SQ_INSTS_VALU"]["mean"] * 64 / (avg_ns * 1e-9)
         out["valu_issue_frac_of_peak"] = out["valu_lane_ops_per_s"] / 78.6e12
 json.dump(out, open(os.path.join(dst, rnd + "_counters.json"), "w"), indent=1)
-for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt")):
+for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("pipeline_sweep.txt", rnd + "_pipeline_sweep.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt")):
     p = os.path.join(src, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))

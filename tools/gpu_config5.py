@@ -18,5 +18,14 @@ b.sync(); dt = time.perf_counter() - t0
 nc, ne, ni = b.counts()
 print("config 5 (step API): %d envs x %d steps: %.1f us/step -> %.3e env-steps/s; mean ncon %.1f nefc %.1f sweeps %.1f; warnings %d"
       % (N, T, 1e6 * dt / T, N * T / dt, nc.mean(), ne.mean(), ni.mean(), (b.status() != 0).sum()))
+b.pipeline(True)
+for t in range(20):
+    b.step_dev(ctrl + t * N * m.nu * 4)
+b.sync(); t0 = time.perf_counter()
+for t in range(T):
+    b.step_dev(ctrl + t * N * m.nu * 4)
+b.sync(); dt = time.perf_counter() - t0
+print("config 5 (step API, pipelined 2 segments): %.1f us/step -> %.3e env-steps/s" % (1e6 * dt / T, N * T / dt))
+b.pipeline(False)
 b.sync(); t0 = time.perf_counter(); b.rollout_dev(ctrl, T); b.sync(); dt = time.perf_counter() - t0
 print("config 5 (rollout) : %.1f us/step -> %.3e env-steps/s" % (1e6 * dt / T, N * T / dt))

@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
   float* ctrl = (float*)hb_dev_alloc(b, (uint64_t)nstep * n_env * sz.nu * sizeof(float));
   if (!ctrl) { fprintf(stderr, "out of device memory\n"); return 1; }
   hb_halton_ctrl_dev(b, nstep, 0, 0, ctrl);
+  hb_batch_pipeline(b, 1);  // two env segments on two streams: one step's tail overlaps the next
   hb_step_dev(b, ctrl, 1);  // warm-up launch
   hb_reset(b, nullptr, -1, 1, 0);
   hb_batch_sync(b);

@@ -135,38 +135,102 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     nanc[i] = adr - m.dof_Madr[i] - 1;
   }
   if (m.nM > 1023) { err = "sparse mass matrix too large for the packed index tables"; return false; }
+  // ---- LDS layout
+  int off = 0;
+  auto take = [&](int n) { int o = off; off += (n + 3) & ~3; return o; };
+  dm.cstride = 33;
+  dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
+  dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(6 * nv);
+  dm.o_qLD = take(2 * m.nM + 6); dm.o_dinv = take(2 * nv); dm.o_dsqrtinv = take(nv); dm.o_smooth = take(nv);  // qLD, dinv: {M, H} pairs; + the three pad pairs of the factor schedule
+  dm.o_vec0 = take(nv); dm.o_vec1 = take(nv); dm.o_vec2 = take(nv); dm.o_tenlen = take(std::max(1, m.ntendon));
+  int region = off;
+  dm.o_xpos = take(3 * nb); dm.o_xquat = take(4 * nb); dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
+  dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(10 * nb);
+  dm.o_cvel = take(6 * nb); dm.o_cacc = take(6 * nb); dm.o_cfrc = take(6 * nb);
+  int endA = off;
+  off = region;
+  dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);
+  // per-row meta (13 slots x kNefcMax) is dead once the row quantities are in registers; W = L^-1 D^-1/2
+  // ([32][33]) is built over it before the J W product and lives until the dual finish
+  dm.o_efc = take(std::max(13 * kNefcMax, 32 * 33));
+  dm.o_force = take(kGroup);
+  int endB = off;
+  // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
+  dm.lds_floats = std::max(endA, endB);
+  if (dm.lds_floats * 4 > 160 * 1024) { err = "model needs more LDS than one CU has"; return false; }
+
   // L^T D L schedule by levels of the elimination tree (a dof is ready once all its descendant dofs are done)
   std::vector<int> height(nv, 0);
   for (int k = nv - 1; k >= 0; k--) { int p = m.dof_parentid[k]; if (p >= 0) height[p] = std::max(height[p], height[k] + 1); }
   int maxh = 0;
   for (int k = 0; k < nv; k++) maxh = std::max(maxh, height[k]);
-  std::vector<int> flev_adr, flev_ent;
-  for (int L = 0; L <= maxh; L++) {
-    std::map<int, std::vector<int>> by_dst;  // dst -> contributions of this level's pivots
-    for (int k = 0; k < nv; k++) {
-      if (height[k] != L) continue;
-      int Mki = m.dof_Madr[k] + 1, i = m.dof_parentid[k];
-      while (i >= 0) {
-        int cnt = nanc[i] + 1;
-        for (int t = 0; t < cnt; t++) by_dst[m.dof_Madr[i] + t].push_back((Mki + t) | (Mki << 10) | (m.dof_Madr[k] << 20));
-        i = m.dof_parentid[i];
-        Mki++;
+  // The top of the elimination tree is a chain (for a floating-base robot: the free joint's six dofs and
+  // whatever single-file joints follow): once the limbs are eliminated, every remaining level has exactly one
+  // pivot and a handful of entries.  That tail is factorised densely in registers instead (factor_ld):
+  // ftop_n chain dofs d_0 (root) .. d_{n-1}, entry (d_a, d_b) at dof_Madr[d_a] + (a - b).
+  int ntop = 0;
+  {
+    std::vector<int> cnt(maxh + 1, 0), who(maxh + 1, -1);
+    for (int k = 0; k < nv; k++) { cnt[height[k]]++; who[height[k]] = k; }
+    while (ntop <= maxh && ntop < kFactorTop && cnt[maxh - ntop] == 1) {
+      const int d = who[maxh - ntop];
+      if (ntop == 0 ? m.dof_parentid[d] != -1 : m.dof_parentid[d] != who[maxh - ntop + 1]) break;
+      ntop++;
+    }
+    if (ntop < 2) ntop = 0;
+    dm.ftop_n = ntop;
+    for (int a = 0; a < kFactorTop; a++) dm.ftop_adr[a] = a < ntop ? m.dof_Madr[who[maxh - a]] : 0;
+  }
+  // Level schedule of the rest, as ROUNDS of up to 64 destination entries (one per lane).  A round's table
+  // block is field-major (dst[64], then lo[64], hi[64] per contribution) so that every lane reads one
+  // coalesced dword per field; all addresses are absolute LDS byte addresses of {M, H} pairs, two per word.
+  // Lanes without an entry and contributions beyond an entry's own are pointed at three pad pairs behind the
+  // matrix (zero, one, dump: 0 * (0 / 1) subtracted from the dump slot), so the kernel's round body has
+  // no per-lane guards at all.  Rounds of one level touch disjoint entries; the wave syncs after the last.
+  std::vector<int> fround, ftab;
+  {
+    auto lds_addr = [&](int idx) { return (dm.o_qLD + 2 * idx) * 4; };
+    const int pad_zero = lds_addr(m.nM), pad_one = lds_addr(m.nM + 1), pad_dump = lds_addr(m.nM + 2);
+    if (pad_dump + 8 > 65535) { err = "LDS layout too large for 16-bit factor addresses"; return false; }
+    for (int L = 0; L <= maxh - ntop; L++) {
+      std::map<int, std::vector<std::pair<int, int>>> by_dst;  // dst -> contributions (lo, hi) of this level's pivots
+      for (int k = 0; k < nv; k++) {
+        if (height[k] != L) continue;
+        int Mki = m.dof_Madr[k] + 1, i = m.dof_parentid[k];
+        while (i >= 0) {
+          int cnt = nanc[i] + 1;
+          // entry (i, t-th ancestor of i) -= M'[k, that ancestor] * M'[k, i] / D[k]
+          for (int t = 0; t < cnt; t++)
+            by_dst[m.dof_Madr[i] + t].push_back({lds_addr(Mki + t) | (lds_addr(Mki) << 16), lds_addr(m.dof_Madr[k])});
+          i = m.dof_parentid[i];
+          Mki++;
+        }
+      }
+      if (by_dst.empty()) continue;
+      std::vector<std::pair<int, std::vector<std::pair<int, int>>>> ent(by_dst.begin(), by_dst.end());
+      std::stable_sort(ent.begin(), ent.end(), [](const auto& x, const auto& y) { return x.second.size() > y.second.size(); });
+      for (size_t e0 = 0; e0 < ent.size(); e0 += 64) {
+        const size_t e1 = std::min(ent.size(), e0 + 64);
+        int nq = 0;
+        for (size_t e = e0; e < e1; e++) nq = std::max(nq, (int)ent[e].second.size());
+        if (nq > 7) { err = "more than seven sibling subtrees under one dof are not supported by the factorisation schedule"; return false; }
+        const int off = (int)ftab.size() / 64;
+        if (off > 65535) { err = "factorisation schedule too large"; return false; }
+        for (int ln = 0; ln < 64; ln++) ftab.push_back(e0 + ln < e1 ? lds_addr(ent[e0 + ln].first) : pad_dump);
+        for (int q = 0; q < nq; q++) {
+          for (int ln = 0; ln < 64; ln++) { bool h = e0 + ln < e1 && q < (int)ent[e0 + ln].second.size(); ftab.push_back(h ? ent[e0 + ln].second[q].first : (pad_zero | (pad_zero << 16))); }
+          for (int ln = 0; ln < 64; ln++) { bool h = e0 + ln < e1 && q < (int)ent[e0 + ln].second.size(); ftab.push_back(h ? ent[e0 + ln].second[q].second : pad_one); }
+        }
+        fround.push_back(off | (nq << 16) | ((e1 == ent.size() ? 1 : 0) << 20));
       }
     }
-    if (by_dst.empty()) continue;
-    flev_adr.push_back((int)flev_ent.size() / 8);
-    for (auto& kv : by_dst) {
-      // more than four pivots of one level reaching the same entry: split into several records of the same dst
-      // is not allowed (two lanes would write it), so chain them through extra levels instead
-      if (kv.second.size() > 4) { err = "more than four sibling subtrees under one dof are not supported by the factorisation schedule"; return false; }
-      flev_ent.push_back(kv.first);
-      for (int q = 0; q < 4; q++) flev_ent.push_back(q < (int)kv.second.size() ? kv.second[q] : -1);
-      for (int q = 0; q < 3; q++) flev_ent.push_back(-1);  // pad to two int4
-    }
+    for (int i = 0; i < 3 * 64; i++) ftab.push_back(0);  // the kernel prefetches one round ahead
+    fround.push_back(0);
+    dm.nfround = (int)fround.size() - 1;
+    if (dm.nfround > 63) { err = "factorisation schedule has more than 63 rounds"; return false; }
+    fround.resize(64, 0);  // one descriptor per lane
+    dm.fpad_zero = pad_zero; dm.fpad_one = pad_one; dm.fpad_dump = pad_dump;
   }
-  flev_adr.push_back((int)flev_ent.size() / 8);
-  dm.nflev = (int)flev_adr.size() - 1;
-  dm.nfac = (int)flev_ent.size() / 8;
   std::vector<int> desc_adr(nv + 1, 0), desc_pack;
   for (int i = 0; i < nv; i++) {
     desc_adr[i] = (int)desc_pack.size();
@@ -279,9 +343,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
 #define TF(field, vec) fo.push_back({&dm.field, T.addf(vec)})
   TI(body_treeid, treeid); TF(body_invweight0, m.body_invweight0); TF(tree_invmass, tree_invmass);
   TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TF(qpos0, m.qpos0); TI(dof_jntid, m.dof_jntid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TF(dof_damping, m.dof_damping); TI(M_j, Mj); TI(mrec, mrec);
-  TI(flev_adr, flev_adr);
-  while (T.iv.size() % 4) T.iv.push_back(0);  // int4 alignment
-  size_t o_flev = T.addi(flev_ent);
+  TI(fround, fround); TI(ftab, ftab);
   TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(chain, chain);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
@@ -300,30 +362,6 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   size_t o_mask = T.addu(dofmask);
   size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag);
 
-  // ---- LDS layout
-  int off = 0;
-  auto take = [&](int n) { int o = off; off += (n + 3) & ~3; return o; };
-  dm.cstride = 33;
-  dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
-  dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(6 * nv);
-  dm.o_qLD = take(2 * m.nM); dm.o_dinv = take(2 * nv); dm.o_dsqrtinv = take(nv); dm.o_smooth = take(nv);  // qLD, dinv: {M, H} pairs
-  dm.o_vec0 = take(nv); dm.o_vec1 = take(nv); dm.o_vec2 = take(nv); dm.o_tenlen = take(std::max(1, m.ntendon));
-  int region = off;
-  dm.o_xpos = take(3 * nb); dm.o_xquat = take(4 * nb); dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
-  dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(10 * nb);
-  dm.o_cvel = take(6 * nb); dm.o_cacc = take(6 * nb); dm.o_cfrc = take(6 * nb);
-  int endA = off;
-  off = region;
-  dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);
-  // per-row meta (13 slots x kNefcMax) is dead once the row quantities are in registers; W = L^-1 D^-1/2
-  // ([32][33]) is built over it before the J W product and lives until the dual finish
-  dm.o_efc = take(std::max(13 * kNefcMax, 32 * 33));
-  dm.o_force = take(kGroup);
-  int endB = off;
-  // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
-  dm.lds_floats = std::max(endA, endB);
-  if (dm.lds_floats * 4 > 160 * 1024) { err = "model needs more LDS than one CU has"; return false; }
-
   // ---- upload
   if (hipMalloc((void**)&D.d_int, T.iv.size() * sizeof(int)) != hipSuccess || hipMalloc((void**)&D.d_flt, T.fv.size() * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&D.d_u64, T.uv.size() * sizeof(unsigned long long)) != hipSuccess) { err = "hipMalloc failed for model tables"; return false; }
@@ -333,7 +371,6 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   for (auto& x : io) *x.p = D.d_int + x.o;
   for (auto& x : fo) *x.p = D.d_flt + x.o;
   dm.body_dofmask = D.d_u64 + o_mask;
-  dm.flev_ent = reinterpret_cast<const int4*>(D.d_int + o_flev);
   dm.brec = reinterpret_cast<const float4*>(D.d_flt + o_brec);
   dm.drec = reinterpret_cast<const float4*>(D.d_flt + o_drec);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);

@@ -27,6 +27,7 @@ constexpr int kConStride = 20;  // floats per contact record in LDS
 constexpr int kDiagConStride = 16;
 constexpr int kCountStride = 8;  // ints per env in BatchPtrs::counts: ncon, nefc, niter, cost, self-collision flag, spare
 constexpr int kMaxAnc = 16;     // deepest dof chain the batched half-solve handles (strict ancestors per dof)
+constexpr int kFactorTop = 9;  // chain dofs at the top of the elimination tree factorised densely in registers
 constexpr int kBrecQuads = 18;  // float4s per level-ordered body record (see build_device_model)
 
 // contact record layout in LDS (floats)
@@ -34,7 +35,7 @@ enum { C_DIST = 0, C_POS = 1, C_FRAME = 4, C_PAIR = 13, C_ROW = 14, C_DIM = 15, 
 
 struct DevModel {
   // sizes
-  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, npair, nlevel, ntree, nfac, nlimcand;
+  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, npair, nlevel, ntree, nlimcand;
   int nstate;   // floats per env in the global state record: time, qpos, qvel, qacc_warmstart
   int nobs;
   // options
@@ -58,11 +59,14 @@ struct DevModel {
   const int HB_CONST* mrec;      // per entry: i | j << 8 | body(i) << 16
   const float2 HB_CONST* mdiag;  // per entry: (armature, damping) on the diagonal, 0 elsewhere
   const int HB_CONST* M_j;       // column dof of each entry (= the ancestors of the row dof, in chain order)
-  // L^T D L schedule by elimination-tree level: flev_adr[nflev+1] into flev_ent, two int4 per destination entry:
-  // {dst, c0, c1, c2} {c3, -, -, -} with contributions c = src | tmp << 10 | Mkk << 20 (-1 = none)
-  const int HB_CONST* flev_adr;
-  const int4 HB_CONST* flev_ent;
-  int nflev;
+  // L^T D L schedule by elimination-tree level, in rounds of <= 64 destination entries:
+  // fround[r] = table offset / 64 | contributions << 16 | sync-after << 20; ftab block of a round is
+  // dst[64], then (lo[64], hi[64]) per contribution: lo = src | tmp << 16, hi = Mkk, absolute LDS byte
+  // addresses of {M, H} pairs; fpad_*: the zero / one / dump pad pairs behind the matrix
+  const int HB_CONST* fround;
+  const int HB_CONST* ftab;
+  int nfround, fpad_zero, fpad_one, fpad_dump;
+  int ftop_n, ftop_adr[kFactorTop];  // dense tail of the factorisation: chain dofs root-first, address of each one's row
   const int HB_CONST *desc_adr, *desc_pack;  // descendants of each dof: k | address of L[k,i] << 8
   const int HB_CONST* chain;     // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)
   // geoms

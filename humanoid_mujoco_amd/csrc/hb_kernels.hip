@@ -23,7 +23,11 @@ namespace hb {
 // Diagnostic build only (-DHB_STAMPS): per-phase cycle stamps of the last step, written to
 // BatchPtrs::diag_contact's tail is NOT used; stamps go to their own buffer P.stamps.
 #ifdef HB_STAMPS
+#ifdef HB_PROBE_FACTOR  /* experiment: slots 6 and 7 are written inside factor_ld (after the rounds, after the dense tail) */
+#define HB_STAMP(i) do { if ((i) != 6 && (i) != 7 && lane == 0 && P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps_[i] = t_; } } while (0)
+#else
 #define HB_STAMP(i) do { if (lane == 0 && P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps_[i] = t_; } } while (0)
+#endif
 #else
 #define HB_STAMP(i) do {} while (0)
 #endif
@@ -311,61 +315,131 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   return d0 + y * (d1 - d0);
 }
 
-__device__ __forceinline__ f32x2 floor2(f32x2 v, float lo) {  // max(v, lo) per component, one v_med3_f32 each
-  return {__builtin_amdgcn_fmed3f(v.x, lo, __builtin_inff()), __builtin_amdgcn_fmed3f(v.y, lo, __builtin_inff())};
+// max(v, lo) per component as one bare v_max_f32 each (values come straight from LDS: the builtin forms add a
+// canonicalising v_max per input; a NaN here is caught by mj_checkAcc either way)
+__device__ __forceinline__ f32x2 floor2(f32x2 v, float lo) {
+  f32x2 r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.x) : "v"(v.x), "v"(lo));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r.y) : "v"(v.y), "v"(lo));
+  return r;
 }
 
-__device__ __forceinline__ void factor_ld(DevModelRef M, f32x2* LD, f32x2* dinv, float* dsqrtinv, int lane) {
+// dense L^T D L of the chain at the top of the elimination tree, in registers (see factor_ld).  GUARD: the chain
+// is shorter than kFactorTop and rows >= nt are skipped.
+template <bool GUARD>
+__device__ __forceinline__ void factor_top(DevModelRef M, f32x2* LD, int nt, int lane) {
+  f32x2 A[kFactorTop * (kFactorTop + 1) / 2];  // (a, b), a >= b, at a(a+1)/2 + b; a = 0 is the root dof
+#pragma unroll
+  for (int a = 0; a < kFactorTop; a++) {
+    const int adr = M.ftop_adr[a];
+#pragma unroll
+    for (int b = 0; b <= a; b++) A[a * (a + 1) / 2 + b] = (!GUARD || a < nt) ? LD[adr + (a - b)] : (f32x2){0.f, 0.f};
+  }
+#pragma unroll
+  for (int k = kFactorTop - 1; k >= 1; k--) {
+    if (!GUARD || k < nt) {
+      const f32x2 d = floor2(A[k * (k + 1) / 2 + k], HB_MINVAL);
+      const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+#pragma unroll
+      for (int i = 0; i < k; i++) {
+        const f32x2 tmp = A[k * (k + 1) / 2 + i] * r;
+#pragma unroll
+        for (int j = 0; j <= i; j++) A[i * (i + 1) / 2 + j] -= A[k * (k + 1) / 2 + j] * tmp;
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < kFactorTop - 1; a++) {  // the deepest row is only ever a pivot row: unchanged
+      const int adr = M.ftop_adr[a];
+#pragma unroll
+      for (int b = 0; b <= a; b++)
+        if (!GUARD || a < nt - 1) LD[adr + (a - b)] = A[a * (a + 1) / 2 + b];
+    }
+  }
+  gsync();
+}
+
+// table words factor_ld starts from, fetched by the caller a phase early (two dependent vector loads and the
+// diagonal address would otherwise sit, exposed, at the head of the factorisation)
+struct FactorHead { int descs, dst, lo, hi, madr; };
+__device__ __forceinline__ FactorHead factor_head(DevModelRef M, int lane) {
+  FactorHead h;
+  h.descs = M.fround[lane];  // lane r holds round r (the host caps the schedule at 63 rounds plus a terminating zero word)
+  const int d0 = __builtin_amdgcn_readlane(h.descs, 0);
+  const int HB_CONST* T = M.ftab + lane + (d0 & 0xffff) * 64;
+  h.dst = T[0]; h.lo = T[64]; h.hi = T[128];
+  h.madr = lane < M.nv ? M.dof_Madr[lane] : 0;
+  return h;
+}
+
+__device__ __forceinline__ void factor_ld(DevModelRef M, float* lds, f32x2* LD, f32x2* dinv, float* dsqrtinv, int lane, const FactorHead& head, unsigned long long* probe = nullptr) {
   // LD[e] = {entry of M, entry of H}: the two matrices share every index and ride the packed fp32
   // instructions (v_pk_mul/v_pk_fma_f32, ds_read_b64) as one.
   //
   // Elimination by levels of the dof tree: pivots whose descendants are all done (both legs, both arms, ...)
-  // are eliminated together.  The work item is a destination entry of an ancestor row; it gathers the (up to
-  // four) contributions  M'[k,j] M'[k,i] / D[k]  of the pivots k of this level that reach it, so no two lanes
+  // are eliminated together.  The work item is a destination entry of an ancestor row; it gathers the
+  // contributions  M'[k,j] M'[k,i] / D[k]  of the pivots k of this level that reach it, so no two lanes
   // write the same entry (deterministic, no atomics).  Pivot rows are read unscaled and are final when read;
   // the division of L by D is one pass at the end.
-  const int nlev = M.nflev;
-  // records are two int4: {dst, c0, c1, c2}, {c3, -, -, -}; the first record of the next level is fetched
-  // while the current level is processed
-  int e0 = M.flev_adr[0], e1 = M.flev_adr[1];
-  int4 ra = {-1, -1, -1, -1}, rb = ra;
-  if (e0 + lane < e1) { ra = M.flev_ent[2 * (size_t)(e0 + lane)]; rb = M.flev_ent[2 * (size_t)(e0 + lane) + 1]; }
-  for (int L = 0; L < nlev; L++) {
-    const int c0 = e0, c1 = e1;
-    int4 qa = ra, qb = rb;
-    if (L + 1 < nlev) {
-      e0 = c1; e1 = M.flev_adr[L + 2];
-      ra = {-1, -1, -1, -1}; rb = ra;
-      if (e0 + lane < e1) { ra = M.flev_ent[2 * (size_t)(e0 + lane)]; rb = M.flev_ent[2 * (size_t)(e0 + lane) + 1]; }
+  //
+  // The schedule comes as rounds of 64 entries with every address precomputed (absolute LDS byte addresses,
+  // field-major table: one coalesced dword per lane and field) and padded with no-op work, so the round body
+  // is straight-line: 2 unpack ops, 3 ds_read_b64, 2 v_med3, 2 v_rcp, 2 v_pk_mul per contribution (nearly
+  // always one), one read-modify-write of the destination.  The next round's words are fetched a round ahead.
+  auto pair_at = [&](int byte_addr) -> f32x2* { return reinterpret_cast<f32x2*>(reinterpret_cast<char*>(lds) + byte_addr); };
+  auto contribution = [&](int lo, int hi) -> f32x2 {
+    const f32x2 d = floor2(*pair_at(hi), HB_MINVAL);
+    const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return *pair_at(lo & 0xffff) * (*pair_at((unsigned)lo >> 16) * r);
+  };
+  const int nr = M.nfround;
+  const int HB_CONST* T = M.ftab + lane;
+  // all round descriptors sit in one register (lane r holds round r): a round costs a v_readlane, not a
+  // scalar-memory round trip
+  const int descs = head.descs;
+  int desc = __builtin_amdgcn_readlane(descs, 0);
+  int dst = head.dst, lo = head.lo, hi = head.hi;
+  for (int r = 0; r < nr; r++) {
+    const int cur = desc, cdst = dst, clo = lo, chi = hi;
+    desc = __builtin_amdgcn_readlane(descs, r + 1);  // a zero word ends the list; the table is padded for the fetch it causes
+    {
+      const int HB_CONST* N = T + (desc & 0xffff) * 64;
+      dst = N[0]; lo = N[64]; hi = N[128];
     }
-    for (int e = c0 + lane; e < c1; e += kGroup) {
-      if (e != c0 + lane) { qa = M.flev_ent[2 * (size_t)e]; qb = M.flev_ent[2 * (size_t)e + 1]; }
-      const int dst = qa.x;
-      const int c[4] = {qa.y, qa.z, qa.w, qb.x};
-      f32x2 acc = {0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (c[q] >= 0) {
-          const int src = c[q] & 1023, ti = (c[q] >> 10) & 1023, kk = c[q] >> 20;
-          const f32x2 d = floor2(LD[kk], HB_MINVAL);
-          const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-          acc += LD[src] * (LD[ti] * r);
-        }
-      }
-      LD[dst] -= acc;
-    }
-    gsync();
+    f32x2 acc = contribution(clo, chi);
+    const int nq = (cur >> 16) & 7;
+    const int HB_CONST* C = T + (cur & 0xffff) * 64;
+    for (int q = 1; q < nq; q++) acc += contribution(C[(1 + 2 * q) * 64], C[(2 + 2 * q) * 64]);
+    *pair_at(cdst) -= acc;
+    if ((cur >> 20) & 1) gsync();
   }
-  for (int i = lane; i < M.nv; i += kGroup) {
-    const f32x2 d = floor2(LD[M.dof_Madr[i]], HB_MINVAL);
-    dinv[i] = {1.f / d.x, 1.f / d.y};
-    dsqrtinv[i] = rsqrtf(d.x);
+  if (probe && lane == 0) probe[6] = __builtin_amdgcn_s_memtime();
+  // The chain at the top of the tree (the floating base and what follows it in single file): one pivot and a
+  // few entries per level, so instead of a wave-wide level each it is eliminated densely in registers - every
+  // lane runs the same unrolled elimination on broadcast reads, lane 0 writes the result back.  A full-length
+  // chain (the floating-base case) takes the branch-free instantiation.
+  const int nt = M.ftop_n;
+  if (nt == kFactorTop) factor_top<false>(M, LD, nt, lane);
+  else if (nt > 1) factor_top<true>(M, LD, nt, lane);
+  if (probe && lane == 0) probe[7] = __builtin_amdgcn_s_memtime();
+  if (lane < M.nv) {  // nv <= 32: one dof per lane
+    const f32x2 d = floor2(LD[head.madr], HB_MINVAL);
+    dinv[lane] = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    dsqrtinv[lane] = rsqrtf(d.x);
   }
   gsync();
-  for (int e = lane; e < M.nM; e += kGroup) {  // L[k,i] = M'[k,i] / D[k]
-    const int pk = M.mrec[e];
-    const int i = pk & 255, j = (pk >> 8) & 255;
-    if (i != j) LD[e] *= dinv[i];
+  // L[k,i] = M'[k,i] / D[k], four table words in flight per lane
+  for (int e0 = 0; e0 < M.nM; e0 += 4 * kGroup) {
+    int pk[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int e = e0 + u * kGroup + lane; pk[u] = e < M.nM ? M.mrec[e] : 0; }  // 0: i == j, skipped
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * kGroup + lane;
+      const int i = pk[u] & 255, j = (pk[u] >> 8) & 255;
+      if (i != j) LD[e] *= dinv[i];
+    }
   }
   gsync();
 }
@@ -473,6 +547,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
 #ifdef HB_STAMPS
   unsigned long long stamps_[16] = {0};
 #endif
+  // pad pairs of the factorisation schedule (zero, one, dump), behind the matrix; never written again except
+  // the dump slot, which only ever has zero subtracted from it
+  if (lane < 6) s_qLD[M.nM + (lane >> 1)][lane & 1] = (lane >> 1) == 1 ? 1.f : 0.f;
   gsync();
 
   for (int step = 0; step < nsteps; step++) {
@@ -756,6 +833,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     HB_STAMP(4);
     // ---------------------------------------------------------------- qM from the composite inertias
+    const FactorHead fhead = factor_head(M, lane);
     for (int e = lane; e < M.nM; e += kGroup) {
       const int pk = M.mrec[e];  // i | j << 8 | body(i) << 16
       const float2 ad = M.mdiag[e];  // (armature, damping) on diagonal entries, 0 elsewhere
@@ -774,7 +852,11 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     gsync();
     HB_STAMP(5);
     // ---------------------------------------------------------------- mj_factorM
-    factor_ld(M, s_qLD, s_dinv, s_dsqrtinv, lane);
+#if defined(HB_STAMPS) && defined(HB_PROBE_FACTOR)
+    factor_ld(M, lds, s_qLD, s_dinv, s_dsqrtinv, lane, fhead, P.stamps ? stamps_ : nullptr);
+#else
+    factor_ld(M, lds, s_qLD, s_dinv, s_dsqrtinv, lane, fhead);
+#endif
 
     HB_STAMP(6);
     // ---------------------------------------------------------------- qfrc_bias, mj_passive, mj_fwdActuation -> qfrc_smooth

@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import humanoid_mujoco_amd.engine as eng
-eng.LIB_PATH = os.path.join(ROOT, "build", "libhb_stamps.so")
+eng.LIB_PATH = os.environ.get("HB_STAMPS_LIB", os.path.join(ROOT, "build", "libhb_stamps.so"))
 import humanoid_mujoco_amd as hb
 L = eng.lib()
 L.hb_get_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -533,6 +533,10 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   // per-row meta slots
   enum { E_POS = 0, E_MARGIN, E_SOLREF0, E_SOLREF1, E_IMP0, E_IMP1, E_IMP2, E_IMP3, E_IMP4, E_DA, E_DAFIRST, E_MU2, E_FORCE, E_NSLOT };
 
+  // the controls of the first step are requested before the state, those of step t+1 at the top of step t:
+  // an HBM round trip each (streamed, never cached) that would otherwise open every step
+  float ctrl_pf = 0.f;
+  if (P.ctrl_mode != 2 && lane < M.nu) ctrl_pf = P.ctrl[(size_t)env * M.nu + lane];
   float* gstate = P.state + (size_t)env * M.nstate;
   float time = gstate[0];
   for (int i = lane; i < nq; i += kGroup) s_qpos[i] = gstate[1 + i];
@@ -563,7 +567,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       for (int i = lane; i < M.nu; i += kGroup) s_ctrl[i] = 2.f * halton(idx, i + 2) - 1.f;
     } else {
       const float* c = P.ctrl + (P.ctrl_mode == 1 ? (size_t)step * P.n_env * M.nu : 0) + (size_t)env * M.nu;
-      for (int i = lane; i < M.nu; i += kGroup) s_ctrl[i] = c[i];
+      if (lane < M.nu) s_ctrl[lane] = ctrl_pf;
+      for (int i = lane + kGroup; i < M.nu; i += kGroup) s_ctrl[i] = c[i];
+      if (P.ctrl_mode == 1 && step + 1 < nsteps && lane < M.nu) ctrl_pf = c[(size_t)P.n_env * M.nu + lane];
     }
     // ---------------------------------------------------------------- mj_checkPos / mj_checkVel
     {

@@ -401,11 +401,17 @@ struct hb_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_stamps = nullptr;
   // env adapter (hb_env_*)
-  EnvConfig env_cfg;
+  EnvConfig env_cfg = {};
   bool env_ready = false;
   float *d_prev = nullptr, *d_latest = nullptr, *d_qfrc = nullptr, *d_action = nullptr;
   int* d_episode = nullptr;
   int env_offset = 0;
+  // realism layer (hb_env_randomize)
+  EnvRand env_rand = {};
+  EnvRandState rs = {};     // device arrays; all null while off
+  bool rand_on = false;
+  uint8_t* d_rmask = nullptr;  // hb_env_reset's pending-envs mask
+  int* d_pending = nullptr;
   // policy MLP (hb_policy_*)
   int mlp_layers = 0;
   int mlp_sizes[5] = {0, 0, 0, 0, 0};
@@ -437,11 +443,20 @@ struct hb_batch {
 
 namespace {
 
-#define HB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { return HB_ENODEVICE; } } while (0)
+// HB_DEBUG=1 in the environment names the failing HIP call on stderr
+static bool hb_debug() { static const bool on = getenv("HB_DEBUG") != nullptr; return on; }
+// a call whose failure is not fatal (teardown paths): still named under HB_DEBUG, and never left behind as the
+// thread's sticky last error for an unrelated launch to trip over
+#define HB_IGN(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    if (hb_debug()) fprintf(stderr, "[hb] %s:%d: %s -> %s (ignored)\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+    (void)hipGetLastError(); } } while (0)
+#define HB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    if (hb_debug()) fprintf(stderr, "[hb] %s:%d: %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+    return HB_ENODEVICE; } } while (0)
 
 int ensure_ctrl(hb_batch* b, size_t floats) {
   if (floats <= b->ctrl_cap) return HB_OK;
-  if (b->d_ctrl) (void)hipFree(b->d_ctrl);
+  if (b->d_ctrl) HB_IGN(hipFree(b->d_ctrl));
   b->d_ctrl = nullptr; b->ctrl_cap = 0;
   if (hipMalloc((void**)&b->d_ctrl, floats * sizeof(float)) != hipSuccess) return HB_ENOMEM;
   b->ctrl_cap = floats;
@@ -710,23 +725,27 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
   return b;
 }
 
+static void envrand_free_fwd(hb_batch* b);
 void hb_batch_free(hb_batch* b) {
   if (!b) return;
-  (void)hipSetDevice(b->device);
+  HB_IGN(hipSetDevice(b->device));
   for (int c = 0; c < hb_batch::kPipes; c++) {
-    if (b->pipe[c]) { (void)hipStreamSynchronize(b->pipe[c]); (void)hipStreamDestroy(b->pipe[c]); }
-    if (b->ev_pipe[c]) (void)hipEventDestroy(b->ev_pipe[c]);
+    if (b->pipe[c]) { HB_IGN(hipStreamSynchronize(b->pipe[c])); HB_IGN(hipStreamDestroy(b->pipe[c])); }
+    if (b->ev_pipe[c]) HB_IGN(hipEventDestroy(b->ev_pipe[c]));
   }
-  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-  if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-  for (auto e : b->tev) (void)hipEventDestroy(e);
-  for (int i = 0; i < 4; i++) { if (b->d_mlp_w[i]) (void)hipFree(b->d_mlp_w[i]); if (b->d_mlp_b[i]) (void)hipFree(b->d_mlp_b[i]); if (b->d_mlp_wp[i]) (void)hipFree(b->d_mlp_wp[i]); }
-  for (int i = 0; i < 2; i++) if (b->d_mlp_h[i]) (void)hipFree(b->d_mlp_h[i]);
-  if (b->ev0) (void)hipEventDestroy(b->ev0);
-  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->ev_fork) HB_IGN(hipEventDestroy(b->ev_fork));
+  if (b->stream) { HB_IGN(hipStreamSynchronize(b->stream)); HB_IGN(hipStreamDestroy(b->stream)); }
+  for (auto e : b->tev) HB_IGN(hipEventDestroy(e));
+  for (int i = 0; i < 4; i++) { if (b->d_mlp_w[i]) HB_IGN(hipFree(b->d_mlp_w[i])); if (b->d_mlp_b[i]) HB_IGN(hipFree(b->d_mlp_b[i])); if (b->d_mlp_wp[i]) HB_IGN(hipFree(b->d_mlp_wp[i])); }
+  for (int i = 0; i < 2; i++) if (b->d_mlp_h[i]) HB_IGN(hipFree(b->d_mlp_h[i]));
+  if (b->ev0) HB_IGN(hipEventDestroy(b->ev0));
+  if (b->ev1) HB_IGN(hipEventDestroy(b->ev1));
+  envrand_free_fwd(b);
+  if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
+  if (b->d_pending) HB_IGN(hipFree(b->d_pending));
   void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
                   b->d_status, b->d_counts, b->d_qpos_out, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
 }
 
@@ -770,7 +789,7 @@ static int reset_impl(hb_batch* b, const uint8_t* mask, int keyframe, float pert
   }
   b->env_offset = env_offset;
   const float* src = b->D.d_qpos_src + (keyframe < 0 ? 0 : (size_t)(1 + keyframe) * m.nq);
-  HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, dmask, src, b->n_env, perturb_scale, env_offset, main_stream(b)));
+  HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, dmask, src, nullptr, b->n_env, perturb_scale, env_offset, main_stream(b)));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
@@ -828,7 +847,7 @@ int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out) {
   if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
   size_t nq_out = (size_t)T * b->n_env * b->D.dm.nq;
   if (qpos_out && nq_out > b->qpos_out_cap) {
-    if (b->d_qpos_out) (void)hipFree(b->d_qpos_out);
+    if (b->d_qpos_out) HB_IGN(hipFree(b->d_qpos_out));
     b->d_qpos_out = nullptr; b->qpos_out_cap = 0;
     if (hipMalloc((void**)&b->d_qpos_out, nq_out * sizeof(float)) != hipSuccess) return HB_ENOMEM;
     b->qpos_out_cap = nq_out;
@@ -882,13 +901,17 @@ static int env_alloc(hb_batch* b) {
   return HB_OK;
 }
 
-static int env_eval(hb_batch* b, bool allow_reset, float* d_obs, float* d_reward, uint8_t* d_term, uint8_t* d_trunc) {
+// reward / termination / observation of every env (or those of `mask`).  observe: push the observation through the
+// realism layer's noise and delay lines (a step of the episode) instead of returning the true one.
+static int env_eval(hb_batch* b, bool allow_reset, bool observe, const uint8_t* mask, float* d_obs, float* d_reward, uint8_t* d_term, uint8_t* d_trunc) {
   EnvConfig cfg = b->env_cfg;
   if (!allow_reset) cfg.auto_reset = 0;
   const Model& m = b->model->m;
   const float* src = b->D.d_qpos_src + (cfg.reset_keyframe < 0 || cfg.reset_keyframe >= m.nkey ? 0 : (size_t)(1 + cfg.reset_keyframe) * m.nq);
-  HB_HIP(launch_env(b->D.dm, cfg, b->d_state, b->d_qfrc, b->d_counts, b->d_prev, b->d_latest, src, b->d_episode, b->d_status, d_obs, d_reward, d_term, d_trunc,
-                    b->n_env, b->env_offset, main_stream(b)));
+  EnvRandState S = b->rs;
+  if (!b->rand_on) memset(&S, 0, sizeof S);
+  HB_HIP(launch_env(b->D.dm, cfg, b->env_rand, S, b->d_state, b->d_qfrc, b->d_counts, b->d_prev, b->d_latest, src, b->d_episode, b->d_status, d_obs, d_reward,
+                    d_term, d_trunc, mask, observe ? 1 : 0, b->n_env, b->env_offset, main_stream(b)));
   return HB_OK;
 }
 
@@ -898,7 +921,7 @@ int hb_get_obs(hb_batch* b, float* obs, float* reward, uint8_t* terminated, uint
   if (rc != HB_OK) return rc;
   int n = b->n_env, nobs = b->D.dm.nobs;
   if (reward || terminated || truncated) {
-    rc = env_eval(b, false, b->d_obs, b->d_reward, b->d_term, b->d_trunc);  // pure evaluation: no reset, no bookkeeping
+    rc = env_eval(b, false, false, nullptr, b->d_obs, b->d_reward, b->d_term, b->d_trunc);  // pure evaluation: no reset, no bookkeeping, true observation
     if (rc != HB_OK) return rc;
   } else {
     HB_HIP(launch_obs(b->D.dm, b->d_state, b->d_obs, n, main_stream(b)));
@@ -937,6 +960,9 @@ int hb_env_default_config(const hb_model* h, hb_env_config* c) {
     }
   }
   c->auto_reset = 1; c->reset_keyframe = -1; c->reset_perturb = 1.f;
+  c->reward_kind = 0; c->w_vvel = 0.f;
+  c->min_z_grounded = (float)(0.25 * z0);  // the reference's MIN_Z_BEFORE_GROUNDED sits a quarter of the way up its robot
+  c->reset_collision_mode = 0;
   return HB_OK;
 }
 
@@ -947,10 +973,86 @@ int hb_env_configure(hb_batch* b, const hb_env_config* cfg) {
   for (int k = 0; k < cfg->n_equal; k++) for (int t = 0; t < 2; t++) if (cfg->equal_pairs[k][t] < 0 || cfg->equal_pairs[k][t] >= nu) return HB_EINVAL;
   for (int k = 0; k < cfg->n_opposite; k++) for (int t = 0; t < 2; t++) if (cfg->opposite_pairs[k][t] < 0 || cfg->opposite_pairs[k][t] >= nu) return HB_EINVAL;
   if (cfg->reset_keyframe >= b->model->m.nkey) return HB_EINVAL;
+  if (cfg->reward_kind < 0 || cfg->reward_kind > 1 || cfg->reset_collision_mode < 0 || cfg->reset_collision_mode > 2) return HB_EINVAL;
   int rc = env_alloc(b);
   if (rc != HB_OK) return rc;
   memcpy(&b->env_cfg, cfg, sizeof *cfg);
   return HB_OK;
+}
+
+int hb_env_default_randomization(const hb_model* h, hb_env_randomization* r) {
+  if (!h || !r) return HB_EINVAL;
+  memset(r, 0, sizeof *r);
+  const float deg = 0.017453292519943295f;
+  r->factor = 1.f; r->seed = 0; r->control_timestep = (float)h->m.timestep;
+  r->joint_angle_noise = 2.f * deg;     // JOINT_ANGLE_NOISE_STDDEV     (simulation_parameters.py:39-45)
+  r->joint_velocity_noise = 5.f * deg;  // JOINT_VELOCITY_NOISE_STDDEV
+  r->gyro_noise = 2.f * deg;            // GYRO_NOISE_STDDEV
+  r->imu_noise = 5.f * deg;             // IMU_NOISE_STDDEV
+  r->action_noise = 0.5f * deg;         // JOINT_ACTION_NOISE_STDDEV
+  r->min_delay = 0.01f; r->max_delay = 0.05f;  // MIN_DELAY, MAX_DELAY
+  r->frozen_noise = 0;
+  r->push_enabled = 1;                  // *_EXTERNAL_FORCE_* (simulation_parameters.py:14-20)
+  r->push_min_interval = 1.f; r->push_max_interval = 3.f; r->push_min_duration = 0.05f; r->push_max_duration = 0.15f;
+  r->push_min_force = 5.f; r->push_max_force = 15.f;
+  return HB_OK;
+}
+
+// releases the realism layer's device arrays
+static void envrand_free_fwd(hb_batch* b) { void* ptrs[] = {b->rs.k_act, b->rs.k_obs, b->rs.delay, b->rs.fifo_act, b->rs.fifo_joint, b->rs.fifo_gyro, b->rs.fifo_grav, b->rs.push}; for (void* p : ptrs) if (p) HB_IGN(hipFree(p)); memset(&b->rs, 0, sizeof b->rs); b->rand_on = false; }
+static void envrand_free(hb_batch* b) { envrand_free_fwd(b); }
+int hb_env_randomize(hb_batch* b, const hb_env_randomization* cfg) {
+  if (!b) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  if (!cfg || !(cfg->factor > 0.f)) { envrand_free(b); return HB_OK; }
+  const DevModel& dm = b->D.dm;
+  const float dt = cfg->control_timestep > 0.f ? cfg->control_timestep : dm.timestep;
+  if (!(cfg->max_delay >= cfg->min_delay) || cfg->min_delay < 0.f || cfg->max_delay * cfg->factor / dt > (float)(kDelaySlots - 1)) return HB_EINVAL;
+  if (cfg->push_enabled && (!(cfg->push_max_interval >= cfg->push_min_interval) || !(cfg->push_max_duration >= cfg->push_min_duration) ||
+                            !(cfg->push_max_force >= cfg->push_min_force) || dm.nbody < 2)) return HB_EINVAL;
+  static_assert(sizeof(hb_env_randomization) == sizeof(EnvRand), "hb_env_randomization and EnvRand must have the same layout");
+  const size_t n = b->n_env, nu = std::max(1, dm.nu), nj2 = std::max(2, dm.nobs - 6);
+  if (!b->rs.k_act) {
+    bool ok = hipMalloc((void**)&b->rs.k_act, n * sizeof(int)) == hipSuccess && hipMalloc((void**)&b->rs.k_obs, n * sizeof(int)) == hipSuccess &&
+              hipMalloc((void**)&b->rs.delay, n * 4 * sizeof(int)) == hipSuccess && hipMalloc((void**)&b->rs.fifo_act, n * kDelaySlots * nu * sizeof(float)) == hipSuccess &&
+              hipMalloc((void**)&b->rs.fifo_joint, n * kDelaySlots * nj2 * sizeof(float)) == hipSuccess &&
+              hipMalloc((void**)&b->rs.fifo_gyro, n * kDelaySlots * 3 * sizeof(float)) == hipSuccess &&
+              hipMalloc((void**)&b->rs.fifo_grav, n * kDelaySlots * 3 * sizeof(float)) == hipSuccess && hipMalloc((void**)&b->rs.push, n * 8 * sizeof(float)) == hipSuccess;
+    if (!ok) { envrand_free(b); return HB_ENOMEM; }
+    HB_HIP(hipMemset(b->rs.push, 0, n * 8 * sizeof(float)));
+  }
+  if (cfg->push_enabled && !b->d_xfrc) {
+    const size_t nx = n * 6 * dm.nbody;
+    if (hipMalloc((void**)&b->d_xfrc, nx * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+    HB_HIP(hipMemset(b->d_xfrc, 0, nx * sizeof(float)));
+  }
+  memcpy(&b->env_rand, cfg, sizeof *cfg);
+  b->rs.xfrc = cfg->push_enabled ? b->d_xfrc : nullptr;
+  b->rand_on = true;
+  // a consistent episode state until the caller resets: delays drawn, rings empty
+  HB_HIP(launch_envrand_reset(dm, b->env_rand, b->rs, b->d_episode, nullptr, b->n_env, b->env_offset, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
+}
+
+// CPUEnv._apply_action (+ pushes) -> n_substeps x mj_step -> reward / termination / observation, for every env or those of `mask`
+static int env_step_impl(hb_batch* b, const float* action_dev, int n_substeps, const uint8_t* mask, bool allow_reset, float* obs_dev, float* reward_dev,
+                         uint8_t* terminated_dev, uint8_t* truncated_dev) {
+  const int n = b->n_env * b->D.dm.nu;
+  if (b->rand_on) {
+    HB_HIP(launch_action_env(b->D.dm, b->env_rand, b->rs, action_dev, b->d_prev, b->d_latest, b->d_ctrl, b->d_episode, b->d_state, mask, b->n_env, b->env_offset,
+                             main_stream(b)));
+  } else if (n && action_dev) {
+    HB_HIP(launch_action(action_dev, b->d_prev, b->d_latest, b->d_ctrl, n, main_stream(b)));
+  }
+  BatchPtrs P = make_ptrs(b);
+  P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.env_mask = mask;
+  int rc = launch_steps(b, P, n_substeps);
+  if (rc != HB_OK) return rc;
+  return env_eval(b, allow_reset, true, mask, obs_dev, reward_dev, terminated_dev, truncated_dev);
 }
 
 int hb_env_reset(hb_batch* b, float* obs) {
@@ -958,26 +1060,51 @@ int hb_env_reset(hb_batch* b, float* obs) {
   int rc = env_alloc(b);
   if (rc != HB_OK) return rc;
   const EnvConfig& c = b->env_cfg;
-  size_t nu = std::max(1, b->D.dm.nu);
-  HB_HIP(hipMemsetAsync(b->d_prev, 0, (size_t)b->n_env * nu * sizeof(float), main_stream(b)));
-  HB_HIP(hipMemsetAsync(b->d_latest, 0, (size_t)b->n_env * nu * sizeof(float), main_stream(b)));
-  HB_HIP(hipMemsetAsync(b->d_episode, 0, (size_t)b->n_env * sizeof(int), main_stream(b)));
-  rc = reset_impl(b, nullptr, c.reset_keyframe, c.reset_perturb, b->env_offset);
+  const Model& m = b->model->m;
+  const size_t n = b->n_env, nu = std::max(1, b->D.dm.nu);
+  HB_HIP(hipMemsetAsync(b->d_prev, 0, n * nu * sizeof(float), main_stream(b)));
+  HB_HIP(hipMemsetAsync(b->d_latest, 0, n * nu * sizeof(float), main_stream(b)));
+  HB_HIP(hipMemsetAsync(b->d_episode, 0, n * sizeof(int), main_stream(b)));
+  if (b->d_ctrl) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * nu * sizeof(float), main_stream(b)));
+  if (c.reset_collision_mode == 0) {
+    rc = reset_impl(b, nullptr, c.reset_keyframe, c.reset_perturb, b->env_offset);
+    if (rc != HB_OK) return rc;
+    if (b->rand_on) HB_HIP(launch_envrand_reset(b->D.dm, b->env_rand, b->rs, b->d_episode, nullptr, b->n_env, b->env_offset, main_stream(b)));
+  } else {
+    // The reference's protocol (cpu_env.py:374-416): randomise, take one step with the current (zero) controls, and
+    // start over with a new draw while that step ends in a collision or in a terminal state.  Pending envs carry
+    // a mask; everything (reset, realism layer, physics, evaluation) runs masked, at most eight draws.
+    if (!b->d_rmask && (hipMalloc((void**)&b->d_rmask, n) != hipSuccess || hipMalloc((void**)&b->d_pending, sizeof(int)) != hipSuccess)) return HB_ENOMEM;
+    HB_HIP(hipMemsetAsync(b->d_rmask, 1, n, main_stream(b)));
+    const float* src = b->D.d_qpos_src + (c.reset_keyframe < 0 ? 0 : (size_t)(1 + c.reset_keyframe) * m.nq);
+    const float dtc = b->rand_on && b->env_rand.control_timestep > 0.f ? b->env_rand.control_timestep : (float)m.timestep;
+    const int substeps = std::max(1, (int)std::lround(dtc / m.timestep));
+    for (int attempt = 0; attempt < 8; attempt++) {
+      HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, b->d_rmask, src, b->d_episode, b->n_env, c.reset_perturb, b->env_offset, main_stream(b)));
+      if (b->rand_on) HB_HIP(launch_envrand_reset(b->D.dm, b->env_rand, b->rs, b->d_episode, b->d_rmask, b->n_env, b->env_offset, main_stream(b)));
+      rc = env_step_impl(b, nullptr, substeps, b->d_rmask, false, b->d_obs, b->d_reward, b->d_term, b->d_trunc);
+      if (rc != HB_OK) return rc;
+      HB_HIP(hipMemsetAsync(b->d_pending, 0, sizeof(int), main_stream(b)));
+      HB_HIP(launch_reset_check(b->d_counts, b->d_term, b->d_trunc, b->d_rmask, b->d_episode, b->d_pending, c.reset_collision_mode, b->n_env, main_stream(b)));
+      int pending = 0;
+      HB_HIP(hipMemcpyAsync(&pending, b->d_pending, sizeof(int), hipMemcpyDeviceToHost, main_stream(b)));
+      HB_HIP(hipStreamSynchronize(main_stream(b)));
+      if (pending == 0) break;
+    }
+  }
+  // the observation the reference returns from reset(): one more pass through the noise and delay lines
+  rc = env_eval(b, false, true, nullptr, b->d_obs, b->d_reward, b->d_term, b->d_trunc);
   if (rc != HB_OK) return rc;
-  return hb_get_obs(b, obs, nullptr, nullptr, nullptr);
+  HB_HIP(hipMemcpyAsync(obs, b->d_obs, n * b->D.dm.nobs * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
 }
 
 int hb_env_step_dev(hb_batch* b, const float* action_dev, int n_substeps, float* obs_dev, float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev) {
   if (!b || !action_dev || n_substeps < 1 || !obs_dev || !reward_dev || !terminated_dev || !truncated_dev) return HB_EINVAL;
   int rc = env_alloc(b);
   if (rc != HB_OK) return rc;
-  int n = b->n_env * b->D.dm.nu;
-  if (n) HB_HIP(launch_action(action_dev, b->d_prev, b->d_latest, b->d_ctrl, n, main_stream(b)));
-  BatchPtrs P = make_ptrs(b);
-  P.ctrl = b->d_ctrl; P.ctrl_mode = 0;
-  rc = launch_steps(b, P, n_substeps);
-  if (rc != HB_OK) return rc;
-  return env_eval(b, true, obs_dev, reward_dev, terminated_dev, truncated_dev);
+  return env_step_impl(b, action_dev, n_substeps, nullptr, true, obs_dev, reward_dev, terminated_dev, truncated_dev);
 }
 
 int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated) {
@@ -1009,7 +1136,7 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
   for (int l = 0; l <= n_layers; l++) fused = fused && sizes[l] <= 256;
   for (int l = 0; l < n_layers; l++) {
     if (!weights[l] || !biases[l]) return HB_EINVAL;
-    if (b->d_mlp_wp[l]) { (void)hipFree(b->d_mlp_wp[l]); b->d_mlp_wp[l] = nullptr; }
+    if (b->d_mlp_wp[l]) { HB_IGN(hipFree(b->d_mlp_wp[l])); b->d_mlp_wp[l] = nullptr; }
     if (fused) {
       // B-operand order of v_mfma_f32_32x32x2_f32: wp[tile][k/2][lane] = W[2(k/2) + lane/32][32 tile + lane%32], zero padded
       const int K = sizes[l], N = sizes[l + 1], KK = (K + 1) / 2, ntile = (N + 31) / 32;
@@ -1023,8 +1150,8 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
       if (hipMalloc((void**)&b->d_mlp_wp[l], wp.size() * sizeof(float)) != hipSuccess) return HB_ENOMEM;
       HB_HIP(hipMemcpy(b->d_mlp_wp[l], wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (b->d_mlp_w[l]) { (void)hipFree(b->d_mlp_w[l]); b->d_mlp_w[l] = nullptr; }
-    if (b->d_mlp_b[l]) { (void)hipFree(b->d_mlp_b[l]); b->d_mlp_b[l] = nullptr; }
+    if (b->d_mlp_w[l]) { HB_IGN(hipFree(b->d_mlp_w[l])); b->d_mlp_w[l] = nullptr; }
+    if (b->d_mlp_b[l]) { HB_IGN(hipFree(b->d_mlp_b[l])); b->d_mlp_b[l] = nullptr; }
     size_t nw = (size_t)sizes[l] * sizes[l + 1];
     if (hipMalloc((void**)&b->d_mlp_w[l], nw * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_mlp_b[l], sizes[l + 1] * sizeof(float)) != hipSuccess) return HB_ENOMEM;
     HB_HIP(hipMemcpy(b->d_mlp_w[l], weights[l], nw * sizeof(float), hipMemcpyHostToDevice));
@@ -1032,7 +1159,7 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
     if (l + 1 < n_layers) maxh = std::max(maxh, sizes[l + 1]);
   }
   for (int i = 0; i < 2; i++) {
-    if (b->d_mlp_h[i]) { (void)hipFree(b->d_mlp_h[i]); b->d_mlp_h[i] = nullptr; }
+    if (b->d_mlp_h[i]) { HB_IGN(hipFree(b->d_mlp_h[i])); b->d_mlp_h[i] = nullptr; }
     if (hipMalloc((void**)&b->d_mlp_h[i], (size_t)b->n_env * maxh * sizeof(float)) != hipSuccess) return HB_ENOMEM;
   }
   b->mlp_layers = n_layers;
@@ -1154,9 +1281,9 @@ void* hb_dev_alloc(hb_batch* b, uint64_t bytes) {
 }
 void hb_dev_free(hb_batch* b, void* p) {
   if (!b || !p) return;
-  (void)hipSetDevice(b->device);
-  (void)hipStreamSynchronize(main_stream(b));
-  (void)hipFree(p);
+  HB_IGN(hipSetDevice(b->device));
+  HB_IGN(hipStreamSynchronize(main_stream(b)));
+  HB_IGN(hipFree(p));
 }
 int hb_memcpy_h2d(hb_batch* b, void* dst_dev, const void* src, uint64_t bytes) {
   if (!b || !dst_dev || !src) return HB_EINVAL;

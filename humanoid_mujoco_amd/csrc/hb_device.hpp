@@ -113,6 +113,33 @@ struct EnvConfig {
   int opposite_pairs[kEnvMaxPairs][2];
   int auto_reset, reset_keyframe;
   float reset_perturb;
+  int reward_kind;
+  float w_vvel, min_z_grounded;
+  int reset_collision_mode;
+};
+
+// hb_env_randomization (include/hb.h), same layout
+struct EnvRand {
+  float factor;
+  unsigned seed;
+  float control_timestep;
+  float joint_angle_noise, joint_velocity_noise, gyro_noise, imu_noise, action_noise;
+  float min_delay, max_delay;
+  int frozen_noise, push_enabled;
+  float push_min_interval, push_max_interval, push_min_duration, push_max_duration, push_min_force, push_max_force;
+};
+constexpr int kDelaySlots = 64;  // ring size of the delay FIFOs (delays <= 63 control steps)
+// per-env state of the realism layer, all [n_env]-major device arrays (null when hb_env_randomize is off)
+struct EnvRandState {
+  int* k_act;      // actions pushed this episode
+  int* k_obs;      // observations pushed this episode
+  int* delay;      // [n][4]: action, joints, gyro, gravity (control steps)
+  float* fifo_act;   // [n][kDelaySlots][nu]
+  float* fifo_joint; // [n][kDelaySlots][2 nscalar]
+  float* fifo_gyro;  // [n][kDelaySlots][3]
+  float* fifo_grav;  // [n][kDelaySlots][3]
+  float* push;     // [n][8]: start, duration, magnitude, dir x, dir y, body, event count, -
+  float* xfrc;     // [n][nbody][6] (the batch's xfrc_applied)
 };
 
 // fused policy kernel (hb_policy_kernel): layer sizes, host-packed weights (MFMA B-operand order) and biases
@@ -143,6 +170,7 @@ struct BatchPtrs {
   // heavy-first block scheduling (nullable): slot s takes env = order[s], a permutation sorted by
   // the cost of each env's previous step (counts[4*e+3]) so the most expensive envs are dispatched first
   const int* order;    // [n_env]
+  const unsigned char* env_mask;  // nullable [n_env]: envs with a zero byte are skipped by this launch
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
 };
 

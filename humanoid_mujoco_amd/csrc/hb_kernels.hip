@@ -493,6 +493,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   if ((int)blockIdx.x >= P.nblk) return;
   const int slot = P.blk0 + (int)blockIdx.x;
   const int env = P.order ? P.order[slot] : slot;
+  if (P.env_mask && !P.env_mask[env]) return;  // masked stepping (hb_env_reset's settle step)
   const int nv = M.nv, nq = M.nq, nb = M.nbody, cs = M.cstride;
 
   float* s_qpos = lds + M.o_qpos;
@@ -1434,22 +1435,157 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
 
 // ------------------------------------------------------------------------------------------
 // reset: qpos0/keyframe (+ Halton perturbation), zero velocity/warmstart/time/status
-__global__ void hb_reset_kernel(const DevModel M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, float perturb, int env_offset) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_env) return;
-  if (mask && !mask[e]) return;
-  float* s = state + (size_t)e * M.nstate;
+// qpos <- reset pose (+ the Halton perturbation indexed by global env and, for the env adapter, episode), rest zero
+__device__ __forceinline__ void reset_state(const DevModel& M, float* s, const float* qpos_src, float perturb, int env_global, int ep) {
   s[0] = 0.f;
   for (int i = 0; i < M.nq; i++) s[1 + i] = qpos_src[i];
   for (int i = 0; i < 2 * M.nv; i++) s[1 + M.nq + i] = 0.f;
   if (perturb > 0.f) {
+    const int idx = env_global + 1 + ep * 7919;
     for (int j = 0; j < M.njnt; j++) {
       int qa = M.jnt_qposadr[j];
-      if (M.jnt_type[j] == 0) s[1 + qa + 2] += perturb * 0.1f * halton(env_offset + e + 1, 3);
-      else s[1 + qa] += perturb * 0.2f * (2.f * halton(env_offset + e + 1, 2 + j) - 1.f);
+      if (M.jnt_type[j] == 0) s[1 + qa + 2] += perturb * 0.1f * halton(idx, 3);
+      else s[1 + qa] += perturb * 0.2f * (2.f * halton(idx, 2 + j) - 1.f);
     }
   }
+}
+__global__ void hb_reset_kernel(const DevModel M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
+                                int env_offset) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env) return;
+  if (mask && !mask[e]) return;
+  reset_state(M, state + (size_t)e * M.nstate, qpos_src, perturb, env_offset + e, episode ? episode[e] : 0);
   status[e] = 0;
+}
+
+// ---- env realism (hb_env_randomization): counter-based random numbers, delay rings, pushes -------------------
+// One 32-bit word per (seed, global env, episode, step, stream, element): reproducible, order-free, and the same
+// on any split of the batch.  tests/env_ref.py restates these functions in numpy.
+__device__ __forceinline__ unsigned rng_mix(unsigned h, unsigned v) {
+  h ^= v; h *= 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ unsigned rng_u32(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
+  unsigned h = rng_mix(0x6A09E667u, seed);
+  h = rng_mix(h, env); h = rng_mix(h, ep); h = rng_mix(h, step); h = rng_mix(h, stream); h = rng_mix(h, idx);
+  return h;
+}
+__device__ __forceinline__ float rng_uniform(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
+  return ((float)(rng_u32(seed, env, ep, step, stream, idx) >> 8) + 0.5f) * (1.f / 16777216.f);  // (0, 1)
+}
+__device__ __forceinline__ float rng_normal(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
+  const float u1 = rng_uniform(seed, env, ep, step, stream, 2 * idx), u2 = rng_uniform(seed, env, ep, step, stream, 2 * idx + 1);
+  return sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);  // Box-Muller
+}
+enum { RS_ACTION = 1, RS_JOINT_POS, RS_JOINT_VEL, RS_GYRO, RS_IMU, RS_DELAY, RS_PUSH };
+
+// start of an episode: delays drawn (cpu_env.py:135-168), rings logically empty, push schedule cleared
+__device__ __forceinline__ void envrand_begin_episode(const DevModel& M, const EnvRand& R, const EnvRandState& S, int e, int env_global, int ep) {
+  const float dt = R.control_timestep > 0.f ? R.control_timestep : M.timestep;
+  for (int c = 0; c < 4; c++) {
+    const float u = rng_uniform(R.seed, env_global, ep, 0, RS_DELAY, c);
+    const float d = (R.min_delay + u * (R.max_delay - R.min_delay)) * R.factor;
+    S.delay[4 * e + c] = min(kDelaySlots - 1, max(0, (int)rintf(d / dt)));
+  }
+  S.k_act[e] = 0;
+  S.k_obs[e] = 0;
+  float* p = S.push + 8 * (size_t)e;
+  if (S.xfrc) {
+    const int body = (int)p[5];
+    if (body > 0 && body < M.nbody) { S.xfrc[((size_t)e * M.nbody + body) * 6] = 0.f; S.xfrc[((size_t)e * M.nbody + body) * 6 + 1] = 0.f; }
+  }
+  for (int i = 0; i < 8; i++) p[i] = 0.f;
+}
+__global__ void hb_envrand_reset_kernel(const DevModel M, const EnvRand R, const EnvRandState S, const int* episode, const uint8_t* mask, int n_env, int env_offset) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env || (mask && !mask[e])) return;
+  envrand_begin_episode(M, R, S, e, env_offset + e, episode[e]);
+}
+
+// value through a delay ring: push x as item k, return item k - d (filler before the ring has d items)
+__device__ __forceinline__ float ring_delay(float* ring, int stride, int k, int d, float x, float filler) {
+  ring[(size_t)(k % kDelaySlots) * stride] = x;
+  if (d == 0) return x;
+  return k >= d ? ring[(size_t)((k - d) % kDelaySlots) * stride] : filler;
+}
+
+// CPUEnv._apply_action + _apply_external_forces (cpu_env.py:612-674) for one env per thread.
+// action == nullptr: the reference's step(None), which re-applies the current controls without noise.
+__global__ void hb_action_env_kernel(const DevModel M, const EnvRand R, const EnvRandState S, const float* action, float* prev, float* latest, float* ctrl,
+                                     const int* episode, const float* state, const uint8_t* mask, int n_env, int env_offset) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env || (mask && !mask[e])) return;
+  const int nu = M.nu, ge = env_offset + e, ep = episode[e];
+  const int k = S.k_act[e], d = S.delay[4 * e];
+  const unsigned kk = R.frozen_noise ? 0u : (unsigned)k;
+  for (int i = 0; i < nu; i++) {
+    const size_t ai = (size_t)e * nu + i;
+    float a = action ? action[ai] : ctrl[ai];
+    if (action && R.action_noise > 0.f) a += R.factor * R.action_noise * rng_normal(R.seed, ge, ep, kk, RS_ACTION, i);
+    const float out = ring_delay(S.fifo_act + ((size_t)e * kDelaySlots) * nu + i, nu, k, d, a, 0.f);
+    prev[ai] = latest[ai];
+    latest[ai] = out;
+    ctrl[ai] = out;
+  }
+  S.k_act[e] = k + 1;
+  if (R.push_enabled && S.xfrc) {
+    float* p = S.push + 8 * (size_t)e;
+    float* xf = S.xfrc + (size_t)e * M.nbody * 6;
+    const float time = state[(size_t)e * M.nstate];
+    if (time >= p[0] + p[1]) {  // window over (or first step): clear the old force, schedule the next push
+      const unsigned ev = (unsigned)p[6];
+      int body = (int)p[5];
+      if (body > 0 && body < M.nbody) { xf[6 * body] = 0.f; xf[6 * body + 1] = 0.f; }
+      p[0] = time + R.push_min_interval + rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 0) * (R.push_max_interval - R.push_min_interval);
+      p[1] = R.push_min_duration + rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 1) * (R.push_max_duration - R.push_min_duration);
+      p[2] = R.factor * (R.push_min_force + rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 2) * (R.push_max_force - R.push_min_force));
+      float dx = 2.f * rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 3) - 1.f, dy = 2.f * rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 4) - 1.f;
+      const float n = sqrtf(dx * dx + dy * dy);  // never 0: the uniforms are odd multiples of 2^-24
+      p[3] = dx / n; p[4] = dy / n;
+      body = 1 + min(M.nbody - 2, (int)(rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 5) * (float)(M.nbody - 1)));
+      p[5] = (float)body;
+      p[6] = (float)(ev + 1);
+    }
+    if (time > p[0] && time < p[0] + p[1]) {
+      const int body = (int)p[5];
+      xf[6 * body] = p[3] * p[2];
+      xf[6 * body + 1] = p[4] * p[2];
+    }
+  }
+}
+
+// CPUEnv._get_obs's noise and delay lines (cpu_env.py:465-545) applied in place to the true observation o
+__device__ __forceinline__ void envrand_observe(const DevModel& M, const EnvRand& R, const EnvRandState& S, int e, int env_global, int ep, const float* s, float* o) {
+  const int k = S.k_obs[e];
+  const unsigned kk = R.frozen_noise ? 0u : (unsigned)k;
+  const int nj = (M.nobs - 6) / 2;
+  const int dj = S.delay[4 * e + 1], dg = S.delay[4 * e + 2], dv = S.delay[4 * e + 3];
+  float* rj = S.fifo_joint + ((size_t)e * kDelaySlots) * 2 * nj;
+  for (int i = 0; i < nj; i++) {
+    const float a = o[i] + R.factor * R.joint_angle_noise * rng_normal(R.seed, env_global, ep, kk, RS_JOINT_POS, i);
+    const float v = o[nj + i] + R.factor * R.joint_velocity_noise * rng_normal(R.seed, env_global, ep, kk, RS_JOINT_VEL, i);
+    o[i] = ring_delay(rj + i, 2 * nj, k, dj, a, 0.f);
+    o[nj + i] = ring_delay(rj + nj + i, 2 * nj, k, dj, v, 0.f);
+  }
+  float* rg = S.fifo_gyro + ((size_t)e * kDelaySlots) * 3;
+  for (int c = 0; c < 3; c++) {
+    const float w = o[2 * nj + c] + R.factor * R.gyro_noise * rng_normal(R.seed, env_global, ep, kk, RS_GYRO, c);
+    o[2 * nj + c] = ring_delay(rg + c, 3, k, dg, w, 0.f);
+  }
+  // gravity direction from the noisy, re-normalised torso quaternion (Rotation.from_quat normalises)
+  Q4 q = {1.f, 0.f, 0.f, 0.f};
+  const int da = M.obs_root_dofadr;
+  if (da >= 0) q = ldq(s + 1 + M.jnt_qposadr[M.dof_jntid[da]] + 3);
+  q.w += R.factor * R.imu_noise * rng_normal(R.seed, env_global, ep, kk, RS_IMU, 0);
+  q.x += R.factor * R.imu_noise * rng_normal(R.seed, env_global, ep, kk, RS_IMU, 1);
+  q.y += R.factor * R.imu_noise * rng_normal(R.seed, env_global, ep, kk, RS_IMU, 2);
+  q.z += R.factor * R.imu_noise * rng_normal(R.seed, env_global, ep, kk, RS_IMU, 3);
+  float m[9];
+  q2mat(m, qnormalize(q));
+  const float gl[3] = {-m[6], -m[7], -m[8]};
+  float* rv = S.fifo_grav + ((size_t)e * kDelaySlots) * 3;
+  for (int c = 0; c < 3; c++) o[2 * nj + 3 + c] = ring_delay(rv + c, 3, k, dv, gl[c], c == 2 ? -1.f : 0.f);
+  S.k_obs[e] = k + 1;
 }
 
 // env adapter: observation, the 27-DoF analogue of CPUEnv._get_obs (cpu_env.py:465-571):
@@ -1501,11 +1637,11 @@ __global__ void hb_action_kernel(const float* action, float* prev, float* latest
 __device__ __forceinline__ float scaled_exp(float x) { return expf(-x / 0.5f); }  // reward_functions.py:17-19
 
 // standupReward (reward_functions.py:247-374) + observation + termination + auto-reset, one thread per env
-__global__ void hb_env_kernel(const DevModel M, const EnvConfig cfg, float* state, const float* qfrc, const int* counts, float* prev, float* latest,
-                              const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env,
-                              int env_offset) {
+__global__ void hb_env_kernel(const DevModel M, const EnvConfig cfg, const EnvRand R, const EnvRandState S, float* state, const float* qfrc, const int* counts,
+                              float* prev, float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated,
+                              uint8_t* truncated, const uint8_t* mask, int observe, int n_env, int env_offset) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_env) return;
+  if (e >= n_env || (mask && !mask[e])) return;
   float* s = state + (size_t)e * M.nstate;
   float* o = obs + (size_t)e * M.nobs;
   float g[3], z;
@@ -1554,32 +1690,44 @@ __global__ void hb_env_kernel(const DevModel M, const EnvConfig cfg, float* stat
     for (int k = 0; k < cfg.n_opposite; k++) { float d = (la[cfg.opposite_pairs[k][0]] + la[cfg.opposite_pairs[k][1]]) * inv; sym += scaled_exp(d * d); }
     r += cfg.w_symmetry * sym / (float)(cfg.n_equal + cfg.n_opposite);
   }
+  if (cfg.w_vvel != 0.f) { const float vz = da >= 0 ? qvel[da + 2] : 0.f; r += cfg.w_vvel * scaled_exp(vz * vz); }  // vertical_velocity_penalty
   if (counts[kCountStride * e + 4]) r += cfg.self_collision_penalty;
-  const bool term = cfg.max_time > 0.f && s[0] >= cfg.max_time;
-  if (term) r = cfg.terminal_reward;
   const bool upright = fmaxf(fabsf(g[0]), fabsf(g[1])) < cfg.upright_tol;
-  const bool trunc = z >= cfg.target_z && upright;
+  const bool timeup = cfg.max_time > 0.f && s[0] >= cfg.max_time;
+  bool term, trunc;
+  if (cfg.reward_kind == 1) {  // controlInputReward: fall = terminal (with the terminal reward), time limit = truncation
+    term = !upright || z < cfg.min_z_grounded;
+    trunc = timeup;
+  } else {                     // standupReward: time limit = terminal, standing up = truncation ("is_success")
+    term = timeup;
+    trunc = z >= cfg.target_z && upright;
+  }
+  if (term) r = cfg.terminal_reward;
   reward[e] = r;
   terminated[e] = term ? 1 : 0;
   truncated[e] = trunc ? 1 : 0;
+  const bool rand_on = S.k_obs != nullptr;
   if ((term || trunc) && cfg.auto_reset) {
     // CPUEnv.reset for this env; the perturbation index advances with the episode count
     const int ep = ++episode[e];
-    s[0] = 0.f;
-    for (int i = 0; i < M.nq; i++) s[1 + i] = qpos_src[i];
-    for (int i = 0; i < 2 * M.nv; i++) s[1 + M.nq + i] = 0.f;
-    if (cfg.reset_perturb > 0.f) {
-      const int idx = env_offset + e + 1 + ep * 7919;
-      for (int j = 0; j < M.njnt; j++) {
-        int qa = M.jnt_qposadr[j];
-        if (M.jnt_type[j] == 0) s[1 + qa + 2] += cfg.reset_perturb * 0.1f * halton(idx, 3);
-        else s[1 + qa] += cfg.reset_perturb * 0.2f * (2.f * halton(idx, 2 + j) - 1.f);
-      }
-    }
+    reset_state(M, s, qpos_src, cfg.reset_perturb, env_offset + e, ep);
     for (int i = 0; i < M.nu; i++) { prev[(size_t)e * M.nu + i] = 0.f; latest[(size_t)e * M.nu + i] = 0.f; }
     status[e] = 0;
+    if (rand_on) envrand_begin_episode(M, R, S, e, env_offset + e, ep);
     compute_obs(M, s, o, g, &z);
   }
+  if (rand_on && observe) envrand_observe(M, R, S, e, env_offset + e, episode[e], s, o);
+}
+
+// hb_env_reset's collision test (cpu_env.py:411-414): envs of the mask that collide (mode 1: any contact, mode 2:
+// self-contact) or ended in their settle step stay in the mask, get a new episode number and are counted
+__global__ void hb_reset_check_kernel(const int* counts, const uint8_t* terminated, const uint8_t* truncated, uint8_t* mask, int* episode, int* pending, int mode,
+                                      int n_env) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env || !mask[e]) return;
+  const bool hit = mode == 1 ? counts[kCountStride * e] > 0 : counts[kCountStride * e + 4] != 0;
+  if (hit || terminated[e] || truncated[e]) { episode[e]++; atomicAdd(pending, 1); }
+  else mask[e] = 0;
 }
 
 
@@ -1752,32 +1900,60 @@ namespace hb {
 
 hipError_t launch_step(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   size_t shmem = (size_t)lds_floats * sizeof(float);
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   return hipGetLastError();
 }
-hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, float perturb, int env_offset, hipStream_t stream) {
-  hipLaunchKernelGGL(hb_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, status, mask, qpos_src, n_env, perturb, env_offset);
+hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
+                        int env_offset, hipStream_t stream) {
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
+  hipLaunchKernelGGL(hb_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, status, mask, qpos_src, episode, n_env, perturb, env_offset);
+  return hipGetLastError();
+}
+hipError_t launch_envrand_reset(const DevModel& M, const EnvRand& R, const EnvRandState& S, const int* episode, const uint8_t* mask, int n_env, int env_offset,
+                                hipStream_t stream) {
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
+  hipLaunchKernelGGL(hb_envrand_reset_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, R, S, episode, mask, n_env, env_offset);
+  return hipGetLastError();
+}
+hipError_t launch_action_env(const DevModel& M, const EnvRand& R, const EnvRandState& S, const float* action, float* prev, float* latest, float* ctrl,
+                             const int* episode, const float* state, const uint8_t* mask, int n_env, int env_offset, hipStream_t stream) {
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
+  hipLaunchKernelGGL(hb_action_env_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, R, S, action, prev, latest, ctrl, episode, state, mask, n_env,
+                     env_offset);
+  return hipGetLastError();
+}
+hipError_t launch_reset_check(const int* counts, const uint8_t* terminated, const uint8_t* truncated, uint8_t* mask, int* episode, int* pending, int mode, int n_env,
+                              hipStream_t stream) {
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
+  hipLaunchKernelGGL(hb_reset_check_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, counts, terminated, truncated, mask, episode, pending, mode, n_env);
   return hipGetLastError();
 }
 hipError_t launch_obs(const DevModel& M, const float* state, float* obs, int n_env, hipStream_t stream) {
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_obs_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, obs, n_env);
   return hipGetLastError();
 }
 hipError_t launch_action(const float* action, float* prev, float* latest, float* ctrl, int n, hipStream_t stream) {
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_action_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, action, prev, latest, ctrl, n);
   return hipGetLastError();
 }
-hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, float* state, const float* qfrc, const int* counts, float* prev, float* latest, const float* qpos_src,
-                      int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env, int env_offset, hipStream_t stream) {
-  hipLaunchKernelGGL(hb_env_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, cfg, state, qfrc, counts, prev, latest, qpos_src, episode, status, obs, reward,
-                     terminated, truncated, n_env, env_offset);
+hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, const EnvRand& R, const EnvRandState& S, float* state, const float* qfrc, const int* counts, float* prev,
+                      float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
+                      const uint8_t* mask, int observe, int n_env, int env_offset, hipStream_t stream) {
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
+  hipLaunchKernelGGL(hb_env_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, cfg, R, S, state, qfrc, counts, prev, latest, qpos_src, episode, status, obs,
+                     reward, terminated, truncated, mask, observe, n_env, env_offset);
   return hipGetLastError();
 }
 hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream) {
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, e0, n);
   return hipGetLastError();
 }
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream) {
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_mlp_layer_kernel, dim3((Mrows + 31) / 32, (N + 31) / 32), dim3(kGroup), (size_t)32 * (K + 1) * sizeof(float), stream, X, W, bias, Y, Mrows, K, N, act);
   return hipGetLastError();
 }
@@ -1789,11 +1965,13 @@ hipError_t launch_policy(const DevModel& M, const PolicyDesc& pd, const float* s
     if (e != hipSuccess) return e;
     raised = true;
   }
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_policy_kernel, dim3((n_env + 31) / 32), dim3(512), shmem, stream, M, pd, state, ctrl, n_env);
   return hipGetLastError();
 }
 hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream) {
   size_t total = (size_t)T * n_env * nu;
+  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_halton_ctrl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, out, T, n_env, nu, t0, env_offset);
   return hipGetLastError();
 }

@@ -4,11 +4,19 @@
 #include "hb_device.hpp"
 namespace hb {
 hipError_t launch_step(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream);
-hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, int n_env, float perturb, int env_offset, hipStream_t stream);
+hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
+                        int env_offset, hipStream_t stream);
+hipError_t launch_envrand_reset(const DevModel& M, const EnvRand& R, const EnvRandState& S, const int* episode, const uint8_t* mask, int n_env, int env_offset,
+                                hipStream_t stream);
+hipError_t launch_action_env(const DevModel& M, const EnvRand& R, const EnvRandState& S, const float* action, float* prev, float* latest, float* ctrl,
+                             const int* episode, const float* state, const uint8_t* mask, int n_env, int env_offset, hipStream_t stream);
+hipError_t launch_reset_check(const int* counts, const uint8_t* terminated, const uint8_t* truncated, uint8_t* mask, int* episode, int* pending, int mode, int n_env,
+                              hipStream_t stream);
 hipError_t launch_obs(const DevModel& M, const float* state, float* obs, int n_env, hipStream_t stream);
 hipError_t launch_action(const float* action, float* prev, float* latest, float* ctrl, int n, hipStream_t stream);
-hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, float* state, const float* qfrc, const int* counts, float* prev, float* latest, const float* qpos_src,
-                      int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, int n_env, int env_offset, hipStream_t stream);
+hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, const EnvRand& R, const EnvRandState& S, float* state, const float* qfrc, const int* counts, float* prev,
+                      float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
+                      const uint8_t* mask, int observe, int n_env, int env_offset, hipStream_t stream);
 hipError_t launch_policy(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, int n_env, hipStream_t stream);
 hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream);
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream);

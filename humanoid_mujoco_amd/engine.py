@@ -45,7 +45,19 @@ class HbEnvConfig(ctypes.Structure):
                 ("w_ctrl_reg", ctypes.c_float), ("w_symmetry", ctypes.c_float), ("self_collision_penalty", ctypes.c_float),
                 ("terminal_reward", ctypes.c_float), ("upright_tol", ctypes.c_float), ("n_equal", ctypes.c_int),
                 ("n_opposite", ctypes.c_int), ("equal_pairs", (ctypes.c_int * 2) * 16), ("opposite_pairs", (ctypes.c_int * 2) * 16),
-                ("auto_reset", ctypes.c_int), ("reset_keyframe", ctypes.c_int), ("reset_perturb", ctypes.c_float)]
+                ("auto_reset", ctypes.c_int), ("reset_keyframe", ctypes.c_int), ("reset_perturb", ctypes.c_float),
+                ("reward_kind", ctypes.c_int), ("w_vvel", ctypes.c_float), ("min_z_grounded", ctypes.c_float),
+                ("reset_collision_mode", ctypes.c_int)]
+
+
+class HbEnvRandomization(ctypes.Structure):
+    """hb_env_randomization (include/hb.h): sensor/action noise, delay FIFOs and pushes of CPUEnv, per env on the device."""
+    _fields_ = [("factor", ctypes.c_float), ("seed", ctypes.c_uint), ("control_timestep", ctypes.c_float),
+                ("joint_angle_noise", ctypes.c_float), ("joint_velocity_noise", ctypes.c_float), ("gyro_noise", ctypes.c_float),
+                ("imu_noise", ctypes.c_float), ("action_noise", ctypes.c_float), ("min_delay", ctypes.c_float),
+                ("max_delay", ctypes.c_float), ("frozen_noise", ctypes.c_int), ("push_enabled", ctypes.c_int),
+                ("push_min_interval", ctypes.c_float), ("push_max_interval", ctypes.c_float), ("push_min_duration", ctypes.c_float),
+                ("push_max_duration", ctypes.c_float), ("push_min_force", ctypes.c_float), ("push_max_force", ctypes.c_float)]
 
 
 class HbError(RuntimeError):
@@ -99,6 +111,8 @@ def lib():
     L.hb_get_qacc.argtypes = [vp, vp]; L.hb_get_efc_force.argtypes = [vp, vp]; L.hb_get_contacts.argtypes = [vp, vp]
     L.hb_env_default_config.argtypes = [vp, ctypes.POINTER(HbEnvConfig)]
     L.hb_env_configure.argtypes = [vp, ctypes.POINTER(HbEnvConfig)]
+    L.hb_env_default_randomization.argtypes = [vp, ctypes.POINTER(HbEnvRandomization)]
+    L.hb_env_randomize.argtypes = [vp, ctypes.POINTER(HbEnvRandomization)]
     L.hb_env_reset.argtypes = [vp, vp]
     L.hb_env_step.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.hb_env_step_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp]
@@ -332,6 +346,15 @@ class Batch:
 
     def env_configure(self, cfg):
         _check(lib().hb_env_configure(self._h, ctypes.byref(cfg)), "hb_env_configure")
+
+    def env_default_randomization(self):
+        r = HbEnvRandomization()
+        _check(lib().hb_env_default_randomization(self.model._h, ctypes.byref(r)), "hb_env_default_randomization")
+        return r
+
+    def env_randomize(self, cfg):
+        """Install (cfg.factor > 0) or remove (None) the realism layer; call before env_reset."""
+        _check(lib().hb_env_randomize(self._h, ctypes.byref(cfg) if cfg is not None else None), "hb_env_randomize")
 
     def env_reset(self):
         o = np.zeros((self.n_env, self.model.nobs), dtype=np.float32)

@@ -12,7 +12,9 @@ from .engine import Batch, Model
 
 
 class VecEnv:
-    def __init__(self, model, n_envs, device=0, n_substeps=1, randomization_factor=1.0, **reward_overrides):
+    def __init__(self, model, n_envs, device=0, n_substeps=1, randomization_factor=1.0, realism=False, seed=0, **reward_overrides):
+        """realism=True adds CPUEnv's sensor/action noise, delay FIFOs and pushes (hb_env_randomization), scaled by
+        randomization_factor exactly like the reset perturbation."""
         self.model = model if isinstance(model, Model) else Model.load(model)
         self.batch = Batch(self.model, n_envs, device)
         self.num_envs = int(n_envs)
@@ -24,6 +26,12 @@ class VecEnv:
                 raise AttributeError("unknown env parameter %r" % k)
             setattr(self.cfg, k, v)
         self.batch.env_configure(self.cfg)
+        self.realism = None
+        if realism:
+            self.realism = self.batch.env_default_randomization()
+            self.realism.seed = int(seed)
+            self.realism.control_timestep = float(self.model.opt.timestep * self.n_substeps)
+            self._apply_realism()
         # gymnasium-style space descriptions (cpu_env.py:56-63: Box(-1,1,(nu,)), Box(-10,10,(nobs,)))
         self.action_shape = (self.model.nu,)
         self.observation_shape = (self.model.nobs,)
@@ -33,11 +41,17 @@ class VecEnv:
     def randomization_factor(self):
         return float(self.cfg.reset_perturb)
 
+    def _apply_realism(self):
+        self.realism.factor = float(self.cfg.reset_perturb)
+        self.batch.env_randomize(self.realism if self.realism.factor > 0 else None)
+
     def set_attr(self, name, value):
         if name != "randomization_factor":
             raise AttributeError(name)
         self.cfg.reset_perturb = float(np.clip(value, 0.0, 1.0))
         self.batch.env_configure(self.cfg)
+        if self.realism is not None:
+            self._apply_realism()
 
     def reset(self):
         return self.batch.env_reset()

@@ -193,10 +193,51 @@ typedef struct hb_env_config {
   int auto_reset;               /* 1: envs that terminate/truncate are reset inside hb_env_step (VecEnv semantics) */
   int reset_keyframe;           /* -1 = qpos0 */
   float reset_perturb;          /* 0..1 scale of the Halton joint/height perturbation (randomization_factor) */
+  /* 0: standupReward semantics (terminated = time limit, with terminal_reward; truncated = success),
+   * 1: controlInputReward semantics (reward_functions.py:116-245: terminated = fallen over or torso below
+   *    min_z_grounded, with terminal_reward; truncated = time limit) */
+  int reward_kind;
+  float w_vvel;                 /* VERTICAL_VELOCITY_PENALTY_WEIGHT (0 for standupReward) */
+  float min_z_grounded;         /* MIN_Z_BEFORE_GROUNDED */
+  /* reset-until-collision-free (cpu_env.py:411-414: reset steps once and starts over while anything collides):
+   * 0 off, 1 any contact (the reference's test), 2 self-collision only; hb_env_reset only, at most 8 draws */
+  int reset_collision_mode;
 } hb_env_config;
 
 int hb_env_default_config(const hb_model* m, hb_env_config* out);
 int hb_env_configure(hb_batch* b, const hb_env_config* cfg);
+
+/* Sensor / actuation realism of CPUEnv (cpu_env.py:135-186,465-545,612-674; values of simulation_parameters.py:5-48),
+ * all on the device and per env.  `factor` is the reference's randomization_factor and scales every magnitude.
+ *  - action noise, then an integer-step action delay FIFO (filled with zeros at reset);
+ *  - observation noise on joint angles / velocities, gyro, and the torso quaternion before the gravity vector is
+ *    taken, then one delay FIFO per channel group (joints, gyro, gravity; fillers 0 / 0 / (0,0,-1));
+ *  - delays are drawn per env and episode: round(U(min_delay, max_delay) * factor / control_timestep) steps;
+ *  - pushes: a horizontal force of U(min,max)*factor N on a random body for U(duration) s every U(interval) s,
+ *    through xfrc_applied (cpu_env.py:612-654).
+ * Random numbers are a counter-based hash of (seed, global env index, episode, step, stream, element), so a run
+ * is reproducible and independent of the batch split across GPUs.  frozen_noise = 1 reproduces a quirk of the
+ * reference (its PRNG key is never split, so every step of an episode adds the same noise vector). */
+typedef struct hb_env_randomization {
+  float factor;
+  unsigned int seed;
+  float control_timestep;      /* seconds per hb_env_step call; <= 0: the model's timestep */
+  float joint_angle_noise;     /* rad   (JOINT_ANGLE_NOISE_STDDEV, degrees in the reference) */
+  float joint_velocity_noise;  /* rad/s (JOINT_VELOCITY_NOISE_STDDEV) */
+  float gyro_noise;            /* rad/s (GYRO_NOISE_STDDEV) */
+  float imu_noise;             /* added to each torso quaternion component (IMU_NOISE_STDDEV in rad) */
+  float action_noise;          /* rad   (JOINT_ACTION_NOISE_STDDEV) */
+  float min_delay, max_delay;  /* s */
+  int frozen_noise;
+  int push_enabled;
+  float push_min_interval, push_max_interval, push_min_duration, push_max_duration, push_min_force, push_max_force;
+} hb_env_randomization;
+
+/* The reference's values (factor = 1, pushes on, fresh noise every step). */
+int hb_env_default_randomization(const hb_model* m, hb_env_randomization* out);
+/* Installs (cfg != NULL and cfg->factor > 0) or removes the above; takes effect at the next hb_env_reset
+ * (call it before resetting).  Delays beyond 63 control steps are refused. */
+int hb_env_randomize(hb_batch* b, const hb_env_randomization* cfg);
 /* CPUEnv.reset for every env: returns obs[n_env][nobs]. */
 int hb_env_reset(hb_batch* b, float* obs);
 /* CPUEnv.step: action[n_env][nu] -> ctrl (unscaled; the physics clamps to ctrlrange), n_substeps x mj_step,

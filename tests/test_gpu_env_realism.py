@@ -1,0 +1,191 @@
+"""the sensor / actuation realism of CPUEnv on the device (hb_env_randomization) —
+action noise and delay (cpu_env.py:656-674), observation noise and delay lines (:465-545), pushes (:612-654),
+controlInputReward semantics (reward_functions.py:116-245) and the reset-until-collision-free protocol
+(:374-416) — against the numpy restatement in tests/env_ref.py."""
+import numpy as np
+import pytest
+
+from env_ref import RealismRef, control_input_reward, obs_from_state
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+STATE_XFRC = 1 << 7  # mjSTATE_XFRC_APPLIED (engine.STATE_XFRC_APPLIED)
+
+
+def make_env(hbmod, m, n, gpu, **kw):
+    rkw = {k: kw.pop(k) for k in list(kw) if k in ("seed", "frozen_noise", "push_enabled", "min_delay", "max_delay", "factor",
+                                                    "joint_angle_noise", "joint_velocity_noise", "gyro_noise", "imu_noise", "action_noise")}
+    env = hbmod.VecEnv(m, n, gpu, auto_reset=0, max_time=0.0, target_z=10.0, **kw)
+    R = env.batch.env_default_randomization()
+    R.push_enabled = 0
+    for k, v in rkw.items():
+        setattr(R, k, v)
+    env.batch.env_randomize(R)
+    return env, R
+
+
+def test_noise_and_delay_lines_match_numpy(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n, T, off = 6, 40, 0
+    env, R = make_env(hbmod, m, n, gpu, seed=11, min_delay=0.0, max_delay=0.06)  # 0..12 steps of 5 ms
+    refs = [RealismRef(R, off + e, m.nu, 21, 17, 0.005) for e in range(n)]
+    assert len({tuple(r.delay) for r in refs}) > 1 and max(max(r.delay) for r in refs) >= 6
+    obs = env.reset()
+    b = env.batch
+    st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+    for e in range(n):
+        assert np.allclose(obs[e], refs[e].observe(st[e, 1:1 + m.nq], st[e, 1 + m.nq:1 + m.nq + m.nv]), atol=2e-5)
+    rng = np.random.default_rng(0)
+    for t in range(T):
+        act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
+        obs, rew, term, trunc, info = env.step(act)
+        st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+        for e in range(n):
+            ref = refs[e].observe(st[e, 1:1 + m.nq], st[e, 1 + m.nq:1 + m.nq + m.nv])
+            assert np.abs(obs[e] - ref).max() < 5e-5, (t, e, np.abs(obs[e] - ref).max())
+
+
+def test_action_delay_is_a_pure_shift(hbmod, humanoid_model, gpu):
+    """No noise, a fixed delay of d control steps: the physics sees zeros for d steps, then action[t - d] — the same
+    states, bit for bit, as a plain env fed the shifted tape."""
+    m = humanoid_model
+    n, T, d = 5, 30, 4
+    env, R = make_env(hbmod, m, n, gpu, min_delay=d * 0.005, max_delay=d * 0.005, action_noise=0.0)
+    plain = hbmod.VecEnv(m, n, gpu, auto_reset=0, max_time=0.0, target_z=10.0)
+    env.reset(); plain.reset()
+    rng = np.random.default_rng(1)
+    tape = rng.uniform(-1, 1, size=(T, n, m.nu)).astype(np.float32)
+    for t in range(T):
+        env.step(tape[t])
+        plain.step(tape[t - d] if t >= d else np.zeros((n, m.nu), np.float32))
+        assert np.array_equal(env.batch.get_state(hbmod.STATE_INTEGRATION), plain.batch.get_state(hbmod.STATE_INTEGRATION)), t
+
+
+def test_noise_statistics_and_frozen_mode(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n, T = 256, 12
+    zeros = np.zeros((n, m.nu), np.float32)
+    env, R = make_env(hbmod, m, n, gpu, seed=5, min_delay=0.0, max_delay=0.0, factor=0.5)
+    env.reset()
+    errs = []
+    for t in range(T):
+        obs, *_ = env.step(zeros)
+        true, *_ = env.batch.obs(want_reward=False)
+        errs.append(obs - true)
+    errs = np.array(errs)  # [T, n, 48]
+    assert abs(errs[..., :21].std() / (0.5 * R.joint_angle_noise) - 1) < 0.05 and abs(errs[..., :21].mean()) < 2e-3 * R.joint_angle_noise * 10
+    assert abs(errs[..., 21:42].std() / (0.5 * R.joint_velocity_noise) - 1) < 0.05
+    assert abs(errs[..., 42:45].std() / (0.5 * R.gyro_noise) - 1) < 0.1
+    assert 0.2 * 0.5 * R.imu_noise < errs[..., 45:48].std() < 3 * 0.5 * R.imu_noise  # quaternion noise through the rotation
+    assert np.abs(errs[0] - errs[1]).max() > 1e-4  # fresh noise every step
+    # frozen: the reference's unsplit key - the same draw at every step of an episode
+    env2, _ = make_env(hbmod, m, 16, gpu, seed=5, min_delay=0.0, max_delay=0.0, frozen_noise=1, imu_noise=0.0)
+    env2.reset()
+    z16 = np.zeros((16, m.nu), np.float32)
+    e1 = env2.step(z16)[0] - env2.batch.obs(want_reward=False)[0]
+    e2 = env2.step(z16)[0] - env2.batch.obs(want_reward=False)[0]
+    assert np.abs(e1[:, :45]).max() > 1e-3 and np.allclose(e1[:, :45], e2[:, :45], atol=2e-6)
+
+
+def test_push_schedule_matches_numpy(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n, T = 4, 900  # 4.5 s: at least one complete push per env
+    env, R = make_env(hbmod, m, n, gpu, seed=3, push_enabled=1, min_delay=0.0, max_delay=0.0)
+    env.reset()
+    refs = [RealismRef(R, e, m.nu, 21, 17, 0.005) for e in range(n)]
+    zeros = np.zeros((n, m.nu), np.float32)
+    seen = 0
+    for t in range(T):
+        time = env.batch.time.copy()
+        env.step(zeros)
+        xf = env.batch.get_state(STATE_XFRC).reshape(n, 17, 6)
+        for e in range(n):
+            want = refs[e].push_update(np.float32(time[e]))
+            f = np.zeros((17, 6))
+            if want is not None:
+                f[want[0], 0], f[want[0], 1] = want[1], want[2]
+                seen += 1
+                assert 5.0 - 1e-4 <= np.hypot(want[1], want[2]) <= 15.0 + 1e-4
+            assert np.allclose(xf[e], f, atol=1e-4), (t, e)
+    assert seen > 4 * 10  # every env was pushed for at least 10 steps (0.05 s)
+
+
+def test_control_input_reward_semantics(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n = 10
+    env = hbmod.VecEnv(m, n, gpu, auto_reset=0, max_time=0.0575, reward_kind=1, w_vvel=5.0, w_hvel=15.0)
+    cfg = env.cfg
+    env.reset()
+    b = env.batch
+    o = Oracle()
+    rng = np.random.default_rng(4)
+    prev = np.zeros((n, m.nu))
+    fell = False
+    for t in range(14):
+        act = rng.uniform(-1.5, 1.5, size=(n, m.nu)).astype(np.float32)
+        st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+        obs, rew, term, trunc, info = env.step(act)
+        st1 = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+        for e in range(n):
+            o.reset()
+            o.qpos[:] = st[e, 1:1 + m.nq]; o.qvel[:] = st[e, 1 + m.nq:1 + m.nq + m.nv]; o.qacc_warmstart[:] = st[e, 1 + m.nq + m.nv:]
+            o.ctrl[:] = act[e]
+            o.forward()
+            torques = (o.qfrc_smooth + o.qfrc_constraint)[6:]
+            selfcol = any(c["geom1"] != 0 for c in o.contacts())
+            r_ref, te, tr = control_input_reward(cfg, st1[e, 0], st1[e, 1:1 + m.nq], st1[e, 1 + m.nq:1 + m.nq + m.nv], torques, prev[e], act[e].astype(np.float64), selfcol)
+            assert abs(rew[e] - r_ref) <= 2e-3 * max(1.0, abs(r_ref)), (t, e, rew[e], r_ref)
+            assert bool(term[e]) == te and bool(trunc[e]) == tr
+        assert trunc.all() == (t >= 11) and trunc.any() == (t >= 11)  # the time limit (12 steps of 5 ms) is a truncation here
+        prev = act.astype(np.float64)
+    # a toppled torso is terminal with the terminal reward
+    q = b.get_state(hbmod.STATE_QPOS, dtype=np.float64)
+    q[:, 3:7] = np.array([0.7071, 0.7071, 0.0, 0.0])  # lying on the side
+    b.set_state(hbmod.STATE_QPOS, q.astype(np.float32))
+    obs, rew, term, trunc, info = env.step(np.zeros((n, m.nu), np.float32))
+    assert term.all() and np.allclose(rew, cfg.terminal_reward)
+
+
+def test_reset_until_collision_free(hbmod, humanoid_model, gpu):
+    """reset_collision_mode = 1 (the reference's any-contact test): every env takes the settle step; envs whose step
+    ends in contact are re-drawn (new episode number), at most 8 times, without disturbing the others."""
+    m = humanoid_model
+    n = 64
+    env = hbmod.VecEnv(m, n, gpu, auto_reset=0, max_time=0.0, target_z=10.0, reset_collision_mode=1)
+    env.reset()
+    b = env.batch
+    ncon, _, _ = b.counts()
+    assert np.allclose(b.time, 0.005)        # exactly one settle step each, whatever the number of draws
+    # the standing humanoid's feet touch the floor unless the height perturbation lifted it: both kinds occur,
+    # and an env only ever stops collision-free or at the draw limit
+    assert (ncon == 0).any()
+    plain = hbmod.VecEnv(m, n, gpu, auto_reset=0, max_time=0.0, target_z=10.0)
+    plain.reset()
+    assert not np.allclose(plain.batch.qpos, b.qpos)  # re-drawn envs do not sit at their first draw
+    # mode 2: only self-collisions count - the unperturbed reset pose has none, so one draw suffices and the
+    # state is the reset pose advanced by one zero-control step
+    env2 = hbmod.VecEnv(m, n, gpu, randomization_factor=0.0, auto_reset=0, max_time=0.0, target_z=10.0, reset_collision_mode=2)
+    env2.reset()
+    plain0 = hbmod.VecEnv(m, n, gpu, randomization_factor=0.0, auto_reset=0, max_time=0.0, target_z=10.0)
+    plain0.reset()
+    plain0.step(np.zeros((n, m.nu), np.float32))
+    assert np.array_equal(env2.batch.get_state(hbmod.STATE_INTEGRATION), plain0.batch.get_state(hbmod.STATE_INTEGRATION))
+
+
+def test_randomize_argument_checks_and_off_switch(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    b = hbmod.Batch(m, 8, gpu)
+    R = b.env_default_randomization()
+    assert abs(R.joint_angle_noise - np.deg2rad(2)) < 1e-7 and R.push_enabled == 1 and R.min_delay == pytest.approx(0.01)
+    R.max_delay = 1.0  # 200 steps of 5 ms: beyond the 63-slot rings
+    with pytest.raises(hbmod.HbError):
+        b.env_randomize(R)
+    R.max_delay = 0.05
+    b.env_randomize(R)
+    b.env_reset()
+    o1 = b.env_step(np.zeros((8, m.nu), np.float32))[0]
+    b.env_randomize(None)  # off again: observations are the true ones
+    b.env_reset()
+    o2 = b.env_step(np.zeros((8, m.nu), np.float32))[0]
+    true, *_ = b.obs(want_reward=False)
+    assert np.allclose(o2, true, atol=1e-6) and not np.allclose(o1, o2)

@@ -260,6 +260,21 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (double v : si) pair_solimp.push_back(v);
     pair_margin.push_back(mg); pair_gap.push_back(gp);
   }
+  // domain randomisation scales the sliding friction of the floor (first plane geom): per pair (floor's own
+  // coefficient if it takes part, else 0; the other geom's coefficient / the mixed one)
+  std::vector<double> pair_fricab;
+  {
+    int floor_geom = -1;
+    for (int g = 0; g < m.ngeom && floor_geom < 0; g++) if (m.geom_type[g] == GEOM_PLANE) floor_geom = g;
+    for (int p = 0; p < m.npair; p++) {
+      const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+      if (g1 == floor_geom || g2 == floor_geom) {
+        const int other = g1 == floor_geom ? g2 : g1;
+        pair_fricab.push_back(m.geom_friction[3 * floor_geom]); pair_fricab.push_back(m.geom_friction[3 * other]);
+      } else { pair_fricab.push_back(0.0); pair_fricab.push_back(pair_fr[3 * p]); }
+    }
+    if (pair_fricab.empty()) { pair_fricab.push_back(0.0); pair_fricab.push_back(0.0); }
+  }
   // limit candidates
   std::vector<int> lim_kind, lim_id, lim_side;
   std::vector<double> lim_range, lim_margin, lim_solref, lim_solimp, lim_invw;
@@ -349,6 +364,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
   TI(pair_geom1, m.pair_geom1); TI(pair_geom2, m.pair_geom2); TI(pair_dim, pair_dim);
+  TF(pair_fricab, pair_fricab);
   TF(pair_friction, pair_fr); TF(pair_solref, pair_solref); TF(pair_solimp, pair_solimp); TF(pair_margin, pair_margin); TF(pair_gap, pair_gap);
   TI(lim_kind, lim_kind); TI(lim_id, lim_id); TI(lim_side, lim_side);
   TF(lim_range, lim_range); TF(lim_margin, lim_margin); TF(lim_solref, lim_solref); TF(lim_solimp, lim_solimp); TF(lim_invweight, lim_invw);
@@ -410,6 +426,9 @@ struct hb_batch {
   EnvRand env_rand = {};
   EnvRandState rs = {};     // device arrays; all null while off
   bool rand_on = false;
+  DomainRand dom_rand = {};    // hb_env_domain_randomize
+  float* d_dr = nullptr;       // [n_env][dr_stride] per-env model parameters, null while off
+  int dr_stride = 0;
   uint8_t* d_rmask = nullptr;  // hb_env_reset's pending-envs mask
   int* d_pending = nullptr;
   // policy MLP (hb_policy_*)
@@ -472,6 +491,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
   P.integrate = 1;
   if (b->schedule && b->order_mode) P.order = b->d_order;
   P.blk0 = 0; P.nblk = b->n_env;
+  P.dr = b->d_dr; P.dr_stride = b->dr_stride;
   P.stamps = b->d_stamps;
   return P;
 }
@@ -741,6 +761,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->ev0) HB_IGN(hipEventDestroy(b->ev0));
   if (b->ev1) HB_IGN(hipEventDestroy(b->ev1));
   envrand_free_fwd(b);
+  if (b->d_dr) HB_IGN(hipFree(b->d_dr));
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
   void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
@@ -911,7 +932,7 @@ static int env_eval(hb_batch* b, bool allow_reset, bool observe, const uint8_t* 
   EnvRandState S = b->rs;
   if (!b->rand_on) memset(&S, 0, sizeof S);
   HB_HIP(launch_env(b->D.dm, cfg, b->env_rand, S, b->d_state, b->d_qfrc, b->d_counts, b->d_prev, b->d_latest, src, b->d_episode, b->d_status, d_obs, d_reward,
-                    d_term, d_trunc, mask, observe ? 1 : 0, b->n_env, b->env_offset, main_stream(b)));
+                    d_term, d_trunc, mask, observe ? 1 : 0, b->dom_rand, b->d_dr, b->dr_stride, b->n_env, b->env_offset, main_stream(b)));
   return HB_OK;
 }
 
@@ -1038,6 +1059,55 @@ int hb_env_randomize(hb_batch* b, const hb_env_randomization* cfg) {
   return HB_OK;
 }
 
+int hb_env_default_domain_randomization(const hb_model* h, hb_domain_randomization* d) {
+  if (!h || !d) return HB_EINVAL;
+  memset(d, 0, sizeof *d);
+  d->factor = 1.f; d->seed = 0;
+  d->friction_min_mult = 0.5f; d->friction_max_mult = 1.f;   // FLOOR_FRICTION_*_MULTIPLIER (simulation_parameters.py:5-7)
+  d->max_mass_change = 0.05f; d->max_external_mass = 0.2f;   // MAX_MASS_CHANGE_PER_LIMB, MAX_EXTERNAL_MASS_ADDED
+  d->armature_max_change = 0.0005f; d->stiffness_max_change = 0.f; d->margin_max_change = 0.05f; d->range_max_change = 0.1f;  // JOINT_*_MAX_CHANGE
+  d->kp_nominal = 0.f; d->kp_max_change = 0.5f;              // JOINT_P_GAIN(_MAX_CHANGE); nominal 0: keep the model's gains
+  d->force_limit_max_change = 0.05f;                         // JOINT_FORCE_LIMIT_MAX_CHANGE
+  return HB_OK;
+}
+
+int hb_env_domain_randomize(hb_batch* b, const hb_domain_randomization* cfg) {
+  if (!b) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  if (!cfg || !(cfg->factor > 0.f)) {
+    if (b->d_dr) HB_IGN(hipFree(b->d_dr));
+    b->d_dr = nullptr; b->dr_stride = 0;
+    return HB_OK;
+  }
+  if (!(cfg->friction_max_mult >= cfg->friction_min_mult) || cfg->friction_min_mult < 0.f || cfg->max_mass_change < 0.f || cfg->max_external_mass < 0.f ||
+      cfg->armature_max_change < 0.f || cfg->stiffness_max_change < 0.f || cfg->margin_max_change < 0.f || cfg->range_max_change < 0.f || cfg->kp_max_change < 0.f ||
+      cfg->force_limit_max_change < 0.f) return HB_EINVAL;
+  static_assert(sizeof(hb_domain_randomization) == sizeof(DomainRand), "hb_domain_randomization and DomainRand must have the same layout");
+  const DevModel& dm = b->D.dm;
+  const DomainLayout L = domain_layout(dm.nbody, dm.nv, dm.nlimcand, dm.nu);
+  if (!b->d_dr && hipMalloc((void**)&b->d_dr, (size_t)b->n_env * L.stride * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+  b->dr_stride = L.stride;
+  memcpy(&b->dom_rand, cfg, sizeof *cfg);
+  // valid parameters at once (the draw of episode 0); hb_env_reset draws again for the episode numbers it assigns
+  HB_HIP(launch_domain_rand(dm, b->dom_rand, b->d_dr, b->dr_stride, b->d_episode, nullptr, b->n_env, b->env_offset, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
+}
+
+int hb_env_get_domain_params(hb_batch* b, float* out) {
+  if (!b) return HB_EINVAL;
+  if (!b->d_dr) return 0;
+  if (out) {
+    HB_HIP(hipSetDevice(b->device));
+    HB_HIP(hipStreamSynchronize(main_stream(b)));
+    HB_HIP(hipMemcpy(out, b->d_dr, (size_t)b->n_env * b->dr_stride * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return b->dr_stride;
+}
+
 // CPUEnv._apply_action (+ pushes) -> n_substeps x mj_step -> reward / termination / observation, for every env or those of `mask`
 static int env_step_impl(hb_batch* b, const float* action_dev, int n_substeps, const uint8_t* mask, bool allow_reset, float* obs_dev, float* reward_dev,
                          uint8_t* terminated_dev, uint8_t* truncated_dev) {
@@ -1070,6 +1140,7 @@ int hb_env_reset(hb_batch* b, float* obs) {
     rc = reset_impl(b, nullptr, c.reset_keyframe, c.reset_perturb, b->env_offset);
     if (rc != HB_OK) return rc;
     if (b->rand_on) HB_HIP(launch_envrand_reset(b->D.dm, b->env_rand, b->rs, b->d_episode, nullptr, b->n_env, b->env_offset, main_stream(b)));
+    if (b->d_dr) HB_HIP(launch_domain_rand(b->D.dm, b->dom_rand, b->d_dr, b->dr_stride, b->d_episode, nullptr, b->n_env, b->env_offset, main_stream(b)));
   } else {
     // The reference's protocol (cpu_env.py:374-416): randomise, take one step with the current (zero) controls, and
     // start over with a new draw while that step ends in a collision or in a terminal state.  Pending envs carry
@@ -1082,6 +1153,7 @@ int hb_env_reset(hb_batch* b, float* obs) {
     for (int attempt = 0; attempt < 8; attempt++) {
       HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, b->d_rmask, src, b->d_episode, b->n_env, c.reset_perturb, b->env_offset, main_stream(b)));
       if (b->rand_on) HB_HIP(launch_envrand_reset(b->D.dm, b->env_rand, b->rs, b->d_episode, b->d_rmask, b->n_env, b->env_offset, main_stream(b)));
+      if (b->d_dr) HB_HIP(launch_domain_rand(b->D.dm, b->dom_rand, b->d_dr, b->dr_stride, b->d_episode, b->d_rmask, b->n_env, b->env_offset, main_stream(b)));
       rc = env_step_impl(b, nullptr, substeps, b->d_rmask, false, b->d_obs, b->d_reward, b->d_term, b->d_trunc);
       if (rc != HB_OK) return rc;
       HB_HIP(hipMemsetAsync(b->d_pending, 0, sizeof(int), main_stream(b)));

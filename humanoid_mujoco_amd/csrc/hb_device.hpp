@@ -77,6 +77,7 @@ struct DevModel {
   const float HB_CONST *hfield_size, *hfield_data;
   // collision candidates with pre-mixed contact parameters
   const int HB_CONST *pair_geom1, *pair_geom2, *pair_dim;
+  const float HB_CONST* pair_fricab;  // per pair: (sliding friction of the floor geom if it is in the pair, else 0; the other geom's / the mixed one)
   const float HB_CONST *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
   // limit candidates: 2 per limited joint/tendon in constraint order (lower, upper)
   const int HB_CONST *lim_kind, *lim_id, *lim_side;  // kind 0 = joint, 1 = tendon
@@ -128,6 +129,25 @@ struct EnvRand {
   int frozen_noise, push_enabled;
   float push_min_interval, push_max_interval, push_min_duration, push_max_duration, push_min_force, push_max_force;
 };
+// hb_domain_randomization (include/hb.h), same layout
+struct DomainRand {
+  float factor;
+  unsigned seed;
+  float friction_min_mult, friction_max_mult, max_mass_change, max_external_mass;
+  float armature_max_change, stiffness_max_change, margin_max_change, range_max_change;
+  float kp_nominal, kp_max_change, force_limit_max_change;
+};
+// per-env model parameters [n_env][stride]: mass[nbody] | armature[nv] | stiffness[nv] | lim_margin[nlimcand] |
+// lim_range[nlimcand] | act_gain[nu] | act_bias1[nu] | act_forcerange[2 nu] | floor friction scale
+struct DomainLayout {
+  int o_mass, o_arm, o_stiff, o_lmargin, o_lrange, o_gain, o_bias1, o_frc, o_fric, stride;
+};
+__host__ __device__ inline DomainLayout domain_layout(int nbody, int nv, int nlimcand, int nu) {
+  DomainLayout L;
+  L.o_mass = 0; L.o_arm = nbody; L.o_stiff = L.o_arm + nv; L.o_lmargin = L.o_stiff + nv; L.o_lrange = L.o_lmargin + nlimcand;
+  L.o_gain = L.o_lrange + nlimcand; L.o_bias1 = L.o_gain + nu; L.o_frc = L.o_bias1 + nu; L.o_fric = L.o_frc + 2 * nu; L.stride = L.o_fric + 1;
+  return L;
+}
 constexpr int kDelaySlots = 64;  // ring size of the delay FIFOs (delays <= 63 control steps)
 // per-env state of the realism layer, all [n_env]-major device arrays (null when hb_env_randomize is off)
 struct EnvRandState {
@@ -170,6 +190,8 @@ struct BatchPtrs {
   // heavy-first block scheduling (nullable): slot s takes env = order[s], a permutation sorted by
   // the cost of each env's previous step (counts[4*e+3]) so the most expensive envs are dispatched first
   const int* order;    // [n_env]
+  const float* dr;     // nullable [n_env][dr_stride]: per-env model parameters (DomainLayout)
+  int dr_stride;
   const unsigned char* env_mask;  // nullable [n_env]: envs with a zero byte are skipped by this launch
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
 };

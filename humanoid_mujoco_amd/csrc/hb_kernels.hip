@@ -494,6 +494,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   const int slot = P.blk0 + (int)blockIdx.x;
   const int env = P.order ? P.order[slot] : slot;
   if (P.env_mask && !P.env_mask[env]) return;  // masked stepping (hb_env_reset's settle step)
+  // per-env model parameters (domain randomisation), nullable; offsets per DomainLayout
+  const float* dr = P.dr ? P.dr + (size_t)env * P.dr_stride : nullptr;
+  const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu);
   const int nv = M.nv, nq = M.nq, nb = M.nbody, cs = M.cstride;
 
   float* s_qpos = lds + M.o_qpos;
@@ -611,6 +614,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     const int myb = __float_as_int(q0.x), myp = __float_as_int(q0.y), myjn = __float_as_int(q0.z), myja = __float_as_int(q0.w);
     const int mylevel = bl ? __float_as_int(q1.x) : -1, mycn = __float_as_int(q1.w);
+    const float mymass = (dr && bl) ? dr[DL.o_mass + myb] : q1.z;
     const int mych[8] = {__float_as_int(ch0.x), __float_as_int(ch0.y), __float_as_int(ch0.z), __float_as_int(ch0.w),
                          __float_as_int(ch1.x), __float_as_int(ch1.y), __float_as_int(ch1.z), __float_as_int(ch1.w)};
     // The pose of a body relative to its parent (body frame, then its joints in order) does not depend on
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     // ---------------------------------------------------------------- mj_comPos
     for (int t = 0; t < M.ntree; t++) {
       V3 acc = {0.f, 0.f, 0.f};
-      if (bl && __float_as_int(q1.y) == t) acc = ld3(s_xipos + 3 * myb) * q1.z;
+      if (bl && __float_as_int(q1.y) == t) acc = ld3(s_xipos + 3 * myb) * mymass;
       float im = M.tree_invmass[t];
       float sx = wave_sum(acc.x) * im, sy = wave_sum(acc.y) * im, sz = wave_sum(acc.z) * im;
       if (lane == 0) st3(s_scom + 3 * t, {sx, sy, sz});
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       V3 dif = ld3(s_xipos + 3 * b) - com;
       float mat[9];
       q2mat(mat, qmul(ldq(s_xquat + 4 * b), {iq.x, iq.y, iq.z, iq.w}));
-      const float in0 = in4.x, in1 = in4.y, in2 = in4.z, mass = q1.z;
+      const float in0 = in4.x, in1 = in4.y, in2 = in4.z, mass = mymass;
       float t[9];
       for (int r = 0; r < 3; r++) { t[3 * r] = mat[3 * r] * in0; t[3 * r + 1] = mat[3 * r + 1] * in1; t[3 * r + 2] = mat[3 * r + 2] * in2; }
       float* res = s_cinert + 10 * b;
@@ -852,7 +856,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       mul_inert_vec(buf, in, cd);
       float sacc = 0.f;
       for (int t = 0; t < 6; t++) sacc += s_cdof[6 * j + t] * buf[t];
-      sacc += ad.x;
+      sacc += (dr && i == j) ? dr[DL.o_arm + i] : ad.x;
       // H = M + h diag(damping): matrix of the implicit-damping Euler solve (mj_Euler), factorised alongside M
       s_qLD[e] = {sacc, sacc + (eulerdamp ? M.timestep * ad.y : 0.f)};
     }
@@ -874,7 +878,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       for (int t = 0; t < 6; t++) bias += s_cdof[6 * d + t] * s_cfrc[6 * b + t];
       float passive = 0.f;
       if (!(M.disableflags & (1 << 5))) {
-        if (__float_as_int(dA.z) >= 2) passive -= dB.w * (s_qpos[__float_as_int(dC.x)] - dC.y);
+        if (__float_as_int(dA.z) >= 2) passive -= (dr ? dr[DL.o_stiff + d] : dB.w) * (s_qpos[__float_as_int(dC.x)] - dC.y);
         passive -= dB.z * s_qvel[d];
       }
       s_smooth[d] = passive - bias;
@@ -885,8 +889,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         float ctrl = s_ctrl[a];
         if (M.act_ctrllimited[a] && !(M.disableflags & (1 << 7))) ctrl = clampf(ctrl, M.act_ctrlrange[2 * a], M.act_ctrlrange[2 * a + 1]);
         float gear = M.act_gear[a];
-        float force = M.act_gain[a] * ctrl + M.act_bias[3 * a] + M.act_bias[3 * a + 1] * gear * s_qpos[M.act_qposadr[a]] + M.act_bias[3 * a + 2] * gear * s_qvel[M.act_dofadr[a]];
-        if (M.act_forcelimited[a]) force = clampf(force, M.act_forcerange[2 * a], M.act_forcerange[2 * a + 1]);
+        const float gain = dr ? dr[DL.o_gain + a] : M.act_gain[a], bias1 = dr ? dr[DL.o_bias1 + a] : M.act_bias[3 * a + 1];
+        float force = gain * ctrl + M.act_bias[3 * a] + bias1 * gear * s_qpos[M.act_qposadr[a]] + M.act_bias[3 * a + 2] * gear * s_qvel[M.act_dofadr[a]];
+        if (M.act_forcelimited[a]) force = clampf(force, dr ? dr[DL.o_frc + 2 * a] : M.act_forcerange[2 * a], dr ? dr[DL.o_frc + 2 * a + 1] : M.act_forcerange[2 * a + 1]);
         atomicAdd(&s_smooth[M.act_dofadr[a]], gear * force);
       }
     }
@@ -1017,9 +1022,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         int side = 0, kind = 0, id = 0;
         if (c < M.nlimcand) {
           kind = M.lim_kind[c]; id = M.lim_id[c]; side = M.lim_side[c];
-          margin = M.lim_margin[c];
+          margin = dr ? dr[DL.o_lmargin + c] : M.lim_margin[c];
           float value = kind == 0 ? s_qpos[M.jnt_qposadr[id]] : s_tenlen[id];
-          dist = (float)side * (M.lim_range[c] - value);
+          dist = (float)side * ((dr ? dr[DL.o_lrange + c] : M.lim_range[c]) - value);
           active = dist < margin;
         }
         unsigned long long bal = __ballot(active);
@@ -1059,7 +1064,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         float* c = s_con + lane * kConStride;
         c[C_ROW] = __int_as_float((incl && fits) ? base : -1);
         c[C_DIM] = __int_as_float(M.pair_dim[pairid] == 1 ? 1 : 3);
-        c[C_FRIC] = fmaxf(1e-5f, M.pair_friction[3 * pairid]);
+        c[C_FRIC] = fmaxf(1e-5f, dr ? fmaxf(M.pair_fricab[2 * pairid] * dr[DL.o_fric], M.pair_fricab[2 * pairid + 1]) : M.pair_friction[3 * pairid]);
       }
       if (__ballot(lane < ncon && incl && !fits)) status |= (1 << 2);
       // contacts are materialised in order; once one does not fit, none of the later ones does
@@ -1502,6 +1507,53 @@ __global__ void hb_envrand_reset_kernel(const DevModel M, const EnvRand R, const
   envrand_begin_episode(M, R, S, e, env_offset + e, episode[e]);
 }
 
+// Per-env model parameters of one episode (cpu_env.py:188-264): see hb_domain_randomization in include/hb.h.
+enum { RS_DR_MASS = 16, RS_DR_EXTRA, RS_DR_FRIC, RS_DR_ARM, RS_DR_STIFF, RS_DR_MARGIN, RS_DR_RANGE, RS_DR_KP, RS_DR_FRC };
+__device__ __forceinline__ void domain_draw(const DevModel& M, const DomainRand& D, float* d, int env_global, int ep) {
+  const DomainLayout L = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu);
+  const float rf = D.factor;
+  auto U = [&](int stream, int idx) { return rng_uniform(D.seed, env_global, ep, 0, stream, idx); };
+  d[L.o_mass] = 0.f;
+  for (int sl = 1; sl < M.nbody; sl++) {  // brec is level-ordered: slot -> body id, mass
+    const float4 q0 = M.brec[(size_t)sl * kBrecQuads], q1 = M.brec[(size_t)sl * kBrecQuads + 1];
+    const int b = __float_as_int(q0.x);
+    d[L.o_mass + b] = fmaxf(1e-5f, q1.z + (2.f * U(RS_DR_MASS, b) - 1.f) * D.max_mass_change * rf);
+  }
+  if (M.nbody > 1) {
+    const int b = 1 + min(M.nbody - 2, (int)(U(RS_DR_EXTRA, 0) * (float)(M.nbody - 1)));
+    d[L.o_mass + b] += U(RS_DR_EXTRA, 1) * D.max_external_mass * rf;
+  }
+  for (int i = 0; i < M.nv; i++) {
+    const float4 dA = M.drec[3 * i], dB = M.drec[3 * i + 1];
+    const bool scalar = __float_as_int(dA.z) >= 2;  // hinge / slide
+    d[L.o_arm + i] = dB.y + (scalar ? U(RS_DR_ARM, i) * D.armature_max_change * rf : 0.f);
+    d[L.o_stiff + i] = dB.w + (scalar ? U(RS_DR_STIFF, i) * D.stiffness_max_change * rf : 0.f);
+  }
+  for (int c = 0; c < M.nlimcand; c++) {
+    const bool joint = M.lim_kind[c] == 0;
+    const int id = M.lim_id[c];
+    d[L.o_lmargin + c] = M.lim_margin[c] + (joint ? U(RS_DR_MARGIN, id) * D.margin_max_change * rf : 0.f);  // one margin per joint
+    d[L.o_lrange + c] = M.lim_range[c] + (joint ? (2.f * U(RS_DR_RANGE, c) - 1.f) * D.range_max_change * rf : 0.f);
+  }
+  for (int a = 0; a < M.nu; a++) {
+    float gain = M.act_gain[a], bias1 = M.act_bias[3 * a + 1];
+    if (D.kp_nominal > 0.f) {
+      gain = D.kp_nominal + (2.f * U(RS_DR_KP, a) - 1.f) * D.kp_max_change * rf;
+      if (bias1 != 0.f) bias1 = -gain;
+    }
+    d[L.o_gain + a] = gain;
+    d[L.o_bias1 + a] = bias1;
+    d[L.o_frc + 2 * a] = M.act_forcerange[2 * a] + (2.f * U(RS_DR_FRC, 2 * a) - 1.f) * D.force_limit_max_change * rf;
+    d[L.o_frc + 2 * a + 1] = M.act_forcerange[2 * a + 1] + (2.f * U(RS_DR_FRC, 2 * a + 1) - 1.f) * D.force_limit_max_change * rf;
+  }
+  d[L.o_fric] = (1.f - rf) + (D.friction_min_mult + U(RS_DR_FRIC, 0) * (D.friction_max_mult - D.friction_min_mult)) * rf;
+}
+__global__ void hb_domain_rand_kernel(const DevModel M, const DomainRand D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env || (mask && !mask[e])) return;
+  domain_draw(M, D, dr + (size_t)e * stride, env_offset + e, episode[e]);
+}
+
 // value through a delay ring: push x as item k, return item k - d (filler before the ring has d items)
 __device__ __forceinline__ float ring_delay(float* ring, int stride, int k, int d, float x, float filler) {
   ring[(size_t)(k % kDelaySlots) * stride] = x;
@@ -1639,7 +1691,7 @@ __device__ __forceinline__ float scaled_exp(float x) { return expf(-x / 0.5f); }
 // standupReward (reward_functions.py:247-374) + observation + termination + auto-reset, one thread per env
 __global__ void hb_env_kernel(const DevModel M, const EnvConfig cfg, const EnvRand R, const EnvRandState S, float* state, const float* qfrc, const int* counts,
                               float* prev, float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated,
-                              uint8_t* truncated, const uint8_t* mask, int observe, int n_env, int env_offset) {
+                              uint8_t* truncated, const uint8_t* mask, int observe, const DomainRand D, float* dr, int dr_stride, int n_env, int env_offset) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_env || (mask && !mask[e])) return;
   float* s = state + (size_t)e * M.nstate;
@@ -1714,6 +1766,7 @@ __global__ void hb_env_kernel(const DevModel M, const EnvConfig cfg, const EnvRa
     for (int i = 0; i < M.nu; i++) { prev[(size_t)e * M.nu + i] = 0.f; latest[(size_t)e * M.nu + i] = 0.f; }
     status[e] = 0;
     if (rand_on) envrand_begin_episode(M, R, S, e, env_offset + e, ep);
+    if (dr) domain_draw(M, D, dr + (size_t)e * dr_stride, env_offset + e, ep);
     compute_obs(M, s, o, g, &z);
   }
   if (rand_on && observe) envrand_observe(M, R, S, e, env_offset + e, episode[e], s, o);
@@ -1941,10 +1994,16 @@ hipError_t launch_action(const float* action, float* prev, float* latest, float*
 }
 hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, const EnvRand& R, const EnvRandState& S, float* state, const float* qfrc, const int* counts, float* prev,
                       float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
-                      const uint8_t* mask, int observe, int n_env, int env_offset, hipStream_t stream) {
+                      const uint8_t* mask, int observe, const DomainRand& D, float* dr, int dr_stride, int n_env, int env_offset, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_env_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, cfg, R, S, state, qfrc, counts, prev, latest, qpos_src, episode, status, obs,
-                     reward, terminated, truncated, mask, observe, n_env, env_offset);
+                     reward, terminated, truncated, mask, observe, D, dr, dr_stride, n_env, env_offset);
+  return hipGetLastError();
+}
+hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset,
+                              hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(hb_domain_rand_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, D, dr, stride, episode, mask, n_env, env_offset);
   return hipGetLastError();
 }
 hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream) {

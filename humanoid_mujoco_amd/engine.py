@@ -60,6 +60,14 @@ class HbEnvRandomization(ctypes.Structure):
                 ("push_max_duration", ctypes.c_float), ("push_min_force", ctypes.c_float), ("push_max_force", ctypes.c_float)]
 
 
+class HbDomainRandomization(ctypes.Structure):
+    """hb_domain_randomization (include/hb.h): per-env model parameters drawn at reset."""
+    _fields_ = [("factor", ctypes.c_float), ("seed", ctypes.c_uint), ("friction_min_mult", ctypes.c_float), ("friction_max_mult", ctypes.c_float),
+                ("max_mass_change", ctypes.c_float), ("max_external_mass", ctypes.c_float), ("armature_max_change", ctypes.c_float),
+                ("stiffness_max_change", ctypes.c_float), ("margin_max_change", ctypes.c_float), ("range_max_change", ctypes.c_float),
+                ("kp_nominal", ctypes.c_float), ("kp_max_change", ctypes.c_float), ("force_limit_max_change", ctypes.c_float)]
+
+
 class HbError(RuntimeError):
     pass
 
@@ -113,6 +121,9 @@ def lib():
     L.hb_env_configure.argtypes = [vp, ctypes.POINTER(HbEnvConfig)]
     L.hb_env_default_randomization.argtypes = [vp, ctypes.POINTER(HbEnvRandomization)]
     L.hb_env_randomize.argtypes = [vp, ctypes.POINTER(HbEnvRandomization)]
+    L.hb_env_default_domain_randomization.argtypes = [vp, ctypes.POINTER(HbDomainRandomization)]
+    L.hb_env_domain_randomize.argtypes = [vp, ctypes.POINTER(HbDomainRandomization)]
+    L.hb_env_get_domain_params.argtypes = [vp, vp]
     L.hb_env_reset.argtypes = [vp, vp]
     L.hb_env_step.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.hb_env_step_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp]
@@ -355,6 +366,26 @@ class Batch:
     def env_randomize(self, cfg):
         """Install (cfg.factor > 0) or remove (None) the realism layer; call before env_reset."""
         _check(lib().hb_env_randomize(self._h, ctypes.byref(cfg) if cfg is not None else None), "hb_env_randomize")
+
+    def env_default_domain_randomization(self):
+        d = HbDomainRandomization()
+        _check(lib().hb_env_default_domain_randomization(self.model._h, ctypes.byref(d)), "hb_env_default_domain_randomization")
+        return d
+
+    def env_domain_randomize(self, cfg):
+        """Install (cfg.factor > 0) or remove (None) per-env model parameters; call before env_reset."""
+        _check(lib().hb_env_domain_randomize(self._h, ctypes.byref(cfg) if cfg is not None else None), "hb_env_domain_randomize")
+
+    def env_domain_params(self):
+        """[n_env, stride] float32 (layout in include/hb.h), or None when domain randomisation is off."""
+        stride = lib().hb_env_get_domain_params(self._h, None)
+        if stride < 0:
+            _check(stride, "hb_env_get_domain_params")
+        if stride == 0:
+            return None
+        out = np.zeros((self.n_env, stride), dtype=np.float32)
+        _check(min(0, lib().hb_env_get_domain_params(self._h, _ptr(out))), "hb_env_get_domain_params")
+        return out
 
     def env_reset(self):
         o = np.zeros((self.n_env, self.model.nobs), dtype=np.float32)

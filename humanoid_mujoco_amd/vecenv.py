@@ -12,9 +12,10 @@ from .engine import Batch, Model
 
 
 class VecEnv:
-    def __init__(self, model, n_envs, device=0, n_substeps=1, randomization_factor=1.0, realism=False, seed=0, **reward_overrides):
+    def __init__(self, model, n_envs, device=0, n_substeps=1, randomization_factor=1.0, realism=False, domain_randomization=False, seed=0, **reward_overrides):
         """realism=True adds CPUEnv's sensor/action noise, delay FIFOs and pushes (hb_env_randomization), scaled by
-        randomization_factor exactly like the reset perturbation."""
+        randomization_factor exactly like the reset perturbation; domain_randomization=True draws per-env masses, floor
+        friction, joint and actuator parameters at every reset (hb_domain_randomization)."""
         self.model = model if isinstance(model, Model) else Model.load(model)
         self.batch = Batch(self.model, n_envs, device)
         self.num_envs = int(n_envs)
@@ -32,6 +33,11 @@ class VecEnv:
             self.realism.seed = int(seed)
             self.realism.control_timestep = float(self.model.opt.timestep * self.n_substeps)
             self._apply_realism()
+        self.domain = None
+        if domain_randomization:
+            self.domain = self.batch.env_default_domain_randomization()
+            self.domain.seed = int(seed)
+            self._apply_domain()
         # gymnasium-style space descriptions (cpu_env.py:56-63: Box(-1,1,(nu,)), Box(-10,10,(nobs,)))
         self.action_shape = (self.model.nu,)
         self.observation_shape = (self.model.nobs,)
@@ -45,6 +51,10 @@ class VecEnv:
         self.realism.factor = float(self.cfg.reset_perturb)
         self.batch.env_randomize(self.realism if self.realism.factor > 0 else None)
 
+    def _apply_domain(self):
+        self.domain.factor = float(self.cfg.reset_perturb)
+        self.batch.env_domain_randomize(self.domain if self.domain.factor > 0 else None)
+
     def set_attr(self, name, value):
         if name != "randomization_factor":
             raise AttributeError(name)
@@ -52,6 +62,8 @@ class VecEnv:
         self.batch.env_configure(self.cfg)
         if self.realism is not None:
             self._apply_realism()
+        if self.domain is not None:
+            self._apply_domain()
 
     def reset(self):
         return self.batch.env_reset()

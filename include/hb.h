@@ -238,6 +238,34 @@ int hb_env_default_randomization(const hb_model* m, hb_env_randomization* out);
 /* Installs (cfg != NULL and cfg->factor > 0) or removes the above; takes effect at the next hb_env_reset
  * (call it before resetting).  Delays beyond 63 control steps are refused. */
 int hb_env_randomize(hb_batch* b, const hb_env_randomization* cfg);
+/* Domain randomisation of the model per env and episode (cpu_env.py:188-264, values of simulation_parameters.py:5-37),
+ * drawn on the device at hb_env_reset and at every auto-reset, all scaled by `factor` as in the reference:
+ *  - body masses += U(-max_mass_change, +max_mass_change) (floor 1e-5 kg) and one random body += U(0, max_external_mass);
+ *    like the reference, derived constants (inverse weights, subtree masses) are NOT recomputed;
+ *  - floor sliding friction *= (1 - factor) + U(friction_min_mult, friction_max_mult) * factor   (first plane geom);
+ *  - per hinge/slide joint: armature += U(0, armature_max_change), stiffness += U(0, stiffness_max_change),
+ *    limit margin += U(0, margin_max_change), each limit bound += U(-range_max_change, +range_max_change);
+ *  - per actuator: force range bounds += U(-force_limit_max_change, +...); if kp_nominal > 0 the gain becomes
+ *    kp_nominal + U(-kp_max_change, +kp_max_change) and, for actuators with an affine bias, biasprm[1] = -gain.
+ * Random numbers come from the same counter-based generator as hb_env_randomization (seed, global env, episode). */
+typedef struct hb_domain_randomization {
+  float factor;
+  unsigned int seed;
+  float friction_min_mult, friction_max_mult;
+  float max_mass_change, max_external_mass;
+  float armature_max_change, stiffness_max_change, margin_max_change, range_max_change;
+  float kp_nominal, kp_max_change, force_limit_max_change;
+} hb_domain_randomization;
+/* The reference's values (factor = 1, kp_nominal = 0: gains stay the model's — JOINT_P_GAIN = 2 is the team robot's). */
+int hb_env_default_domain_randomization(const hb_model* m, hb_domain_randomization* out);
+/* Installs (cfg != NULL and cfg->factor > 0) or removes per-env model parameters; call before hb_env_reset. */
+int hb_env_domain_randomize(hb_batch* b, const hb_domain_randomization* cfg);
+/* Current per-env parameters, for inspection: out[n_env][stride] with per env
+ * mass[nbody] | armature[nv] | stiffness[nv] | limit margin[nlim] | limit bound[nlim] | gain[nu] | biasprm1[nu] |
+ * forcerange[2 nu] | floor friction scale; returns stride (also when out == NULL), 0 when off. nlim = 2 per limited
+ * joint / tendon in constraint order (lower, upper). */
+int hb_env_get_domain_params(hb_batch* b, float* out);
+
 /* CPUEnv.reset for every env: returns obs[n_env][nobs]. */
 int hb_env_reset(hb_batch* b, float* obs);
 /* CPUEnv.step: action[n_env][nu] -> ctrl (unscaled; the physics clamps to ctrlrange), n_substeps x mj_step,

@@ -1194,6 +1194,8 @@ double* om_model_ptr(om_model* m, const char* name, int* len) {
   FIELD(body_mass, nb) FIELD(body_subtreemass, nb) FIELD(body_inertia, 3 * nb) FIELD(body_invweight0, 2 * nb) FIELD(dof_invweight0, nv) FIELD(dof_M0, nv)
   FIELD(tendon_invweight0, m->ntendon) FIELD(qpos0, m->nq) FIELD(key_qpos, m->nkey * m->nq) FIELD(dof_damping, nv) FIELD(dof_armature, nv)
   FIELD(jnt_range, 2 * m->njnt) FIELD(gravity, 3) FIELD(body_ipos, 3 * nb) FIELD(jnt_stiffness, m->njnt)
+  FIELD(jnt_margin, m->njnt) FIELD(geom_friction, 3 * m->ngeom) FIELD(actuator_gainprm, m->nu) FIELD(actuator_biasprm, 3 * m->nu)
+  FIELD(actuator_forcerange, 2 * m->nu)
   *len = 0;
   return NULL;
 }

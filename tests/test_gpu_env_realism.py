@@ -189,3 +189,115 @@ def test_randomize_argument_checks_and_off_switch(hbmod, humanoid_model, gpu):
     o2 = b.env_step(np.zeros((8, m.nu), np.float32))[0]
     true, *_ = b.obs(want_reward=False)
     assert np.allclose(o2, true, atol=1e-6) and not np.allclose(o1, o2)
+
+
+def _domain_layout(m, nlim):
+    nb, nv, nu = 17, m.nv, m.nu
+    o = dict(mass=0, arm=nb, stiff=nb + nv, lmargin=nb + 2 * nv)
+    o["lrange"] = o["lmargin"] + nlim
+    o["gain"] = o["lrange"] + nlim
+    o["bias1"] = o["gain"] + nu
+    o["frc"] = o["bias1"] + nu
+    o["fric"] = o["frc"] + 2 * nu
+    o["stride"] = o["fric"] + 1
+    return o
+
+
+def test_domain_randomization_draws_and_physics(hbmod, humanoid_model, gpu):
+    """hb_domain_randomization: per-env masses, armature, joint limits, actuator force ranges and floor friction are
+    drawn inside the reference's bounds, differ between envs and episodes, and the physics uses them — one step from
+    identical states matches the fp64 oracle whose model arrays were set to the env's parameters."""
+    m = humanoid_model
+    n = 6
+    env = hbmod.VecEnv(m, n, gpu, auto_reset=0, max_time=0.0, target_z=10.0)
+    b = env.batch
+    assert b.env_domain_params() is None
+    D = b.env_default_domain_randomization()
+    assert D.friction_min_mult == pytest.approx(0.5) and D.max_external_mass == pytest.approx(0.2) and D.kp_nominal == 0.0
+    D.seed = 9
+    D.stiffness_max_change = 2.0   # the reference leaves stiffness at 0; exercised here
+    D.max_mass_change = 0.5        # larger than the reference's 0.05 kg so that the physics difference is far above fp32 noise
+    b.env_domain_randomize(D)
+    env.reset()
+    P = b.env_domain_params()
+    o = Oracle()
+    base_mass = o.marr("body_mass").copy(); base_arm = o.marr("dof_armature").copy(); base_rng = o.marr("jnt_range").copy()
+    base_frc = o.marr("actuator_forcerange").copy(); base_stiff = o.marr("jnt_stiffness").copy(); base_margin = o.marr("jnt_margin").copy()
+    base_fric = o.marr("geom_friction").copy()
+    nlim = (P.shape[1] - 1 - 17 - 2 * m.nv - 4 * m.nu) // 2
+    L = _domain_layout(m, nlim)
+    assert P.shape[1] == L["stride"] and nlim == 2 * 21 + 2 * 2  # 21 limited hinges + 2 limited tendons, lower and upper each
+    mass = P[:, L["mass"]:L["mass"] + 17]
+    assert np.all(np.abs(mass[:, 1:] - base_mass[1:]) <= 0.5 + 0.2 + 1e-5) and np.all(mass[:, 1:] >= 1e-5) and mass[:, 1:].std(axis=0).min() > 0
+    arm = P[:, L["arm"]:L["arm"] + m.nv]
+    assert np.allclose(arm[:, :6], base_arm[:6]) and np.all(arm[:, 6:] >= base_arm[6:] - 1e-9) and np.all(arm[:, 6:] <= base_arm[6:] + 0.0005 + 1e-7)
+    fric = P[:, L["fric"]]
+    assert np.all((fric >= 0.5 - 1e-6) & (fric <= 1.0 + 1e-6)) and fric.std() > 0
+    frc = P[:, L["frc"]:L["frc"] + 2 * m.nu]
+    assert np.all(np.abs(frc - base_frc) <= 0.05 + 1e-6)
+    gains = P[:, L["gain"]:L["gain"] + m.nu]
+    assert np.allclose(gains, o.marr("actuator_gainprm"))  # kp_nominal = 0: the model's gains
+    # physics: teacher-forced steps against the oracle carrying env e's parameters
+    lim_joint = [j for j in range(1, 22)]  # joints 1..21 are the limited hinges, in constraint order
+    rng = np.random.default_rng(8)
+    for t in range(12):
+        act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
+        st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+        env.step(act)
+        q1 = b.qpos
+        for e in range(n):
+            o.marr("body_mass")[:] = mass[e]
+            o.marr("dof_armature")[:] = arm[e]
+            o.marr("jnt_stiffness")[1:] = P[e, L["stiff"] + 6:L["stiff"] + m.nv]
+            for k, j in enumerate(lim_joint):
+                o.marr("jnt_margin")[j] = P[e, L["lmargin"] + 2 * k]
+                o.marr("jnt_range")[2 * j] = P[e, L["lrange"] + 2 * k]
+                o.marr("jnt_range")[2 * j + 1] = P[e, L["lrange"] + 2 * k + 1]
+            o.marr("actuator_forcerange")[:] = frc[e]
+            o.marr("geom_friction")[0] = base_fric[0] * fric[e]
+            o.reset()
+            o.qpos[:] = st[e, 1:1 + m.nq]; o.qvel[:] = st[e, 1 + m.nq:1 + m.nq + m.nv]; o.qacc_warmstart[:] = st[e, 1 + m.nq + m.nv:]
+            o.ctrl[:] = act[e]
+            o.step()
+            assert np.abs(q1[e] - o.qpos).max() < 2e-5, (t, e, np.abs(q1[e] - o.qpos).max())
+    # and the parameters matter: the unrandomised oracle does not reproduce these steps
+    o.marr("body_mass")[:] = base_mass; o.marr("dof_armature")[:] = base_arm; o.marr("jnt_range")[:] = base_rng; o.marr("actuator_forcerange")[:] = base_frc
+    o.marr("jnt_stiffness")[:] = base_stiff; o.marr("jnt_margin")[:] = base_margin; o.marr("geom_friction")[:] = base_fric
+    o.reset()
+    o.qpos[:] = st[0, 1:1 + m.nq]; o.qvel[:] = st[0, 1 + m.nq:1 + m.nq + m.nv]; o.qacc_warmstart[:] = st[0, 1 + m.nq + m.nv:]
+    o.ctrl[:] = act[0]
+    o.step()
+    assert np.abs(q1[0] - o.qpos).max() > 2e-5
+    # the draw itself against the numpy restatement of the generator (streams 16 = per-limb change, 17 = attached mass)
+    from env_ref import rng_uniform
+    for e in range(n):
+        want = np.array([max(1e-5, base_mass[bd] + (2 * float(rng_uniform(9, e, 0, 0, 16, bd)) - 1) * 0.5) for bd in range(17)])
+        want[0] = 0.0
+        bd = 1 + min(15, int(np.float32(rng_uniform(9, e, 0, 0, 17, 0)) * np.float32(16)))
+        want[bd] += float(rng_uniform(9, e, 0, 0, 17, 1)) * 0.2
+        assert np.allclose(mass[e], want, atol=2e-6), (e, np.abs(mass[e] - want).max())
+
+
+def test_domain_randomization_redraws_per_episode_and_switches_off(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    n = 8
+    env = hbmod.VecEnv(m, n, gpu, domain_randomization=True, seed=4, max_time=0.0149, target_z=10.0)  # 3-step episodes, auto-reset
+    env.reset()
+    p0 = env.batch.env_domain_params().copy()
+    assert np.abs(p0[0] - p0[1]).max() > 1e-4  # envs differ
+    zeros = np.zeros((n, m.nu), np.float32)
+    for t in range(3):
+        obs, rew, term, trunc, info = env.step(zeros)
+    assert term.all()
+    p1 = env.batch.env_domain_params().copy()
+    assert np.abs(p1 - p0).max() > 1e-4 and np.isfinite(p1).all()  # new episode, new draw
+    # same seed, same envs, same episode numbers: reproducible
+    env_b = hbmod.VecEnv(m, n, gpu, domain_randomization=True, seed=4, max_time=0.0149, target_z=10.0)
+    env_b.reset()
+    assert np.array_equal(env_b.batch.env_domain_params(), p0)
+    env.set_attr("randomization_factor", 0.0)  # factor 0 removes the layer
+    assert env.batch.env_domain_params() is None
+    D = env.batch.env_default_domain_randomization()
+    D.range_max_change = -1.0
+    with pytest.raises(hbmod.HbError):
+        env.batch.env_domain_randomize(D)

@@ -142,7 +142,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
   dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(6 * nv);
   dm.o_qLD = take(2 * m.nM + 6); dm.o_dinv = take(2 * nv); dm.o_dsqrtinv = take(nv); dm.o_smooth = take(nv);  // qLD, dinv: {M, H} pairs; + the three pad pairs of the factor schedule
-  dm.o_vec0 = take(nv); dm.o_vec1 = take(nv); dm.o_vec2 = take(nv); dm.o_tenlen = take(std::max(1, m.ntendon));
+  dm.o_vec0 = take(32); dm.o_vec1 = take(32); dm.o_vec2 = take(32);  /* read 32 wide */ dm.o_tenlen = take(std::max(1, m.ntendon));
   int region = off;
   dm.o_xpos = take(3 * nb); dm.o_xquat = take(4 * nb); dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
   dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(10 * nb);
@@ -152,7 +152,11 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);
   // per-row meta (13 slots x kNefcMax) is dead once the row quantities are in registers; W = L^-1 D^-1/2
   // ([32][33]) is built over it before the J W product and lives until the dual finish
-  dm.o_efc = take(std::max(13 * kNefcMax, 32 * 33));
+  dm.o_efc = take(std::max(13 * kNefcMax, 32 * 36));
+  // mj_Euler builds W_H and its transpose (2 x [32][36]) from the start of C, running on into the row-meta area
+  if (dm.o_efc != dm.o_C + (((kNefcMax + 1) * dm.cstride + 3) & ~3) || dm.o_efc + std::max(13 * kNefcMax, 32 * 36) - dm.o_C < 2 * 32 * 36) {
+    err = "internal: LDS layout leaves no room for the Euler solve's W_H pair"; return false;
+  }
   dm.o_force = take(kGroup);
   int endB = off;
   // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
@@ -739,6 +743,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
   ok = ok && hipMemset(b->d_counts, 0, (size_t)n_env * kCountStride * sizeof(int)) == hipSuccess;
   ok = ok && ensure_ctrl(b, (size_t)n_env * std::max(1, dm.nu)) == HB_OK;
   ok = ok && hipMalloc((void**)&b->d_order, (size_t)n_env * sizeof(int)) == hipSuccess;
+  if (hb_debug()) fprintf(stderr, "[hb] LDS per env: %d bytes (%d envs per CU)\n", dm.lds_floats * 4, 160 * 1024 / (dm.lds_floats * 4));
   if (ok && dm.lds_floats * 4 > 64 * 1024) ok = set_step_lds_limit(dm.lds_floats * 4) == hipSuccess;
   if (!ok) { set_err(err, err_sz, "device allocation failed"); hb_batch_free(b); return nullptr; }
   if (hb_reset(b, nullptr, -1, 0, 0) != HB_OK) { set_err(err, err_sz, "initial reset failed"); hb_batch_free(b); return nullptr; }

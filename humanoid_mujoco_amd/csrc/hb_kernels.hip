@@ -451,11 +451,22 @@ __device__ __forceinline__ void factor_ld(DevModelRef M, float* lds, f32x2* LD, 
 // address of its L row) comes packed from M.chain.  WHICH selects the M (0) or H (1) half of the
 // interleaved factor; this pass is bound by its 136 LDS reads per lane, so the halves are built when
 // needed (dword reads) rather than together (qword reads cost twice the LDS cycles).
-constexpr int kWs = 33;
-template <int WHICH>
-__device__ __forceinline__ void build_w(DevModelRef M, const f32x2* LD2, const f32x2* dinv, const float* dsqrtinv, float* W, int lane) {
+constexpr int kWs = 36;  // 16-byte aligned rows: a row times a vector is eight ds_read_b128 pairs (dot32)
+// 32-term dot product of a W row with a dof vector, both 16-byte aligned and zero beyond nv
+__device__ __forceinline__ float dot32(const float* row, const float* v) {
+  const float4* a = reinterpret_cast<const float4*>(row);
+  const float4* b = reinterpret_cast<const float4*>(v);
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; q++) { const float4 x = a[q], y = b[q]; acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
+  return acc;
+}
+
+// TRANS: also write the transpose WT (row c holds column c of W), so that W^T times a vector is a row product too
+template <int WHICH, bool TRANS>
+__device__ __forceinline__ void build_w(DevModelRef M, const f32x2* LD2, const f32x2* dinv, const float* dsqrtinv, float* W, float* WT, int lane) {
   const float* LD = reinterpret_cast<const float*>(LD2) + WHICH;
-  for (int idx = lane; idx < 32 * kWs; idx += kGroup) W[idx] = 0.f;
+  for (int idx = lane; idx < 32 * kWs; idx += kGroup) { W[idx] = 0.f; if (TRANS) WT[idx] = 0.f; }
   gsync();
   if (lane < M.nv) {
     const int i = lane;
@@ -475,7 +486,11 @@ __device__ __forceinline__ void build_w(DevModelRef M, const f32x2* LD2, const f
     }
 #pragma unroll
     for (int t = 0; t <= kMaxAnc; t++)
-      if (t <= n) W[i * kWs + c[t]] = u[t] * (WHICH ? sqrtf(dinv[c[t]].y) : dsqrtinv[c[t]]);
+      if (t <= n) {
+        const float w = u[t] * (WHICH ? sqrtf(dinv[c[t]].y) : dsqrtinv[c[t]]);
+        W[i * kWs + c[t]] = w;
+        if (TRANS) WT[c[t] * kWs + i] = w;
+      }
   }
   gsync();
 }
@@ -558,6 +573,8 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   // pad pairs of the factorisation schedule (zero, one, dump), behind the matrix; never written again except
   // the dump slot, which only ever has zero subtracted from it
   if (lane < 6) s_qLD[M.nM + (lane >> 1)][lane & 1] = (lane >> 1) == 1 ? 1.f : 0.f;
+  // the dof vectors are read 32 wide (dot32): their tails beyond nv stay zero for the whole launch
+  if (lane < 32) { s_v0[lane] = 0.f; s_v1[lane] = 0.f; s_v2[lane] = 0.f; }
   gsync();
 
   for (int step = 0; step < nsteps; step++) {
@@ -1158,7 +1175,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     // rows 0..nefc-1 are constraint rows, row nefc is qfrc_smooth (-> y = D^-1/2 L^-T qfrc_smooth).
     // 32-row tiles x 32 dof columns x K = 32 on the matrix cores; A operands are preloaded so the
     // product can be written back over J in place.
-    build_w<0>(M, s_qLD, s_dinv, s_dsqrtinv, s_W, lane);
+    build_w<0, false>(M, s_qLD, s_dinv, s_dsqrtinv, s_W, nullptr, lane);
     {
       const int col = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -1329,8 +1346,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     {
       float qacc_i = 0.f, rhs_i = 0.f;
       if (lane < nv) {
-        const float* Wr = s_W + lane * kWs;
-        for (int n = 0; n < nv; n++) qacc_i += Wr[n] * s_v2[n];
+        qacc_i = dot32(s_W + lane * kWs, s_v2);
         float acc = s_v1[lane];
         // descendants of this dof, four table entries in flight at a time (the table is padded by four)
         const int t1 = M.desc_adr[lane + 1];
@@ -1388,14 +1404,15 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       if (eulerdamp) {
         // qacc' = H^-1 (qfrc_smooth + qfrc_constraint), H^-1 = W_H W_H^T; W_H is built in the (now dead) C rows
         float* WH = s_C;
-        build_w<1>(M, s_qLD, s_dinv, s_dsqrtinv, WH, lane);
+        float* WHT = s_C + 32 * kWs;  // runs on into the (dead) row-meta / W area behind C: the host checks the room
+        build_w<1, true>(M, s_qLD, s_dinv, s_dsqrtinv, WH, WHT, lane);
         float p = 0.f;
-        if (lane < nv) for (int k = 0; k < nv; k++) p += WH[k * kWs + lane] * s_v2[k];  // p = W_H^T rhs
+        if (lane < nv) p = dot32(WHT + lane * kWs, s_v2);  // p = W_H^T rhs
         gsync();
         if (lane < nv) s_v1[lane] = p;
         gsync();
         float q = 0.f;
-        if (lane < nv) { const float* Wr = WH + lane * kWs; for (int n = 0; n < nv; n++) q += Wr[n] * s_v1[n]; }
+        if (lane < nv) q = dot32(WH + lane * kWs, s_v1);
         gsync();
         if (lane < nv) s_v2[lane] = q;
         gsync();

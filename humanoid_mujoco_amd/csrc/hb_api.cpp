@@ -380,7 +380,22 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
 #undef TI
 #undef TF
   size_t o_mask = T.addu(dofmask);
-  size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag);
+  // per collision pair, everything mj_makeConstraint needs of it in one 5-quad record (one scalar fetch per contact):
+  // [0] body1, body2, tree1, tree2   [1] dof mask of body1 (lo, hi), of body2 (lo, hi)
+  // [2] margin - gap, solref[2], invweight0 sum   [3] solimp[0..3]   [4] solimp[4], condim, -, -
+  std::vector<float> prec((size_t)std::max(1, m.npair) * 20, 0.f);
+  for (int p = 0; p < m.npair; p++) {
+    float* r = &prec[(size_t)p * 20];
+    const int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
+    r[0] = fi(b1); r[1] = fi(b2); r[2] = fi(treeid[b1]); r[3] = fi(treeid[b2]);
+    r[4] = fi((int)(dofmask[b1] & 0xffffffffull)); r[5] = fi((int)(dofmask[b1] >> 32));
+    r[6] = fi((int)(dofmask[b2] & 0xffffffffull)); r[7] = fi((int)(dofmask[b2] >> 32));
+    r[8] = (float)(pair_margin[p] - pair_gap[p]); r[9] = (float)pair_solref[2 * p]; r[10] = (float)pair_solref[2 * p + 1];
+    r[11] = (float)(m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2]);
+    for (int i = 0; i < 4; i++) r[12 + i] = (float)pair_solimp[5 * p + i];
+    r[16] = (float)pair_solimp[5 * p + 4]; r[17] = fi(pair_dim[p]);
+  }
+  size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec);
 
   // ---- upload
   if (hipMalloc((void**)&D.d_int, T.iv.size() * sizeof(int)) != hipSuccess || hipMalloc((void**)&D.d_flt, T.fv.size() * sizeof(float)) != hipSuccess ||
@@ -393,6 +408,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.body_dofmask = D.d_u64 + o_mask;
   dm.brec = reinterpret_cast<const float4*>(D.d_flt + o_brec);
   dm.drec = reinterpret_cast<const float4*>(D.d_flt + o_drec);
+  dm.prec = reinterpret_cast<const float4*>(D.d_flt + o_prec);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);

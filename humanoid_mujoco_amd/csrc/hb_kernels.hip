@@ -1090,20 +1090,26 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       for (int m = 32; m >= 1; m >>= 1) endrow = max(endrow, __shfl_xor(endrow, m, kGroup));
       const int nefc_after = uniform(endrow);
       gsync();
-      // Jacobian rows: uniform loop over contacts, lanes over dofs
+      // Jacobian rows: uniform loop over contacts, lanes over dofs.  The pair id and first row of contact ci come
+      // out of the lanes that own them (v_readlane); everything the pair contributes is one 5-quad record, fetched
+      // with scalar loads.
+      const int rowv = (lane < ncon && incl && fits) ? base : -1;
       for (int ci = 0; ci < ncon; ci++) {
-        const float* c = s_con + ci * kConStride;
-        int row = __float_as_int(c[C_ROW]);
+        const int row = __builtin_amdgcn_readlane(rowv, ci);
         if (row < 0) continue;
-        int pid = __float_as_int(c[C_PAIR]);
-        int dim = __float_as_int(c[C_DIM]);
-        int g1 = M.pair_geom1[pid], g2 = M.pair_geom2[pid];
-        int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
-        unsigned long long m1 = M.body_dofmask[b1], m2 = M.body_dofmask[b2];
+        const int pid = __builtin_amdgcn_readlane(pairid, ci);
+        const float4 HB_CONST* PR = M.prec + (size_t)pid * 5;
+        const float4 p0 = PR[0], p1 = PR[1], p2 = PR[2], p3 = PR[3], p4 = PR[4];
+        const float* c = s_con + ci * kConStride;
+        const int dim = __float_as_int(p4.y) == 1 ? 1 : 3;
+        const int b1 = __float_as_int(p0.x), b2 = __float_as_int(p0.y);
+        const unsigned long long m1 = ((unsigned long long)__float_as_uint(p1.y) << 32) | __float_as_uint(p1.x);
+        const unsigned long long m2 = ((unsigned long long)__float_as_uint(p1.w) << 32) | __float_as_uint(p1.z);
         V3 cpos = ld3(c + C_POS);
-        V3 off1 = cpos - ld3(s_scom + 3 * M.body_treeid[b1]), off2 = cpos - ld3(s_scom + 3 * M.body_treeid[b2]);
+        V3 off1 = cpos - ld3(s_scom + 3 * __float_as_int(p0.z)), off2 = cpos - ld3(s_scom + 3 * __float_as_int(p0.w));
         V3 fn = ld3(c + C_FRAME), ft1 = ld3(c + C_FRAME + 3), ft2 = ld3(c + C_FRAME + 6);
         float mu = c[C_FRIC];
+        (void)b1; (void)b2;
         for (int d = lane; d < cs; d += kGroup) {
           V3 jd = {0.f, 0.f, 0.f};
           if (d < nv) {
@@ -1123,12 +1129,13 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         }
         int nr = dim == 1 ? 1 : 4;
         if (lane < nr) {
-          float tran = M.body_invweight0[2 * b1] + M.body_invweight0[2 * b2];
+          const float tran = p2.w;
           float* e = s_efc + row + lane;
           e[E_POS * kNefcMax] = c[C_DIST];
-          e[E_MARGIN * kNefcMax] = M.pair_margin[pid] - M.pair_gap[pid];
-          e[E_SOLREF0 * kNefcMax] = M.pair_solref[2 * pid]; e[E_SOLREF1 * kNefcMax] = M.pair_solref[2 * pid + 1];
-          for (int i = 0; i < 5; i++) e[(E_IMP0 + i) * kNefcMax] = M.pair_solimp[5 * pid + i];
+          e[E_MARGIN * kNefcMax] = p2.x;
+          e[E_SOLREF0 * kNefcMax] = p2.y; e[E_SOLREF1 * kNefcMax] = p2.z;
+          e[(E_IMP0 + 0) * kNefcMax] = p3.x; e[(E_IMP0 + 1) * kNefcMax] = p3.y; e[(E_IMP0 + 2) * kNefcMax] = p3.z; e[(E_IMP0 + 3) * kNefcMax] = p3.w;
+          e[(E_IMP0 + 4) * kNefcMax] = p4.x;
           float da = dim == 1 ? tran : tran + mu * mu * tran;
           e[E_DA * kNefcMax] = da; e[E_DAFIRST * kNefcMax] = da;
           float mus = mu * M.inv_sqrt_impratio;

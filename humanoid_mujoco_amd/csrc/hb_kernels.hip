@@ -308,10 +308,15 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   float x = fabsf((pos - margin) / width);
   if (x >= 1.f) return d1;
   if (x <= 0.f) return d0;
+  // both halves of the sigmoid are the same power curve, mirrored: one evaluation, and the usual exponent 2
+  // (MuJoCo's default solimp) needs no powf at all
+  const bool lower = x <= mid;
+  const float t = lower ? x : 1.f - x, mm = lower ? mid : 1.f - mid;
   float y;
-  if (power == 1.f) y = x;
-  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
-  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  if (power == 1.f) y = t;  // x or 1 - x: the curve is the identity
+  else if (power == 2.f) y = t * t / mm;
+  else y = powf(t, power) / powf(mm, power - 1.f);
+  if (!lower) y = 1.f - y;
   return d0 + y * (d1 - d0);
 }
 
@@ -1156,7 +1161,17 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     if (rowact) {
       const float* Jr = s_C + lane * cs;
       float vel = 0.f;
-      for (int k = 0; k < nv; k++) { float j = Jr[k]; vel += j * s_qvel[k]; jw += j * s_warm[k]; }
+      {  // four columns in flight: two independent accumulation chains per product
+        float vel2 = 0.f, jw2 = 0.f;
+        int k = 0;
+        for (; k + 4 <= nv; k += 4) {
+          const float j0 = Jr[k], j1 = Jr[k + 1], j2 = Jr[k + 2], j3 = Jr[k + 3];
+          vel += j0 * s_qvel[k] + j2 * s_qvel[k + 2]; vel2 += j1 * s_qvel[k + 1] + j3 * s_qvel[k + 3];
+          jw += j0 * s_warm[k] + j2 * s_warm[k + 2]; jw2 += j1 * s_warm[k + 1] + j3 * s_warm[k + 3];
+        }
+        for (; k < nv; k++) { const float j = Jr[k]; vel += j * s_qvel[k]; jw += j * s_warm[k]; }
+        vel += vel2; jw += jw2;
+      }
       const float* e = s_efc + lane;
       float pos = e[E_POS * kNefcMax], margin = e[E_MARGIN * kNefcMax];
       float solref0 = e[E_SOLREF0 * kNefcMax], solref1 = e[E_SOLREF1 * kNefcMax];

@@ -395,7 +395,17 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (int i = 0; i < 4; i++) r[12 + i] = (float)pair_solimp[5 * p + i];
     r[16] = (float)pair_solimp[5 * p + 4]; r[17] = fi(pair_dim[p]);
   }
-  size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec);
+  // per collision pair, what mj_collision needs of it in one 3-quad record (one vector fetch per lane and round):
+  // [0] geom1, geom2, type1 | type2 << 8, margin   [1] rbound1, rbound2, size1[0], size1[1]   [2] size2[0], size2[1], -, -
+  std::vector<float> crec((size_t)(std::max(1, m.npair) + 64) * 12, 0.f);  // + one round of padding for the prefetch
+  for (int p = 0; p < m.npair; p++) {
+    float* r = &crec[(size_t)p * 12];
+    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    r[0] = fi(g1); r[1] = fi(g2); r[2] = fi(m.geom_type[g1] | (m.geom_type[g2] << 8)); r[3] = (float)pair_margin[p];
+    r[4] = (float)m.geom_rbound[g1]; r[5] = (float)m.geom_rbound[g2]; r[6] = (float)m.geom_size[3 * g1]; r[7] = (float)m.geom_size[3 * g1 + 1];
+    r[8] = (float)m.geom_size[3 * g2]; r[9] = (float)m.geom_size[3 * g2 + 1];
+  }
+  size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec), o_crec = T.addraw(crec);
 
   // ---- upload
   if (hipMalloc((void**)&D.d_int, T.iv.size() * sizeof(int)) != hipSuccess || hipMalloc((void**)&D.d_flt, T.fv.size() * sizeof(float)) != hipSuccess ||
@@ -409,6 +419,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.brec = reinterpret_cast<const float4*>(D.d_flt + o_brec);
   dm.drec = reinterpret_cast<const float4*>(D.d_flt + o_drec);
   dm.prec = reinterpret_cast<const float4*>(D.d_flt + o_prec);
+  dm.crec = reinterpret_cast<const float4*>(D.d_flt + o_crec);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);

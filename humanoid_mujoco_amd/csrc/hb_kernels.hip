@@ -948,21 +948,27 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     int ncon = 0;
     const bool contacts_on = !(M.disableflags & ((1 << 0) | (1 << 4)));
     if (contacts_on) {
+      // one 3-quad record per candidate pair (table padded by a round); the next round's records are in flight
+      // while this round's narrowphase runs
+      float4 n0 = M.crec[3 * (size_t)lane], n1 = M.crec[3 * (size_t)lane + 1], n2 = M.crec[3 * (size_t)lane + 2];
       for (int p0 = 0; p0 < M.npair; p0 += kGroup) {
         int p = p0 + lane;
+        const float4 c0 = n0, c1 = n1, c2 = n2;
+        if (p0 + kGroup < M.npair) { const float4 HB_CONST* N = M.crec + 3 * (size_t)(p + kGroup); n0 = N[0]; n1 = N[1]; n2 = N[2]; }
         ConOut co0, co1;
         int n = 0;
         V3 hint = {0.f, 0.f, 0.f};
         float margin = 0.f;
         if (p < M.npair) {
-          int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-          int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
-          margin = M.pair_margin[p];
+          const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y);
+          const int t1 = __float_as_int(c0.z) & 255, t2 = __float_as_int(c0.z) >> 8;
+          margin = c0.w;
+          const float rb1 = c1.x, rb2 = c1.y;
           V3 pos1 = ld3(s_gpos + 3 * g1), pos2 = ld3(s_gpos + 3 * g2), ax2 = ld3(s_gaxis + 3 * g2);
-          float r2 = M.geom_size[3 * g2], l2 = M.geom_size[3 * g2 + 1];
+          float r2 = c2.x, l2 = c2.y;
           if (t1 == 0) {
             V3 normal = ld3(s_gaxis + 3 * g1);
-            if (dot(pos2 - pos1, normal) <= margin + M.geom_rbound[g2]) {
+            if (dot(pos2 - pos1, normal) <= margin + rb2) {
               if (t2 == 2) n = plane_sphere(co0, margin, pos1, normal, pos2, r2) ? 1 : 0;
               else {
                 ConOut ca, cb;
@@ -990,9 +996,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
             }
           } else if (t1 >= 2) {
             V3 dp = pos2 - pos1;
-            float bound = M.geom_rbound[g1] + M.geom_rbound[g2] + margin;
+            float bound = rb1 + rb2 + margin;
             if (dot(dp, dp) <= bound * bound) {
-              float r1 = M.geom_size[3 * g1], l1 = M.geom_size[3 * g1 + 1];
+              float r1 = c1.z, l1 = c1.w;
               if (t1 == 2 && t2 == 2) n = sphere_sphere(co0, margin, pos1, r1, pos2, r2) ? 1 : 0;
               else if (t1 == 2) {
                 float x = clampf(dot(ax2, pos1 - pos2), -l2, l2);

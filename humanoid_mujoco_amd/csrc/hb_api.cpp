@@ -145,8 +145,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.o_vec0 = take(32); dm.o_vec1 = take(32); dm.o_vec2 = take(32);  /* read 32 wide */ dm.o_tenlen = take(std::max(1, m.ntendon));
   int region = off;
   dm.o_xpos = take(3 * nb); dm.o_xquat = take(4 * nb); dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
-  dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(10 * nb);
-  dm.o_cvel = take(6 * nb); dm.o_cacc = take(6 * nb); dm.o_cfrc = take(6 * nb);
+  dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(16 * nb);  // crb: inertia[10] | cfrc[6] records
+  dm.o_cvel = take(12 * nb);  // cvel[6] | cacc[6] records
   int endA = off;
   off = region;
   dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);

@@ -547,10 +547,8 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   float* s_xanchor = lds + M.o_xanchor;
   float* s_xaxis = lds + M.o_xaxis;
   float* s_cinert = lds + M.o_cinert;
-  float* s_crb = lds + M.o_crb;
-  float* s_cvel = lds + M.o_cvel;
-  float* s_cacc = lds + M.o_cacc;
-  float* s_cfrc = lds + M.o_cfrc;
+  float* s_if = lds + M.o_crb;   // per body: composite inertia[10] | cfrc[6]
+  float* s_va = lds + M.o_cvel;  // per body: cvel[6] | cacc[6]
   float* s_con = lds + M.o_con;
   float* s_C = lds + M.o_C;
   float* s_efc = lds + M.o_efc;  // per-row meta, stride kNefcMax; dead once the row quantities are in registers
@@ -813,58 +811,56 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         }
       }
     }
-    if (lane < 6) {
-      s_cvel[lane] = 0.f;
-      s_cacc[lane] = (lane >= 3 && !(M.disableflags & (1 << 6))) ? -M.gravity[lane - 3] : 0.f;
-      s_cfrc[lane] = 0.f;
-    }
+    // Tree-pass storage is one record per body, 16-byte aligned, moved as ds_read/write_b128:
+    //   s_va[12 b ..] = cvel[6] | cacc[6]          s_if[16 b ..] = composite inertia[10] | force[6]
+    if (lane < 12) s_va[lane] = (lane >= 9 && !(M.disableflags & (1 << 6))) ? -M.gravity[lane - 9] : 0.f;  // world: cacc = -gravity
     gsync();
     float mycvel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mycacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int L = 1; L < M.nlevel; L++) {
       if (mylevel == L) {
-        float pv[6], t[6];
-        for (int i = 0; i < 6; i++) { pv[i] = s_cvel[6 * myp + i]; mycacc[i] = s_cacc[6 * myp + i]; }
+        const float4* Pp = reinterpret_cast<const float4*>(s_va + 12 * myp);
+        const float4 a0 = Pp[0], a1 = Pp[1], a2 = Pp[2];
+        const float pv[6] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y};
+        const float pa[6] = {a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+        float t[6];
         cross_motion(t, pv, lv);
-        for (int i = 0; i < 6; i++) {
-          mycvel[i] = pv[i] + lv[i];
-          mycacc[i] += t[i] + la[i];
-          s_cvel[6 * myb + i] = mycvel[i];
-          s_cacc[6 * myb + i] = mycacc[i];
-        }
+        for (int i = 0; i < 6; i++) { mycvel[i] = pv[i] + lv[i]; mycacc[i] = pa[i] + t[i] + la[i]; }
+        float4* Op = reinterpret_cast<float4*>(s_va + 12 * myb);
+        Op[0] = {mycvel[0], mycvel[1], mycvel[2], mycvel[3]};
+        Op[1] = {mycvel[4], mycvel[5], mycacc[0], mycacc[1]};
+        Op[2] = {mycacc[2], mycacc[3], mycacc[4], mycacc[5]};
       }
       gsync();
     }
     // body-local force cinert cacc + cvel x* (cinert cvel), and the composite inertia seeds, all bodies at once
     if (bl) {
       float in[10], f0[6], f1[6], f2[6];
-      for (int i = 0; i < 10; i++) { in[i] = s_cinert[10 * myb + i]; s_crb[10 * myb + i] = in[i]; }
+      for (int i = 0; i < 10; i++) in[i] = s_cinert[10 * myb + i];
       mul_inert_vec(f0, in, mycacc);
       mul_inert_vec(f1, in, mycvel);
       cross_force(f2, mycvel, f1);
-      for (int i = 0; i < 6; i++) s_cfrc[6 * myb + i] = f0[i] + f2[i];
+      float4* Op = reinterpret_cast<float4*>(s_if + 16 * myb);
+      Op[0] = {in[0], in[1], in[2], in[3]};
+      Op[1] = {in[4], in[5], in[6], in[7]};
+      Op[2] = {in[8], in[9], f0[0] + f2[0], f0[1] + f2[1]};
+      Op[3] = {f0[2] + f2[2], f0[3] + f2[3], f0[4] + f2[4], f0[5] + f2[5]};
     }
-    if (lane < 10) s_crb[lane] = s_cinert[lane];
+    if (lane < 16) s_if[lane] = lane < 10 ? s_cinert[lane] : 0.f;  // world body
     gsync();
     // mj_crb and the mj_rne backward pass share one sweep up the tree: children into parents (pull form)
     for (int L = M.nlevel - 2; L >= 1; L--) {
       if (mylevel == L && mycn > 0) {
-        float acc[16];
-#pragma unroll
-        for (int c = 0; c < 10; c++) acc[c] = s_crb[10 * myb + c];
-#pragma unroll
-        for (int c = 0; c < 6; c++) acc[10 + c] = s_cfrc[6 * myb + c];
+        float4* Op = reinterpret_cast<float4*>(s_if + 16 * myb);
+        float4 acc[4] = {Op[0], Op[1], Op[2], Op[3]};
 #pragma unroll
         for (int k = 0; k < 8; k++)
           if (k < mycn) {
+            const float4* Cp = reinterpret_cast<const float4*>(s_if + 16 * mych[k]);
 #pragma unroll
-            for (int c = 0; c < 10; c++) acc[c] += s_crb[10 * mych[k] + c];
-#pragma unroll
-            for (int c = 0; c < 6; c++) acc[10 + c] += s_cfrc[6 * mych[k] + c];
+            for (int q = 0; q < 4; q++) { const float4 c = Cp[q]; acc[q].x += c.x; acc[q].y += c.y; acc[q].z += c.z; acc[q].w += c.w; }
           }
 #pragma unroll
-        for (int c = 0; c < 10; c++) s_crb[10 * myb + c] = acc[c];
-#pragma unroll
-        for (int c = 0; c < 6; c++) s_cfrc[6 * myb + c] = acc[10 + c];
+        for (int q = 0; q < 4; q++) Op[q] = acc[q];
       }
       gsync();
     }
@@ -878,7 +874,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       float buf[6], cd[6];
       for (int t = 0; t < 6; t++) cd[t] = s_cdof[6 * i + t];
       float in[10];
-      for (int t = 0; t < 10; t++) in[t] = s_crb[10 * bi + t];
+      for (int t = 0; t < 10; t++) in[t] = s_if[16 * bi + t];
       mul_inert_vec(buf, in, cd);
       float sacc = 0.f;
       for (int t = 0; t < 6; t++) sacc += s_cdof[6 * j + t] * buf[t];
@@ -901,7 +897,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       const float4 dA = M.drec[3 * d], dB = M.drec[3 * d + 1], dC = M.drec[3 * d + 2];
       float bias = 0.f;
       const int b = __float_as_int(dA.y);
-      for (int t = 0; t < 6; t++) bias += s_cdof[6 * d + t] * s_cfrc[6 * b + t];
+      for (int t = 0; t < 6; t++) bias += s_cdof[6 * d + t] * s_if[16 * b + 10 + t];
       float passive = 0.f;
       if (!(M.disableflags & (1 << 5))) {
         if (__float_as_int(dA.z) >= 2) passive -= (dr ? dr[DL.o_stiff + d] : dB.w) * (s_qpos[__float_as_int(dC.x)] - dC.y);

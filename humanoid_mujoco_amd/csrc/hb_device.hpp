@@ -98,7 +98,7 @@ struct DevModel {
   // LDS layout (float offsets per env) — persistent region
   int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qLD, o_dinv, o_dsqrtinv, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
   // region A (dynamics scratch)
-  int o_xpos, o_xquat, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cvel;
+  int o_xpos, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cvel;
   // region B (constraints), aliases region A: contacts, C rows, row meta (later W), forces
   int o_con, o_C, o_efc, o_force;
   int lds_floats;  // total floats per env

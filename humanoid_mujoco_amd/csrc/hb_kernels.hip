@@ -461,6 +461,13 @@ __device__ __forceinline__ void factor_ld(DevModelRef M, float* lds, f32x2* LD, 
 // interleaved factor; this pass is bound by its 136 LDS reads per lane, so the halves are built when
 // needed (dword reads) rather than together (qword reads cost twice the LDS cycles).
 constexpr int kWs = 36;  // 16-byte aligned rows: a row times a vector is eight ds_read_b128 pairs (dot32)
+// one dof's motion axis record: s_cdof[8 d ..] = angular[3], -, linear[3], - (two ds_read_b128)
+__device__ __forceinline__ void ld_cdof(const float* s_cdof, int d, float out[6]) {
+  const float4* p = reinterpret_cast<const float4*>(s_cdof + 8 * d);
+  const float4 a = p[0], l = p[1];
+  out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = l.x; out[4] = l.y; out[5] = l.z;
+}
+
 // 32-term dot product of a W row with a dof vector, both 16-byte aligned and zero beyond nv
 __device__ __forceinline__ float dot32(const float* row, const float* v) {
   const float4* a = reinterpret_cast<const float4*>(row);
@@ -540,8 +547,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   float* s_v1 = lds + M.o_vec1;
   float* s_v2 = lds + M.o_vec2;
   float* s_tenlen = lds + M.o_tenlen;
-  float* s_xpos = lds + M.o_xpos;
-  float* s_xquat = lds + M.o_xquat;
+  float* s_xpq = lds + M.o_xpos;  // per body: xpos[3], -, xquat[4] (two ds_read/write_b128)
   float* s_xmat = lds + M.o_xmat;
   float* s_xipos = lds + M.o_xipos;
   float* s_xanchor = lds + M.o_xanchor;
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     // Tree passes read one level-ordered record per body (M.brec: parent, joints, frames, children
     // in kBrecQuads float4s) so that all table loads of a lane are independent of each other.
     if (lane == 0) {
-      st3(s_xpos, {0.f, 0.f, 0.f}); stq(s_xquat, {1.f, 0.f, 0.f, 0.f}); st3(s_xipos, {0.f, 0.f, 0.f});
+      st3(s_xpq, {0.f, 0.f, 0.f}); stq(s_xpq + 4, {1.f, 0.f, 0.f, 0.f}); st3(s_xipos, {0.f, 0.f, 0.f});
       for (int i = 0; i < 9; i++) s_xmat[i] = (i % 4 == 0) ? 1.f : 0.f;
     }
     gsync();
@@ -677,12 +683,14 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     for (int L = 1; L < M.nlevel; L++) {
       if (mylevel == L) {
         if (!isfree) {
-          const Q4 pq = ldq(s_xquat + 4 * myp);
-          mypos = ld3(s_xpos + 3 * myp) + qrot(pq, posl);
+          const float4* Pp = reinterpret_cast<const float4*>(s_xpq + 8 * myp);
+          const float4 pp4 = Pp[0], pq4 = Pp[1];
+          const Q4 pq = {pq4.x, pq4.y, pq4.z, pq4.w};
+          mypos = V3{pp4.x, pp4.y, pp4.z} + qrot(pq, posl);
           myquat = qnormalize(qmul(pq, quatl));
         }
-        st3(s_xpos + 3 * myb, mypos);
-        stq(s_xquat + 4 * myb, myquat);
+        reinterpret_cast<float4*>(s_xpq + 8 * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
+        reinterpret_cast<float4*>(s_xpq + 8 * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
       }
       gsync();
     }
@@ -691,8 +699,8 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         st3(s_xanchor + 3 * myja, mypos);
         st3(s_xaxis + 3 * myja, {JB[0].x, JB[0].y, JB[0].z});
       } else {
-        const Q4 pq = ldq(s_xquat + 4 * myp);
-        const V3 pp = ld3(s_xpos + 3 * myp);
+        const Q4 pq = ldq(s_xpq + 8 * myp + 4);
+        const V3 pp = ld3(s_xpq + 8 * myp);
 #pragma unroll
         for (int jj = 0; jj < 3; jj++) {
           if (jj < myjn) {
@@ -711,8 +719,8 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     // geoms: world position and z axis
     for (int g = lane; g < M.ngeom; g += kGroup) {
       int b = M.geom_bodyid[g];
-      st3(s_gpos + 3 * g, ld3(s_xpos + 3 * b) + mrot(s_xmat + 9 * b, ld3(M.geom_pos + 3 * g)));
-      Q4 q = qmul(ldq(s_xquat + 4 * b), ldq(M.geom_quat + 4 * g));
+      st3(s_gpos + 3 * g, ld3(s_xpq + 8 * b) + mrot(s_xmat + 9 * b, ld3(M.geom_pos + 3 * g)));
+      Q4 q = qmul(ldq(s_xpq + 8 * b + 4), ldq(M.geom_quat + 4 * g));
       st3(s_gaxis + 3 * g, {2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z});
     }
     // ---------------------------------------------------------------- mj_comPos
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       V3 com = ld3(s_scom + 3 * __float_as_int(q1.y));
       V3 dif = ld3(s_xipos + 3 * b) - com;
       float mat[9];
-      q2mat(mat, qmul(ldq(s_xquat + 4 * b), {iq.x, iq.y, iq.z, iq.w}));
+      q2mat(mat, qmul(ldq(s_xpq + 8 * b + 4), {iq.x, iq.y, iq.z, iq.w}));
       const float in0 = in4.x, in1 = in4.y, in2 = in4.z, mass = mymass;
       float t[9];
       for (int r = 0; r < 3; r++) { t[3 * r] = mat[3 * r] * in0; t[3 * r + 1] = mat[3 * r + 1] * in1; t[3 * r + 2] = mat[3 * r + 2] * in2; }
@@ -763,8 +771,8 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         ang = ld3(s_xaxis + 3 * j);
         lin = cross(ang, off);
       }
-      st3(s_cdof + 6 * d, ang);
-      st3(s_cdof + 6 * d + 3, lin);
+      reinterpret_cast<float4*>(s_cdof + 8 * d)[0] = {ang.x, ang.y, ang.z, 0.f};
+      reinterpret_cast<float4*>(s_cdof + 8 * d)[1] = {lin.x, lin.y, lin.z, 0.f};
     }
     // fixed tendon lengths
     for (int t = lane; t < M.ntendon; t += kGroup) {
@@ -787,13 +795,14 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         const int da = __float_as_int(JA[0].z);
         for (int k = 0; k < 3; k++) {
           const float qv = s_qvel[da + k];
-          for (int i = 0; i < 6; i++) lv[i] += s_cdof[6 * (da + k) + i] * qv;
+          ld_cdof(s_cdof, da + k, cd);
+          for (int i = 0; i < 6; i++) lv[i] += cd[i] * qv;
         }
         // the three rotational dofs all see the velocity after the translational ones (mj_comVel, free joint)
         float rot[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < 3; k++) {
           const float qv = s_qvel[da + 3 + k];
-          for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * (da + 3 + k) + i];
+          ld_cdof(s_cdof, da + 3 + k, cd);
           cross_motion(t, lv, cd);
           for (int i = 0; i < 6; i++) { la[i] += t[i] * qv; rot[i] += cd[i] * qv; }
         }
@@ -804,7 +813,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
           if (jj < myjn) {
             const int da = __float_as_int(JA[jj].z);
             const float qv = s_qvel[da];
-            for (int i = 0; i < 6; i++) cd[i] = s_cdof[6 * da + i];
+            ld_cdof(s_cdof, da, cd);
             cross_motion(t, lv, cd);
             for (int i = 0; i < 6; i++) { la[i] += t[i] * qv; lv[i] += cd[i] * qv; }
           }
@@ -872,12 +881,18 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       const float2 ad = M.mdiag[e];  // (armature, damping) on diagonal entries, 0 elsewhere
       const int i = pk & 255, j = (pk >> 8) & 255, bi = pk >> 16;
       float buf[6], cd[6];
-      for (int t = 0; t < 6; t++) cd[t] = s_cdof[6 * i + t];
+      ld_cdof(s_cdof, i, cd);
       float in[10];
-      for (int t = 0; t < 10; t++) in[t] = s_if[16 * bi + t];
+      {
+        const float4* Ip = reinterpret_cast<const float4*>(s_if + 16 * bi);
+        const float4 i0 = Ip[0], i1 = Ip[1], i2 = Ip[2];
+        in[0] = i0.x; in[1] = i0.y; in[2] = i0.z; in[3] = i0.w; in[4] = i1.x; in[5] = i1.y; in[6] = i1.z; in[7] = i1.w; in[8] = i2.x; in[9] = i2.y;
+      }
       mul_inert_vec(buf, in, cd);
       float sacc = 0.f;
-      for (int t = 0; t < 6; t++) sacc += s_cdof[6 * j + t] * buf[t];
+      float cj[6];
+      ld_cdof(s_cdof, j, cj);
+      for (int t = 0; t < 6; t++) sacc += cj[t] * buf[t];
       sacc += (dr && i == j) ? dr[DL.o_arm + i] : ad.x;
       // H = M + h diag(damping): matrix of the implicit-damping Euler solve (mj_Euler), factorised alongside M
       s_qLD[e] = {sacc, sacc + (eulerdamp ? M.timestep * ad.y : 0.f)};
@@ -897,7 +912,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       const float4 dA = M.drec[3 * d], dB = M.drec[3 * d + 1], dC = M.drec[3 * d + 2];
       float bias = 0.f;
       const int b = __float_as_int(dA.y);
-      for (int t = 0; t < 6; t++) bias += s_cdof[6 * d + t] * s_if[16 * b + 10 + t];
+      float cdd[6];
+      ld_cdof(s_cdof, d, cdd);
+      for (int t = 0; t < 6; t++) bias += cdd[t] * s_if[16 * b + 10 + t];
       float passive = 0.f;
       if (!(M.disableflags & (1 << 5))) {
         if (__float_as_int(dA.z) >= 2) passive -= (dr ? dr[DL.o_stiff + d] : dB.w) * (s_qpos[__float_as_int(dC.x)] - dC.y);
@@ -930,7 +947,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         unsigned long long mask = M.body_dofmask[b];
         for (int d = lane; d < nv; d += kGroup) {
           if (!((mask >> d) & 1ull)) continue;
-          V3 ang = ld3(s_cdof + 6 * d), lin = ld3(s_cdof + 6 * d + 3);
+          float cdd[6];
+          ld_cdof(s_cdof, d, cdd);
+          V3 ang = {cdd[0], cdd[1], cdd[2]}, lin = {cdd[3], cdd[4], cdd[5]};
           V3 jp = lin + cross(ang, off);
           s_smooth[d] += jp.x * f[0] + jp.y * f[1] + jp.z * f[2] + ang.x * f[3] + ang.y * f[4] + ang.z * f[5];
         }
@@ -1124,7 +1143,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         for (int d = lane; d < cs; d += kGroup) {
           V3 jd = {0.f, 0.f, 0.f};
           if (d < nv) {
-            V3 ang = ld3(s_cdof + 6 * d), lin = ld3(s_cdof + 6 * d + 3);
+            float cdd[6];
+          ld_cdof(s_cdof, d, cdd);
+          V3 ang = {cdd[0], cdd[1], cdd[2]}, lin = {cdd[3], cdd[4], cdd[5]};
             if ((m2 >> d) & 1ull) jd = jd + lin + cross(ang, off2);
             if ((m1 >> d) & 1ull) jd = jd - (lin + cross(ang, off1));
           }

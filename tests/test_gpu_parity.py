@@ -297,10 +297,12 @@ def test_disable_flags_and_options(hbmod, gpu):
     assert np.allclose(b2.qpos[:, 0], 1.5 * 10 * 0.005, atol=1e-5)
 
 
-@pytest.mark.parametrize("name,steps", [("ball_plane", 400), ("capsules", 300), ("chain", 300), ("pendulum_limit", 500), ("ball_hfield", 900)])
+@pytest.mark.parametrize("name,steps", [("ball_plane", 400), ("capsules", 300), ("chain", 300), ("pendulum_limit", 500), ("ball_hfield", 900),
+                                        ("maxsize", 600)])
 def test_other_models_one_step_parity_along_oracle_trajectory(hbmod, gpu, tmp_path, name, steps):
-    """Multi-tree models, slide joints, tendon limits, affine actuators, condim-1 pairs: teacher-forced
-    one-step parity at states sampled along an oracle rollout."""
+    """Multi-tree models, slide joints, tendon limits, affine actuators, condim-1 pairs, and the engine's capacity
+    limits all at once (maxsize: nv = 32, a 17-dof chain, three joints on a body, six children under one):
+    teacher-forced one-step parity at states sampled along an oracle rollout."""
     xml = os.path.join(MODELS, name + ".xml")
     m = hbmod.Model.load(xml)
     p = str(tmp_path / (name + ".hbm"))

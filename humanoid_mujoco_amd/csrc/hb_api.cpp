@@ -542,6 +542,8 @@ hipStream_t main_stream(hb_batch* b) {
   return b->stream;
 }
 
+// heavy-first re-sort every N-th step call (HB_REORDER_PERIOD overrides, for experiments)
+int reorder_period() { static const int p = [] { const char* e = getenv("HB_REORDER_PERIOD"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }(); return p; }
 // number of segments the next step call is cut into (1: one launch on the batch's stream)
 int segment_count(const hb_batch* b) { return (b->npipe > 1 && !b->time_steps && b->n_env >= 64 * b->npipe) ? b->npipe : 1; }
 struct Segment { int lo, hi; hipStream_t st; };
@@ -576,7 +578,7 @@ void steps_enqueued(hb_batch* b, int nseg, bool reorder) {
 int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
   const int nseg = segment_count(b);
   const bool sample = nseg == 1 && b->time_steps && (b->launch_count % 8 == 0) && b->tev_used + 2 <= (int)b->tev.size();
-  const bool reorder = b->schedule && (b->launch_count % 4 == 0);
+  const bool reorder = b->schedule && (b->launch_count % reorder_period() == 0);
   int rc = fork_pipes(b, nseg);
   if (rc != HB_OK) return rc;
   if (sample) HB_HIP(hipEventRecord(b->tev[b->tev_used], b->stream));
@@ -1316,7 +1318,7 @@ int hb_rollout_policy(hb_batch* b, int T, float* qpos_out_dev) {
   int rc = fork_pipes(b, nseg);
   if (rc != HB_OK) return rc;
   for (int t = 0; t < T; t++) {
-    const bool reorder = b->schedule && (b->launch_count % 4 == 0);
+    const bool reorder = b->schedule && (b->launch_count % reorder_period() == 0);
     BatchPtrs P = make_ptrs(b);
     P.ctrl = b->d_ctrl; P.ctrl_mode = 0;
     P.qpos_out = qpos_out_dev ? qpos_out_dev + (size_t)t * b->n_env * b->D.dm.nq : nullptr;

@@ -1987,10 +1987,18 @@ __global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* 
     atomicAdd(&hist[255 - key], 1);  // bin 0 = most expensive
   }
   __syncthreads();
-  if (tid == 0) {
-    int acc = e0;
-    for (int i = 0; i < 256; i++) { base[i] = acc; acc += hist[i]; }
+  // exclusive prefix sum of the 256 bins (Hillis-Steele on 256 threads: 8 rounds instead of a 256-step serial loop
+  // on one thread, which was most of this kernel's 9 us on the critical path of every fourth step)
+  if (tid < 256) base[tid] = hist[tid];
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    int v = 0;
+    if (tid < 256 && tid >= o) v = base[tid - o];
+    __syncthreads();
+    if (tid < 256) base[tid] += v;
+    __syncthreads();
   }
+  if (tid < 256) base[tid] += e0 - hist[tid];  // inclusive -> exclusive, offset by the segment start
   __syncthreads();
   for (int e = e0 + tid; e < e0 + n; e += blockDim.x) {
     int key = min(255, counts[kCountStride * e + 3] >> 3);

@@ -444,6 +444,8 @@ struct hb_batch {
   size_t ctrl_cap = 0;  // floats
   float* d_qpos_out = nullptr;
   size_t qpos_out_cap = 0;
+  float* d_sensor_out = nullptr;
+  size_t sensor_out_cap = 0;
   bool diag = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_stamps = nullptr;
@@ -657,6 +659,16 @@ int set_state_impl(hb_batch* b, unsigned spec, const T* in) {
   return HB_OK;
 }
 
+template <class T>
+int set_state_broadcast_impl(hb_batch* b, unsigned spec, const T* one) {
+  if (!b || !one) return HB_EINVAL;
+  if ((spec & ~kSupportedSpec) || !spec) return HB_EINVAL;
+  const int w = spec_size(b->model->m, spec);
+  std::vector<T> all((size_t)b->n_env * w);
+  for (int e = 0; e < b->n_env; e++) memcpy(&all[(size_t)e * w], one, (size_t)w * sizeof(T));
+  return set_state_impl<T>(b, spec, all.data());
+}
+
 }  // namespace
 
 extern "C" {
@@ -795,6 +807,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->ev0) HB_IGN(hipEventDestroy(b->ev0));
   if (b->ev1) HB_IGN(hipEventDestroy(b->ev1));
   envrand_free_fwd(b);
+  if (b->d_sensor_out) HB_IGN(hipFree(b->d_sensor_out));
   if (b->d_dr) HB_IGN(hipFree(b->d_dr));
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
@@ -913,6 +926,81 @@ int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out) {
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
+
+int hb_sensor_size(const hb_sensor_spec* spec) {
+  if (!spec || spec->n_framepos < 0 || spec->n_framepos > HB_MAX_FRAMEPOS) return HB_EINVAL;
+  return 3 * spec->n_framepos + (spec->subtree_body >= 0 ? 6 : 0);
+}
+
+// fills the sensor fields of P and sizes the device read-out buffer for T steps
+static int sensor_setup(hb_batch* b, const hb_sensor_spec* spec, int T, BatchPtrs& P) {
+  const Model& m = b->model->m;
+  const int ns = hb_sensor_size(spec);
+  if (ns <= 0) return HB_EINVAL;
+  for (int k = 0; k < spec->n_framepos; k++) if (spec->framepos_body[k] < 0 || spec->framepos_body[k] >= m.nbody) return HB_EINVAL;
+  int tree = -1;
+  if (spec->subtree_body >= 0) {
+    if (spec->subtree_body < 1 || spec->subtree_body >= m.nbody || m.body_parentid[spec->subtree_body] != 0) return HB_EINVAL;  // a tree root
+    for (int bd = 1, t = 0; bd <= spec->subtree_body; bd++)
+      if (m.body_parentid[bd] == 0) { if (bd == spec->subtree_body) tree = t; t++; }
+    if (tree < 0) return HB_EINVAL;
+  }
+  const size_t need = (size_t)T * b->n_env * ns;
+  if (need > b->sensor_out_cap) {
+    if (b->d_sensor_out) HB_IGN(hipFree(b->d_sensor_out));
+    b->d_sensor_out = nullptr; b->sensor_out_cap = 0;
+    if (hipMalloc((void**)&b->d_sensor_out, need * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+    b->sensor_out_cap = need;
+  }
+  P.sensor_out = b->d_sensor_out; P.sensor_stride = ns; P.sensor_nframe = spec->n_framepos; P.sensor_tree = tree;
+  for (int k = 0; k < spec->n_framepos; k++) P.sensor_body[k] = spec->framepos_body[k];
+  return HB_OK;
+}
+
+int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_spec* spec, float* sensor_out, float* qpos_out) {
+  if (!b || T < 1 || !spec || !sensor_out || (!ctrl && b->D.dm.nu > 0)) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  const size_t n = (size_t)T * b->n_env * b->D.dm.nu;
+  int rc = ensure_ctrl(b, std::max<size_t>(n, 1));
+  if (rc != HB_OK) return rc;
+  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  const size_t nq_out = (size_t)T * b->n_env * b->D.dm.nq;
+  if (qpos_out && nq_out > b->qpos_out_cap) {
+    if (b->d_qpos_out) HB_IGN(hipFree(b->d_qpos_out));
+    b->d_qpos_out = nullptr; b->qpos_out_cap = 0;
+    if (hipMalloc((void**)&b->d_qpos_out, nq_out * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+    b->qpos_out_cap = nq_out;
+  }
+  BatchPtrs P = make_ptrs(b);
+  P.ctrl = b->d_ctrl; P.ctrl_mode = 1; P.qpos_out = qpos_out ? b->d_qpos_out : nullptr;
+  rc = sensor_setup(b, spec, T, P);
+  if (rc != HB_OK) return rc;
+  rc = launch_steps(b, P, T);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipMemcpyAsync(sensor_out, b->d_sensor_out, (size_t)T * b->n_env * P.sensor_stride * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  if (qpos_out) HB_HIP(hipMemcpyAsync(qpos_out, b->d_qpos_out, nq_out * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
+}
+
+int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float* sensor_out) {
+  if (!b || !spec || !sensor_out) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  const size_t n = (size_t)b->n_env * b->D.dm.nu;
+  if (ctrl && n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  else if (n) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * sizeof(float), main_stream(b)));
+  BatchPtrs P = make_ptrs(b);
+  P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
+  int rc = sensor_setup(b, spec, 1, P);
+  if (rc != HB_OK) return rc;
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, 1, main_stream(b)));
+  HB_HIP(hipMemcpyAsync(sensor_out, b->d_sensor_out, (size_t)b->n_env * P.sensor_stride * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
+}
+
+int hb_set_state_broadcast(hb_batch* b, unsigned spec, const float* state) { return set_state_broadcast_impl<float>(b, spec, state); }
+int hb_set_state_broadcast_f64(hb_batch* b, unsigned spec, const double* state) { return set_state_broadcast_impl<double>(b, spec, state); }
 
 int hb_rollout_halton(hb_batch* b, int T, int t0, int env_offset, float* qpos_out_dev) {
   if (!b || T < 1) return HB_EINVAL;

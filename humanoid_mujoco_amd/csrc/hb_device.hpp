@@ -197,6 +197,10 @@ struct BatchPtrs {
   const int* order;    // [n_env]
   const float* dr;     // nullable [n_env][dr_stride]: per-env model parameters (DomainLayout)
   int dr_stride;
+  // sensor read-out (hb_rollout_sensors), nullable: [T][n_env][sensor_stride] = framepos of sensor_body[0..n) | subtreecom | subtreelinvel of tree sensor_tree
+  float* sensor_out;
+  int sensor_stride, sensor_nframe, sensor_tree;  // sensor_tree < 0: no subtree sensors
+  int sensor_body[16];
   const unsigned char* env_mask;  // nullable [n_env]: envs with a zero byte are skipped by this launch
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
 };

@@ -841,6 +841,28 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       }
       gsync();
     }
+    // sensor read-out for planner residuals (mj_sensorPos/Vel of framepos, subtreecom, subtreelinvel)
+    if (P.sensor_out) {
+      float* so = P.sensor_out + ((size_t)step * P.n_env + env) * P.sensor_stride;
+      for (int k = 0; k < P.sensor_nframe; k++)
+        if (lane < 3) so[3 * k + lane] = s_xpq[8 * P.sensor_body[k] + lane];
+      if (P.sensor_tree >= 0) {
+        const int t = P.sensor_tree;
+        const V3 com = ld3(s_scom + 3 * t);
+        // mj_subtreeVel for a whole tree: linear momentum over mass; a body's com moves with lin + ang x (xipos - com)
+        V3 mom = {0.f, 0.f, 0.f};
+        if (bl && __float_as_int(q1.y) == t) {
+          const V3 ang = {mycvel[0], mycvel[1], mycvel[2]}, lin = {mycvel[3], mycvel[4], mycvel[5]};
+          mom = (lin + cross(ang, ld3(s_xipos + 3 * myb) - com)) * mymass;
+        }
+        const float im = M.tree_invmass[t];
+        const float vx = wave_sum(mom.x) * im, vy = wave_sum(mom.y) * im, vz = wave_sum(mom.z) * im;
+        if (lane < 3) {
+          so[3 * P.sensor_nframe + lane] = lane == 0 ? com.x : (lane == 1 ? com.y : com.z);
+          so[3 * P.sensor_nframe + 3 + lane] = lane == 0 ? vx : (lane == 1 ? vy : vz);
+        }
+      }
+    }
     // body-local force cinert cacc + cvel x* (cinert cvel), and the composite inertia seeds, all bodies at once
     if (bl) {
       float in[10], f0[6], f1[6], f2[6];

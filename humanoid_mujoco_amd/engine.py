@@ -60,6 +60,11 @@ class HbEnvRandomization(ctypes.Structure):
                 ("push_max_duration", ctypes.c_float), ("push_min_force", ctypes.c_float), ("push_max_force", ctypes.c_float)]
 
 
+class HbSensorSpec(ctypes.Structure):
+    """hb_sensor_spec (include/hb.h): framepos bodies and the tree whose subtreecom / subtreelinvel are read out."""
+    _fields_ = [("n_framepos", ctypes.c_int), ("framepos_body", ctypes.c_int * 16), ("subtree_body", ctypes.c_int)]
+
+
 class HbDomainRandomization(ctypes.Structure):
     """hb_domain_randomization (include/hb.h): per-env model parameters drawn at reset."""
     _fields_ = [("factor", ctypes.c_float), ("seed", ctypes.c_uint), ("friction_min_mult", ctypes.c_float), ("friction_max_mult", ctypes.c_float),
@@ -124,6 +129,11 @@ def lib():
     L.hb_env_default_domain_randomization.argtypes = [vp, ctypes.POINTER(HbDomainRandomization)]
     L.hb_env_domain_randomize.argtypes = [vp, ctypes.POINTER(HbDomainRandomization)]
     L.hb_env_get_domain_params.argtypes = [vp, vp]
+    L.hb_sensor_size.argtypes = [ctypes.POINTER(HbSensorSpec)]
+    L.hb_set_state_broadcast.argtypes = [vp, cu, vp]
+    L.hb_set_state_broadcast_f64.argtypes = [vp, cu, vp]
+    L.hb_rollout_sensors.argtypes = [vp, vp, ci, ctypes.POINTER(HbSensorSpec), vp, vp]
+    L.hb_sensors.argtypes = [vp, vp, ctypes.POINTER(HbSensorSpec), vp]
     L.hb_env_reset.argtypes = [vp, vp]
     L.hb_env_step.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.hb_env_step_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp]
@@ -347,6 +357,47 @@ class Batch:
     def contacts(self):
         out = np.zeros((self.n_env, self.model.ncon_max, 16), dtype=np.float32)
         _check(lib().hb_get_contacts(self._h, _ptr(out)), "hb_get_contacts")
+        return out
+
+    # ---- planner rollouts (MJPC Trajectory::Rollout analogue)
+    @staticmethod
+    def sensor_spec(framepos_bodies=(), subtree_body=-1):
+        sp = HbSensorSpec()
+        sp.n_framepos = len(framepos_bodies)
+        for k, bd in enumerate(framepos_bodies):
+            sp.framepos_body[k] = int(bd)
+        sp.subtree_body = int(subtree_body)
+        return sp
+
+    def set_state_broadcast(self, spec, state):
+        """One state record on every env (the common start of a sampling planner's candidates)."""
+        s = np.ascontiguousarray(state)
+        if s.dtype == np.float64:
+            _check(lib().hb_set_state_broadcast_f64(self._h, spec, _ptr(s)), "hb_set_state_broadcast_f64")
+        else:
+            s = s.astype(np.float32)
+            _check(lib().hb_set_state_broadcast(self._h, spec, _ptr(s)), "hb_set_state_broadcast")
+
+    def rollout_sensors(self, ctrl, spec, want_qpos=False):
+        """ctrl [T, n_env, nu] -> sensors [T, n_env, ns] (evaluated before each step's integration), qpos [T, n_env, nq] or None."""
+        c = np.ascontiguousarray(ctrl, dtype=np.float32)
+        T = c.shape[0]
+        assert c.shape == (T, self.n_env, self.model.nu), c.shape
+        ns = lib().hb_sensor_size(ctypes.byref(spec))
+        if ns <= 0:
+            raise HbError("hb_sensor_size: invalid sensor spec")
+        out = np.zeros((T, self.n_env, ns), dtype=np.float32)
+        q = np.zeros((T, self.n_env, self.model.nq), dtype=np.float32) if want_qpos else None
+        _check(lib().hb_rollout_sensors(self._h, _ptr(c), T, ctypes.byref(spec), _ptr(out), _ptr(q)), "hb_rollout_sensors")
+        return out, q
+
+    def sensors(self, spec, ctrl=None):
+        ns = lib().hb_sensor_size(ctypes.byref(spec))
+        if ns <= 0:
+            raise HbError("hb_sensor_size: invalid sensor spec")
+        out = np.zeros((self.n_env, ns), dtype=np.float32)
+        c = None if ctrl is None else np.ascontiguousarray(ctrl, dtype=np.float32)
+        _check(lib().hb_sensors(self._h, _ptr(c), ctypes.byref(spec), _ptr(out)), "hb_sensors")
         return out
 
     # ---- env adapter (CPUEnv.step/reset analogue)

@@ -142,6 +142,30 @@ int hb_rollout_halton(hb_batch* b, int T, int t0, int env_offset, float* qpos_ou
 /* Replaces mj_forward (mujoco.h:129): recompute everything up to qacc without integrating. */
 int hb_forward(hb_batch* b, const float* ctrl);
 
+/* ---- planner rollouts (MJPC's Trajectory::Rollout, mujoco_mpc/mjpc/trajectory.cc:100-210) -------------------- */
+
+/* The sensors MJPC's humanoid tasks build their residuals from (tasks/humanoid_cap/stand/task.xml:22-40): framepos of
+ * up to 16 bodies, and subtreecom / subtreelinvel (mj_subtreeVel, mujoco.h:346) of one kinematic tree, named by its root
+ * body (a direct child of the world; < 0: none).  Per env and step the read-out is
+ * [framepos 0 (3) | ... | subtreecom (3) | subtreelinvel (3)], hb_sensor_size() floats. */
+#define HB_MAX_FRAMEPOS 16
+typedef struct hb_sensor_spec {
+  int n_framepos;
+  int framepos_body[HB_MAX_FRAMEPOS];
+  int subtree_body;
+} hb_sensor_spec;
+int hb_sensor_size(const hb_sensor_spec* spec);
+/* mj_setState of ONE state on every env: the N candidate action sequences of a sampling planner all start from the
+ * current state (sampling/planner.cc:342-380).  `state` is one record of hb_state_size(b, spec) floats. */
+int hb_set_state_broadcast(hb_batch* b, unsigned spec, const float* state);
+int hb_set_state_broadcast_f64(hb_batch* b, unsigned spec, const double* state);
+/* hb_rollout plus the sensor read-out of every step: sensor_out[t][e][:] holds the sensors mj_step evaluates at the
+ * state BEFORE step t's integration (what mjData.sensordata holds after the t-th mj_step call).  Host pointers;
+ * qpos_out nullable. */
+int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_spec* spec, float* sensor_out, float* qpos_out);
+/* The same read-out at the current state (mj_forward, no integration): the terminal residual of a trajectory. */
+int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float* sensor_out);
+
 /* Replaces mj_stateSize / mj_getState / mj_setState (mujoco.h:378-384). */
 int hb_state_size(const hb_batch* b, unsigned spec);
 int hb_get_state(hb_batch* b, unsigned spec, float* out);

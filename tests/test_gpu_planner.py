@@ -1,0 +1,83 @@
+"""the batched rollout backend of a sampling planner (MJPC's Trajectory::Rollout,
+mujoco_mpc/mjpc/trajectory.cc:100-210; candidates from one state, sampling/planner.cc:342-380) — N action
+sequences from one common state in one launch, with the sensor read-out the humanoid tasks' residuals use
+(framepos, subtreecom, subtreelinvel: tasks/humanoid_cap/stand/task.xml:22-40), against the fp64 oracle."""
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_sensors(o, bodies, nb):
+    xpos = o.xpos.reshape(nb, 3)
+    mass = o.marr("body_mass")
+    com = o.subtree_com.reshape(nb, 3)[1]  # the humanoid is one tree rooted at body 1
+    cvel = o.cvel.reshape(nb, 6)
+    xipos = o.xipos.reshape(nb, 3)
+    v = cvel[:, 3:] + np.cross(cvel[:, :3], xipos - com)  # mj_subtreeVel: a body's com moves with lin + ang x (xipos - com)
+    linvel = (mass[1:, None] * v[1:]).sum(0) / mass[1:].sum()
+    return np.concatenate([xpos[bodies].ravel(), com, linvel])
+
+
+def test_candidates_from_one_state_with_sensor_readout(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    N, T, nb = 24, 30, 17
+    head, foot_r, foot_l = m.name2id("body", "head"), m.name2id("body", "foot_right"), m.name2id("body", "foot_left")
+    torso = m.name2id("body", "torso")
+    assert min(head, foot_r, foot_l, torso) > 0
+    spec = hbmod.Batch.sensor_spec([head, foot_r, foot_l], subtree_body=torso)
+    # the common start: a mid-fall state from the oracle (moving, in contact)
+    o = Oracle()
+    o.init_env(3)
+    for t in range(150):
+        o.ctrl[:] = o.ctrl_env(t, 3); o.step()
+    start = np.concatenate([[o.time], o.qpos, o.qvel, o.qacc_warmstart])
+    rng = np.random.default_rng(6)
+    actions = rng.uniform(-1, 1, size=(T, N, m.nu)).astype(np.float32)
+    b = hbmod.Batch(m, N, gpu)
+    b.set_state_broadcast(hbmod.STATE_INTEGRATION, start)
+    assert np.allclose(b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64), start[None], atol=1e-6)
+    sens, qpos = b.rollout_sensors(actions, spec, want_qpos=True)
+    assert sens.shape == (T, N, 15) and qpos.shape == (T, N, m.nq)
+    assert not b.status().any()  # no failure flags (CheckWarnings, utilities.cc:787-799)
+    # candidate k against the oracle driven with the same action sequence, teacher-forced per step from the device
+    # states (free-running fp32 vs fp64 decorrelates in contact; the sensors are a function of the state)
+    for k in (0, 7, 23):
+        o.reset()
+        for t in range(T):
+            if t == 0:
+                o.qpos[:] = start[1:1 + m.nq]; o.qvel[:] = start[1 + m.nq:1 + m.nq + m.nv]
+            else:
+                o.qpos[:] = qpos[t - 1, k]
+                o.qvel[:] = qvel_prev
+            o.ctrl[:] = actions[t, k]
+            o.forward()
+            ref = oracle_sensors(o, [head, foot_r, foot_l], nb)
+            assert np.abs(sens[t, k] - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), (k, t, np.abs(sens[t, k] - ref).max())
+            # advance the oracle one step to obtain the velocity the device state has next (positions come from qpos_out)
+            o.step()
+            qvel_prev = o.qvel.copy()
+            if t == 0:
+                assert np.abs(o.qpos - qpos[0, k]).max() < 1e-4
+    # the candidates differ, and the terminal read-out (mj_forward at the final state) matches a fresh evaluation
+    assert np.abs(sens[-1, 0] - sens[-1, 1]).max() > 1e-4
+    term = b.sensors(spec)
+    q_end, v_end = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
+    o.reset(); o.qpos[:] = q_end[5]; o.qvel[:] = v_end[5]; o.forward()
+    ref = oracle_sensors(o, [head, foot_r, foot_l], nb)
+    assert np.abs(term[5] - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_sensor_spec_checks(hbmod, humanoid_model, gpu):
+    m = humanoid_model
+    b = hbmod.Batch(m, 4, gpu)
+    with pytest.raises(hbmod.HbError):
+        b.sensors(hbmod.Batch.sensor_spec([99]))                      # no such body
+    with pytest.raises(hbmod.HbError):
+        b.sensors(hbmod.Batch.sensor_spec([1], subtree_body=2))       # not the root of a tree
+    with pytest.raises(hbmod.HbError):
+        b.sensors(hbmod.Batch.sensor_spec([]))                        # nothing to read
+    out = b.sensors(hbmod.Batch.sensor_spec([1]))
+    assert out.shape == (4, 3) and np.allclose(out, b.qpos[:, :3], atol=1e-6)  # torso frame position = free joint position

@@ -927,6 +927,95 @@ int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out) {
   return HB_OK;
 }
 
+// ---- agent.proto State <-> one env's state record (protobuf wire format, no protobuf dependency) ----
+namespace {
+size_t pb_varint(unsigned long long v, unsigned char* out) {
+  size_t n = 0;
+  do { unsigned char c = v & 0x7f; v >>= 7; if (v) c |= 0x80; if (out) out[n] = c; n++; } while (v);
+  return n;
+}
+// appends `tag`, and for packed doubles the byte length, then the little-endian doubles; counts when out == nullptr
+size_t pb_doubles(int field, const double* v, int n, bool packed, unsigned char* out) {
+  size_t k = 0;
+  k += pb_varint(((unsigned long long)field << 3) | (packed ? 2 : 1), out ? out + k : nullptr);
+  if (packed) k += pb_varint((unsigned long long)n * 8, out ? out + k : nullptr);
+  if (out) memcpy(out + k, v, (size_t)n * 8);  // hosts of this engine are little-endian
+  return k + (size_t)n * 8;
+}
+bool pb_read_varint(const unsigned char* buf, int len, int& pos, unsigned long long& v) {
+  v = 0;
+  for (int shift = 0; pos < len && shift < 64; shift += 7) {
+    const unsigned char c = buf[pos++];
+    v |= (unsigned long long)(c & 0x7f) << shift;
+    if (!(c & 0x80)) return true;
+  }
+  return false;
+}
+}  // namespace
+
+int hb_state_to_proto(hb_batch* b, int env, unsigned char* buf, int cap) {
+  if (!b || env < 0 || env >= b->n_env || cap < 0) return HB_EINVAL;
+  const Model& m = b->model->m;
+  const int ns = b->D.dm.nstate;
+  std::vector<float> rec(ns);
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  HB_HIP(hipMemcpy(rec.data(), b->d_state + (size_t)env * ns, (size_t)ns * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<double> d(rec.begin(), rec.end());
+  const size_t need = pb_doubles(1, &d[0], 1, false, nullptr) + pb_doubles(2, &d[1], m.nq, true, nullptr) + pb_doubles(3, &d[1 + m.nq], m.nv, true, nullptr);
+  if (buf && (size_t)cap >= need) {
+    size_t k = pb_doubles(1, &d[0], 1, false, buf);
+    k += pb_doubles(2, &d[1], m.nq, true, buf + k);
+    k += pb_doubles(3, &d[1 + m.nq], m.nv, true, buf + k);
+  }
+  return (int)need;
+}
+
+int hb_state_from_proto(hb_batch* b, int env, const unsigned char* buf, int len) {
+  if (!b || env < 0 || env >= b->n_env || !buf || len < 0) return HB_EINVAL;
+  const Model& m = b->model->m;
+  const int ns = b->D.dm.nstate;
+  std::vector<float> rec(ns);
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  HB_HIP(hipMemcpy(rec.data(), b->d_state + (size_t)env * ns, (size_t)ns * sizeof(float), hipMemcpyDeviceToHost));
+  int pos = 0, nqpos = 0, nqvel = 0;  // repeated doubles may arrive packed or one by one; both are appended in order
+  bool touched = false;
+  while (pos < len) {
+    unsigned long long key, l;
+    if (!pb_read_varint(buf, len, pos, key)) return HB_EINVAL;
+    const int field = (int)(key >> 3), wt = (int)(key & 7);
+    if (wt == 1) {  // one double
+      if (pos + 8 > len) return HB_EINVAL;
+      double v; memcpy(&v, buf + pos, 8); pos += 8;
+      if (field == 1) rec[0] = (float)v;
+      else if (field == 2) { if (nqpos >= m.nq) return HB_EINVAL; rec[1 + nqpos++] = (float)v; }
+      else if (field == 3) { if (nqvel >= m.nv) return HB_EINVAL; rec[1 + m.nq + nqvel++] = (float)v; }
+      else if (field >= 4 && field <= 7) return HB_EUNSUPPORTED;
+      touched = true;
+    } else if (wt == 2) {  // packed doubles (or an unknown length-delimited field)
+      if (!pb_read_varint(buf, len, pos, l) || l > (unsigned long long)(len - pos)) return HB_EINVAL;
+      if (field >= 4 && field <= 7) { if (l) return HB_EUNSUPPORTED; }
+      else if (field == 2 || field == 3) {
+        if (l % 8) return HB_EINVAL;
+        for (unsigned long long k = 0; k < l / 8; k++) {
+          double v; memcpy(&v, buf + pos + 8 * k, 8);
+          if (field == 2) { if (nqpos >= m.nq) return HB_EINVAL; rec[1 + nqpos++] = (float)v; }
+          else { if (nqvel >= m.nv) return HB_EINVAL; rec[1 + m.nq + nqvel++] = (float)v; }
+        }
+        touched = true;
+      }
+      pos += (int)l;
+    } else if (wt == 0) { if (!pb_read_varint(buf, len, pos, l)) return HB_EINVAL; }
+    else if (wt == 5) { if (pos + 4 > len) return HB_EINVAL; pos += 4; }
+    else return HB_EINVAL;
+  }
+  if ((nqpos && nqpos != m.nq) || (nqvel && nqvel != m.nv)) return HB_EINVAL;  // a partial vector is an error, an absent one is not
+  if (touched) for (int i = 0; i < m.nv; i++) rec[1 + m.nq + m.nv + i] = 0.f;
+  HB_HIP(hipMemcpy(b->d_state + (size_t)env * ns, rec.data(), (size_t)ns * sizeof(float), hipMemcpyHostToDevice));
+  return HB_OK;
+}
+
 int hb_sensor_size(const hb_sensor_spec* spec) {
   if (!spec || spec->n_framepos < 0 || spec->n_framepos > HB_MAX_FRAMEPOS) return HB_EINVAL;
   return 3 * spec->n_framepos + (spec->subtree_body >= 0 ? 6 : 0);

@@ -129,6 +129,8 @@ def lib():
     L.hb_env_default_domain_randomization.argtypes = [vp, ctypes.POINTER(HbDomainRandomization)]
     L.hb_env_domain_randomize.argtypes = [vp, ctypes.POINTER(HbDomainRandomization)]
     L.hb_env_get_domain_params.argtypes = [vp, vp]
+    L.hb_state_to_proto.argtypes = [vp, ci, vp, ci]
+    L.hb_state_from_proto.argtypes = [vp, ci, cp, ci]
     L.hb_sensor_size.argtypes = [ctypes.POINTER(HbSensorSpec)]
     L.hb_set_state_broadcast.argtypes = [vp, cu, vp]
     L.hb_set_state_broadcast_f64.argtypes = [vp, cu, vp]
@@ -358,6 +360,18 @@ class Batch:
         out = np.zeros((self.n_env, self.model.ncon_max, 16), dtype=np.float32)
         _check(lib().hb_get_contacts(self._h, _ptr(out)), "hb_get_contacts")
         return out
+
+    # ---- wire format: agent.proto State of one env
+    def state_to_proto(self, env):
+        n = lib().hb_state_to_proto(self._h, int(env), None, 0)
+        if n < 0:
+            _check(n, "hb_state_to_proto")
+        buf = ctypes.create_string_buffer(n)
+        _check(min(0, lib().hb_state_to_proto(self._h, int(env), buf, n)), "hb_state_to_proto")
+        return buf.raw
+
+    def state_from_proto(self, env, data):
+        _check(lib().hb_state_from_proto(self._h, int(env), bytes(data), len(data)), "hb_state_from_proto")
 
     # ---- planner rollouts (MJPC Trajectory::Rollout analogue)
     @staticmethod

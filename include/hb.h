@@ -142,6 +142,19 @@ int hb_rollout_halton(hb_batch* b, int T, int t0, int env_offset, float* qpos_ou
 /* Replaces mj_forward (mujoco.h:129): recompute everything up to qacc without integrating. */
 int hb_forward(hb_batch* b, const float* ctrl);
 
+/* ---- wire format of a state ------------------------------------------------------------ */
+
+/* One env's state as the `State` message of the reference's gRPC agent service (mujoco_mpc/mjpc/grpc/agent.proto:75-83:
+ * time = 1, qpos = 2, qvel = 3, act = 4, mocap_pos = 5, mocap_quat = 6, userdata = 7; doubles, repeated fields packed),
+ * in protobuf wire encoding, so that existing clients' GetState / SetState payloads can be produced and consumed
+ * without a protobuf dependency.  This engine has no activations, mocap bodies or user data: those fields are not
+ * written, and a message that carries any of them is refused (HB_EUNSUPPORTED).
+ * hb_state_to_proto returns the number of bytes the message takes (also when buf is NULL or cap is too small: call
+ * twice), hb_state_from_proto sets the fields present (absent ones keep their values; qacc_warmstart is reset to 0 as
+ * mj_setState leaves it for a new state). */
+int hb_state_to_proto(hb_batch* b, int env, unsigned char* buf, int cap);
+int hb_state_from_proto(hb_batch* b, int env, const unsigned char* buf, int len);
+
 /* ---- planner rollouts (MJPC's Trajectory::Rollout, mujoco_mpc/mjpc/trajectory.cc:100-210) -------------------- */
 
 /* The sensors MJPC's humanoid tasks build their residuals from (tasks/humanoid_cap/stand/task.xml:22-40): framepos of

@@ -1406,34 +1406,37 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     if (lane < kNefcMax) s_force[lane] = rowact ? force : 0.f;
     gsync();
     HB_STAMP(13);
-    // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = W (y + s) ; qfrc_constraint = L^T D^1/2 s
+    // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = W (y + s)
+    // qfrc_constraint = L^T D^1/2 s is formed only for callers that read the joint torques (the env adapter's
+    // reward): the integrator does not need it (see mj_Euler below).
+    const bool want_qfrc = P.qfrc_out != nullptr;
     for (int k = lane; k < nv; k += kGroup) {
       float sacc = 0.f;
       for (int i = 0; i < nefc; i++) sacc += s_force[i] * s_C[i * cs + k];
-      s_v1[k] = sacc / s_dsqrtinv[k];  // D^1/2 s
-      s_v2[k] = yv[k] + sacc;          // y + s
+      if (want_qfrc) s_v1[k] = sacc / s_dsqrtinv[k];  // D^1/2 s
+      s_v2[k] = yv[k] + sacc;                          // y + s
     }
     gsync();
     {
-      float qacc_i = 0.f, rhs_i = 0.f;
+      float qacc_i = 0.f;
       if (lane < nv) {
         qacc_i = dot32(s_W + lane * kWs, s_v2);
-        float acc = s_v1[lane];
-        // descendants of this dof, four table entries in flight at a time (the table is padded by four)
-        const int t1 = M.desc_adr[lane + 1];
-        for (int t = M.desc_adr[lane]; t < t1; t += 4) {
-          int pk[4];
+        if (want_qfrc) {
+          float acc = s_v1[lane];
+          // descendants of this dof, four table entries in flight at a time (the table is padded by four)
+          const int t1 = M.desc_adr[lane + 1];
+          for (int t = M.desc_adr[lane]; t < t1; t += 4) {
+            int pk[4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) pk[q] = M.desc_pack[t + q];
+            for (int q = 0; q < 4; q++) pk[q] = M.desc_pack[t + q];
 #pragma unroll
-          for (int q = 0; q < 4; q++)
-            if (t + q < t1) acc += s_qLD[pk[q] >> 8].x * s_v1[pk[q] & 255];
+            for (int q = 0; q < 4; q++)
+              if (t + q < t1) acc += s_qLD[pk[q] >> 8].x * s_v1[pk[q] & 255];
+          }
+          P.qfrc_out[(size_t)env * nv + lane] = s_smooth[lane] + acc;  // qfrc_smooth + qfrc_constraint
         }
-        rhs_i = s_smooth[lane] + acc;  // qfrc_smooth + qfrc_constraint: right-hand side of the Euler solve
-        if (P.qfrc_out) P.qfrc_out[(size_t)env * nv + lane] = rhs_i;
+        s_v0[lane] = qacc_i;
       }
-      gsync();
-      if (lane < nv) { s_v0[lane] = qacc_i; s_v2[lane] = rhs_i; }
     }
     gsync();
     // mj_checkAcc
@@ -1443,7 +1446,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       if (__any(bad)) {
         status |= (1 << 6);
         for (int i = lane; i < nq; i += kGroup) s_qpos[i] = M.qpos0[i];
-        for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; s_v0[i] = 0.f; s_v2[i] = 0.f; }
+        for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; s_v0[i] = 0.f; }
         time = 0.f;
         gsync();
       }
@@ -1471,21 +1474,25 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     HB_STAMP(14);
     if (P.integrate) {
       // ---------------------------------------------------------------- mj_Euler: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint
+      // With H = M + h B and M qacc = qfrc_smooth + qfrc_constraint the solve is the same as
+      //   qacc' = qacc - H^-1 (h B qacc),
+      // which needs neither the right-hand side nor qfrc_constraint: only qacc and the damping vector.
       for (int i = lane; i < nv; i += kGroup) s_warm[i] = s_v0[i];  // qacc_warmstart <- qacc
       if (eulerdamp) {
-        // qacc' = H^-1 (qfrc_smooth + qfrc_constraint), H^-1 = W_H W_H^T; W_H is built in the (now dead) C rows
+        // H^-1 = W_H W_H^T; W_H and its transpose are built in the (now dead) C rows
         float* WH = s_C;
         float* WHT = s_C + 32 * kWs;  // runs on into the (dead) row-meta / W area behind C: the host checks the room
-        build_w<1, true>(M, s_qLD, s_dinv, s_dsqrtinv, WH, WHT, lane);
+        if (lane < nv) s_v2[lane] = M.timestep * M.dof_damping[lane] * s_v0[lane];  // h B qacc
+        build_w<1, true>(M, s_qLD, s_dinv, s_dsqrtinv, WH, WHT, lane);  // (its barriers also publish s_v2)
         float p = 0.f;
-        if (lane < nv) p = dot32(WHT + lane * kWs, s_v2);  // p = W_H^T rhs
+        if (lane < nv) p = dot32(WHT + lane * kWs, s_v2);  // W_H^T (h B qacc)
         gsync();
         if (lane < nv) s_v1[lane] = p;
         gsync();
         float q = 0.f;
         if (lane < nv) q = dot32(WH + lane * kWs, s_v1);
         gsync();
-        if (lane < nv) s_v2[lane] = q;
+        if (lane < nv) s_v2[lane] = s_v0[lane] - q;
         gsync();
       } else {
         for (int i = lane; i < nv; i += kGroup) s_v2[i] = s_v0[i];

@@ -405,7 +405,17 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     r[4] = (float)m.geom_rbound[g1]; r[5] = (float)m.geom_rbound[g2]; r[6] = (float)m.geom_size[3 * g1]; r[7] = (float)m.geom_size[3 * g1 + 1];
     r[8] = (float)m.geom_size[3 * g2]; r[9] = (float)m.geom_size[3 * g2 + 1];
   }
-  size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec), o_crec = T.addraw(crec);
+  // per fixed tendon, its first four wraps in one 3-quad record (a tendon with more falls back to the wrap tables):
+  // [0] coefficients   [1] qpos addresses   [2] dof addresses; unused slots have coefficient 0 and address 0
+  std::vector<float> trec((size_t)std::max(1, m.ntendon) * 12, 0.f);
+  for (int t = 0; t < m.ntendon; t++)
+    for (int w = 0; w < std::min(4, m.tendon_num[t]); w++) {
+      const int a = m.tendon_adr[t] + w;
+      trec[(size_t)t * 12 + w] = (float)m.wrap_prm[a];
+      trec[(size_t)t * 12 + 4 + w] = fi(wrap_qposadr[a]);
+      trec[(size_t)t * 12 + 8 + w] = fi(wrap_dofadr[a]);
+    }
+  size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec), o_crec = T.addraw(crec), o_trec = T.addraw(trec);
 
   // ---- upload
   if (hipMalloc((void**)&D.d_int, T.iv.size() * sizeof(int)) != hipSuccess || hipMalloc((void**)&D.d_flt, T.fv.size() * sizeof(float)) != hipSuccess ||
@@ -420,6 +430,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.drec = reinterpret_cast<const float4*>(D.d_flt + o_drec);
   dm.prec = reinterpret_cast<const float4*>(D.d_flt + o_prec);
   dm.crec = reinterpret_cast<const float4*>(D.d_flt + o_crec);
+  dm.trec = reinterpret_cast<const float4*>(D.d_flt + o_trec);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);

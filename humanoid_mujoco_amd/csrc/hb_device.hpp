@@ -90,6 +90,7 @@ struct DevModel {
   // tendons (fixed)
   const int HB_CONST *tendon_adr, *tendon_num, *wrap_dofadr, *wrap_qposadr;
   const float HB_CONST* wrap_prm;
+  const float4 HB_CONST* trec;  // per tendon, 3 float4: coefficients, qpos addresses, dof addresses of its first four wraps
   // actuators
   const int HB_CONST *act_qposadr, *act_dofadr, *act_ctrllimited, *act_forcelimited;
   const float HB_CONST *act_gear, *act_ctrlrange, *act_forcerange, *act_gain, *act_bias;

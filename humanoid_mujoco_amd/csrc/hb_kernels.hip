@@ -777,7 +777,11 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     // fixed tendon lengths
     for (int t = lane; t < M.ntendon; t += kGroup) {
       float len = 0.f;
-      for (int w = 0; w < M.tendon_num[t]; w++) len += M.wrap_prm[M.tendon_adr[t] + w] * s_qpos[M.wrap_qposadr[M.tendon_adr[t] + w]];
+      // the first four wraps come in one record (no dependent table walk); longer tendons finish from the wrap tables
+      const float4 tc = M.trec[3 * t], tq = M.trec[3 * t + 1];
+      len = tc.x * s_qpos[__float_as_int(tq.x)] + tc.y * s_qpos[__float_as_int(tq.y)] + tc.z * s_qpos[__float_as_int(tq.z)] + tc.w * s_qpos[__float_as_int(tq.w)];
+      const int nw = M.tendon_num[t];
+      for (int w = 4; w < nw; w++) len += M.wrap_prm[M.tendon_adr[t] + w] * s_qpos[M.wrap_qposadr[M.tendon_adr[t] + w]];
       s_tenlen[t] = len;
     }
     gsync();

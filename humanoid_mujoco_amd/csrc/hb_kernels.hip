@@ -1128,10 +1128,11 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         incl = c[C_DIST] < includemargin;
         myrows = incl ? (M.pair_dim[pairid] == 1 ? 1 : 4) : 0;
       }
-      int scan = myrows;  // inclusive scan
-#pragma unroll
-      for (int o = 1; o < kGroup; o <<= 1) { int v = __shfl_up(scan, o, kGroup); if (lane >= o) scan += v; }
-      int base = nefc + scan - myrows;
+      // rows before this contact: a contact has 0, 1 or 4 rows, so the exclusive prefix sum is two ballots and two
+      // population counts (no cross-lane shuffles)
+      const unsigned long long lower = (1ull << lane) - 1ull;
+      const unsigned long long one_row = __ballot(myrows == 1), four_rows = __ballot(myrows == 4);
+      int base = nefc + __popcll(one_row & lower) + 4 * __popcll(four_rows & lower);
       bool fits = base + myrows <= kNefcMax;
       if (lane < ncon) {
         float* c = s_con + lane * kConStride;
@@ -1141,10 +1142,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       }
       if (__ballot(lane < ncon && incl && !fits)) status |= (1 << 2);
       // contacts are materialised in order; once one does not fit, none of the later ones does
-      int endrow = (lane < ncon && incl && fits) ? base + myrows : nefc;
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) endrow = max(endrow, __shfl_xor(endrow, m, kGroup));
-      const int nefc_after = uniform(endrow);
+      // (bases grow with the lane: the last contact that fits ends the rows)
+      const unsigned long long placed = __ballot(lane < ncon && incl && fits);
+      const int nefc_after = placed ? __builtin_amdgcn_readlane(base + myrows, 63 - __builtin_clzll(placed)) : nefc;
       gsync();
       // Jacobian rows: uniform loop over contacts, lanes over dofs.  The pair id and first row of contact ci come
       // out of the lanes that own them (v_readlane); everything the pair contributes is one 5-quad record, fetched

@@ -1303,7 +1303,10 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       const bool v0 = col < nefc, v1 = 32 + col < nefc;
       const float* A0p = s_C + col * cs + half;
       const float* A1p = s_C + (32 + col) * cs + half;
-      const float R0 = __shfl(R, col, kGroup), R1 = __shfl(R, 32 + col, kGroup);
+      // R of rows col and 32 + col in every lane: one v_permlane32_swap of R with itself (x: the lower half copied
+      // up, y: the upper half copied down)
+      const u32x2 rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(R), __float_as_uint(R), false, false);
+      const float R0 = __uint_as_float(rr.x), R1 = __uint_as_float(rr.y);
       f32x16 X0, Y0, X1, Y1;
 #pragma unroll
       for (int r = 0; r < 16; r++) {

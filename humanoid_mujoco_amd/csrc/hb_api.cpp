@@ -315,6 +315,14 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     if (m.jnt_type[j] == JNT_HINGE || m.jnt_type[j] == JNT_SLIDE) nscalar++;
   }
   dm.nobs = 2 * nscalar + 6;
+  // observation gather table: state-record offsets of the scalar joints' qpos and qvel, then the root's angular
+  // velocity (3) - the first nobs - 3 observation entries are plain copies out of the state record
+  std::vector<int> obs_src;
+  for (int j = 0; j < m.njnt; j++) if (m.jnt_type[j] == JNT_HINGE || m.jnt_type[j] == JNT_SLIDE) obs_src.push_back(1 + m.jnt_qposadr[j]);
+  for (int j = 0; j < m.njnt; j++) if (m.jnt_type[j] == JNT_HINGE || m.jnt_type[j] == JNT_SLIDE) obs_src.push_back(1 + m.nq + m.jnt_dofadr[j]);
+  for (int i = 0; i < 3; i++) obs_src.push_back(dm.obs_root_dofadr >= 0 ? 1 + m.nq + dm.obs_root_dofadr + 3 + i : -1);
+  dm.obs_root_qadr = -1;
+  for (int j = 0; j < m.njnt; j++) if (m.jnt_type[j] == JNT_FREE) { dm.obs_root_qadr = m.jnt_qposadr[j]; break; }
 
   // level-ordered body records, dof records, packed M entries (layouts in hb_device.hpp)
   std::vector<float> brec((size_t)nb * kBrecQuads * 4, 0.f);
@@ -372,6 +380,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TF(pair_friction, pair_fr); TF(pair_solref, pair_solref); TF(pair_solimp, pair_solimp); TF(pair_margin, pair_margin); TF(pair_gap, pair_gap);
   TI(lim_kind, lim_kind); TI(lim_id, lim_id); TI(lim_side, lim_side);
   TF(lim_range, lim_range); TF(lim_margin, lim_margin); TF(lim_solref, lim_solref); TF(lim_solimp, lim_solimp); TF(lim_invweight, lim_invw);
+  TI(obs_src, obs_src);
   TI(tendon_adr, m.tendon_adr); TI(tendon_num, m.tendon_num); TI(wrap_dofadr, wrap_dofadr); TI(wrap_qposadr, wrap_qposadr);
   TF(wrap_prm, m.wrap_prm);
   TI(act_qposadr, act_qposadr); TI(act_dofadr, act_dofadr); TI(act_ctrllimited, m.actuator_ctrllimited); TI(act_forcelimited, m.actuator_forcelimited);

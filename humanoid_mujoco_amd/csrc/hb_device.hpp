@@ -95,7 +95,8 @@ struct DevModel {
   const int HB_CONST *act_qposadr, *act_dofadr, *act_ctrllimited, *act_forcelimited;
   const float HB_CONST *act_gear, *act_ctrlrange, *act_forcerange, *act_gain, *act_bias;
   // env adapter
-  int obs_root_body, obs_root_dofadr;
+  int obs_root_body, obs_root_dofadr, obs_root_qadr;
+  const int HB_CONST* obs_src;  // [nobs - 3]: state-record offset each copied observation entry comes from (-1: zero)
   // LDS layout (float offsets per env) — persistent region
   int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qLD, o_dinv, o_dsqrtinv, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
   // region A (dynamics scratch)

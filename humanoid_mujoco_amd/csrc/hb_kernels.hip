@@ -1934,15 +1934,26 @@ __global__ __launch_bounds__(512) void hb_policy_kernel(const DevModel M, const 
   float* cur = sm;
   float* nxt = sm + 32 * ldx;
   float* part = sm + 64 * ldx;  // [8][32][32] partial tiles
-  if (tid < 32) {
-    float* o = cur + tid * ldx;
-    if (m0 + tid < n_env) {
-      float g[3], z;
-      compute_obs(M, state + (size_t)(m0 + tid) * M.nstate, o, g, &z);
-    } else {
-      for (int j = 0; j < M.nobs; j++) o[j] = 0.f;
+  // observation tile: 16 threads per env row gather the copied entries through the gather table (independent loads,
+  // all in flight at once), one thread per row derives the gravity direction from the root quaternion
+  {
+    const int row = tid >> 4, sub = tid & 15;
+    float* o = cur + row * ldx;
+    const bool live = m0 + row < n_env;
+    const float* s = state + (size_t)(m0 + row) * M.nstate;
+    const int ncopy = M.nobs - 3;
+    for (int k = sub; k < ncopy; k += 16) {
+      const int src = M.obs_src[k];
+      o[k] = (live && src >= 0) ? s[src] : 0.f;
     }
-    o[M.nobs] = 0.f;  // K is swept in pairs: the pad column must be finite
+    if (sub == 0) {
+      Q4 q = {1.f, 0.f, 0.f, 0.f};
+      if (live && M.obs_root_qadr >= 0) q = qnormalize(ldq(s + 1 + M.obs_root_qadr + 3));
+      float mm[9];
+      q2mat(mm, q);
+      o[ncopy] = live ? -mm[6] : 0.f; o[ncopy + 1] = live ? -mm[7] : 0.f; o[ncopy + 2] = live ? -mm[8] : 0.f;
+      o[M.nobs] = 0.f;  // K is swept in pairs: the pad column must be finite
+    }
   }
   __syncthreads();
   const int col = lane & 31, half = lane >> 5;

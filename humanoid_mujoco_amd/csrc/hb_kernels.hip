@@ -1380,7 +1380,10 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       // The reference reverts a row whose cost change is > 1e-10.  For scalar rows that is unreachable:
       // the unclamped step gives -0.5 res^2 / AR_ii, the clamped one -f (res - 0.5 f AR_ii) with
       // res > f AR_ii, both <= 0; the oracle counts its reverts and the tests assert zero.
-      while (niter < M.iterations) {
+      // (the solver options are read once: a scalar load inside the sweep loop is a memory round trip per sweep)
+      const int max_sweeps = M.iterations;
+      const float pgs_tol = M.tolerance, pgs_scale = M.pgs_scale;
+      while (niter < max_sweeps) {
         int ne;
         asm volatile("s_mov_b32 %0, %1" : "=s"(ne) : "s"(nefc));
         const float nforce = -force, res0 = res;
@@ -1407,7 +1410,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         force += delta;  // a clamped row lands on exactly 0
         const float improvement = -0.5f * wave_sum(delta * (res0 + res));
         niter++;
-        if (improvement * M.pgs_scale < M.tolerance) break;
+        if (improvement * pgs_scale < pgs_tol) break;
       }
     }
     if (lane < kNefcMax) s_force[lane] = rowact ? force : 0.f;

@@ -499,7 +499,7 @@ struct hb_batch {
   long long launch_count = 0;
   int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
   int order_mode = 0;       // 0: none yet, 1: one permutation of the whole batch, 2: one permutation per pipe segment
-  bool schedule = true;
+  bool schedule = getenv("HB_NO_SCHEDULE") == nullptr;  // heavy-first dispatch order (experiments can switch it off)
   // Pipelined stepping (hb_batch_pipeline): the batch is cut into npipe fixed env segments, each stepped by
   // its own launch on its own stream.  Envs are independent, so segment c of step t+1 only has to follow
   // segment c of step t: the tail of one step (its slowest envs) overlaps the head of the next.  `stream`

@@ -1441,13 +1441,13 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
     if (!weights[l] || !biases[l]) return HB_EINVAL;
     if (b->d_mlp_wp[l]) { HB_IGN(hipFree(b->d_mlp_wp[l])); b->d_mlp_wp[l] = nullptr; }
     if (fused) {
-      // B-operand order of v_mfma_f32_32x32x2_f32: wp[tile][k/2][lane] = W[2(k/2) + lane/32][32 tile + lane%32], zero padded
-      const int K = sizes[l], N = sizes[l + 1], KK = (K + 1) / 2, ntile = (N + 31) / 32;
+      // B-operand order of v_mfma_f32_16x16x4_f32: wp[tile][k/4][lane] = W[4(k/4) + lane/16][16 tile + lane%16], zero padded
+      const int K = sizes[l], N = sizes[l + 1], KK = (K + 3) / 4, ntile = (N + 15) / 16;
       std::vector<float> wp((size_t)ntile * KK * 64, 0.f);
       for (int nt = 0; nt < ntile; nt++)
         for (int kk = 0; kk < KK; kk++)
           for (int ln = 0; ln < 64; ln++) {
-            const int k = 2 * kk + (ln >> 5), n = 32 * nt + (ln & 31);
+            const int k = 4 * kk + (ln >> 4), n = 16 * nt + (ln & 15);
             if (k < K && n < N) wp[((size_t)nt * KK + kk) * 64 + ln] = weights[l][(size_t)k * N + n];
           }
       if (hipMalloc((void**)&b->d_mlp_wp[l], wp.size() * sizeof(float)) != hipSuccess) return HB_ENOMEM;
@@ -1482,7 +1482,7 @@ static int policy_forward(hb_batch* b, int lo, int hi, hipStream_t st) {
     int widest = 1;
     for (int l = 0; l <= b->mlp_layers; l++) { pd.sizes[l] = b->mlp_sizes[l]; widest = std::max(widest, b->mlp_sizes[l]); }
     for (int l = 0; l < b->mlp_layers; l++) { pd.w[l] = b->d_mlp_wp[l]; pd.b[l] = b->d_mlp_b[l]; }
-    pd.ldx = widest + 1;
+    pd.ldx = widest + 4;  // + the K pad columns (K is swept four at a time); 16-row tiles
     HB_HIP(launch_policy(dm, pd, b->d_state + (size_t)lo * dm.nstate, b->d_ctrl + (size_t)lo * dm.nu, hi - lo, st));
     return HB_OK;
   }

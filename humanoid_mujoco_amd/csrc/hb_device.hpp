@@ -175,7 +175,7 @@ struct PolicyDesc {
   int sizes[5];
   const float* w[4];
   const float* b[4];
-  int ldx;  // LDS row stride of an activation tile: widest layer + 1 (odd or not, + 1 keeps the K pad column)
+  int ldx;  // LDS row stride of an activation tile: widest layer + 4 (K is swept four columns at a time: zero pad columns)
 };
 
 struct BatchPtrs {

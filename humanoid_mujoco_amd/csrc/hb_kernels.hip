@@ -1923,29 +1923,31 @@ __global__ __launch_bounds__(kGroup) void hb_mlp_layer_kernel(const float* X, co
   }
 }
 
-// The whole policy in one launch: observation -> every MLP layer -> controls, for 32 envs per block.
-// Activations never leave LDS (two ping-pong tiles of 32 rows); eight waves share the 32-column output tiles
-// of a layer, each sweeping K two columns per v_mfma_f32_32x32x2_f32 (exact f32) with the A operand from LDS
-// and the B operand from weights pre-packed on the host in operand order (one coalesced 256-byte wave load
-// per MFMA: wp[tile][k/2][lane] = W[2(k/2) + lane/32][32 tile + lane%32]).  A layer with fewer than eight
-// tiles (the nu-wide output layer) splits K across the idle waves instead; the partial tiles are summed in
-// a fixed order (deterministic, no atomics).
+// The whole policy in one launch: observation -> every MLP layer -> controls, for 16 envs per block (4096 envs = 256
+// blocks: one per CU; f32 MFMA throughput per CU is the bound, so the batch is spread over the whole chip).
+// Activations never leave LDS (two ping-pong tiles of 16 rows); eight waves share the 16-column output tiles of a
+// layer, each sweeping K four columns per v_mfma_f32_16x16x4_f32 (exact f32) with the A operand from LDS and the
+// B operand from weights pre-packed on the host in operand order (one coalesced 256-byte wave load per MFMA:
+// wp[tile][k/4][lane] = W[4(k/4) + lane/16][16 tile + lane%16]).  A layer with fewer than eight tiles (the
+// nu-wide output layer) splits K across the idle waves instead; the partial tiles are summed in a fixed order
+// (deterministic, no atomics).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512) void hb_policy_kernel(const DevModel M, const PolicyDesc pd, const float* state, float* ctrl, int n_env) {
   extern __shared__ float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * 32, ldx = pd.ldx;
+  const int m0 = blockIdx.x * 16, ldx = pd.ldx;
   float* cur = sm;
-  float* nxt = sm + 32 * ldx;
-  float* part = sm + 64 * ldx;  // [8][32][32] partial tiles
-  // observation tile: 16 threads per env row gather the copied entries through the gather table (independent loads,
+  float* nxt = sm + 16 * ldx;
+  float* part = sm + 32 * ldx;  // [8][16][16] partial tiles
+  // observation tile: 32 threads per env row gather the copied entries through the gather table (independent loads,
   // all in flight at once), one thread per row derives the gravity direction from the root quaternion
   {
-    const int row = tid >> 4, sub = tid & 15;
+    const int row = tid >> 5, sub = tid & 31;
     float* o = cur + row * ldx;
     const bool live = m0 + row < n_env;
     const float* s = state + (size_t)(m0 + row) * M.nstate;
     const int ncopy = M.nobs - 3;
-    for (int k = sub; k < ncopy; k += 16) {
+    for (int k = sub; k < ncopy; k += 32) {
       const int src = M.obs_src[k];
       o[k] = (live && src >= 0) ? s[src] : 0.f;
     }
@@ -1955,42 +1957,40 @@ __global__ __launch_bounds__(512) void hb_policy_kernel(const DevModel M, const 
       float mm[9];
       q2mat(mm, q);
       o[ncopy] = live ? -mm[6] : 0.f; o[ncopy + 1] = live ? -mm[7] : 0.f; o[ncopy + 2] = live ? -mm[8] : 0.f;
-      o[M.nobs] = 0.f;  // K is swept in pairs: the pad column must be finite
+      for (int k = M.nobs; k < M.nobs + 3; k++) o[k] = 0.f;  // K is swept four at a time: the pad columns must be finite
     }
   }
   __syncthreads();
-  const int col = lane & 31, half = lane >> 5;
+  const int col = lane & 15, quad = lane >> 4;  // A: row = col, k offset = quad;  B: k offset = quad, column = col;  D: rows 4 quad + r, column col
   for (int l = 0; l < pd.nl; l++) {
-    const int K = pd.sizes[l], N = pd.sizes[l + 1], KK = (K + 1) / 2, ntile = (N + 31) / 32;
+    const int K = pd.sizes[l], N = pd.sizes[l + 1], KK = (K + 3) / 4, ntile = (N + 15) / 16;
     const bool last = l + 1 == pd.nl;
     int S = 1;  // K slices per tile
     while (S * 2 * ntile <= 8) S *= 2;
     const float* wp = pd.w[l];
     const float* bias = pd.b[l];
-    if (!last && tid < 32) nxt[tid * ldx + N] = 0.f;
+    if (!last && tid < 48) nxt[(tid / 3) * ldx + N + tid % 3] = 0.f;  // pad columns of the next layer's input
     for (int it = wave; it < ntile * S; it += 8) {
       const int nt = it / S, sl = it - nt * S;
       const int kb = KK * sl / S, ke = KK * (sl + 1) / S;
-      f32x16 D;
-#pragma unroll
-      for (int r = 0; r < 16; r++) D[r] = 0.f;
-      const float* ap = cur + col * ldx + half;
+      f32x4v D = {0.f, 0.f, 0.f, 0.f};
+      const float* ap = cur + col * ldx + quad;
       const float* bp = wp + (size_t)nt * KK * 64 + lane;
       int kk = kb;
       for (; kk + 8 <= ke; kk += 8) {  // eight operand pairs in flight per batch of MFMAs
         float a[8], w[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { a[u] = ap[2 * (kk + u)]; w[u] = bp[(size_t)(kk + u) * 64]; }
+        for (int u = 0; u < 8; u++) { a[u] = ap[4 * (kk + u)]; w[u] = bp[(size_t)(kk + u) * 64]; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], w[u], D, 0, 0, 0);
+        for (int u = 0; u < 8; u++) D = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w[u], D, 0, 0, 0);
       }
-      for (; kk < ke; kk++) D = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bp[(size_t)kk * 64], D, 0, 0, 0);
-      const int n = nt * 32 + col;
+      for (; kk < ke; kk++) D = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk], bp[(size_t)kk * 64], D, 0, 0, 0);
+      const int n = nt * 16 + col;
       if (S == 1) {
         const float bn = n < N ? bias[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        for (int r = 0; r < 4; r++) {
+          const int row = 4 * quad + r;
           if (n < N) {
             const float v = tanhf(D[r] + bn);
             if (!last) nxt[row * ldx + n] = v;
@@ -1998,18 +1998,18 @@ __global__ __launch_bounds__(512) void hb_policy_kernel(const DevModel M, const 
           }
         }
       } else {
-        float* pp = part + it * 1024;
+        float* pp = part + it * 256;
 #pragma unroll
-        for (int r = 0; r < 16; r++) pp[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = D[r];
+        for (int r = 0; r < 4; r++) pp[(4 * quad + r) * 16 + col] = D[r];
       }
     }
     __syncthreads();
     if (S > 1) {
-      for (int idx = tid; idx < ntile * 1024; idx += 512) {
-        const int nt = idx >> 10, rc = idx & 1023, row = rc >> 5, n = nt * 32 + (rc & 31);
+      for (int idx = tid; idx < ntile * 256; idx += 512) {
+        const int nt = idx >> 8, rc = idx & 255, row = rc >> 4, n = nt * 16 + (rc & 15);
         if (n < N) {
           float v = bias[n];
-          for (int sl = 0; sl < S; sl++) v += part[(nt * S + sl) * 1024 + rc];
+          for (int sl = 0; sl < S; sl++) v += part[(nt * S + sl) * 256 + rc];
           v = tanhf(v);
           if (!last) nxt[row * ldx + n] = v;
           else if (m0 + row < n_env) ctrl[(size_t)(m0 + row) * N + n] = v;
@@ -2141,15 +2141,9 @@ hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, f
   return hipGetLastError();
 }
 hipError_t launch_policy(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, int n_env, hipStream_t stream) {
-  const size_t shmem = ((size_t)64 * pd.ldx + 8 * 1024) * sizeof(float);
-  static bool raised = false;  // > 64 KiB of dynamic LDS needs the attribute once per process
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)hb_policy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    raised = true;
-  }
+  const size_t shmem = ((size_t)32 * pd.ldx + 8 * 256) * sizeof(float);
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_policy_kernel, dim3((n_env + 31) / 32), dim3(512), shmem, stream, M, pd, state, ctrl, n_env);
+  hipLaunchKernelGGL(hb_policy_kernel, dim3((n_env + 15) / 16), dim3(512), shmem, stream, M, pd, state, ctrl, n_env);
   return hipGetLastError();
 }
 hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream) {

@@ -183,6 +183,33 @@ def test_ball_rests_on_plane(compiled):
     assert np.allclose(J[0] + J[1], J[2] + J[3])
 
 
+def test_sliding_friction_of_the_pyramidal_cone(compiled):
+    """A sphere set sliding on the plane along an axis of the contact frame decelerates at nearly mu*g (one pyramid
+    edge carries the normal load; the soft constraint keeps it a few percent under), and clearly less along the
+    diagonal, where two edges share the load: the L1 friction 'cone' of the pyramidal approximation (rigid limit
+    1/sqrt(2); the soft, hopping contact of this model gives about half)."""
+    acc = {}
+    for diag in (False, True):
+        o = Oracle(compiled["ball_plane"])
+        o.reset()
+        o.step(1500)
+        o.forward()
+        fr = o.contacts()[0]["frame"]
+        assert o.contacts()[0]["friction"] == pytest.approx(1.0)
+        d = fr[1] + fr[2] if diag else fr[1]
+        d = d / np.linalg.norm(d)
+        o.qvel[0:3] = 2.0 * d
+        vs = []
+        for t in range(20):
+            o.step()
+            vs.append(o.qvel[0:3] @ d)
+        acc[diag] = -(vs[19] - vs[0]) / (19 * 0.002)
+        lateral = o.qvel[0:3] - (o.qvel[0:3] @ d) * d
+        assert np.abs(lateral[:2]).max() < 0.02  # friction acts along the slip direction: no sideways drift
+    assert 0.88 * 9.81 < acc[False] < 1.001 * 9.81, acc
+    assert 0.4 < acc[True] / acc[False] < 0.8, acc
+
+
 def test_pgs_kkt(compiled):
     """After many sweeps the PGS solution satisfies the LCP: f >= 0, AR f + b >= 0, complementarity."""
     o = Oracle(compiled["capsules"])

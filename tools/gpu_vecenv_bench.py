@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Throughput of the env adapter (CPUEnv.step analogue): VecEnv.step with host actions and host observations, plain
+and with the full sim-to-real layer (noise, delays, pushes, domain randomisation)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import humanoid_mujoco_amd as hb
+model = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm")
+N, T = 4096, 600
+rng = np.random.default_rng(0)
+acts = rng.uniform(-1, 1, size=(8, N, 21)).astype(np.float32)
+for label, kw in (("plain", {}), ("realism + domain randomisation", dict(realism=True, domain_randomization=True, seed=1))):
+    env = hb.VecEnv(model, N, 0, randomization_factor=1.0, target_z=10.0, max_time=2.0, **kw)  # success unreachable: episodes run 400 steps
+    env.reset()
+    for t in range(20):
+        env.step(acts[t % 8])
+    t0 = time.perf_counter()
+    done = 0
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(acts[t % 8])
+        done += int(info["done"].sum())
+    dt = time.perf_counter() - t0
+    print("VecEnv.step (%s): %d envs x %d steps in %.3f s -> %.3e env-steps/s (%.0f us/step, host round trip included); %d episodes ended"
+          % (label, N, T, dt, N * T / dt, 1e6 * dt / T, done))
+    env.close()

@@ -1588,6 +1588,12 @@ void hb_dev_free(hb_batch* b, void* p) {
   HB_IGN(hipStreamSynchronize(main_stream(b)));
   HB_IGN(hipFree(p));
 }
+void* hb_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void hb_host_free(void* p) { if (p) HB_IGN(hipHostFree(p)); }
 int hb_memcpy_h2d(hb_batch* b, void* dst_dev, const void* src, uint64_t bytes) {
   if (!b || !dst_dev || !src) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));

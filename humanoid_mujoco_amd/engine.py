@@ -144,6 +144,8 @@ def lib():
     L.hb_rollout_policy.argtypes = [vp, ci, vp]
     L.hb_dev_alloc.restype = vp; L.hb_dev_alloc.argtypes = [vp, ctypes.c_uint64]
     L.hb_dev_free.restype = None; L.hb_dev_free.argtypes = [vp, vp]
+    L.hb_host_alloc.restype = vp; L.hb_host_alloc.argtypes = [ctypes.c_uint64]
+    L.hb_host_free.restype = None; L.hb_host_free.argtypes = [vp]
     L.hb_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_uint64]; L.hb_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_uint64]
     L.hb_halton_ctrl_dev.argtypes = [vp, ci, ci, ci, vp]
     L.hb_timer_start.argtypes = [vp]; L.hb_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -159,6 +161,24 @@ def _check(rc, what):
 
 def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class _Pinned:
+    """numpy array over page-locked host memory (hb_host_alloc): copies to and from it are DMA transfers."""
+
+    def __init__(self, shape, dtype):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib().hb_host_alloc(max(1, self.nbytes))
+        if not self.ptr:
+            raise HbError("hb_host_alloc(%d) failed" % self.nbytes)
+        buf = (ctypes.c_char * max(1, self.nbytes)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().hb_host_free(ctypes.c_void_p(self.ptr))
+            self.ptr = None
 
 
 class Model:
@@ -243,6 +263,9 @@ class Batch:
         if getattr(self, "_h", None):
             lib().hb_batch_free(self._h)
             self._h = None
+        for pb in (getattr(self, "_env_pin", None) or {}).values():
+            pb.free()
+        self._env_pin = None
 
     def __del__(self):
         try:
@@ -458,14 +481,18 @@ class Batch:
         return o
 
     def env_step(self, action, n_substeps=1):
-        a = np.ascontiguousarray(action, dtype=np.float32)
+        """action [n_env, nu] -> (obs, reward, terminated, truncated).  The transfer buffers are page-locked and reused:
+        the returned arrays are fresh copies, so the caller may keep them."""
+        pin = getattr(self, "_env_pin", None)
+        if pin is None:
+            pin = self._env_pin = dict(a=_Pinned((self.n_env, self.model.nu), np.float32), o=_Pinned((self.n_env, self.model.nobs), np.float32),
+                                       r=_Pinned((self.n_env,), np.float32), te=_Pinned((self.n_env,), np.uint8), tr=_Pinned((self.n_env,), np.uint8))
+        a = np.asarray(action, dtype=np.float32)
         assert a.shape == (self.n_env, self.model.nu), a.shape
-        o = np.zeros((self.n_env, self.model.nobs), dtype=np.float32)
-        r = np.zeros(self.n_env, dtype=np.float32)
-        te = np.zeros(self.n_env, dtype=np.uint8)
-        tr = np.zeros(self.n_env, dtype=np.uint8)
-        _check(lib().hb_env_step(self._h, _ptr(a), int(n_substeps), _ptr(o), _ptr(r), _ptr(te), _ptr(tr)), "hb_env_step")
-        return o, r, te.astype(bool), tr.astype(bool)
+        pin["a"].array[...] = a
+        _check(lib().hb_env_step(self._h, ctypes.c_void_p(pin["a"].ptr), int(n_substeps), ctypes.c_void_p(pin["o"].ptr), ctypes.c_void_p(pin["r"].ptr),
+                                 ctypes.c_void_p(pin["te"].ptr), ctypes.c_void_p(pin["tr"].ptr)), "hb_env_step")
+        return pin["o"].array.copy(), pin["r"].array.copy(), pin["te"].array.astype(bool), pin["tr"].array.astype(bool)
 
     # ---- policy in the loop (BASELINE config 4)
     def set_policy_mlp(self, weights, biases):

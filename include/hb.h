@@ -330,6 +330,11 @@ int hb_rollout_policy(hb_batch* b, int T, float* qpos_out_dev);
 /* Device buffer on the batch's GPU (hipMalloc / hipFree). */
 void* hb_dev_alloc(hb_batch* b, uint64_t bytes);
 void hb_dev_free(hb_batch* b, void* p);
+/* Page-locked host memory (hipHostMalloc / hipHostFree).  Host pointers handed to hb_step, hb_env_step, hb_get_obs ...
+ * may be any memory; when they are page-locked the copies are DMA transfers that overlap instead of staged ones
+ * (VecEnv keeps its action and observation arrays in such buffers). */
+void* hb_host_alloc(uint64_t bytes);
+void hb_host_free(void* p);
 int hb_memcpy_h2d(hb_batch* b, void* dst_dev, const void* src, uint64_t bytes);
 int hb_memcpy_d2h(hb_batch* b, void* dst, const void* src_dev, uint64_t bytes);
 /* Fills out_dev[T][n_env][nu] with the benchmark's deterministic controls, the generator of

@@ -246,6 +246,14 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   }
   desc_adr[nv] = (int)desc_pack.size();
   for (int i = 0; i < 4; i++) desc_pack.push_back(0);  // the half-solve reads four entries at a time
+  // the same lists transposed, [t][32 dofs], padded with a no-op entry (dof 0 times the factor storage's zero pad
+  // pair): lane i reads its t-th descendant with one coalesced load per t and no dependent walk
+  int maxdesc = 0;
+  for (int i = 0; i < nv; i++) maxdesc = std::max(maxdesc, desc_adr[i + 1] - desc_adr[i]);
+  std::vector<int> desc_t((size_t)std::max(1, maxdesc) * 32, 0 | (m.nM << 8));
+  for (int i = 0; i < nv; i++)
+    for (int t = desc_adr[i]; t < desc_adr[i + 1]; t++) desc_t[(size_t)(t - desc_adr[i]) * 32 + i] = desc_pack[t];
+  dm.ndesc_max = maxdesc;
   std::vector<int> chain((size_t)32 * (kMaxAnc + 1), 0);
   for (int i = 0; i < nv; i++) {
     int t = 0;
@@ -371,7 +379,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(body_treeid, treeid); TF(body_invweight0, m.body_invweight0); TF(tree_invmass, tree_invmass);
   TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TF(qpos0, m.qpos0); TI(dof_jntid, m.dof_jntid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TF(dof_damping, m.dof_damping); TI(M_j, Mj); TI(mrec, mrec);
   TI(fround, fround); TI(ftab, ftab);
-  TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(chain, chain);
+  TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(desc_t, desc_t); TI(chain, chain);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);

@@ -68,6 +68,8 @@ struct DevModel {
   int nfround, fpad_zero, fpad_one, fpad_dump;
   int ftop_n, ftop_adr[kFactorTop];  // dense tail of the factorisation: chain dofs root-first, address of each one's row
   const int HB_CONST *desc_adr, *desc_pack;  // descendants of each dof: k | address of L[k,i] << 8
+  const int HB_CONST* desc_t;    // the same, transposed and padded: [ndesc_max][32]
+  int ndesc_max;
   const int HB_CONST* chain;     // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)
   // geoms
   const int HB_CONST *geom_type, *geom_bodyid;

@@ -1433,15 +1433,15 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         qacc_i = dot32(s_W + lane * kWs, s_v2);
         if (want_qfrc) {
           float acc = s_v1[lane];
-          // descendants of this dof, four table entries in flight at a time (the table is padded by four)
-          const int t1 = M.desc_adr[lane + 1];
-          for (int t = M.desc_adr[lane]; t < t1; t += 4) {
-            int pk[4];
+          // descendants of this dof from the transposed, padded table: every load is independent of the others
+          // (eight in flight), no per-lane list walk
+          const int nd = M.ndesc_max;
+          for (int t = 0; t < nd; t += 8) {
+            int pk[8];
 #pragma unroll
-            for (int q = 0; q < 4; q++) pk[q] = M.desc_pack[t + q];
+            for (int q = 0; q < 8; q++) pk[q] = (t + q < nd) ? M.desc_t[(t + q) * 32 + lane] : (M.nM << 8);
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-              if (t + q < t1) acc += s_qLD[pk[q] >> 8].x * s_v1[pk[q] & 255];
+            for (int q = 0; q < 8; q++) acc += s_qLD[pk[q] >> 8].x * s_v1[pk[q] & 255];
           }
           P.qfrc_out[(size_t)env * nv + lane] = s_smooth[lane] + acc;  // qfrc_smooth + qfrc_constraint
         }

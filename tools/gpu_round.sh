@@ -28,6 +28,6 @@ timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_V
 timeout -k 10 200 python tools/gpu_pipeline_sweep.py > $OUT/pipeline_sweep.txt 2>&1; echo "sweep rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_phase_profile.py 4096 > $OUT/phase_profile.txt 2>&1; echo "phase rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_parity_report.py > $OUT/parity_report.txt 2>&1; echo "parity rc=$?" | tee -a $OUT/progress.log
-timeout -k 10 200 python tools/gpu_vecenv_bench.py > $OUT/vecenv.txt 2>&1; timeout -k 10 200 python tools/gpu_pgs_fit.py > $OUT/pgs_fit.txt 2>&1; timeout -k 10 200 python tools/gpu_config4.py > $OUT/config4.txt 2>&1; timeout -k 10 200 python tools/gpu_config5.py > $OUT/config5.txt 2>&1; echo "configs rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 300 python tools/gpu_soak.py > $OUT/soak.txt 2>&1; timeout -k 10 200 python tools/gpu_vecenv_bench.py > $OUT/vecenv.txt 2>&1; timeout -k 10 200 python tools/gpu_pgs_fit.py > $OUT/pgs_fit.txt 2>&1; timeout -k 10 200 python tools/gpu_config4.py > $OUT/config4.txt 2>&1; timeout -k 10 200 python tools/gpu_config5.py > $OUT/config5.txt 2>&1; echo "configs rc=$?" | tee -a $OUT/progress.log
 find $OUT -name "*.csv" | head -40
 echo done | tee -a $OUT/progress.log

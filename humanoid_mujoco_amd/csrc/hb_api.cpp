@@ -341,7 +341,13 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     if (m.body_jntnum[b] > 3) { err = "at most 3 joints per body are supported (body '" + m.body_name[b] + "')"; return false; }
     if (childnum[b] > 8) { err = "at most 8 child bodies per body are supported (body '" + m.body_name[b] + "')"; return false; }
     r[0] = fi(b); r[1] = fi(m.body_parentid[b]); r[2] = fi(m.body_jntnum[b]); r[3] = fi(m.body_jntadr[b]);
-    r[4] = fi(m.body_depth[b]); r[5] = fi(treeid[b]); r[6] = (float)m.body_mass[b]; r[7] = fi(childnum[b]);
+    {  // depth, and the ancestors 2, 4 and 8 links up (the world once the chain ends): the kinematics pass composes
+       // poses by pointer jumping, log2(depth) rounds instead of one per level
+      auto up = [&](int x, int k) { while (k-- > 0 && x > 0) x = m.body_parentid[x]; return x; };
+      if (m.body_depth[b] > 16) { err = "kinematic trees deeper than 16 bodies are not supported"; return false; }
+      r[4] = fi(m.body_depth[b] | (up(b, 2) << 8) | (up(b, 4) << 16) | (up(b, 8) << 24));
+    }
+    r[5] = fi(treeid[b]); r[6] = (float)m.body_mass[b]; r[7] = fi(childnum[b]);
     for (int i = 0; i < 3; i++) { r[8 + i] = (float)m.body_pos[3 * b + i]; r[16 + i] = (float)m.body_ipos[3 * b + i]; r[24 + i] = (float)m.body_inertia[3 * b + i]; }
     for (int i = 0; i < 4; i++) { r[12 + i] = (float)m.body_quat[4 * b + i]; r[20 + i] = (float)m.body_iquat[4 * b + i]; }
     for (int c = 0; c < 8; c++) r[28 + c] = fi(c < childnum[b] ? child_list[childadr[b] + c] : 0);

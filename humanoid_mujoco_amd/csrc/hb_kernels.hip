@@ -643,7 +643,8 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       for (int jj = 0; jj < 3; jj++) { JA[jj] = R[9 + 3 * jj]; JB[jj] = R[10 + 3 * jj]; JC[jj] = R[11 + 3 * jj]; }
     }
     const int myb = __float_as_int(q0.x), myp = __float_as_int(q0.y), myjn = __float_as_int(q0.z), myja = __float_as_int(q0.w);
-    const int mylevel = bl ? __float_as_int(q1.x) : -1, mycn = __float_as_int(q1.w);
+    const int mylevel = bl ? (__float_as_int(q1.x) & 255) : -1, mycn = __float_as_int(q1.w);
+    const int myanc2 = (__float_as_int(q1.x) >> 8) & 255, myanc4 = (__float_as_int(q1.x) >> 16) & 255, myanc8 = (__float_as_int(q1.x) >> 24) & 255;
     const float mymass = (dr && bl) ? dr[DL.o_mass + myb] : q1.z;
     const int mych[8] = {__float_as_int(ch0.x), __float_as_int(ch0.y), __float_as_int(ch0.z), __float_as_int(ch0.w),
                          __float_as_int(ch1.x), __float_as_int(ch1.y), __float_as_int(ch1.z), __float_as_int(ch1.w)};
@@ -678,17 +679,26 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         }
       }
     }
+    // World poses by pointer jumping: every body starts with its pose relative to its parent and, in round r, composes
+    // it with the (partially composed) pose of its ancestor 2^r links up; after ceil(log2(depth)) rounds it is the world
+    // pose.  The world body holds the identity and is every short chain's fixed point.  (mj_kinematics composes the same
+    // transforms root to leaf; the association differs, the product does not.)
     V3 mypos = posl;
     Q4 myquat = quatl;
-    for (int L = 1; L < M.nlevel; L++) {
-      if (mylevel == L) {
-        if (!isfree) {
-          const float4* Pp = reinterpret_cast<const float4*>(s_xpq + 8 * myp);
-          const float4 pp4 = Pp[0], pq4 = Pp[1];
-          const Q4 pq = {pq4.x, pq4.y, pq4.z, pq4.w};
-          mypos = V3{pp4.x, pp4.y, pp4.z} + qrot(pq, posl);
-          myquat = qnormalize(qmul(pq, quatl));
-        }
+    if (bl) {
+      reinterpret_cast<float4*>(s_xpq + 8 * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
+      reinterpret_cast<float4*>(s_xpq + 8 * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
+    }
+    gsync();
+    for (int r = 0, span = 1; span < M.nlevel - 1 || r == 0; r++, span <<= 1) {
+      const int anc = r == 0 ? myp : (r == 1 ? myanc2 : (r == 2 ? myanc4 : myanc8));
+      float4 pp4 = {0.f, 0.f, 0.f, 0.f}, pq4 = {1.f, 0.f, 0.f, 0.f};
+      if (bl) { const float4* Pp = reinterpret_cast<const float4*>(s_xpq + 8 * anc); pp4 = Pp[0]; pq4 = Pp[1]; }
+      gsync();  // every lane has read its ancestor before anyone overwrites a pose
+      if (bl && anc != 0) {
+        const Q4 pq = {pq4.x, pq4.y, pq4.z, pq4.w};
+        mypos = V3{pp4.x, pp4.y, pp4.z} + qrot(pq, mypos);
+        myquat = qnormalize(qmul(pq, myquat));
         reinterpret_cast<float4*>(s_xpq + 8 * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
         reinterpret_cast<float4*>(s_xpq + 8 * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
       }

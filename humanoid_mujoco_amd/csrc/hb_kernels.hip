@@ -836,18 +836,31 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     // Tree-pass storage is one record per body, 16-byte aligned, moved as ds_read/write_b128:
     //   s_va[12 b ..] = cvel[6] | cacc[6]          s_if[16 b ..] = composite inertia[10] | force[6]
-    if (lane < 12) s_va[lane] = (lane >= 9 && !(M.disableflags & (1 << 6))) ? -M.gravity[lane - 9] : 0.f;  // world: cacc = -gravity
+    // Velocities and bias accelerations along each chain, also by pointer jumping.  A chain segment carries
+    //   V = sum of its bodies' lv,   A = sum of their la + sum over ordered pairs (a' above a) of lv_a' x lv_a,
+    // and an upper segment U composes with the lower one L as  V = V_U + V_L,  A = A_U + A_L + V_U x V_L  (the motion
+    // cross product is bilinear, so the cross terms of all pairs (a' in U, a in L) collapse into one product).  This is
+    // associative: after ceil(log2(depth)) rounds V is the body's cvel and A its cacc minus the world's (-gravity).
+    float mycvel[6], mycacc[6];
+    for (int i = 0; i < 6; i++) { mycvel[i] = lv[i]; mycacc[i] = la[i]; }
+    if (bl) {
+      float4* Op = reinterpret_cast<float4*>(s_va + 12 * myb);
+      Op[0] = {mycvel[0], mycvel[1], mycvel[2], mycvel[3]};
+      Op[1] = {mycvel[4], mycvel[5], mycacc[0], mycacc[1]};
+      Op[2] = {mycacc[2], mycacc[3], mycacc[4], mycacc[5]};
+    }
     gsync();
-    float mycvel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mycacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int L = 1; L < M.nlevel; L++) {
-      if (mylevel == L) {
-        const float4* Pp = reinterpret_cast<const float4*>(s_va + 12 * myp);
-        const float4 a0 = Pp[0], a1 = Pp[1], a2 = Pp[2];
-        const float pv[6] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y};
-        const float pa[6] = {a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+    for (int r = 0, span = 1; span < M.nlevel - 1 || r == 0; r++, span <<= 1) {
+      const int anc = r == 0 ? myp : (r == 1 ? myanc2 : (r == 2 ? myanc4 : myanc8));
+      float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+      if (bl && anc != 0) { const float4* Pp = reinterpret_cast<const float4*>(s_va + 12 * anc); a0 = Pp[0]; a1 = Pp[1]; a2 = Pp[2]; }
+      gsync();  // every lane has read its ancestor's segment before anyone overwrites one
+      if (bl && anc != 0) {
+        const float uv[6] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y};
+        const float ua[6] = {a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
         float t[6];
-        cross_motion(t, pv, lv);
-        for (int i = 0; i < 6; i++) { mycvel[i] = pv[i] + lv[i]; mycacc[i] = pa[i] + t[i] + la[i]; }
+        cross_motion(t, uv, mycvel);
+        for (int i = 0; i < 6; i++) { mycacc[i] += ua[i] + t[i]; mycvel[i] += uv[i]; }
         float4* Op = reinterpret_cast<float4*>(s_va + 12 * myb);
         Op[0] = {mycvel[0], mycvel[1], mycvel[2], mycvel[3]};
         Op[1] = {mycvel[4], mycvel[5], mycacc[0], mycacc[1]};
@@ -855,6 +868,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       }
       gsync();
     }
+    if (!(M.disableflags & (1 << 6))) for (int i = 0; i < 3; i++) mycacc[3 + i] -= M.gravity[i];  // the world's cacc
     // sensor read-out for planner residuals (mj_sensorPos/Vel of framepos, subtreecom, subtreelinvel)
     if (P.sensor_out) {
       float* so = P.sensor_out + ((size_t)step * P.n_env + env) * P.sensor_stride;

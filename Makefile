@@ -32,6 +32,13 @@ build/libhb_stamps.so: $(HOST_SRCS) $(HIP_SRCS) $(HDRS)
 	$(HIPCC) $(FLAGS) -DHB_STAMPS -c -x hip $(HIP_SRCS) -o build/obj_stamps/hb_kernels.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ build/obj_stamps/*.o
 
+# diagnostic build: section cycles inside the Newton iterations (tools/gpu_newton_bench.py --probe)
+build/libhb_probe.so: $(HOST_SRCS) $(HIP_SRCS) $(HDRS)
+	@mkdir -p build/obj_probe
+	for f in $(HOST_SRCS); do g++ $(HOSTFLAGS) -DHB_STAMPS -c $$f -o build/obj_probe/$$(basename $$f .cpp).o || exit 1; done
+	$(HIPCC) $(FLAGS) -DHB_STAMPS -DHB_PROBE_NEWTON -c -x hip $(HIP_SRCS) -o build/obj_probe/hb_kernels.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ build/obj_probe/*.o
+
 build/hb_compile: tools/hb_compile.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp $(HDRS)
 	@mkdir -p build
 	g++ -O2 -std=c++17 -Wall -o $@ tools/hb_compile.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp

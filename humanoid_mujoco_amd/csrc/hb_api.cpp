@@ -100,6 +100,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.pgs_scale = (float)(1.0 / (m.meaninertia * std::max(1, nv)));
   dm.iterations = m.iterations;
   dm.disableflags = m.disableflags;
+  dm.solver = m.solver; dm.ls_iterations = m.ls_iterations; dm.ls_tolerance = (float)m.ls_tolerance;
 
   // trees, levels, children, dof masks
   std::vector<int> treeid(nb, 0), roots;
@@ -254,6 +255,9 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   for (int i = 0; i < nv; i++)
     for (int t = desc_adr[i]; t < desc_adr[i + 1]; t++) desc_t[(size_t)(t - desc_adr[i]) * 32 + i] = desc_pack[t];
   dm.ndesc_max = maxdesc;
+  std::vector<int> mdense((size_t)32 * 32, m.nM);
+  for (int i = 0; i < 32; i++) mdense[(size_t)i * 32 + i] = m.nM + 1;
+  for (int e = 0; e < m.nM; e++) { mdense[(size_t)Mj[e] * 32 + Mi[e]] = e; mdense[(size_t)Mi[e] * 32 + Mj[e]] = e; }
   std::vector<int> chain((size_t)32 * (kMaxAnc + 1), 0);
   for (int i = 0; i < nv; i++) {
     int t = 0;
@@ -385,7 +389,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(body_treeid, treeid); TF(body_invweight0, m.body_invweight0); TF(tree_invmass, tree_invmass);
   TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TF(qpos0, m.qpos0); TI(dof_jntid, m.dof_jntid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TF(dof_damping, m.dof_damping); TI(M_j, Mj); TI(mrec, mrec);
   TI(fround, fround); TI(ftab, ftab);
-  TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(desc_t, desc_t); TI(chain, chain);
+  TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(desc_t, desc_t); TI(mdense, mdense); TI(chain, chain);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
@@ -602,7 +606,7 @@ int launch_segment(hb_batch* b, BatchPtrs P, int nsteps, const Segment& sg, int 
   P.blk0 = sg.lo; P.nblk = sg.hi - sg.lo;
   // a whole-batch permutation would mix segments: a segment only uses the order of its own envs
   P.order = (b->schedule && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2)) ? b->d_order : nullptr;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, nsteps, sg.st));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, nsteps, sg.st));
   if (reorder) HB_HIP(launch_order(b->d_counts, b->d_order, sg.lo, sg.hi - sg.lo, sg.st));
   return HB_OK;
 }
@@ -752,16 +756,18 @@ int hb_options_get(const hb_model* h, hb_options* o) {
   const Model& m = h->m;
   o->timestep = m.timestep; memcpy(o->gravity, m.gravity, sizeof o->gravity); o->impratio = m.impratio; o->tolerance = m.tolerance;
   o->iterations = m.iterations; o->solver = m.solver; o->cone = m.cone; o->integrator = m.integrator; o->disableflags = m.disableflags;
+  o->ls_iterations = m.ls_iterations; o->ls_tolerance = m.ls_tolerance;
   return HB_OK;
 }
 
 int hb_options_set(hb_model* h, const hb_options* o) {
   if (!h || !o) return HB_EINVAL;
-  if (o->solver != SOL_PGS || o->cone != 0 || o->integrator != 0) return HB_EUNSUPPORTED;
-  if (!(o->timestep > 0) || !(o->impratio > 0) || o->iterations < 0) return HB_EINVAL;
+  if ((o->solver != SOL_PGS && o->solver != SOL_NEWTON) || o->cone != 0 || o->integrator != 0) return HB_EUNSUPPORTED;
+  if (!(o->timestep > 0) || !(o->impratio > 0) || o->iterations < 0 || o->ls_iterations < 0 || !(o->ls_tolerance >= 0)) return HB_EINVAL;
   Model& m = h->m;
   m.timestep = o->timestep; memcpy(m.gravity, o->gravity, sizeof o->gravity); m.impratio = o->impratio; m.tolerance = o->tolerance;
-  m.iterations = o->iterations; m.disableflags = o->disableflags;
+  m.iterations = o->iterations; m.disableflags = o->disableflags; m.solver = o->solver;
+  m.ls_iterations = o->ls_iterations; m.ls_tolerance = o->ls_tolerance;
   return HB_OK;
 }
 
@@ -927,7 +933,7 @@ int hb_forward(hb_batch* b, const float* ctrl) {
   else if (n) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * sizeof(float), main_stream(b)));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, 1, main_stream(b)));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b)));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
@@ -1116,7 +1122,7 @@ int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
   int rc = sensor_setup(b, spec, 1, P);
   if (rc != HB_OK) return rc;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.lds_floats, P, 1, main_stream(b)));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b)));
   HB_HIP(hipMemcpyAsync(sensor_out, b->d_sensor_out, (size_t)b->n_env * P.sensor_stride * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;

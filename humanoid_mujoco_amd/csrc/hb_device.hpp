@@ -41,6 +41,8 @@ struct DevModel {
   // options
   float timestep, gravity[3], inv_sqrt_impratio, tolerance, pgs_scale;
   int iterations, disableflags;
+  int solver, ls_iterations;  // mjtSolver (0 PGS, 2 Newton); Newton line-search evaluation cap
+  float ls_tolerance;
   // bodies.  Level-ordered records, kBrecQuads float4 each (slot 0 = world, slot s = lane s-1 of the tree passes):
   // [0] b,parent,jntnum,jntadr  [1] depth,treeid,mass,childnum  [2] pos  [3] quat  [4] ipos  [5] iquat  [6] inertia
   // [7..8] children[8]  [9+3j] joint j: (type,qposadr,dofadr,qpos0) (axis) (pos)
@@ -70,6 +72,9 @@ struct DevModel {
   const int HB_CONST *desc_adr, *desc_pack;  // descendants of each dof: k | address of L[k,i] << 8
   const int HB_CONST* desc_t;    // the same, transposed and padded: [ndesc_max][32]
   int ndesc_max;
+  // Newton solver: dense view of the sparse mass matrix, [32 columns j][32 rows i] -> index of the {M, H} pair holding
+  // M(i, j) (nM: the zero pad pair, nM + 1: the one pad pair = identity beyond nv)
+  const int HB_CONST* mdense;
   const int HB_CONST* chain;     // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)
   // geoms
   const int HB_CONST *geom_type, *geom_bodyid;

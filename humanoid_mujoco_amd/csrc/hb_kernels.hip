@@ -31,6 +31,12 @@ namespace hb {
 #else
 #define HB_STAMP(i) do {} while (0)
 #endif
+#if defined(HB_STAMPS) && defined(HB_PROBE_NEWTON)
+// diagnostic: cycles per section of the Newton solve, accumulated over the iterations of one step (slots 0..7 of the stamps)
+#define HB_NP(i) do { if (P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); np_acc[i] += t_ - np_t; np_t = t_; } } while (0)
+#else
+#define HB_NP(i) do {} while (0)
+#endif
 #define HB_MINVAL 1e-15f
 #define HB_MAXVAL 1e10f
 #define HB_MINIMP 0.0001f
@@ -513,7 +519,110 @@ __device__ __forceinline__ void build_w(DevModelRef M, const f32x2* LD2, const f
 
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) {
+// ---- dense helpers of the Newton solver ------------------------------------------------------------------------
+// A symmetric nv x nv matrix (nv <= 32, identity beyond nv) lives one ROW PER LANE: lane l (and its mirror l + 32)
+// holds row l & 31 in 32 registers.  Vectors live one element per lane (lanes 0..31).  Everything is readlane + fma
+// on statically indexed registers: no LDS traffic, no cross-lane reductions.
+
+// sum_j row[j] * x_j over LDS rows (N terms, the tails are zero by construction), x_j taken from lane j: all loads of
+// the unrolled body are issued before the first use; the two-row form shares the broadcasts
+template <int N>
+__device__ __forceinline__ float rowdot(const float* row, float x) {
+  float v[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] = row[j];
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    a0 = __builtin_fmaf(v[j], rdlane(x, j), a0);
+    a1 = __builtin_fmaf(v[j + 1], rdlane(x, j + 1), a1);
+  }
+  return a0 + a1;
+}
+template <int N>
+__device__ __forceinline__ void rowdot2(const float* rowA, const float* rowB, float x, float& ra, float& rb) {
+  float va[N], vb[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) { va[j] = rowA[j]; vb[j] = rowB[j]; }
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    const float x0 = rdlane(x, j), x1 = rdlane(x, j + 1);
+    a0 = __builtin_fmaf(va[j], x0, a0); b0 = __builtin_fmaf(vb[j], x0, b0);
+    a1 = __builtin_fmaf(va[j + 1], x1, a1); b1 = __builtin_fmaf(vb[j + 1], x1, b1);
+  }
+  ra = a0 + a1; rb = b0 + b1;
+}
+
+// Right-looking Cholesky A = L L' in place (mju_cholFactor, mujoco.h:1211, incl. its diagonal floor) of the leading
+// N x N block (N = nv rounded up to 4; identity beyond nv).  Every lane updates its whole row, so that lane i ends up with
+//   element k < i: L[i][k] d_k;   element k > i: S_i[i][k] d_i^2 = L[k][i] d_i   (S_i: the Schur complement at pivot i),
+// i.e. row i of L and column i of L, each pre-scaled so that the two triangular solves below are one v_readlane and one
+// fma per step.  Returns d_i = 1 / L[i][i].
+// The dependent chain of a pivot is readlane - rsq - mul - readlane - fma: the NEXT pivot column is updated first, with
+// its multiplier taken by v_readlane; the rest of the trailing update goes through a 64-float LDS line (one ds_write,
+// broadcast ds_read_b128s) as packed math on register pairs (v_pk_fma_f32) and overlaps the following pivots.
+template <int N>
+__device__ __forceinline__ float chol_rows(f32x2 (&A)[16], float* s_l, int li, int lane) {
+  float dv = 1.f;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const float akk = A[k >> 1][k & 1];
+    const float piv = fmaxf(rdlane(akk, k), HB_MINVAL);
+    const float d = __builtin_amdgcn_rsqf(piv);
+    const float l = akk * d;
+    s_l[lane] = l;  // all 64 lanes (the upper half lands in the next 32 floats): an unconditional store keeps the code straight-line
+    if (li == k) dv = d;
+    const float lm = li > k ? -l : 0.f;  // rows at and above the pivot are final
+    if (k + 1 < N) A[(k + 1) >> 1][(k + 1) & 1] = __builtin_fmaf(lm, rdlane(l, k + 1), A[(k + 1) >> 1][(k + 1) & 1]);
+    const f32x2 lm2 = {lm, lm};
+#pragma unroll
+    for (int c = (k + 2) / 4; c < N / 4; c++) {
+      const float4 lv = *reinterpret_cast<const float4*>(s_l + 4 * c);
+      const float lq[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int lo = 4 * c + 2 * h, hi = lo + 1;
+        if (lo > k + 1) A[2 * c + h] = lm2 * f32x2{lq[2 * h], lq[2 * h + 1]} + A[2 * c + h];
+        else if (hi > k + 1) A[2 * c + h][1] = __builtin_fmaf(lm, lq[2 * h + 1], A[2 * c + h][1]);
+      }
+    }
+    A[k >> 1][k & 1] = li > k ? l * d : akk;
+  }
+  const float dv2 = dv * dv;
+#pragma unroll
+  for (int k = 1; k < N; k++) A[k >> 1][k & 1] = li < k ? A[k >> 1][k & 1] * dv2 : A[k >> 1][k & 1];
+  return dv;
+}
+
+// x = (L L')^-1 g for the factor left by chol_rows (mju_cholSolve, mujoco.h:1214): column-oriented forward and backward
+// substitution; with the pre-scaled factor the element solved at step k is lane k's running value itself: v_readlane
+// broadcasts it, one fma updates every other row, v_writelane (off the chain) keeps it
+template <int N>
+__device__ __forceinline__ float chol_solve_rows(const f32x2 (&A)[16], float dv, float g) {
+  float r = g;
+  int y = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int rk = __builtin_amdgcn_readlane(__float_as_int(r), k);
+    y = hb_writelane(rk, k, y);
+    r = __builtin_fmaf(-A[k >> 1][k & 1], __int_as_float(rk), r);  // rows below k; rows above are done (their r is dead)
+  }
+  r = __int_as_float(y) * (dv * dv);  // y_k = r_k d_k, and the backward pass runs on d_i-scaled rows
+  int x = 0;
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const int xk = __builtin_amdgcn_readlane(__float_as_int(r), k);
+    x = hb_writelane(xk, k, x);
+    r = __builtin_fmaf(-A[k >> 1][k & 1], __int_as_float(xk), r);  // rows above k
+  }
+  return __int_as_float(x);
+}
+
+// SOLVER: mjtSolver of the instantiation (0 = PGS, 2 = Newton); everything outside the constraint solve, the mass-matrix
+// factorisation and the integrator's damped solve is shared.
+template <int SOLVER, int NDENSE>
+__device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps) {
   // the model tables are read through a constant-address-space pointer (not by-value kernel
   // arguments): the ~100 table pointers and every wave-uniform table entry are fetched on demand by
   // scalar loads through the scalar cache instead of living in (and spilling from) SGPRs
@@ -925,7 +1034,8 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     HB_STAMP(4);
     // ---------------------------------------------------------------- qM from the composite inertias
-    const FactorHead fhead = factor_head(M, lane);
+    FactorHead fhead;
+    if constexpr (SOLVER == 0) fhead = factor_head(M, lane);
     for (int e = lane; e < M.nM; e += kGroup) {
       const int pk = M.mrec[e];  // i | j << 8 | body(i) << 16
       const float2 ad = M.mdiag[e];  // (armature, damping) on diagonal entries, 0 elsewhere
@@ -950,11 +1060,14 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     gsync();
     HB_STAMP(5);
     // ---------------------------------------------------------------- mj_factorM
+    // (the Newton instantiation works on dense rows of M in registers and leaves the sparse matrix as assembled)
+    if constexpr (SOLVER == 0) {
 #if defined(HB_STAMPS) && defined(HB_PROBE_FACTOR)
-    factor_ld(M, lds, s_qLD, s_dinv, s_dsqrtinv, lane, fhead, P.stamps ? stamps_ : nullptr);
+      factor_ld(M, lds, s_qLD, s_dinv, s_dsqrtinv, lane, fhead, P.stamps ? stamps_ : nullptr);
 #else
-    factor_ld(M, lds, s_qLD, s_dinv, s_dsqrtinv, lane, fhead);
+      factor_ld(M, lds, s_qLD, s_dinv, s_dsqrtinv, lane, fhead);
 #endif
+    }
 
     HB_STAMP(6);
     // ---------------------------------------------------------------- qfrc_bias, mj_passive, mj_fwdActuation -> qfrc_smooth
@@ -1228,7 +1341,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     nefc = uniform(nefc);
     // extra right-hand side: row nefc of C holds qfrc_smooth (transformed below, with the rows, into y)
-    for (int d = lane; d < cs; d += kGroup) s_C[nefc * cs + d] = d < nv ? s_smooth[d] : 0.f;
+    if constexpr (SOLVER == 0) for (int d = lane; d < cs; d += kGroup) s_C[nefc * cs + d] = d < nv ? s_smooth[d] : 0.f;
     gsync();
 
     HB_STAMP(9);
@@ -1270,6 +1383,10 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     gsync();
     HB_STAMP(10);
+    int niter = 0;
+    float newton_grad = 0.f;  // Newton: gradient left at the solution (lane = dof); enters the damped Euler solve
+    (void)newton_grad;
+    if constexpr (SOLVER == 0) {
     // ---------------------------------------------------------------- C = J W, W = L^-1 D^-1/2 (the half solve of mj_solveM2 as one GEMM)
     // rows 0..nefc-1 are constraint rows, row nefc is qfrc_smooth (-> y = D^-1/2 L^-T qfrc_smooth).
     // 32-row tiles x 32 dof columns x K = 32 on the matrix cores; A operands are preloaded so the
@@ -1370,7 +1487,6 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
     }
     HB_STAMP(12);
     // ---------------------------------------------------------------- mj_fwdConstraint: warm start + PGS
-    int niter = 0;
     if (nefc > 0) {
       // Rows >= nefc are inert by construction (zero AR entries, zero residual and force), so the
       // unrolled row loops below run in unguarded 4-row chunks up to nefc rounded up.
@@ -1473,6 +1589,167 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       }
     }
     gsync();
+    } else {
+      // ---------------------------------------------------------------- mj_fwdConstraint, Newton solver (mj_solNewton)
+      // Primal problem (oracle/mjstep_oracle.c: sol_newton): minimise over qacc
+      //   1/2 (qacc - qacc_smooth)' M (qacc - qacc_smooth) + sum_rows 1/2 D min(0, J qacc - aref)^2
+      // by Newton steps with an exact line search.  One wave owns the env, so the whole iteration is uniform:
+      // lane = constraint row for jar / force / J rows, lane = dof for qacc / gradient / M rows; the Hessian
+      // H = M + J' diag(D active) J is formed on the matrix cores and factorised in registers.
+      const int li = lane & 31;
+      const bool dofl = lane < nv;
+      // dense M (identity beyond nv) one row per lane, [32][33] over the dead row meta; J rows stay in C
+      float* s_Md = s_efc;
+      const float* Mrow = s_Md + li * kCs;
+      const float* Jrow = s_C + (rowact ? lane : 0) * cs;
+      f32x2 H[16];
+#pragma unroll
+      for (int j = 0; j < 32; j++) H[j >> 1][j & 1] = s_qLD[M.mdense[j * 32 + li]].x;
+      if (lane < 32) {
+#pragma unroll
+        for (int j = 0; j < 32; j++) s_Md[lane * kCs + j] = H[j >> 1][j & 1];
+      }
+      const float smooth = dofl ? s_smooth[lane] : 0.f;
+      const float warm = dofl ? s_warm[lane] : 0.f;
+      // qacc_smooth = M^-1 qfrc_smooth
+      float dv = chol_rows<NDENSE>(H, s_v1, li, lane);
+      const float qs = chol_solve_rows<NDENSE>(H, dv, smooth);
+      gsync();
+      float qacc = qs, qfc = 0.f;
+      HB_STAMP(11);
+      if (nefc > 0) {
+        // starting point (warmstart() of mj_fwdConstraint): qacc_warmstart unless qacc_smooth costs less
+        float Ma, jqs;
+        rowdot2<NDENSE>(Mrow, Jrow, qs, Ma, jqs);
+        float jar = rowact ? jqs - aref : 1.f;  // rows beyond nefc: never active
+        if (!(M.disableflags & (1 << 8))) {
+          const float Mw = rowdot<NDENSE>(Mrow, warm);
+          const float jarw = rowact ? jw - aref : 1.f;
+          const float cw = (jarw < 0.f ? 0.5f * Dd * jarw * jarw : 0.f) + (dofl ? 0.5f * (Mw - smooth) * (warm - qs) : 0.f);
+          const float cq = jar < 0.f ? 0.5f * Dd * jar * jar : 0.f;
+          if (wave_sum(cw - cq) <= 0.f) { qacc = warm; Ma = Mw; jar = jarw; }
+        }
+        const float scale = M.pgs_scale, tol = M.tolerance, lstol = M.ls_tolerance;
+        const int maxiter = M.iterations, lsmax = M.ls_iterations;
+        float cost = 0.f;
+        unsigned long long act_prev = 0ull;
+        bool have_factor = false;
+        HB_STAMP(12);
+#if defined(HB_STAMPS) && defined(HB_PROBE_NEWTON)
+        unsigned long long np_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, np_t = __builtin_amdgcn_s_memtime();
+#endif
+        for (;;) {
+          // PrimalUpdateConstraint: state, force, qfrc_constraint = J' force, cost
+          const bool act = jar < 0.f;
+          force = act ? -Dd * jar : 0.f;
+          const unsigned long long actmask = __ballot(act);
+          qfc = 0.f;
+          {
+            // eight rows in flight; rows beyond nefc are read from the last row with a zero force
+            float q1 = 0.f;
+            const int last = nefc - 1;
+            for (int i0 = 0; i0 < nefc; i0 += 8) {
+              float c[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) c[u] = s_C[min(i0 + u, last) * cs + li];
+#pragma unroll
+              for (int u = 0; u < 8; u += 2) {
+                qfc = __builtin_fmaf(c[u], rdlane(force, i0 + u), qfc);
+                q1 = __builtin_fmaf(c[u + 1], rdlane(force, i0 + u + 1), q1);
+              }
+            }
+            qfc += q1;
+          }
+          const float oldcost = cost;
+          newton_grad = dofl ? Ma - smooth - qfc : 0.f;
+          cost = wave_sum((act ? 0.5f * Dd * jar * jar : 0.f) + (dofl ? 0.5f * (Ma - smooth) * (qacc - qs) : 0.f));
+          const float g2 = wave_sum(newton_grad * newton_grad);
+          if (niter > 0 && (scale * (oldcost - cost) < tol || scale * sqrtf(g2) < tol)) break;
+          if (niter >= maxiter) break;
+          HB_NP(0);
+          // Hessian of the active set (MakeHessian; rebuilt only when the active set changed) and its Cholesky factor
+          if (!have_factor || actmask != act_prev) {
+            s_force[lane] = act ? Dd : 0.f;
+            gsync();
+            const int half = lane >> 5;
+            f32x16 X;
+#pragma unroll
+            for (int r = 0; r < 16; r++) X[r] = 0.f;
+            for (int kk = 0; 2 * kk < nefc; kk++) {
+              const int row = 2 * kk + half;
+              const bool v = row < nefc;
+              const float a = v ? s_C[row * cs + li] : 0.f;
+              const float b = v ? a * s_force[row] : 0.f;
+              X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, X, 0, 0, 0);  // += J_row' (D J_row)
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              const int ra = (r & 3) + 8 * (r >> 2);  // C/D layout: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+              const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[r]), __float_as_uint(X[r]), false, false);
+              H[ra >> 1][ra & 1] = Mrow[ra] + __uint_as_float(sw.x);
+              H[(ra + 4) >> 1][ra & 1] = Mrow[ra + 4] + __uint_as_float(sw.y);
+            }
+            HB_NP(1);
+            dv = chol_rows<NDENSE>(H, s_v1, li, lane);
+            HB_NP(2);
+            act_prev = actmask;
+            have_factor = true;
+            gsync();
+          }
+          // PrimalUpdateGradient: search = -H^-1 grad
+          const float search = -chol_solve_rows<NDENSE>(H, dv, newton_grad);
+          HB_NP(3);
+          float Mv, Jv0;
+          rowdot2<NDENSE>(Mrow, Jrow, search, Mv, Jv0);
+          const float Jv = rowact ? Jv0 : 0.f;
+          HB_NP(4);
+          // PrimalSearch: exact line search on the piecewise quadratic phi(alpha) = cost(qacc + alpha search):
+          // Newton iterations in alpha, kept inside the bracket of the sign change once there is one.  The slope
+          // tolerance is the reference's (tolerance * ls_tolerance * |search| / scale) floored at fp32 resolution
+          // of the slope's own terms.
+          const float gq = dofl ? Ma - smooth : 0.f;
+          const float qg1 = wave_sum(search * gq), qg2 = 0.5f * wave_sum(dofl ? search * Mv : 0.f), sn2 = wave_sum(search * search);
+          const float DJv = Dd * Jv, DJv2 = DJv * Jv;
+          const float mag = wave_sum(fabsf(search * gq) + (act ? fabsf(DJv * jar) : 0.f));
+          const float gtol = fmaxf(tol * lstol * sqrtf(sn2) / scale, 2e-6f * mag);
+          float alpha = 0.f;
+          {
+            const float d0 = qg1 + wave_sum(act ? DJv * jar : 0.f), d1 = 2.f * qg2 + wave_sum(act ? DJv2 : 0.f);
+            if (d0 < -gtol) {
+              float lo = 0.f, hi = -1.f, a = -d0 / d1;
+              for (int it = 0; it < lsmax; it++) {
+                const float x = jar + a * Jv;
+                const bool on = x < 0.f;
+                const float e0 = qg1 + 2.f * a * qg2 + wave_sum(on ? DJv * x : 0.f), e1 = 2.f * qg2 + wave_sum(on ? DJv2 : 0.f);
+                alpha = a;
+                if (fabsf(e0) < gtol) break;
+                if (e0 < 0.f) lo = a; else hi = a;
+                float an = a - e0 / e1;
+                if (hi >= 0.f && !(an > lo && an < hi)) an = 0.5f * (lo + hi);
+                a = an;
+              }
+            }
+          }
+          HB_NP(5);
+          if (alpha == 0.f) break;
+          qacc = __builtin_fmaf(alpha, search, qacc);
+          Ma = __builtin_fmaf(alpha, Mv, Ma);
+          jar = __builtin_fmaf(alpha, Jv, jar);
+          niter++;
+        }
+#if defined(HB_STAMPS) && defined(HB_PROBE_NEWTON)
+        if (P.stamps) for (int i = 0; i < 8; i++) stamps_[i] = np_acc[i];
+#endif
+      } else {
+        HB_STAMP(12);
+      }
+      HB_STAMP(13);
+      if (dofl) {
+        s_v0[lane] = qacc;
+        if (P.qfrc_out) P.qfrc_out[(size_t)env * nv + lane] = smooth + qfc;  // qfrc_smooth + qfrc_constraint
+      }
+      gsync();
+    }
     // mj_checkAcc
     {
       bool bad = false;
@@ -1482,6 +1759,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
         for (int i = lane; i < nq; i += kGroup) s_qpos[i] = M.qpos0[i];
         for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; s_v0[i] = 0.f; }
         time = 0.f;
+        newton_grad = 0.f;
         gsync();
       }
     }
@@ -1513,21 +1791,36 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
       // which needs neither the right-hand side nor qfrc_constraint: only qacc and the damping vector.
       for (int i = lane; i < nv; i += kGroup) s_warm[i] = s_v0[i];  // qacc_warmstart <- qacc
       if (eulerdamp) {
-        // H^-1 = W_H W_H^T; W_H and its transpose are built in the (now dead) C rows
-        float* WH = s_C;
-        float* WHT = s_C + 32 * kWs;  // runs on into the (dead) row-meta / W area behind C: the host checks the room
-        if (lane < nv) s_v2[lane] = M.timestep * M.dof_damping[lane] * s_v0[lane];  // h B qacc
-        build_w<1, true>(M, s_qLD, s_dinv, s_dsqrtinv, WH, WHT, lane);  // (its barriers also publish s_v2)
-        float p = 0.f;
-        if (lane < nv) p = dot32(WHT + lane * kWs, s_v2);  // W_H^T (h B qacc)
-        gsync();
-        if (lane < nv) s_v1[lane] = p;
-        gsync();
-        float q = 0.f;
-        if (lane < nv) q = dot32(WH + lane * kWs, s_v1);
-        gsync();
-        if (lane < nv) s_v2[lane] = s_v0[lane] - q;
-        gsync();
+        if constexpr (SOLVER == 0) {
+          // H^-1 = W_H W_H^T; W_H and its transpose are built in the (now dead) C rows
+          float* WH = s_C;
+          float* WHT = s_C + 32 * kWs;  // runs on into the (dead) row-meta / W area behind C: the host checks the room
+          if (lane < nv) s_v2[lane] = M.timestep * M.dof_damping[lane] * s_v0[lane];  // h B qacc
+          build_w<1, true>(M, s_qLD, s_dinv, s_dsqrtinv, WH, WHT, lane);  // (its barriers also publish s_v2)
+          float p = 0.f;
+          if (lane < nv) p = dot32(WHT + lane * kWs, s_v2);  // W_H^T (h B qacc)
+          gsync();
+          if (lane < nv) s_v1[lane] = p;
+          gsync();
+          float q = 0.f;
+          if (lane < nv) q = dot32(WH + lane * kWs, s_v1);
+          gsync();
+          if (lane < nv) s_v2[lane] = s_v0[lane] - q;
+          gsync();
+        } else {
+          // dense: H = M + h B from the H halves of the assembled pairs, Cholesky in registers; the right-hand side
+          // h B qacc + grad (grad = M qacc - qfrc_smooth - qfrc_constraint, the Newton residual: qfrc_smooth + qfrc_constraint
+          // = M qacc - grad, so H^-1 (qfrc_smooth + qfrc_constraint) = qacc - H^-1 (h B qacc + grad))
+          const int li = lane & 31;
+          f32x2 He[16];
+#pragma unroll
+          for (int j = 0; j < 32; j++) He[j >> 1][j & 1] = s_qLD[M.mdense[j * 32 + li]].y;
+          const float dve = chol_rows<NDENSE>(He, s_v1, li, lane);
+          const float rhs = lane < nv ? M.timestep * M.dof_damping[lane] * s_v0[lane] + newton_grad : 0.f;
+          const float x = chol_solve_rows<NDENSE>(He, dve, rhs);
+          if (lane < nv) s_v2[lane] = s_v0[lane] - x;
+          gsync();
+        }
       } else {
         for (int i = lane; i < nv; i += kGroup) s_v2[i] = s_v0[i];
         gsync();
@@ -1566,6 +1859,11 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, 
   }
   if (status && lane == 0) atomicOr(P.status + env, status);
 }
+
+__global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 32>(Mp, P, nsteps); }
+// Newton instantiations: dense order 28 (nv <= 28: the 27-dof humanoid) and 32
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
 
 // ------------------------------------------------------------------------------------------
 // reset: qpos0/keyframe (+ Halton perturbation), zero velocity/warmstart/time/status
@@ -2099,10 +2397,12 @@ __global__ void hb_halton_ctrl_kernel(float* out, int T, int n_env, int nu, int 
 
 namespace hb {
 
-hipError_t launch_step(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
+hipError_t launch_step(const DevModel* M_dev, int solver, int nv, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   size_t shmem = (size_t)lds_floats * sizeof(float);
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  if (solver == 2 && nv <= 28) hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (solver == 2) hipLaunchKernelGGL(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   return hipGetLastError();
 }
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
@@ -2177,7 +2477,11 @@ hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int 
   return hipGetLastError();
 }
 hipError_t set_step_lds_limit(int bytes) {
-  return hipFuncSetAttribute((const void*)hb_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  hipError_t e = hipFuncSetAttribute((const void*)hb_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step_newton28_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)hb_step_newton32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 }  // namespace hb

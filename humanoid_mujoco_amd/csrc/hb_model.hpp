@@ -33,6 +33,8 @@ struct Model {
   double timestep = 0.002, impratio = 1.0, tolerance = 1e-8;
   double gravity[3] = {0, 0, -9.81};
   int integrator = 0, cone = 0, solver = SOL_PGS, iterations = 50, disableflags = 0;
+  int ls_iterations = 50;      // Newton line search: evaluation cap (mjOption.ls_iterations, mjmodel.h:434)
+  double ls_tolerance = 0.01;  // and its slope tolerance relative to the main one (mjmodel.h:411)
   double meaninertia = 1.0;  // mjModel.stat.meaninertia (mjmodel.h:547)
 
   // ---- bodies (mjmodel.h:660-690)
@@ -80,7 +82,7 @@ struct Model {
     HB_F(timestep); HB_F(impratio); HB_F(tolerance);
     f("gravity", gravity, 3);
     HB_F(integrator); HB_F(cone); HB_F(solver); HB_F(iterations); HB_F(disableflags);
-    HB_F(meaninertia);
+    HB_F(meaninertia); HB_F(ls_iterations); HB_F(ls_tolerance);
     HB_F(body_parentid); HB_F(body_rootid); HB_F(body_weldid); HB_F(body_jntnum); HB_F(body_jntadr);
     HB_F(body_dofnum); HB_F(body_dofadr); HB_F(body_geomnum); HB_F(body_geomadr); HB_F(body_depth);
     HB_F(body_pos); HB_F(body_quat); HB_F(body_ipos); HB_F(body_iquat); HB_F(body_mass);

@@ -28,7 +28,8 @@ DSBL_CLAMPCTRL, DSBL_WARMSTART, DSBL_FILTERPARENT, DSBL_ACTUATION, DSBL_REFSAFE,
 class HbOptions(ctypes.Structure):
     _fields_ = [("timestep", ctypes.c_double), ("gravity", ctypes.c_double * 3), ("impratio", ctypes.c_double),
                 ("tolerance", ctypes.c_double), ("iterations", ctypes.c_int), ("solver", ctypes.c_int),
-                ("cone", ctypes.c_int), ("integrator", ctypes.c_int), ("disableflags", ctypes.c_int)]
+                ("cone", ctypes.c_int), ("integrator", ctypes.c_int), ("disableflags", ctypes.c_int),
+                ("ls_iterations", ctypes.c_int), ("ls_tolerance", ctypes.c_double)]
 
 
 class HbSizes(ctypes.Structure):

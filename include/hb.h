@@ -57,12 +57,14 @@ typedef struct hb_options {
   double timestep;
   double gravity[3];
   double impratio;
-  double tolerance;  /* PGS early-exit threshold on the scaled cost improvement */
-  int iterations;    /* PGS sweep cap */
-  int solver;        /* 0 = PGS (mjSOL_PGS); the only solver implemented */
+  double tolerance;  /* solver early-exit threshold on the scaled cost improvement (Newton: also on the scaled gradient) */
+  int iterations;    /* PGS sweep cap / Newton iteration cap */
+  int solver;        /* 0 = PGS (mjSOL_PGS), 2 = Newton (mjSOL_NEWTON, the reference's default); CG is not implemented */
   int cone;          /* 0 = pyramidal; the only cone implemented */
   int integrator;    /* 0 = Euler (semi-implicit, implicit joint damping) */
   int disableflags;  /* mjtDisableBit (mjmodel.h:50-68) */
+  int ls_iterations;   /* Newton: cap on line-search evaluations per iteration (mjOption.ls_iterations, mjmodel.h:434) */
+  double ls_tolerance; /* Newton: line-search slope tolerance relative to `tolerance` (mjmodel.h:411) */
 } hb_options;
 
 /* sizes a caller needs to allocate buffers (mjModel.nq/nv/nu/..., mjmodel.h:560-620) */

@@ -26,6 +26,8 @@
 
 static long g_pgs_reverts = 0;
 
+enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 }; /* mjtSolver, mjmodel.h:159-163 */
+
 #define MINVAL 1E-15   /* mjMINVAL */
 #define MAXVAL 1E+10   /* mjmodel.h:23 mjMAXVAL */
 #define MINIMP 0.0001  /* mjmodel.h:25 */
@@ -46,6 +48,8 @@ typedef struct {
   int nq, nv, nu, nbody, njnt, ngeom, ntendon, nwrap, nM, nkey, npair, nhfield, nhfielddata;
   double timestep, impratio, tolerance, meaninertia, gravity[3];
   int integrator, cone, solver, iterations, disableflags;
+  int ls_iterations;    /* mjOption.ls_iterations, mjmodel.h:434 (default 50) */
+  double ls_tolerance;  /* mjOption.ls_tolerance, mjmodel.h:411 (default 0.01) */
   int *body_parentid, *body_rootid, *body_weldid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
   double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_subtreemass, *body_inertia, *body_invweight0;
   int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
@@ -82,6 +86,7 @@ typedef struct {  /* the subset of mjData (mjdata.h:164-431) this path touches *
   int *efc_type, *efc_id;
   double *efc_J, *efc_pos, *efc_margin, *efc_diagApprox, *efc_R, *efc_D, *efc_KBIP, *efc_vel, *efc_aref, *efc_b, *efc_force, *efc_AR, *efc_B;
   int solver_niter;
+  int solver_nls;       /* line-search evaluations of the last Newton solve (statistics) */
   int warning[8];
   /* counters for statistics (testspeed.cc:97-98 accumulates ncon/nefc the same way) */
   long long sum_ncon, sum_nefc, sum_iter, nstep;
@@ -155,6 +160,7 @@ om_model* om_load(const char* path, char* err, int errsz) {
   RI(nq); RI(nv); RI(nu); RI(nbody); RI(njnt); RI(ngeom); RI(ntendon); RI(nwrap); RI(nM); RI(nkey); RI(npair); RI(nhfield); RI(nhfielddata);
   RD(timestep); RD(impratio); RD(tolerance); RD(meaninertia);
   RI(integrator); RI(cone); RI(solver); RI(iterations); RI(disableflags);
+  m->ls_iterations = rec_int(recs, nr, "ls_iterations", 50); m->ls_tolerance = rec_dbl(recs, nr, "ls_tolerance", 0.01);
   { double* g = rec_darr(recs, nr, "gravity", 3); memcpy(m->gravity, g, sizeof m->gravity); free(g); }
   int nb = m->nbody, nj = m->njnt, nv = m->nv, ng = m->ngeom, nt = m->ntendon, nu = m->nu;
   AI(body_parentid, nb); AI(body_rootid, nb); AI(body_weldid, nb); AI(body_jntnum, nb); AI(body_jntadr, nb); AI(body_dofnum, nb); AI(body_dofadr, nb);
@@ -1034,7 +1040,196 @@ static void constraint_update(om_data* d, const double* jar) {
   for (int i = 0; i < d->nefc; i++) d->efc_force[i] = jar[i] < 0 ? -d->efc_D[i] * jar[i] : 0;
 }
 
-/* mj_fwdConstraint with the PGS solver, mujoco.h:259; mj_solPGS [recall] */
+/* ---- Newton solver (mjSOL_NEWTON, mjmodel.h:162; the reference's default: its humanoid XML sets no solver) ----
+ * mj_solNewton -> the primal solver of MuJoCo's engine_solver.c [recall; the source is not vendored, see header].
+ * Published algorithm (MuJoCo "Computation" chapter, "Solver algorithms / Newton"): minimise over qacc
+ *     cost(qacc) = 1/2 (qacc - qacc_smooth)' M (qacc - qacc_smooth) + s(J qacc - aref),
+ * where for the inequality rows of this path (limits, pyramidal contacts) s = sum_i 1/2 D_i min(0, jar_i)^2,
+ * by Newton steps  search = -H^-1 grad,  H = M + J' diag(D_i [jar_i < 0]) J  (Cholesky),
+ * grad = M qacc - qfrc_smooth - J' force,  force_i = -D_i min(0, jar_i),
+ * each followed by an exact line search on the (convex, piecewise quadratic) 1-D restriction.
+ * Termination: scale * (cost decrease) < tolerance or scale * |grad| < tolerance, scale = 1/(meaninertia * max(1, nv)).
+ * The minimiser of this strictly convex problem is unique, so the converged qacc does not depend on line-search
+ * bookkeeping; iteration counts may differ from MuJoCo's by the details recalled here. */
+
+/* mj_mulM, mujoco.h:381: res = M * vec with M in the sparse dof-ancestor format */
+static void mul_M(const om_model* m, const double* qM, const double* v, double* res) {
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++) res[i] = 0;
+  for (int i = 0; i < nv; i++) {
+    int adr = m->dof_Madr[i];
+    res[i] += qM[adr] * v[i];
+    adr++;
+    for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j], adr++) { res[i] += qM[adr] * v[j]; res[j] += qM[adr] * v[i]; }
+  }
+}
+
+typedef struct { double alpha, cost, d0, d1; } om_lspt;
+typedef struct { int n; const double *jar, *Jv, *D; double qg[3]; int nev; } om_lsctx;
+
+/* PrimalEval [recall]: cost and its first two derivatives along the search direction at p->alpha */
+static void ls_eval(om_lsctx* c, om_lspt* p) {
+  double a = p->alpha;
+  double cost = c->qg[0] + a * c->qg[1] + a * a * c->qg[2], d0 = c->qg[1] + 2 * a * c->qg[2], d1 = 2 * c->qg[2];
+  for (int i = 0; i < c->n; i++) {
+    double x = c->jar[i] + a * c->Jv[i];
+    if (x < 0) { cost += 0.5 * c->D[i] * x * x; d0 += c->D[i] * x * c->Jv[i]; d1 += c->D[i] * c->Jv[i] * c->Jv[i]; }
+  }
+  if (d1 <= 0) d1 = MINVAL;
+  p->cost = cost; p->d0 = d0; p->d1 = d1;
+  c->nev++;
+}
+
+/* updateBracket [recall]: move p to the candidate on its side of the sign change that is closest to it */
+static int ls_update_bracket(om_lsctx* c, om_lspt* p, const om_lspt cand[3], om_lspt* pnext) {
+  int flag = 0;
+  for (int i = 0; i < 3; i++) {
+    if (p->d0 < 0 && cand[i].d0 < 0 && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
+    else if (p->d0 > 0 && cand[i].d0 > 0 && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
+  }
+  if (flag) { pnext->alpha = p->alpha - p->d0 / p->d1; ls_eval(c, pnext); }
+  return flag;
+}
+
+/* PrimalSearch [recall]: exact line search, Newton iterations in alpha, one-sided until the derivative changes
+   sign, then bracketed */
+static double ls_search(const om_model* m, om_lsctx* c, double snorm, double scale) {
+  if (snorm < MINVAL) return 0;
+  double gtol = m->tolerance * m->ls_tolerance * snorm / scale;
+  int lsmax = m->ls_iterations, it = 0;
+  om_lspt p0, p1, p2, pmid, p1next, p2next;
+  p0.alpha = 0; ls_eval(c, &p0);
+  p1.alpha = p0.alpha - p0.d0 / p0.d1; ls_eval(c, &p1);
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabs(p1.d0) < gtol) return p1.alpha;
+  int dir = p1.d0 < 0 ? 1 : -1, p2update = 0;
+  p2 = p1;
+  while (p1.d0 * dir <= -gtol && it < lsmax) {
+    p2 = p1; p2update = 1;
+    p1.alpha = p1.alpha - p1.d0 / p1.d1; ls_eval(c, &p1); it++;
+    if (fabs(p1.d0) < gtol) return p1.alpha;
+  }
+  if (it >= lsmax || !p2update) return p1.alpha;
+  p2next = p1;
+  p1next.alpha = p1.alpha - p1.d0 / p1.d1; ls_eval(c, &p1next);
+  while (it < lsmax) {
+    pmid.alpha = 0.5 * (p1.alpha + p2.alpha); ls_eval(c, &pmid); it++;
+    om_lspt cand[3] = {p1next, p2next, pmid};
+    int best = -1;
+    for (int i = 0; i < 3; i++) if (fabs(cand[i].d0) < gtol && (best < 0 || cand[i].cost < cand[best].cost)) best = i;
+    if (best >= 0) return cand[best].alpha;
+    int b1 = ls_update_bracket(c, &p1, cand, &p1next), b2 = ls_update_bracket(c, &p2, cand, &p2next);
+    if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : 0;
+  }
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0;
+}
+
+/* dense Cholesky H = L L' in place (lower triangle), mju_cholFactor (mujoco.h:1211) incl. its diagonal floor */
+static void chol_factor(double* H, int n) {
+  for (int j = 0; j < n; j++) {
+    double t = H[j * n + j];
+    for (int k = 0; k < j; k++) t -= H[j * n + k] * H[j * n + k];
+    if (t < MINVAL) t = MINVAL;
+    t = sqrt(t);
+    H[j * n + j] = t;
+    for (int i = j + 1; i < n; i++) {
+      double s = H[i * n + j];
+      for (int k = 0; k < j; k++) s -= H[i * n + k] * H[j * n + k];
+      H[i * n + j] = s / t;
+    }
+  }
+}
+static void chol_solve(const double* L, int n, double* x) { /* mju_cholSolve, mujoco.h:1214 */
+  for (int i = 0; i < n; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k]; x[i] = s / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
+}
+
+/* constraint part of the primal cost at jar (mj_constraintUpdate, mujoco.h:371) */
+static double primal_constraint_cost(const om_data* d, const double* jar) {
+  double c = 0;
+  for (int i = 0; i < d->nefc; i++) if (jar[i] < 0) c += 0.5 * d->efc_D[i] * jar[i] * jar[i];
+  return c;
+}
+
+static void sol_newton(const om_model* m, om_data* d) {
+  int nv = m->nv, n = d->nefc;
+  double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+  double* buf = (double*)calloc((size_t)6 * nv + 2 * n + (size_t)nv * nv, sizeof(double));
+  double *Ma = buf, *grad = Ma + nv, *search = grad + nv, *Mv = search + nv, *tmp = Mv + nv, *dq = tmp + nv, *jar = dq + nv, *Jv = jar + n, *H = Jv + n;
+  int* state = (int*)calloc(2 * (size_t)n + 1, sizeof(int));
+  double cost = 0;
+  d->solver_nls = 0;
+  /* initial point: d->qacc (set by the warm start) */
+  mul_M(m, d->qM, d->qacc, Ma);
+  for (int i = 0; i < n; i++) {
+    double s = 0;
+    for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * d->qacc[k];
+    jar[i] = s - d->efc_aref[i];
+  }
+  int need_factor = 1, iter = 0;
+  for (;;) {
+    /* PrimalUpdateConstraint: force, state, qfrc_constraint, cost */
+    constraint_update(d, jar);
+    int changed = need_factor;
+    for (int i = 0; i < n; i++) { int st = jar[i] < 0; if (st != state[i]) changed = 1; state[i] = st; }
+    memset(d->qfrc_constraint, 0, sizeof(double) * nv);
+    for (int i = 0; i < n; i++) if (state[i]) for (int k = 0; k < nv; k++) d->qfrc_constraint[k] += d->efc_J[(size_t)i * nv + k] * d->efc_force[i];
+    double oldcost = cost;
+    cost = primal_constraint_cost(d, jar);
+    for (int k = 0; k < nv; k++) cost += 0.5 * (Ma[k] - d->qfrc_smooth[k]) * (d->qacc[k] - d->qacc_smooth[k]);
+    /* Hessian (MakeHessian / HessianIncremental give the same matrix): H = M + J' diag(D active) J, Cholesky */
+    if (changed) {
+      memset(H, 0, sizeof(double) * nv * nv);
+      for (int i = 0; i < nv; i++) {
+        int adr = m->dof_Madr[i];
+        for (int j = i; j >= 0; j = m->dof_parentid[j], adr++) { H[i * nv + j] = d->qM[adr]; H[j * nv + i] = d->qM[adr]; }
+      }
+      for (int r = 0; r < n; r++) if (state[r]) {
+        const double* Jr = d->efc_J + (size_t)r * nv;
+        for (int i = 0; i < nv; i++) if (Jr[i] != 0) for (int j = 0; j < nv; j++) H[i * nv + j] += d->efc_D[r] * Jr[i] * Jr[j];
+      }
+      chol_factor(H, nv);
+      need_factor = 0;
+    }
+    /* PrimalUpdateGradient */
+    double gnorm = 0;
+    for (int k = 0; k < nv; k++) { grad[k] = Ma[k] - d->qfrc_smooth[k] - d->qfrc_constraint[k]; gnorm += grad[k] * grad[k]; tmp[k] = grad[k]; }
+    gnorm = sqrt(gnorm);
+    chol_solve(H, nv, tmp);
+    if (iter > 0) {
+      double improvement = scale * (oldcost - cost), gradient = scale * gnorm;
+      if (improvement < m->tolerance || gradient < m->tolerance) break;
+    }
+    if (iter >= m->iterations) break;
+    for (int k = 0; k < nv; k++) search[k] = -tmp[k];
+    /* PrimalSearch */
+    mul_M(m, d->qM, search, Mv);
+    double snorm = 0, qg1 = 0, qg2 = 0;
+    for (int k = 0; k < nv; k++) { snorm += search[k] * search[k]; qg1 += search[k] * (Ma[k] - d->qfrc_smooth[k]); qg2 += 0.5 * search[k] * Mv[k]; }
+    snorm = sqrt(snorm);
+    for (int i = 0; i < n; i++) {
+      double s = 0;
+      for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * search[k];
+      Jv[i] = s;
+    }
+    double gauss = 0;
+    for (int k = 0; k < nv; k++) gauss += 0.5 * (Ma[k] - d->qfrc_smooth[k]) * (d->qacc[k] - d->qacc_smooth[k]);
+    om_lsctx c = {n, jar, Jv, d->efc_D, {gauss, qg1, qg2}, 0};
+    double alpha = ls_search(m, &c, snorm, scale);
+    d->solver_nls += c.nev;
+    if (alpha == 0) break;
+    for (int k = 0; k < nv; k++) { d->qacc[k] += alpha * search[k]; Ma[k] += alpha * Mv[k]; }
+    for (int i = 0; i < n; i++) jar[i] += alpha * Jv[i];
+    iter++;
+  }
+  d->solver_niter = iter;
+  free(state);
+  free(buf);
+}
+
+/* mj_fwdConstraint, mujoco.h:259: warm start, then mj_solPGS [recall] or the Newton solver above */
 static void fwd_constraint(const om_model* m, om_data* d) {
   int nv = m->nv, n = d->nefc;
   d->solver_niter = 0;
@@ -1049,6 +1244,28 @@ static void fwd_constraint(const om_model* m, om_data* d) {
     d->efc_b[i] = s - d->efc_aref[i];
   }
   double* jar = (double*)malloc(sizeof(double) * n);
+  if (m->solver == SOL_NEWTON) {
+    /* warmstart() of mj_fwdConstraint for the primal solvers [recall]: start from qacc_warmstart unless
+       qacc_smooth has the lower cost (its Gauss term is zero) */
+    memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
+    if (!(m->disableflags & DSBL_WARMSTART)) {
+      double* Ma = (double*)malloc(sizeof(double) * nv);
+      for (int i = 0; i < n; i++) {
+        double s = 0;
+        for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * d->qacc_warmstart[k];
+        jar[i] = s - d->efc_aref[i];
+      }
+      double cost_warm = primal_constraint_cost(d, jar);
+      mul_M(m, d->qM, d->qacc_warmstart, Ma);
+      for (int k = 0; k < nv; k++) cost_warm += 0.5 * (Ma[k] - d->qfrc_smooth[k]) * (d->qacc_warmstart[k] - d->qacc_smooth[k]);
+      double cost_smooth = primal_constraint_cost(d, d->efc_b);
+      if (cost_warm <= cost_smooth) memcpy(d->qacc, d->qacc_warmstart, sizeof(double) * nv);
+      free(Ma);
+    }
+    sol_newton(m, d);
+    free(jar);
+    return;
+  }
   /* warm start */
   if (!(m->disableflags & DSBL_WARMSTART)) {
     for (int i = 0; i < n; i++) {
@@ -1117,7 +1334,7 @@ void om_forward(const om_model* m, om_data* d) {
   factor_i(m, d->qM, d->qLD, d->qLDiagInv);
   collision(m, d);
   make_constraint(m, d);
-  project_constraint(m, d);
+  if (m->solver == SOL_PGS) project_constraint(m, d);
   com_vel(m, d);
   passive(m, d);
   reference_constraint(m, d);
@@ -1207,12 +1424,15 @@ int om_model_int(const om_model* m, const char* name) {
 void om_model_set_int(om_model* m, const char* name, int v) {
   if (!strcmp(name, "iterations")) m->iterations = v;
   else if (!strcmp(name, "disableflags")) m->disableflags = v;
+  else if (!strcmp(name, "solver")) m->solver = v;
+  else if (!strcmp(name, "ls_iterations")) m->ls_iterations = v;
 }
 void om_model_set_dbl(om_model* m, const char* name, double v) {
   if (!strcmp(name, "timestep")) m->timestep = v;
   else if (!strcmp(name, "tolerance")) m->tolerance = v;
   else if (!strcmp(name, "impratio")) m->impratio = v;
   else if (!strcmp(name, "meaninertia")) m->meaninertia = v;
+  else if (!strcmp(name, "ls_tolerance")) m->ls_tolerance = v;
 }
 double om_model_dbl(const om_model* m, const char* name) {
   if (!strcmp(name, "timestep")) return m->timestep;
@@ -1226,6 +1446,7 @@ int om_data_int(const om_data* d, const char* name) {
   if (!strcmp(name, "nefc")) return d->nefc;
   if (!strcmp(name, "nl")) return d->nl;
   if (!strcmp(name, "solver_niter")) return d->solver_niter;
+  if (!strcmp(name, "solver_nls")) return d->solver_nls;
   if (!strcmp(name, "max_ncon")) return d->max_ncon;
   if (!strcmp(name, "max_nefc")) return d->max_nefc;
   if (!strcmp(name, "warn_contactfull")) return d->warning[WARN_CONTACTFULL];

@@ -146,8 +146,12 @@ def test_multi_tree_weld_and_options(hbmod, tmp_path):
     assert info["npair"] == 6  # 3 with the plane + 3 among the bodies
     m.set_opt(timestep=0.001, iterations=10, disableflags=16)
     assert m.opt.timestep == 0.001 and m.opt.iterations == 10 and m.opt.disableflags == 16
+    m.set_opt(solver=2, ls_iterations=20)  # Newton
+    assert m.opt.solver == 2 and m.opt.ls_iterations == 20
+    n = hbmod.Model.from_xml_string("<mujoco><option solver='Newton'/><worldbody><body><joint/><geom size='0.1'/></body></worldbody></mujoco>")
+    assert n.opt.solver == 2 and n.opt.iterations == 100  # mjOption's default cap, which this compiler otherwise replaces by the benchmark's 50
     with pytest.raises(hbmod.HbError):
-        m.set_opt(solver=2)  # Newton is not implemented: refused, not silently ignored
+        m.set_opt(solver=1)  # CG is not implemented: refused, not silently ignored
 
 
 @pytest.mark.parametrize("xml,frag", [
@@ -156,7 +160,7 @@ def test_multi_tree_weld_and_options(hbmod, tmp_path):
     ("<mujoco><worldbody><body><joint/><geom type='sphere'/></body></worldbody></mujoco>", "size"),
     ("<mujoco><worldbody><body><joint/></body></worldbody></mujoco>", "no mass"),
     ("<mujoco><worldbody><body></worldbody></mujoco>", "mismatched"),
-    ("<mujoco><option solver='Newton'/><worldbody/></mujoco>", "PGS"),
+    ("<mujoco><option solver='CG'/><worldbody/></mujoco>", "PGS"),
     ("<notmujoco/>", "root element"),
 ])
 def test_compile_errors_are_reported_not_fatal(hbmod, xml, frag):

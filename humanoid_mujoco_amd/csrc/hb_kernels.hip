@@ -619,6 +619,74 @@ __device__ __forceinline__ float chol_solve_rows(const f32x2 (&A)[16], float dv,
   return __int_as_float(x);
 }
 
+// ---- symmetric elimination on the matrix cores (Newton instantiation of order <= 28) -----------------------------
+// A symmetric 32 x 32 matrix S lives in the accumulator layout of v_mfma_f32_32x32x2_f32 (f32x16 per lane: lane = column
+// + 32 * half, register r = row crow(r) + 4 * half).  In that layout ROW k of S is one register on the 32 lanes of one
+// half - which is exactly the shape of an MFMA operand - and by symmetry it is also column k.  Gaussian elimination of
+// two pivots is therefore ONE rank-2 MFMA update  S -= a b'  with b = the two pivot rows (one per half, moved by a
+// v_permlane32_swap) and a = -b / D masked to the rows below the pivot: about twenty-five VALU instructions per pivot
+// pair instead of a trailing update of N - k columns.  The same multipliers applied to T (started at I) by a second
+// MFMA leave T = L^-1; the right-hand side rides along as row / column 31, so z_k = U[k][31] / D_k = (D^-1 L^-1 g)_k
+// falls out of the pivot rows, and x = T' z is sixteen lane-local fmas plus one swap.  NP pivot pairs (order 2 NP <= 30);
+// rows beyond are identity padding and are never pivots.
+// (Building T in place of the eliminated triangle - pivot row with a doubled diagonal, one MFMA per pair - was measured
+// too: fewer MFMAs but more VALU work per pair, and VALU issue is what the two waves of a SIMD compete for: slower.)
+__device__ __forceinline__ constexpr int crow(int r) { return (r & 3) + 8 * (r >> 2); }
+
+template <int NP>
+__device__ __forceinline__ float sym_solve_mfma(f32x16 X, float g, int lane) {
+  const int li = lane & 31, half = lane >> 5;
+  const bool up = half != 0;
+  {  // right-hand side into row 31 and column 31 (g is mirrored in both halves and zero beyond nv): S += e31 g' + g e31'
+    const float e31 = li == 31 ? 1.f : 0.f;
+    X = __builtin_amdgcn_mfma_f32_32x32x2f32(up ? g : e31, up ? e31 : g, X, 0, 0, 0);
+  }
+  f32x16 T, Z;
+  const int q = li - 4 * half;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { T[r] = q == crow(r) ? 1.f : 0.f; Z[r] = 0.f; }
+  const float lik = (float)(li - half);  // row index minus the pivot slot of this half
+#pragma unroll
+  for (int b = 0; b < NP; b++) {
+    const int k0 = 2 * b, r0 = (k0 & 3) + 4 * (k0 >> 3), h0 = (k0 >> 2) & 1, L0 = 32 * h0;
+    const float rowa = X[r0], rowb = X[r0 + 1], ta = T[r0], tb = T[r0 + 1];  // rows k0, k0 + 1 on the lanes of half h0
+    const float inv0 = __builtin_amdgcn_rcpf(fmaxf(rdlane(rowa, L0 + k0), HB_MINVAL));
+    const float m = rdlane(rowb, L0 + k0) * inv0;
+    const float rowb1 = __builtin_fmaf(-m, rowa, rowb), tb1 = __builtin_fmaf(-m, ta, tb);  // row k0 + 1 after pivot k0
+    const float inv1 = __builtin_amdgcn_rcpf(fmaxf(rdlane(rowb1, L0 + k0 + 1), HB_MINVAL));
+    const u32x2 sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(rowa), __float_as_uint(rowb1), false, false);
+    const u32x2 st = __builtin_amdgcn_permlane32_swap(__float_as_uint(ta), __float_as_uint(tb1), false, false);
+    const float vb = __uint_as_float(h0 ? sx.y : sx.x), vt = __uint_as_float(h0 ? st.y : st.x);  // half 0: row k0, half 1: row k0 + 1
+    const float below = __builtin_amdgcn_fmed3f(lik - (float)k0, 0.f, 1.f);                       // 1 on the rows below this half's pivot
+    const float va = -(vb * (up ? inv1 : inv0)) * below;
+    X = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, X, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vt, T, 0, 0, 0);
+    const float z0 = rdlane(rowa, L0 + 31) * inv0, z1 = rdlane(rowb1, L0 + 31) * inv1;
+    if (half == h0) { Z[r0] = z0; Z[r0 + 1] = z1; }
+  }
+  float p = 0.f, p1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) { p = __builtin_fmaf(T[r], Z[r], p); p1 = __builtin_fmaf(T[r + 1], Z[r + 1], p1); }
+  p += p1;
+  const u32x2 sp = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+  return p + __uint_as_float(up ? sp.x : sp.y);
+}
+
+// a dof vector valid on lanes 0..31, copied to both halves
+__device__ __forceinline__ float rdlane_mirror(float x, int lane) {
+  const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return lane >= 32 ? __uint_as_float(sw.x) : x;
+}
+
+// the dense mass matrix ([32][kCs] in LDS, identity beyond nv) in the accumulator layout
+__device__ __forceinline__ f32x16 load_sym(const float* s_Md, int stride, int lane) {
+  const float* pl = s_Md + 4 * (lane >> 5) * stride + (lane & 31);
+  f32x16 X;
+#pragma unroll
+  for (int r = 0; r < 16; r++) X[r] = pl[crow(r) * stride];
+  return X;
+}
+
 // SOLVER: mjtSolver of the instantiation (0 = PGS, 2 = Newton); everything outside the constraint solve, the mass-matrix
 // factorisation and the integrator's damped solve is shared.
 template <int SOLVER, int NDENSE>
@@ -1602,6 +1670,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       float* s_Md = s_efc;
       const float* Mrow = s_Md + li * kCs;
       const float* Jrow = s_C + (rowact ? lane : 0) * cs;
+      constexpr bool kMfma = NDENSE <= 28;  // order <= 28: elimination on the matrix cores; else Cholesky in registers
       f32x2 H[16];
 #pragma unroll
       for (int j = 0; j < 32; j++) H[j >> 1][j & 1] = s_qLD[M.mdense[j * 32 + li]].x;
@@ -1609,12 +1678,21 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 #pragma unroll
         for (int j = 0; j < 32; j++) s_Md[lane * kCs + j] = H[j >> 1][j & 1];
       }
-      const float smooth = dofl ? s_smooth[lane] : 0.f;
-      const float warm = dofl ? s_warm[lane] : 0.f;
+      // dof vectors are mirrored in both halves of the wave (lane l and l + 32 hold dof l & 31)
+      const float smooth = li < nv ? s_smooth[li] : 0.f;
+      const float warm = li < nv ? s_warm[li] : 0.f;
       // qacc_smooth = M^-1 qfrc_smooth
-      float dv = chol_rows<NDENSE>(H, s_v1, li, lane);
-      const float qs = chol_solve_rows<NDENSE>(H, dv, smooth);
-      gsync();
+      float dv = 1.f;
+      float qs;
+      if constexpr (kMfma) {
+        gsync();
+        qs = sym_solve_mfma<NDENSE / 2>(load_sym(s_Md, kCs, lane), smooth, lane);
+      } else {
+        dv = chol_rows<NDENSE>(H, s_v1, li, lane);
+        qs = chol_solve_rows<NDENSE>(H, dv, smooth);
+        qs = rdlane_mirror(qs, lane);
+        gsync();
+      }
       float qacc = qs, qfc = 0.f;
       HB_STAMP(11);
       if (nefc > 0) {
@@ -1661,20 +1739,25 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             qfc += q1;
           }
           const float oldcost = cost;
-          newton_grad = dofl ? Ma - smooth - qfc : 0.f;
+          newton_grad = li < nv ? Ma - smooth - qfc : 0.f;
           cost = wave_sum((act ? 0.5f * Dd * jar * jar : 0.f) + (dofl ? 0.5f * (Ma - smooth) * (qacc - qs) : 0.f));
-          const float g2 = wave_sum(newton_grad * newton_grad);
-          if (niter > 0 && (scale * (oldcost - cost) < tol || scale * sqrtf(g2) < tol)) break;
+          // |grad| and the fp32 resolution of its own terms: the reference's gradient test (scale |grad| < tolerance) cannot
+          // be met by a sum of O(1e2) terms in fp32, so the test is floored at that sum's rounding level
+          const float g2 = wave_sum(dofl ? newton_grad * newton_grad : 0.f);
+          const float gm = fabsf(Ma) + fabsf(smooth) + fabsf(qfc);
+          const float gm2 = wave_sum(dofl ? gm * gm : 0.f);
+          const float gradtol = fmaxf(tol / scale, 1e-6f * sqrtf(gm2));
+          if (niter > 0 && (scale * (oldcost - cost) < tol || sqrtf(g2) < gradtol)) break;
           if (niter >= maxiter) break;
           HB_NP(0);
-          // Hessian of the active set (MakeHessian; rebuilt only when the active set changed) and its Cholesky factor
-          if (!have_factor || actmask != act_prev) {
+          float search;
+          if constexpr (kMfma) {
+            // Hessian of the active set in the accumulator layout: M, plus J' diag(D active) J on the matrix cores
+            // (MakeHessian), eliminated together with the gradient: search = -H^-1 grad
             s_force[lane] = act ? Dd : 0.f;
             gsync();
             const int half = lane >> 5;
-            f32x16 X;
-#pragma unroll
-            for (int r = 0; r < 16; r++) X[r] = 0.f;
+            f32x16 X = load_sym(s_Md, kCs, lane);
             for (int kk = 0; 2 * kk < nefc; kk++) {
               const int row = 2 * kk + half;
               const bool v = row < nefc;
@@ -1682,22 +1765,43 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
               const float b = v ? a * s_force[row] : 0.f;
               X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, X, 0, 0, 0);  // += J_row' (D J_row)
             }
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-              const int ra = (r & 3) + 8 * (r >> 2);  // C/D layout: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
-              const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[r]), __float_as_uint(X[r]), false, false);
-              H[ra >> 1][ra & 1] = Mrow[ra] + __uint_as_float(sw.x);
-              H[(ra + 4) >> 1][ra & 1] = Mrow[ra + 4] + __uint_as_float(sw.y);
-            }
             HB_NP(1);
-            dv = chol_rows<NDENSE>(H, s_v1, li, lane);
+            search = -sym_solve_mfma<NDENSE / 2>(X, newton_grad, lane);
             HB_NP(2);
-            act_prev = actmask;
-            have_factor = true;
             gsync();
+          } else {
+            // Hessian of the active set (MakeHessian; rebuilt only when the active set changed) and its Cholesky factor
+            if (!have_factor || actmask != act_prev) {
+              s_force[lane] = act ? Dd : 0.f;
+              gsync();
+              const int half = lane >> 5;
+              f32x16 X;
+#pragma unroll
+              for (int r = 0; r < 16; r++) X[r] = 0.f;
+              for (int kk = 0; 2 * kk < nefc; kk++) {
+                const int row = 2 * kk + half;
+                const bool v = row < nefc;
+                const float a = v ? s_C[row * cs + li] : 0.f;
+                const float b = v ? a * s_force[row] : 0.f;
+                X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, X, 0, 0, 0);  // += J_row' (D J_row)
+              }
+#pragma unroll
+              for (int r = 0; r < 16; r++) {
+                const int ra = crow(r);  // C/D layout: row = crow(reg) + 4*(lane>>5), col = lane&31
+                const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(X[r]), __float_as_uint(X[r]), false, false);
+                H[ra >> 1][ra & 1] = Mrow[ra] + __uint_as_float(sw.x);
+                H[(ra + 4) >> 1][ra & 1] = Mrow[ra + 4] + __uint_as_float(sw.y);
+              }
+              HB_NP(1);
+              dv = chol_rows<NDENSE>(H, s_v1, li, lane);
+              HB_NP(2);
+              act_prev = actmask;
+              have_factor = true;
+              gsync();
+            }
+            // PrimalUpdateGradient: search = -H^-1 grad
+            search = -rdlane_mirror(chol_solve_rows<NDENSE>(H, dv, newton_grad), lane);
           }
-          // PrimalUpdateGradient: search = -H^-1 grad
-          const float search = -chol_solve_rows<NDENSE>(H, dv, newton_grad);
           HB_NP(3);
           float Mv, Jv0;
           rowdot2<NDENSE>(Mrow, Jrow, search, Mv, Jv0);
@@ -1708,7 +1812,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
           // tolerance is the reference's (tolerance * ls_tolerance * |search| / scale) floored at fp32 resolution
           // of the slope's own terms.
           const float gq = dofl ? Ma - smooth : 0.f;
-          const float qg1 = wave_sum(search * gq), qg2 = 0.5f * wave_sum(dofl ? search * Mv : 0.f), sn2 = wave_sum(search * search);
+          const float qg1 = wave_sum(search * gq), qg2 = 0.5f * wave_sum(dofl ? search * Mv : 0.f), sn2 = wave_sum(dofl ? search * search : 0.f);
           const float DJv = Dd * Jv, DJv2 = DJv * Jv;
           const float mag = wave_sum(fabsf(search * gq) + (act ? fabsf(DJv * jar) : 0.f));
           const float gtol = fmaxf(tol * lstol * sqrtf(sn2) / scale, 2e-6f * mag);
@@ -1812,12 +1916,23 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
           // h B qacc + grad (grad = M qacc - qfrc_smooth - qfrc_constraint, the Newton residual: qfrc_smooth + qfrc_constraint
           // = M qacc - grad, so H^-1 (qfrc_smooth + qfrc_constraint) = qacc - H^-1 (h B qacc + grad))
           const int li = lane & 31;
-          f32x2 He[16];
+          const float rhs = li < nv ? M.timestep * M.dof_damping[li] * s_v0[li] + newton_grad : 0.f;
+          float x;
+          if constexpr (NDENSE <= 28) {
+            const float* s_Md = s_efc;  // dense M, still in place
+            f32x16 X = load_sym(s_Md, kCs, lane);
+            const float hd = li < nv ? M.timestep * M.dof_damping[li] : 0.f;
+            const int q = li - 4 * (lane >> 5);
 #pragma unroll
-          for (int j = 0; j < 32; j++) He[j >> 1][j & 1] = s_qLD[M.mdense[j * 32 + li]].y;
-          const float dve = chol_rows<NDENSE>(He, s_v1, li, lane);
-          const float rhs = lane < nv ? M.timestep * M.dof_damping[lane] * s_v0[lane] + newton_grad : 0.f;
-          const float x = chol_solve_rows<NDENSE>(He, dve, rhs);
+            for (int r = 0; r < 16; r++) X[r] += q == crow(r) ? hd : 0.f;
+            x = sym_solve_mfma<NDENSE / 2>(X, rhs, lane);
+          } else {
+            f32x2 He[16];
+#pragma unroll
+            for (int j = 0; j < 32; j++) He[j >> 1][j & 1] = s_qLD[M.mdense[j * 32 + li]].y;
+            const float dve = chol_rows<NDENSE>(He, s_v1, li, lane);
+            x = chol_solve_rows<NDENSE>(He, dve, rhs);
+          }
           if (lane < nv) s_v2[lane] = s_v0[lane] - x;
           gsync();
         }

@@ -104,6 +104,45 @@ def test_free_running_tracks_oracle_through_contacts(hbmod, newton_model, gpu):
     assert worst <= 5e-4, worst
 
 
+MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+
+
+@pytest.mark.parametrize("name,steps", [("ball_plane", 400), ("capsules", 300), ("chain", 300), ("pendulum_limit", 500), ("maxsize", 600)])
+def test_other_models_one_step_parity_along_oracle_trajectory(hbmod, gpu, tmp_path, name, steps):
+    """Small models (dense order padded to 28: elimination on the matrix cores) and the nv = 32 model (the order-32
+    instantiation: Cholesky in registers), teacher-forced one-step parity along an oracle rollout."""
+    m = hbmod.Model.load(os.path.join(MODELS, name + ".xml"))
+    m.set_opt(solver=SOL_NEWTON, iterations=100)
+    p = str(tmp_path / (name + ".hbm"))
+    m.save(p)
+    o = Oracle(p)
+    assert o.opt("solver") == SOL_NEWTON
+    o.reset(0 if name == "chain" else -1)
+    rng = np.random.default_rng(11)
+    states, ctrls, outs = [], [], []
+    for t in range(steps):
+        c = rng.uniform(-1, 1, size=max(o.nu, 1))[:o.nu]
+        o.ctrl[:] = c
+        if t % 10 == 0:
+            states.append(np.concatenate([[o.time], o.qpos, o.qvel, o.qacc_warmstart]))
+            ctrls.append(c.copy())
+        o.step()
+        if t % 10 == 0:
+            outs.append((o.qpos.copy(), o.qvel.copy(), o.ncon, o.nefc))
+    n = len(states)
+    b = hbmod.Batch(m, n, gpu)
+    b.set_state(hbmod.STATE_INTEGRATION, np.array(states))
+    b.step(np.array(ctrls, dtype=np.float32).reshape(n, m.nu))
+    q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
+    nc, ne, ni = b.counts()
+    assert not b.status().any()
+    assert ni.max() <= 30
+    for k, (qo, vo, nco, neo) in enumerate(outs):
+        assert (nc[k], ne[k]) == (nco, neo), (k, nc[k], ne[k], nco, neo)
+        assert (np.abs(q[k] - qo) / np.maximum(1, np.abs(qo))).max() <= 1e-4
+        assert np.abs(v[k] - vo).max() <= 1e-3 * max(1.0, np.abs(vo).max())
+
+
 def test_rollout_is_sane_and_matches_oracle_statistics(hbmod, newton_model, gpu):
     n, T = 256, 600
     b = hbmod.Batch(newton_model, n, gpu)

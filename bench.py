@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the second (single-launch rollout) measurement, e.g. under rocprofv3")
+    ap.add_argument("--no-newton", action="store_true", help="skip the third measurement (same workload with the reference's default solver, Newton)")
     ap.add_argument("--no-pipeline", action="store_true", help="time the unpipelined step API (one launch per step) as `value`")
     args = ap.parse_args()
 
@@ -177,6 +178,30 @@ def main():
         elapsed_rollout = float(tt.item())
         dist.barrier()
 
+    # Third measurement (N = 1 only), reported beside `value`: the same workload and step API with the solver the
+    # reference's own model file selects (none given = mjOption's default, Newton / 100 iterations) instead of the
+    # benchmark configuration's PGS / 50.
+    newton = None
+    if world == 1 and not args.no_newton:
+        nm = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm"))
+        nm.set_opt(solver=2, iterations=100)
+        nb = hb.Batch(nm, n_env, device)
+        nb.reset(perturb=True, env_offset=lo)
+        nb.pipeline(pipelined)
+        for t in range(W):
+            nb.step_dev(ctrl + t * stride)
+        nb.sync()
+        t2 = time.perf_counter()
+        for t in range(W, W + K):
+            nb.step_dev(ctrl + t * stride)
+        nb.sync()
+        el = time.perf_counter() - t2
+        _, _, nit = nb.counts()
+        newton = {"value": n_env * K / el, "unit": "env-steps/s", "ms_per_step": 1e3 * el / K, "mean_iterations": float(nit.mean()),
+                  "envs_with_warnings": int((nb.status() != 0).sum()),
+                  "what": "same workload and step API, solver = Newton (mjOption default: what the reference's humanoid.xml runs), 100 iterations max, tolerance 1e-8"}
+        nb.close()
+
     if rank == 0:
         value = n_env * world * K / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (launch_us * 1e-6) / 1e9
@@ -205,6 +230,8 @@ def main():
         if elapsed_rollout is not None:
             out["rollout"] = {"value": n_env * world * K / elapsed_rollout, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed_rollout / K,
                               "what": "same K steps as one hb_rollout_dev launch per GPU (no per-step batch barrier; testspeed.cc shape)"}
+        if newton is not None:
+            out["newton"] = newton
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -32,7 +32,7 @@ struct Model {
   // ---- options (mjOption, mjmodel.h:403-445) — only the fields this path honours
   double timestep = 0.002, impratio = 1.0, tolerance = 1e-8;
   double gravity[3] = {0, 0, -9.81};
-  int integrator = 0, cone = 0, solver = SOL_PGS, iterations = 50, disableflags = 0;
+  int integrator = 0, cone = 0, solver = SOL_NEWTON, iterations = 100, disableflags = 0;  // mjOption defaults (mj_defaultOption)
   int ls_iterations = 50;      // Newton line search: evaluation cap (mjOption.ls_iterations, mjmodel.h:434)
   double ls_tolerance = 0.01;  // and its slope tolerance relative to the main one (mjmodel.h:411)
   double meaninertia = 1.0;  // mjModel.stat.meaninertia (mjmodel.h:547)

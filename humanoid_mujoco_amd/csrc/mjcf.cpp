@@ -522,14 +522,13 @@ bool read_option(Ctx& c, const XmlNode& n) {
   m.timestep = a.num("timestep", m.timestep);
   m.impratio = a.num("impratio", m.impratio);
   m.tolerance = a.num("tolerance", m.tolerance);
-  const bool iterations_given = n.attr("iterations") != nullptr;
   m.iterations = a.integer("iterations", m.iterations);
   m.ls_iterations = a.integer("ls_iterations", m.ls_iterations);
   m.ls_tolerance = a.num("ls_tolerance", m.ls_tolerance);
   if (a.vec("gravity", m.gravity, 3, 3) < 0) return false;
   std::string s = a.str("solver", "");
   if (s == "PGS") m.solver = SOL_PGS;
-  else if (s == "Newton") { m.solver = SOL_NEWTON; if (!iterations_given) m.iterations = 100; /* mjOption default */ }
+  else if (s == "Newton") m.solver = SOL_NEWTON;
   else if (s == "CG") return c.fail("mjcf: solver 'CG' is not implemented; this engine runs PGS or Newton (see DESIGN.md)");
   s = a.str("cone", "pyramidal");
   if (s != "pyramidal") return c.fail("mjcf: only the pyramidal friction cone is implemented");

@@ -101,7 +101,10 @@ def test_setconst_products_match_oracle_recomputation(oracle):
 def test_fixture_reproduced_from_reference_xml(hbmod, tmp_path):
     """The committed humanoid27.hbm is exactly what the compiler produces from the reference's MJCF."""
     p = str(tmp_path / "h.hbm")
-    hbmod.Model.load(REF_HUMANOID_XML).save(p)
+    m = hbmod.Model.load(REF_HUMANOID_XML)
+    assert m.opt.solver == 2 and m.opt.iterations == 100  # the MJCF sets no solver: mjOption's defaults (Newton, 100)
+    m.set_opt(solver=0, iterations=50)                    # the benchmark configuration the committed model carries
+    m.save(p)
     assert open(p).read() == open(HUMANOID_HBM).read()
 
 
@@ -149,7 +152,9 @@ def test_multi_tree_weld_and_options(hbmod, tmp_path):
     m.set_opt(solver=2, ls_iterations=20)  # Newton
     assert m.opt.solver == 2 and m.opt.ls_iterations == 20
     n = hbmod.Model.from_xml_string("<mujoco><option solver='Newton'/><worldbody><body><joint/><geom size='0.1'/></body></worldbody></mujoco>")
-    assert n.opt.solver == 2 and n.opt.iterations == 100  # mjOption's default cap, which this compiler otherwise replaces by the benchmark's 50
+    assert n.opt.solver == 2 and n.opt.iterations == 100
+    d = hbmod.Model.from_xml_string("<mujoco><worldbody><body><joint/><geom size='0.1'/></body></worldbody></mujoco>")
+    assert d.opt.solver == 2 and d.opt.iterations == 100 and d.opt.ls_iterations == 50  # mjOption defaults
     with pytest.raises(hbmod.HbError):
         m.set_opt(solver=1)  # CG is not implemented: refused, not silently ignored
 

@@ -70,7 +70,7 @@ if "SQ_INSTS_VALU" in counters:
         out["valu_lane_ops_per_s"] = counters["SQ_INSTS_VALU"]["mean"] * 64 / (avg_ns * 1e-9)
         out["valu_issue_frac_of_peak"] = out["valu_lane_ops_per_s"] / 78.6e12
 json.dump(out, open(os.path.join(dst, rnd + "_counters.json"), "w"), indent=1)
-for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("pipeline_sweep.txt", rnd + "_pipeline_sweep.txt"), ("vecenv.txt", rnd + "_vecenv.txt"), ("soak.txt", rnd + "_soak.txt"), ("pgs_fit.txt", rnd + "_pgs_fit.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt")):
+for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("pipeline_sweep.txt", rnd + "_pipeline_sweep.txt"), ("vecenv.txt", rnd + "_vecenv.txt"), ("soak.txt", rnd + "_soak.txt"), ("pgs_fit.txt", rnd + "_pgs_fit.txt"), ("newton_bench.txt", rnd + "_newton_bench.txt"), ("newton_phases.txt", rnd + "_newton_phases.txt"), ("newton_sections.txt", rnd + "_newton_sections.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt")):
     p = os.path.join(src, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))

@@ -1,13 +1,24 @@
 // hb_compile — compile an MJCF file to the .hbm text model (host only, no GPU needed).
-// usage: hb_compile in.xml out.hbm
+// usage: hb_compile in.xml out.hbm [--solver PGS|Newton] [--iterations N]
+// (the options override mjOption after compilation: the committed benchmark model carries the benchmark's PGS / 50)
 #include "../humanoid_mujoco_amd/csrc/hb_model.hpp"
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 int main(int argc, char** argv) {
   if (argc < 3) { fprintf(stderr, "usage: %s in.xml|in.hbm out.hbm\n", argv[0]); return 2; }
   hb::Model m;
   std::string err, in = argv[1];
   bool ok = in.size() > 4 && in.substr(in.size() - 4) == ".hbm" ? hb::load_hbm(in, m, err) : hb::compile_mjcf_file(in, m, err);
   if (!ok) { fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
+  for (int i = 3; i + 1 < argc; i += 2) {
+    if (!strcmp(argv[i], "--solver")) {
+      if (!strcmp(argv[i + 1], "PGS")) m.solver = hb::SOL_PGS;
+      else if (!strcmp(argv[i + 1], "Newton")) m.solver = hb::SOL_NEWTON;
+      else { fprintf(stderr, "error: unknown solver %s\n", argv[i + 1]); return 2; }
+    } else if (!strcmp(argv[i], "--iterations")) m.iterations = atoi(argv[i + 1]);
+    else { fprintf(stderr, "error: unknown option %s\n", argv[i]); return 2; }
+  }
   if (!hb::save_hbm(m, argv[2], err)) { fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
   double mass = 0;
   for (int b = 0; b < m.nbody; b++) mass += m.body_mass[b];

@@ -258,6 +258,9 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   std::vector<int> mdense((size_t)32 * 32, m.nM);
   for (int i = 0; i < 32; i++) mdense[(size_t)i * 32 + i] = m.nM + 1;
   for (int e = 0; e < m.nM; e++) { mdense[(size_t)Mj[e] * 32 + Mi[e]] = e; mdense[(size_t)Mi[e] * 32 + Mj[e]] = e; }
+  std::vector<int> mdense_c((size_t)16 * 64);
+  for (int r = 0; r < 16; r++)
+    for (int ln = 0; ln < 64; ln++) mdense_c[(size_t)r * 64 + ln] = mdense[(size_t)(ln & 31) * 32 + ((r & 3) + 8 * (r >> 2) + 4 * (ln >> 5))];
   std::vector<int> chain((size_t)32 * (kMaxAnc + 1), 0);
   for (int i = 0; i < nv; i++) {
     int t = 0;
@@ -389,7 +392,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(body_treeid, treeid); TF(body_invweight0, m.body_invweight0); TF(tree_invmass, tree_invmass);
   TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TF(qpos0, m.qpos0); TI(dof_jntid, m.dof_jntid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TF(dof_damping, m.dof_damping); TI(M_j, Mj); TI(mrec, mrec);
   TI(fround, fround); TI(ftab, ftab);
-  TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(desc_t, desc_t); TI(mdense, mdense); TI(chain, chain);
+  TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(desc_t, desc_t); TI(mdense, mdense); TI(mdense_c, mdense_c); TI(chain, chain);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);

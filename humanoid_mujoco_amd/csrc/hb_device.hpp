@@ -75,6 +75,7 @@ struct DevModel {
   // Newton solver: dense view of the sparse mass matrix, [32 columns j][32 rows i] -> index of the {M, H} pair holding
   // M(i, j) (nM: the zero pad pair, nM + 1: the one pad pair = identity beyond nv)
   const int HB_CONST* mdense;
+  const int HB_CONST* mdense_c;  // the same view in the MFMA accumulator layout: [16 registers][64 lanes]
   const int HB_CONST* chain;     // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)
   // geoms
   const int HB_CONST *geom_type, *geom_bodyid;

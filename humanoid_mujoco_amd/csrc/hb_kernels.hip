@@ -687,6 +687,57 @@ __device__ __forceinline__ f32x16 load_sym(const float* s_Md, int stride, int la
   return X;
 }
 
+// the {M, H} pairs in the accumulator layout (WHICH = 0: M, 1: H = M + h B), straight from the sparse storage
+template <int WHICH>
+__device__ __forceinline__ f32x16 load_sym_pairs(DevModelRef M, const f32x2* s_qLD, int lane) {
+  int e[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) e[r] = M.mdense_c[r * 64 + lane];
+  f32x16 X;
+#pragma unroll
+  for (int r = 0; r < 16; r++) X[r] = s_qLD[e[r]][WHICH];
+  return X;
+}
+
+// Elimination only (PGS instantiation): T = L^-1 and, per register and half, D^-1/2 of that register's row, so that
+// W = T' D^-1/2 (M^-1 = W W') can be written out.  Same rank-2 updates as sym_solve_mfma, no right-hand side.
+template <int NP>
+__device__ __forceinline__ void sym_factor_mfma(f32x16 X, f32x16& T, f32x16& S, int lane) {
+  const int li = lane & 31, half = lane >> 5;
+  const bool up = half != 0;
+  const int q = li - 4 * half;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { T[r] = q == crow(r) ? 1.f : 0.f; S[r] = 1.f; }
+  const float lik = (float)(li - half);
+#pragma unroll
+  for (int b = 0; b < NP; b++) {
+    const int k0 = 2 * b, r0 = (k0 & 3) + 4 * (k0 >> 3), h0 = (k0 >> 2) & 1, L0 = 32 * h0;
+    const float rowa = X[r0], rowb = X[r0 + 1], ta = T[r0], tb = T[r0 + 1];
+    const float d0 = fmaxf(rdlane(rowa, L0 + k0), HB_MINVAL);
+    const float inv0 = __builtin_amdgcn_rcpf(d0);
+    const float m = rdlane(rowb, L0 + k0) * inv0;
+    const float rowb1 = __builtin_fmaf(-m, rowa, rowb), tb1 = __builtin_fmaf(-m, ta, tb);
+    const float d1 = fmaxf(rdlane(rowb1, L0 + k0 + 1), HB_MINVAL);
+    const float inv1 = __builtin_amdgcn_rcpf(d1);
+    const u32x2 sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(rowa), __float_as_uint(rowb1), false, false);
+    const u32x2 st = __builtin_amdgcn_permlane32_swap(__float_as_uint(ta), __float_as_uint(tb1), false, false);
+    const float vb = __uint_as_float(h0 ? sx.y : sx.x), vt = __uint_as_float(h0 ? st.y : st.x);
+    const float below = __builtin_amdgcn_fmed3f(lik - (float)k0, 0.f, 1.f);
+    const float va = -(vb * (up ? inv1 : inv0)) * below;
+    X = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, X, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vt, T, 0, 0, 0);
+    if (half == h0) { S[r0] = __builtin_amdgcn_rsqf(d0); S[r0 + 1] = __builtin_amdgcn_rsqf(d1); }
+  }
+}
+
+// W[c][row] = T[row][c] * S(row): lane (c, half) owns four runs of four consecutive rows: four 16-byte stores
+__device__ __forceinline__ void store_w_rows(float* W, int stride, const f32x16& T, const f32x16& S, int lane) {
+  float* p = W + (lane & 31) * stride + 4 * (lane >> 5);
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+    *reinterpret_cast<float4*>(p + 8 * g) = {T[4 * g] * S[4 * g], T[4 * g + 1] * S[4 * g + 1], T[4 * g + 2] * S[4 * g + 2], T[4 * g + 3] * S[4 * g + 3]};
+}
+
 // SOLVER: mjtSolver of the instantiation (0 = PGS, 2 = Newton); everything outside the constraint solve, the mass-matrix
 // factorisation and the integrator's damped solve is shared.
 template <int SOLVER, int NDENSE>
@@ -695,6 +746,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   // arguments): the ~100 table pointers and every wave-uniform table entry are fetched on demand by
   // scalar loads through the scalar cache instead of living in (and spilling from) SGPRs
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
+  // PGS instantiation of dense order <= 28: M^-1 = W W' from an elimination on the matrix cores instead of the sparse
+  // L'DL schedule (which stays for 29..32 dofs)
+  constexpr bool kDensePgs = SOLVER == 0 && NDENSE <= 28;
   extern __shared__ float lds[];
   const int lane0 = threadIdx.x;
   int lane = lane0;
@@ -1103,7 +1157,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     HB_STAMP(4);
     // ---------------------------------------------------------------- qM from the composite inertias
     FactorHead fhead;
-    if constexpr (SOLVER == 0) fhead = factor_head(M, lane);
+    if constexpr (SOLVER == 0 && !kDensePgs) fhead = factor_head(M, lane);
     for (int e = lane; e < M.nM; e += kGroup) {
       const int pk = M.mrec[e];  // i | j << 8 | body(i) << 16
       const float2 ad = M.mdiag[e];  // (armature, damping) on diagonal entries, 0 elsewhere
@@ -1128,8 +1182,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     gsync();
     HB_STAMP(5);
     // ---------------------------------------------------------------- mj_factorM
-    // (the Newton instantiation works on dense rows of M in registers and leaves the sparse matrix as assembled)
-    if constexpr (SOLVER == 0) {
+    // (the Newton instantiation and the dense PGS one leave the sparse matrix as assembled)
+    if constexpr (SOLVER == 0 && !kDensePgs) {
 #if defined(HB_STAMPS) && defined(HB_PROBE_FACTOR)
       factor_ld(M, lds, s_qLD, s_dinv, s_dsqrtinv, lane, fhead, P.stamps ? stamps_ : nullptr);
 #else
@@ -1459,7 +1513,14 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // rows 0..nefc-1 are constraint rows, row nefc is qfrc_smooth (-> y = D^-1/2 L^-T qfrc_smooth).
     // 32-row tiles x 32 dof columns x K = 32 on the matrix cores; A operands are preloaded so the
     // product can be written back over J in place.
-    build_w<0, false>(M, s_qLD, s_dinv, s_dsqrtinv, s_W, nullptr, lane);
+    if constexpr (kDensePgs) {
+      f32x16 T, S;
+      sym_factor_mfma<NDENSE / 2>(load_sym_pairs<0>(M, s_qLD, lane), T, S, lane);
+      store_w_rows(s_W, kWs, T, S, lane);
+      gsync();
+    } else {
+      build_w<0, false>(M, s_qLD, s_dinv, s_dsqrtinv, s_W, nullptr, lane);
+    }
     {
       const int col = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -1631,7 +1692,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     for (int k = lane; k < nv; k += kGroup) {
       float sacc = 0.f;
       for (int i = 0; i < nefc; i++) sacc += s_force[i] * s_C[i * cs + k];
-      if (want_qfrc) s_v1[k] = sacc / s_dsqrtinv[k];  // D^1/2 s
+      if constexpr (!kDensePgs) { if (want_qfrc) s_v1[k] = sacc / s_dsqrtinv[k]; }  // D^1/2 s
       s_v2[k] = yv[k] + sacc;                          // y + s
     }
     gsync();
@@ -1639,24 +1700,35 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       float qacc_i = 0.f;
       if (lane < nv) {
         qacc_i = dot32(s_W + lane * kWs, s_v2);
-        if (want_qfrc) {
-          float acc = s_v1[lane];
-          // descendants of this dof from the transposed, padded table: every load is independent of the others
-          // (eight in flight), no per-lane list walk
-          const int nd = M.ndesc_max;
-          for (int t = 0; t < nd; t += 8) {
-            int pk[8];
+        if constexpr (!kDensePgs) {
+          if (want_qfrc) {
+            float acc = s_v1[lane];
+            // descendants of this dof from the transposed, padded table: every load is independent of the others
+            // (eight in flight), no per-lane list walk
+            const int nd = M.ndesc_max;
+            for (int t = 0; t < nd; t += 8) {
+              int pk[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) pk[q] = (t + q < nd) ? M.desc_t[(t + q) * 32 + lane] : (M.nM << 8);
+              for (int q = 0; q < 8; q++) pk[q] = (t + q < nd) ? M.desc_t[(t + q) * 32 + lane] : (M.nM << 8);
 #pragma unroll
-            for (int q = 0; q < 8; q++) acc += s_qLD[pk[q] >> 8].x * s_v1[pk[q] & 255];
+              for (int q = 0; q < 8; q++) acc += s_qLD[pk[q] >> 8].x * s_v1[pk[q] & 255];
+            }
+            P.qfrc_out[(size_t)env * nv + lane] = s_smooth[lane] + acc;  // qfrc_smooth + qfrc_constraint
           }
-          P.qfrc_out[(size_t)env * nv + lane] = s_smooth[lane] + acc;  // qfrc_smooth + qfrc_constraint
         }
         s_v0[lane] = qacc_i;
       }
     }
     gsync();
+    if constexpr (kDensePgs) {
+      // qfrc_smooth + qfrc_constraint = M qacc (the dual finish defines qacc that way); M is intact in the sparse pairs
+      if (want_qfrc && lane < nv) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 32; j++) acc = __builtin_fmaf(s_qLD[M.mdense[j * 32 + lane]].x, j < nv ? s_v0[j] : 0.f, acc);
+        P.qfrc_out[(size_t)env * nv + lane] = acc;
+      }
+    }
     } else {
       // ---------------------------------------------------------------- mj_fwdConstraint, Newton solver (mj_solNewton)
       // Primal problem (oracle/mjstep_oracle.c: sol_newton): minimise over qacc
@@ -1895,7 +1967,15 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       // which needs neither the right-hand side nor qfrc_constraint: only qacc and the damping vector.
       for (int i = lane; i < nv; i += kGroup) s_warm[i] = s_v0[i];  // qacc_warmstart <- qacc
       if (eulerdamp) {
-        if constexpr (SOLVER == 0) {
+        if constexpr (kDensePgs) {
+          // H = M + h B from the H halves of the assembled pairs, eliminated on the matrix cores with h B qacc as the
+          // right-hand side column
+          const int li = lane & 31;
+          const float rhs = li < nv ? M.timestep * M.dof_damping[li] * s_v0[li] : 0.f;
+          const float x = sym_solve_mfma<NDENSE / 2>(load_sym_pairs<1>(M, s_qLD, lane), rhs, lane);
+          if (lane < nv) s_v2[lane] = s_v0[lane] - x;
+          gsync();
+        } else if constexpr (SOLVER == 0) {
           // H^-1 = W_H W_H^T; W_H and its transpose are built in the (now dead) C rows
           float* WH = s_C;
           float* WHT = s_C + 32 * kWs;  // runs on into the (dead) row-meta / W area behind C: the host checks the room
@@ -1975,7 +2055,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   if (status && lane == 0) atomicOr(P.status + env, status);
 }
 
-__global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 32>(Mp, P, nsteps); }
+// PGS instantiations: dense order 28 (nv <= 28: the 27-dof humanoid; M^-1 by elimination on the matrix cores) and 32 (sparse L'DL)
+__global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 32>(Mp, P, nsteps); }
 // Newton instantiations: dense order 28 (nv <= 28: the 27-dof humanoid) and 32
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
@@ -2517,7 +2599,8 @@ hipError_t launch_step(const DevModel* M_dev, int solver, int nv, int lds_floats
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   if (solver == 2 && nv <= 28) hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (solver == 2) hipLaunchKernelGGL(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-  else hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (nv <= 28) hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else hipLaunchKernelGGL(hb_step32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   return hipGetLastError();
 }
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
@@ -2593,6 +2676,8 @@ hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int 
 }
 hipError_t set_step_lds_limit(int bytes) {
   hipError_t e = hipFuncSetAttribute((const void*)hb_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)hb_step_newton28_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;

@@ -82,8 +82,10 @@ def test_forward_matches_oracle_and_leaves_state(hbmod, humanoid_model, gpu, gol
 
 
 def test_contact_free_drift_within_north_star_bar(hbmod, humanoid_model, gpu):
-    """Free-running GPU vs oracle over the contact-free opening of the benchmark workload."""
-    envs = [0, 1, 2, 3, 4, 5, 6, 7]
+    """Free-running GPU vs oracle over the contact-free opening of the benchmark workload: every env is compared up to
+    its first constraint row (contact or joint limit) on either side.  (Once an env has been through a contact its
+    later contact-free stretches carry that history: those are covered, teacher-forced, by the one-step tests.)"""
+    envs = list(range(64))
     n = len(envs)
     b = hbmod.Batch(humanoid_model, n, gpu)
     b.reset(perturb=True)
@@ -98,6 +100,8 @@ def test_contact_free_drift_within_north_star_bar(hbmod, humanoid_model, gpu):
         assert np.abs(q0[i] - o.qpos).max() < 1e-6
     T = 50
     worst = 0.0
+    free = [True] * n  # still in its contact-free opening: no constraint row on either side so far
+    compared = 0
     for t in range(T):
         ctrl = np.stack([o.ctrl_env(t, e) for o, e in zip(oracles, envs)]).astype(np.float32)
         b.step(ctrl)
@@ -105,9 +109,13 @@ def test_contact_free_drift_within_north_star_bar(hbmod, humanoid_model, gpu):
             o.ctrl[:] = c
             o.step()
         q = b.qpos
+        _, nefc, _ = b.counts()
         for i, o in enumerate(oracles):
-            if o.ncon == 0:
+            free[i] = free[i] and o.nefc == 0 and int(nefc[i]) == 0
+            if free[i]:
+                compared += 1
                 worst = max(worst, float((np.abs(q[i] - o.qpos) / np.maximum(1.0, np.abs(o.qpos))).max()))
+    assert compared >= 100, compared
     assert worst <= 1e-4, worst
 
 

@@ -689,7 +689,11 @@ __device__ __forceinline__ f32x16 load_sym(const float* s_Md, int stride, int la
 
 // the {M, H} pairs in the accumulator layout (WHICH = 0: M, 1: H = M + h B), straight from the sparse storage
 template <int WHICH>
-__device__ __forceinline__ f32x16 load_sym_pairs(DevModelRef M, const f32x2* s_qLD, int lane) {
+__device__ __forceinline__ f32x16 load_sym_pairs(DevModelRef M, const f32x2* s_qLD, int lane0) {
+  // (the lane id is re-materialised so that the sixteen table words are fetched again at every use instead of being
+  // kept in registers from the W stage, across the PGS sweeps, to the Euler solve)
+  int lane;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0));
   int e[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) e[r] = M.mdense_c[r * 64 + lane];
@@ -1514,9 +1518,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // 32-row tiles x 32 dof columns x K = 32 on the matrix cores; A operands are preloaded so the
     // product can be written back over J in place.
     if constexpr (kDensePgs) {
+      // (lane id re-materialised: keeps the masks and addresses of this stage from being computed, and held, phases early)
+      int lw;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(lw) : "v"(lane0));
       f32x16 T, S;
-      sym_factor_mfma<NDENSE / 2>(load_sym_pairs<0>(M, s_qLD, lane), T, S, lane);
-      store_w_rows(s_W, kWs, T, S, lane);
+      sym_factor_mfma<NDENSE / 2>(load_sym_pairs<0>(M, s_qLD, lw), T, S, lw);
+      store_w_rows(s_W, kWs, T, S, lw);
       gsync();
     } else {
       build_w<0, false>(M, s_qLD, s_dinv, s_dsqrtinv, s_W, nullptr, lane);
@@ -1970,10 +1977,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         if constexpr (kDensePgs) {
           // H = M + h B from the H halves of the assembled pairs, eliminated on the matrix cores with h B qacc as the
           // right-hand side column
-          const int li = lane & 31;
+          int le;
+          asm volatile("v_mov_b32 %0, %1" : "=v"(le) : "v"(lane0));
+          const int li = le & 31;
           const float rhs = li < nv ? M.timestep * M.dof_damping[li] * s_v0[li] : 0.f;
-          const float x = sym_solve_mfma<NDENSE / 2>(load_sym_pairs<1>(M, s_qLD, lane), rhs, lane);
-          if (lane < nv) s_v2[lane] = s_v0[lane] - x;
+          const float x = sym_solve_mfma<NDENSE / 2>(load_sym_pairs<1>(M, s_qLD, le), rhs, le);
+          if (le < nv) s_v2[le] = s_v0[le] - x;
           gsync();
         } else if constexpr (SOLVER == 0) {
           // H^-1 = W_H W_H^T; W_H and its transpose are built in the (now dead) C rows

@@ -485,6 +485,8 @@ struct hb_batch {
   size_t ctrl_cap = 0;  // floats
   float* d_qpos_out = nullptr;
   size_t qpos_out_cap = 0;
+  float* d_qvel_out = nullptr;
+  size_t qvel_out_cap = 0;
   float* d_sensor_out = nullptr;
   size_t sensor_out_cap = 0;
   bool diag = false;
@@ -855,7 +857,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
   void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
-                  b->d_status, b->d_counts, b->d_qpos_out, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
+                  b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
 }
@@ -967,6 +969,45 @@ int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out) {
   if (rc != HB_OK) return rc;
   if (qpos_out) HB_HIP(hipMemcpyAsync(qpos_out, b->d_qpos_out, nq_out * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
+}
+
+// grows a device trace buffer to `need` floats
+static int ensure_trace(float** buf, size_t* cap, size_t need) {
+  if (need <= *cap) return HB_OK;
+  if (*buf) HB_IGN(hipFree(*buf));
+  *buf = nullptr; *cap = 0;
+  if (hipMalloc((void**)buf, need * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+  *cap = need;
+  return HB_OK;
+}
+
+int hb_rollout_trajectory(hb_batch* b, const float* ctrl, int T, float* qpos_out, float* qvel_out, int* failed) {
+  if (!b || T < 1 || (!ctrl && b->D.dm.nu > 0)) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  const size_t n = (size_t)T * b->n_env * b->D.dm.nu;
+  int rc = ensure_ctrl(b, std::max<size_t>(n, 1));
+  if (rc != HB_OK) return rc;
+  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  const size_t nq_out = (size_t)T * b->n_env * b->D.dm.nq, nv_out = (size_t)T * b->n_env * b->D.dm.nv;
+  if (qpos_out && (rc = ensure_trace(&b->d_qpos_out, &b->qpos_out_cap, nq_out)) != HB_OK) return rc;
+  if (qvel_out && (rc = ensure_trace(&b->d_qvel_out, &b->qvel_out_cap, nv_out)) != HB_OK) return rc;
+  BatchPtrs P = make_ptrs(b);
+  P.ctrl = b->d_ctrl; P.ctrl_mode = 1;
+  P.qpos_out = qpos_out ? b->d_qpos_out : nullptr;
+  P.qvel_out = qvel_out ? b->d_qvel_out : nullptr;
+  rc = launch_steps(b, P, T);
+  if (rc != HB_OK) return rc;
+  if (qpos_out) HB_HIP(hipMemcpyAsync(qpos_out, b->d_qpos_out, nq_out * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  if (qvel_out) HB_HIP(hipMemcpyAsync(qvel_out, b->d_qvel_out, nv_out * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  if (failed) {
+    // CheckWarnings (mujoco_mpc/mjpc/utilities.cc:787-799): a trajectory that raised a bad-state warning is a failure
+    std::vector<int> st(b->n_env);
+    rc = hb_get_status(b, st.data());
+    if (rc != HB_OK) return rc;
+    for (int e = 0; e < b->n_env; e++) failed[e] = (st[e] & (HB_WARN_BADQPOS | HB_WARN_BADQVEL | HB_WARN_BADQACC)) ? 1 : 0;
+  }
   return HB_OK;
 }
 

@@ -190,6 +190,7 @@ struct BatchPtrs {
   float* state;        // [n_env][nstate]
   const float* ctrl;   // [n_env][nu] or [T][n_env][nu]
   float* qpos_out;     // nullable, [T][n_env][nq]
+  float* qvel_out;     // nullable, [T][n_env][nv]: with qpos_out the recorded states of a trajectory (trajectory.cc:175-190)
   float* xfrc;         // nullable, [n_env][nbody][6]
   int* status;         // [n_env] accumulated HB_WARN_* bits
   int* counts;         // [n_env][kCountStride]

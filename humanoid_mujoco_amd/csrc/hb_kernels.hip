@@ -2049,6 +2049,10 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         float* o = P.qpos_out + ((size_t)step * P.n_env + env) * nq;
         for (int i = lane; i < nq; i += kGroup) o[i] = s_qpos[i];
       }
+      if (P.qvel_out) {
+        float* o = P.qvel_out + ((size_t)step * P.n_env + env) * nv;
+        for (int i = lane; i < nv; i += kGroup) o[i] = s_qvel[i];
+      }
     }
   }
 

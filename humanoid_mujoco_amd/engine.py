@@ -136,6 +136,7 @@ def lib():
     L.hb_set_state_broadcast.argtypes = [vp, cu, vp]
     L.hb_set_state_broadcast_f64.argtypes = [vp, cu, vp]
     L.hb_rollout_sensors.argtypes = [vp, vp, ci, ctypes.POINTER(HbSensorSpec), vp, vp]
+    L.hb_rollout_trajectory.argtypes = [vp, vp, ci, vp, vp, vp]
     L.hb_sensors.argtypes = [vp, vp, ctypes.POINTER(HbSensorSpec), vp]
     L.hb_env_reset.argtypes = [vp, vp]
     L.hb_env_step.argtypes = [vp, vp, ci, vp, vp, vp, vp]
@@ -428,6 +429,17 @@ class Batch:
         q = np.zeros((T, self.n_env, self.model.nq), dtype=np.float32) if want_qpos else None
         _check(lib().hb_rollout_sensors(self._h, _ptr(c), T, ctypes.byref(spec), _ptr(out), _ptr(q)), "hb_rollout_sensors")
         return out, q
+
+    def rollout_trajectory(self, ctrl):
+        """ctrl [T, n_env, nu] -> (qpos [T, n_env, nq], qvel [T, n_env, nv], failed [n_env]): the states after every step."""
+        c = np.ascontiguousarray(ctrl, dtype=np.float32)
+        T = c.shape[0]
+        assert c.shape == (T, self.n_env, self.model.nu), c.shape
+        q = np.zeros((T, self.n_env, self.model.nq), dtype=np.float32)
+        v = np.zeros((T, self.n_env, self.model.nv), dtype=np.float32)
+        f = np.zeros(self.n_env, dtype=np.int32)
+        _check(lib().hb_rollout_trajectory(self._h, _ptr(c), T, _ptr(q), _ptr(v), _ptr(f)), "hb_rollout_trajectory")
+        return q, v, f.astype(bool)
 
     def sensors(self, spec, ctrl=None):
         ns = lib().hb_sensor_size(ctypes.byref(spec))

@@ -178,6 +178,11 @@ int hb_set_state_broadcast_f64(hb_batch* b, unsigned spec, const double* state);
  * state BEFORE step t's integration (what mjData.sensordata holds after the t-th mj_step call).  Host pointers;
  * qpos_out nullable. */
 int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_spec* spec, float* sensor_out, float* qpos_out);
+/* Open-loop rollout that records the trajectory the way MJPC's Trajectory::Rollout does (mujoco_mpc/mjpc/trajectory.cc:
+ * 141-190): states after every step, qpos_out[t][e][nq] and qvel_out[t][e][nv] (host pointers, each nullable; times are
+ * t0 + (t + 1) * timestep and the actions are the caller's own tape), and failed[e] = 1 when the env raised a bad-state
+ * warning on the way (CheckWarnings, utilities.cc:787-799; nullable). */
+int hb_rollout_trajectory(hb_batch* b, const float* ctrl, int T, float* qpos_out, float* qvel_out, int* failed);
 /* The same read-out at the current state (mj_forward, no integration): the terminal residual of a trajectory. */
 int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float* sensor_out);
 

@@ -9,8 +9,14 @@ from oracle_lib import Oracle
 pytestmark = pytest.mark.gpu
 
 
-def test_env_step_matches_reference_reward(hbmod, humanoid_model, gpu):
+@pytest.mark.parametrize("solver", [0, 2])
+def test_env_step_matches_reference_reward(hbmod, humanoid_model, gpu, solver):
+    """solver 0: the benchmark configuration (PGS); 2: Newton, what the reference's CPUEnv runs on its model file."""
     m = humanoid_model
+    if solver == 2:
+        from oracle_lib import HUMANOID_HBM
+        m = hbmod.Model.load(HUMANOID_HBM)
+        m.set_opt(solver=2, iterations=100)
     n = 12
     env = hbmod.VecEnv(m, n, gpu, auto_reset=0, max_time=0.0)
     cfg = env.cfg
@@ -24,6 +30,8 @@ def test_env_step_matches_reference_reward(hbmod, humanoid_model, gpu):
     rng = np.random.default_rng(2)
     prev = np.zeros((n, m.nu))
     o = Oracle()
+    if solver == 2:
+        o.set_opt(solver=2, iterations=100)
     worst = 0.0
     for t in range(60):
         act = rng.uniform(-1.2, 1.2, size=(n, m.nu)).astype(np.float32)

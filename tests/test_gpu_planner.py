@@ -81,3 +81,39 @@ def test_sensor_spec_checks(hbmod, humanoid_model, gpu):
         b.sensors(hbmod.Batch.sensor_spec([]))                        # nothing to read
     out = b.sensors(hbmod.Batch.sensor_spec([1]))
     assert out.shape == (4, 3) and np.allclose(out, b.qpos[:, :3], atol=1e-6)  # torso frame position = free joint position
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_trajectory_rollout_records_states_like_mjpc(hbmod, humanoid_model, gpu, pipelined):
+    """hb_rollout_trajectory: the states after every step (qpos and qvel: what Trajectory::Rollout records,
+    trajectory.cc:175-190) equal, bit for bit, the states of the same rollout taken step by step; the failure flag
+    mirrors CheckWarnings."""
+    m = humanoid_model
+    N, T = 16, 25
+    rng = np.random.default_rng(9)
+    ctrl = rng.uniform(-1, 1, size=(T, N, m.nu)).astype(np.float32)
+    st = np.zeros(1 + m.nq + 2 * m.nv)
+    o = Oracle()
+    o.init_env(2)
+    st[1:1 + m.nq] = o.qpos
+    a = hbmod.Batch(m, N, gpu)
+    a.set_state_broadcast(hbmod.STATE_INTEGRATION, st)
+    q_ref, v_ref = [], []
+    for t in range(T):
+        a.step(ctrl[t])
+        q_ref.append(a.qpos.copy()); v_ref.append(a.qvel.copy())
+    b = hbmod.Batch(m, N, gpu)
+    b.pipeline(pipelined)
+    b.set_state_broadcast(hbmod.STATE_INTEGRATION, st)
+    q, v, failed = b.rollout_trajectory(ctrl)
+    assert q.shape == (T, N, m.nq) and v.shape == (T, N, m.nv)
+    assert np.array_equal(q, np.array(q_ref)) and np.array_equal(v, np.array(v_ref))
+    assert not failed.any()
+    # a candidate that blows up is flagged, the others are not
+    bad = st.copy()
+    c = hbmod.Batch(m, N, gpu)
+    states = np.tile(st, (N, 1))
+    states[3, 1 + m.nq + 2] = 1e12  # absurd root velocity: mj_checkVel resets the env and raises mjWARN_BADQVEL
+    c.set_state(hbmod.STATE_INTEGRATION, states)
+    _, _, failed = c.rollout_trajectory(ctrl[:3])
+    assert failed.tolist() == [i == 3 for i in range(N)]

@@ -70,7 +70,21 @@ if "SQ_INSTS_VALU" in counters:
         out["valu_lane_ops_per_s"] = counters["SQ_INSTS_VALU"]["mean"] * 64 / (avg_ns * 1e-9)
         out["valu_issue_frac_of_peak"] = out["valu_lane_ops_per_s"] / 78.6e12
 json.dump(out, open(os.path.join(dst, rnd + "_counters.json"), "w"), indent=1)
-for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("pipeline_sweep.txt", rnd + "_pipeline_sweep.txt"), ("vecenv.txt", rnd + "_vecenv.txt"), ("soak.txt", rnd + "_soak.txt"), ("pgs_fit.txt", rnd + "_pgs_fit.txt"), ("newton_bench.txt", rnd + "_newton_bench.txt"), ("newton_phases.txt", rnd + "_newton_phases.txt"), ("newton_sections.txt", rnd + "_newton_sections.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt")):
+# second kernel trace (bench.py --no-pipeline with its Newton leg): every hb_* kernel's 4096-block launches
+tn = glob.glob(os.path.join(src, "prof_trace_newton", "*", "*_kernel_trace.csv"))
+if tn:
+    per = collections.defaultdict(list)
+    for row in csv.DictReader(open(tn[0])):
+        if "hb_step" in row["Kernel_Name"] and int(row.get("Grid_Size") or row["Grid_Size_X"]) == full:
+            per[row["Kernel_Name"].split("(")[0]].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    json.dump({"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-rollout --no-pipeline",
+               "launch": "4096 blocks x 64 lanes, one step per launch",
+               "kernels": {k: {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": min(v), "max_ns": max(v)} for k, v in per.items()}},
+              open(os.path.join(dst, rnd + "_kernel_trace_solvers.json"), "w"), indent=1)
+    st2 = glob.glob(os.path.join(src, "prof_trace_newton", "*", "*_kernel_stats.csv"))
+    if st2:
+        shutil.copy(st2[0], os.path.join(dst, rnd + "_kernel_stats_solvers.csv"))
+for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("pipeline_sweep.txt", rnd + "_pipeline_sweep.txt"), ("vecenv.txt", rnd + "_vecenv.txt"), ("soak.txt", rnd + "_soak.txt"), ("pgs_fit.txt", rnd + "_pgs_fit.txt"), ("parity_report_newton.txt", rnd + "_parity_report_newton.txt"), ("newton_bench.txt", rnd + "_newton_bench.txt"), ("newton_phases.txt", rnd + "_newton_phases.txt"), ("newton_sections.txt", rnd + "_newton_sections.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("testspeed_newton.log", rnd + "_testspeed_newton.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt")):
     p = os.path.join(src, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))

@@ -1,15 +1,31 @@
 #!/usr/bin/env python3
-"""Per-sample one-step parity report: GPU (fp32) vs the golden vectors of the fp64 oracle."""
+"""Per-sample one-step parity report: GPU (fp32) vs the fp64 oracle on the golden states.
+usage: gpu_parity_report.py [newton]   (default: the benchmark configuration, PGS/50, against the golden vectors;
+"newton": solver = Newton/100 on both sides, the oracle run here on the same states)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import humanoid_mujoco_amd as hb
-from oracle_lib import GOLDEN, HUMANOID_HBM
+from oracle_lib import GOLDEN, HUMANOID_HBM, Oracle
 
-g = np.load(os.path.join(GOLDEN, "humanoid27_steps.npz"))
+g = dict(np.load(os.path.join(GOLDEN, "humanoid27_steps.npz")))
 n = len(g["env"])
 m = hb.Model.load(HUMANOID_HBM)
+if len(sys.argv) > 1 and sys.argv[1] == "newton":
+    m.set_opt(solver=2, iterations=100)
+    o = Oracle()
+    o.set_opt(solver=2, iterations=100)
+    for key in ("qpos1", "qvel1", "qacc", "efc_force", "niter"):
+        g[key] = g[key].copy()
+    for k in range(n):
+        o.qpos[:] = g["qpos"][k]; o.qvel[:] = g["qvel"][k]; o.qacc_warmstart[:] = g["warm"][k]; o.ctrl[:] = g["ctrl"][k]
+        o.forward()
+        g["qacc"][k] = o.qacc; g["niter"][k] = o.dint("solver_niter")
+        g["efc_force"][k] = 0; g["efc_force"][k, :o.nefc] = o.efc_force[:o.nefc]
+        o.step()
+        g["qpos1"][k] = o.qpos; g["qvel1"][k] = o.qvel
+    print("solver: Newton/100 on both sides")
 b = hb.Batch(m, n, 0)
 b.diag_enable(True)
 st = np.concatenate([g["time"][:, None], g["qpos"], g["qvel"], g["warm"]], axis=1)

@@ -5,17 +5,26 @@
 #include "hb.h"
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: %s model.{xml,hbm} [nstep] [n_env] [device]\n", argv[0]); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: %s model.{xml,hbm} [nstep] [n_env] [device] [PGS|Newton]\n", argv[0]); return 2; }
   int nstep = argc > 2 ? atoi(argv[2]) : 1000, n_env = argc > 3 ? atoi(argv[3]) : 4096, device = argc > 4 ? atoi(argv[4]) : 0;
   char err[1024] = "";
   hb_model* m = hb_model_load(argv[1], err, sizeof err);
   if (!m) { fprintf(stderr, "could not load model: %s\n", err); return 1; }
   hb_sizes sz;
   hb_model_sizes(m, &sz);
+  if (argc > 5) {  // solver override (the committed benchmark model carries PGS / 50; the reference's XML means Newton / 100)
+    hb_options o;
+    hb_options_get(m, &o);
+    if (!strcmp(argv[5], "Newton")) { o.solver = 2; o.iterations = 100; }
+    else if (!strcmp(argv[5], "PGS")) { o.solver = 0; o.iterations = 50; }
+    else { fprintf(stderr, "unknown solver %s\n", argv[5]); return 2; }
+    if (hb_options_set(m, &o) != HB_OK) { fprintf(stderr, "could not set options\n"); return 1; }
+  }
   hb_batch* b = hb_batch_create(m, n_env, device, err, sizeof err);
   if (!b) { fprintf(stderr, "could not create batch: %s\n", err); return 1; }
   hb_reset(b, nullptr, -1, /*perturb=*/1, /*env_offset=*/0);
@@ -49,6 +58,7 @@ int main(int argc, char** argv) {
   printf("Contacts / env (last): %.3f\n", (double)contacts / n_env);
   printf("Constraints / env    : %.3f\n", (double)constraints / n_env);
   printf("Degrees of freedom   : %d\n", sz.nv);
+  printf("Solver               : %s, at most %d iterations\n", opt.solver == 2 ? "Newton" : "PGS", opt.iterations);
   printf("Envs with warnings   : %d\n", flagged);
   hb_dev_free(b, ctrl);
   hb_batch_free(b);

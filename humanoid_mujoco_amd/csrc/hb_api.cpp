@@ -487,6 +487,8 @@ struct hb_batch {
   size_t qpos_out_cap = 0;
   float* d_qvel_out = nullptr;
   size_t qvel_out_cap = 0;
+  float* d_task_out = nullptr;  // task returns and stage costs
+  size_t task_out_cap = 0;
   float* d_sensor_out = nullptr;
   size_t sensor_out_cap = 0;
   bool diag = false;
@@ -857,7 +859,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
   void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
-                  b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
+                  b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
 }
@@ -1152,6 +1154,78 @@ int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_sp
   if (rc != HB_OK) return rc;
   HB_HIP(hipMemcpyAsync(sensor_out, b->d_sensor_out, (size_t)T * b->n_env * P.sensor_stride * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
   if (qpos_out) HB_HIP(hipMemcpyAsync(qpos_out, b->d_qpos_out, nq_out * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
+}
+
+int hb_task_stand_default(const hb_model* h, hb_task_stand* t) {
+  if (!h || !t) return HB_EINVAL;
+  memset(t, 0, sizeof *t);
+  const int head = hb_model_name2id(h, "body", "head"), fl = hb_model_name2id(h, "body", "foot_left"), fr = hb_model_name2id(h, "body", "foot_right"),
+            torso = hb_model_name2id(h, "body", "torso");
+  if (head < 0 || fl < 0 || fr < 0 || torso < 0) return HB_EINVAL;
+  t->head_body = head; t->subtree_body = torso; t->n_feet = 4;
+  const int fb[4] = {fl, fl, fr, fr};
+  const float fx[4] = {-0.07f, 0.14f, -0.07f, 0.14f};
+  for (int k = 0; k < 4; k++) { t->foot_body[k] = fb[k]; t->foot_offset[k][0] = fx[k]; }
+  t->height_goal = 1.4f;
+  const int norm[5] = {6, 6, 0, 0, 3};
+  const float w[5] = {100.f, 50.f, 10.f, 0.01f, 0.025f}, p[5] = {0.1f, 0.1f, 0.f, 0.f, 0.3f};
+  for (int k = 0; k < 5; k++) { t->norm[k] = norm[k]; t->weight[k] = w[k]; t->norm_p[k][0] = p[k]; }
+  return HB_OK;
+}
+
+int hb_rollout_task_stand(hb_batch* b, const float* ctrl, int H, const hb_task_stand* task, float* total_return, float* costs) {
+  if (!b || !task || !total_return || H < 1 || (H > 1 && !ctrl && b->D.dm.nu > 0)) return HB_EINVAL;
+  const Model& m = b->model->m;
+  const DevModel& dm = b->D.dm;
+  if (task->n_feet < 1 || task->n_feet > 4 || task->head_body < 0 || task->head_body >= m.nbody || dm.nv < 6) return HB_EINVAL;
+  for (int k = 0; k < task->n_feet; k++) if (task->foot_body[k] < 0 || task->foot_body[k] >= m.nbody) return HB_EINVAL;
+  for (int k = 0; k < 5; k++) if (task->norm[k] < -1 || task->norm[k] > 8 || task->norm[k] == 4) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  // read-out rows: [head | feet | subtreecom | subtreelinvel | qvel | ctrl]
+  hb_sensor_spec spec;
+  memset(&spec, 0, sizeof spec);
+  spec.n_framepos = 1 + task->n_feet;
+  spec.framepos_body[0] = task->head_body;
+  for (int k = 0; k < task->n_feet; k++) spec.framepos_body[1 + k] = task->foot_body[k];
+  spec.subtree_body = task->subtree_body;
+  if (spec.subtree_body < 0) return HB_EINVAL;
+  const int N = b->n_env, nu = dm.nu, nv = dm.nv;
+  const size_t n = (size_t)(H - 1) * N * nu;
+  int rc = ensure_ctrl(b, std::max<size_t>(std::max<size_t>(n, (size_t)N * nu), 1));
+  if (rc != HB_OK) return rc;
+  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  else if (nu) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, (size_t)N * nu * sizeof(float), main_stream(b)));
+  // failure is a property of THIS rollout (CheckWarnings looks at the warnings of the rollout's own mjData)
+  HB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)N * sizeof(int), main_stream(b)));
+  BatchPtrs P = make_ptrs(b);
+  rc = sensor_setup(b, &spec, H, P);  // sizes the buffer for 3 * n_framepos + 6 per row; grown below for the qvel / ctrl tail
+  if (rc != HB_OK) return rc;
+  StandTask K;
+  memset(&K, 0, sizeof K);
+  K.n_feet = task->n_feet; K.o_head = 0; K.o_feet = 3; K.o_com = 3 * spec.n_framepos; K.o_vel = K.o_com + 3; K.o_qvel = K.o_com + 6; K.o_ctrl = K.o_qvel + nv;
+  K.nv = nv; K.nu = nu; K.stride = K.o_ctrl + nu;
+  K.height_goal = task->height_goal; K.risk = task->risk;
+  for (int k = 0; k < 5; k++) { K.norm[k] = task->norm[k]; K.weight[k] = task->weight[k]; K.p[k] = task->norm_p[k][0]; K.q[k] = task->norm_p[k][1]; }
+  if ((rc = ensure_trace(&b->d_sensor_out, &b->sensor_out_cap, (size_t)H * N * K.stride)) != HB_OK) return rc;
+  if ((rc = ensure_trace(&b->d_task_out, &b->task_out_cap, (size_t)(H + 1) * N)) != HB_OK) return rc;
+  P.sensor_out = b->d_sensor_out; P.sensor_stride = K.stride; P.sensor_flags = 3;
+  for (int k = 0; k < task->n_feet; k++) for (int i = 0; i < 3; i++) P.sensor_off[1 + k][i] = task->foot_offset[k][i];
+  if (H > 1) {
+    P.ctrl = b->d_ctrl; P.ctrl_mode = 1;
+    rc = launch_steps(b, P, H - 1);
+    if (rc != HB_OK) return rc;
+  }
+  // final mj_forward with the last action repeated (trajectory.cc:188-202)
+  BatchPtrs F = P;
+  F.ctrl = b->d_ctrl + (H > 1 ? (size_t)(H - 2) * N * nu : 0); F.ctrl_mode = 0; F.integrate = 0;
+  F.sensor_out = b->d_sensor_out + (size_t)(H - 1) * N * K.stride;
+  F.blk0 = 0; F.nblk = N;
+  HB_HIP(launch_step(b->D.d_dm, dm.solver, dm.nv, dm.lds_floats, F, 1, main_stream(b)));
+  HB_HIP(launch_stand_cost(b->d_sensor_out, H, N, K, b->d_status, b->d_task_out, costs ? b->d_task_out + N : nullptr, main_stream(b)));
+  HB_HIP(hipMemcpyAsync(total_return, b->d_task_out, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  if (costs) HB_HIP(hipMemcpyAsync(costs, b->d_task_out + N, (size_t)H * N * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }

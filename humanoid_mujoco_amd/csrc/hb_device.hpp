@@ -178,6 +178,14 @@ struct EnvRandState {
 };
 
 // fused policy kernel (hb_policy_kernel): layer sizes, host-packed weights (MFMA B-operand order) and biases
+// MJPC "Humanoid Stand" cost (tasks/humanoid/stand/stand.cc:41-104): layout of the read-out row and the cost terms
+struct StandTask {
+  int n_feet, o_head, o_feet, o_com, o_vel, o_qvel, o_ctrl, nv, nu, stride;
+  float height_goal, risk;
+  int norm[5];
+  float weight[5], p[5], q[5];
+};
+
 struct PolicyDesc {
   int nl;
   int sizes[5];
@@ -212,6 +220,8 @@ struct BatchPtrs {
   float* sensor_out;
   int sensor_stride, sensor_nframe, sensor_tree;  // sensor_tree < 0: no subtree sensors
   int sensor_body[16];
+  float sensor_off[16][3];  // framepos of a site: offset in the body frame (zero: the body frame itself)
+  int sensor_flags;         // bit 0: append qvel[nv], bit 1: append ctrl[nu] (the inputs MJPC residuals read beside sensors)
   const unsigned char* env_mask;  // nullable [n_env]: envs with a zero byte are skipped by this launch
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
 };

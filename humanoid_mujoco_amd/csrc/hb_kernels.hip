@@ -1107,8 +1107,16 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // sensor read-out for planner residuals (mj_sensorPos/Vel of framepos, subtreecom, subtreelinvel)
     if (P.sensor_out) {
       float* so = P.sensor_out + ((size_t)step * P.n_env + env) * P.sensor_stride;
-      for (int k = 0; k < P.sensor_nframe; k++)
-        if (lane < 3) so[3 * k + lane] = s_xpq[8 * P.sensor_body[k] + lane];
+      for (int k = 0; k < P.sensor_nframe; k++) {
+        const int sb = P.sensor_body[k];
+        const V3 w = ld3(s_xpq + 8 * sb) + qrot(ldq(s_xpq + 8 * sb + 4), {P.sensor_off[k][0], P.sensor_off[k][1], P.sensor_off[k][2]});  // site = body frame + offset
+        if (lane < 3) so[3 * k + lane] = lane == 0 ? w.x : (lane == 1 ? w.y : w.z);
+      }
+      {
+        int o = 3 * P.sensor_nframe + (P.sensor_tree >= 0 ? 6 : 0);
+        if (P.sensor_flags & 1) { for (int i = lane; i < nv; i += kGroup) so[o + i] = s_qvel[i]; o += nv; }
+        if (P.sensor_flags & 2) for (int i = lane; i < M.nu; i += kGroup) so[o + i] = s_ctrl[i];
+      }
       if (P.sensor_tree >= 0) {
         const int t = P.sensor_tree;
         const V3 com = ld3(s_scom + 3 * t);
@@ -2075,6 +2083,52 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step32_kernel(const DevModel* Mp
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
 
+// ---- MJPC task cost on the recorded read-out rows --------------------------------------------------------------
+// mjpc::Norm (mujoco_mpc/mjpc/norm.cc:50-208), value only
+__device__ __forceinline__ float mjpc_norm(int type, const float* x, int n, float p, float q) {
+  float y = 0.f;
+  switch (type) {
+    case 0: for (int i = 0; i < n; i++) y += x[i] * x[i]; return 0.5f * y;                                   // kQuadratic
+    case 1: { float c = 0.f; for (int i = 0; i < n; i++) c += x[i] * x[i]; return powf(powf(c, 0.5f * q) + powf(p, q), 1.f / q) - p; }  // kL22
+    case 2: { float c = 0.f; for (int i = 0; i < n; i++) c += x[i] * x[i]; return sqrtf(c + p * p) - p; }  // kL2
+    case 3: for (int i = 0; i < n; i++) y += p * p * (coshf(x[i] / p) - 1.f); return y;                      // kCosh
+    case 5: for (int i = 0; i < n; i++) y += powf(fabsf(x[i]), p); return y;                                   // kPowerLoss
+    case 6: for (int i = 0; i < n; i++) y += sqrtf(x[i] * x[i] + p * p) - p; return y;                         // kSmoothAbsLoss
+    case 7: for (int i = 0; i < n; i++) y += powf(powf(fabsf(x[i]), q) + powf(p, q), 1.f / q) - p; return y;  // kSmoothAbs2Loss
+    case 8: for (int i = 0; i < n; i++) y += p > 0.f ? p * logf(1.f + expf(x[i] / p)) : fmaxf(x[i], 0.f); return y;  // kRectifyLoss
+    default: return x[0];                                                                                       // kNull
+  }
+}
+
+// One thread per candidate: Stand::ResidualFn::Residual (tasks/humanoid/stand/stand.cc:41-104) on each of the H rows,
+// BaseResidualFn::CostValue (task.cc:71-110), Trajectory::UpdateReturn (trajectory.cc:312-326); a candidate that raised
+// a bad-state warning returns kMaxReturnValue (trajectory.cc:29,169-173)
+__global__ void hb_stand_cost_kernel(const float* rows, int H, int n_env, const StandTask K, const int* status, float* total, float* costs) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env) return;
+  float sum = 0.f;
+  for (int t = 0; t < H; t++) {
+    const float* r = rows + ((size_t)t * n_env + e) * K.stride;
+    float fz = 0.f, fx = 0.f, fy = 0.f;
+    for (int k = 0; k < K.n_feet; k++) { fx += r[K.o_feet + 3 * k]; fy += r[K.o_feet + 3 * k + 1]; fz += r[K.o_feet + 3 * k + 2]; }
+    const float inv = 1.f / (float)K.n_feet;
+    const float height = r[K.o_head + 2] - fz * inv - K.height_goal;
+    const float kFallTime = 0.2f;
+    const float dx = fx * inv - (r[K.o_com] + kFallTime * r[K.o_vel]), dy = fy * inv - (r[K.o_com + 1] + kFallTime * r[K.o_vel + 1]);
+    const float balance = sqrtf(dx * dx + dy * dy);
+    float c = K.weight[0] * mjpc_norm(K.norm[0], &height, 1, K.p[0], K.q[0]);
+    c += K.weight[1] * mjpc_norm(K.norm[1], &balance, 1, K.p[1], K.q[1]);
+    c += K.weight[2] * mjpc_norm(K.norm[2], r + K.o_vel, 2, K.p[2], K.q[2]);
+    c += K.weight[3] * mjpc_norm(K.norm[3], r + K.o_qvel + 6, K.nv - 6, K.p[3], K.q[3]);
+    c += K.weight[4] * mjpc_norm(K.norm[4], r + K.o_ctrl, K.nu, K.p[4], K.q[4]);
+    if (fabsf(K.risk) >= 1e-6f) c = (expf(K.risk * c) - 1.f) / K.risk;
+    if (costs) costs[(size_t)t * n_env + e] = c;
+    sum += c;
+  }
+  const bool failed = status[e] & ((1 << 4) | (1 << 5) | (1 << 6));
+  total[e] = failed ? 1.0e6f : sum / (float)max(H, 1);
+}
+
 // ------------------------------------------------------------------------------------------
 // reset: qpos0/keyframe (+ Halton perturbation), zero velocity/warmstart/time/status
 // qpos <- reset pose (+ the Halton perturbation indexed by global env and, for the env adapter, episode), rest zero
@@ -2685,6 +2739,11 @@ hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int 
   size_t total = (size_t)T * n_env * nu;
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_halton_ctrl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, out, T, n_env, nu, t0, env_offset);
+  return hipGetLastError();
+}
+hipError_t launch_stand_cost(const float* rows, int H, int n_env, const StandTask& K, const int* status, float* total, float* costs, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(hb_stand_cost_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, rows, H, n_env, K, status, total, costs);
   return hipGetLastError();
 }
 hipError_t set_step_lds_limit(int bytes) {

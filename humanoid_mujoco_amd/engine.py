@@ -61,6 +61,12 @@ class HbEnvRandomization(ctypes.Structure):
                 ("push_max_duration", ctypes.c_float), ("push_min_force", ctypes.c_float), ("push_max_force", ctypes.c_float)]
 
 
+class HbTaskStand(ctypes.Structure):
+    _fields_ = [("head_body", ctypes.c_int), ("n_feet", ctypes.c_int), ("foot_body", ctypes.c_int * 4), ("foot_offset", (ctypes.c_float * 3) * 4),
+                ("subtree_body", ctypes.c_int), ("height_goal", ctypes.c_float), ("norm", ctypes.c_int * 5), ("weight", ctypes.c_float * 5),
+                ("norm_p", (ctypes.c_float * 2) * 5), ("risk", ctypes.c_float)]
+
+
 class HbSensorSpec(ctypes.Structure):
     """hb_sensor_spec (include/hb.h): framepos bodies and the tree whose subtreecom / subtreelinvel are read out."""
     _fields_ = [("n_framepos", ctypes.c_int), ("framepos_body", ctypes.c_int * 16), ("subtree_body", ctypes.c_int)]
@@ -137,6 +143,8 @@ def lib():
     L.hb_set_state_broadcast_f64.argtypes = [vp, cu, vp]
     L.hb_rollout_sensors.argtypes = [vp, vp, ci, ctypes.POINTER(HbSensorSpec), vp, vp]
     L.hb_rollout_trajectory.argtypes = [vp, vp, ci, vp, vp, vp]
+    L.hb_task_stand_default.argtypes = [vp, ctypes.POINTER(HbTaskStand)]
+    L.hb_rollout_task_stand.argtypes = [vp, vp, ci, ctypes.POINTER(HbTaskStand), vp, vp]
     L.hb_sensors.argtypes = [vp, vp, ctypes.POINTER(HbSensorSpec), vp]
     L.hb_env_reset.argtypes = [vp, vp]
     L.hb_env_step.argtypes = [vp, vp, ci, vp, vp, vp, vp]
@@ -429,6 +437,21 @@ class Batch:
         q = np.zeros((T, self.n_env, self.model.nq), dtype=np.float32) if want_qpos else None
         _check(lib().hb_rollout_sensors(self._h, _ptr(c), T, ctypes.byref(spec), _ptr(out), _ptr(q)), "hb_rollout_sensors")
         return out, q
+
+    def task_stand_default(self):
+        t = HbTaskStand()
+        _check(lib().hb_task_stand_default(self.model._h, ctypes.byref(t)), "hb_task_stand_default")
+        return t
+
+    def rollout_task_stand(self, ctrl, task, want_costs=False):
+        """ctrl [horizon - 1, n_env, nu] -> (total_return [n_env], stage costs [horizon, n_env] or None) of MJPC's Humanoid Stand task."""
+        c = np.ascontiguousarray(ctrl, dtype=np.float32)
+        H = c.shape[0] + 1
+        assert c.shape == (H - 1, self.n_env, self.model.nu), c.shape
+        total = np.zeros(self.n_env, dtype=np.float32)
+        costs = np.zeros((H, self.n_env), dtype=np.float32) if want_costs else None
+        _check(lib().hb_rollout_task_stand(self._h, _ptr(c) if H > 1 else None, H, ctypes.byref(task), _ptr(total), _ptr(costs)), "hb_rollout_task_stand")
+        return total, costs
 
     def rollout_trajectory(self, ctrl):
         """ctrl [T, n_env, nu] -> (qpos [T, n_env, nq], qvel [T, n_env, nv], failed [n_env]): the states after every step."""

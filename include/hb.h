@@ -183,6 +183,35 @@ int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_sp
  * t0 + (t + 1) * timestep and the actions are the caller's own tape), and failed[e] = 1 when the env raised a bad-state
  * warning on the way (CheckWarnings, utilities.cc:787-799; nullable). */
 int hb_rollout_trajectory(hb_batch* b, const float* ctrl, int T, float* qpos_out, float* qvel_out, int* failed);
+/* ---- a planner iteration's cost evaluation on the device: MJPC's "Humanoid Stand" task ------------------------------
+ * (mujoco_mpc/mjpc/tasks/humanoid/stand/{stand.cc:41-104, task.xml:14-36}; the two-foot variant of
+ * tasks/humanoid_cap/stand is the same residual with n_feet = 2).  Residual, in order: Height (head z minus mean foot z
+ * minus height_goal), Balance (distance in xy of the mean foot position from the capture point com + 0.2 s * com
+ * velocity), CoM Vel. (xy), Joint Vel. (qvel[6:]), Control (ctrl); cost = sum_k weight[k] * Norm(norm[k]; norm_p[k])
+ * (mjpc/norm.h:24-36, task.cc:71-110), risk transformation as in task.cc:104-109. */
+typedef struct hb_task_stand {
+  int head_body;
+  int n_feet;              /* 1..4 foot frames (the reference's sites sp0..sp3): body + offset in the body frame */
+  int foot_body[4];
+  float foot_offset[4][3];
+  int subtree_body;        /* root body of the tree whose subtreecom / subtreelinvel enter (torso) */
+  float height_goal;       /* task parameter "Height Goal" */
+  int norm[5];             /* mjpc::NormType per term */
+  float weight[5];
+  float norm_p[5][2];      /* norm parameters p, q */
+  float risk;              /* task_risk (0: risk neutral) */
+} hb_task_stand;
+/* The values of the reference's task.xml for this model: bodies "head", "foot_left", "foot_right", "torso" by name, feet
+ * offsets of sites sp0..sp3 (humanoid.xml.patch:170-171,217-218); HB_EINVAL if the model has no such bodies. */
+int hb_task_stand_default(const hb_model* m, hb_task_stand* out);
+/* Trajectory::Rollout + UpdateReturn (trajectory.cc:100-210,312-326) for N candidates at once: from the batch's current
+ * state, horizon - 1 steps with ctrl[t][e][nu] (host, [horizon-1][n_env][nu]; the last action is repeated for the final
+ * mj_forward, zero when horizon = 1), the residual of every one of the `horizon` states, its cost, and
+ * total_return[e] = mean cost (1e6 for a candidate that raised a bad-state warning: kMaxReturnValue).  costs
+ * ([horizon][n_env], nullable) receives the stage costs.  Nothing but these floats crosses PCIe on the way back.  The
+ * per-env status words are cleared first: failure is a property of this rollout. */
+int hb_rollout_task_stand(hb_batch* b, const float* ctrl, int horizon, const hb_task_stand* task, float* total_return, float* costs);
+
 /* The same read-out at the current state (mj_forward, no integration): the terminal residual of a trajectory. */
 int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float* sensor_out);
 

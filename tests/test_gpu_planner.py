@@ -117,3 +117,47 @@ def test_trajectory_rollout_records_states_like_mjpc(hbmod, humanoid_model, gpu,
     c.set_state(hbmod.STATE_INTEGRATION, states)
     _, _, failed = c.rollout_trajectory(ctrl[:3])
     assert failed.tolist() == [i == 3 for i in range(N)]
+
+
+def test_stand_task_return_matches_mjpc_restatement(hbmod, humanoid_model, gpu):
+    """hb_rollout_task_stand: residual, norms, stage costs and return of MJPC's Humanoid Stand task for N candidates,
+    all evaluated on the device, against the numpy restatement (tests/mjpc_ref.py) on fp64 oracle rollouts."""
+    from mjpc_ref import stand_rollout
+    m = humanoid_model
+    N, H, nb = 12, 24, 17
+    b = hbmod.Batch(m, N, gpu)
+    task = b.task_stand_default()
+    assert task.n_feet == 4 and task.norm[:] == [6, 6, 0, 0, 3] and abs(task.height_goal - 1.4) < 1e-6
+    o = Oracle()
+    o.init_env(1)
+    for t in range(40):  # a state with the feet near the ground
+        o.ctrl[:] = o.ctrl_env(t, 1)
+        o.step()
+    q0, v0, w0 = o.qpos.copy(), o.qvel.copy(), o.qacc_warmstart.copy()
+    st = np.concatenate([[0.0], q0, v0, w0])
+    rng = np.random.default_rng(4)
+    ctrl = rng.uniform(-0.6, 0.6, size=(H - 1, N, m.nu)).astype(np.float32)
+    b.set_state_broadcast(hbmod.STATE_INTEGRATION, st)
+    total, costs = b.rollout_task_stand(ctrl, task, want_costs=True)
+    assert costs.shape == (H, N)
+    worst = 0.0
+    for e in range(0, N, 3):
+        o.reset()
+        o.qpos[:] = q0; o.qvel[:] = v0; o.qacc_warmstart[:] = w0
+        ret, cs = stand_rollout(o, ctrl[:, e].astype(np.float64), task, nb)
+        # stage costs: teacher-forcing is not possible inside a rollout, so compare the early stages tightly and the return loosely
+        assert np.allclose(costs[:6, e], cs[:6], rtol=2e-3, atol=1e-3), (e, costs[:6, e], cs[:6])
+        worst = max(worst, abs(total[e] - ret) / max(1.0, abs(ret)))
+    assert worst < 2e-2, worst
+    # the first stage is the same state for every candidate: only the control term differs
+    ctrl_term = np.array([task.weight[4] * (0.3 ** 2) * (np.cosh(ctrl[0, e].astype(np.float64) / 0.3) - 1).sum() for e in range(N)])
+    assert np.allclose(costs[0] - ctrl_term, (costs[0] - ctrl_term)[0], rtol=1e-4, atol=1e-3)
+    # horizon 1: one mj_forward with a zero action
+    t1, c1 = b.rollout_task_stand(np.zeros((0, N, m.nu), np.float32), task, want_costs=True)
+    assert c1.shape == (1, N) and np.allclose(t1, c1[0])
+    # a diverging candidate returns kMaxReturnValue
+    states = np.tile(st, (N, 1))
+    states[5, 1 + m.nq + 1] = 1e12
+    b.set_state(hbmod.STATE_INTEGRATION, states)
+    total, _ = b.rollout_task_stand(ctrl[:4], task)
+    assert total[5] == 1e6 and (np.delete(total, 5) < 1e5).all()

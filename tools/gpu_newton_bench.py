@@ -91,3 +91,24 @@ for solver, name in ((0, "PGS/50 (benchmark configuration)"), (2, "Newton/100 (r
     dt = time.perf_counter() - t0
     print("%-34s rollout (one launch):     %6.1f us/step -> %.3e env-steps/s; status flags %d" % (name, 1e6 * dt / K, N * K / dt, int(np.count_nonzero(b.status()))), flush=True)
     b.close()
+
+# contact-rich regime: every env lying on the floor with its servos off (zero controls), ~45 constraint rows per env
+import ctypes
+hb.lib().hb_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+for solver, name in ((0, "PGS/50 (benchmark configuration)"), (2, "Newton/100 (reference default)")):
+    m = model(solver)
+    b = hb.Batch(m, N, 0)
+    zeros = b.dev_alloc(N * m.nu * 4)
+    z = np.zeros((N, m.nu), np.float32)
+    assert hb.lib().hb_memcpy_h2d(b._h, ctypes.c_void_p(zeros), z.ctypes.data_as(ctypes.c_void_p), z.nbytes) == 0
+    b.reset(perturb=True)
+    b.pipeline(2)
+    for t in range(1500): b.step_dev(zeros)
+    b.sync()
+    t0 = time.perf_counter()
+    for t in range(300): b.step_dev(zeros)
+    b.sync()
+    dt = time.perf_counter() - t0
+    nc, ne, ni = b.counts()
+    print("%-34s collapsed on the floor, zero controls, step API 2 segments: %6.1f us/step -> %.3e env-steps/s (mean nefc %.1f, mean solver iterations %.2f)" % (name, 1e6 * dt / 300, N * 300 / dt, ne.mean(), ni.mean()), flush=True)
+    b.dev_free(zeros); b.close()

@@ -1260,18 +1260,44 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     int ncon = 0;
     const bool contacts_on = !(M.disableflags & ((1 << 0) | (1 << 4)));
     if (contacts_on) {
-      // one 3-quad record per candidate pair (table padded by a round); the next round's records are in flight
-      // while this round's narrowphase runs
-      float4 n0 = M.crec[3 * (size_t)lane], n1 = M.crec[3 * (size_t)lane + 1], n2 = M.crec[3 * (size_t)lane + 2];
-      for (int p0 = 0; p0 < M.npair; p0 += kGroup) {
-        int p = p0 + lane;
-        const float4 c0 = n0, c1 = n1, c2 = n2;
-        if (p0 + kGroup < M.npair) { const float4 HB_CONST* N = M.crec + 3 * (size_t)(p + kGroup); n0 = N[0]; n1 = N[1]; n2 = N[2]; }
+      // Two passes.  (1) Broadphase over every candidate pair - bounding spheres, or distance to the plane - with the
+      // survivors compacted, IN PAIR ORDER, into a list (ballot + popcount; the list borrows the head of C, which is not
+      // written before makeConstraint).  (2) Narrowphase over the list, 64 survivors per round: for the humanoid that is
+      // one round instead of three, and the contact order (= pair order) is what it was.  One 3-quad record per pair;
+      // pass 1 reads two of them and has the next round's in flight.
+      int* s_list = reinterpret_cast<int*>(s_C);
+      int nlist = 0;
+      {
+        float4 n0 = M.crec[3 * (size_t)lane], n1 = M.crec[3 * (size_t)lane + 1];
+        for (int p0 = 0; p0 < M.npair; p0 += kGroup) {
+          const int p = p0 + lane;
+          const float4 c0 = n0, c1 = n1;
+          if (p0 + kGroup < M.npair) { const float4 HB_CONST* N = M.crec + 3 * (size_t)(p + kGroup); n0 = N[0]; n1 = N[1]; }
+          bool pass = false;
+          if (p < M.npair) {
+            const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y), t1 = __float_as_int(c0.z) & 255;
+            const V3 dp = ld3(s_gpos + 3 * g2) - ld3(s_gpos + 3 * g1);
+            if (t1 == 0) pass = dot(dp, ld3(s_gaxis + 3 * g1)) <= c0.w + c1.y;
+            else if (t1 == 1) pass = true;
+            else { const float bound = c1.x + c1.y + c0.w; pass = dot(dp, dp) <= bound * bound; }
+          }
+          const unsigned long long bal = __ballot(pass);
+          if (pass) s_list[nlist + __popcll(bal & ((1ull << lane) - 1ull))] = p;
+          nlist += __popcll(bal);
+        }
+      }
+      nlist = uniform(nlist);
+      gsync();
+      for (int i0 = 0; i0 < nlist; i0 += kGroup) {
+        const bool have = i0 + lane < nlist;
+        const int p = have ? s_list[i0 + lane] : 0;
+        float4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+        if (have) { const float4 HB_CONST* N = M.crec + 3 * (size_t)p; c0 = N[0]; c1 = N[1]; c2 = N[2]; }
         ConOut co0, co1;
         int n = 0;
         V3 hint = {0.f, 0.f, 0.f};
         float margin = 0.f;
-        if (p < M.npair) {
+        if (have) {
           const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y);
           const int t1 = __float_as_int(c0.z) & 255, t2 = __float_as_int(c0.z) >> 8;
           margin = c0.w;

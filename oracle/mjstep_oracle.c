@@ -11,7 +11,10 @@
  * for mj_step.  This file restates the published algorithm (MuJoCo
  * "Computation" documentation and the API contracts in mujoco.h) stage by stage; every function
  * cites the declaration it follows.  It is validated by closed-form cases and invariants in
- * tests/test_oracle_*.py, not against MuJoCo output.
+ * tests/test_oracle_*.py, not against MuJoCo output.  Both constraint solvers of the path are here: PGS
+ * (the benchmark configuration) and Newton (mjOption's default, what the reference's humanoid.xml runs);
+ * they solve the dual and the primal form of one convex problem, and tests/test_oracle_newton.py pins each
+ * with the other (Newton vs PGS run to convergence: the same qacc to 1e-6).
  *
  * Call sites of the path in the reference: simulation/cpu_env.py:684 (mujoco.mj_step),
  * mujoco_mpc/mjpc/trajectory.cc:158, simulation/mujoco/sample/testspeed.cc:96.

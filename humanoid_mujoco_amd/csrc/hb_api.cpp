@@ -1128,7 +1128,10 @@ static int sensor_setup(hb_batch* b, const hb_sensor_spec* spec, int T, BatchPtr
     b->sensor_out_cap = need;
   }
   P.sensor_out = b->d_sensor_out; P.sensor_stride = ns; P.sensor_nframe = spec->n_framepos; P.sensor_tree = tree;
-  for (int k = 0; k < spec->n_framepos; k++) P.sensor_body[k] = spec->framepos_body[k];
+  for (int k = 0; k < spec->n_framepos; k++) {
+    P.sensor_body[k] = spec->framepos_body[k];
+    for (int i = 0; i < 3; i++) P.sensor_off[k][i] = spec->framepos_offset[k][i];
+  }
   return HB_OK;
 }
 
@@ -1188,7 +1191,10 @@ int hb_rollout_task_stand(hb_batch* b, const float* ctrl, int H, const hb_task_s
   memset(&spec, 0, sizeof spec);
   spec.n_framepos = 1 + task->n_feet;
   spec.framepos_body[0] = task->head_body;
-  for (int k = 0; k < task->n_feet; k++) spec.framepos_body[1 + k] = task->foot_body[k];
+  for (int k = 0; k < task->n_feet; k++) {
+    spec.framepos_body[1 + k] = task->foot_body[k];
+    for (int i = 0; i < 3; i++) spec.framepos_offset[1 + k][i] = task->foot_offset[k][i];
+  }
   spec.subtree_body = task->subtree_body;
   if (spec.subtree_body < 0) return HB_EINVAL;
   const int N = b->n_env, nu = dm.nu, nv = dm.nv;
@@ -1211,7 +1217,6 @@ int hb_rollout_task_stand(hb_batch* b, const float* ctrl, int H, const hb_task_s
   if ((rc = ensure_trace(&b->d_sensor_out, &b->sensor_out_cap, (size_t)H * N * K.stride)) != HB_OK) return rc;
   if ((rc = ensure_trace(&b->d_task_out, &b->task_out_cap, (size_t)(H + 1) * N)) != HB_OK) return rc;
   P.sensor_out = b->d_sensor_out; P.sensor_stride = K.stride; P.sensor_flags = 3;
-  for (int k = 0; k < task->n_feet; k++) for (int i = 0; i < 3; i++) P.sensor_off[1 + k][i] = task->foot_offset[k][i];
   if (H > 1) {
     P.ctrl = b->d_ctrl; P.ctrl_mode = 1;
     rc = launch_steps(b, P, H - 1);

@@ -69,7 +69,8 @@ class HbTaskStand(ctypes.Structure):
 
 class HbSensorSpec(ctypes.Structure):
     """hb_sensor_spec (include/hb.h): framepos bodies and the tree whose subtreecom / subtreelinvel are read out."""
-    _fields_ = [("n_framepos", ctypes.c_int), ("framepos_body", ctypes.c_int * 16), ("subtree_body", ctypes.c_int)]
+    _fields_ = [("n_framepos", ctypes.c_int), ("framepos_body", ctypes.c_int * 16), ("subtree_body", ctypes.c_int),
+                ("framepos_offset", (ctypes.c_float * 3) * 16)]
 
 
 class HbDomainRandomization(ctypes.Structure):
@@ -408,11 +409,15 @@ class Batch:
 
     # ---- planner rollouts (MJPC Trajectory::Rollout analogue)
     @staticmethod
-    def sensor_spec(framepos_bodies=(), subtree_body=-1):
+    def sensor_spec(framepos_bodies=(), subtree_body=-1, offsets=None):
+        """offsets: per frame, the site's position in its body frame (None / missing: the body frame itself)."""
         sp = HbSensorSpec()
         sp.n_framepos = len(framepos_bodies)
         for k, bd in enumerate(framepos_bodies):
             sp.framepos_body[k] = int(bd)
+            if offsets is not None and offsets[k] is not None:
+                for i in range(3):
+                    sp.framepos_offset[k][i] = float(offsets[k][i])
         sp.subtree_body = int(subtree_body)
         return sp
 

@@ -160,7 +160,7 @@ int hb_state_from_proto(hb_batch* b, int env, const unsigned char* buf, int len)
 /* ---- planner rollouts (MJPC's Trajectory::Rollout, mujoco_mpc/mjpc/trajectory.cc:100-210) -------------------- */
 
 /* The sensors MJPC's humanoid tasks build their residuals from (tasks/humanoid_cap/stand/task.xml:22-40): framepos of
- * up to 16 bodies, and subtreecom / subtreelinvel (mj_subtreeVel, mujoco.h:346) of one kinematic tree, named by its root
+ * up to 16 bodies or sites (a site is a body plus an offset in the body frame), and subtreecom / subtreelinvel (mj_subtreeVel, mujoco.h:346) of one kinematic tree, named by its root
  * body (a direct child of the world; < 0: none).  Per env and step the read-out is
  * [framepos 0 (3) | ... | subtreecom (3) | subtreelinvel (3)], hb_sensor_size() floats. */
 #define HB_MAX_FRAMEPOS 16
@@ -168,6 +168,7 @@ typedef struct hb_sensor_spec {
   int n_framepos;
   int framepos_body[HB_MAX_FRAMEPOS];
   int subtree_body;
+  float framepos_offset[HB_MAX_FRAMEPOS][3]; /* objtype="site": the site's position in its body's frame (zeros: the body frame itself) */
 } hb_sensor_spec;
 int hb_sensor_size(const hb_sensor_spec* spec);
 /* mj_setState of ONE state on every env: the N candidate action sequences of a sampling planner all start from the

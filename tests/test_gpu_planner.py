@@ -70,6 +70,27 @@ def test_candidates_from_one_state_with_sensor_readout(hbmod, humanoid_model, gp
     assert np.abs(term[5] - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
 
 
+def test_site_framepos(hbmod, humanoid_model, gpu):
+    """framepos of a site = body position + body rotation * offset (the foot sites sp0..sp3 of the reference's humanoid task)."""
+    m = humanoid_model
+    foot = m.name2id("body", "foot_left")
+    off = (-0.07, 0.02, 0.01)
+    spec = hbmod.Batch.sensor_spec([foot, foot], offsets=[None, off])
+    b = hbmod.Batch(m, 4, gpu)
+    b.reset(perturb=True)
+    b.rollout_halton(30)
+    s = b.sensors(spec)
+    o = Oracle()
+    st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+    for e in range(4):
+        o.reset()
+        o.qpos[:] = st[e, 1:1 + m.nq]; o.qvel[:] = st[e, 1 + m.nq:1 + m.nq + m.nv]
+        o.forward()
+        xpos = o.xpos.reshape(-1, 3)[foot]; xmat = o.xmat.reshape(-1, 3, 3)[foot]
+        assert np.allclose(s[e, :3], xpos, atol=2e-6)
+        assert np.allclose(s[e, 3:6], xpos + xmat @ np.array(off), atol=2e-6)
+
+
 def test_sensor_spec_checks(hbmod, humanoid_model, gpu):
     m = humanoid_model
     b = hbmod.Batch(m, 4, gpu)

@@ -1191,6 +1191,8 @@ int hb_rollout_task_stand(hb_batch* b, const float* ctrl, int H, const hb_task_s
   memset(&spec, 0, sizeof spec);
   spec.n_framepos = 1 + task->n_feet;
   spec.framepos_body[0] = task->head_body;
+  // "head_position" is a framepos with objtype="body": MuJoCo's body objtype is the INERTIAL frame (xipos = xpos + R ipos)
+  for (int i = 0; i < 3; i++) spec.framepos_offset[0][i] = (float)m.body_ipos[3 * task->head_body + i];
   for (int k = 0; k < task->n_feet; k++) {
     spec.framepos_body[1 + k] = task->foot_body[k];
     for (int i = 0; i < 3; i++) spec.framepos_offset[1 + k][i] = task->foot_offset[k][i];

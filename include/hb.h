@@ -168,7 +168,8 @@ typedef struct hb_sensor_spec {
   int n_framepos;
   int framepos_body[HB_MAX_FRAMEPOS];
   int subtree_body;
-  float framepos_offset[HB_MAX_FRAMEPOS][3]; /* objtype="site": the site's position in its body's frame (zeros: the body frame itself) */
+  float framepos_offset[HB_MAX_FRAMEPOS][3]; /* position in the body's frame: zeros = objtype "xbody" (the body frame); a site's pos = objtype
+                                               "site"; the body's ipos (hb_model_get_array "body_ipos") = objtype "body" (inertial frame) */
 } hb_sensor_spec;
 int hb_sensor_size(const hb_sensor_spec* spec);
 /* mj_setState of ONE state on every env: the N candidate action sequences of a sampling planner all start from the

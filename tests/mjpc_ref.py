@@ -31,7 +31,7 @@ def stand_residual(o, task, nb):
     xpos = o.xpos.reshape(nb, 3)
     xmat = o.xmat.reshape(nb, 3, 3)
     feet = np.array([xpos[task.foot_body[k]] + xmat[task.foot_body[k]] @ np.array(task.foot_offset[k][:]) for k in range(task.n_feet)])
-    head = xpos[task.head_body]
+    head = o.xipos.reshape(nb, 3)[task.head_body]  # framepos objtype="body": the inertial frame
     mass = o.marr("body_mass")
     com = o.subtree_com.reshape(nb, 3)[task.subtree_body]
     cvel = o.cvel.reshape(nb, 6)

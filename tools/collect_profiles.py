@@ -59,8 +59,8 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     hbm = 2 * fetch + write
     out["hbm"] = {"fetch_bytes_raw": fetch, "write_bytes": write, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 748 * n_env,
                   "note": "FETCH_SIZE doubled per the gfx950 correction (calibrated for 16 B/lane streams; this kernel reads dwords, so this is an upper estimate)"}
-    json.dump({"hbm_bytes_per_launch": hbm, "source": "profiles/%s_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_round.sh)" % rnd},
-              open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+    latest = {"hbm_bytes_per_launch": hbm, "source": "profiles/%s_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_round.sh)" % rnd}
+    json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 if "SQ_INSTS_VALU" in counters:
     w = counters["SQ_WAVES"]["mean"]
     out["per_wave"] = {k: counters[k]["mean"] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
@@ -70,6 +70,12 @@ if "SQ_INSTS_VALU" in counters:
         out["valu_lane_ops_per_s"] = counters["SQ_INSTS_VALU"]["mean"] * 64 / (avg_ns * 1e-9)
         out["valu_issue_frac_of_peak"] = out["valu_lane_ops_per_s"] / 78.6e12
 json.dump(out, open(os.path.join(dst, rnd + "_counters.json"), "w"), indent=1)
+if "valu_issue_frac_of_peak" in out and os.path.exists(os.path.join(dst, "traffic_latest.json")):
+    latest = json.load(open(os.path.join(dst, "traffic_latest.json")))
+    latest["valu_issue_frac_of_peak"] = out["valu_issue_frac_of_peak"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "SQ_BUSY_CU_CYCLES" in counters:
+        latest["mfma_busy_frac"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (4.0 * counters["SQ_BUSY_CU_CYCLES"]["mean"])
+    json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 # second kernel trace (bench.py --no-pipeline with its Newton leg): every hb_* kernel's 4096-block launches
 tn = glob.glob(os.path.join(src, "prof_trace_newton", "*", "*_kernel_trace.csv"))
 if tn:

@@ -1104,7 +1104,8 @@ int hb_state_from_proto(hb_batch* b, int env, const unsigned char* buf, int len)
 
 int hb_sensor_size(const hb_sensor_spec* spec) {
   if (!spec || spec->n_framepos < 0 || spec->n_framepos > HB_MAX_FRAMEPOS) return HB_EINVAL;
-  return 3 * spec->n_framepos + (spec->subtree_body >= 0 ? 6 : 0);
+  if (spec->n_frameaxis < 0 || spec->n_frameaxis > 8 || spec->n_framelinvel < 0 || spec->n_framelinvel > 8 || spec->n_subtreelinvel < 0 || spec->n_subtreelinvel > 4) return HB_EINVAL;
+  return 3 * spec->n_framepos + (spec->subtree_body >= 0 ? 6 : 0) + 3 * (spec->n_frameaxis + spec->n_framelinvel + spec->n_subtreelinvel);
 }
 
 // fills the sensor fields of P and sizes the device read-out buffer for T steps
@@ -1131,6 +1132,26 @@ static int sensor_setup(hb_batch* b, const hb_sensor_spec* spec, int T, BatchPtr
   for (int k = 0; k < spec->n_framepos; k++) {
     P.sensor_body[k] = spec->framepos_body[k];
     for (int i = 0; i < 3; i++) P.sensor_off[k][i] = spec->framepos_offset[k][i];
+  }
+  P.sensor_naxis = spec->n_frameaxis; P.sensor_nlinvel = spec->n_framelinvel; P.sensor_nsub = spec->n_subtreelinvel;
+  for (int k = 0; k < spec->n_frameaxis; k++) {
+    if (spec->frameaxis_body[k] < 0 || spec->frameaxis_body[k] >= m.nbody || (spec->frameaxis_which[k] != 0 && spec->frameaxis_which[k] != 2)) return HB_EINVAL;
+    P.sensor_axis_body[k] = spec->frameaxis_body[k]; P.sensor_axis_which[k] = spec->frameaxis_which[k];
+  }
+  for (int k = 0; k < spec->n_framelinvel; k++) {
+    if (spec->framelinvel_body[k] < 1 || spec->framelinvel_body[k] >= m.nbody) return HB_EINVAL;
+    P.sensor_linvel_body[k] = spec->framelinvel_body[k];
+  }
+  for (int k = 0; k < spec->n_subtreelinvel; k++) {
+    const int root = spec->subtreelinvel_body[k];
+    if (root < 1 || root >= m.nbody) return HB_EINVAL;
+    unsigned long long mask = 0;
+    double mass = 0;
+    for (int bd = 1; bd < m.nbody; bd++)
+      for (int a = bd; a > 0; a = m.body_parentid[a])
+        if (a == root) { mask |= 1ull << bd; mass += m.body_mass[bd]; break; }
+    P.sensor_submask[k] = mask;
+    P.sensor_subinv[k] = mass > 1e-15 ? (float)(1.0 / mass) : 0.f;
   }
   return HB_OK;
 }
@@ -1159,6 +1180,118 @@ int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_sp
   if (qpos_out) HB_HIP(hipMemcpyAsync(qpos_out, b->d_qpos_out, nq_out * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
+}
+
+// Trajectory::Rollout's data flow for a task cost on the device: `horizon - 1` steps from the current state with the
+// read-out row of every step (sensors of `spec`, then the state / control parts in `flags`), then one mj_forward with the
+// last action repeated (zero when horizon = 1) for the terminal row.  Leaves `horizon` rows of `*stride` floats in
+// b->d_sensor_out and room for horizon + 1 floats per env in b->d_task_out; the status words are cleared first.
+static int rollout_rows(hb_batch* b, const float* ctrl, int H, const hb_sensor_spec* spec, int flags, int* stride) {
+  const DevModel& dm = b->D.dm;
+  const int N = b->n_env, nu = dm.nu;
+  const size_t n = (size_t)(H - 1) * N * nu;
+  int rc = ensure_ctrl(b, std::max<size_t>(std::max<size_t>(n, (size_t)N * nu), 1));
+  if (rc != HB_OK) return rc;
+  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  else if (nu) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, (size_t)N * nu * sizeof(float), main_stream(b)));
+  // failure is a property of THIS rollout (CheckWarnings looks at the warnings of the rollout's own mjData)
+  HB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)N * sizeof(int), main_stream(b)));
+  BatchPtrs P = make_ptrs(b);
+  rc = sensor_setup(b, spec, H, P);
+  if (rc != HB_OK) return rc;
+  *stride = P.sensor_stride + ((flags & 4) ? dm.nq : 0) + ((flags & 1) ? dm.nv : 0) + ((flags & 2) ? nu : 0);
+  if ((rc = ensure_trace(&b->d_sensor_out, &b->sensor_out_cap, (size_t)H * N * *stride)) != HB_OK) return rc;
+  if ((rc = ensure_trace(&b->d_task_out, &b->task_out_cap, (size_t)(H + 1) * N)) != HB_OK) return rc;
+  P.sensor_out = b->d_sensor_out; P.sensor_stride = *stride; P.sensor_flags = flags;
+  if (H > 1) {
+    P.ctrl = b->d_ctrl; P.ctrl_mode = 1;
+    rc = launch_steps(b, P, H - 1);
+    if (rc != HB_OK) return rc;
+  }
+  // final mj_forward with the last action repeated (trajectory.cc:188-202)
+  BatchPtrs F = P;
+  F.ctrl = b->d_ctrl + (H > 1 ? (size_t)(H - 2) * N * nu : 0); F.ctrl_mode = 0; F.integrate = 0;
+  F.sensor_out = b->d_sensor_out + (size_t)(H - 1) * N * *stride;
+  F.blk0 = 0; F.nblk = N;
+  HB_HIP(launch_step(b->D.d_dm, dm.solver, dm.nv, dm.lds_floats, F, 1, main_stream(b)));
+  return HB_OK;
+}
+
+static int task_results(hb_batch* b, int H, float* total_return, float* costs) {
+  const int N = b->n_env;
+  HB_HIP(hipMemcpyAsync(total_return, b->d_task_out, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  if (costs) HB_HIP(hipMemcpyAsync(costs, b->d_task_out + N, (size_t)H * N * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
+}
+
+int hb_task_walk_default(const hb_model* h, hb_task_walk* t) {
+  if (!h || !t) return HB_EINVAL;
+  memset(t, 0, sizeof *t);
+  const char* names[5] = {"torso", "pelvis", "foot_right", "foot_left", "waist_lower"};
+  int id[5];
+  for (int k = 0; k < 5; k++) if ((id[k] = hb_model_name2id(h, "body", names[k])) < 0) return HB_EINVAL;
+  t->torso_body = id[0]; t->pelvis_body = id[1]; t->foot_right_body = id[2]; t->foot_left_body = id[3]; t->waist_lower_body = id[4];
+  t->height_goal = 1.35f; t->speed_goal = 0.5f;
+  hb_sizes sz;
+  hb_model_sizes(h, &sz);
+  // user sensors of tasks/humanoid/walk/task.xml:28-35: name, dim, "norm weight lo hi [p [q]]"
+  const int dim[8] = {1, 1, 2, 8, sz.nq - 7, 2, 1, sz.nu}, norm[8] = {7, 8, 1, 2, 0, 7, 7, 3};
+  const float w[8] = {5.f, 1.f, 5.f, 5.f, 0.025f, 0.625f, 1.f, 0.1f};
+  const float p[8] = {0.1f, 0.05f, 0.02f, 0.01f, 0.f, 0.2f, 0.5f, 0.3f}, q[8] = {4.f, 0.f, 4.f, 0.f, 0.f, 4.f, 3.f, 0.f};
+  t->n_term = 8;
+  for (int k = 0; k < 8; k++) { t->dim[k] = dim[k]; t->norm[k] = norm[k]; t->weight[k] = w[k]; t->norm_p[k][0] = p[k]; t->norm_p[k][1] = q[k]; }
+  return HB_OK;
+}
+
+int hb_rollout_task_walk(hb_batch* b, const float* ctrl, int H, const hb_task_walk* task, float* total_return, float* costs) {
+  if (!b || !task || !total_return || H < 1 || (H > 1 && !ctrl && b->D.dm.nu > 0)) return HB_EINVAL;
+  const Model& m = b->model->m;
+  const DevModel& dm = b->D.dm;
+  const int bodies[5] = {task->torso_body, task->pelvis_body, task->foot_right_body, task->foot_left_body, task->waist_lower_body};
+  for (int bd : bodies) if (bd < 1 || bd >= m.nbody) return HB_EINVAL;
+  if (dm.nq < 7 || task->n_term < 1 || task->n_term > 8) return HB_EINVAL;
+  const int nres = 1 + 1 + 2 + 8 + (dm.nq - 7) + 1 + 2 + dm.nu;
+  int total_dim = 0;
+  for (int k = 0; k < task->n_term; k++) {
+    if (task->dim[k] < 1 || task->norm[k] < -1 || task->norm[k] > 8 || task->norm[k] == 4) return HB_EINVAL;
+    total_dim += task->dim[k];
+  }
+  if (total_dim != nres || nres > 96) return HB_EINVAL;  // "mismatch between total user-sensor dimension and actual length of residual" (walk.cc:150-162)
+  HB_HIP(hipSetDevice(b->device));
+  // read-out rows: framepos (objtype body: inertial frames) torso, foot_right, foot_left, pelvis | subtreecom, subtreelinvel (torso's tree)
+  // | up axes x4, forward axes x4 | framelinvel torso, foot_right, foot_left | subtreelinvel waist_lower | qpos | ctrl
+  hb_sensor_spec spec;
+  memset(&spec, 0, sizeof spec);
+  const int fp[4] = {task->torso_body, task->foot_right_body, task->foot_left_body, task->pelvis_body};
+  spec.n_framepos = 4;
+  for (int k = 0; k < 4; k++) {
+    spec.framepos_body[k] = fp[k];
+    for (int i = 0; i < 3; i++) spec.framepos_offset[k][i] = (float)m.body_ipos[3 * fp[k] + i];
+  }
+  int root = task->torso_body;
+  while (m.body_parentid[root] != 0) root = m.body_parentid[root];
+  if (root != task->torso_body) return HB_EINVAL;  // torso_subcom / torso_subcomvel are read as a whole tree
+  spec.subtree_body = root;
+  const int axb[4] = {task->torso_body, task->pelvis_body, task->foot_right_body, task->foot_left_body};
+  spec.n_frameaxis = 8;
+  for (int k = 0; k < 4; k++) { spec.frameaxis_body[k] = axb[k]; spec.frameaxis_which[k] = 2; spec.frameaxis_body[4 + k] = axb[k]; spec.frameaxis_which[4 + k] = 0; }
+  spec.n_framelinvel = 3;
+  spec.framelinvel_body[0] = task->torso_body; spec.framelinvel_body[1] = task->foot_right_body; spec.framelinvel_body[2] = task->foot_left_body;
+  spec.n_subtreelinvel = 1;
+  spec.subtreelinvel_body[0] = task->waist_lower_body;
+  int stride = 0;
+  int rc = rollout_rows(b, ctrl, H, &spec, /*qpos | ctrl*/ 4 | 2, &stride);
+  if (rc != HB_OK) return rc;
+  WalkTask K;
+  memset(&K, 0, sizeof K);
+  K.o_torso = 0; K.o_foot_r = 3; K.o_foot_l = 6; K.o_pelvis = 9; K.o_com = 12; K.o_vel = 15; K.o_axes = 18; K.o_linvel = K.o_axes + 24; K.o_sub = K.o_linvel + 9;
+  K.o_qpos = K.o_sub + 3; K.o_ctrl = K.o_qpos + dm.nq; K.nq = dm.nq; K.nu = dm.nu; K.stride = stride;
+  if (K.o_ctrl + dm.nu != stride) return HB_EINVAL;
+  K.height_goal = task->height_goal; K.speed_goal = task->speed_goal; K.risk = task->risk; K.nterm = task->n_term;
+  for (int k = 0; k < task->n_term; k++) { K.dim[k] = task->dim[k]; K.norm[k] = task->norm[k]; K.weight[k] = task->weight[k]; K.p[k] = task->norm_p[k][0]; K.q[k] = task->norm_p[k][1]; }
+  HB_HIP(launch_walk_cost(b->d_sensor_out, H, b->n_env, K, b->d_status, b->d_task_out, costs ? b->d_task_out + b->n_env : nullptr, main_stream(b)));
+  return task_results(b, H, total_return, costs);
 }
 
 int hb_task_stand_default(const hb_model* h, hb_task_stand* t) {
@@ -1199,42 +1332,19 @@ int hb_rollout_task_stand(hb_batch* b, const float* ctrl, int H, const hb_task_s
   }
   spec.subtree_body = task->subtree_body;
   if (spec.subtree_body < 0) return HB_EINVAL;
-  const int N = b->n_env, nu = dm.nu, nv = dm.nv;
-  const size_t n = (size_t)(H - 1) * N * nu;
-  int rc = ensure_ctrl(b, std::max<size_t>(std::max<size_t>(n, (size_t)N * nu), 1));
-  if (rc != HB_OK) return rc;
-  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
-  else if (nu) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, (size_t)N * nu * sizeof(float), main_stream(b)));
-  // failure is a property of THIS rollout (CheckWarnings looks at the warnings of the rollout's own mjData)
-  HB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)N * sizeof(int), main_stream(b)));
-  BatchPtrs P = make_ptrs(b);
-  rc = sensor_setup(b, &spec, H, P);  // sizes the buffer for 3 * n_framepos + 6 per row; grown below for the qvel / ctrl tail
+  const int nu = dm.nu, nv = dm.nv;
+  int stride = 0;
+  int rc = rollout_rows(b, ctrl, H, &spec, /*qvel | ctrl*/ 1 | 2, &stride);
   if (rc != HB_OK) return rc;
   StandTask K;
   memset(&K, 0, sizeof K);
   K.n_feet = task->n_feet; K.o_head = 0; K.o_feet = 3; K.o_com = 3 * spec.n_framepos; K.o_vel = K.o_com + 3; K.o_qvel = K.o_com + 6; K.o_ctrl = K.o_qvel + nv;
-  K.nv = nv; K.nu = nu; K.stride = K.o_ctrl + nu;
+  K.nv = nv; K.nu = nu; K.stride = stride;
+  if (K.o_ctrl + nu != stride) return HB_EINVAL;
   K.height_goal = task->height_goal; K.risk = task->risk;
   for (int k = 0; k < 5; k++) { K.norm[k] = task->norm[k]; K.weight[k] = task->weight[k]; K.p[k] = task->norm_p[k][0]; K.q[k] = task->norm_p[k][1]; }
-  if ((rc = ensure_trace(&b->d_sensor_out, &b->sensor_out_cap, (size_t)H * N * K.stride)) != HB_OK) return rc;
-  if ((rc = ensure_trace(&b->d_task_out, &b->task_out_cap, (size_t)(H + 1) * N)) != HB_OK) return rc;
-  P.sensor_out = b->d_sensor_out; P.sensor_stride = K.stride; P.sensor_flags = 3;
-  if (H > 1) {
-    P.ctrl = b->d_ctrl; P.ctrl_mode = 1;
-    rc = launch_steps(b, P, H - 1);
-    if (rc != HB_OK) return rc;
-  }
-  // final mj_forward with the last action repeated (trajectory.cc:188-202)
-  BatchPtrs F = P;
-  F.ctrl = b->d_ctrl + (H > 1 ? (size_t)(H - 2) * N * nu : 0); F.ctrl_mode = 0; F.integrate = 0;
-  F.sensor_out = b->d_sensor_out + (size_t)(H - 1) * N * K.stride;
-  F.blk0 = 0; F.nblk = N;
-  HB_HIP(launch_step(b->D.d_dm, dm.solver, dm.nv, dm.lds_floats, F, 1, main_stream(b)));
-  HB_HIP(launch_stand_cost(b->d_sensor_out, H, N, K, b->d_status, b->d_task_out, costs ? b->d_task_out + N : nullptr, main_stream(b)));
-  HB_HIP(hipMemcpyAsync(total_return, b->d_task_out, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
-  if (costs) HB_HIP(hipMemcpyAsync(costs, b->d_task_out + N, (size_t)H * N * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
-  HB_HIP(hipStreamSynchronize(main_stream(b)));
-  return HB_OK;
+  HB_HIP(launch_stand_cost(b->d_sensor_out, H, b->n_env, K, b->d_status, b->d_task_out, costs ? b->d_task_out + b->n_env : nullptr, main_stream(b)));
+  return task_results(b, H, total_return, costs);
 }
 
 int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float* sensor_out) {

@@ -186,6 +186,15 @@ struct StandTask {
   float weight[5], p[5], q[5];
 };
 
+// MJPC "Humanoid Walk" cost (tasks/humanoid/walk/walk.cc:44-163): read-out row offsets and the cost terms (dims as the
+// task's user sensors declare them, applied to the residual vector in order)
+struct WalkTask {
+  int o_torso, o_foot_r, o_foot_l, o_pelvis, o_com, o_vel, o_axes, o_linvel, o_sub, o_qpos, o_ctrl, nq, nu, stride;
+  float height_goal, speed_goal, risk;
+  int nterm, dim[8], norm[8];
+  float weight[8], p[8], q[8];
+};
+
 struct PolicyDesc {
   int nl;
   int sizes[5];
@@ -221,7 +230,13 @@ struct BatchPtrs {
   int sensor_stride, sensor_nframe, sensor_tree;  // sensor_tree < 0: no subtree sensors
   int sensor_body[16];
   float sensor_off[16][3];  // framepos of a site: offset in the body frame (zero: the body frame itself)
-  int sensor_flags;         // bit 0: append qvel[nv], bit 1: append ctrl[nu] (the inputs MJPC residuals read beside sensors)
+  int sensor_flags;         // bit 0: append qvel[nv], bit 1: append ctrl[nu], bit 2: append qpos[nq] (the inputs MJPC residuals read beside sensors)
+  // further read-outs, appended in this order behind framepos / subtreecom / subtreelinvel:
+  int sensor_naxis, sensor_axis_body[8], sensor_axis_which[8];  // framexaxis (0) / framezaxis (2) of a body frame (objtype xbody)
+  int sensor_nlinvel, sensor_linvel_body[8];                     // framelinvel, objtype body: velocity of the inertial frame origin, world axes
+  int sensor_nsub;                                               // subtreelinvel of further bodies (any body, not only a tree root)
+  unsigned long long sensor_submask[4];                          //   bit b: body b belongs to that subtree
+  float sensor_subinv[4];                                        //   1 / subtree mass
   const unsigned char* env_mask;  // nullable [n_env]: envs with a zero byte are skipped by this launch
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
 };

@@ -1114,6 +1114,28 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       }
       {
         int o = 3 * P.sensor_nframe + (P.sensor_tree >= 0 ? 6 : 0);
+        for (int k = 0; k < P.sensor_naxis; k++, o += 3) {  // framexaxis / framezaxis: a column of the body's rotation
+          const V3 e = P.sensor_axis_which[k] == 0 ? V3{1.f, 0.f, 0.f} : V3{0.f, 0.f, 1.f};
+          const V3 a = qrot(ldq(s_xpq + 8 * P.sensor_axis_body[k] + 4), e);
+          if (lane < 3) so[o + lane] = lane == 0 ? a.x : (lane == 1 ? a.y : a.z);
+        }
+        for (int k = 0; k < P.sensor_nlinvel; k++, o += 3) {  // mj_objectVelocity at the inertial frame origin, world axes
+          const int sb = P.sensor_linvel_body[k];
+          const float* cv = s_va + 12 * sb;
+          const V3 v = V3{cv[3], cv[4], cv[5]} + cross(V3{cv[0], cv[1], cv[2]}, ld3(s_xipos + 3 * sb) - ld3(s_scom + 3 * M.body_treeid[sb]));
+          if (lane < 3) so[o + lane] = lane == 0 ? v.x : (lane == 1 ? v.y : v.z);
+        }
+        for (int k = 0; k < P.sensor_nsub; k++, o += 3) {  // mj_subtreeVel of a body's subtree: its linear momentum over its mass
+          V3 mom = {0.f, 0.f, 0.f};
+          if (bl && ((P.sensor_submask[k] >> myb) & 1ull)) {
+            const V3 ang = {mycvel[0], mycvel[1], mycvel[2]}, lin = {mycvel[3], mycvel[4], mycvel[5]};
+            mom = (lin + cross(ang, ld3(s_xipos + 3 * myb) - ld3(s_scom + 3 * __float_as_int(q1.y)))) * mymass;
+          }
+          const float im = P.sensor_subinv[k];
+          const float vx = wave_sum(mom.x) * im, vy = wave_sum(mom.y) * im, vz = wave_sum(mom.z) * im;
+          if (lane < 3) so[o + lane] = lane == 0 ? vx : (lane == 1 ? vy : vz);
+        }
+        if (P.sensor_flags & 4) { for (int i = lane; i < nq; i += kGroup) so[o + i] = s_qpos[i]; o += nq; }
         if (P.sensor_flags & 1) { for (int i = lane; i < nv; i += kGroup) so[o + i] = s_qvel[i]; o += nv; }
         if (P.sensor_flags & 2) for (int i = lane; i < M.nu; i += kGroup) so[o + i] = s_ctrl[i];
       }
@@ -2155,6 +2177,69 @@ __global__ void hb_stand_cost_kernel(const float* rows, int H, int n_env, const 
   total[e] = failed ? 1.0e6f : sum / (float)max(H, 1);
 }
 
+// Walk::ResidualFn::Residual (tasks/humanoid/walk/walk.cc:44-163) on each of the H rows, then the cost terms in the
+// order and with the dimensions the task's user sensors declare (task.cc:71-89), return as in hb_stand_cost_kernel
+__global__ void hb_walk_cost_kernel(const float* rows, int H, int n_env, const WalkTask K, const int* status, float* total, float* costs) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_env) return;
+  float sum = 0.f;
+  for (int t = 0; t < H; t++) {
+    const float* r = rows + ((size_t)t * n_env + e) * K.stride;
+    float res[96];
+    int c = 0;
+    const float torso_height = r[K.o_torso + 2];
+    res[c++] = torso_height - K.height_goal;
+    const float* fr = r + K.o_foot_r;
+    const float* fl = r + K.o_foot_l;
+    res[c++] = 0.5f * (fl[2] + fr[2]) - r[K.o_pelvis + 2] - 0.2f;
+    // balance: capture point against its projection onto the segment between the feet
+    float cp[3] = {r[K.o_com] + 0.3f * r[K.o_vel], r[K.o_com + 1] + 0.3f * r[K.o_vel + 1], 1.0e-3f};
+    float axis[3] = {fr[0] - fl[0], fr[1] - fl[1], 1.0e-3f};
+    float an = sqrtf(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+    if (an < 1e-15f) { axis[0] = 1.f; axis[1] = 0.f; axis[2] = 0.f; } else { axis[0] /= an; axis[1] /= an; axis[2] /= an; }  // mju_normalize3
+    const float length = 0.5f * an - 0.05f;
+    const float center[3] = {0.5f * (fr[0] + fl[0]), 0.5f * (fr[1] + fl[1]), 0.5f * (fr[2] + fl[2])};
+    const float vec[3] = {cp[0] - center[0], cp[1] - center[1], cp[2] - center[2]};
+    float tt = vec[0] * axis[0] + vec[1] * axis[1] + vec[2] * axis[2];
+    tt = fmaxf(-length, fminf(length, tt));
+    const float pcp[2] = {axis[0] * tt + center[0], axis[1] * tt + center[1]};
+    const float standing = torso_height / sqrtf(torso_height * torso_height + 0.45f * 0.45f) - 0.4f;
+    res[c++] = standing * (cp[0] - pcp[0]);
+    res[c++] = standing * (cp[1] - pcp[1]);
+    // upright: axes are [torso_up, pelvis_up, foot_right_up, foot_left_up, torso_forward, pelvis_forward, foot_right_forward, foot_left_forward]
+    const float* ax = r + K.o_axes;
+    res[c++] = ax[2] - 1.f;
+    res[c++] = 0.3f * (ax[3 + 2] - 1.f);
+    for (int f = 0; f < 2; f++) {
+      const float* up = ax + 3 * (2 + f);
+      res[c++] = 0.1f * standing * up[0]; res[c++] = 0.1f * standing * up[1]; res[c++] = 0.1f * standing * (up[2] - 1.f);
+    }
+    // posture
+    for (int i = 7; i < K.nq; i++) res[c++] = r[K.o_qpos + i];
+    // walk
+    float fw[2] = {0.f, 0.f};
+    for (int k = 4; k < 8; k++) { fw[0] += ax[3 * k]; fw[1] += ax[3 * k + 1]; }
+    const float fn = sqrtf(fw[0] * fw[0] + fw[1] * fw[1]);
+    if (fn < 1e-15f) { fw[0] = 1.f; fw[1] = 0.f; } else { fw[0] /= fn; fw[1] /= fn; }  // mju_normalize
+    const float* tv = r + K.o_linvel;  // torso, foot_right, foot_left
+    const float cv[2] = {0.5f * (r[K.o_sub] + tv[0]), 0.5f * (r[K.o_sub + 1] + tv[1])};
+    res[c++] = standing * (cv[0] * fw[0] + cv[1] * fw[1] - K.speed_goal);
+    // move feet
+    res[c++] = standing * (cv[0] - 0.5f * tv[3] - 0.5f * tv[6]);
+    res[c++] = standing * (cv[1] - 0.5f * tv[4] - 0.5f * tv[7]);
+    // control
+    for (int i = 0; i < K.nu; i++) res[c++] = r[K.o_ctrl + i];
+    float cost = 0.f;
+    int sh = 0;
+    for (int k = 0; k < K.nterm; k++) { cost += K.weight[k] * mjpc_norm(K.norm[k], res + sh, K.dim[k], K.p[k], K.q[k]); sh += K.dim[k]; }
+    if (fabsf(K.risk) >= 1e-6f) cost = (expf(K.risk * cost) - 1.f) / K.risk;
+    if (costs) costs[(size_t)t * n_env + e] = cost;
+    sum += cost;
+  }
+  const bool failed = status[e] & ((1 << 4) | (1 << 5) | (1 << 6));
+  total[e] = failed ? 1.0e6f : sum / (float)max(H, 1);
+}
+
 // ------------------------------------------------------------------------------------------
 // reset: qpos0/keyframe (+ Halton perturbation), zero velocity/warmstart/time/status
 // qpos <- reset pose (+ the Halton perturbation indexed by global env and, for the env adapter, episode), rest zero
@@ -2770,6 +2855,11 @@ hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int 
 hipError_t launch_stand_cost(const float* rows, int H, int n_env, const StandTask& K, const int* status, float* total, float* costs, hipStream_t stream) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(hb_stand_cost_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, rows, H, n_env, K, status, total, costs);
+  return hipGetLastError();
+}
+hipError_t launch_walk_cost(const float* rows, int H, int n_env, const WalkTask& K, const int* status, float* total, float* costs, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(hb_walk_cost_kernel, dim3((n_env + 63) / 64), dim3(64), 0, stream, rows, H, n_env, K, status, total, costs);
   return hipGetLastError();
 }
 hipError_t set_step_lds_limit(int bytes) {

@@ -24,5 +24,6 @@ hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream);
 hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream);
 hipError_t launch_stand_cost(const float* rows, int H, int n_env, const StandTask& K, const int* status, float* total, float* costs, hipStream_t stream);
+hipError_t launch_walk_cost(const float* rows, int H, int n_env, const WalkTask& K, const int* status, float* total, float* costs, hipStream_t stream);
 hipError_t set_step_lds_limit(int bytes);
 }  // namespace hb

@@ -67,10 +67,20 @@ class HbTaskStand(ctypes.Structure):
                 ("norm_p", (ctypes.c_float * 2) * 5), ("risk", ctypes.c_float)]
 
 
+class HbTaskWalk(ctypes.Structure):
+    _fields_ = [("torso_body", ctypes.c_int), ("pelvis_body", ctypes.c_int), ("foot_right_body", ctypes.c_int), ("foot_left_body", ctypes.c_int),
+                ("waist_lower_body", ctypes.c_int), ("height_goal", ctypes.c_float), ("speed_goal", ctypes.c_float), ("n_term", ctypes.c_int),
+                ("dim", ctypes.c_int * 8), ("norm", ctypes.c_int * 8), ("weight", ctypes.c_float * 8), ("norm_p", (ctypes.c_float * 2) * 8),
+                ("risk", ctypes.c_float)]
+
+
 class HbSensorSpec(ctypes.Structure):
     """hb_sensor_spec (include/hb.h): framepos bodies and the tree whose subtreecom / subtreelinvel are read out."""
     _fields_ = [("n_framepos", ctypes.c_int), ("framepos_body", ctypes.c_int * 16), ("subtree_body", ctypes.c_int),
-                ("framepos_offset", (ctypes.c_float * 3) * 16)]
+                ("framepos_offset", (ctypes.c_float * 3) * 16),
+                ("n_frameaxis", ctypes.c_int), ("frameaxis_body", ctypes.c_int * 8), ("frameaxis_which", ctypes.c_int * 8),
+                ("n_framelinvel", ctypes.c_int), ("framelinvel_body", ctypes.c_int * 8),
+                ("n_subtreelinvel", ctypes.c_int), ("subtreelinvel_body", ctypes.c_int * 4)]
 
 
 class HbDomainRandomization(ctypes.Structure):
@@ -146,6 +156,8 @@ def lib():
     L.hb_rollout_trajectory.argtypes = [vp, vp, ci, vp, vp, vp]
     L.hb_task_stand_default.argtypes = [vp, ctypes.POINTER(HbTaskStand)]
     L.hb_rollout_task_stand.argtypes = [vp, vp, ci, ctypes.POINTER(HbTaskStand), vp, vp]
+    L.hb_task_walk_default.argtypes = [vp, ctypes.POINTER(HbTaskWalk)]
+    L.hb_rollout_task_walk.argtypes = [vp, vp, ci, ctypes.POINTER(HbTaskWalk), vp, vp]
     L.hb_sensors.argtypes = [vp, vp, ctypes.POINTER(HbSensorSpec), vp]
     L.hb_env_reset.argtypes = [vp, vp]
     L.hb_env_step.argtypes = [vp, vp, ci, vp, vp, vp, vp]
@@ -409,8 +421,10 @@ class Batch:
 
     # ---- planner rollouts (MJPC Trajectory::Rollout analogue)
     @staticmethod
-    def sensor_spec(framepos_bodies=(), subtree_body=-1, offsets=None):
-        """offsets: per frame, the site's position in its body frame (None / missing: the body frame itself)."""
+    def sensor_spec(framepos_bodies=(), subtree_body=-1, offsets=None, axes=(), linvel_bodies=(), subtreelinvel_bodies=()):
+        """offsets: per frame, the site's position in its body frame (None / missing: the body frame itself);
+        axes: (body, which) pairs, which = 0 (framexaxis) or 2 (framezaxis); linvel_bodies: framelinvel (objtype body);
+        subtreelinvel_bodies: subtreelinvel of further bodies."""
         sp = HbSensorSpec()
         sp.n_framepos = len(framepos_bodies)
         for k, bd in enumerate(framepos_bodies):
@@ -419,6 +433,15 @@ class Batch:
                 for i in range(3):
                     sp.framepos_offset[k][i] = float(offsets[k][i])
         sp.subtree_body = int(subtree_body)
+        sp.n_frameaxis = len(axes)
+        for k, (bd, which) in enumerate(axes):
+            sp.frameaxis_body[k] = int(bd); sp.frameaxis_which[k] = int(which)
+        sp.n_framelinvel = len(linvel_bodies)
+        for k, bd in enumerate(linvel_bodies):
+            sp.framelinvel_body[k] = int(bd)
+        sp.n_subtreelinvel = len(subtreelinvel_bodies)
+        for k, bd in enumerate(subtreelinvel_bodies):
+            sp.subtreelinvel_body[k] = int(bd)
         return sp
 
     def set_state_broadcast(self, spec, state):
@@ -456,6 +479,21 @@ class Batch:
         total = np.zeros(self.n_env, dtype=np.float32)
         costs = np.zeros((H, self.n_env), dtype=np.float32) if want_costs else None
         _check(lib().hb_rollout_task_stand(self._h, _ptr(c) if H > 1 else None, H, ctypes.byref(task), _ptr(total), _ptr(costs)), "hb_rollout_task_stand")
+        return total, costs
+
+    def task_walk_default(self):
+        t = HbTaskWalk()
+        _check(lib().hb_task_walk_default(self.model._h, ctypes.byref(t)), "hb_task_walk_default")
+        return t
+
+    def rollout_task_walk(self, ctrl, task, want_costs=False):
+        """ctrl [horizon - 1, n_env, nu] -> (total_return [n_env], stage costs [horizon, n_env] or None) of MJPC's Humanoid Walk task."""
+        c = np.ascontiguousarray(ctrl, dtype=np.float32)
+        H = c.shape[0] + 1
+        assert c.shape == (H - 1, self.n_env, self.model.nu), c.shape
+        total = np.zeros(self.n_env, dtype=np.float32)
+        costs = np.zeros((H, self.n_env), dtype=np.float32) if want_costs else None
+        _check(lib().hb_rollout_task_walk(self._h, _ptr(c) if H > 1 else None, H, ctypes.byref(task), _ptr(total), _ptr(costs)), "hb_rollout_task_walk")
         return total, costs
 
     def rollout_trajectory(self, ctrl):

@@ -170,6 +170,14 @@ typedef struct hb_sensor_spec {
   int subtree_body;
   float framepos_offset[HB_MAX_FRAMEPOS][3]; /* position in the body's frame: zeros = objtype "xbody" (the body frame); a site's pos = objtype
                                                "site"; the body's ipos (hb_model_get_array "body_ipos") = objtype "body" (inertial frame) */
+  /* further read-outs, appended behind the above in this order (3 floats each): */
+  int n_frameaxis;            /* framexaxis / framezaxis of a body frame (objtype "xbody") */
+  int frameaxis_body[8];
+  int frameaxis_which[8];     /* 0: x axis, 2: z axis */
+  int n_framelinvel;          /* framelinvel, objtype "body": linear velocity of the body's inertial frame origin, world axes */
+  int framelinvel_body[8];
+  int n_subtreelinvel;        /* subtreelinvel of further bodies (any body of the model, not only a tree root) */
+  int subtreelinvel_body[4];
 } hb_sensor_spec;
 int hb_sensor_size(const hb_sensor_spec* spec);
 /* mj_setState of ONE state on every env: the N candidate action sequences of a sampling planner all start from the
@@ -213,6 +221,25 @@ int hb_task_stand_default(const hb_model* m, hb_task_stand* out);
  * ([horizon][n_env], nullable) receives the stage costs.  Nothing but these floats crosses PCIe on the way back.  The
  * per-env status words are cleared first: failure is a property of this rollout. */
 int hb_rollout_task_stand(hb_batch* b, const float* ctrl, int horizon, const hb_task_stand* task, float* total_return, float* costs);
+
+/* MJPC's "Humanoid Walk" task the same way (mujoco_mpc/mjpc/tasks/humanoid/walk/{walk.cc:44-163, task.xml:14-86}).
+ * Residual, in order: torso height (1), pelvis/feet (1), balance (2: capture point against its projection onto the
+ * segment between the feet), upright (8), posture (qpos[7:]), walk (1), move feet (2), control (nu).  The cost terms are
+ * the task's user sensors IN THEIR ORDER with THEIR dimensions (Height 1, Pelvis/Feet 1, Balance 2, Upright 8, Posture
+ * nq-7, Velocity 2, Walk 1, Control nu), applied to consecutive slices of that vector as BaseResidualFn::CostTerms does. */
+typedef struct hb_task_walk {
+  int torso_body, pelvis_body, foot_right_body, foot_left_body, waist_lower_body;
+  float height_goal;  /* residual_Torso */
+  float speed_goal;   /* residual_Speed */
+  int n_term;
+  int dim[8];
+  int norm[8];
+  float weight[8];
+  float norm_p[8][2];
+  float risk;
+} hb_task_walk;
+int hb_task_walk_default(const hb_model* m, hb_task_walk* out);
+int hb_rollout_task_walk(hb_batch* b, const float* ctrl, int horizon, const hb_task_walk* task, float* total_return, float* costs);
 
 /* The same read-out at the current state (mj_forward, no integration): the terminal residual of a trajectory. */
 int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float* sensor_out);

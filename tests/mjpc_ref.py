@@ -66,3 +66,94 @@ def stand_rollout(o, ctrl, task, nb):
     o.forward()
     costs.append(stand_cost(stand_residual(o, task, nb), task))
     return float(np.mean(costs)), np.array(costs)
+
+
+# ---- sensors as MuJoCo evaluates them, from oracle quantities -------------------------------------------------------
+def body_linvel(o, body, nb):
+    """framelinvel, objtype body (mj_objectVelocity at the inertial frame origin, world axes): cvel is the spatial
+    velocity at the tree's com, so the point velocity is lin + ang x (xipos - com)."""
+    cvel = o.cvel.reshape(nb, 6)[body]
+    com = o.subtree_com.reshape(nb, 3)[1]  # one tree, rooted at body 1
+    return cvel[3:] + np.cross(cvel[:3], o.xipos.reshape(nb, 3)[body] - com)
+
+
+def subtree_linvel(o, root, nb, parent):
+    """subtreelinvel of any body: linear momentum of its subtree over the subtree's mass (mj_subtreeVel)."""
+    mass = o.marr("body_mass")
+    members = [b for b in range(1, nb) if root in _ancestors(b, parent)]
+    mom = sum(mass[b] * body_linvel(o, b, nb) for b in members)
+    return mom / sum(mass[b] for b in members)
+
+
+def _ancestors(b, parent):
+    out = []
+    while b > 0:
+        out.append(b)
+        b = parent[b]
+    return out
+
+
+def walk_residual(o, task, nb, parent):
+    """Walk::ResidualFn::Residual (mujoco_mpc/mjpc/tasks/humanoid/walk/walk.cc:44-163)."""
+    xipos = o.xipos.reshape(nb, 3)
+    xmat = o.xmat.reshape(nb, 3, 3)
+    up = lambda b: xmat[b][:, 2]
+    fwd = lambda b: xmat[b][:, 0]
+    res = []
+    torso_height = xipos[task.torso_body][2]
+    res.append(torso_height - task.height_goal)
+    fr, fl = xipos[task.foot_right_body], xipos[task.foot_left_body]
+    res.append(0.5 * (fl[2] + fr[2]) - xipos[task.pelvis_body][2] - 0.2)
+    com = o.subtree_com.reshape(nb, 3)[task.torso_body]
+    comvel = subtree_linvel(o, task.torso_body, nb, parent)
+    cp = com + 0.3 * comvel
+    cp[2] = 1e-3
+    axis = fr - fl
+    axis[2] = 1e-3
+    n = np.linalg.norm(axis)
+    axis = axis / n
+    length = 0.5 * n - 0.05
+    center = 0.5 * (fr + fl)
+    t = float(np.clip((cp - center) @ axis, -length, length))
+    pcp = axis * t + center
+    standing = torso_height / np.sqrt(torso_height ** 2 + 0.45 ** 2) - 0.4
+    res += list(standing * (cp[:2] - pcp[:2]))
+    z = np.array([0.0, 0.0, 1.0])
+    res.append(up(task.torso_body)[2] - 1.0)
+    res.append(0.3 * (up(task.pelvis_body)[2] - 1.0))
+    res += list(0.1 * standing * (up(task.foot_right_body) - z))
+    res += list(0.1 * standing * (up(task.foot_left_body) - z))
+    res += list(o.qpos[7:])
+    f = fwd(task.torso_body)[:2] + fwd(task.pelvis_body)[:2] + fwd(task.foot_right_body)[:2] + fwd(task.foot_left_body)[:2]
+    f = f / np.linalg.norm(f)
+    com_vel = 0.5 * (subtree_linvel(o, task.waist_lower_body, nb, parent)[:2] + body_linvel(o, task.torso_body, nb)[:2])
+    res.append(standing * (com_vel @ f - task.speed_goal))
+    move = com_vel - 0.5 * body_linvel(o, task.foot_right_body, nb)[:2] - 0.5 * body_linvel(o, task.foot_left_body, nb)[:2]
+    res += list(standing * move)
+    res += list(o.ctrl)
+    return np.array(res)
+
+
+def terms_cost(res, task):
+    """BaseResidualFn::CostTerms / CostValue (mjpc/task.cc:71-110): the terms' dims slice the residual in order."""
+    c, sh = 0.0, 0
+    for k in range(task.n_term):
+        c += task.weight[k] * norm(task.norm[k], res[sh:sh + task.dim[k]], task.norm_p[k][0], task.norm_p[k][1])
+        sh += task.dim[k]
+    assert sh == len(res)
+    if abs(task.risk) >= 1e-6:
+        c = (np.exp(task.risk * c) - 1.0) / task.risk
+    return c
+
+
+def walk_rollout(o, ctrl, task, nb, parent):
+    costs = []
+    for t in range(len(ctrl)):
+        o.ctrl[:] = ctrl[t]
+        o.forward()
+        costs.append(terms_cost(walk_residual(o, task, nb, parent), task))
+        o.step()
+    o.ctrl[:] = ctrl[-1] if len(ctrl) else 0
+    o.forward()
+    costs.append(terms_cost(walk_residual(o, task, nb, parent), task))
+    return float(np.mean(costs)), np.array(costs)

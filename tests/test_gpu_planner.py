@@ -182,3 +182,63 @@ def test_stand_task_return_matches_mjpc_restatement(hbmod, humanoid_model, gpu):
     b.set_state(hbmod.STATE_INTEGRATION, states)
     total, _ = b.rollout_task_stand(ctrl[:4], task)
     assert total[5] == 1e6 and (np.delete(total, 5) < 1e5).all()
+
+
+def test_axis_linvel_and_subtree_sensors(hbmod, humanoid_model, gpu):
+    """framexaxis / framezaxis (xbody), framelinvel (body) and subtreelinvel of a non-root body against oracle quantities."""
+    from mjpc_ref import body_linvel, subtree_linvel
+    m = humanoid_model
+    nb = 17
+    torso, pelvis, foot, waist = (m.name2id("body", n) for n in ("torso", "pelvis", "foot_right", "waist_lower"))
+    spec = hbmod.Batch.sensor_spec([], axes=[(pelvis, 2), (foot, 0)], linvel_bodies=[torso, foot], subtreelinvel_bodies=[waist, foot])
+    b = hbmod.Batch(m, 4, gpu)
+    b.reset(perturb=True)
+    b.rollout_halton(45)
+    s = b.sensors(spec)
+    assert s.shape == (4, 18)
+    o = Oracle()
+    parent = o.info["body_parentid"]
+    st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+    for e in range(4):
+        o.reset()
+        o.qpos[:] = st[e, 1:1 + m.nq]; o.qvel[:] = st[e, 1 + m.nq:1 + m.nq + m.nv]
+        o.forward()
+        xmat = o.xmat.reshape(nb, 3, 3)
+        ref = np.concatenate([xmat[pelvis][:, 2], xmat[foot][:, 0], body_linvel(o, torso, nb), body_linvel(o, foot, nb),
+                              subtree_linvel(o, waist, nb, parent), subtree_linvel(o, foot, nb, parent)])
+        assert np.allclose(s[e], ref, atol=2e-5 * max(1.0, np.abs(ref).max())), (e, s[e], ref)
+
+
+def test_walk_task_return_matches_mjpc_restatement(hbmod, humanoid_model, gpu):
+    """hb_rollout_task_walk against the numpy restatement of Walk::ResidualFn::Residual on fp64 oracle rollouts."""
+    from mjpc_ref import walk_rollout
+    m = humanoid_model
+    N, H, nb = 12, 20, 17
+    b = hbmod.Batch(m, N, gpu)
+    task = b.task_walk_default()
+    assert task.n_term == 8 and list(task.dim[:]) == [1, 1, 2, 8, 21, 2, 1, 21] and list(task.norm[:]) == [7, 8, 1, 2, 0, 7, 7, 3]
+    o = Oracle()
+    parent = o.info["body_parentid"]
+    o.init_env(2)
+    for t in range(25):
+        o.ctrl[:] = o.ctrl_env(t, 2)
+        o.step()
+    q0, v0, w0 = o.qpos.copy(), o.qvel.copy(), o.qacc_warmstart.copy()
+    st = np.concatenate([[0.0], q0, v0, w0])
+    rng = np.random.default_rng(6)
+    ctrl = rng.uniform(-0.5, 0.5, size=(H - 1, N, m.nu)).astype(np.float32)
+    b.set_state_broadcast(hbmod.STATE_INTEGRATION, st)
+    total, costs = b.rollout_task_walk(ctrl, task, want_costs=True)
+    worst = 0.0
+    for e in range(0, N, 3):
+        o.reset()
+        o.qpos[:] = q0; o.qvel[:] = v0; o.qacc_warmstart[:] = w0
+        ret, cs = walk_rollout(o, ctrl[:, e].astype(np.float64), task, nb, parent)
+        assert np.allclose(costs[:6, e], cs[:6], rtol=2e-3, atol=2e-3), (e, costs[:6, e], cs[:6])
+        worst = max(worst, abs(total[e] - ret) / max(1.0, abs(ret)))
+    assert worst < 2e-2, worst
+    # a cost-term layout that does not cover the residual is refused (the reference aborts with "mismatch between total
+    # user-sensor dimension and actual length of residual")
+    task.dim[4] = 20
+    with pytest.raises(hbmod.HbError):
+        b.rollout_task_walk(ctrl, task)

@@ -30,6 +30,15 @@ for solver, name in ((0, "PGS/50"), (2, "Newton/100")):
             b.set_state_broadcast(hb.STATE_INTEGRATION, st)
             total, _ = b.rollout_task_stand(ctrl, task)
         dt = (time.perf_counter() - t0) / reps
+        wt = b.task_walk_default()
+        b.set_state_broadcast(hb.STATE_INTEGRATION, st)
+        b.rollout_task_walk(ctrl, wt)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            b.set_state_broadcast(hb.STATE_INTEGRATION, st)
+            wtotal, _ = b.rollout_task_walk(ctrl, wt)
+        dtw = (time.perf_counter() - t1) / reps
+        print("%-10s %6d candidates x %d states, Walk task: %.2f ms per planner iteration; best return %.3f" % (name, N, H, 1e3 * dtw, float(wtotal.min())), flush=True)
         print("%-10s %6d candidates x %d states: %.2f ms per planner iteration (%.3e env-steps/s incl. tape upload, cost evaluation and return download); best return %.3f, failures %d"
               % (name, N, H, 1e3 * dt, N * (H - 1) / dt, float(total.min()), int((total >= 1e6).sum())), flush=True)
         b.close()

@@ -488,6 +488,8 @@ struct hb_batch {
   float* d_qvel_out = nullptr;
   size_t qvel_out_cap = 0;
   float* d_task_out = nullptr;  // task returns and stage costs
+  float xfrc_std = 0.f, xfrc_rate = 0.f;  // rollout noise (hb_rollout_noise)
+  unsigned xfrc_seed = 0, xfrc_calls = 0;
   size_t task_out_cap = 0;
   float* d_sensor_out = nullptr;
   size_t sensor_out_cap = 0;
@@ -571,6 +573,11 @@ BatchPtrs make_ptrs(hb_batch* b) {
   P.blk0 = 0; P.nblk = b->n_env;
   P.dr = b->d_dr; P.dr_stride = b->dr_stride;
   P.stamps = b->d_stamps;
+  if (b->xfrc_std > 0.f && b->d_xfrc) {
+    const double rate = b->xfrc_rate > 0.f ? std::exp(-b->model->m.timestep / b->xfrc_rate) : 0.0;  // trajectory.cc:149-150
+    P.xfrc_rate = (float)rate; P.xfrc_scale = (float)(b->xfrc_std * std::sqrt(1.0 - rate * rate));
+    P.xfrc_seed = b->xfrc_seed; P.xfrc_call = b->xfrc_calls++;
+  }
   return P;
 }
 
@@ -981,6 +988,18 @@ static int ensure_trace(float** buf, size_t* cap, size_t need) {
   *buf = nullptr; *cap = 0;
   if (hipMalloc((void**)buf, need * sizeof(float)) != hipSuccess) return HB_ENOMEM;
   *cap = need;
+  return HB_OK;
+}
+
+int hb_rollout_noise(hb_batch* b, float xfrc_std, float xfrc_rate, unsigned seed) {
+  if (!b || !(xfrc_std >= 0.f) || !(xfrc_rate >= 0.f)) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  if (xfrc_std > 0.f && !b->d_xfrc) {
+    const size_t nx = (size_t)b->n_env * b->D.dm.nbody * 6;
+    if (hipMalloc((void**)&b->d_xfrc, nx * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+    HB_HIP(hipMemset(b->d_xfrc, 0, nx * sizeof(float)));
+  }
+  b->xfrc_std = xfrc_std; b->xfrc_rate = xfrc_rate; b->xfrc_seed = seed; b->xfrc_calls = 0;
   return HB_OK;
 }
 

@@ -209,6 +209,8 @@ struct BatchPtrs {
   float* qpos_out;     // nullable, [T][n_env][nq]
   float* qvel_out;     // nullable, [T][n_env][nv]: with qpos_out the recorded states of a trajectory (trajectory.cc:175-190)
   float* xfrc;         // nullable, [n_env][nbody][6]
+  float xfrc_rate, xfrc_scale;  // rollout noise (hb_rollout_noise): xfrc <- rate * xfrc + scale * N(0, 1) before every step; scale 0: off
+  unsigned xfrc_seed, xfrc_call;
   int* status;         // [n_env] accumulated HB_WARN_* bits
   int* counts;         // [n_env][kCountStride]
   float* qfrc_out;     // nullable [n_env][nv]: qfrc_smooth + qfrc_constraint of the last step (env adapter's joint torques)

@@ -519,6 +519,26 @@ __device__ __forceinline__ void build_w(DevModelRef M, const f32x2* LD2, const f
 
 // ------------------------------------------------------------------------------------------
 
+// ---- counter-based random numbers (env realism, rollout noise): one 32-bit word per (seed, global env, episode, step,
+// stream, element): reproducible, order-free, the same on any split of the batch.  tests/env_ref.py restates them in numpy.
+__device__ __forceinline__ unsigned rng_mix(unsigned h, unsigned v) {
+  h ^= v; h *= 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ unsigned rng_u32(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
+  unsigned h = rng_mix(0x6A09E667u, seed);
+  h = rng_mix(h, env); h = rng_mix(h, ep); h = rng_mix(h, step); h = rng_mix(h, stream); h = rng_mix(h, idx);
+  return h;
+}
+__device__ __forceinline__ float rng_uniform(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
+  return ((float)(rng_u32(seed, env, ep, step, stream, idx) >> 8) + 0.5f) * (1.f / 16777216.f);  // (0, 1)
+}
+__device__ __forceinline__ float rng_normal(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
+  const float u1 = rng_uniform(seed, env, ep, step, stream, 2 * idx), u2 = rng_uniform(seed, env, ep, step, stream, 2 * idx + 1);
+  return sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);  // Box-Muller
+}
+enum { RS_ACTION = 1, RS_JOINT_POS, RS_JOINT_VEL, RS_GYRO, RS_IMU, RS_DELAY, RS_PUSH, RS_XFRC };
+
 // ---- dense helpers of the Newton solver ------------------------------------------------------------------------
 // A symmetric nv x nv matrix (nv <= 32, identity beyond nv) lives one ROW PER LANE: lane l (and its mirror l + 32)
 // holds row l & 31 in 32 registers.  Vectors live one element per lane (lanes 0..31).  Everything is readlane + fma
@@ -1256,6 +1276,13 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     gsync();
     // xfrc_applied: Cartesian wrench at each body com (mj_xfrcAccumulate)
     if (P.xfrc) {
+      if (P.xfrc_scale > 0.f) {
+        // Trajectory::NoisyRollout's perturbation (trajectory.cc:147-156): Ornstein-Uhlenbeck noise on every xfrc_applied entry
+        float* xw = P.xfrc + (size_t)env * nb * 6;
+        for (int i = lane; i < 6 * nb; i += kGroup)
+          xw[i] = P.xfrc_rate * xw[i] + P.xfrc_scale * rng_normal(P.xfrc_seed, P.env_offset + env, P.xfrc_call, P.t0 + step, RS_XFRC, i);
+        gsync();
+      }
       const float* xf = P.xfrc + (size_t)env * nb * 6;
       for (int b = 1; b < nb; b++) {
         float f[6];
@@ -2268,23 +2295,7 @@ __global__ void hb_reset_kernel(const DevModel M, float* state, int* status, con
 // ---- env realism (hb_env_randomization): counter-based random numbers, delay rings, pushes -------------------
 // One 32-bit word per (seed, global env, episode, step, stream, element): reproducible, order-free, and the same
 // on any split of the batch.  tests/env_ref.py restates these functions in numpy.
-__device__ __forceinline__ unsigned rng_mix(unsigned h, unsigned v) {
-  h ^= v; h *= 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
-  return h;
-}
-__device__ __forceinline__ unsigned rng_u32(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
-  unsigned h = rng_mix(0x6A09E667u, seed);
-  h = rng_mix(h, env); h = rng_mix(h, ep); h = rng_mix(h, step); h = rng_mix(h, stream); h = rng_mix(h, idx);
-  return h;
-}
-__device__ __forceinline__ float rng_uniform(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
-  return ((float)(rng_u32(seed, env, ep, step, stream, idx) >> 8) + 0.5f) * (1.f / 16777216.f);  // (0, 1)
-}
-__device__ __forceinline__ float rng_normal(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
-  const float u1 = rng_uniform(seed, env, ep, step, stream, 2 * idx), u2 = rng_uniform(seed, env, ep, step, stream, 2 * idx + 1);
-  return sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);  // Box-Muller
-}
-enum { RS_ACTION = 1, RS_JOINT_POS, RS_JOINT_VEL, RS_GYRO, RS_IMU, RS_DELAY, RS_PUSH };
+
 
 // start of an episode: delays drawn (cpu_env.py:135-168), rings logically empty, push schedule cleared
 __device__ __forceinline__ void envrand_begin_episode(const DevModel& M, const EnvRand& R, const EnvRandState& S, int e, int env_global, int ep) {

@@ -154,6 +154,7 @@ def lib():
     L.hb_set_state_broadcast_f64.argtypes = [vp, cu, vp]
     L.hb_rollout_sensors.argtypes = [vp, vp, ci, ctypes.POINTER(HbSensorSpec), vp, vp]
     L.hb_rollout_trajectory.argtypes = [vp, vp, ci, vp, vp, vp]
+    L.hb_rollout_noise.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_uint]
     L.hb_task_stand_default.argtypes = [vp, ctypes.POINTER(HbTaskStand)]
     L.hb_rollout_task_stand.argtypes = [vp, vp, ci, ctypes.POINTER(HbTaskStand), vp, vp]
     L.hb_task_walk_default.argtypes = [vp, ctypes.POINTER(HbTaskWalk)]
@@ -495,6 +496,10 @@ class Batch:
         costs = np.zeros((H, self.n_env), dtype=np.float32) if want_costs else None
         _check(lib().hb_rollout_task_walk(self._h, _ptr(c) if H > 1 else None, H, ctypes.byref(task), _ptr(total), _ptr(costs)), "hb_rollout_task_walk")
         return total, costs
+
+    def rollout_noise(self, xfrc_std, xfrc_rate, seed=0):
+        """Ornstein-Uhlenbeck noise on xfrc_applied for the rollouts that follow (Trajectory::NoisyRollout); std 0: off."""
+        _check(lib().hb_rollout_noise(self._h, float(xfrc_std), float(xfrc_rate), int(seed)), "hb_rollout_noise")
 
     def rollout_trajectory(self, ctrl):
         """ctrl [T, n_env, nu] -> (qpos [T, n_env, nq], qvel [T, n_env, nv], failed [n_env]): the states after every step."""

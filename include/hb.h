@@ -188,6 +188,12 @@ int hb_set_state_broadcast_f64(hb_batch* b, unsigned spec, const double* state);
  * state BEFORE step t's integration (what mjData.sensordata holds after the t-th mj_step call).  Host pointers;
  * qpos_out nullable. */
 int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_spec* spec, float* sensor_out, float* qpos_out);
+/* Trajectory::NoisyRollout's perturbation (mujoco_mpc/mjpc/trajectory.cc:147-156): before every step of the calls that
+ * follow, every xfrc_applied entry of every env becomes rate * xfrc + scale * N(0, 1), rate = exp(-timestep / xfrc_rate),
+ * scale = xfrc_std * sqrt(1 - rate^2) (an Ornstein-Uhlenbeck process with stationary deviation xfrc_std); xfrc_std = 0
+ * switches it off (the xfrc_applied values stay as they are).  The draws are counter-based (seed, global env, call, step,
+ * entry): reproducible, unlike the reference's absl::BitGen, and independent across envs. */
+int hb_rollout_noise(hb_batch* b, float xfrc_std, float xfrc_rate, unsigned seed);
 /* Open-loop rollout that records the trajectory the way MJPC's Trajectory::Rollout does (mujoco_mpc/mjpc/trajectory.cc:
  * 141-190): states after every step, qpos_out[t][e][nq] and qvel_out[t][e][nv] (host pointers, each nullable; times are
  * t0 + (t + 1) * timestep and the actions are the caller's own tape), and failed[e] = 1 when the env raised a bad-state

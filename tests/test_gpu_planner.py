@@ -242,3 +242,42 @@ def test_walk_task_return_matches_mjpc_restatement(hbmod, humanoid_model, gpu):
     task.dim[4] = 20
     with pytest.raises(hbmod.HbError):
         b.rollout_task_walk(ctrl, task)
+
+
+def test_rollout_noise_is_an_ou_process_on_xfrc(hbmod, humanoid_model, gpu):
+    """hb_rollout_noise: xfrc_applied follows x <- rate x + scale N(0,1) (Trajectory::NoisyRollout, trajectory.cc:147-156):
+    stationary deviation xfrc_std, lag-one correlation exp(-timestep / xfrc_rate), independent across envs, reproducible,
+    and it actually pushes the robot."""
+    m = humanoid_model
+    N, nb = 256, 17
+    std, tau = 2.0, 0.05
+    rate = np.exp(-0.005 / tau)
+    b = hbmod.Batch(m, N, gpu)
+    b.reset(perturb=True)
+    b.rollout_noise(std, tau, seed=11)
+    zeros = np.zeros((1, N, m.nu), np.float32)
+    xs = []
+    for t in range(120):
+        b.rollout(zeros)
+        xs.append(b.get_state(hbmod.STATE_XFRC_APPLIED).reshape(N, nb, 6).copy())
+    xs = np.array(xs)[40:]  # past the transient from zero
+    assert abs(xs.std() - std) < 0.05 * std, xs.std()
+    assert abs(xs.mean()) < 0.05
+    lag = (xs[1:] * xs[:-1]).mean() / (xs * xs).mean()
+    assert abs(lag - rate) < 0.03, (lag, rate)
+    assert abs(np.corrcoef(xs[:, 0].ravel(), xs[:, 1].ravel())[0, 1]) < 0.15  # envs draw independently (all entries of two envs)
+    assert abs(np.corrcoef(xs[:, :, 3, 0].ravel(), xs[:, :, 3, 1].ravel())[0, 1]) < 0.05  # and so do entries
+    q_noisy = b.qpos.copy()
+    # same seed, same call sequence: the same noise
+    c = hbmod.Batch(m, N, gpu)
+    c.reset(perturb=True)
+    c.rollout_noise(std, tau, seed=11)
+    for t in range(120):
+        c.rollout(zeros)
+    assert np.array_equal(c.qpos, q_noisy)
+    # off: xfrc stays as it is, and the trajectory differs from the noisy one
+    d = hbmod.Batch(m, N, gpu)
+    d.reset(perturb=True)
+    for t in range(120):
+        d.rollout(zeros)
+    assert np.abs(d.qpos - q_noisy).max() > 1e-4

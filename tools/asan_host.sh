@@ -1,0 +1,27 @@
+#!/bin/bash
+# AddressSanitizer + UBSan pass over the host-side model compiler (CPU only; GPU sanitizers are not available on this pool):
+# every test MJCF and the compiled benchmark model through compile -> save -> load -> save, plus malformed inputs.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${TMPDIR:-/tmp}/hb_asan
+mkdir -p $OUT
+g++ -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -o $OUT/hb_compile $ROOT/tools/hb_compile.cpp \
+    $ROOT/humanoid_mujoco_amd/csrc/mjcf.cpp $ROOT/humanoid_mujoco_amd/csrc/setconst.cpp $ROOT/humanoid_mujoco_amd/csrc/model_io.cpp 2>/dev/null
+fail=0
+for f in $ROOT/tests/models/*.xml $ROOT/humanoid_mujoco_amd/assets/*.hbm; do
+  $OUT/hb_compile $f $OUT/a.hbm > $OUT/log.txt 2>&1 || { echo "FAIL $f"; cat $OUT/log.txt; fail=1; }
+  $OUT/hb_compile $OUT/a.hbm $OUT/b.hbm >> $OUT/log.txt 2>&1 || { echo "FAIL reload $f"; fail=1; }
+  cmp -s $OUT/a.hbm $OUT/b.hbm || { echo "round trip differs: $f"; fail=1; }
+  grep -q "AddressSanitizer\|runtime error" $OUT/log.txt && { echo "sanitizer report: $f"; cat $OUT/log.txt; fail=1; }
+done
+printf '<mujoco><worldbody><body><joint type="ball"/><geom size="1"/></body></worldbody></mujoco>' > $OUT/bad1.xml
+printf '<mujoco><worldbody><body><geom type="box" size="1 1 1"/></body></worldbody>' > $OUT/bad2.xml
+printf '<mujoco><worldbody><body childclass="zzz"><joint/><geom size="0.1"/></body></worldbody></mujoco>' > $OUT/bad3.xml
+printf '<mujoco><worldbody><body><joint/><geom size="0.1"' > $OUT/bad4.xml
+head -c 300 $ROOT/humanoid_mujoco_amd/assets/humanoid27.hbm > $OUT/bad5.hbm
+for f in $OUT/bad1.xml $OUT/bad2.xml $OUT/bad3.xml $OUT/bad4.xml $OUT/bad5.hbm; do
+  if $OUT/hb_compile $f $OUT/c.hbm > $OUT/log.txt 2>&1; then echo "accepted a malformed input: $f"; fail=1; fi
+  grep -q "AddressSanitizer\|runtime error" $OUT/log.txt && { echo "sanitizer report: $f"; cat $OUT/log.txt; fail=1; }
+done
+[ $fail = 0 ] && echo "asan/ubsan host pass: clean"
+exit $fail

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+ORACLE_SO = os.environ.get("HB_ORACLE_SO") or os.path.join(ORACLE_DIR, "liboracle.so")  # HB_ORACLE_SO: e.g. a sanitizer build (tools/asan_host.sh)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 HUMANOID_HBM = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm")
 
@@ -19,6 +19,8 @@ _lib = None
 
 def build_oracle(force=False):
     src = os.path.join(ORACLE_DIR, "mjstep_oracle.c")
+    if os.environ.get("HB_ORACLE_SO"):
+        return ORACLE_SO
     if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return ORACLE_SO

@@ -23,5 +23,10 @@ for f in $OUT/bad1.xml $OUT/bad2.xml $OUT/bad3.xml $OUT/bad4.xml $OUT/bad5.hbm; 
   if $OUT/hb_compile $f $OUT/c.hbm > $OUT/log.txt 2>&1; then echo "accepted a malformed input: $f"; fail=1; fi
   grep -q "AddressSanitizer\|runtime error" $OUT/log.txt && { echo "sanitizer report: $f"; cat $OUT/log.txt; fail=1; }
 done
-[ $fail = 0 ] && echo "asan/ubsan host pass: clean"
+# the fp64 oracle under the same sanitizers, driven by its own tests
+gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -shared -fPIC -o $OUT/liboracle_asan.so $ROOT/oracle/mjstep_oracle.c -lm -lpthread
+( cd $ROOT && ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) HB_ORACLE_SO=$OUT/liboracle_asan.so \
+    python -m pytest tests/test_oracle_kat.py tests/test_oracle_newton.py -x -q > $OUT/oracle.txt 2>&1 ) || { echo "oracle under sanitizers: FAIL"; tail -20 $OUT/oracle.txt; fail=1; }
+grep -q "AddressSanitizer\|runtime error" $OUT/oracle.txt && { echo "sanitizer report in the oracle run"; fail=1; }
+[ $fail = 0 ] && echo "asan/ubsan host pass: clean (model compiler, oracle)"
 exit $fail

@@ -578,6 +578,13 @@ class Batch:
                                  ctypes.c_void_p(pin["te"].ptr), ctypes.c_void_p(pin["tr"].ptr)), "hb_env_step")
         return pin["o"].array.copy(), pin["r"].array.copy(), pin["te"].array.astype(bool), pin["tr"].array.astype(bool)
 
+    def env_step_dev(self, action_ptr, obs_ptr, reward_ptr, terminated_ptr, truncated_ptr, n_substeps=1):
+        """hb_env_step_dev: device pointers (e.g. torch tensors' data_ptr()), asynchronous on the batch's stream: a policy on
+        the same GPU never sees the host.  Work the caller enqueued on other streams must be finished (or ordered before
+        this call through hb_batch_stream); call sync() before reading the outputs from another stream."""
+        _check(lib().hb_env_step_dev(self._h, ctypes.c_void_p(action_ptr), int(n_substeps), ctypes.c_void_p(obs_ptr), ctypes.c_void_p(reward_ptr),
+                                     ctypes.c_void_p(terminated_ptr), ctypes.c_void_p(truncated_ptr)), "hb_env_step_dev")
+
     # ---- policy in the loop (BASELINE config 4)
     def set_policy_mlp(self, weights, biases):
         """weights[l]: [in, out] float32 (transpose of torch.nn.Linear.weight); tanh after every layer."""

@@ -74,5 +74,25 @@ class VecEnv:
         infos = {"is_success": trunc.copy(), "done": done}  # cpu_env.py:688-689
         return obs, rew, term, trunc, infos
 
+    def step_torch(self, actions):
+        """The same step with the policy on the GPU: `actions` is a float32 CUDA tensor [n_envs, nu]; returns CUDA tensors
+        (obs, reward, terminated, truncated) that are rewritten by the next call.  No host transfer and no host
+        synchronisation: the batch's stream waits for the caller's current torch stream, and the caller's stream for the step."""
+        import torch
+        a = actions.contiguous()
+        if getattr(self, "_t_out", None) is None:
+            dev = a.device
+            self._t_out = (torch.empty((self.num_envs, self.model.nobs), dtype=torch.float32, device=dev), torch.empty(self.num_envs, dtype=torch.float32, device=dev),
+                           torch.empty(self.num_envs, dtype=torch.uint8, device=dev), torch.empty(self.num_envs, dtype=torch.uint8, device=dev))
+            self._t_stream = torch.cuda.ExternalStream(self.batch.stream, device=dev)  # the batch's own HIP stream, seen by torch
+        assert a.dtype == torch.float32 and tuple(a.shape) == (self.num_envs, self.model.nu)
+        cur = torch.cuda.current_stream(a.device)
+        self._t_stream.wait_stream(cur)   # the policy's output is complete before the step reads it
+        o, r, te, tr = self._t_out
+        self.batch.env_step_dev(a.data_ptr(), o.data_ptr(), r.data_ptr(), te.data_ptr(), tr.data_ptr(), self.n_substeps)
+        cur.wait_stream(self._t_stream)   # and the caller's stream sees the results
+        a.record_stream(self._t_stream)
+        return o, r, te.bool(), tr.bool()
+
     def close(self):
         self.batch.close()

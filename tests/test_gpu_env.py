@@ -99,3 +99,23 @@ def test_success_truncation_and_randomization_factor(hbmod, humanoid_model, gpu)
         env.set_attr("nope", 1)
     with pytest.raises(AttributeError):
         hbmod.VecEnv(m, 2, gpu, not_a_parameter=1)
+
+
+def test_device_resident_step_matches_host_step(hbmod, humanoid_model, gpu):
+    """hb_env_step_dev through torch tensors (policy on the same GPU) == hb_env_step through host buffers."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    m = humanoid_model
+    n = 64
+    a = hbmod.VecEnv(m, n, gpu, seed=3)
+    b = hbmod.VecEnv(m, n, gpu, seed=3)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
+        o1, r1, te1, tr1, _ = a.step(act)
+        o2, r2, te2, tr2 = b.step_torch(torch.from_numpy(act).cuda())
+        assert np.array_equal(o1, o2.cpu().numpy()) and np.array_equal(r1, r2.cpu().numpy())
+        assert np.array_equal(te1, te2.cpu().numpy()) and np.array_equal(tr1, tr2.cpu().numpy())

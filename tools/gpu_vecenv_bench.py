@@ -5,6 +5,11 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+try:  # torch first: its device probe must run before this process opens the GPU through libhb
+    import torch
+    HAVE_TORCH = torch.cuda.is_available() and torch.zeros(1, device="cuda").is_cuda
+except ImportError:
+    HAVE_TORCH = False
 import humanoid_mujoco_amd as hb
 model = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm")
 N, T = 4096, 600
@@ -24,3 +29,24 @@ for label, kw in (("plain", {}), ("realism + domain randomisation", dict(realism
     print("VecEnv.step (%s): %d envs x %d steps in %.3f s -> %.3e env-steps/s (%.0f us/step, host round trip included); %d episodes ended"
           % (label, N, T, dt, N * T / dt, 1e6 * dt / T, done))
     env.close()
+
+# the same loop with the policy on the GPU (torch): actions, observations, rewards and flags never leave the device
+if True:
+    if not HAVE_TORCH:
+        print("torch sees no GPU: device-resident loop skipped")
+    else:
+        for label, kw in (("plain", {}), ("realism + domain randomisation", dict(realism=True, domain_randomization=True, seed=1))):
+            env = hb.VecEnv(model, N, 0, randomization_factor=1.0, target_z=10.0, max_time=2.0, **kw)
+            env.reset()
+            w = torch.randn(48, 21, device="cuda") * 0.1
+            obs = torch.zeros(N, 48, device="cuda")
+            for t in range(20):
+                obs, rew, term, trunc = env.step_torch(torch.tanh(obs @ w))
+            t0 = time.perf_counter()
+            for t in range(T):
+                obs, rew, term, trunc = env.step_torch(torch.tanh(obs @ w))  # a linear policy stands in for the network
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print("VecEnv.step_torch (%s): %d envs x %d steps in %.3f s -> %.3e env-steps/s (%.0f us/step; policy, env and physics on the GPU, no host transfer)"
+                  % (label, N, T, dt, N * T / dt, 1e6 * dt / T))
+            env.close()

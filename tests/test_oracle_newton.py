@@ -84,3 +84,31 @@ def test_pgs_50_is_not_the_converged_solution_but_newton_is_iteration_independen
     _, qp, _, _ = run(SOL_PGS, 50, 150, 3)
     assert np.abs(qa[:40] - qp[:40]).max() < 5e-3  # close early on ...
     assert np.abs(qa - qp).max() > 1e-4            # ... but not the same trajectory
+
+
+def test_newton_agrees_with_converged_pgs_on_other_models(tmp_path):
+    """Same cross-check on the small test models: condim-1 pairs, multi-tree contact, slide joints, joint limits."""
+    import os
+    import humanoid_mujoco_amd as hb
+    models = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+    for name, steps in (("ball_plane", 300), ("capsules", 300), ("chain", 200)):
+        p = str(tmp_path / (name + ".hbm"))
+        hb.Model.load(os.path.join(models, name + ".xml")).save(p)
+        on, op = Oracle(p), Oracle(p)
+        on.set_opt(solver=SOL_NEWTON, iterations=100)
+        op.set_opt(solver=SOL_PGS, iterations=50000, tolerance=1e-15)
+        on.reset(0 if name == "chain" else -1)
+        rng = np.random.default_rng(5)
+        active, worst = 0, 0.0
+        for t in range(steps):
+            c = rng.uniform(-1, 1, size=max(on.nu, 1))[:on.nu]
+            op.qpos[:] = on.qpos; op.qvel[:] = on.qvel; op.qacc_warmstart[:] = on.qacc_warmstart
+            on.ctrl[:] = c; op.ctrl[:] = c
+            on.forward(); op.forward()
+            assert on.nefc == op.nefc
+            if on.nefc:
+                active += 1
+                worst = max(worst, np.abs(on.qacc - op.qacc).max() / max(1.0, np.abs(op.qacc).max()))
+            on.step()
+        assert active > 20, (name, active)
+        assert worst < 1e-5, (name, worst)

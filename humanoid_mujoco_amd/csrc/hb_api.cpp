@@ -489,6 +489,9 @@ struct hb_batch {
   size_t qvel_out_cap = 0;
   float* d_task_out = nullptr;  // task returns and stage costs
   float xfrc_std = 0.f, xfrc_rate = 0.f;  // rollout noise (hb_rollout_noise)
+  int tape_steps = 0;                      // steps of the action tape hb_ctrl_tape_splines left in d_ctrl (0: none)
+  float* d_knots = nullptr;               // spline nodes and node times staged for it
+  size_t knots_cap = 0;
   unsigned xfrc_seed = 0, xfrc_calls = 0;
   size_t task_out_cap = 0;
   float* d_sensor_out = nullptr;
@@ -866,7 +869,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
   void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
-                  b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
+                  b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
 }
@@ -988,6 +991,24 @@ static int ensure_trace(float** buf, size_t* cap, size_t need) {
   *buf = nullptr; *cap = 0;
   if (hipMalloc((void**)buf, need * sizeof(float)) != hipSuccess) return HB_ENOMEM;
   *cap = need;
+  return HB_OK;
+}
+
+int hb_ctrl_tape_splines(hb_batch* b, const float* knots, const float* times, int n_points, int interpolation, double time0, int T) {
+  if (!b || !knots || !times || n_points < 1 || n_points > 64 || interpolation < 0 || interpolation > 2 || T < 1 || b->D.dm.nu < 1) return HB_EINVAL;
+  if (interpolation == 2 && n_points < 2) return HB_EINVAL;
+  for (int k = 1; k < n_points; k++) if (!(times[k] > times[k - 1])) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  const int N = b->n_env, nu = b->D.dm.nu;
+  const size_t nk = (size_t)N * n_points * nu;
+  int rc = ensure_trace(&b->d_knots, &b->knots_cap, nk + 64);
+  if (rc != HB_OK) return rc;
+  rc = ensure_ctrl(b, (size_t)T * N * nu);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipMemcpyAsync(b->d_knots, knots, nk * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  HB_HIP(hipMemcpyAsync(b->d_knots + nk, times, (size_t)n_points * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  HB_HIP(launch_spline_tape(b->D.dm, b->d_knots, b->d_knots + nk, n_points, interpolation, (float)time0, (float)b->model->m.timestep, T, N, b->d_ctrl, main_stream(b)));
+  b->tape_steps = T;
   return HB_OK;
 }
 
@@ -1209,10 +1230,16 @@ static int rollout_rows(hb_batch* b, const float* ctrl, int H, const hb_sensor_s
   const DevModel& dm = b->D.dm;
   const int N = b->n_env, nu = dm.nu;
   const size_t n = (size_t)(H - 1) * N * nu;
-  int rc = ensure_ctrl(b, std::max<size_t>(std::max<size_t>(n, (size_t)N * nu), 1));
-  if (rc != HB_OK) return rc;
-  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
-  else if (nu) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, (size_t)N * nu * sizeof(float), main_stream(b)));
+  int rc = HB_OK;
+  if (ctrl == HB_CTRL_TAPE) {
+    if (H < 2 || b->tape_steps < H - 1) return HB_EINVAL;  // the tape hb_ctrl_tape_splines left is shorter than this rollout
+  } else {
+    rc = ensure_ctrl(b, std::max<size_t>(std::max<size_t>(n, (size_t)N * nu), 1));
+    if (rc != HB_OK) return rc;
+    b->tape_steps = 0;
+    if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+    else if (nu) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, (size_t)N * nu * sizeof(float), main_stream(b)));
+  }
   // failure is a property of THIS rollout (CheckWarnings looks at the warnings of the rollout's own mjData)
   HB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)N * sizeof(int), main_stream(b)));
   BatchPtrs P = make_ptrs(b);

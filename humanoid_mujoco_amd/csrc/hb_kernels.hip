@@ -2267,6 +2267,48 @@ __global__ void hb_walk_cost_kernel(const float* rows, int H, int n_env, const W
   total[e] = failed ? 1.0e6f : sum / (float)max(H, 1);
 }
 
+// ---- SamplingPolicy::Action on the device (mujoco_mpc/mjpc/planners/sampling/policy.cc:50-58): every candidate's
+// time spline (mjpc/spline/spline.cc:103-156,240-277: zero-order / linear / cubic Hermite with finite-difference slopes)
+// sampled at time0 + t * dt and clamped to ctrlrange, written as the action tape [T][n_env][nu] the rollouts read.
+// knots: [n_env][P][nu]; times: [P], increasing, shared by the candidates.
+__global__ void hb_spline_tape_kernel(const DevModel M, const float* knots, const float* times, int P, int interp, float time0, float dt, int T, int n_env, float* tape) {
+  const int nu = M.nu;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)T * n_env * nu;
+  if (idx >= total) return;
+  const int i = (int)(idx % nu), e = (int)((idx / nu) % n_env), t = (int)(idx / ((size_t)nu * n_env));
+  const float time = time0 + (float)t * dt;
+  const float* y = knots + (size_t)e * P * nu + i;  // y[k * nu]: node k
+  float v;
+  int up = 0;
+  while (up < P && times[up] <= time) up++;  // std::upper_bound
+  if (P == 0) v = 0.f;
+  else if (up == P) v = y[(size_t)(P - 1) * nu];
+  else if (up == 0) v = y[0];
+  else {
+    const int lo = up - 1;
+    const float t0 = times[lo], t1 = times[up], x = (time - t0) / (t1 - t0);
+    const float p0 = y[(size_t)lo * nu], p1 = y[(size_t)up * nu];
+    if (interp == 0) v = p0;
+    else if (interp == 1) v = p0 * (1.f - x) + p1 * x;
+    else {
+      // TimeSpline::Slope: one-sided at the ends, mean of the two one-sided differences inside
+      auto slope = [&](int k) {
+        if (k == 0) return (y[(size_t)1 * nu] - y[0]) / (times[1] - times[0]);
+        const float back = (y[(size_t)k * nu] - y[(size_t)(k - 1) * nu]) / (times[k] - times[k - 1]);
+        if (k == P - 1) return back;
+        return 0.5f * (y[(size_t)(k + 1) * nu] - y[(size_t)k * nu]) / (times[k + 1] - times[k]) + 0.5f * back;
+      };
+      const float h = t1 - t0, x2 = x * x, x3 = x2 * x;
+      v = (2.f * x3 - 3.f * x2 + 1.f) * p0 + (x3 - 2.f * x2 + x) * h * slope(lo) + (-2.f * x3 + 3.f * x2) * p1 + (x3 - x2) * h * slope(up);
+    }
+  }
+  // Clamp(action, actuator_ctrlrange, nu) (utilities.cc:94-98); an actuator without a control range is left alone
+  const float lo_r = M.act_ctrlrange[2 * i], hi_r = M.act_ctrlrange[2 * i + 1];
+  if (M.act_ctrllimited[i] || lo_r < hi_r) v = fminf(fmaxf(v, lo_r), hi_r);
+  tape[idx] = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // reset: qpos0/keyframe (+ Halton perturbation), zero velocity/warmstart/time/status
 // qpos <- reset pose (+ the Halton perturbation indexed by global env and, for the env adapter, episode), rest zero
@@ -2871,6 +2913,12 @@ hipError_t launch_stand_cost(const float* rows, int H, int n_env, const StandTas
 hipError_t launch_walk_cost(const float* rows, int H, int n_env, const WalkTask& K, const int* status, float* total, float* costs, hipStream_t stream) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(hb_walk_cost_kernel, dim3((n_env + 63) / 64), dim3(64), 0, stream, rows, H, n_env, K, status, total, costs);
+  return hipGetLastError();
+}
+hipError_t launch_spline_tape(const DevModel& M, const float* knots, const float* times, int P, int interp, float time0, float dt, int T, int n_env, float* tape, hipStream_t stream) {
+  (void)hipGetLastError();
+  const size_t total = (size_t)T * n_env * M.nu;
+  hipLaunchKernelGGL(hb_spline_tape_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, M, knots, times, P, interp, time0, dt, T, n_env, tape);
   return hipGetLastError();
 }
 hipError_t set_step_lds_limit(int bytes) {

@@ -155,6 +155,7 @@ def lib():
     L.hb_rollout_sensors.argtypes = [vp, vp, ci, ctypes.POINTER(HbSensorSpec), vp, vp]
     L.hb_rollout_trajectory.argtypes = [vp, vp, ci, vp, vp, vp]
     L.hb_rollout_noise.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_uint]
+    L.hb_ctrl_tape_splines.argtypes = [vp, vp, vp, ci, ci, ctypes.c_double, ci]
     L.hb_task_stand_default.argtypes = [vp, ctypes.POINTER(HbTaskStand)]
     L.hb_rollout_task_stand.argtypes = [vp, vp, ci, ctypes.POINTER(HbTaskStand), vp, vp]
     L.hb_task_walk_default.argtypes = [vp, ctypes.POINTER(HbTaskWalk)]
@@ -467,6 +468,23 @@ class Batch:
         _check(lib().hb_rollout_sensors(self._h, _ptr(c), T, ctypes.byref(spec), _ptr(out), _ptr(q)), "hb_rollout_sensors")
         return out, q
 
+    def ctrl_tape_splines(self, knots, times, interpolation, time0, T):
+        """knots [n_env, P, nu], times [P] -> the action tape of T steps on the device (SamplingPolicy::Action per candidate);
+        pass ("tape", T) as `ctrl` to rollout_task_stand / rollout_task_walk."""
+        k = np.ascontiguousarray(knots, dtype=np.float32)
+        tm = np.ascontiguousarray(times, dtype=np.float32)
+        assert k.shape == (self.n_env, len(tm), self.model.nu), k.shape
+        _check(lib().hb_ctrl_tape_splines(self._h, _ptr(k), _ptr(tm), len(tm), int(interpolation), float(time0), int(T)), "hb_ctrl_tape_splines")
+
+    def _tape_or_ctrl(self, ctrl):
+        if isinstance(ctrl, tuple) and ctrl[0] == "tape":
+            return int(ctrl[1]) + 1, ctypes.c_void_p(1)  # HB_CTRL_TAPE
+        c = np.ascontiguousarray(ctrl, dtype=np.float32)
+        H = c.shape[0] + 1
+        assert c.shape == (H - 1, self.n_env, self.model.nu), c.shape
+        self._keep = c
+        return H, (_ptr(c) if H > 1 else None)
+
     def task_stand_default(self):
         t = HbTaskStand()
         _check(lib().hb_task_stand_default(self.model._h, ctypes.byref(t)), "hb_task_stand_default")
@@ -474,12 +492,10 @@ class Batch:
 
     def rollout_task_stand(self, ctrl, task, want_costs=False):
         """ctrl [horizon - 1, n_env, nu] -> (total_return [n_env], stage costs [horizon, n_env] or None) of MJPC's Humanoid Stand task."""
-        c = np.ascontiguousarray(ctrl, dtype=np.float32)
-        H = c.shape[0] + 1
-        assert c.shape == (H - 1, self.n_env, self.model.nu), c.shape
+        H, cp = self._tape_or_ctrl(ctrl)
         total = np.zeros(self.n_env, dtype=np.float32)
         costs = np.zeros((H, self.n_env), dtype=np.float32) if want_costs else None
-        _check(lib().hb_rollout_task_stand(self._h, _ptr(c) if H > 1 else None, H, ctypes.byref(task), _ptr(total), _ptr(costs)), "hb_rollout_task_stand")
+        _check(lib().hb_rollout_task_stand(self._h, cp, H, ctypes.byref(task), _ptr(total), _ptr(costs)), "hb_rollout_task_stand")
         return total, costs
 
     def task_walk_default(self):
@@ -489,12 +505,10 @@ class Batch:
 
     def rollout_task_walk(self, ctrl, task, want_costs=False):
         """ctrl [horizon - 1, n_env, nu] -> (total_return [n_env], stage costs [horizon, n_env] or None) of MJPC's Humanoid Walk task."""
-        c = np.ascontiguousarray(ctrl, dtype=np.float32)
-        H = c.shape[0] + 1
-        assert c.shape == (H - 1, self.n_env, self.model.nu), c.shape
+        H, cp = self._tape_or_ctrl(ctrl)
         total = np.zeros(self.n_env, dtype=np.float32)
         costs = np.zeros((H, self.n_env), dtype=np.float32) if want_costs else None
-        _check(lib().hb_rollout_task_walk(self._h, _ptr(c) if H > 1 else None, H, ctypes.byref(task), _ptr(total), _ptr(costs)), "hb_rollout_task_walk")
+        _check(lib().hb_rollout_task_walk(self._h, cp, H, ctypes.byref(task), _ptr(total), _ptr(costs)), "hb_rollout_task_walk")
         return total, costs
 
     def rollout_noise(self, xfrc_std, xfrc_rate, seed=0):

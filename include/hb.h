@@ -188,6 +188,15 @@ int hb_set_state_broadcast_f64(hb_batch* b, unsigned spec, const double* state);
  * state BEFORE step t's integration (what mjData.sensordata holds after the t-th mj_step call).  Host pointers;
  * qpos_out nullable. */
 int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_spec* spec, float* sensor_out, float* qpos_out);
+/* SamplingPolicy::Action for every candidate on the device (mujoco_mpc/mjpc/planners/sampling/policy.cc:50-58 over
+ * mjpc/spline/spline.cc:103-156,240-277): knots[e][k][nu] are the spline nodes of candidate e (host, [n_env][n_points][nu]),
+ * times[n_points] the node times shared by the candidates, interpolation 0 = zero-order, 1 = linear, 2 = cubic Hermite
+ * with finite-difference slopes.  The splines are sampled at time0 + t * timestep for t = 0..T-1, clamped to ctrlrange
+ * and left on the device as the action tape of the rollouts that follow: pass HB_CTRL_TAPE as their `ctrl` (the
+ * hb_rollout_task_* functions accept it; horizon - 1 <= T).  n_points * nu floats per candidate cross PCIe instead of
+ * T * nu. */
+#define HB_CTRL_TAPE ((const float*)(uintptr_t)1)
+int hb_ctrl_tape_splines(hb_batch* b, const float* knots, const float* times, int n_points, int interpolation, double time0, int T);
 /* Trajectory::NoisyRollout's perturbation (mujoco_mpc/mjpc/trajectory.cc:147-156): before every step of the calls that
  * follow, every xfrc_applied entry of every env becomes rate * xfrc + scale * N(0, 1), rate = exp(-timestep / xfrc_rate),
  * scale = xfrc_std * sqrt(1 - rate^2) (an Ornstein-Uhlenbeck process with stationary deviation xfrc_std); xfrc_std = 0

@@ -157,3 +157,34 @@ def walk_rollout(o, ctrl, task, nb, parent):
     o.forward()
     costs.append(terms_cost(walk_residual(o, task, nb, parent), task))
     return float(np.mean(costs)), np.array(costs)
+
+
+def spline_sample(times, values, interp, t):
+    """TimeSpline::Sample (mujoco_mpc/mjpc/spline/spline.cc:103-156) with Slope / CubicCoefficients (:240-277);
+    values [P, dim]; interp 0 zero-order, 1 linear, 2 cubic."""
+    times = np.asarray(times, dtype=np.float64)
+    values = np.asarray(values, dtype=np.float64)
+    P = len(times)
+    up = int(np.searchsorted(times, t, side="right"))  # std::upper_bound
+    if up == P:
+        return values[P - 1].copy()
+    if up == 0:
+        return values[0].copy()
+    lo = up - 1
+    x = (t - times[lo]) / (times[up] - times[lo])
+    if interp == 0:
+        return values[lo].copy()
+    if interp == 1:
+        return values[lo] * (1 - x) + values[up] * x
+
+    def slope(k):
+        if k == 0:
+            return (values[1] - values[0]) / (times[1] - times[0])
+        back = (values[k] - values[k - 1]) / (times[k] - times[k - 1])
+        if k == P - 1:
+            return back
+        return 0.5 * (values[k + 1] - values[k]) / (times[k + 1] - times[k]) + 0.5 * back
+
+    h = times[up] - times[lo]
+    c = (2 * x ** 3 - 3 * x ** 2 + 1, (x ** 3 - 2 * x ** 2 + x) * h, -2 * x ** 3 + 3 * x ** 2, (x ** 3 - x ** 2) * h)
+    return c[0] * values[lo] + c[1] * slope(lo) + c[2] * values[up] + c[3] * slope(up)

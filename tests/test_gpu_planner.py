@@ -281,3 +281,40 @@ def test_rollout_noise_is_an_ou_process_on_xfrc(hbmod, humanoid_model, gpu):
     for t in range(120):
         d.rollout(zeros)
     assert np.abs(d.qpos - q_noisy).max() > 1e-4
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_spline_policies_on_the_device(hbmod, humanoid_model, gpu, interp):
+    """hb_ctrl_tape_splines: every candidate's time spline sampled and clamped on the device equals the host evaluation of
+    TimeSpline::Sample (tests/mjpc_ref.py) fed through the ordinary host tape: same returns."""
+    from mjpc_ref import spline_sample
+    m = humanoid_model
+    N, H, P = 16, 24, 4
+    o = Oracle()
+    o.init_env(1)
+    for t in range(40):
+        o.ctrl[:] = o.ctrl_env(t, 1)
+        o.step()
+    st = np.concatenate([[0.0], o.qpos, o.qvel, o.qacc_warmstart])
+    rng = np.random.default_rng(8 + interp)
+    knots = rng.uniform(-1.4, 1.4, size=(N, P, m.nu)).astype(np.float32)  # beyond ctrlrange: the clamp matters
+    time0 = 0.37
+    times = (time0 + np.array([-0.01, 0.03, 0.07, 0.09])).astype(np.float32)  # first node in the past, last before the horizon's end
+    h = 0.005
+    tape = np.zeros((H - 1, N, m.nu), np.float32)
+    lo, hi = m.array("actuator_ctrlrange").reshape(-1, 2).T
+    for e in range(N):
+        for t in range(H - 1):
+            tape[t, e] = np.clip(spline_sample(times.astype(np.float64), knots[e].astype(np.float64), interp, float(np.float32(time0) + np.float32(t) * np.float32(h))), lo, hi)
+    b = hbmod.Batch(m, N, gpu)
+    task = b.task_stand_default()
+    b.set_state_broadcast(hbmod.STATE_INTEGRATION, st)
+    ref_total, ref_costs = b.rollout_task_stand(tape, task, want_costs=True)
+    b.set_state_broadcast(hbmod.STATE_INTEGRATION, st)
+    b.ctrl_tape_splines(knots, times, interp, time0, H - 1)
+    total, costs = b.rollout_task_stand(("tape", H - 1), task, want_costs=True)
+    assert np.allclose(costs[:4], ref_costs[:4], rtol=1e-4, atol=1e-4)
+    assert np.allclose(total, ref_total, rtol=5e-3, atol=5e-3)
+    # a tape shorter than the rollout is refused
+    with pytest.raises(hbmod.HbError):
+        b.rollout_task_stand(("tape", H + 3), task)

@@ -30,6 +30,19 @@ for solver, name in ((0, "PGS/50"), (2, "Newton/100")):
             b.set_state_broadcast(hb.STATE_INTEGRATION, st)
             total, _ = b.rollout_task_stand(ctrl, task)
         dt = (time.perf_counter() - t0) / reps
+        # the same iteration with the candidates' spline policies evaluated on the device (3 nodes, cubic: task.xml)
+        knots = rng.uniform(-0.5, 0.5, size=(N, 3, m.nu)).astype(np.float32)
+        times = np.array([0.0, 0.175, 0.35], np.float32)
+        b.set_state_broadcast(hb.STATE_INTEGRATION, st)
+        b.ctrl_tape_splines(knots, times, 2, 0.0, H - 1)
+        b.rollout_task_stand(("tape", H - 1), task)
+        t2 = time.perf_counter()
+        for _ in range(reps):
+            b.set_state_broadcast(hb.STATE_INTEGRATION, st)
+            b.ctrl_tape_splines(knots, times, 2, 0.0, H - 1)
+            stotal, _ = b.rollout_task_stand(("tape", H - 1), task)
+        dts = (time.perf_counter() - t2) / reps
+        print("%-10s %6d candidates x %d states, spline policies sampled on the device: %.2f ms per planner iteration" % (name, N, H, 1e3 * dts), flush=True)
         wt = b.task_walk_default()
         b.set_state_broadcast(hb.STATE_INTEGRATION, st)
         b.rollout_task_walk(ctrl, wt)

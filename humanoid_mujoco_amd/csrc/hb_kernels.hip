@@ -1889,6 +1889,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             float q1 = 0.f;
             const int last = nefc - 1;
             for (int i0 = 0; i0 < nefc; i0 += 8) {
+              if (!((actmask >> i0) & 0xffull)) continue;  // eight inactive rows: zero force
               float c[8];
 #pragma unroll
               for (int u = 0; u < 8; u++) c[u] = s_C[min(i0 + u, last) * cs + li];
@@ -1921,6 +1922,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             const int half = lane >> 5;
             f32x16 X = load_sym(s_Md, kCs, lane);
             for (int kk = 0; 2 * kk < nefc; kk++) {
+              if (!((actmask >> (2 * kk)) & 3ull)) continue;  // both rows inactive: nothing to add
               const int row = 2 * kk + half;
               const bool v = row < nefc;
               const float a = v ? s_C[row * cs + li] : 0.f;

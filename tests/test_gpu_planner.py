@@ -173,6 +173,12 @@ def test_stand_task_return_matches_mjpc_restatement(hbmod, humanoid_model, gpu):
     # the first stage is the same state for every candidate: only the control term differs
     ctrl_term = np.array([task.weight[4] * (0.3 ** 2) * (np.cosh(ctrl[0, e].astype(np.float64) / 0.3) - 1).sum() for e in range(N)])
     assert np.allclose(costs[0] - ctrl_term, (costs[0] - ctrl_term)[0], rtol=1e-4, atol=1e-3)
+    # pipelined stepping (env segments on their own streams) changes nothing
+    bp = hbmod.Batch(m, N, gpu)
+    bp.pipeline(True)
+    bp.set_state_broadcast(hbmod.STATE_INTEGRATION, st)
+    tp, cp = bp.rollout_task_stand(ctrl, task, want_costs=True)
+    assert np.array_equal(tp, total) and np.array_equal(cp, costs)
     # horizon 1: one mj_forward with a zero action
     t1, c1 = b.rollout_task_stand(np.zeros((0, N, m.nu), np.float32), task, want_costs=True)
     assert c1.shape == (1, N) and np.allclose(t1, c1[0])

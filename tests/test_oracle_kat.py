@@ -370,3 +370,22 @@ def test_heightfield_contact_model(compiled):
     o.step(400)
     assert o.qpos[0] > x0 + 0.2  # rolled downhill
     assert np.isfinite(o.qpos).all()
+
+
+def test_benchmark_workload_amplifies_rounding_level_perturbations():
+    """Why free-running fp32-vs-fp64 drift cannot stay below 1e-4 for 1000 steps on this workload (parity): in
+    fp64, an initial joint-angle perturbation of 1e-7 - one fp32 rounding - is amplified beyond 1e-4 well before step 1000,
+    with contacts and even without them.  (A property of the dynamics, asserted here so that the claim is checked.)"""
+    for flags, horizon, floor in ((0, 500, 1e-3), (CONTACT, 1000, 1e-4)):
+        worst = 0.0
+        for e in range(3):
+            a, b = Oracle(), Oracle()
+            a.set_opt(disableflags=flags); b.set_opt(disableflags=flags)
+            a.init_env(e); b.init_env(e)
+            b.qpos[7:] += 1e-7
+            for t in range(horizon):
+                c = a.ctrl_env(t, e)
+                a.ctrl[:] = c; b.ctrl[:] = c
+                a.step(); b.step()
+            worst = max(worst, float((np.abs(a.qpos - b.qpos) / np.maximum(1, np.abs(a.qpos))).max()))
+        assert worst > floor, (flags, worst)

@@ -994,6 +994,119 @@ static int ensure_trace(float** buf, size_t* cap, size_t need) {
   return HB_OK;
 }
 
+// ---- mjd_transitionFD over a batch ------------------------------------------------------------------------------
+namespace {
+// mj_integratePos (mujoco.h:466) with dt = 1 on one state: qpos <- qpos (+) dq, dq in R^nv
+void integrate_pos(const Model& m, double* qpos, const double* dq) {
+  for (int j = 0; j < m.njnt; j++) {
+    const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    if (m.jnt_type[j] == JNT_FREE) {
+      for (int i = 0; i < 3; i++) qpos[qa + i] += dq[da + i];
+      double v[3] = {dq[da + 3], dq[da + 4], dq[da + 5]};
+      const double ang = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (ang > 1e-15) {
+        const double s = std::sin(0.5 * ang) / ang, c = std::cos(0.5 * ang);
+        const double r[4] = {c, v[0] * s, v[1] * s, v[2] * s};
+        double* q = qpos + qa + 3;
+        const double o[4] = {q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3], q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2],
+                             q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1], q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0]};
+        const double n = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+        for (int i = 0; i < 4; i++) q[i] = o[i] / n;
+      }
+    } else qpos[qa] += dq[da];
+  }
+}
+// mj_differentiatePos (mujoco.h:463) with dt = 1: dq = q2 (-) q1 in R^nv
+void differentiate_pos(const Model& m, double* dq, const double* q1, const double* q2) {
+  for (int j = 0; j < m.njnt; j++) {
+    const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    if (m.jnt_type[j] == JNT_FREE) {
+      for (int i = 0; i < 3; i++) dq[da + i] = q2[qa + i] - q1[qa + i];
+      // rotation taking q1 to q2, in q1's frame: conj(q1) * q2, as a rotation vector (mju_subQuat)
+      const double* a = q1 + qa + 3;
+      const double* c = q2 + qa + 3;
+      double d[4] = {a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3], a[0] * c[1] - a[1] * c[0] - a[2] * c[3] + a[3] * c[2],
+                     a[0] * c[2] + a[1] * c[3] - a[2] * c[0] - a[3] * c[1], a[0] * c[3] - a[1] * c[2] + a[2] * c[1] - a[3] * c[0]};
+      const double sn = std::sqrt(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+      double ang = 2 * std::atan2(sn, d[0]);
+      if (ang > M_PI) ang -= 2 * M_PI;
+      const double k = sn > 1e-15 ? ang / sn : 0.0;
+      for (int i = 0; i < 3; i++) dq[da + 3 + i] = d[1 + i] * k;
+    } else dq[da] = q2[qa] - q1[qa];
+  }
+}
+}  // namespace
+
+int hb_transition_fd(hb_batch* b, const double* x, const double* u, const double* warm, int T, double eps, int centered, double* A, double* B) {
+  if (!b || !x || T < 1 || !(eps > 0) || (!u && b->D.dm.nu > 0) || (!A && !B)) return HB_EINVAL;
+  const Model& m = b->model->m;
+  const int nq = m.nq, nv = m.nv, nu = m.nu, nx = 2 * nv, ncol = nx + nu, k = centered ? 2 : 1, per = 1 + k * ncol;
+  if ((long long)T * per > b->n_env) return HB_EINVAL;
+  const int N = b->n_env, rec = 1 + nq + 2 * nv;
+  std::vector<double> st((size_t)N * rec, 0.0), step_of((size_t)T * per, 0.0);
+  std::vector<float> ctrl((size_t)N * std::max(1, nu), 0.f);
+  // unused envs: a valid rest state (they step along and are ignored)
+  for (int e = T * per; e < N; e++) for (int i = 0; i < nq; i++) st[(size_t)e * rec + 1 + i] = m.qpos0[i];
+  std::vector<double> dq(nv);
+  for (int t = 0; t < T; t++) {
+    const double* xt = x + (size_t)t * (nq + nv);
+    for (int c = 0; c < per; c++) {
+      const int e = t * per + c;
+      double* s = st.data() + (size_t)e * rec;
+      for (int i = 0; i < nq; i++) s[1 + i] = xt[i];
+      for (int i = 0; i < nv; i++) s[1 + nq + i] = xt[nq + i];
+      if (warm) for (int i = 0; i < nv; i++) s[1 + nq + nv + i] = warm[(size_t)t * nv + i];
+      for (int i = 0; i < nu; i++) ctrl[(size_t)e * nu + i] = (float)u[(size_t)t * nu + i];
+      if (c == 0) continue;
+      const int col = (c - 1) % ncol;
+      const double sign = (c - 1) / ncol == 0 ? 1.0 : -1.0;  // second block: the minus side of a centered difference
+      double h = sign * eps;
+      if (col < nv) {  // position, in the tangent space
+        std::fill(dq.begin(), dq.end(), 0.0);
+        dq[col] = h;
+        integrate_pos(m, s + 1, dq.data());
+      } else if (col < nx) s[1 + nq + (col - nv)] += h;
+      else {
+        const int a = col - nx;
+        double v = u[(size_t)t * nu + a] + h;
+        if (m.actuator_ctrllimited[a]) v = std::min(std::max(v, m.actuator_ctrlrange[2 * a]), m.actuator_ctrlrange[2 * a + 1]);  // nudge inside the range
+        ctrl[(size_t)e * nu + a] = (float)v;
+        h = v - u[(size_t)t * nu + a];
+      }
+      step_of[e] = h;  // the step actually taken
+    }
+  }
+  int rc = hb_set_state_f64(b, HB_STATE_INTEGRATION, st.data());
+  if (rc != HB_OK) return rc;
+  rc = hb_step(b, ctrl.data(), 1);
+  if (rc != HB_OK) return rc;
+  rc = hb_get_state_f64(b, HB_STATE_INTEGRATION, st.data());
+  if (rc != HB_OK) return rc;
+  std::vector<double> dp(nx), dm(nx);
+  auto diff = [&](int e_ref, int e, double* out) {  // x'(e) (-) x'(e_ref) in tangent coordinates
+    const double* r = st.data() + (size_t)e_ref * rec;
+    const double* s = st.data() + (size_t)e * rec;
+    differentiate_pos(m, out, r + 1, s + 1);
+    for (int i = 0; i < nv; i++) out[nv + i] = s[1 + nq + i] - r[1 + nq + i];
+  };
+  for (int t = 0; t < T; t++) {
+    const int e0 = t * per;
+    for (int col = 0; col < ncol; col++) {
+      const int ep = e0 + 1 + col, em = centered ? e0 + 1 + ncol + col : e0;
+      const double hp = step_of[ep], hm = centered ? step_of[em] : 0.0;
+      std::vector<double> d(nx, 0.0);
+      if (hp - hm != 0.0) {
+        diff(e0, ep, dp.data());
+        if (centered) diff(e0, em, dm.data()); else std::fill(dm.begin(), dm.end(), 0.0);
+        for (int i = 0; i < nx; i++) d[i] = (dp[i] - dm[i]) / (hp - hm);
+      }
+      if (col < nx) { if (A) for (int i = 0; i < nx; i++) A[((size_t)t * nx + i) * nx + col] = d[i]; }
+      else if (B) for (int i = 0; i < nx; i++) B[((size_t)t * nx + i) * nu + (col - nx)] = d[i];
+    }
+  }
+  return HB_OK;
+}
+
 int hb_ctrl_tape_splines(hb_batch* b, const float* knots, const float* times, int n_points, int interpolation, double time0, int T) {
   if (!b || !knots || !times || n_points < 1 || n_points > 64 || interpolation < 0 || interpolation > 2 || T < 1 || b->D.dm.nu < 1) return HB_EINVAL;
   if (interpolation == 2 && n_points < 2) return HB_EINVAL;

@@ -156,6 +156,7 @@ def lib():
     L.hb_rollout_trajectory.argtypes = [vp, vp, ci, vp, vp, vp]
     L.hb_rollout_noise.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_uint]
     L.hb_ctrl_tape_splines.argtypes = [vp, vp, vp, ci, ci, ctypes.c_double, ci]
+    L.hb_transition_fd.argtypes = [vp, vp, vp, vp, ci, ctypes.c_double, ci, vp, vp]
     L.hb_task_stand_default.argtypes = [vp, ctypes.POINTER(HbTaskStand)]
     L.hb_rollout_task_stand.argtypes = [vp, vp, ci, ctypes.POINTER(HbTaskStand), vp, vp]
     L.hb_task_walk_default.argtypes = [vp, ctypes.POINTER(HbTaskWalk)]
@@ -467,6 +468,17 @@ class Batch:
         q = np.zeros((T, self.n_env, self.model.nq), dtype=np.float32) if want_qpos else None
         _check(lib().hb_rollout_sensors(self._h, _ptr(c), T, ctypes.byref(spec), _ptr(out), _ptr(q)), "hb_rollout_sensors")
         return out, q
+
+    def transition_fd(self, x, u, warmstart=None, eps=1e-3, centered=True):
+        """mjd_transitionFD for T points at once: x [T, nq + nv], u [T, nu] -> A [T, 2nv, 2nv], B [T, 2nv, nu] (float64)."""
+        xs = np.ascontiguousarray(x, dtype=np.float64)
+        us = np.ascontiguousarray(u, dtype=np.float64)
+        T, nv, nu = xs.shape[0], self.model.nv, self.model.nu
+        assert xs.shape == (T, self.model.nq + nv) and us.shape == (T, nu)
+        w = None if warmstart is None else np.ascontiguousarray(warmstart, dtype=np.float64)
+        A = np.zeros((T, 2 * nv, 2 * nv)); B = np.zeros((T, 2 * nv, nu))
+        _check(lib().hb_transition_fd(self._h, _ptr(xs), _ptr(us), _ptr(w), T, float(eps), int(bool(centered)), _ptr(A), _ptr(B)), "hb_transition_fd")
+        return A, B
 
     def ctrl_tape_splines(self, knots, times, interpolation, time0, T):
         """knots [n_env, P, nu], times [P] -> the action tape of T steps on the device (SamplingPolicy::Action per candidate);

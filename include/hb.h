@@ -208,6 +208,20 @@ int hb_rollout_noise(hb_batch* b, float xfrc_std, float xfrc_rate, unsigned seed
  * t0 + (t + 1) * timestep and the actions are the caller's own tape), and failed[e] = 1 when the env raised a bad-state
  * warning on the way (CheckWarnings, utilities.cc:787-799; nullable). */
 int hb_rollout_trajectory(hb_batch* b, const float* ctrl, int T, float* qpos_out, float* qvel_out, int* failed);
+/* ---- transition derivatives for the gradient-based planners ------------------------------------------------------
+ * mjd_transitionFD (mujoco.h:1242-1251) for T (state, control) points at once, the way ModelDerivatives::Compute fans it
+ * over its thread pool (mujoco_mpc/mjpc/planners/model_derivatives.cc:44-105): finite differences of the discrete
+ * dynamics x' = step(x, u) in tangent-space coordinates, x = (qpos, qvel), dx = (dqpos in R^nv, dqvel),
+ *     A[t] = d x'/d x   [2nv][2nv],     B[t] = d x'/d u   [2nv][nu]      (row-major doubles; either may be NULL).
+ * Every perturbed copy of every point is one env of the batch: T * (1 + k * (2nv + nu)) envs are needed, k = 2 when
+ * `centered`, else 1 (HB_EINVAL if the batch is smaller); all of them advance in ONE step launch.  x[t] = qpos[nq] |
+ * qvel[nv]; warmstart[t][nv] (nullable: zeros) is used by the nominal and by every perturbed copy, as mjd_transitionFD
+ * does.  Position perturbations and differences go through mj_integratePos / mj_differentiatePos (quaternion dofs in
+ * the tangent space); a control is nudged inside its ctrlrange.  The arithmetic is fp32 on the device: eps should be
+ * about 1e-3 (rounding in x' divided by eps is the noise floor), not the 1e-6 an fp64 caller would use.
+ * The batch's states are overwritten. */
+int hb_transition_fd(hb_batch* b, const double* x, const double* u, const double* warmstart, int T, double eps, int centered, double* A, double* B);
+
 /* ---- a planner iteration's cost evaluation on the device: MJPC's "Humanoid Stand" task ------------------------------
  * (mujoco_mpc/mjpc/tasks/humanoid/stand/{stand.cc:41-104, task.xml:14-36}; the two-foot variant of
  * tasks/humanoid_cap/stand is the same residual with n_feet = 2).  Residual, in order: Height (head z minus mean foot z

@@ -324,3 +324,91 @@ def test_spline_policies_on_the_device(hbmod, humanoid_model, gpu, interp):
     # a tape shorter than the rollout is refused
     with pytest.raises(hbmod.HbError):
         b.rollout_task_stand(("tape", H + 3), task)
+
+
+def _oracle_transition_fd(o, x, u, warm, eps, nq, nv, nu):
+    """mjd_transitionFD restated on the fp64 oracle: centered differences of one step in tangent coordinates."""
+    def step(q, v, uu):
+        o.reset()
+        o.qpos[:] = q; o.qvel[:] = v; o.qacc_warmstart[:] = warm; o.ctrl[:] = uu
+        o.step()
+        return o.qpos.copy(), o.qvel.copy()
+
+    def quat_mul(a, b):
+        return np.array([a[0]*b[0]-a[1]*b[1]-a[2]*b[2]-a[3]*b[3], a[0]*b[1]+a[1]*b[0]+a[2]*b[3]-a[3]*b[2],
+                         a[0]*b[2]-a[1]*b[3]+a[2]*b[0]+a[3]*b[1], a[0]*b[3]+a[1]*b[2]-a[2]*b[1]+a[3]*b[0]])
+
+    def integrate(q, dq):  # the humanoid: one free joint (dofs 0..5), hinges after it
+        q = q.copy()
+        q[:3] += dq[:3]
+        ang = np.linalg.norm(dq[3:6])
+        if ang > 0:
+            r = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * dq[3:6] / ang])
+            q[3:7] = quat_mul(q[3:7], r); q[3:7] /= np.linalg.norm(q[3:7])
+        q[7:] += dq[6:]
+        return q
+
+    def differentiate(q1, q2):
+        d = np.zeros(nv)
+        d[:3] = q2[:3] - q1[:3]
+        c = quat_mul(q1[3:7] * np.array([1, -1, -1, -1]), q2[3:7])
+        sn = np.linalg.norm(c[1:])
+        ang = 2 * np.arctan2(sn, c[0])
+        if ang > np.pi:
+            ang -= 2 * np.pi
+        d[3:6] = c[1:] * (ang / sn if sn > 1e-15 else 0.0)
+        d[6:] = q2[7:] - q1[7:]
+        return d
+
+    q0, v0 = x[:nq], x[nq:]
+    qn, vn = step(q0, v0, u)
+    A = np.zeros((2 * nv, 2 * nv)); B = np.zeros((2 * nv, nu))
+    for col in range(2 * nv + nu):
+        out = []
+        for sgn in (1.0, -1.0):
+            q, v, uu = q0, v0.copy(), u.copy()
+            if col < nv:
+                dq = np.zeros(nv); dq[col] = sgn * eps
+                q = integrate(q0, dq)
+            elif col < 2 * nv:
+                v[col - nv] += sgn * eps
+            else:
+                uu[col - 2 * nv] += sgn * eps
+            q2, v2 = step(q, v, uu)
+            out.append(np.concatenate([differentiate(qn, q2), v2 - vn]))
+        d = (out[0] - out[1]) / (2 * eps)
+        if col < 2 * nv:
+            A[:, col] = d
+        else:
+            B[:, col - 2 * nv] = d
+    return A, B
+
+
+def test_transition_derivatives_by_batched_finite_differences(hbmod, humanoid_model, gpu):
+    """hb_transition_fd (mjd_transitionFD for T points in one launch) against the same differences on the fp64 oracle."""
+    m = humanoid_model
+    nq, nv, nu = m.nq, m.nv, m.nu
+    T, eps = 3, 2e-3
+    o = Oracle()
+    xs, us, ws = [], [], []
+    o.init_env(4)
+    for t in range(30):
+        o.ctrl[:] = o.ctrl_env(t, 4)
+        o.step()
+        if t in (5, 17, 29):
+            xs.append(np.concatenate([o.qpos, o.qvel])); us.append(0.5 * o.ctrl_env(t + 1, 4)); ws.append(o.qacc_warmstart.copy())
+    per = 1 + 2 * (2 * nv + nu)
+    b = hbmod.Batch(m, T * per + 5, gpu)
+    A, B = b.transition_fd(np.array(xs), np.array(us), np.array(ws), eps=eps, centered=True)
+    assert A.shape == (T, 2 * nv, 2 * nv) and B.shape == (T, 2 * nv, nu)
+    for t in range(T):
+        Ao, Bo = _oracle_transition_fd(o, xs[t], us[t], ws[t], eps, nq, nv, nu)
+        sa, sb = np.abs(Ao).max(), np.abs(Bo).max()
+        # fp32 rounding of x' (|qvel'| up to ~30) over 2 eps is the floor: worst entry 5e-3 of the matrix scale, typical entry 1e-4
+        assert np.abs(A[t] - Ao).max() <= 5e-3 * sa, (t, np.abs(A[t] - Ao).max(), sa)
+        assert np.abs(B[t] - Bo).max() <= 5e-3 * max(sb, 1e-3), (t, np.abs(B[t] - Bo).max(), sb)
+        assert np.median(np.abs(A[t] - Ao)) <= 2e-4 * sa and np.median(np.abs(B[t] - Bo)) <= 2e-4 * max(sb, 1e-3)
+    # a batch too small for the perturbed copies is refused
+    small = hbmod.Batch(m, 10, gpu)
+    with pytest.raises(hbmod.HbError):
+        small.transition_fd(np.array(xs), np.array(us))

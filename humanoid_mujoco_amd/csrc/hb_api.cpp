@@ -1037,8 +1037,9 @@ void differentiate_pos(const Model& m, double* dq, const double* q1, const doubl
 }
 }  // namespace
 
-int hb_transition_fd(hb_batch* b, const double* x, const double* u, const double* warm, int T, double eps, int centered, double* A, double* B) {
-  if (!b || !x || T < 1 || !(eps > 0) || (!u && b->D.dm.nu > 0) || (!A && !B)) return HB_EINVAL;
+static int transition_fd_impl(hb_batch* b, const double* x, const double* u, const double* warm, int T, double eps, int centered, const hb_sensor_spec* spec,
+                              double* A, double* B, double* C, double* D) {
+  if (!b || !x || T < 1 || !(eps > 0) || (!u && b->D.dm.nu > 0) || (!A && !B && !C && !D) || ((C || D) && !spec)) return HB_EINVAL;
   const Model& m = b->model->m;
   const int nq = m.nq, nv = m.nv, nu = m.nu, nx = 2 * nv, ncol = nx + nu, k = centered ? 2 : 1, per = 1 + k * ncol;
   if ((long long)T * per > b->n_env) return HB_EINVAL;
@@ -1078,7 +1079,15 @@ int hb_transition_fd(hb_batch* b, const double* x, const double* u, const double
   }
   int rc = hb_set_state_f64(b, HB_STATE_INTEGRATION, st.data());
   if (rc != HB_OK) return rc;
-  rc = hb_step(b, ctrl.data(), 1);
+  std::vector<float> rows;
+  int ns = 0;
+  if (C || D) {
+    // one step with the read-out row of every env (evaluated in the forward pass, before the integration)
+    ns = hb_sensor_size(spec);
+    if (ns <= 0) return HB_EINVAL;
+    rows.resize((size_t)N * ns);
+    rc = hb_rollout_sensors(b, ctrl.data(), 1, spec, rows.data(), nullptr);
+  } else rc = hb_step(b, ctrl.data(), 1);
   if (rc != HB_OK) return rc;
   rc = hb_get_state_f64(b, HB_STATE_INTEGRATION, st.data());
   if (rc != HB_OK) return rc;
@@ -1102,9 +1111,27 @@ int hb_transition_fd(hb_batch* b, const double* x, const double* u, const double
       }
       if (col < nx) { if (A) for (int i = 0; i < nx; i++) A[((size_t)t * nx + i) * nx + col] = d[i]; }
       else if (B) for (int i = 0; i < nx; i++) B[((size_t)t * nx + i) * nu + (col - nx)] = d[i];
+      if (C || D) {
+        const float* rp = rows.data() + (size_t)ep * ns;
+        const float* rm = rows.data() + (size_t)em * ns;
+        for (int i = 0; i < ns; i++) {
+          const double g = hp - hm != 0.0 ? ((double)rp[i] - (double)rm[i]) / (hp - hm) : 0.0;
+          if (col < nx) { if (C) C[((size_t)t * ns + i) * nx + col] = g; }
+          else if (D) D[((size_t)t * ns + i) * nu + (col - nx)] = g;
+        }
+      }
     }
   }
   return HB_OK;
+}
+
+int hb_transition_fd(hb_batch* b, const double* x, const double* u, const double* warm, int T, double eps, int centered, double* A, double* B) {
+  if (!A && !B) return HB_EINVAL;
+  return transition_fd_impl(b, x, u, warm, T, eps, centered, nullptr, A, B, nullptr, nullptr);
+}
+int hb_transition_fd_sensors(hb_batch* b, const double* x, const double* u, const double* warm, int T, double eps, int centered, const hb_sensor_spec* spec,
+                             double* A, double* B, double* C, double* D) {
+  return transition_fd_impl(b, x, u, warm, T, eps, centered, spec, A, B, C, D);
 }
 
 int hb_ctrl_tape_splines(hb_batch* b, const float* knots, const float* times, int n_points, int interpolation, double time0, int T) {

@@ -157,6 +157,7 @@ def lib():
     L.hb_rollout_noise.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_uint]
     L.hb_ctrl_tape_splines.argtypes = [vp, vp, vp, ci, ci, ctypes.c_double, ci]
     L.hb_transition_fd.argtypes = [vp, vp, vp, vp, ci, ctypes.c_double, ci, vp, vp]
+    L.hb_transition_fd_sensors.argtypes = [vp, vp, vp, vp, ci, ctypes.c_double, ci, ctypes.POINTER(HbSensorSpec), vp, vp, vp, vp]
     L.hb_task_stand_default.argtypes = [vp, ctypes.POINTER(HbTaskStand)]
     L.hb_rollout_task_stand.argtypes = [vp, vp, ci, ctypes.POINTER(HbTaskStand), vp, vp]
     L.hb_task_walk_default.argtypes = [vp, ctypes.POINTER(HbTaskWalk)]
@@ -469,7 +470,7 @@ class Batch:
         _check(lib().hb_rollout_sensors(self._h, _ptr(c), T, ctypes.byref(spec), _ptr(out), _ptr(q)), "hb_rollout_sensors")
         return out, q
 
-    def transition_fd(self, x, u, warmstart=None, eps=1e-3, centered=True):
+    def transition_fd(self, x, u, warmstart=None, eps=1e-3, centered=True, sensor_spec=None):
         """mjd_transitionFD for T points at once: x [T, nq + nv], u [T, nu] -> A [T, 2nv, 2nv], B [T, 2nv, nu] (float64)."""
         xs = np.ascontiguousarray(x, dtype=np.float64)
         us = np.ascontiguousarray(u, dtype=np.float64)
@@ -477,8 +478,14 @@ class Batch:
         assert xs.shape == (T, self.model.nq + nv) and us.shape == (T, nu)
         w = None if warmstart is None else np.ascontiguousarray(warmstart, dtype=np.float64)
         A = np.zeros((T, 2 * nv, 2 * nv)); B = np.zeros((T, 2 * nv, nu))
-        _check(lib().hb_transition_fd(self._h, _ptr(xs), _ptr(us), _ptr(w), T, float(eps), int(bool(centered)), _ptr(A), _ptr(B)), "hb_transition_fd")
-        return A, B
+        if sensor_spec is None:
+            _check(lib().hb_transition_fd(self._h, _ptr(xs), _ptr(us), _ptr(w), T, float(eps), int(bool(centered)), _ptr(A), _ptr(B)), "hb_transition_fd")
+            return A, B
+        ns = lib().hb_sensor_size(ctypes.byref(sensor_spec))
+        C = np.zeros((T, ns, 2 * nv)); D = np.zeros((T, ns, nu))
+        _check(lib().hb_transition_fd_sensors(self._h, _ptr(xs), _ptr(us), _ptr(w), T, float(eps), int(bool(centered)), ctypes.byref(sensor_spec),
+                                              _ptr(A), _ptr(B), _ptr(C), _ptr(D)), "hb_transition_fd_sensors")
+        return A, B, C, D
 
     def ctrl_tape_splines(self, knots, times, interpolation, time0, T):
         """knots [n_env, P, nu], times [P] -> the action tape of T steps on the device (SamplingPolicy::Action per candidate);

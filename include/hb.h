@@ -221,6 +221,11 @@ int hb_rollout_trajectory(hb_batch* b, const float* ctrl, int T, float* qpos_out
  * about 1e-3 (rounding in x' divided by eps is the noise floor), not the 1e-6 an fp64 caller would use.
  * The batch's states are overwritten. */
 int hb_transition_fd(hb_batch* b, const double* x, const double* u, const double* warmstart, int T, double eps, int centered, double* A, double* B);
+/* The same with the sensor derivatives of mjd_transitionFD: d(sensor) = C dx + D du, for the read-out row of `spec`
+ * (hb_sensor_size(spec) values, evaluated in the step's forward pass, i.e. at (x, u) itself: the residual Jacobians a
+ * gradient-based planner builds its cost derivatives from).  C[t][ns][2nv], D[t][ns][nu], either nullable. */
+int hb_transition_fd_sensors(hb_batch* b, const double* x, const double* u, const double* warmstart, int T, double eps, int centered,
+                             const hb_sensor_spec* spec, double* A, double* B, double* C, double* D);
 
 /* ---- a planner iteration's cost evaluation on the device: MJPC's "Humanoid Stand" task ------------------------------
  * (mujoco_mpc/mjpc/tasks/humanoid/stand/{stand.cc:41-104, task.xml:14-36}; the two-foot variant of

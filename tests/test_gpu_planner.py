@@ -408,6 +408,18 @@ def test_transition_derivatives_by_batched_finite_differences(hbmod, humanoid_mo
         assert np.abs(A[t] - Ao).max() <= 5e-3 * sa, (t, np.abs(A[t] - Ao).max(), sa)
         assert np.abs(B[t] - Bo).max() <= 5e-3 * max(sb, 1e-3), (t, np.abs(B[t] - Bo).max(), sb)
         assert np.median(np.abs(A[t] - Ao)) <= 2e-4 * sa and np.median(np.abs(B[t] - Bo)) <= 2e-4 * max(sb, 1e-3)
+    # sensor derivatives: the torso's frame position (objtype xbody) moves one to one with the root translation, its
+    # dependence on the controls is nil (sensors are evaluated at (x, u) itself, before the step)
+    torso = m.name2id("body", "torso")
+    spec = hbmod.Batch.sensor_spec([torso], subtree_body=torso)
+    A2, B2, C, D = b.transition_fd(np.array(xs), np.array(us), np.array(ws), eps=eps, centered=True, sensor_spec=spec)
+    assert np.allclose(A2, A) and np.allclose(B2, B)
+    assert C.shape == (T, 9, 2 * nv) and D.shape == (T, 9, nu)
+    for t in range(T):
+        assert np.allclose(C[t][:3, :3], np.eye(3), atol=2e-3)       # d xpos(torso) / d root translation
+        assert np.abs(C[t][:3, nv:]).max() < 2e-3                    # positions do not depend on velocities
+        assert np.allclose(C[t][6:9, nv:nv + 3], np.eye(3), atol=5e-3)  # d subtreelinvel / d root linear velocity
+        assert np.abs(D[t]).max() < 2e-3
     # a batch too small for the perturbed copies is refused
     small = hbmod.Batch(m, 10, gpu)
     with pytest.raises(hbmod.HbError):

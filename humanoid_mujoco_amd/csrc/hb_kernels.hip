@@ -1276,7 +1276,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     gsync();
     // xfrc_applied: Cartesian wrench at each body com (mj_xfrcAccumulate)
     if (P.xfrc) {
-      if (P.xfrc_scale > 0.f) {
+      if (P.xfrc_scale > 0.f && P.integrate) {  // (a plain mj_forward - hb_forward, the terminal read-out - leaves the process where it is)
         // Trajectory::NoisyRollout's perturbation (trajectory.cc:147-156): Ornstein-Uhlenbeck noise on every xfrc_applied entry
         float* xw = P.xfrc + (size_t)env * nb * 6;
         for (int i = lane; i < 6 * nb; i += kGroup)

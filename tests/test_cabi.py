@@ -75,3 +75,26 @@ def test_product_never_touches_the_oracle():
     mk = open(os.path.join(ROOT, "Makefile")).read()
     lib_rule = mk[mk.index("$(LIB):"):mk.index("build/hb_compile:")]
     assert "oracle" not in lib_rule
+
+
+def test_ctypes_structs_match_the_header(hbmod, tmp_path):
+    """Every struct the Python host mirrors with ctypes has the size and field offsets the C header gives it."""
+    import humanoid_mujoco_amd.engine as eng
+    pairs = [("hb_options", eng.HbOptions), ("hb_sizes", eng.HbSizes), ("hb_env_config", eng.HbEnvConfig), ("hb_env_randomization", eng.HbEnvRandomization),
+             ("hb_domain_randomization", eng.HbDomainRandomization), ("hb_sensor_spec", eng.HbSensorSpec), ("hb_task_stand", eng.HbTaskStand),
+             ("hb_task_walk", eng.HbTaskWalk)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hb.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in pairs:
+        assert int(out[cname]) == ctypes.sizeof(cls), (cname, out[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(out["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Soak: 4096 envs x 20000 steps of the benchmark workload in a few launches, then 5000 steps with zero controls
 (collapsed, contact-rich); checks that nothing diverged and reports warning bits and capacity use.
-usage: gpu_soak.py [newton]   (default: the benchmark configuration PGS/50; "newton": solver = Newton/100)"""
+usage: gpu_soak.py [newton] [thousands-of-steps]   (default: the benchmark configuration PGS/50, 20 x 1000 steps;
+"newton": solver = Newton/100)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import humanoid_mujoco_amd as hb
 m = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm"))
-NEWTON = len(sys.argv) > 1 and sys.argv[1] == "newton"
+NEWTON = "newton" in sys.argv[1:]
+KSTEPS = next((int(a) for a in sys.argv[1:] if a.isdigit()), 20)
 if NEWTON:
     m.set_opt(solver=2, iterations=100)
     print("solver: Newton/100")
@@ -17,15 +19,15 @@ b = hb.Batch(m, N, 0)
 b.reset(perturb=True)
 t0 = time.perf_counter()
 mx_c = mx_e = mx_i = 0
-for k in range(20):
+for k in range(KSTEPS):
     b.rollout_halton(1000, t0=1000 * k)
     nc, ne, ni = b.counts()
     mx_c, mx_e, mx_i = max(mx_c, nc.max()), max(mx_e, ne.max()), max(mx_i, ni.max())
 dt = time.perf_counter() - t0
 st = b.get_state()
 s = b.status()
-print("20000 steps x %d envs in %.2f s (%.3e env-steps/s); finite %s; |qpos|max %.2f |qvel|max %.1f; envs with warnings %d (bits %s); max ncon %d max nefc %d max solver iterations %d (sampled every 1000 steps)"
-      % (N, dt, 20000 * N / dt, np.isfinite(st).all(), np.abs(st[:, 1:29]).max(), np.abs(st[:, 29:56]).max(), (s != 0).sum(), sorted(set(s[s != 0].tolist())), mx_c, mx_e, mx_i))
+print("%d steps x %d envs in %.2f s (%.3e env-steps/s); finite %s; |qpos|max %.2f |qvel|max %.1f; envs with warnings %d (bits %s); max ncon %d max nefc %d max solver iterations %d (sampled every 1000 steps)"
+      % (1000 * KSTEPS, N, dt, 1000 * KSTEPS * N / dt, np.isfinite(st).all(), np.abs(st[:, 1:29]).max(), np.abs(st[:, 29:56]).max(), (s != 0).sum(), sorted(set(s[s != 0].tolist())), mx_c, mx_e, mx_i))
 zeros = b.dev_alloc(N * m.nu * 4)
 b.halton_ctrl_dev(1, 0, 0, zeros)  # (any finite controls; the position servos are then switched off below)
 import ctypes

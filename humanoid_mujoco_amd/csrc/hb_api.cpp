@@ -91,7 +91,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   DevModel& dm = D.dm;
   memset(&dm, 0, sizeof dm);
   int nb = m.nbody, nv = m.nv;
-  dm.nq = m.nq; dm.nv = nv; dm.nu = m.nu; dm.nbody = nb; dm.njnt = m.njnt; dm.ngeom = m.ngeom; dm.ntendon = m.ntendon; dm.nM = m.nM; dm.npair = m.npair;
+  dm.nq = m.nq; dm.nv = nv; dm.nu = m.nu; dm.nbody = nb; dm.njnt = m.njnt; dm.ngeom = m.ngeom; dm.ntendon = m.ntendon; dm.nM = m.nM; dm.npair = m.npair; dm.nhfielddata = m.nhfielddata;
   dm.nstate = 1 + m.nq + 2 * nv;
   dm.timestep = (float)m.timestep;
   for (int i = 0; i < 3; i++) dm.gravity[i] = (float)m.gravity[i];
@@ -1740,6 +1740,7 @@ int hb_env_default_domain_randomization(const hb_model* h, hb_domain_randomizati
   d->armature_max_change = 0.0005f; d->stiffness_max_change = 0.f; d->margin_max_change = 0.05f; d->range_max_change = 0.1f;  // JOINT_*_MAX_CHANGE
   d->kp_nominal = 0.f; d->kp_max_change = 0.5f;              // JOINT_P_GAIN(_MAX_CHANGE); nominal 0: keep the model's gains
   d->force_limit_max_change = 0.05f;                         // JOINT_FORCE_LIMIT_MAX_CHANGE
+  d->floor_bump_min = 0.f; d->floor_bump_max = h->m.nhfield > 0 ? 0.1f : 0.f;  // MIN/MAX_FLOOR_BUMP_HEIGHT (simulation_parameters.py:47-48); only with a height field
   return HB_OK;
 }
 
@@ -1756,10 +1757,10 @@ int hb_env_domain_randomize(hb_batch* b, const hb_domain_randomization* cfg) {
   }
   if (!(cfg->friction_max_mult >= cfg->friction_min_mult) || cfg->friction_min_mult < 0.f || cfg->max_mass_change < 0.f || cfg->max_external_mass < 0.f ||
       cfg->armature_max_change < 0.f || cfg->stiffness_max_change < 0.f || cfg->margin_max_change < 0.f || cfg->range_max_change < 0.f || cfg->kp_max_change < 0.f ||
-      cfg->force_limit_max_change < 0.f) return HB_EINVAL;
+      cfg->force_limit_max_change < 0.f || cfg->floor_bump_min < 0.f || cfg->floor_bump_max < 0.f) return HB_EINVAL;
   static_assert(sizeof(hb_domain_randomization) == sizeof(DomainRand), "hb_domain_randomization and DomainRand must have the same layout");
   const DevModel& dm = b->D.dm;
-  const DomainLayout L = domain_layout(dm.nbody, dm.nv, dm.nlimcand, dm.nu);
+  const DomainLayout L = domain_layout(dm.nbody, dm.nv, dm.nlimcand, dm.nu, dm.nhfielddata);
   if (!b->d_dr && hipMalloc((void**)&b->d_dr, (size_t)b->n_env * L.stride * sizeof(float)) != hipSuccess) return HB_ENOMEM;
   b->dr_stride = L.stride;
   memcpy(&b->dom_rand, cfg, sizeof *cfg);

@@ -35,7 +35,7 @@ enum { C_DIST = 0, C_POS = 1, C_FRAME = 4, C_PAIR = 13, C_ROW = 14, C_DIM = 15, 
 
 struct DevModel {
   // sizes
-  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, npair, nlevel, ntree, nlimcand;
+  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, npair, nlevel, ntree, nlimcand, nhfielddata;
   int nstate;   // floats per env in the global state record: time, qpos, qvel, qacc_warmstart
   int nobs;
   // options
@@ -151,16 +151,17 @@ struct DomainRand {
   float friction_min_mult, friction_max_mult, max_mass_change, max_external_mass;
   float armature_max_change, stiffness_max_change, margin_max_change, range_max_change;
   float kp_nominal, kp_max_change, force_limit_max_change;
+  float floor_bump_min, floor_bump_max;  // height-field elevations in [0, min + factor (max - min)] (cpu_env.py:267-280); max 0: the model's own data
 };
 // per-env model parameters [n_env][stride]: mass[nbody] | armature[nv] | stiffness[nv] | lim_margin[nlimcand] |
-// lim_range[nlimcand] | act_gain[nu] | act_bias1[nu] | act_forcerange[2 nu] | floor friction scale
+// lim_range[nlimcand] | act_gain[nu] | act_bias1[nu] | act_forcerange[2 nu] | floor friction scale | hfield_data[nhfielddata]
 struct DomainLayout {
-  int o_mass, o_arm, o_stiff, o_lmargin, o_lrange, o_gain, o_bias1, o_frc, o_fric, stride;
+  int o_mass, o_arm, o_stiff, o_lmargin, o_lrange, o_gain, o_bias1, o_frc, o_fric, o_hfield, stride;
 };
-__host__ __device__ inline DomainLayout domain_layout(int nbody, int nv, int nlimcand, int nu) {
+__host__ __device__ inline DomainLayout domain_layout(int nbody, int nv, int nlimcand, int nu, int nhfielddata) {
   DomainLayout L;
   L.o_mass = 0; L.o_arm = nbody; L.o_stiff = L.o_arm + nv; L.o_lmargin = L.o_stiff + nv; L.o_lrange = L.o_lmargin + nlimcand;
-  L.o_gain = L.o_lrange + nlimcand; L.o_bias1 = L.o_gain + nu; L.o_frc = L.o_bias1 + nu; L.o_fric = L.o_frc + 2 * nu; L.stride = L.o_fric + 1;
+  L.o_gain = L.o_lrange + nlimcand; L.o_bias1 = L.o_gain + nu; L.o_frc = L.o_bias1 + nu; L.o_fric = L.o_frc + 2 * nu; L.o_hfield = L.o_fric + 1; L.stride = L.o_hfield + nhfielddata;
   return L;
 }
 constexpr int kDelaySlots = 64;  // ring size of the delay FIFOs (delays <= 63 control steps)

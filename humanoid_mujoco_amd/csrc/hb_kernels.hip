@@ -254,10 +254,10 @@ __device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
 // height field (geom1, static) vs sphere: this engine's terrain contact model (see the oracle's
 // hfield_sphere): closest point on the triangulated surface inside the sphere's footprint, one contact,
 // normal out of the terrain.  hmat = rotation of the field's frame (row-major), hpos its origin.
-__device__ __forceinline__ bool hfield_sphere(DevModelRef M, ConOut& c, float margin, int hid, V3 hpos, const float* hmat, V3 spos, float radius) {
+__device__ __forceinline__ bool hfield_sphere(DevModelRef M, const float* hdata, ConOut& c, float margin, int hid, V3 hpos, const float* hmat, V3 spos, float radius) {
   const float hsx = M.hfield_size[4 * hid], hsy = M.hfield_size[4 * hid + 1], hsz = M.hfield_size[4 * hid + 2], hsb = M.hfield_size[4 * hid + 3];
   const int nrow = M.hfield_nrow[hid], ncol = M.hfield_ncol[hid];
-  const float HB_CONST* data = M.hfield_data + M.hfield_adr[hid];
+  const float* data = hdata + M.hfield_adr[hid];  // the model's elevations, or this env's own (domain randomisation)
   const V3 dif = spos - hpos;
   const V3 p = {hmat[0] * dif.x + hmat[3] * dif.y + hmat[6] * dif.z, hmat[1] * dif.x + hmat[4] * dif.y + hmat[7] * dif.z, hmat[2] * dif.x + hmat[5] * dif.y + hmat[8] * dif.z};
   const float reach = radius + margin;
@@ -782,7 +782,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   if (P.env_mask && !P.env_mask[env]) return;  // masked stepping (hb_env_reset's settle step)
   // per-env model parameters (domain randomisation), nullable; offsets per DomainLayout
   const float* dr = P.dr ? P.dr + (size_t)env * P.dr_stride : nullptr;
-  const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu);
+  const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
   const int nv = M.nv, nq = M.nq, nb = M.nbody, cs = M.cstride;
 
   float* s_qpos = lds + M.o_qpos;
@@ -1372,11 +1372,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             float hm[9];
             q2mat(hm, ldq(M.geom_quat + 4 * g1));
             const int hid = M.geom_dataid[g1];
-            if (t2 == 2) n = hfield_sphere(M, co0, margin, hid, pos1, hm, pos2, r2) ? 1 : 0;
+            const float* hdata = dr ? dr + DL.o_hfield : (const float*)M.hfield_data;
+            if (t2 == 2) n = hfield_sphere(M, hdata, co0, margin, hid, pos1, hm, pos2, r2) ? 1 : 0;
             else {
               ConOut ca, cb;
-              const bool h1 = hfield_sphere(M, ca, margin, hid, pos1, hm, pos2 + ax2 * l2, r2);
-              const bool h2 = hfield_sphere(M, cb, margin, hid, pos1, hm, pos2 - ax2 * l2, r2);
+              const bool h1 = hfield_sphere(M, hdata, ca, margin, hid, pos1, hm, pos2 + ax2 * l2, r2);
+              const bool h2 = hfield_sphere(M, hdata, cb, margin, hid, pos1, hm, pos2 - ax2 * l2, r2);
               co0 = h1 ? ca : cb;
               co1 = cb;
               n = (h1 ? 1 : 0) + (h2 ? 1 : 0);
@@ -2365,9 +2366,9 @@ __global__ void hb_envrand_reset_kernel(const DevModel M, const EnvRand R, const
 }
 
 // Per-env model parameters of one episode (cpu_env.py:188-264): see hb_domain_randomization in include/hb.h.
-enum { RS_DR_MASS = 16, RS_DR_EXTRA, RS_DR_FRIC, RS_DR_ARM, RS_DR_STIFF, RS_DR_MARGIN, RS_DR_RANGE, RS_DR_KP, RS_DR_FRC };
+enum { RS_DR_MASS = 16, RS_DR_EXTRA, RS_DR_FRIC, RS_DR_ARM, RS_DR_STIFF, RS_DR_MARGIN, RS_DR_RANGE, RS_DR_KP, RS_DR_FRC, RS_DR_FLOOR };
 __device__ __forceinline__ void domain_draw(const DevModel& M, const DomainRand& D, float* d, int env_global, int ep) {
-  const DomainLayout L = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu);
+  const DomainLayout L = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
   const float rf = D.factor;
   auto U = [&](int stream, int idx) { return rng_uniform(D.seed, env_global, ep, 0, stream, idx); };
   d[L.o_mass] = 0.f;
@@ -2404,6 +2405,34 @@ __device__ __forceinline__ void domain_draw(const DevModel& M, const DomainRand&
     d[L.o_frc + 2 * a + 1] = M.act_forcerange[2 * a + 1] + (2.f * U(RS_DR_FRC, 2 * a + 1) - 1.f) * D.force_limit_max_change * rf;
   }
   d[L.o_fric] = (1.f - rf) + (D.friction_min_mult + U(RS_DR_FRIC, 0) * (D.friction_max_mult - D.friction_min_mult)) * rf;
+  // floor height maps (CPUEnv._randomize_floor_heightmap, cpu_env.py:267-280: Perlin noise on the grid, shifted and scaled to
+  // [0, 1], times MIN + factor (MAX - MIN)).  The reference's noise comes from the third-party perlin_noise package; here:
+  // three octaves of smooth value noise from the counter-based generator, normalised the same way.
+  const float bump = D.floor_bump_min + rf * (D.floor_bump_max - D.floor_bump_min);
+  for (int hf = 0, adr = 0; adr < M.nhfielddata; hf++) {
+    const int nr = M.hfield_nrow[hf], nc = M.hfield_ncol[hf], n = nr * nc;
+    float* h = d + L.o_hfield + adr;
+    if (!(D.floor_bump_max > 0.f)) { for (int i = 0; i < n; i++) h[i] = M.hfield_data[adr + i]; adr += n; continue; }
+    float lo = 3.0e38f, hi = -3.0e38f;
+    for (int r = 0; r < nr; r++)
+      for (int c = 0; c < nc; c++) {
+        float v = 0.f, amp = 1.f;
+        for (int oct = 0, cells = 2; oct < 3; oct++, cells *= 2, amp *= 0.5f) {  // lattices of 3x3, 5x5, 9x9 nodes over the field
+          const float x = (float)c / (float)max(1, nc - 1) * (float)cells, y = (float)r / (float)max(1, nr - 1) * (float)cells;
+          const int x0 = min((int)x, cells - 1), y0 = min((int)y, cells - 1);
+          float fx = x - (float)x0, fy = y - (float)y0;
+          fx = fx * fx * (3.f - 2.f * fx); fy = fy * fy * (3.f - 2.f * fy);  // smoothstep
+          auto node = [&](int ix, int iy) { return rng_uniform(D.seed, env_global, ep, hf, RS_DR_FLOOR, (oct * 16 + iy) * 16 + ix); };
+          const float a = node(x0, y0), b = node(x0 + 1, y0), cc = node(x0, y0 + 1), dd = node(x0 + 1, y0 + 1);
+          v += amp * ((a * (1.f - fx) + b * fx) * (1.f - fy) + (cc * (1.f - fx) + dd * fx) * fy);
+        }
+        h[r * nc + c] = v;
+        lo = fminf(lo, v); hi = fmaxf(hi, v);
+      }
+    const float sc = hi > lo ? bump / (hi - lo) : 0.f;
+    for (int i = 0; i < n; i++) h[i] = (h[i] - lo) * sc;
+    adr += n;
+  }
 }
 __global__ void hb_domain_rand_kernel(const DevModel M, const DomainRand D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -88,7 +88,8 @@ class HbDomainRandomization(ctypes.Structure):
     _fields_ = [("factor", ctypes.c_float), ("seed", ctypes.c_uint), ("friction_min_mult", ctypes.c_float), ("friction_max_mult", ctypes.c_float),
                 ("max_mass_change", ctypes.c_float), ("max_external_mass", ctypes.c_float), ("armature_max_change", ctypes.c_float),
                 ("stiffness_max_change", ctypes.c_float), ("margin_max_change", ctypes.c_float), ("range_max_change", ctypes.c_float),
-                ("kp_nominal", ctypes.c_float), ("kp_max_change", ctypes.c_float), ("force_limit_max_change", ctypes.c_float)]
+                ("kp_nominal", ctypes.c_float), ("kp_max_change", ctypes.c_float), ("force_limit_max_change", ctypes.c_float),
+                ("floor_bump_min", ctypes.c_float), ("floor_bump_max", ctypes.c_float)]
 
 
 class HbError(RuntimeError):

@@ -391,6 +391,8 @@ typedef struct hb_domain_randomization {
   float max_mass_change, max_external_mass;
   float armature_max_change, stiffness_max_change, margin_max_change, range_max_change;
   float kp_nominal, kp_max_change, force_limit_max_change;
+  float floor_bump_min, floor_bump_max;  /* height fields: per-env elevations, smooth noise scaled to [0, min + factor (max - min)]
+                                            (CPUEnv._randomize_floor_heightmap, cpu_env.py:267-280); max = 0: the model's own data */
 } hb_domain_randomization;
 /* The reference's values (factor = 1, kp_nominal = 0: gains stay the model's — JOINT_P_GAIN = 2 is the team robot's). */
 int hb_env_default_domain_randomization(const hb_model* m, hb_domain_randomization* out);
@@ -398,7 +400,7 @@ int hb_env_default_domain_randomization(const hb_model* m, hb_domain_randomizati
 int hb_env_domain_randomize(hb_batch* b, const hb_domain_randomization* cfg);
 /* Current per-env parameters, for inspection: out[n_env][stride] with per env
  * mass[nbody] | armature[nv] | stiffness[nv] | limit margin[nlim] | limit bound[nlim] | gain[nu] | biasprm1[nu] |
- * forcerange[2 nu] | floor friction scale; returns stride (also when out == NULL), 0 when off. nlim = 2 per limited
+ * forcerange[2 nu] | floor friction scale | hfield_data[nhfielddata]; returns stride (also when out == NULL), 0 when off. nlim = 2 per limited
  * joint / tendon in constraint order (lower, upper). */
 int hb_env_get_domain_params(hb_batch* b, float* out);
 

@@ -1415,7 +1415,7 @@ double* om_model_ptr(om_model* m, const char* name, int* len) {
   FIELD(tendon_invweight0, m->ntendon) FIELD(qpos0, m->nq) FIELD(key_qpos, m->nkey * m->nq) FIELD(dof_damping, nv) FIELD(dof_armature, nv)
   FIELD(jnt_range, 2 * m->njnt) FIELD(gravity, 3) FIELD(body_ipos, 3 * nb) FIELD(jnt_stiffness, m->njnt)
   FIELD(jnt_margin, m->njnt) FIELD(geom_friction, 3 * m->ngeom) FIELD(actuator_gainprm, m->nu) FIELD(actuator_biasprm, 3 * m->nu)
-  FIELD(actuator_forcerange, 2 * m->nu)
+  FIELD(actuator_forcerange, 2 * m->nu) FIELD(hfield_data, m->nhfielddata)
   *len = 0;
   return NULL;
 }

@@ -301,3 +301,60 @@ def test_domain_randomization_redraws_per_episode_and_switches_off(hbmod, humano
     D.range_max_change = -1.0
     with pytest.raises(hbmod.HbError):
         env.batch.env_domain_randomize(D)
+
+
+def test_floor_heightmap_randomization(hbmod, gpu):
+    """CPUEnv._randomize_floor_heightmap (cpu_env.py:267-280) on the device: every env gets its own 8 x 8 elevation map,
+    smooth noise shifted and scaled to [0, MIN + factor (MAX - MIN)], redrawn per episode; the collision kernel reads the
+    env's own map (one step from identical states matches the oracle whose hfield_data was set to that env's map)."""
+    import os
+    from oracle_lib import ROOT
+    path = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27_hfield.hbm")
+    m = hbmod.Model.load(path)
+    n = 6
+    env = hbmod.VecEnv(m, n, gpu, auto_reset=0, max_time=0.0, target_z=10.0)
+    b = env.batch
+    D = b.env_default_domain_randomization()
+    assert D.floor_bump_min == 0.0 and D.floor_bump_max == pytest.approx(0.1)  # MIN / MAX_FLOOR_BUMP_HEIGHT
+    # only the floor varies here, so that the oracle needs nothing but the map
+    D.seed = 21
+    D.friction_min_mult = D.friction_max_mult = 1.0
+    D.max_mass_change = D.max_external_mass = D.armature_max_change = D.margin_max_change = D.range_max_change = D.force_limit_max_change = 0.0
+    D.floor_bump_max = 0.3  # taller than the reference's 0.1 m so that the terrain clearly matters
+    b.env_domain_randomize(D)
+    env.reset()
+    P = b.env_domain_params()
+    hf = P[:, -64:].reshape(n, 8, 8)
+    assert np.allclose(hf.min(axis=(1, 2)), 0.0, atol=1e-7) and np.allclose(hf.max(axis=(1, 2)), 0.3, atol=1e-6)
+    assert np.abs(hf[0] - hf[1]).max() > 0.05                              # envs differ
+    assert np.abs(np.diff(hf, axis=2)).mean() < 0.5 * hf.std() * 2          # smooth: neighbours are closer than random nodes would be
+    o = Oracle(path)
+    zero = np.zeros((n, m.nu), np.float32)
+    contacts = 0
+    for t in range(260):
+        take = t > 60 and t % 12 == 0
+        if take:
+            st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
+        env.step(zero)
+        if take:
+            q = b.qpos.astype(np.float64)
+            nc, ne, _ = b.counts()
+            for e in range(n):
+                o.reset()
+                o.marr("hfield_data")[:] = hf[e].ravel()
+                o.qpos[:] = st[e, 1:1 + m.nq]; o.qvel[:] = st[e, 1 + m.nq:1 + m.nq + m.nv]; o.qacc_warmstart[:] = st[e, 1 + m.nq + m.nv:]
+                o.ctrl[:] = 0
+                o.step()
+                assert (o.ncon, o.nefc) == (nc[e], ne[e]), (t, e, o.ncon, nc[e])
+                contacts += o.ncon
+                assert (np.abs(q[e] - o.qpos) / np.maximum(1, np.abs(o.qpos))).max() <= 1e-4
+    assert contacts > 30
+    # same seed: the same maps (episode numbering restarts at an explicit reset); another seed: other maps; off: none
+    env.reset()
+    assert np.array_equal(b.env_domain_params()[:, -64:], P[:, -64:])
+    D.seed = 22
+    b.env_domain_randomize(D)
+    env.reset()
+    assert np.abs(b.env_domain_params()[:, -64:] - P[:, -64:]).max() > 0.02
+    b.env_domain_randomize(None)
+    assert b.env_domain_params() is None

@@ -122,9 +122,12 @@ def main():
     stride = n_env * nu * 4
 
     def barrier():
-        batch.sync()
+        batch.sync()  # the batch's own HIP stream(s)
         if dist is not None:
             dist.barrier()
+            if backend == "nccl":
+                import torch
+                torch.cuda.synchronize()  # an RCCL barrier is enqueued on a stream: wait for it on the host as well
 
     pipelined = not args.no_pipeline
     batch.pipeline(pipelined)

@@ -762,6 +762,13 @@ __device__ __forceinline__ void store_w_rows(float* W, int stride, const f32x16&
     *reinterpret_cast<float4*>(p + 8 * g) = {T[4 * g] * S[4 * g], T[4 * g + 1] * S[4 * g + 1], T[4 * g + 2] * S[4 * g + 2], T[4 * g + 3] * S[4 * g + 3]};
 }
 
+// WT[row][c] = T[row][c] * S(row): the transpose of store_w_rows' matrix (consecutive lanes, consecutive addresses)
+__device__ __forceinline__ void store_w_cols(float* WT, int stride, const f32x16& T, const f32x16& S, int lane) {
+  float* p = WT + 4 * (lane >> 5) * stride + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; r++) p[crow(r) * stride] = T[r] * S[r];
+}
+
 // SOLVER: mjtSolver of the instantiation (0 = PGS, 2 = Newton); everything outside the constraint solve, the mass-matrix
 // factorisation and the integrator's damped solve is shared.
 template <int SOLVER, int NDENSE>
@@ -772,7 +779,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
   // PGS instantiation of dense order <= 28: M^-1 = W W' from an elimination on the matrix cores instead of the sparse
   // L'DL schedule (which stays for 29..32 dofs)
-  constexpr bool kDensePgs = SOLVER == 0 && NDENSE <= 28;
+  constexpr bool kDensePgs = SOLVER == 0;  // (both dense orders)
   extern __shared__ float lds[];
   const int lane0 = threadIdx.x;
   int lane = lane0;
@@ -2065,11 +2072,34 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
           // right-hand side column
           int le;
           asm volatile("v_mov_b32 %0, %1" : "=v"(le) : "v"(lane0));
-          const int li = le & 31;
-          const float rhs = li < nv ? M.timestep * M.dof_damping[li] * s_v0[li] : 0.f;
-          const float x = sym_solve_mfma<NDENSE / 2>(load_sym_pairs<1>(M, s_qLD, le), rhs, le);
-          if (le < nv) s_v2[le] = s_v0[le] - x;
-          gsync();
+          if constexpr (NDENSE <= 28) {
+            const int li = le & 31;
+            const float rhs = li < nv ? M.timestep * M.dof_damping[li] * s_v0[li] : 0.f;
+            const float x = sym_solve_mfma<NDENSE / 2>(load_sym_pairs<1>(M, s_qLD, le), rhs, le);
+            if (le < nv) s_v2[le] = s_v0[le] - x;
+            gsync();
+          } else {
+            // order 32 has no spare column for the right-hand side: H^-1 = W_H W_H' with W_H and its transpose written
+            // out of the elimination into the (now dead) C rows, then two row-times-vector passes
+            float* WH = s_C;
+            float* WHT = s_C + 32 * kWs;  // runs on into the (dead) row-meta / W area behind C: the host checks the room
+            if (le < nv) s_v2[le] = M.timestep * M.dof_damping[le] * s_v0[le];  // h B qacc
+            f32x16 T, S;
+            sym_factor_mfma<NDENSE / 2>(load_sym_pairs<1>(M, s_qLD, le), T, S, le);
+            store_w_rows(WH, kWs, T, S, le);
+            store_w_cols(WHT, kWs, T, S, le);
+            gsync();
+            float p = 0.f;
+            if (le < nv) p = dot32(WHT + le * kWs, s_v2);  // W_H' (h B qacc)
+            gsync();
+            if (le < nv) s_v1[le] = p;
+            gsync();
+            float q = 0.f;
+            if (le < nv) q = dot32(WH + le * kWs, s_v1);
+            gsync();
+            if (le < nv) s_v2[le] = s_v0[le] - q;
+            gsync();
+          }
         } else if constexpr (SOLVER == 0) {
           // H^-1 = W_H W_H^T; W_H and its transpose are built in the (now dead) C rows
           float* WH = s_C;

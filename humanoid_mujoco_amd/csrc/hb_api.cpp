@@ -129,11 +129,10 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (int a = b; a > 0; a = m.body_parentid[a])
       for (int k = 0; k < m.body_dofnum[a]; k++) dofmask[b] |= 1ull << (m.body_dofadr[a] + k);
   // dof ancestry
-  std::vector<int> nanc(nv, 0), Mi(m.nM), Mj(m.nM);
+  std::vector<int> Mi(m.nM), Mj(m.nM);
   for (int i = 0; i < nv; i++) {
     int adr = m.dof_Madr[i];
     for (int j = i; j >= 0; j = m.dof_parentid[j]) { Mi[adr] = i; Mj[adr] = j; adr++; }
-    nanc[i] = adr - m.dof_Madr[i] - 1;
   }
   if (m.nM > 1023) { err = "sparse mass matrix too large for the packed index tables"; return false; }
   // ---- LDS layout
@@ -142,7 +141,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.cstride = 33;
   dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
   dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(8 * nv);  /* angular[3], -, linear[3], - per dof */
-  dm.o_qLD = take(2 * m.nM + 6); dm.o_dinv = take(2 * nv); dm.o_dsqrtinv = take(nv); dm.o_smooth = take(nv);  // qLD, dinv: {M, H} pairs; + the three pad pairs of the factor schedule
+  dm.o_qLD = take(2 * m.nM + 4); dm.o_smooth = take(nv);  // qLD: {M, H} pairs + the zero and one pad pairs of the dense views
   dm.o_vec0 = take(32); dm.o_vec1 = take(32); dm.o_vec2 = take(32);  /* read 32 wide */ dm.o_tenlen = take(std::max(1, m.ntendon));
   int region = off;
   dm.o_xpos = take(8 * nb);  /* xpos[3], -, xquat[4] records */ dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
@@ -164,108 +163,12 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.lds_floats = std::max(endA, endB);
   if (dm.lds_floats * 4 > 160 * 1024) { err = "model needs more LDS than one CU has"; return false; }
 
-  // L^T D L schedule by levels of the elimination tree (a dof is ready once all its descendant dofs are done)
-  std::vector<int> height(nv, 0);
-  for (int k = nv - 1; k >= 0; k--) { int p = m.dof_parentid[k]; if (p >= 0) height[p] = std::max(height[p], height[k] + 1); }
-  int maxh = 0;
-  for (int k = 0; k < nv; k++) maxh = std::max(maxh, height[k]);
-  // The top of the elimination tree is a chain (for a floating-base robot: the free joint's six dofs and
-  // whatever single-file joints follow): once the limbs are eliminated, every remaining level has exactly one
-  // pivot and a handful of entries.  That tail is factorised densely in registers instead (factor_ld):
-  // ftop_n chain dofs d_0 (root) .. d_{n-1}, entry (d_a, d_b) at dof_Madr[d_a] + (a - b).
-  int ntop = 0;
-  {
-    std::vector<int> cnt(maxh + 1, 0), who(maxh + 1, -1);
-    for (int k = 0; k < nv; k++) { cnt[height[k]]++; who[height[k]] = k; }
-    while (ntop <= maxh && ntop < kFactorTop && cnt[maxh - ntop] == 1) {
-      const int d = who[maxh - ntop];
-      if (ntop == 0 ? m.dof_parentid[d] != -1 : m.dof_parentid[d] != who[maxh - ntop + 1]) break;
-      ntop++;
-    }
-    if (ntop < 2) ntop = 0;
-    dm.ftop_n = ntop;
-    for (int a = 0; a < kFactorTop; a++) dm.ftop_adr[a] = a < ntop ? m.dof_Madr[who[maxh - a]] : 0;
-  }
-  // Level schedule of the rest, as ROUNDS of up to 64 destination entries (one per lane).  A round's table
-  // block is field-major (dst[64], then lo[64], hi[64] per contribution) so that every lane reads one
-  // coalesced dword per field; all addresses are absolute LDS byte addresses of {M, H} pairs, two per word.
-  // Lanes without an entry and contributions beyond an entry's own are pointed at three pad pairs behind the
-  // matrix (zero, one, dump: 0 * (0 / 1) subtracted from the dump slot), so the kernel's round body has
-  // no per-lane guards at all.  Rounds of one level touch disjoint entries; the wave syncs after the last.
-  std::vector<int> fround, ftab;
-  {
-    auto lds_addr = [&](int idx) { return (dm.o_qLD + 2 * idx) * 4; };
-    const int pad_zero = lds_addr(m.nM), pad_one = lds_addr(m.nM + 1), pad_dump = lds_addr(m.nM + 2);
-    if (pad_dump + 8 > 65535) { err = "LDS layout too large for 16-bit factor addresses"; return false; }
-    for (int L = 0; L <= maxh - ntop; L++) {
-      std::map<int, std::vector<std::pair<int, int>>> by_dst;  // dst -> contributions (lo, hi) of this level's pivots
-      for (int k = 0; k < nv; k++) {
-        if (height[k] != L) continue;
-        int Mki = m.dof_Madr[k] + 1, i = m.dof_parentid[k];
-        while (i >= 0) {
-          int cnt = nanc[i] + 1;
-          // entry (i, t-th ancestor of i) -= M'[k, that ancestor] * M'[k, i] / D[k]
-          for (int t = 0; t < cnt; t++)
-            by_dst[m.dof_Madr[i] + t].push_back({lds_addr(Mki + t) | (lds_addr(Mki) << 16), lds_addr(m.dof_Madr[k])});
-          i = m.dof_parentid[i];
-          Mki++;
-        }
-      }
-      if (by_dst.empty()) continue;
-      std::vector<std::pair<int, std::vector<std::pair<int, int>>>> ent(by_dst.begin(), by_dst.end());
-      std::stable_sort(ent.begin(), ent.end(), [](const auto& x, const auto& y) { return x.second.size() > y.second.size(); });
-      for (size_t e0 = 0; e0 < ent.size(); e0 += 64) {
-        const size_t e1 = std::min(ent.size(), e0 + 64);
-        int nq = 0;
-        for (size_t e = e0; e < e1; e++) nq = std::max(nq, (int)ent[e].second.size());
-        if (nq > 7) { err = "more than seven sibling subtrees under one dof are not supported by the factorisation schedule"; return false; }
-        const int off = (int)ftab.size() / 64;
-        if (off > 65535) { err = "factorisation schedule too large"; return false; }
-        for (int ln = 0; ln < 64; ln++) ftab.push_back(e0 + ln < e1 ? lds_addr(ent[e0 + ln].first) : pad_dump);
-        for (int q = 0; q < nq; q++) {
-          for (int ln = 0; ln < 64; ln++) { bool h = e0 + ln < e1 && q < (int)ent[e0 + ln].second.size(); ftab.push_back(h ? ent[e0 + ln].second[q].first : (pad_zero | (pad_zero << 16))); }
-          for (int ln = 0; ln < 64; ln++) { bool h = e0 + ln < e1 && q < (int)ent[e0 + ln].second.size(); ftab.push_back(h ? ent[e0 + ln].second[q].second : pad_one); }
-        }
-        fround.push_back(off | (nq << 16) | ((e1 == ent.size() ? 1 : 0) << 20));
-      }
-    }
-    for (int i = 0; i < 3 * 64; i++) ftab.push_back(0);  // the kernel prefetches one round ahead
-    fround.push_back(0);
-    dm.nfround = (int)fround.size() - 1;
-    if (dm.nfround > 63) { err = "factorisation schedule has more than 63 rounds"; return false; }
-    fround.resize(64, 0);  // one descriptor per lane
-    dm.fpad_zero = pad_zero; dm.fpad_one = pad_one; dm.fpad_dump = pad_dump;
-  }
-  std::vector<int> desc_adr(nv + 1, 0), desc_pack;
-  for (int i = 0; i < nv; i++) {
-    desc_adr[i] = (int)desc_pack.size();
-    for (int k = i + 1; k < nv; k++) {
-      int pos = 1;
-      for (int a = m.dof_parentid[k]; a >= 0; a = m.dof_parentid[a], pos++)
-        if (a == i) { desc_pack.push_back(k | ((m.dof_Madr[k] + pos) << 8)); break; }
-    }
-  }
-  desc_adr[nv] = (int)desc_pack.size();
-  for (int i = 0; i < 4; i++) desc_pack.push_back(0);  // the half-solve reads four entries at a time
-  // the same lists transposed, [t][32 dofs], padded with a no-op entry (dof 0 times the factor storage's zero pad
-  // pair): lane i reads its t-th descendant with one coalesced load per t and no dependent walk
-  int maxdesc = 0;
-  for (int i = 0; i < nv; i++) maxdesc = std::max(maxdesc, desc_adr[i + 1] - desc_adr[i]);
-  std::vector<int> desc_t((size_t)std::max(1, maxdesc) * 32, 0 | (m.nM << 8));
-  for (int i = 0; i < nv; i++)
-    for (int t = desc_adr[i]; t < desc_adr[i + 1]; t++) desc_t[(size_t)(t - desc_adr[i]) * 32 + i] = desc_pack[t];
-  dm.ndesc_max = maxdesc;
   std::vector<int> mdense((size_t)32 * 32, m.nM);
   for (int i = 0; i < 32; i++) mdense[(size_t)i * 32 + i] = m.nM + 1;
   for (int e = 0; e < m.nM; e++) { mdense[(size_t)Mj[e] * 32 + Mi[e]] = e; mdense[(size_t)Mi[e] * 32 + Mj[e]] = e; }
   std::vector<int> mdense_c((size_t)16 * 64);
   for (int r = 0; r < 16; r++)
     for (int ln = 0; ln < 64; ln++) mdense_c[(size_t)r * 64 + ln] = mdense[(size_t)(ln & 31) * 32 + ((r & 3) + 8 * (r >> 2) + 4 * (ln >> 5))];
-  std::vector<int> chain((size_t)32 * (kMaxAnc + 1), 0);
-  for (int i = 0; i < nv; i++) {
-    int t = 0;
-    for (int c = i; c >= 0 && t <= kMaxAnc; c = m.dof_parentid[c], t++) chain[(size_t)i * (kMaxAnc + 1) + t] = c | (m.dof_Madr[c] << 8);
-  }
   // pairs
   std::vector<int> pair_dim;
   std::vector<double> pair_fr, pair_solref, pair_solimp, pair_margin, pair_gap;
@@ -379,8 +282,6 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     mrec[e] = Mi[e] | (Mj[e] << 8) | (m.dof_bodyid[Mi[e]] << 16);
     if (Mi[e] == Mj[e]) { mdiag[2 * e] = (float)m.dof_armature[Mi[e]]; mdiag[2 * e + 1] = (float)m.dof_damping[Mi[e]]; }
   }
-  for (int i = 0; i < nv; i++)
-    if (nanc[i] > kMaxAnc) { err = "kinematic chains deeper than " + std::to_string(kMaxAnc + 1) + " dofs are not supported"; return false; }
 
   // ---- offsets into the flat tables
   struct IO { const int** p; size_t o; };
@@ -390,9 +291,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
 #define TI(field, vec) io.push_back({&dm.field, T.addi(vec)})
 #define TF(field, vec) fo.push_back({&dm.field, T.addf(vec)})
   TI(body_treeid, treeid); TF(body_invweight0, m.body_invweight0); TF(tree_invmass, tree_invmass);
-  TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TF(qpos0, m.qpos0); TI(dof_jntid, m.dof_jntid); TI(dof_Madr, m.dof_Madr); TI(dof_nanc, nanc); TF(dof_damping, m.dof_damping); TI(M_j, Mj); TI(mrec, mrec);
-  TI(fround, fround); TI(ftab, ftab);
-  TI(desc_adr, desc_adr); TI(desc_pack, desc_pack); TI(desc_t, desc_t); TI(mdense, mdense); TI(mdense_c, mdense_c); TI(chain, chain);
+  TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TF(qpos0, m.qpos0); TI(dof_jntid, m.dof_jntid); TI(dof_Madr, m.dof_Madr); TF(dof_damping, m.dof_damping); TI(mrec, mrec);
+  TI(mdense, mdense); TI(mdense_c, mdense_c);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);

@@ -26,8 +26,6 @@ constexpr int kNefcMax = 63;    // constraint-row capacity per env (overflow -> 
 constexpr int kConStride = 20;  // floats per contact record in LDS
 constexpr int kDiagConStride = 16;
 constexpr int kCountStride = 8;  // ints per env in BatchPtrs::counts: ncon, nefc, niter, cost, self-collision flag, spare
-constexpr int kMaxAnc = 16;     // deepest dof chain the batched half-solve handles (strict ancestors per dof)
-constexpr int kFactorTop = 9;  // chain dofs at the top of the elimination tree factorised densely in registers
 constexpr int kBrecQuads = 18;  // float4s per level-ordered body record (see build_device_model)
 
 // contact record layout in LDS (floats)
@@ -55,28 +53,15 @@ struct DevModel {
   const float HB_CONST* qpos0;
   // dofs
   const float4 HB_CONST* drec;   // per dof: (jntid,bodyid,type,k) (treeid,armature,damping,stiffness) (qposadr,qpos_spring,-,-)
-  const int HB_CONST *dof_jntid, *dof_Madr, *dof_nanc;
+  const int HB_CONST *dof_jntid, *dof_Madr;
   const float HB_CONST* dof_damping;
   // sparse mass matrix (ancestor-chain layout of mjModel.dof_Madr)
   const int HB_CONST* mrec;      // per entry: i | j << 8 | body(i) << 16
   const float2 HB_CONST* mdiag;  // per entry: (armature, damping) on the diagonal, 0 elsewhere
-  const int HB_CONST* M_j;       // column dof of each entry (= the ancestors of the row dof, in chain order)
-  // L^T D L schedule by elimination-tree level, in rounds of <= 64 destination entries:
-  // fround[r] = table offset / 64 | contributions << 16 | sync-after << 20; ftab block of a round is
-  // dst[64], then (lo[64], hi[64]) per contribution: lo = src | tmp << 16, hi = Mkk, absolute LDS byte
-  // addresses of {M, H} pairs; fpad_*: the zero / one / dump pad pairs behind the matrix
-  const int HB_CONST* fround;
-  const int HB_CONST* ftab;
-  int nfround, fpad_zero, fpad_one, fpad_dump;
-  int ftop_n, ftop_adr[kFactorTop];  // dense tail of the factorisation: chain dofs root-first, address of each one's row
-  const int HB_CONST *desc_adr, *desc_pack;  // descendants of each dof: k | address of L[k,i] << 8
-  const int HB_CONST* desc_t;    // the same, transposed and padded: [ndesc_max][32]
-  int ndesc_max;
-  // Newton solver: dense view of the sparse mass matrix, [32 columns j][32 rows i] -> index of the {M, H} pair holding
+  // dense view of the sparse mass matrix (both solvers eliminate it on the matrix cores): [32 columns j][32 rows i] -> index of the {M, H} pair holding
   // M(i, j) (nM: the zero pad pair, nM + 1: the one pad pair = identity beyond nv)
   const int HB_CONST* mdense;
   const int HB_CONST* mdense_c;  // the same view in the MFMA accumulator layout: [16 registers][64 lanes]
-  const int HB_CONST* chain;     // per dof, kMaxAnc+1 entries: chain dof c_t | Madr[c_t] << 8 (c_0 = the dof itself)
   // geoms
   const int HB_CONST *geom_type, *geom_bodyid;
   const float HB_CONST *geom_size, *geom_pos, *geom_quat, *geom_rbound;
@@ -106,7 +91,7 @@ struct DevModel {
   int obs_root_body, obs_root_dofadr, obs_root_qadr;
   const int HB_CONST* obs_src;  // [nobs - 3]: state-record offset each copied observation entry comes from (-1: zero)
   // LDS layout (float offsets per env) — persistent region
-  int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qLD, o_dinv, o_dsqrtinv, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
+  int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qLD, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
   // region A (dynamics scratch)
   int o_xpos, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cvel;
   // region B (constraints), aliases region A: contacts, C rows, row meta (later W), forces

@@ -23,11 +23,7 @@ namespace hb {
 // Diagnostic build only (-DHB_STAMPS): per-phase cycle stamps of the last step, written to
 // BatchPtrs::diag_contact's tail is NOT used; stamps go to their own buffer P.stamps.
 #ifdef HB_STAMPS
-#ifdef HB_PROBE_FACTOR  /* experiment: slots 6 and 7 are written inside factor_ld (after the rounds, after the dense tail) */
-#define HB_STAMP(i) do { if ((i) != 6 && (i) != 7 && lane == 0 && P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps_[i] = t_; } } while (0)
-#else
 #define HB_STAMP(i) do { if (lane == 0 && P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps_[i] = t_; } } while (0)
-#endif
 #else
 #define HB_STAMP(i) do {} while (0)
 #endif
@@ -330,142 +326,6 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   return d0 + y * (d1 - d0);
 }
 
-// max(v, lo) per component as one bare v_max_f32 each (values come straight from LDS: the builtin forms add a
-// canonicalising v_max per input; a NaN here is caught by mj_checkAcc either way)
-__device__ __forceinline__ f32x2 floor2(f32x2 v, float lo) {
-  f32x2 r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r.x) : "v"(v.x), "v"(lo));
-  asm("v_max_f32 %0, %1, %2" : "=v"(r.y) : "v"(v.y), "v"(lo));
-  return r;
-}
-
-// dense L^T D L of the chain at the top of the elimination tree, in registers (see factor_ld).  GUARD: the chain
-// is shorter than kFactorTop and rows >= nt are skipped.
-template <bool GUARD>
-__device__ __forceinline__ void factor_top(DevModelRef M, f32x2* LD, int nt, int lane) {
-  f32x2 A[kFactorTop * (kFactorTop + 1) / 2];  // (a, b), a >= b, at a(a+1)/2 + b; a = 0 is the root dof
-#pragma unroll
-  for (int a = 0; a < kFactorTop; a++) {
-    const int adr = M.ftop_adr[a];
-#pragma unroll
-    for (int b = 0; b <= a; b++) A[a * (a + 1) / 2 + b] = (!GUARD || a < nt) ? LD[adr + (a - b)] : (f32x2){0.f, 0.f};
-  }
-#pragma unroll
-  for (int k = kFactorTop - 1; k >= 1; k--) {
-    if (!GUARD || k < nt) {
-      const f32x2 d = floor2(A[k * (k + 1) / 2 + k], HB_MINVAL);
-      const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-#pragma unroll
-      for (int i = 0; i < k; i++) {
-        const f32x2 tmp = A[k * (k + 1) / 2 + i] * r;
-#pragma unroll
-        for (int j = 0; j <= i; j++) A[i * (i + 1) / 2 + j] -= A[k * (k + 1) / 2 + j] * tmp;
-      }
-    }
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int a = 0; a < kFactorTop - 1; a++) {  // the deepest row is only ever a pivot row: unchanged
-      const int adr = M.ftop_adr[a];
-#pragma unroll
-      for (int b = 0; b <= a; b++)
-        if (!GUARD || a < nt - 1) LD[adr + (a - b)] = A[a * (a + 1) / 2 + b];
-    }
-  }
-  gsync();
-}
-
-// table words factor_ld starts from, fetched by the caller a phase early (two dependent vector loads and the
-// diagonal address would otherwise sit, exposed, at the head of the factorisation)
-struct FactorHead { int descs, dst, lo, hi, madr; };
-__device__ __forceinline__ FactorHead factor_head(DevModelRef M, int lane) {
-  FactorHead h;
-  h.descs = M.fround[lane];  // lane r holds round r (the host caps the schedule at 63 rounds plus a terminating zero word)
-  const int d0 = __builtin_amdgcn_readlane(h.descs, 0);
-  const int HB_CONST* T = M.ftab + lane + (d0 & 0xffff) * 64;
-  h.dst = T[0]; h.lo = T[64]; h.hi = T[128];
-  h.madr = lane < M.nv ? M.dof_Madr[lane] : 0;
-  return h;
-}
-
-__device__ __forceinline__ void factor_ld(DevModelRef M, float* lds, f32x2* LD, f32x2* dinv, float* dsqrtinv, int lane, const FactorHead& head, unsigned long long* probe = nullptr) {
-  // LD[e] = {entry of M, entry of H}: the two matrices share every index and ride the packed fp32
-  // instructions (v_pk_mul/v_pk_fma_f32, ds_read_b64) as one.
-  //
-  // Elimination by levels of the dof tree: pivots whose descendants are all done (both legs, both arms, ...)
-  // are eliminated together.  The work item is a destination entry of an ancestor row; it gathers the
-  // contributions  M'[k,j] M'[k,i] / D[k]  of the pivots k of this level that reach it, so no two lanes
-  // write the same entry (deterministic, no atomics).  Pivot rows are read unscaled and are final when read;
-  // the division of L by D is one pass at the end.
-  //
-  // The schedule comes as rounds of 64 entries with every address precomputed (absolute LDS byte addresses,
-  // field-major table: one coalesced dword per lane and field) and padded with no-op work, so the round body
-  // is straight-line: 2 unpack ops, 3 ds_read_b64, 2 v_med3, 2 v_rcp, 2 v_pk_mul per contribution (nearly
-  // always one), one read-modify-write of the destination.  The next round's words are fetched a round ahead.
-  auto pair_at = [&](int byte_addr) -> f32x2* { return reinterpret_cast<f32x2*>(reinterpret_cast<char*>(lds) + byte_addr); };
-  auto contribution = [&](int lo, int hi) -> f32x2 {
-    const f32x2 d = floor2(*pair_at(hi), HB_MINVAL);
-    const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    return *pair_at(lo & 0xffff) * (*pair_at((unsigned)lo >> 16) * r);
-  };
-  const int nr = M.nfround;
-  const int HB_CONST* T = M.ftab + lane;
-  // all round descriptors sit in one register (lane r holds round r): a round costs a v_readlane, not a
-  // scalar-memory round trip
-  const int descs = head.descs;
-  int desc = __builtin_amdgcn_readlane(descs, 0);
-  int dst = head.dst, lo = head.lo, hi = head.hi;
-  for (int r = 0; r < nr; r++) {
-    const int cur = desc, cdst = dst, clo = lo, chi = hi;
-    desc = __builtin_amdgcn_readlane(descs, r + 1);  // a zero word ends the list; the table is padded for the fetch it causes
-    {
-      const int HB_CONST* N = T + (desc & 0xffff) * 64;
-      dst = N[0]; lo = N[64]; hi = N[128];
-    }
-    f32x2 acc = contribution(clo, chi);
-    const int nq = (cur >> 16) & 7;
-    const int HB_CONST* C = T + (cur & 0xffff) * 64;
-    for (int q = 1; q < nq; q++) acc += contribution(C[(1 + 2 * q) * 64], C[(2 + 2 * q) * 64]);
-    *pair_at(cdst) -= acc;
-    if ((cur >> 20) & 1) gsync();
-  }
-  if (probe && lane == 0) probe[6] = __builtin_amdgcn_s_memtime();
-  // The chain at the top of the tree (the floating base and what follows it in single file): one pivot and a
-  // few entries per level, so instead of a wave-wide level each it is eliminated densely in registers - every
-  // lane runs the same unrolled elimination on broadcast reads, lane 0 writes the result back.  A full-length
-  // chain (the floating-base case) takes the branch-free instantiation.
-  const int nt = M.ftop_n;
-  if (nt == kFactorTop) factor_top<false>(M, LD, nt, lane);
-  else if (nt > 1) factor_top<true>(M, LD, nt, lane);
-  if (probe && lane == 0) probe[7] = __builtin_amdgcn_s_memtime();
-  if (lane < M.nv) {  // nv <= 32: one dof per lane
-    const f32x2 d = floor2(LD[head.madr], HB_MINVAL);
-    dinv[lane] = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    dsqrtinv[lane] = rsqrtf(d.x);
-  }
-  gsync();
-  // L[k,i] = M'[k,i] / D[k], four table words in flight per lane
-  for (int e0 = 0; e0 < M.nM; e0 += 4 * kGroup) {
-    int pk[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int e = e0 + u * kGroup + lane; pk[u] = e < M.nM ? M.mrec[e] : 0; }  // 0: i == j, skipped
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int e = e0 + u * kGroup + lane;
-      const int i = pk[u] & 255, j = (pk[u] >> 8) & 255;
-      if (i != j) LD[e] *= dinv[i];
-    }
-  }
-  gsync();
-}
-
-// W = L^-1 D^-1/2 (so that M^-1 = W W^T), dense row-major [32][kWs] in LDS.  L^-1 has the sparsity of L
-// (row i is supported on the ancestor chain of dof i) and from L^-1 L = I row i follows from its own
-// earlier entries and L along that chain:  Linv[i][c_t] = - sum_{s<t} Linv[i][c_s] L[c_s, c_t],
-// c_0 = i, c_1 = parent dof, ...  One lane per row, no cross-lane dependency; the chain (dof id and
-// address of its L row) comes packed from M.chain.  WHICH selects the M (0) or H (1) half of the
-// interleaved factor; this pass is bound by its 136 LDS reads per lane, so the halves are built when
-// needed (dword reads) rather than together (qword reads cost twice the LDS cycles).
 constexpr int kWs = 36;  // 16-byte aligned rows: a row times a vector is eight ds_read_b128 pairs (dot32)
 // one dof's motion axis record: s_cdof[8 d ..] = angular[3], -, linear[3], - (two ds_read_b128)
 __device__ __forceinline__ void ld_cdof(const float* s_cdof, int d, float out[6]) {
@@ -482,39 +342,6 @@ __device__ __forceinline__ float dot32(const float* row, const float* v) {
 #pragma unroll
   for (int q = 0; q < 8; q++) { const float4 x = a[q], y = b[q]; acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
   return acc;
-}
-
-// TRANS: also write the transpose WT (row c holds column c of W), so that W^T times a vector is a row product too
-template <int WHICH, bool TRANS>
-__device__ __forceinline__ void build_w(DevModelRef M, const f32x2* LD2, const f32x2* dinv, const float* dsqrtinv, float* W, float* WT, int lane) {
-  const float* LD = reinterpret_cast<const float*>(LD2) + WHICH;
-  for (int idx = lane; idx < 32 * kWs; idx += kGroup) { W[idx] = 0.f; if (TRANS) WT[idx] = 0.f; }
-  gsync();
-  if (lane < M.nv) {
-    const int i = lane;
-    const int n = M.dof_nanc[i];
-    const int HB_CONST* ch = M.chain + i * (kMaxAnc + 1);
-    int c[kMaxAnc + 1], ca[kMaxAnc + 1];
-    float u[kMaxAnc + 1];
-#pragma unroll
-    for (int t = 0; t <= kMaxAnc; t++) { const int pk = ch[t]; c[t] = pk & 255; ca[t] = 2 * (pk >> 8); }
-    u[0] = 1.f;
-#pragma unroll
-    for (int t = 1; t <= kMaxAnc; t++) {
-      float acc = 0.f;
-#pragma unroll
-      for (int sx = 0; sx < t; sx++) acc += LD[ca[sx] + 2 * (t - sx)] * u[sx];
-      u[t] = (t <= n) ? -acc : 0.f;
-    }
-#pragma unroll
-    for (int t = 0; t <= kMaxAnc; t++)
-      if (t <= n) {
-        const float w = u[t] * (WHICH ? sqrtf(dinv[c[t]].y) : dsqrtinv[c[t]]);
-        W[i * kWs + c[t]] = w;
-        if (TRANS) WT[c[t] * kWs + i] = w;
-      }
-  }
-  gsync();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -779,7 +606,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
   // PGS instantiation of dense order <= 28: M^-1 = W W' from an elimination on the matrix cores instead of the sparse
   // L'DL schedule (which stays for 29..32 dofs)
-  constexpr bool kDensePgs = SOLVER == 0;  // (both dense orders)
   extern __shared__ float lds[];
   const int lane0 = threadIdx.x;
   int lane = lane0;
@@ -800,10 +626,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   float* s_gaxis = lds + M.o_gaxis;
   float* s_scom = lds + M.o_scom;
   float* s_cdof = lds + M.o_cdof;
-  // {M, H = M + h*diag(damping)} interleaved: assembled, factorised in place (L and D), later L | W_H
+  // {M, H = M + h*diag(damping)} interleaved, in the sparse dof-ancestor layout: assembled once per step, read as dense views
   f32x2* s_qLD = reinterpret_cast<f32x2*>(lds + M.o_qLD);
-  f32x2* s_dinv = reinterpret_cast<f32x2*>(lds + M.o_dinv);  // {1/D, 1/D_H}
-  float* s_dsqrtinv = lds + M.o_dsqrtinv;
   float* s_smooth = lds + M.o_smooth;  // qfrc_smooth
   float* s_v0 = lds + M.o_vec0;        // scratch dof vectors
   float* s_v1 = lds + M.o_vec1;
@@ -845,9 +669,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 #ifdef HB_STAMPS
   unsigned long long stamps_[16] = {0};
 #endif
-  // pad pairs of the factorisation schedule (zero, one, dump), behind the matrix; never written again except
-  // the dump slot, which only ever has zero subtracted from it
-  if (lane < 6) s_qLD[M.nM + (lane >> 1)][lane & 1] = (lane >> 1) == 1 ? 1.f : 0.f;
+  // pad pairs behind the matrix (zero, one: what the dense views read outside the sparsity pattern / beyond nv); never written again
+  if (lane < 4) s_qLD[M.nM + (lane >> 1)][lane & 1] = (lane >> 1) == 1 ? 1.f : 0.f;
   // the dof vectors are read 32 wide (dot32): their tails beyond nv stay zero for the whole launch
   if (lane < 32) { s_v0[lane] = 0.f; s_v1[lane] = 0.f; s_v2[lane] = 0.f; }
   gsync();
@@ -1217,8 +1040,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     }
     HB_STAMP(4);
     // ---------------------------------------------------------------- qM from the composite inertias
-    FactorHead fhead;
-    if constexpr (SOLVER == 0 && !kDensePgs) fhead = factor_head(M, lane);
     for (int e = lane; e < M.nM; e += kGroup) {
       const int pk = M.mrec[e];  // i | j << 8 | body(i) << 16
       const float2 ad = M.mdiag[e];  // (armature, damping) on diagonal entries, 0 elsewhere
@@ -1237,21 +1058,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       ld_cdof(s_cdof, j, cj);
       for (int t = 0; t < 6; t++) sacc += cj[t] * buf[t];
       sacc += (dr && i == j) ? dr[DL.o_arm + i] : ad.x;
-      // H = M + h diag(damping): matrix of the implicit-damping Euler solve (mj_Euler), factorised alongside M
+      // H = M + h diag(damping): matrix of the implicit-damping Euler solve (mj_Euler), kept beside M
       s_qLD[e] = {sacc, sacc + (eulerdamp ? M.timestep * ad.y : 0.f)};
     }
     gsync();
     HB_STAMP(5);
-    // ---------------------------------------------------------------- mj_factorM
-    // (the Newton instantiation and the dense PGS one leave the sparse matrix as assembled)
-    if constexpr (SOLVER == 0 && !kDensePgs) {
-#if defined(HB_STAMPS) && defined(HB_PROBE_FACTOR)
-      factor_ld(M, lds, s_qLD, s_dinv, s_dsqrtinv, lane, fhead, P.stamps ? stamps_ : nullptr);
-#else
-      factor_ld(M, lds, s_qLD, s_dinv, s_dsqrtinv, lane, fhead);
-#endif
-    }
-
+    // (mj_factorM: the assembled sparse matrix stays as it is; both solvers eliminate a dense view of it on the matrix cores later)
     HB_STAMP(6);
     // ---------------------------------------------------------------- qfrc_bias, mj_passive, mj_fwdActuation -> qfrc_smooth
     for (int d = lane; d < nv; d += kGroup) {
@@ -1608,7 +1420,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // rows 0..nefc-1 are constraint rows, row nefc is qfrc_smooth (-> y = D^-1/2 L^-T qfrc_smooth).
     // 32-row tiles x 32 dof columns x K = 32 on the matrix cores; A operands are preloaded so the
     // product can be written back over J in place.
-    if constexpr (kDensePgs) {
+    {
+      // M^-1 = W W', W = T' D^-1/2 out of the elimination of the dense view of M on the matrix cores
       // (lane id re-materialised: keeps the masks and addresses of this stage from being computed, and held, phases early)
       int lw;
       asm volatile("v_mov_b32 %0, %1" : "=v"(lw) : "v"(lane0));
@@ -1616,8 +1429,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       sym_factor_mfma<NDENSE / 2>(load_sym_pairs<0>(M, s_qLD, lw), T, S, lw);
       store_w_rows(s_W, kWs, T, S, lw);
       gsync();
-    } else {
-      build_w<0, false>(M, s_qLD, s_dinv, s_dsqrtinv, s_W, nullptr, lane);
     }
     {
       const int col = lane & 31, half = lane >> 5;
@@ -1784,48 +1595,22 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     gsync();
     HB_STAMP(13);
     // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = W (y + s)
-    // qfrc_constraint = L^T D^1/2 s is formed only for callers that read the joint torques (the env adapter's
-    // reward): the integrator does not need it (see mj_Euler below).
     const bool want_qfrc = P.qfrc_out != nullptr;
     for (int k = lane; k < nv; k += kGroup) {
       float sacc = 0.f;
       for (int i = 0; i < nefc; i++) sacc += s_force[i] * s_C[i * cs + k];
-      if constexpr (!kDensePgs) { if (want_qfrc) s_v1[k] = sacc / s_dsqrtinv[k]; }  // D^1/2 s
-      s_v2[k] = yv[k] + sacc;                          // y + s
+      s_v2[k] = yv[k] + sacc;  // y + s
     }
     gsync();
-    {
-      float qacc_i = 0.f;
-      if (lane < nv) {
-        qacc_i = dot32(s_W + lane * kWs, s_v2);
-        if constexpr (!kDensePgs) {
-          if (want_qfrc) {
-            float acc = s_v1[lane];
-            // descendants of this dof from the transposed, padded table: every load is independent of the others
-            // (eight in flight), no per-lane list walk
-            const int nd = M.ndesc_max;
-            for (int t = 0; t < nd; t += 8) {
-              int pk[8];
-#pragma unroll
-              for (int q = 0; q < 8; q++) pk[q] = (t + q < nd) ? M.desc_t[(t + q) * 32 + lane] : (M.nM << 8);
-#pragma unroll
-              for (int q = 0; q < 8; q++) acc += s_qLD[pk[q] >> 8].x * s_v1[pk[q] & 255];
-            }
-            P.qfrc_out[(size_t)env * nv + lane] = s_smooth[lane] + acc;  // qfrc_smooth + qfrc_constraint
-          }
-        }
-        s_v0[lane] = qacc_i;
-      }
-    }
+    if (lane < nv) s_v0[lane] = dot32(s_W + lane * kWs, s_v2);
     gsync();
-    if constexpr (kDensePgs) {
-      // qfrc_smooth + qfrc_constraint = M qacc (the dual finish defines qacc that way); M is intact in the sparse pairs
-      if (want_qfrc && lane < nv) {
-        float acc = 0.f;
+    // qfrc_smooth + qfrc_constraint = M qacc (the dual finish defines qacc that way; M is intact in the sparse pairs): formed
+    // only for callers that read the joint torques (the env adapter's reward); the integrator does not need it (mj_Euler below)
+    if (want_qfrc && lane < nv) {
+      float acc = 0.f;
 #pragma unroll 8
-        for (int j = 0; j < 32; j++) acc = __builtin_fmaf(s_qLD[M.mdense[j * 32 + lane]].x, j < nv ? s_v0[j] : 0.f, acc);
-        P.qfrc_out[(size_t)env * nv + lane] = acc;
-      }
+      for (int j = 0; j < 32; j++) acc = __builtin_fmaf(s_qLD[M.mdense[j * 32 + lane]].x, j < nv ? s_v0[j] : 0.f, acc);
+      P.qfrc_out[(size_t)env * nv + lane] = acc;
     }
     } else {
       // ---------------------------------------------------------------- mj_fwdConstraint, Newton solver (mj_solNewton)
@@ -2067,7 +1852,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       // which needs neither the right-hand side nor qfrc_constraint: only qacc and the damping vector.
       for (int i = lane; i < nv; i += kGroup) s_warm[i] = s_v0[i];  // qacc_warmstart <- qacc
       if (eulerdamp) {
-        if constexpr (kDensePgs) {
+        if constexpr (SOLVER == 0) {
           // H = M + h B from the H halves of the assembled pairs, eliminated on the matrix cores with h B qacc as the
           // right-hand side column
           int le;
@@ -2100,22 +1885,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             if (le < nv) s_v2[le] = s_v0[le] - q;
             gsync();
           }
-        } else if constexpr (SOLVER == 0) {
-          // H^-1 = W_H W_H^T; W_H and its transpose are built in the (now dead) C rows
-          float* WH = s_C;
-          float* WHT = s_C + 32 * kWs;  // runs on into the (dead) row-meta / W area behind C: the host checks the room
-          if (lane < nv) s_v2[lane] = M.timestep * M.dof_damping[lane] * s_v0[lane];  // h B qacc
-          build_w<1, true>(M, s_qLD, s_dinv, s_dsqrtinv, WH, WHT, lane);  // (its barriers also publish s_v2)
-          float p = 0.f;
-          if (lane < nv) p = dot32(WHT + lane * kWs, s_v2);  // W_H^T (h B qacc)
-          gsync();
-          if (lane < nv) s_v1[lane] = p;
-          gsync();
-          float q = 0.f;
-          if (lane < nv) q = dot32(WH + lane * kWs, s_v1);
-          gsync();
-          if (lane < nv) s_v2[lane] = s_v0[lane] - q;
-          gsync();
         } else {
           // dense: H = M + h B from the H halves of the assembled pairs, Cholesky in registers; the right-hand side
           // h B qacc + grad (grad = M qacc - qfrc_smooth - qfrc_constraint, the Newton residual: qfrc_smooth + qfrc_constraint

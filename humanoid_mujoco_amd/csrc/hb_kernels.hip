@@ -679,6 +679,20 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // re-materialise the lane id every step: keeps per-lane table addresses and loads inside the step
     // instead of hoisted out of the rollout loop into long-lived (spilled) registers
     asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0) : "memory");
+    // Lane l owns body slot l+1 (level order) for the whole step: its record is fetched once, here,
+    // and stays in registers through the tree passes (no table loads inside the level loops).
+    // (requested first thing in the step: in a one-step launch the records then travel together with the state)
+    const bool bl = lane + 1 < nb;
+    float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, bp = q0, bq = q0, ip = q0, ch0 = q0, ch1 = q0;
+    float4 JA[3], JB[3], JC[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) { JA[jj] = q0; JB[jj] = q0; JC[jj] = q0; }
+    if (bl) {
+      const float4 HB_CONST* R = M.brec + (size_t)(lane + 1) * kBrecQuads;
+      q0 = R[0]; q1 = R[1]; bp = R[2]; bq = R[3]; ip = R[4]; ch0 = R[7]; ch1 = R[8];
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) { JA[jj] = R[9 + 3 * jj]; JB[jj] = R[10 + 3 * jj]; JC[jj] = R[11 + 3 * jj]; }
+    }
     HB_STAMP(0);
     // ---------------------------------------------------------------- controls
     if (P.ctrl_mode == 2) {
@@ -714,19 +728,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       for (int i = 0; i < 9; i++) s_xmat[i] = (i % 4 == 0) ? 1.f : 0.f;
     }
     gsync();
-    // Lane l owns body slot l+1 (level order) for the whole step: its record is fetched once, here,
-    // and stays in registers through the tree passes (no table loads inside the level loops).
-    const bool bl = lane + 1 < nb;
-    float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, bp = q0, bq = q0, ip = q0, ch0 = q0, ch1 = q0;
-    float4 JA[3], JB[3], JC[3];
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) { JA[jj] = q0; JB[jj] = q0; JC[jj] = q0; }
-    if (bl) {
-      const float4 HB_CONST* R = M.brec + (size_t)(lane + 1) * kBrecQuads;
-      q0 = R[0]; q1 = R[1]; bp = R[2]; bq = R[3]; ip = R[4]; ch0 = R[7]; ch1 = R[8];
-#pragma unroll
-      for (int jj = 0; jj < 3; jj++) { JA[jj] = R[9 + 3 * jj]; JB[jj] = R[10 + 3 * jj]; JC[jj] = R[11 + 3 * jj]; }
-    }
     const int myb = __float_as_int(q0.x), myp = __float_as_int(q0.y), myjn = __float_as_int(q0.z), myja = __float_as_int(q0.w);
     const int mylevel = bl ? (__float_as_int(q1.x) & 255) : -1, mycn = __float_as_int(q1.w);
     const int myanc2 = (__float_as_int(q1.x) >> 8) & 255, myanc4 = (__float_as_int(q1.x) >> 16) & 255, myanc8 = (__float_as_int(q1.x) >> 24) & 255;

@@ -296,7 +296,9 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
-  TI(pair_geom1, m.pair_geom1); TI(pair_geom2, m.pair_geom2); TI(pair_dim, pair_dim);
+  std::vector<int> pair_self;  // both geoms of the pair on the robot (neither on the world body)
+  for (int p = 0; p < m.npair; p++) pair_self.push_back(m.geom_bodyid[m.pair_geom1[p]] != 0);
+  TI(pair_geom1, m.pair_geom1); TI(pair_geom2, m.pair_geom2); TI(pair_dim, pair_dim); TI(pair_self, pair_self);
   TF(pair_fricab, pair_fricab);
   TF(pair_friction, pair_fr); TF(pair_solref, pair_solref); TF(pair_solimp, pair_solimp); TF(pair_margin, pair_margin); TF(pair_gap, pair_gap);
   TI(lim_kind, lim_kind); TI(lim_id, lim_id); TI(lim_side, lim_side);
@@ -345,7 +347,20 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
       trec[(size_t)t * 12 + 4 + w] = fi(wrap_qposadr[a]);
       trec[(size_t)t * 12 + 8 + w] = fi(wrap_dofadr[a]);
     }
-  size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec), o_crec = T.addraw(crec), o_trec = T.addraw(trec);
+  // per limit candidate, everything mj_instantiateLimit needs of it in one 4-quad record (one round trip instead of the
+  // dependent walk candidate -> joint -> addresses):
+  // [0] kind, id, side, qpos address (joints)   [1] margin, range, solref[2]   [2] solimp[0..3]   [3] solimp[4], invweight, dof address (joints), -
+  std::vector<float> lrec((size_t)std::max(1, dm.nlimcand) * 16, 0.f);
+  for (int c = 0; c < dm.nlimcand; c++) {
+    float* r = &lrec[(size_t)c * 16];
+    const bool joint = lim_kind[c] == 0;
+    r[0] = fi(lim_kind[c]); r[1] = fi(lim_id[c]); r[2] = fi(lim_side[c]); r[3] = fi(joint ? m.jnt_qposadr[lim_id[c]] : 0);
+    r[4] = (float)lim_margin[c]; r[5] = (float)lim_range[c]; r[6] = (float)lim_solref[2 * c]; r[7] = (float)lim_solref[2 * c + 1];
+    for (int i = 0; i < 5; i++) r[8 + i] = (float)lim_solimp[5 * c + i];
+    r[13] = (float)lim_invw[c]; r[14] = fi(joint ? m.jnt_dofadr[lim_id[c]] : 0);
+  }
+  size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec), o_crec = T.addraw(crec), o_trec = T.addraw(trec),
+         o_lrec = T.addraw(lrec);
 
   // ---- upload
   if (hipMalloc((void**)&D.d_int, T.iv.size() * sizeof(int)) != hipSuccess || hipMalloc((void**)&D.d_flt, T.fv.size() * sizeof(float)) != hipSuccess ||
@@ -361,6 +376,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.prec = reinterpret_cast<const float4*>(D.d_flt + o_prec);
   dm.crec = reinterpret_cast<const float4*>(D.d_flt + o_crec);
   dm.trec = reinterpret_cast<const float4*>(D.d_flt + o_trec);
+  dm.lrec = reinterpret_cast<const float4*>(D.d_flt + o_lrec);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);

@@ -69,12 +69,13 @@ struct DevModel {
   const int HB_CONST *geom_dataid, *hfield_nrow, *hfield_ncol, *hfield_adr;
   const float HB_CONST *hfield_size, *hfield_data;
   // collision candidates with pre-mixed contact parameters
-  const int HB_CONST *pair_geom1, *pair_geom2, *pair_dim;
+  const int HB_CONST *pair_geom1, *pair_geom2, *pair_dim, *pair_self;
   // per pair, 5 float4: [0] body1,body2,tree1,tree2 [1] dofmask1 (lo,hi), dofmask2 (lo,hi) [2] margin-gap, solref[2], invweight0 sum
   // [3] solimp[0..3] [4] solimp[4], condim
   const float4 HB_CONST* prec;
   // per pair, 3 float4 for mj_collision: [0] geom1, geom2, type1 | type2 << 8, margin [1] rbound1, rbound2, size1[0..1] [2] size2[0..1]
   const float4 HB_CONST* crec;
+  const float4 HB_CONST* lrec;  // per limit candidate: 4 quads (hb_api.cpp)
   const float HB_CONST* pair_fricab;  // per pair: (sliding friction of the floor geom if it is in the pair, else 0; the other geom's / the mixed one)
   const float HB_CONST *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
   // limit candidates: 2 per limited joint/tendon in constraint order (lower, upper)

@@ -1241,12 +1241,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     }
     ncon = uniform(ncon);
     // self collision (CPUEnv._check_self_collision, cpu_env.py:576-584): a contact whose geoms both belong to the robot
-    int selfcol = 0;
-    {
-      bool sc = false;
-      if (lane < ncon) sc = M.geom_bodyid[M.pair_geom1[__float_as_int(s_con[lane * kConStride + C_PAIR])]] != 0;
-      selfcol = __any(sc) ? 1 : 0;
-    }
+    // (one table fetch, requested here and collected behind the limit rows)
+    bool selfc = false;
+    if (lane < ncon) selfc = M.pair_self[__float_as_int(s_con[lane * kConStride + C_PAIR])] != 0;
     gsync();
 
     HB_STAMP(8);
@@ -1260,11 +1257,14 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         bool active = false;
         float dist = 0.f, margin = 0.f;
         int side = 0, kind = 0, id = 0;
+        float4 l0 = {0.f, 0.f, 0.f, 0.f}, l1 = l0, l2 = l0, l3 = l0;
         if (c < M.nlimcand) {
-          kind = M.lim_kind[c]; id = M.lim_id[c]; side = M.lim_side[c];
-          margin = dr ? dr[DL.o_lmargin + c] : M.lim_margin[c];
-          float value = kind == 0 ? s_qpos[M.jnt_qposadr[id]] : s_tenlen[id];
-          dist = (float)side * ((dr ? dr[DL.o_lrange + c] : M.lim_range[c]) - value);
+          const float4 HB_CONST* LR = M.lrec + (size_t)c * 4;  // the candidate's whole record in one round trip
+          l0 = LR[0]; l1 = LR[1]; l2 = LR[2]; l3 = LR[3];
+          kind = __float_as_int(l0.x); id = __float_as_int(l0.y); side = __float_as_int(l0.z);
+          margin = dr ? dr[DL.o_lmargin + c] : l1.x;
+          float value = kind == 0 ? s_qpos[__float_as_int(l0.w)] : s_tenlen[id];
+          dist = (float)side * ((dr ? dr[DL.o_lrange + c] : l1.y) - value);
           active = dist < margin;
         }
         unsigned long long bal = __ballot(active);
@@ -1272,18 +1272,20 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         if (active && row < kNefcMax) {
           float* Jr = s_C + row * cs;
           for (int k = 0; k < cs; k++) Jr[k] = 0.f;
-          if (kind == 0) Jr[M.jnt_dofadr[id]] = (float)(-side);
+          if (kind == 0) Jr[__float_as_int(l3.z)] = (float)(-side);
           else for (int w = 0; w < M.tendon_num[id]; w++) Jr[M.wrap_dofadr[M.tendon_adr[id] + w]] = (float)(-side) * M.wrap_prm[M.tendon_adr[id] + w];
           float* e = s_efc + row;
           e[E_POS * kNefcMax] = dist; e[E_MARGIN * kNefcMax] = margin;
-          e[E_SOLREF0 * kNefcMax] = M.lim_solref[2 * c]; e[E_SOLREF1 * kNefcMax] = M.lim_solref[2 * c + 1];
-          for (int i = 0; i < 5; i++) e[(E_IMP0 + i) * kNefcMax] = M.lim_solimp[5 * c + i];
-          e[E_DA * kNefcMax] = M.lim_invweight[c]; e[E_DAFIRST * kNefcMax] = M.lim_invweight[c]; e[E_MU2 * kNefcMax] = 0.f;
+          e[E_SOLREF0 * kNefcMax] = l1.z; e[E_SOLREF1 * kNefcMax] = l1.w;
+          e[(E_IMP0 + 0) * kNefcMax] = l2.x; e[(E_IMP0 + 1) * kNefcMax] = l2.y; e[(E_IMP0 + 2) * kNefcMax] = l2.z; e[(E_IMP0 + 3) * kNefcMax] = l2.w;
+          e[(E_IMP0 + 4) * kNefcMax] = l3.x;
+          e[E_DA * kNefcMax] = l3.y; e[E_DAFIRST * kNefcMax] = l3.y; e[E_MU2 * kNefcMax] = 0.f;
         }
         nefc += __popcll(bal);
       }
       if (nefc > kNefcMax) { status |= (1 << 2); nefc = kNefcMax; }
     }
+    const int selfcol = __any(selfc) ? 1 : 0;
     // (b) contacts: row base by prefix sum over contacts (1 row for condim 1, 4 for condim 3)
     if (constraints_on && contacts_on) {
       int myrows = 0, pairid = 0;

@@ -359,6 +359,17 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (int i = 0; i < 5; i++) r[8 + i] = (float)lim_solimp[5 * c + i];
     r[13] = (float)lim_invw[c]; r[14] = fi(joint ? m.jnt_dofadr[lim_id[c]] : 0);
   }
+  // per actuator, one 4-quad record: [0] ctrllimited, forcelimited, qpos address, dof address   [1] ctrlrange[2], gear, gain
+  // [2] biasprm[0..2], -   [3] forcerange[2], -, -
+  std::vector<float> arec((size_t)std::max(1, m.nu) * 16, 0.f);
+  for (int a = 0; a < m.nu; a++) {
+    float* r = &arec[(size_t)a * 16];
+    r[0] = fi(m.actuator_ctrllimited[a]); r[1] = fi(m.actuator_forcelimited[a]); r[2] = fi(act_qposadr[a]); r[3] = fi(act_dofadr[a]);
+    r[4] = (float)m.actuator_ctrlrange[2 * a]; r[5] = (float)m.actuator_ctrlrange[2 * a + 1]; r[6] = (float)m.actuator_gear[a]; r[7] = (float)m.actuator_gainprm[a];
+    for (int i = 0; i < 3; i++) r[8 + i] = (float)m.actuator_biasprm[3 * a + i];
+    r[12] = (float)m.actuator_forcerange[2 * a]; r[13] = (float)m.actuator_forcerange[2 * a + 1];
+  }
+  const size_t o_arec = T.addraw(arec);
   size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec), o_crec = T.addraw(crec), o_trec = T.addraw(trec),
          o_lrec = T.addraw(lrec);
 
@@ -377,6 +388,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.crec = reinterpret_cast<const float4*>(D.d_flt + o_crec);
   dm.trec = reinterpret_cast<const float4*>(D.d_flt + o_trec);
   dm.lrec = reinterpret_cast<const float4*>(D.d_flt + o_lrec);
+  dm.arec = reinterpret_cast<const float4*>(D.d_flt + o_arec);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);

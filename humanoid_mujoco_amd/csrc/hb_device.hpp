@@ -75,6 +75,7 @@ struct DevModel {
   const float4 HB_CONST* prec;
   // per pair, 3 float4 for mj_collision: [0] geom1, geom2, type1 | type2 << 8, margin [1] rbound1, rbound2, size1[0..1] [2] size2[0..1]
   const float4 HB_CONST* crec;
+  const float4 HB_CONST* arec;  // per actuator: 4 quads (hb_api.cpp)
   const float4 HB_CONST* lrec;  // per limit candidate: 4 quads (hb_api.cpp)
   const float HB_CONST* pair_fricab;  // per pair: (sliding friction of the floor geom if it is in the pair, else 0; the other geom's / the mixed one)
   const float HB_CONST *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *pair_gap;

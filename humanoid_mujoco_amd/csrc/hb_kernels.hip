@@ -693,6 +693,13 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 #pragma unroll
       for (int jj = 0; jj < 3; jj++) { JA[jj] = R[9 + 3 * jj]; JB[jj] = R[10 + 3 * jj]; JC[jj] = R[11 + 3 * jj]; }
     }
+    // likewise what the passes right behind the kinematics read per geom / per dof (at most 64 geoms, 32 dofs: one each per lane)
+    int pf_gbody = 0;
+    V3 pf_gpos = {0.f, 0.f, 0.f};
+    Q4 pf_gquat = {1.f, 0.f, 0.f, 0.f};
+    if (lane < M.ngeom) { pf_gbody = M.geom_bodyid[lane]; pf_gpos = ld3(M.geom_pos + 3 * lane); pf_gquat = ldq(M.geom_quat + 4 * lane); }
+    float4 pf_dA = {0.f, 0.f, 0.f, 0.f}, pf_dB = pf_dA;
+    if (lane < nv) { pf_dA = M.drec[3 * lane]; pf_dB = M.drec[3 * lane + 1]; }
     HB_STAMP(0);
     // ---------------------------------------------------------------- controls
     if (P.ctrl_mode == 2) {
@@ -813,10 +820,10 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     gsync();
     HB_STAMP(2);
     // geoms: world position and z axis
-    for (int g = lane; g < M.ngeom; g += kGroup) {
-      int b = M.geom_bodyid[g];
-      st3(s_gpos + 3 * g, ld3(s_xpq + 8 * b) + mrot(s_xmat + 9 * b, ld3(M.geom_pos + 3 * g)));
-      Q4 q = qmul(ldq(s_xpq + 8 * b + 4), ldq(M.geom_quat + 4 * g));
+    if (lane < M.ngeom) {
+      const int g = lane, b = pf_gbody;
+      st3(s_gpos + 3 * g, ld3(s_xpq + 8 * b) + mrot(s_xmat + 9 * b, pf_gpos));
+      Q4 q = qmul(ldq(s_xpq + 8 * b + 4), pf_gquat);
       st3(s_gaxis + 3 * g, {2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z});
     }
     // ---------------------------------------------------------------- mj_comPos
@@ -849,8 +856,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       res[6] = mass * dif.x; res[7] = mass * dif.y; res[8] = mass * dif.z; res[9] = mass;
     }
     if (lane < 10) s_cinert[lane] = 0.f;
-    for (int d = lane; d < nv; d += kGroup) {
-      const float4 dA = M.drec[3 * d], dB = M.drec[3 * d + 1];
+    if (lane < nv) {
+      const int d = lane;
+      const float4 dA = pf_dA, dB = pf_dB;
       const int j = __float_as_int(dA.x), b = __float_as_int(dA.y), type = __float_as_int(dA.z), k = __float_as_int(dA.w);
       V3 off = ld3(s_scom + 3 * __float_as_int(dB.x)) - ld3(s_xanchor + 3 * j);
       V3 ang = {0.f, 0.f, 0.f}, lin = {0.f, 0.f, 0.f};
@@ -1021,6 +1029,10 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       Op[3] = {f0[2] + f2[2], f0[3] + f2[3], f0[4] + f2[4], f0[5] + f2[5]};
     }
     if (lane < 16) s_if[lane] = lane < 10 ? s_cinert[lane] : 0.f;  // world body
+    // first round of mass-matrix entry words, requested ahead of the sweep that produces what they index
+    int pf_pk = 0;
+    float2 pf_ad = {0.f, 0.f};
+    if (lane < M.nM) { pf_pk = M.mrec[lane]; pf_ad = M.mdiag[lane]; }
     gsync();
     // mj_crb and the mj_rne backward pass share one sweep up the tree: children into parents (pull form)
     for (int L = M.nlevel - 2; L >= 1; L--) {
@@ -1041,9 +1053,14 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     }
     HB_STAMP(4);
     // ---------------------------------------------------------------- qM from the composite inertias
+    // dof records of the bias pass and the actuator records: requested here, used behind the mass matrix
+    float4 pf_bA = {0.f, 0.f, 0.f, 0.f}, pf_bB = pf_bA, pf_bC = pf_bA, pf_a0 = pf_bA, pf_a1 = pf_bA, pf_a2 = pf_bA, pf_a3 = pf_bA;
+    if (lane < nv) { pf_bA = M.drec[3 * lane]; pf_bB = M.drec[3 * lane + 1]; pf_bC = M.drec[3 * lane + 2]; }
+    if (lane < M.nu) { const float4 HB_CONST* AR4 = M.arec + (size_t)lane * 4; pf_a0 = AR4[0]; pf_a1 = AR4[1]; pf_a2 = AR4[2]; pf_a3 = AR4[3]; }
     for (int e = lane; e < M.nM; e += kGroup) {
-      const int pk = M.mrec[e];  // i | j << 8 | body(i) << 16
-      const float2 ad = M.mdiag[e];  // (armature, damping) on diagonal entries, 0 elsewhere
+      const int pk = pf_pk;  // i | j << 8 | body(i) << 16
+      const float2 ad = pf_ad;  // (armature, damping) on diagonal entries, 0 elsewhere
+      if (e + kGroup < M.nM) { pf_pk = M.mrec[e + kGroup]; pf_ad = M.mdiag[e + kGroup]; }  // the next round's, one ahead
       const int i = pk & 255, j = (pk >> 8) & 255, bi = pk >> 16;
       float buf[6], cd[6];
       ld_cdof(s_cdof, i, cd);
@@ -1067,8 +1084,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // (mj_factorM: the assembled sparse matrix stays as it is; both solvers eliminate a dense view of it on the matrix cores later)
     HB_STAMP(6);
     // ---------------------------------------------------------------- qfrc_bias, mj_passive, mj_fwdActuation -> qfrc_smooth
-    for (int d = lane; d < nv; d += kGroup) {
-      const float4 dA = M.drec[3 * d], dB = M.drec[3 * d + 1], dC = M.drec[3 * d + 2];
+    if (lane < nv) {
+      const int d = lane;
+      const float4 dA = pf_bA, dB = pf_bB, dC = pf_bC;
       float bias = 0.f;
       const int b = __float_as_int(dA.y);
       float cdd[6];
@@ -1084,13 +1102,15 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     gsync();
     if (!(M.disableflags & (1 << 10))) {
       for (int a = lane; a < M.nu; a += kGroup) {
+        if (a != lane) { const float4 HB_CONST* AR4 = M.arec + (size_t)a * 4; pf_a0 = AR4[0]; pf_a1 = AR4[1]; pf_a2 = AR4[2]; pf_a3 = AR4[3]; }  // (more than 64 actuators)
+        const int qa = __float_as_int(pf_a0.z), da = __float_as_int(pf_a0.w);
         float ctrl = s_ctrl[a];
-        if (M.act_ctrllimited[a] && !(M.disableflags & (1 << 7))) ctrl = clampf(ctrl, M.act_ctrlrange[2 * a], M.act_ctrlrange[2 * a + 1]);
-        float gear = M.act_gear[a];
-        const float gain = dr ? dr[DL.o_gain + a] : M.act_gain[a], bias1 = dr ? dr[DL.o_bias1 + a] : M.act_bias[3 * a + 1];
-        float force = gain * ctrl + M.act_bias[3 * a] + bias1 * gear * s_qpos[M.act_qposadr[a]] + M.act_bias[3 * a + 2] * gear * s_qvel[M.act_dofadr[a]];
-        if (M.act_forcelimited[a]) force = clampf(force, dr ? dr[DL.o_frc + 2 * a] : M.act_forcerange[2 * a], dr ? dr[DL.o_frc + 2 * a + 1] : M.act_forcerange[2 * a + 1]);
-        atomicAdd(&s_smooth[M.act_dofadr[a]], gear * force);
+        if (__float_as_int(pf_a0.x) && !(M.disableflags & (1 << 7))) ctrl = clampf(ctrl, pf_a1.x, pf_a1.y);
+        float gear = pf_a1.z;
+        const float gain = dr ? dr[DL.o_gain + a] : pf_a1.w, bias1 = dr ? dr[DL.o_bias1 + a] : pf_a2.y;
+        float force = gain * ctrl + pf_a2.x + bias1 * gear * s_qpos[qa] + pf_a2.z * gear * s_qvel[da];
+        if (__float_as_int(pf_a0.y)) force = clampf(force, dr ? dr[DL.o_frc + 2 * a] : pf_a3.x, dr ? dr[DL.o_frc + 2 * a + 1] : pf_a3.y);
+        atomicAdd(&s_smooth[da], gear * force);
       }
     }
     gsync();

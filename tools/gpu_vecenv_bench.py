@@ -50,3 +50,32 @@ if True:
             print("VecEnv.step_torch (%s): %d envs x %d steps in %.3f s -> %.3e env-steps/s (%.0f us/step; policy, env and physics on the GPU, no host transfer)"
                   % (label, N, T, dt, N * T / dt, 1e6 * dt / T))
             env.close()
+
+        # Two half-size envs, each with its policy on its own torch stream: the two obs -> policy -> step chains are
+        # independent, so one half's policy and env kernels run under the other half's physics (a closed loop over ONE
+        # batch cannot overlap anything with its own step).
+        H = N // 2
+        envs = [hb.VecEnv(model, H, 0, randomization_factor=1.0, target_z=10.0, max_time=2.0, seed=s) for s in (0, 1)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        w = torch.randn(48, 21, device="cuda") * 0.1
+        obs = []
+        for e in envs:
+            e.reset()
+            obs.append(torch.zeros(H, 48, device="cuda"))
+        torch.cuda.synchronize()
+        def sweep(n):
+            for t in range(n):
+                for k in (0, 1):
+                    with torch.cuda.stream(streams[k]):
+                        obs[k] = envs[k].step_torch(torch.tanh(obs[k] @ w))[0]
+        sweep(20)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sweep(T)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("VecEnv.step_torch, two half-size envs on two torch streams: 2 x %d envs x %d steps in %.3f s -> %.3e env-steps/s (%.0f us per step of both)"
+              % (H, T, dt, N * T / dt, 1e6 * dt / T))
+        for e in envs:
+            e.close()
+

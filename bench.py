@@ -3,28 +3,39 @@
 4096 envs per GPU, Halton random actions (BASELINE.json configs[1]).
 
 One "step" = one hb_step_dev call = one physics step of every env of this rank's batch, with
-state and controls already resident in HBM.  The timed loop runs with hb_batch_pipeline on: each call
-enqueues the batch as two env segments on two streams, so the slow tail of one step overlaps the
-next (same results, tests/test_gpu_parity.py::test_pipelined_stepping_is_bit_identical).  The roofline
-object is measured on a second, unpipelined leg (one 4096-block launch per step, HIP events on the
-launch stream) so that it is a per-launch figure comparable with the rocprofv3 kernel trace.  N>1: one process per GPU (torch.distributed over
-RCCL for the barrier and the max-over-ranks reduction only — the path has no data collective;
-envs shard by env_offset = rank * 4096), weak scaling.
+state and controls already resident in HBM.  Before anything is timed every env is rolled through
+PREROLL (600) untimed steps of the same workload, so that a short timed window (the driver runs
+--steps 20) samples the steady regime — the humanoids on the floor, about ten constraint rows per
+env — and not the contact-free fall that follows the reset.  The CPU leg times the same window.
+The timed loop runs with hb_batch_pipeline on: each call enqueues the batch as two env segments on
+two streams, so the slow tail of one step overlaps the next (same results,
+tests/test_gpu_parity.py::test_pipelined_stepping_is_bit_identical).  The roofline object is
+measured on a second, unpipelined leg (one 4096-block launch per step, HIP events on the launch
+stream) so that it is a per-launch figure comparable with the rocprofv3 kernel trace.
+
+Launching.  `python3 bench.py --gpus N`: with WORLD_SIZE unset the parent process — before it makes
+any HIP or torch call — starts N children of itself, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT set, the thread-per-device shape of simulation/mujoco/sample/testspeed.cc:
+165-183,203-210 as processes), relays rank 0's JSON line and exits non-zero if any child failed.
+Under torchrun (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) the
+environment already names the rank and the process just runs it.  Ranks use torch.distributed (RCCL)
+for the barrier and the max-over-ranks reduction only — the path has no data collective; envs shard
+by env_offset = rank * 4096, weak scaling.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
+PREROLL = 600                  # untimed steps from the reset before any measurement (the fall takes ~300)
 ALGO_BYTES_PER_ENV_STEP = 748  # SURVEY.md §8(d): fp32 x [read qpos 28 + qvel 27 + warmstart 27 + ctrl 21 + time 1; write 28+27+27+1]
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
@@ -36,27 +47,135 @@ def shard_range(n_total, world, rank):
     return lo, hi
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv, script=None, timeout=None):
+    """Start n child processes of this script, one rank each, and relay rank 0's stdout.
+
+    Called before the parent has touched HIP or torch (a process that has initialised the GPU must not
+    exec or fork GPU work).  Returns the exit code: 0 only if every child exited 0."""
+    script = script or os.path.abspath(__file__)
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        out = subprocess.PIPE if r == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=out))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()  # rank 0's pipe is drained while everybody runs (it prints one line at the very end)
+    rc = 0
+    t_end = None if timeout is None else time.time() + timeout
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes) or (t_end is not None and time.time() > t_end):
+            # one rank failed (or the run timed out): the others would wait for it at the rendezvous; stop exactly those processes
+            if not any(c not in (None, 0) for c in codes):
+                rc = 124
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            break
+        time.sleep(0.05)
+    own = [p.returncode for p in procs if p.returncode > 0]  # exit codes of ranks that failed by themselves (killed ones are negative)
+    for r, p in enumerate(procs):
+        if p.returncode != 0:
+            sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, p.returncode))
+            rc = rc or (own[0] if own else 1)
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def probe_libmujoco():
+    """Opportunistic probe promised by BASELINE.md §3 / SURVEY.md §8(d): is a MuJoCo already installed on this box?
+    Never installs or fetches anything.  Absent -> {"libmujoco": "absent"}; present -> version, and, when a model file
+    is reachable (HB_MUJOCO_XML, or the reference tree), real mj_step timing and one-step deltas on the golden states."""
+    import importlib.util
+    info = {"libmujoco": "absent"}
+    spec = None
+    try:
+        spec = importlib.util.find_spec("mujoco")
+    except Exception:
+        spec = None
+    try:
+        out = subprocess.run(["ldconfig", "-p"], capture_output=True, text=True, timeout=10).stdout
+        libs = [ln.split("=>")[-1].strip() for ln in out.splitlines() if "mujoco" in ln.lower()]
+    except Exception:
+        libs = []
+    if libs:
+        info = {"libmujoco": "shared library present", "libs": libs[:4]}
+    if spec is None:
+        return info
+    try:
+        import mujoco  # noqa: only reached when the package is already installed
+        import numpy as np
+        info = {"libmujoco": "python package present", "version": getattr(mujoco, "__version__", "?")}
+        xml = os.environ.get("HB_MUJOCO_XML") or "/root/reference/simulation/mujoco/model/humanoid/humanoid.xml"
+        if not os.path.exists(xml):
+            info["note"] = "no MJCF file reachable (set HB_MUJOCO_XML): timing and deltas skipped"
+            return info
+        m = mujoco.MjModel.from_xml_path(xml)
+        m.opt.solver, m.opt.iterations = 0, 50  # the benchmark configuration: PGS / 50 (mjSOL_PGS = 0)
+        d = mujoco.MjData(m)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "humanoid27_steps.npz"))
+        dq = dv = 0.0
+        for k in range(len(g["env"])):
+            mujoco.mj_resetData(m, d)
+            d.time = g["time"][k]; d.qpos[:] = g["qpos"][k]; d.qvel[:] = g["qvel"][k]; d.qacc_warmstart[:] = g["warm"][k]; d.ctrl[:] = g["ctrl"][k]
+            mujoco.mj_step(m, d)
+            dq = max(dq, float(np.abs(d.qpos - g["qpos1"][k]).max()))
+            dv = max(dv, float(np.abs(d.qvel - g["qvel1"][k]).max()))
+        info["one_step_delta_vs_golden"] = {"max_abs_dqpos": dq, "max_abs_dqvel": dv, "states": int(len(g["env"]))}
+        mujoco.mj_resetData(m, d)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 3.0:
+            for _ in range(200):
+                mujoco.mj_step(m, d)
+            n += 200
+        info["mj_step_per_s_one_core"] = n / (time.perf_counter() - t0)
+    except Exception as ex:  # a probe must never fail the benchmark
+        info["error"] = repr(ex)[:200]
+    return info
+
+
 def cpu_baseline(target_seconds=12.0):
-    """The oracle (kind "port") on this box's host cores, on a bounded sample of the same workload.
+    """The oracle (kind "port") on this box's host cores, on a bounded sample of the same workload AND the same
+    window as the GPU leg: every env is rolled through PREROLL untimed steps, then timed.
     Shape of simulation/mujoco/sample/testspeed.cc:203-210: shared model, a chunk of envs per thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     o = Oracle()
-    # calibration on a sample large enough to load every core, including the contact-rich later steps
+    # calibration: a few envs per core over the start of the window
+    _, _, _, rate = o.rollout_window(cores * 2, PREROLL, 100, cores)
+    # ~target_seconds of CPU work in all (pre-roll included): envs x (PREROLL + steps)
+    steps = 200
+    n_env = int(rate * target_seconds / (PREROLL + steps))
+    n_env = max(cores, min(ENVS_PER_GPU, (n_env // cores) * cores))
     t0 = time.perf_counter()
-    n, _, _ = o.rollout_threads(max(cores * 8, 256), 300, cores)
-    rate = n / (time.perf_counter() - t0)
-    # ~target_seconds of CPU work: the benchmark's batch (or a small multiple of it on many-core hosts), up to 1000 steps
-    steps = int(max(50, min(1000, rate * target_seconds / ENVS_PER_GPU)))
-    mult = int(min(4, max(1, rate * target_seconds // (ENVS_PER_GPU * steps))))
-    n_env = max(cores, (ENVS_PER_GPU * mult // cores) * cores)
-    t0 = time.perf_counter()
-    n, _, st = o.rollout_threads(n_env, steps, cores)
+    n, _, st, rate = o.rollout_window(n_env, PREROLL, steps, cores)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d steps of the same Halton workload, fp64 oracle/mjstep_oracle.c (CPU restatement, not libmujoco), %d threads, %.1f s"
-                      % (n_env, steps, cores, dt),
+    return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d timed steps after %d untimed pre-roll steps each (the GPU leg's window) of the same Halton workload, fp64 oracle/mjstep_oracle.c "
+                      "(CPU restatement, not libmujoco), %d threads, %.1f s in all; value = sum over threads of timed env-steps / that thread's timed seconds"
+                      % (n_env, steps, PREROLL, cores, dt),
             "mean_nefc": st["mean_nefc"]}
 
 
@@ -77,15 +196,23 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--preroll", type=int, default=PREROLL, help="untimed steps from the reset before any measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the second (single-launch rollout) measurement, e.g. under rocprofv3")
     ap.add_argument("--no-newton", action="store_true", help="skip the third measurement (same workload with the reference's default solver, Newton)")
     ap.add_argument("--no-pipeline", action="store_true", help="time the unpipelined step API (one launch per step) as `value`")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction only, no GPU work (CPU rehearsal of the N>1 path with HB_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU, started before this process touches HIP or torch
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs\n" % (args.gpus, world))
     dist = None
     backend = os.environ.get("HB_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on a box with fewer GPUs than ranks
     red_dev = "cpu"
@@ -101,11 +228,34 @@ def main():
             dist_.init_process_group(backend=backend)
         dist = dist_
 
-    import humanoid_mujoco_amd as hb
-    model = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm"))
+    def reduce_max(x):
+        if dist is None:
+            return x
+        import torch
+        tt = torch.tensor([x], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    K, W, PRE = args.steps, args.warmup, max(0, args.preroll)
     n_env = args.envs_per_gpu
     lo, hi = shard_range(n_env * world, world, rank)
     assert hi - lo == n_env
+
+    if args.dry_run:
+        if dist is not None:
+            dist.barrier()
+        elapsed = reduce_max(1e-3 * (1 + rank))
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "env-steps/sec (whole node), 27-DoF humanoid, 4096 envs/GPU", "dry_run": True, "value": None, "n_gpus": world,
+                              "steps": K, "warmup": W, "max_over_ranks_s": elapsed, "shard_of_last_rank": list(shard_range(n_env * world, world, world - 1))}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    import humanoid_mujoco_amd as hb
+    model = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm"))
     device = local_rank
     if backend != "nccl":
         import ctypes
@@ -113,13 +263,17 @@ def main():
         ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(ndev))
         device = local_rank % max(1, ndev.value)
     batch = hb.Batch(model, n_env, device)  # raises without a GPU: no CPU fallback
-    K, W = args.steps, args.warmup
     nu = model.nu
-    # controls for every timed step live in HBM, generated there (testspeed.cc:64-80)
+    # controls for every timed step live in HBM, generated there (testspeed.cc:64-80); step indices continue behind the pre-roll
     ctrl = batch.dev_alloc((K + W) * n_env * nu * 4)
-    batch.halton_ctrl_dev(K + W, 0, lo, ctrl)
-    batch.reset(perturb=True, env_offset=lo)
+    batch.halton_ctrl_dev(K + W, PRE, lo, ctrl)
     stride = n_env * nu * 4
+
+    def preroll(b):
+        b.reset(perturb=True, env_offset=lo)
+        if PRE > 0:
+            b.rollout_halton(PRE, 0, lo)  # untimed: every env through its fall, controls t = 0 .. PRE-1
+        b.sync()
 
     def barrier():
         batch.sync()  # the batch's own HIP stream(s)
@@ -129,6 +283,7 @@ def main():
                 import torch
                 torch.cuda.synchronize()  # an RCCL barrier is enqueued on a stream: wait for it on the host as well
 
+    preroll(batch)
     pipelined = not args.no_pipeline
     batch.pipeline(pipelined)
     for t in range(W):
@@ -142,10 +297,7 @@ def main():
     batch.sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = reduce_max(elapsed)
         dist.barrier()
     status = batch.status()
     nc, ne, ni = batch.counts()
@@ -155,7 +307,7 @@ def main():
     batch.pipeline(False)
     KR = min(K, 200)
     for t in range(5):
-        batch.step_dev(ctrl + (W + t) * stride)
+        batch.step_dev(ctrl + (W + min(t, K - 1)) * stride)
     batch.sync()
     batch.timer_start()
     for t in range(KR):
@@ -167,7 +319,7 @@ def main():
     # the shape of the reference's C++ harness simulation/mujoco/sample/testspeed.cc:84-103,203-210.
     elapsed_rollout = None
     if not args.no_rollout:
-        batch.reset(perturb=True, env_offset=lo)
+        preroll(batch)
         batch.rollout_dev(ctrl, W)
         barrier()
         t1 = time.perf_counter()
@@ -175,10 +327,7 @@ def main():
         batch.sync()
         elapsed_rollout = time.perf_counter() - t1
     if dist is not None and elapsed_rollout is not None:
-        import torch
-        tt = torch.tensor([elapsed_rollout], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed_rollout = float(tt.item())
+        elapsed_rollout = reduce_max(elapsed_rollout)
         dist.barrier()
 
     # Third measurement (N = 1 only), reported beside `value`: the same workload and step API with the solver the
@@ -189,7 +338,7 @@ def main():
         nm = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm"))
         nm.set_opt(solver=2, iterations=100)
         nb = hb.Batch(nm, n_env, device)
-        nb.reset(perturb=True, env_offset=lo)
+        preroll(nb)
         nb.pipeline(pipelined)
         for t in range(W):
             nb.step_dev(ctrl + t * stride)
@@ -199,10 +348,10 @@ def main():
             nb.step_dev(ctrl + t * stride)
         nb.sync()
         el = time.perf_counter() - t2
-        _, _, nit = nb.counts()
-        newton = {"value": n_env * K / el, "unit": "env-steps/s", "ms_per_step": 1e3 * el / K, "mean_iterations": float(nit.mean()),
+        _, nne, nit = nb.counts()
+        newton = {"value": n_env * K / el, "unit": "env-steps/s", "ms_per_step": 1e3 * el / K, "mean_iterations": float(nit.mean()), "mean_nefc": float(nne.mean()),
                   "envs_with_warnings": int((nb.status() != 0).sum()),
-                  "what": "same workload and step API, solver = Newton (mjOption default: what the reference's humanoid.xml runs), 100 iterations max, tolerance 1e-8"}
+                  "what": "same workload, window and step API, solver = Newton (mjOption default: what the reference's humanoid.xml runs), 100 iterations max, tolerance 1e-8"}
         nb.close()
 
     if rank == 0:
@@ -214,9 +363,11 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d parallel humanoid envs per GPU, Halton random actions, fp32, PGS<=50 iters tol 1e-8, dt 0.005, one mj_step of every env per hb_step_dev call%s"
-                                   % (n_env, " (pipelined: 2 env segments on 2 streams)" if pipelined else ""),
-                       "model": "27-DoF humanoid (assets/humanoid27.hbm)", "envs_per_gpu": n_env, "global_envs": n_env * world,
+            "config": {"workload": "configs[1]: %d parallel humanoid envs per GPU, Halton random actions, fp32, PGS<=50 iters tol 1e-8, dt 0.005, one mj_step of every env per "
+                                   "hb_step_dev call%s; every env pre-rolled %d untimed steps from the perturbed reset (steady regime: fallen humanoids, ~10 constraint rows), "
+                                   "then %d warm-up and %d timed steps"
+                                   % (n_env, " (pipelined: 2 env segments on 2 streams)" if pipelined else "", PRE, W, K),
+                       "model": "27-DoF humanoid (assets/humanoid27.hbm)", "envs_per_gpu": n_env, "global_envs": n_env * world, "preroll_steps": PRE,
                        "sharding": "env blocks by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
@@ -229,7 +380,7 @@ def main():
                             "mean_pgs_iters": float(ni.mean())},
         }
         if traffic:
-            out["roofline"]["traffic_source"] = traffic.get("source")
+            out["roofline"]["traffic_source"] = "committed profile, not this run: " + str(traffic.get("source"))
             # what actually bounds the kernel (from the same PMC passes; informational): share of the chip's fp32 VALU
             # lane-op rate the kernel issues, and the share of SIMD cycles with the MFMA pipe busy
             for k in ("valu_issue_frac_of_peak", "mfma_busy_frac"):
@@ -242,6 +393,7 @@ def main():
             out["newton"] = newton
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"].update(probe_libmujoco())
         print(json.dumps(out), flush=True)
     batch.dev_free(ctrl)
     batch.close()

@@ -21,11 +21,13 @@
  *
  * Build: gcc -O2 -shared -fPIC -o liboracle.so mjstep_oracle.c -lm -lpthread   (see Makefile)
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 static long g_pgs_reverts = 0;
 
@@ -1503,8 +1505,16 @@ void om_ctrl_env(const om_model* m, double* ctrl, int t, int e) {
   for (int i = 0; i < m->nu; i++) ctrl[i] = 2 * om_halton(1 + t + 1000 * e, i + 2) - 1;
 }
 
-typedef struct { const om_model* m; int e0, e1, nstep, env_offset; double* qpos_out; double stats[5]; long long steps; } om_job;
+typedef struct { const om_model* m; int e0, e1, nstep, env_offset, t_pre; double* qpos_out; double stats[5]; long long steps; double seconds; } om_job;
 
+static double now_seconds(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* one chunk of envs on one thread (the loop shape of simulation/mujoco/sample/testspeed.cc:84-103): every env first runs
+ * t_pre untimed steps of the same workload, then nstep steps whose wall time and statistics are what the job reports */
 static void* rollout_worker(void* arg) {
   om_job* job = (om_job*)arg;
   const om_model* m = job->m;
@@ -1512,12 +1522,20 @@ static void* rollout_worker(void* arg) {
   double sc = 0, se = 0, si = 0, mc = 0, me = 0;
   for (int e = job->e0; e < job->e1; e++) {
     om_init_env(m, d, e + job->env_offset);
-    for (int t = 0; t < job->nstep; t++) {
+    for (int t = 0; t < job->t_pre; t++) {
       om_ctrl_env(m, d->ctrl, t, e + job->env_offset);
       om_step(m, d);
     }
+    const double c0 = (double)d->sum_ncon, e0 = (double)d->sum_nefc, i0 = (double)d->sum_iter;
+    if (job->t_pre > 0) { d->max_ncon = 0; d->max_nefc = 0; }
+    const double t0 = now_seconds();
+    for (int t = job->t_pre; t < job->t_pre + job->nstep; t++) {
+      om_ctrl_env(m, d->ctrl, t, e + job->env_offset);
+      om_step(m, d);
+    }
+    job->seconds += now_seconds() - t0;
     if (job->qpos_out) memcpy(job->qpos_out + (size_t)e * m->nq, d->qpos, sizeof(double) * m->nq);
-    sc += (double)d->sum_ncon; se += (double)d->sum_nefc; si += (double)d->sum_iter;
+    sc += (double)d->sum_ncon - c0; se += (double)d->sum_nefc - e0; si += (double)d->sum_iter - i0;
     if (d->max_ncon > mc) mc = d->max_ncon;
     if (d->max_nefc > me) me = d->max_nefc;
     job->steps += job->nstep;
@@ -1527,24 +1545,28 @@ static void* rollout_worker(void* arg) {
   return NULL;
 }
 
-/* run n_env envs x nstep steps on nthread threads; qpos_out (nullable) [n_env x nq];
- * stats_out[5] = mean ncon, mean nefc, mean PGS iters, max ncon, max nefc.  Returns env-steps done. */
-long long om_rollout_threads(const om_model* m, int n_env, int nstep, int nthread, int env_offset, double* qpos_out, double* stats_out) {
+/* run n_env envs on nthread threads: t_pre untimed steps, then nstep timed ones, per env; qpos_out (nullable) [n_env x nq];
+ * stats_out[5] = mean ncon, mean nefc, mean PGS iters, max ncon, max nefc over the timed steps; rate_out (nullable) = sum
+ * over threads of (timed env-steps / seconds that thread spent in them): the throughput of the timed window with every
+ * thread busy (a thread is in its pre-roll while its neighbours are timed and the other way round).  Returns the timed env-steps. */
+long long om_rollout_window(const om_model* m, int n_env, int t_pre, int nstep, int nthread, int env_offset, double* qpos_out, double* stats_out,
+                            double* rate_out) {
   if (nthread < 1) nthread = 1;
   if (nthread > n_env) nthread = n_env;
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthread);
   om_job* jobs = (om_job*)calloc(nthread, sizeof(om_job));
   for (int i = 0; i < nthread; i++) {
-    jobs[i].m = m; jobs[i].nstep = nstep; jobs[i].env_offset = env_offset; jobs[i].qpos_out = qpos_out;
+    jobs[i].m = m; jobs[i].nstep = nstep; jobs[i].t_pre = t_pre; jobs[i].env_offset = env_offset; jobs[i].qpos_out = qpos_out;
     jobs[i].e0 = (int)((long long)n_env * i / nthread);
     jobs[i].e1 = (int)((long long)n_env * (i + 1) / nthread);
     pthread_create(th + i, NULL, rollout_worker, jobs + i);
   }
   long long total = 0;
-  double s[5] = {0, 0, 0, 0, 0};
+  double s[5] = {0, 0, 0, 0, 0}, rate = 0;
   for (int i = 0; i < nthread; i++) {
     pthread_join(th[i], NULL);
     total += jobs[i].steps;
+    if (jobs[i].seconds > 0) rate += (double)jobs[i].steps / jobs[i].seconds;
     s[0] += jobs[i].stats[0]; s[1] += jobs[i].stats[1]; s[2] += jobs[i].stats[2];
     if (jobs[i].stats[3] > s[3]) s[3] = jobs[i].stats[3];
     if (jobs[i].stats[4] > s[4]) s[4] = jobs[i].stats[4];
@@ -1553,8 +1575,12 @@ long long om_rollout_threads(const om_model* m, int n_env, int nstep, int nthrea
     double n = total > 0 ? (double)total : 1.0;
     stats_out[0] = s[0] / n; stats_out[1] = s[1] / n; stats_out[2] = s[2] / n; stats_out[3] = s[3]; stats_out[4] = s[4];
   }
+  if (rate_out) *rate_out = rate;
   free(th); free(jobs);
   return total;
+}
+long long om_rollout_threads(const om_model* m, int n_env, int nstep, int nthread, int env_offset, double* qpos_out, double* stats_out) {
+  return om_rollout_window(m, n_env, 0, nstep, nthread, env_offset, qpos_out, stats_out, NULL);
 }
 
 void om_free_model(om_model* m) { free(m); /* arrays intentionally leaked at process end: test-only code */ }

@@ -57,6 +57,8 @@ def lib():
         L.om_pgs_reverts.restype = ctypes.c_long; L.om_pgs_reverts.argtypes = []
         L.om_rollout_threads.restype = ctypes.c_longlong
         L.om_rollout_threads.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+        L.om_rollout_window.restype = ctypes.c_longlong
+        L.om_rollout_window.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, pd]
         _lib = L
     return _lib
 
@@ -219,6 +221,16 @@ class Oracle:
         n = self.L.om_rollout_threads(self.m, n_env, nstep, nthread, env_offset,
                                       q.ctypes.data if q is not None else None, ctypes.addressof(st))
         return n, q, dict(mean_ncon=st[0], mean_nefc=st[1], mean_iter=st[2], max_ncon=st[3], max_nefc=st[4])
+
+    def rollout_window(self, n_env, t_pre, nstep, nthread, env_offset=0, want_qpos=False):
+        """t_pre untimed steps then nstep timed ones per env (the benchmark's pre-rolled window); returns
+        (timed env-steps, qpos, stats over the timed steps, env-steps/s of the timed window with all threads busy)."""
+        q = np.zeros((n_env, self.nq)) if want_qpos else None
+        st = (ctypes.c_double * 5)()
+        rate = ctypes.c_double(0.0)
+        n = self.L.om_rollout_window(self.m, n_env, t_pre, nstep, nthread, env_offset,
+                                     q.ctypes.data if q is not None else None, ctypes.addressof(st), ctypes.byref(rate))
+        return n, q, dict(mean_ncon=st[0], mean_nefc=st[1], mean_iter=st[2], max_ncon=st[3], max_nefc=st[4]), rate.value
 
 
 def halton(index, base):

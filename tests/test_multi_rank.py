@@ -72,3 +72,56 @@ def test_two_rank_gloo_sharded_equals_unsharded():
     from oracle_lib import Oracle
     _, whole, _ = Oracle().rollout_threads(n_total, steps, 2, env_offset=0, want_qpos=True)
     assert np.array_equal(gathered, whole)
+
+
+def _run_bench(argv, extra_env=None, timeout=180):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["HB_BENCH_BACKEND"] = "gloo"
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python3 bench.py --gpus 2` with WORLD_SIZE unset (the way the driver calls it when it does not use torchrun): the
+    parent must start two ranks itself and relay rank 0's line.  --dry-run keeps it to launch, rendezvous and the
+    max-over-ranks reduction (no GPU here); the GPU legs behind it are the single-rank code path."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "7", "--warmup", "3", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 7 and out["warmup"] == 3 and out["dry_run"] is True
+    assert out["max_over_ranks_s"] == 2e-3                  # MAX over ranks of (1 + rank) ms
+    assert out["shard_of_last_rank"] == [4096, 8192]        # env blocks by rank
+
+
+def test_bench_under_a_launcher_keeps_the_launchers_world():
+    """The torchrun shape: RANK / WORLD_SIZE already in the environment -> no second spawn, the process runs its rank."""
+    import json
+    import subprocess
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HB_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert json.loads(outs[0].strip().splitlines()[-1])["n_gpus"] == 2 and not any(ln.startswith("{") for ln in outs[1].splitlines())
+
+
+def test_bench_spawn_reports_a_failed_rank():
+    """A rank that dies must fail the whole run (non-zero exit) instead of leaving the others at the rendezvous."""
+    sys.path.insert(0, ROOT)
+    import tempfile
+    from bench import spawn_ranks
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(60)\n")
+        script = f.name
+    try:
+        assert spawn_ranks(2, [], script=script, timeout=30) == 3
+    finally:
+        os.unlink(script)

@@ -82,7 +82,7 @@ void mix_pair(const Model& m, int g1, int g2, int& dim, double* fr, double* solr
 
 bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   if (m.nv > 32) { err = "this build supports nv <= 32 degrees of freedom"; return false; }
-  if (m.nbody > 65 || m.ngeom > 64) { err = "this build supports at most 64 bodies and 64 geoms"; return false; }
+  if (m.nbody > 64 || m.ngeom > 64) { err = "this build supports at most 64 bodies and 64 geoms"; return false; }
   for (int g = 0; g < m.ngeom; g++)
     if (m.geom_type[g] == GEOM_HFIELD && m.geom_bodyid[g] != 0) { err = "height fields must be attached to the world body"; return false; }
   for (int j = 0; j < m.njnt; j++)
@@ -484,10 +484,14 @@ static bool hb_debug() { static const bool on = getenv("HB_DEBUG") != nullptr; r
     if (hb_debug()) fprintf(stderr, "[hb] %s:%d: %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
     return HB_ENODEVICE; } } while (0)
 
+// the batch's control buffer for WRITING: whatever hb_ctrl_tape_splines left there is gone afterwards, so a later
+// HB_CTRL_TAPE rollout must fail (HB_EINVAL) instead of rolling out stale controls
+float* ctrl_for_write(hb_batch* b) { b->tape_steps = 0; return b->d_ctrl; }
+
 int ensure_ctrl(hb_batch* b, size_t floats) {
   if (floats <= b->ctrl_cap) return HB_OK;
   if (b->d_ctrl) HB_IGN(hipFree(b->d_ctrl));
-  b->d_ctrl = nullptr; b->ctrl_cap = 0;
+  b->d_ctrl = nullptr; b->ctrl_cap = 0; b->tape_steps = 0;
   if (hipMalloc((void**)&b->d_ctrl, floats * sizeof(float)) != hipSuccess) return HB_ENOMEM;
   b->ctrl_cap = floats;
   return HB_OK;
@@ -660,19 +664,33 @@ const char* hb_version(void) { return "hb 0.1 (gfx950)"; }
 
 hb_model* hb_model_load(const char* path, char* err, int err_sz) {
   if (!path) { set_err(err, err_sz, "null path"); return nullptr; }
-  hb_model* h = new hb_model;
-  std::string e, p = path;
-  bool ok = (p.size() > 4 && p.substr(p.size() - 4) == ".hbm") ? load_hbm(p, h->m, e) : compile_mjcf_file(p, h->m, e);
-  if (!ok) { set_err(err, err_sz, e); delete h; return nullptr; }
-  return h;
+  hb_model* h = nullptr;
+  try {  // nothing may propagate through the C boundary (a malformed file can make the loaders throw bad_alloc / length_error)
+    h = new hb_model;
+    std::string e, p = path;
+    bool ok = (p.size() > 4 && p.substr(p.size() - 4) == ".hbm") ? load_hbm(p, h->m, e) : compile_mjcf_file(p, h->m, e);
+    if (!ok) { set_err(err, err_sz, e); delete h; return nullptr; }
+    return h;
+  } catch (const std::exception& ex) {
+    set_err(err, err_sz, std::string("model load failed: ") + ex.what());
+    delete h;
+    return nullptr;
+  }
 }
 
 hb_model* hb_model_load_xml_string(const char* xml, char* err, int err_sz) {
   if (!xml) { set_err(err, err_sz, "null xml"); return nullptr; }
-  hb_model* h = new hb_model;
-  std::string e;
-  if (!compile_mjcf_string(xml, h->m, e)) { set_err(err, err_sz, e); delete h; return nullptr; }
-  return h;
+  hb_model* h = nullptr;
+  try {
+    h = new hb_model;
+    std::string e;
+    if (!compile_mjcf_string(xml, h->m, e)) { set_err(err, err_sz, e); delete h; return nullptr; }
+    return h;
+  } catch (const std::exception& ex) {
+    set_err(err, err_sz, std::string("model load failed: ") + ex.what());
+    delete h;
+    return nullptr;
+  }
 }
 
 int hb_model_save(const hb_model* m, const char* path, char* err, int err_sz) {
@@ -863,7 +881,7 @@ int hb_step(hb_batch* b, const float* ctrl, int n_substeps) {
   if (!b || n_substeps < 1 || (!ctrl && b->D.dm.nu > 0)) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   size_t n = (size_t)b->n_env * b->D.dm.nu;
-  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  if (n) HB_HIP(hipMemcpyAsync(ctrl_for_write(b), ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
   int rc = hb_step_dev(b, b->d_ctrl, n_substeps);
   if (rc != HB_OK) return rc;
   HB_HIP(hipStreamSynchronize(main_stream(b)));
@@ -874,8 +892,8 @@ int hb_forward(hb_batch* b, const float* ctrl) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   size_t n = (size_t)b->n_env * b->D.dm.nu;
-  if (ctrl && n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
-  else if (n) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * sizeof(float), main_stream(b)));
+  if (ctrl && n) HB_HIP(hipMemcpyAsync(ctrl_for_write(b), ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  else if (n) HB_HIP(hipMemsetAsync(ctrl_for_write(b), 0, n * sizeof(float), main_stream(b)));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
   HB_HIP(launch_step(b->D.d_dm, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b)));
@@ -897,7 +915,7 @@ int hb_rollout(hb_batch* b, const float* ctrl, int T, float* qpos_out) {
   size_t n = (size_t)T * b->n_env * b->D.dm.nu;
   int rc = ensure_ctrl(b, std::max<size_t>(n, 1));
   if (rc != HB_OK) return rc;
-  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  if (n) HB_HIP(hipMemcpyAsync(ctrl_for_write(b), ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
   size_t nq_out = (size_t)T * b->n_env * b->D.dm.nq;
   if (qpos_out && nq_out > b->qpos_out_cap) {
     if (b->d_qpos_out) HB_IGN(hipFree(b->d_qpos_out));
@@ -1098,7 +1116,7 @@ int hb_rollout_trajectory(hb_batch* b, const float* ctrl, int T, float* qpos_out
   const size_t n = (size_t)T * b->n_env * b->D.dm.nu;
   int rc = ensure_ctrl(b, std::max<size_t>(n, 1));
   if (rc != HB_OK) return rc;
-  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  if (n) HB_HIP(hipMemcpyAsync(ctrl_for_write(b), ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
   const size_t nq_out = (size_t)T * b->n_env * b->D.dm.nq, nv_out = (size_t)T * b->n_env * b->D.dm.nv;
   if (qpos_out && (rc = ensure_trace(&b->d_qpos_out, &b->qpos_out_cap, nq_out)) != HB_OK) return rc;
   if (qvel_out && (rc = ensure_trace(&b->d_qvel_out, &b->qvel_out_cap, nv_out)) != HB_OK) return rc;
@@ -1270,7 +1288,7 @@ int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_sp
   const size_t n = (size_t)T * b->n_env * b->D.dm.nu;
   int rc = ensure_ctrl(b, std::max<size_t>(n, 1));
   if (rc != HB_OK) return rc;
-  if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  if (n) HB_HIP(hipMemcpyAsync(ctrl_for_write(b), ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
   const size_t nq_out = (size_t)T * b->n_env * b->D.dm.nq;
   if (qpos_out && nq_out > b->qpos_out_cap) {
     if (b->d_qpos_out) HB_IGN(hipFree(b->d_qpos_out));
@@ -1305,8 +1323,8 @@ static int rollout_rows(hb_batch* b, const float* ctrl, int H, const hb_sensor_s
     rc = ensure_ctrl(b, std::max<size_t>(std::max<size_t>(n, (size_t)N * nu), 1));
     if (rc != HB_OK) return rc;
     b->tape_steps = 0;
-    if (n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
-    else if (nu) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, (size_t)N * nu * sizeof(float), main_stream(b)));
+    if (n) HB_HIP(hipMemcpyAsync(ctrl_for_write(b), ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+    else if (nu) HB_HIP(hipMemsetAsync(ctrl_for_write(b), 0, (size_t)N * nu * sizeof(float), main_stream(b)));
   }
   // failure is a property of THIS rollout (CheckWarnings looks at the warnings of the rollout's own mjData)
   HB_HIP(hipMemsetAsync(b->d_status, 0, (size_t)N * sizeof(int), main_stream(b)));
@@ -1465,8 +1483,8 @@ int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float
   if (!b || !spec || !sensor_out) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   const size_t n = (size_t)b->n_env * b->D.dm.nu;
-  if (ctrl && n) HB_HIP(hipMemcpyAsync(b->d_ctrl, ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
-  else if (n) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * sizeof(float), main_stream(b)));
+  if (ctrl && n) HB_HIP(hipMemcpyAsync(ctrl_for_write(b), ctrl, n * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  else if (n) HB_HIP(hipMemsetAsync(ctrl_for_write(b), 0, n * sizeof(float), main_stream(b)));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
   int rc = sensor_setup(b, spec, 1, P);
@@ -1714,10 +1732,10 @@ static int env_step_impl(hb_batch* b, const float* action_dev, int n_substeps, c
                          uint8_t* terminated_dev, uint8_t* truncated_dev) {
   const int n = b->n_env * b->D.dm.nu;
   if (b->rand_on) {
-    HB_HIP(launch_action_env(b->D.dm, b->env_rand, b->rs, action_dev, b->d_prev, b->d_latest, b->d_ctrl, b->d_episode, b->d_state, mask, b->n_env, b->env_offset,
+    HB_HIP(launch_action_env(b->D.dm, b->env_rand, b->rs, action_dev, b->d_prev, b->d_latest, ctrl_for_write(b), b->d_episode, b->d_state, mask, b->n_env, b->env_offset,
                              main_stream(b)));
   } else if (n && action_dev) {
-    HB_HIP(launch_action(action_dev, b->d_prev, b->d_latest, b->d_ctrl, n, main_stream(b)));
+    HB_HIP(launch_action(action_dev, b->d_prev, b->d_latest, ctrl_for_write(b), n, main_stream(b)));
   }
   BatchPtrs P = make_ptrs(b);
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.env_mask = mask;
@@ -1736,7 +1754,7 @@ int hb_env_reset(hb_batch* b, float* obs) {
   HB_HIP(hipMemsetAsync(b->d_prev, 0, n * nu * sizeof(float), main_stream(b)));
   HB_HIP(hipMemsetAsync(b->d_latest, 0, n * nu * sizeof(float), main_stream(b)));
   HB_HIP(hipMemsetAsync(b->d_episode, 0, n * sizeof(int), main_stream(b)));
-  if (b->d_ctrl) HB_HIP(hipMemsetAsync(b->d_ctrl, 0, n * nu * sizeof(float), main_stream(b)));
+  if (b->d_ctrl) HB_HIP(hipMemsetAsync(ctrl_for_write(b), 0, n * nu * sizeof(float), main_stream(b)));
   if (c.reset_collision_mode == 0) {
     rc = reset_impl(b, nullptr, c.reset_keyframe, c.reset_perturb, b->env_offset);
     if (rc != HB_OK) return rc;
@@ -1853,14 +1871,14 @@ static int policy_forward(hb_batch* b, int lo, int hi, hipStream_t st) {
     for (int l = 0; l <= b->mlp_layers; l++) { pd.sizes[l] = b->mlp_sizes[l]; widest = std::max(widest, b->mlp_sizes[l]); }
     for (int l = 0; l < b->mlp_layers; l++) { pd.w[l] = b->d_mlp_wp[l]; pd.b[l] = b->d_mlp_b[l]; }
     pd.ldx = widest + 4;  // + the K pad columns (K is swept four at a time); 16-row tiles
-    HB_HIP(launch_policy(dm, pd, b->d_state + (size_t)lo * dm.nstate, b->d_ctrl + (size_t)lo * dm.nu, hi - lo, st));
+    HB_HIP(launch_policy(dm, pd, b->d_state + (size_t)lo * dm.nstate, ctrl_for_write(b) + (size_t)lo * dm.nu, hi - lo, st));
     return HB_OK;
   }
   // wide layers: one launch per layer, activations through HBM
   HB_HIP(launch_obs(dm, b->d_state + (size_t)lo * dm.nstate, b->d_obs + (size_t)lo * b->mlp_sizes[0], hi - lo, st));
   const float* x = b->d_obs + (size_t)lo * b->mlp_sizes[0];
   for (int l = 0; l < b->mlp_layers; l++) {
-    float* y = ((l + 1 == b->mlp_layers) ? b->d_ctrl : b->d_mlp_h[l & 1]) + (size_t)lo * b->mlp_sizes[l + 1];
+    float* y = ((l + 1 == b->mlp_layers) ? ctrl_for_write(b) : b->d_mlp_h[l & 1]) + (size_t)lo * b->mlp_sizes[l + 1];
     HB_HIP(launch_mlp_layer(x, b->d_mlp_w[l], b->d_mlp_b[l], y, hi - lo, b->mlp_sizes[l], b->mlp_sizes[l + 1], 1, st));
     x = y;
   }

@@ -675,6 +675,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   if (lane < 32) { s_v0[lane] = 0.f; s_v1[lane] = 0.f; s_v2[lane] = 0.f; }
   gsync();
 
+  // mj_resetData inside a step (mj_check*, mujoco.h:301-307) also zeroes ctrl and xfrc_applied: the rest of that step runs without controls
+  bool ctrl_zeroed = false;  // this pass of the step runs on reset data
+  bool redo = false;         // this pass is the second mj_forward of a step whose first one gave a bad qacc (mj_checkAcc)
   for (int step = 0; step < nsteps; step++) {
     // re-materialise the lane id every step: keeps per-lane table addresses and loads inside the step
     // instead of hoisted out of the rollout loop into long-lived (spilled) registers
@@ -722,7 +725,10 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         for (int i = lane; i < nq; i += kGroup) s_qpos[i] = M.qpos0[i];
         for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; }
         time = 0.f;
+        ctrl_zeroed = true;
+        if (P.xfrc) for (int i = lane; i < 6 * nb; i += kGroup) P.xfrc[(size_t)env * nb * 6 + i] = 0.f;
       }
+      if (ctrl_zeroed) for (int i = lane; i < M.nu; i += kGroup) s_ctrl[i] = 0.f;
     }
     gsync();
 
@@ -1834,7 +1840,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       }
       gsync();
     }
-    // mj_checkAcc
+    // mj_checkAcc (mujoco.h:307): a bad qacc resets the data and runs mj_forward again; the step then integrates that result
     {
       bool bad = false;
       for (int i = lane; i < nv; i += kGroup) bad |= !(fabsf(s_v0[i]) <= HB_MAXVAL);
@@ -1844,9 +1850,19 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; s_v0[i] = 0.f; }
         time = 0.f;
         newton_grad = 0.f;
+        if (P.xfrc) for (int i = lane; i < 6 * nb; i += kGroup) P.xfrc[(size_t)env * nb * 6 + i] = 0.f;
         gsync();
+        if (!redo) {  // second pass of this step from the reset state (the loop increment undoes the decrement)
+          redo = true;
+          ctrl_zeroed = true;
+          step--;
+          continue;
+        }
+        // (the reset state itself gives a bad qacc: nothing sane is left to do; integrate with qacc = 0)
       }
     }
+    redo = false;
+    ctrl_zeroed = false;
     // diagnostics of this step (parity tests)
     if (P.diag_qacc) for (int i = lane; i < nv; i += kGroup) P.diag_qacc[(size_t)env * nv + i] = s_v0[i];
     if (P.diag_force && lane < kNefcMax) P.diag_force[(size_t)env * kNefcMax + lane] = rowact ? force : 0.f;

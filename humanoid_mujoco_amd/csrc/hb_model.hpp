@@ -120,5 +120,7 @@ bool set_const(Model& m, std::string& err);
 bool save_hbm(const Model& m, const std::string& path, std::string& err);
 bool load_hbm(const std::string& path, Model& m, std::string& err);
 bool load_hbm_string(const std::string& text, Model& m, std::string& err);
+// every array length against its size field, every id / address against its range (run on every load and compile)
+bool validate_model(const Model& m, std::string& err);
 
 }  // namespace hb

@@ -803,6 +803,7 @@ bool compile_root(Ctx& c, XmlNode& root) {
     }
   }
   build_pairs(m);
+  if (!validate_model(m, c.err)) return false;
   return set_const(m, c.err);
 }
 

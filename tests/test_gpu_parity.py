@@ -2,14 +2,16 @@
 
 Tolerances (fp32 device arithmetic vs fp64 oracle, stated per SURVEY.md §8(c)/(d)):
   one step, teacher-forced from identical states
-      qpos   : |d| <= 1e-4 * max(1, |qpos|)            (measured: median 7e-8, max 1.1e-5..2.6e-5 on one stiff 6-limit-row impact state)
-      qvel   : |d| <= 1e-3 * max(1, max|qvel|)         (measured: median 8e-7, max 1.2e-4; qvel' = qvel + h*qacc, |qacc| up to 4e3)
-      qacc   : |d| <= 2e-3 * max(1, max|qacc|)         (measured: median 2e-6, max 1.2e-4)
+      qpos   : |d| <= 4e-5 * max(1, |qpos|)            (measured: median 7e-8, max 1.2e-5 on one stiff 6-limit-row impact state)
+      qvel   : |d| <= 4e-4 * max(1, max|qvel|)         (measured: median 8e-7, max 1.35e-4; qvel' = qvel + h*qacc, |qacc| up to 4e3)
+      qacc   : |d| <= 4e-4 * max(1, max|qacc|)         (measured: median 2e-6, max 1.30e-4)
       contact: dist/pos 1e-5; frame 1e-3 (a capsule-capsule normal is (p2-p1)/|p2-p1| of two nearly coincident
                closest points under deep penetration: ill-conditioned in fp32, measured max 2.3e-4, median 1e-7);
                counts (ncon, nefc) identical
-      forces : |d| <= 2e-3 * max(1, max|efc_force|)   (measured: median 4e-6, max 8e-5; PGS sweep counts identical)
-  (measurements: tools/gpu_parity_report.py on the 128 golden states, profiles/r01_parity_report.txt)
+      forces : |d| <= 4e-4 * max(1, max|efc_force|)   (measured: median 3e-6, max 1.26e-4; PGS sweep counts identical)
+  (measurements: tools/gpu_parity_report.py on the 128 golden states, profiles/r01_parity_report.txt; every bound is at
+  most 3x the measured maximum, so a 3x numerical regression fails.  History: the bounds were 1e-4 / 1e-3 / 2e-3 / 2e-3 in
+  round 1, loosened from 1e-5 for qpos when the first hardware runs measured 1.1e-5 and 2.6e-5 on the impact state.)
   free-running, contact-free segment: relative qpos drift <= 1e-4 (the north-star bar);
   free-running through contacts: chaotic, reported not asserted beyond sanity.
 """
@@ -45,12 +47,12 @@ def test_one_step_parity_on_golden_states(hbmod, humanoid_model, gpu, golden):
     assert not b.status().any()
     assert np.array_equal(ncon, g["ncon"]) and np.array_equal(nefc, g["nefc"])
     dq = np.abs(q - g["qpos1"]) / np.maximum(1.0, np.abs(g["qpos1"]))
-    assert dq.max() <= 1e-4, dq.max()
+    assert dq.max() <= 4e-5, dq.max()
     assert np.median(dq.max(axis=1)) <= 1e-6
     vs = np.maximum(1.0, np.abs(g["qvel1"]).max(axis=1, keepdims=True))
-    assert (np.abs(v - g["qvel1"]) / vs).max() <= 1e-3
+    assert (np.abs(v - g["qvel1"]) / vs).max() <= 4e-4
     as_ = np.maximum(1.0, np.abs(g["qacc"]).max(axis=1, keepdims=True))
-    assert (np.abs(a - g["qacc"]) / as_).max() <= 2e-3
+    assert (np.abs(a - g["qacc"]) / as_).max() <= 4e-4
     # time advanced by one timestep
     assert np.allclose(b.time, g["time"] + 0.005, atol=1e-5)
     # contact geometry
@@ -64,7 +66,7 @@ def test_one_step_parity_on_golden_states(hbmod, humanoid_model, gpu, golden):
     # constraint forces
     f = b.efc_force().astype(np.float64)
     fs = np.maximum(1.0, np.abs(g["efc_force"]).max(axis=1, keepdims=True))
-    assert (np.abs(f - g["efc_force"]) / fs).max() <= 2e-3
+    assert (np.abs(f - g["efc_force"]) / fs).max() <= 4e-4
 
 
 def test_forward_matches_oracle_and_leaves_state(hbmod, humanoid_model, gpu, golden):
@@ -78,7 +80,7 @@ def test_forward_matches_oracle_and_leaves_state(hbmod, humanoid_model, gpu, gol
     assert np.allclose(b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64), st.astype(np.float32), atol=0)
     a = b.qacc()
     as_ = np.maximum(1.0, np.abs(g["qacc"][idx]).max(axis=1, keepdims=True))
-    assert (np.abs(a - g["qacc"][idx]) / as_).max() <= 2e-3
+    assert (np.abs(a - g["qacc"][idx]) / as_).max() <= 4e-4
 
 
 def test_contact_free_drift_within_north_star_bar(hbmod, humanoid_model, gpu):
@@ -102,6 +104,11 @@ def test_contact_free_drift_within_north_star_bar(hbmod, humanoid_model, gpu):
     worst = 0.0
     free = [True] * n  # still in its contact-free opening: no constraint row on either side so far
     compared = 0
+    # the wider window the test had before commit 73adc25: contact-free, but THROUGH joint-limit rows.  Reported, not
+    # asserted: with the mass matrix eliminated on the matrix cores it measured 1.25e-4 (step 35, an env passing through a
+    # limit row; 9.8e-5 with the sparse L'DL before), i.e. just over the 1e-4 bar (DESIGN.md §2 records the history)
+    nocontact = [True] * n
+    worst_wide, compared_wide = 0.0, 0
     for t in range(T):
         ctrl = np.stack([o.ctrl_env(t, e) for o, e in zip(oracles, envs)]).astype(np.float32)
         b.step(ctrl)
@@ -109,12 +116,19 @@ def test_contact_free_drift_within_north_star_bar(hbmod, humanoid_model, gpu):
             o.ctrl[:] = c
             o.step()
         q = b.qpos
-        _, nefc, _ = b.counts()
+        ncon, nefc, _ = b.counts()
         for i, o in enumerate(oracles):
             free[i] = free[i] and o.nefc == 0 and int(nefc[i]) == 0
+            nocontact[i] = nocontact[i] and o.ncon == 0 and int(ncon[i]) == 0
+            d = float((np.abs(q[i] - o.qpos) / np.maximum(1.0, np.abs(o.qpos))).max())
             if free[i]:
                 compared += 1
-                worst = max(worst, float((np.abs(q[i] - o.qpos) / np.maximum(1.0, np.abs(o.qpos))).max()))
+                worst = max(worst, d)
+            if nocontact[i]:
+                compared_wide += 1
+                worst_wide = max(worst_wide, d)
+    print("\ncontact-free drift: up to the first constraint row %.3e (%d env-steps, asserted <= 1e-4); "
+          "through joint-limit rows %.3e (%d env-steps, reported only)" % (worst, compared, worst_wide, compared_wide))
     assert compared >= 100, compared
     assert worst <= 1e-4, worst
 
@@ -264,23 +278,141 @@ def test_state_io_reset_and_keyframes(hbmod, humanoid_model, gpu):
 
 
 def test_bad_state_is_flagged_and_reset(hbmod, humanoid_model, gpu):
-    """mj_checkPos / mj_checkVel semantics (mujoco.h:301-307): NaN or |x|>1e10 resets the env and
-    raises the warning; other envs are untouched."""
+    """mj_checkPos / mj_checkVel / mj_checkAcc semantics (mujoco.h:301-307) against the oracle: NaN or |x| > 1e10 raises the
+    warning and resets the data — qpos0, zero velocity, warm start, ctrl and xfrc_applied, time 0 — and the step carries on
+    from there (a bad qacc runs mj_forward a second time on the reset data, then integrates); other envs are untouched."""
     m = humanoid_model
     n = 8
     b = hbmod.Batch(m, n, gpu)
     b.reset(perturb=True)
-    st = b.get_state(hbmod.STATE_INTEGRATION)
-    st[2, 5] = np.nan
-    st[5, 1 + m.nq + 3] = 1e12
-    b.set_state(hbmod.STATE_INTEGRATION, st)
-    b.step(np.zeros((n, m.nu), np.float32))
+    b.rollout_halton(30)
+    spec = hbmod.STATE_INTEGRATION | hbmod.STATE_XFRC_APPLIED
+    st = b.get_state(spec, dtype=np.float64)
+    st0 = st.copy()
+    nint = 1 + m.nq + 2 * m.nv
+    st[2, 5] = np.nan                      # qpos      -> mjWARN_BADQPOS
+    st[5, 1 + m.nq + 3] = 1e12             # qvel      -> mjWARN_BADQVEL
+    st[6, nint + 6 * 1 + 2] = 1e14         # xfrc_applied on the torso: |qacc| > 1e10 -> mjWARN_BADQACC
+    b.set_state(spec, st)
+    ctrl = np.full((n, m.nu), 0.7, np.float32)
+    b.step(ctrl)
     s = b.status()
-    assert s[2] & hbmod.WARN_BADQPOS and s[5] & hbmod.WARN_BADQVEL
-    assert not s[[0, 1, 3, 4, 6, 7]].any()
-    assert np.isfinite(b.qpos).all() and np.isfinite(b.qvel).all()
+    assert s[2] == hbmod.WARN_BADQPOS and s[5] == hbmod.WARN_BADQVEL and s[6] == hbmod.WARN_BADQACC
+    assert not s[[0, 1, 3, 4, 7]].any()
+    q, v, t = b.qpos.astype(np.float64), b.qvel.astype(np.float64), b.time
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    # the oracle on the same inputs: flagged envs end up at "qpos0 stepped once with zero controls", time = h
+    for e in range(n):
+        o = Oracle()
+        o.reset()
+        o.L.om_data_set_time(o.d, st[e, 0])
+        o.qpos[:] = st[e, 1:1 + m.nq]; o.qvel[:] = st[e, 1 + m.nq:1 + m.nq + m.nv]; o.qacc_warmstart[:] = st[e, 1 + m.nq + m.nv:nint]
+        o.xfrc_applied[:] = st[e, nint:]
+        o.ctrl[:] = ctrl[e]
+        o.step()
+        want_bad = e in (2, 5, 6)
+        assert (o.dint("warn_badqpos"), o.dint("warn_badqvel"), o.dint("warn_badqacc")) == (int(e == 2), int(e == 5), int(e == 6))
+        assert abs(t[e] - o.time) < 1e-6 and (abs(o.time - 0.005) < 1e-12) == want_bad
+        assert (np.abs(q[e] - o.qpos) / np.maximum(1, np.abs(o.qpos))).max() <= 4e-5
+        assert np.abs(v[e] - o.qvel).max() <= 4e-4 * max(1.0, np.abs(o.qvel).max())
+    # the three reset envs are the same state (nothing of their old data survives), and it is not simply qpos0: gravity acted
+    assert np.array_equal(q[2], q[5]) and np.array_equal(q[2], q[6]) and np.array_equal(v[2], v[6])
+    assert np.abs(v[2]).max() > 1e-3
+    # mj_resetData also cleared xfrc_applied of the flagged env, and only that one's
+    after = b.get_state(spec, dtype=np.float64)
+    assert not after[6, nint:].any() and np.array_equal(after[0, nint:], st0[0, nint:])
     b.reset()
     assert not b.status().any()
+
+
+def test_config3_last_rank_shard_at_env_offset_28672(hbmod, humanoid_model, gpu):
+    """BASELINE configs[2]: 32768 envs over 8 GPUs, env e on GPU floor(e / 4096).  Rank 7's shard: env_offset = 28672,
+    Halton indices 1 + t + 1000 e up to 3.3e7 (beyond 2^24: the device generator divides in integers), initial
+    perturbation indexed by the global env; two half shards at that offset equal the whole one bit for bit."""
+    n, off, T = 4096, 28672, 200
+    nu = humanoid_model.nu
+    b = hbmod.Batch(humanoid_model, n, gpu)
+    # device Halton controls vs the fp64 Python generator, sampled over the shard (first, last and strided envs; late steps)
+    buf = b.dev_alloc(4 * n * nu * 4)
+    b.halton_ctrl_dev(4, T - 4, off, buf)
+    got = b.from_dev(buf, (4, n, nu))
+    envs = [0, 1, 2047, 2048, 4094, 4095] + list(range(5, n, 611))
+    for t in (0, 3):
+        for e in envs:
+            want = np.array([2 * halton(1 + (T - 4) + t + 1000 * (off + e), i + 2) - 1 for i in range(nu)])
+            assert np.abs(got[t, e] - want).max() < 2e-6, (t, e)
+    b.dev_free(buf)
+    # initial state and a free-running start against the oracle at the global indices
+    b.reset(perturb=True, env_offset=off)
+    q0 = b.qpos
+    for e in (0, 4095):
+        o = Oracle()
+        o.init_env(off + e)
+        assert np.abs(q0[e] - o.qpos).max() < 1e-6
+    b.rollout_halton(T, 0, off)
+    whole = b.get_state(hbmod.STATE_INTEGRATION)
+    assert np.isfinite(whole).all() and not b.status().any()
+    o = Oracle()
+    o.init_env(off + 4095)
+    for t in range(20):  # contact-free opening: the device follows the oracle
+        o.ctrl[:] = o.ctrl_env(t, off + 4095)
+        o.step()
+    c = hbmod.Batch(humanoid_model, 1, gpu)
+    c.reset(perturb=True, env_offset=off + 4095)
+    c.rollout_halton(20, 0, off + 4095)
+    assert (np.abs(c.qpos[0] - o.qpos) / np.maximum(1, np.abs(o.qpos))).max() <= 1e-4
+    # sharded == whole, bitwise, on a 2 x 2048 split of this shard
+    for r in range(2):
+        part = hbmod.Batch(humanoid_model, n // 2, gpu)
+        part.reset(perturb=True, env_offset=off + r * (n // 2))
+        part.rollout_halton(T, 0, off + r * (n // 2))
+        assert np.array_equal(part.get_state(hbmod.STATE_INTEGRATION), whole[r * (n // 2):(r + 1) * (n // 2)])
+    # and the shard differs from rank 0's (the offset really selects other envs)
+    b.reset(perturb=True, env_offset=0)
+    assert not np.array_equal(b.qpos, q0)
+
+
+def test_config3_all_32768_envs_on_one_gpu(hbmod, humanoid_model, gpu):
+    """The whole of configs[2] as one batch: size-independent properties after 300 steps, and its rank-3 block equal to a
+    4096-env batch at env_offset 3 * 4096 (what the 8-GPU run computes on GPU 3)."""
+    n, T = 32768, 300
+    b = hbmod.Batch(humanoid_model, n, gpu)
+    b.reset(perturb=True)
+    b.rollout_halton(T)
+    st = b.get_state(hbmod.STATE_INTEGRATION)
+    q = st[:, 1:1 + humanoid_model.nq]
+    assert np.isfinite(st).all() and not b.status().any()
+    assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max() < 1e-4
+    assert q[:, 2].min() > -0.02 and q[:, 2].max() < 1.6
+    assert np.allclose(st[:, 0], T * 0.005, rtol=1e-4)
+    nc, ne, ni = b.counts()
+    assert nc.max() <= humanoid_model.ncon_max and ne.max() <= humanoid_model.nefc_max
+    assert len(np.unique(q[:, 2])) > n // 2
+    part = hbmod.Batch(humanoid_model, 4096, gpu)
+    part.reset(perturb=True, env_offset=3 * 4096)
+    part.rollout_halton(T, 0, 3 * 4096)
+    assert np.array_equal(part.get_state(hbmod.STATE_INTEGRATION), st[3 * 4096:4 * 4096])
+
+
+def test_benchmark_workload_stays_inside_the_row_capacity(hbmod, humanoid_model, gpu):
+    """Row capacity (24 contacts / 63 rows per env) against the benchmark workload: 4096 envs x 3000 steps = 1.2e7 env-steps
+    (fall, impact, flailing on the floor) without a single dropped contact or row — status bits are sticky, so a clean status
+    word at the end means no env-step overflowed; the distribution's tail is printed.  (The collapsed zero-control regime
+    sits at the edge: profiles/r01_soak_1e10.txt saw one CNSTRFULL in 1e10 env-steps; VecEnv reports the bits, see
+    test_gpu_env.py.)"""
+    n, T = 4096, 3000
+    b = hbmod.Batch(humanoid_model, n, gpu)
+    b.reset(perturb=True)
+    mx_c = mx_e = 0
+    for k in range(T // 100):
+        b.rollout_halton(100, 100 * k)
+        nc, ne, _ = b.counts()
+        mx_c, mx_e = max(mx_c, int(nc.max())), max(mx_e, int(ne.max()))
+    s = b.status()
+    print("\nmax ncon %d / %d, max nefc %d / %d sampled every 100 steps over %.1e env-steps; envs flagged %d"
+          % (mx_c, humanoid_model.ncon_max, mx_e, humanoid_model.nefc_max, n * T, int((s != 0).sum())))
+    assert not (s & (hbmod.WARN_CONTACTFULL | hbmod.WARN_CNSTRFULL)).any()
+    assert not s.any()
 
 
 def test_disable_flags_and_options(hbmod, gpu):

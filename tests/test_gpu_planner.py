@@ -324,6 +324,14 @@ def test_spline_policies_on_the_device(hbmod, humanoid_model, gpu, interp):
     # a tape shorter than the rollout is refused
     with pytest.raises(hbmod.HbError):
         b.rollout_task_stand(("tape", H + 3), task)
+    # and so is a tape that another call has written over since (hb_step copies its controls into the same buffer):
+    # stale controls must never be rolled out silently
+    b.ctrl_tape_splines(knots, times, interp, time0, H - 1)
+    b.step(np.zeros((N, m.nu), np.float32))
+    with pytest.raises(hbmod.HbError):
+        b.rollout_task_stand(("tape", H - 1), task)
+    b.ctrl_tape_splines(knots, times, interp, time0, H - 1)
+    b.rollout_task_stand(("tape", H - 1), task)  # a fresh tape is accepted again
 
 
 def _oracle_transition_fd(o, x, u, warm, eps, nq, nv, nu):

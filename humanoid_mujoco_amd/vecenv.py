@@ -8,7 +8,7 @@ with finished envs reset in place (SB3 VecEnv semantics) and ``set_attr("randomi
 """
 import numpy as np
 
-from .engine import Batch, Model
+from .engine import WARN_BADQACC, WARN_BADQPOS, WARN_BADQVEL, WARN_CNSTRFULL, WARN_CONTACTFULL, Batch, Model
 
 
 class VecEnv:
@@ -71,8 +71,19 @@ class VecEnv:
     def step(self, actions):
         obs, rew, term, trunc = self.batch.env_step(actions, self.n_substeps)
         done = term | trunc
-        infos = {"is_success": trunc.copy(), "done": done}  # cpu_env.py:688-689
+        # "warnings": the per-env HB_WARN_* bits (mjData.warning, mjdata.h:54-65) accumulated since the env's last reset:
+        # a contact or constraint-row overflow (rows were dropped for that env-step) or a bad-state reset is visible to
+        # the training loop instead of silently changing that env's physics
+        w = self.batch.status()
+        infos = {"is_success": trunc.copy(), "done": done, "warnings": w,  # cpu_env.py:688-689
+                 "overflow": (w & (WARN_CONTACTFULL | WARN_CNSTRFULL)) != 0}
         return obs, rew, term, trunc, infos
+
+    def warning_counts(self):
+        """Number of envs currently carrying each warning bit."""
+        w = self.batch.status()
+        return {"contact_full": int(((w & WARN_CONTACTFULL) != 0).sum()), "constraint_full": int(((w & WARN_CNSTRFULL) != 0).sum()),
+                "bad_qpos": int(((w & WARN_BADQPOS) != 0).sum()), "bad_qvel": int(((w & WARN_BADQVEL) != 0).sum()), "bad_qacc": int(((w & WARN_BADQACC) != 0).sum())}
 
     def step_torch(self, actions):
         """The same step with the policy on the GPU: `actions` is a float32 CUDA tensor [n_envs, nu]; returns CUDA tensors

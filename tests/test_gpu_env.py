@@ -119,3 +119,22 @@ def test_device_resident_step_matches_host_step(hbmod, humanoid_model, gpu):
         o2, r2, te2, tr2 = b.step_torch(torch.from_numpy(act).cuda())
         assert np.array_equal(o1, o2.cpu().numpy()) and np.array_equal(r1, r2.cpu().numpy())
         assert np.array_equal(te1, te2.cpu().numpy()) and np.array_equal(tr1, tr2.cpu().numpy())
+
+
+def test_vecenv_reports_warning_bits(hbmod, humanoid_model, gpu):
+    """The step's info carries the per-env HB_WARN_* bits (mjData.warning): an overflow or a bad-state reset of an env is
+    visible to the training loop.  A NaN planted in one env's state shows up as BADQPOS for that env only."""
+    n = 6
+    env = hbmod.VecEnv(humanoid_model, n, gpu, auto_reset=0, max_time=0.0)
+    env.reset()
+    act = np.zeros((n, humanoid_model.nu), np.float32)
+    _, _, _, _, info = env.step(act)
+    assert info["warnings"].shape == (n,) and not info["warnings"].any() and not info["overflow"].any()
+    st = env.batch.get_state(hbmod.STATE_INTEGRATION)
+    st[4, 3] = np.nan
+    env.batch.set_state(hbmod.STATE_INTEGRATION, st)
+    obs, rew, _, _, info = env.step(act)
+    assert info["warnings"][4] & hbmod.WARN_BADQPOS and not np.delete(info["warnings"], 4).any()
+    assert np.isfinite(obs).all() and np.isfinite(rew).all()
+    assert env.warning_counts() == {"contact_full": 0, "constraint_full": 0, "bad_qpos": 1, "bad_qvel": 0, "bad_qacc": 0}
+    env.close()

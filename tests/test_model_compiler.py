@@ -201,3 +201,57 @@ def test_heightfield_asset_and_config5_model(hbmod, tmp_path):
     assert np.array_equal(h["body_mass"], base["body_mass"]) and np.array_equal(h["pair_geom1"], base["pair_geom1"])
     assert abs((h["hfield_data"] * 1.0).mean() + h["geom_pos"][2]) < 1e-12  # mean terrain height 0
     assert h["hfield_data"].max() <= 0.1
+
+
+def _mutate_hbm(tmp_path, fn):
+    from oracle_lib import HUMANOID_HBM
+    lines = open(HUMANOID_HBM).read().splitlines()
+    out = fn(lines)
+    p = tmp_path / "mutated.hbm"
+    p.write_text("\n".join(out) + "\n")
+    return str(p)
+
+
+def _set_record(lines, name, values):
+    kind = [ln.split()[0] for ln in lines if len(ln.split()) > 1 and ln.split()[1] == name][0]
+    return [("%s %s %d %s" % (kind, name, len(values), " ".join(str(v) for v in values))) if (len(ln.split()) > 1 and ln.split()[1] == name) else ln for ln in lines]
+
+
+@pytest.mark.parametrize("case", ["short_array", "bad_actuator_joint", "bad_pair_geom", "bad_geom_body", "bad_parent", "bad_madr", "huge_count", "bad_tendon_wrap", "bad_key"])
+def test_edited_or_truncated_hbm_is_an_error_not_a_fault(hbmod, tmp_path, case):
+    """A damaged compiled model must come back as an error string from hb_model_load: every array length is checked against
+    its size field and every id / address against its range before build_device_model or a kernel indexes with it."""
+    from oracle_lib import HUMANOID_HBM, parse_hbm
+    info = parse_hbm(HUMANOID_HBM)
+
+    def edit(lines):
+        if case == "short_array":
+            return _set_record(lines, "jnt_axis", list(info["jnt_axis"][:-3]))
+        if case == "bad_actuator_joint":
+            v = list(info["actuator_trnid"]); v[3] = 999
+            return _set_record(lines, "actuator_trnid", v)
+        if case == "bad_pair_geom":
+            v = list(info["pair_geom2"]); v[-1] = 64
+            return _set_record(lines, "pair_geom2", v)
+        if case == "bad_geom_body":
+            v = list(info["geom_bodyid"]); v[5] = -2
+            return _set_record(lines, "geom_bodyid", v)
+        if case == "bad_parent":
+            v = list(info["body_parentid"]); v[4] = 9
+            return _set_record(lines, "body_parentid", v)
+        if case == "bad_madr":
+            v = list(info["dof_Madr"]); v[10] += 1
+            return _set_record(lines, "dof_Madr", v)
+        if case == "huge_count":
+            return [("I body_parentid 99999999999 0 0") if ln.startswith("I body_parentid ") else ln for ln in lines]
+        if case == "bad_tendon_wrap":
+            v = list(info["tendon_adr"]); v[1] = 3
+            return _set_record(lines, "tendon_adr", v)
+        if case == "bad_key":
+            return _set_record(lines, "key_qpos", list(info["key_qpos"][:-1]))
+        raise AssertionError(case)
+
+    path = _mutate_hbm(tmp_path, edit)
+    with pytest.raises(hbmod.HbError) as ei:
+        hbmod.Model.load(path)
+    assert len(str(ei.value)) > 10

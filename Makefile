@@ -2,7 +2,7 @@
 HIPCC ?= hipcc
 ARCH ?= gfx950
 CSRC := humanoid_mujoco_amd/csrc
-HOST_SRCS := $(CSRC)/hb_api.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp
+HOST_SRCS := $(CSRC)/hb_api.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp $(CSRC)/mesh.cpp
 HIP_SRCS := $(CSRC)/hb_kernels.hip
 HDRS := $(wildcard $(CSRC)/*.hpp) include/hb.h
 LIB := humanoid_mujoco_amd/libhb.so
@@ -39,9 +39,9 @@ build/libhb_probe.so: $(HOST_SRCS) $(HIP_SRCS) $(HDRS)
 	$(HIPCC) $(FLAGS) -DHB_STAMPS -DHB_PROBE_NEWTON -c -x hip $(HIP_SRCS) -o build/obj_probe/hb_kernels.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ build/obj_probe/*.o
 
-build/hb_compile: tools/hb_compile.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp $(HDRS)
+build/hb_compile: tools/hb_compile.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp $(CSRC)/mesh.cpp $(HDRS)
 	@mkdir -p build
-	g++ -O2 -std=c++17 -Wall -o $@ tools/hb_compile.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp
+	g++ -O2 -std=c++17 -Wall -o $@ tools/hb_compile.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp $(CSRC)/mesh.cpp
 
 build/hb_testspeed: tools/hb_testspeed.cpp $(LIB) include/hb.h
 	@mkdir -p build

@@ -12,7 +12,7 @@ namespace hb {
 
 // enums mirror mjmodel.h values so integer codes stay familiar
 enum JointType { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };          // mjmodel.h:86-91
-enum GeomType { GEOM_PLANE = 0, GEOM_HFIELD = 1, GEOM_SPHERE = 2, GEOM_CAPSULE = 3 };   // mjmodel.h:94-103
+enum GeomType { GEOM_PLANE = 0, GEOM_HFIELD = 1, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5, GEOM_BOX = 6, GEOM_MESH = 7 };   // mjmodel.h:94-103
 enum Solver { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };                                // mjmodel.h:159-163
 enum DisableBit {                                                                      // mjmodel.h:50-68
   DSBL_CONSTRAINT = 1 << 0, DSBL_EQUALITY = 1 << 1, DSBL_FRICTIONLOSS = 1 << 2, DSBL_LIMIT = 1 << 3,
@@ -27,7 +27,7 @@ typedef std::vector<int> veci;
 struct Model {
   // ---- sizes (mjmodel.h:560-620)
   int nq = 0, nv = 0, nu = 0, nbody = 0, njnt = 0, ngeom = 0, ntendon = 0, nwrap = 0, nM = 0,
-      nkey = 0, nexclude = 0, npair = 0, nhfield = 0, nhfielddata = 0;
+      nkey = 0, nexclude = 0, npair = 0, nhfield = 0, nhfielddata = 0, nmesh = 0, nmeshvert = 0;
 
   // ---- options (mjOption, mjmodel.h:403-445) — only the fields this path honours
   double timestep = 0.002, impratio = 1.0, tolerance = 1e-8;
@@ -56,6 +56,10 @@ struct Model {
   // ---- height fields (mjmodel.h:822-829)
   veci hfield_nrow, hfield_ncol, hfield_adr;
   vecd hfield_size, hfield_data;
+  // ---- meshes (mjmodel.h:770-800): only what the collision path needs, the vertices of each mesh's CONVEX HULL in the
+  // mesh geom's frame (MuJoCo collides mesh geoms through their hulls; mesh.cpp); geom_dataid = mesh id for mesh geoms
+  veci mesh_vertadr, mesh_vertnum;
+  vecd mesh_vert;
   // ---- fixed tendons (mjmodel.h:950-985): wrap_objid = joint id, wrap_prm = coef
   veci tendon_adr, tendon_num, tendon_limited, wrap_objid;
   vecd tendon_range, tendon_margin, tendon_solref_lim, tendon_solimp_lim, tendon_invweight0,
@@ -72,13 +76,15 @@ struct Model {
   vecd qpos0, qpos_spring, key_qpos;
 
   // ---- names
-  std::vector<std::string> body_name, jnt_name, geom_name, tendon_name, actuator_name, key_name;
+  std::vector<std::string> body_name, jnt_name, geom_name, tendon_name, actuator_name, key_name, mesh_name;
+
+  std::string pair_unsupported;  // compile time only: why a colliding geom pair cannot be simulated (empty: all pairs have colliders)
 
   // ---- field visitor used by serialisation (model_io.cpp): f(name, member) for every field
   template <class F> void visit(F& f) {
 #define HB_F(x) f(#x, x)
     HB_F(nq); HB_F(nv); HB_F(nu); HB_F(nbody); HB_F(njnt); HB_F(ngeom); HB_F(ntendon); HB_F(nwrap);
-    HB_F(nM); HB_F(nkey); HB_F(nexclude); HB_F(npair); HB_F(nhfield); HB_F(nhfielddata);
+    HB_F(nM); HB_F(nkey); HB_F(nexclude); HB_F(npair); HB_F(nhfield); HB_F(nhfielddata); HB_F(nmesh); HB_F(nmeshvert);
     HB_F(timestep); HB_F(impratio); HB_F(tolerance);
     f("gravity", gravity, 3);
     HB_F(integrator); HB_F(cone); HB_F(solver); HB_F(iterations); HB_F(disableflags);
@@ -97,6 +103,7 @@ struct Model {
     HB_F(geom_size); HB_F(geom_pos); HB_F(geom_quat); HB_F(geom_rbound); HB_F(geom_friction);
     HB_F(geom_solmix); HB_F(geom_solref); HB_F(geom_solimp); HB_F(geom_margin); HB_F(geom_gap);
     HB_F(hfield_nrow); HB_F(hfield_ncol); HB_F(hfield_adr); HB_F(hfield_size); HB_F(hfield_data);
+    HB_F(mesh_vertadr); HB_F(mesh_vertnum); HB_F(mesh_vert);
     HB_F(tendon_adr); HB_F(tendon_num); HB_F(tendon_limited); HB_F(wrap_objid);
     HB_F(tendon_range); HB_F(tendon_margin); HB_F(tendon_solref_lim); HB_F(tendon_solimp_lim);
     HB_F(tendon_invweight0); HB_F(tendon_length0); HB_F(wrap_prm);
@@ -106,7 +113,7 @@ struct Model {
     HB_F(exclude_body1); HB_F(exclude_body2); HB_F(pair_geom1); HB_F(pair_geom2);
     HB_F(qpos0); HB_F(qpos_spring); HB_F(key_qpos);
     HB_F(body_name); HB_F(jnt_name); HB_F(geom_name); HB_F(tendon_name); HB_F(actuator_name);
-    HB_F(key_name);
+    HB_F(key_name); HB_F(mesh_name);
 #undef HB_F
   }
 };
@@ -114,6 +121,9 @@ struct Model {
 // mjcf.cpp — MJCF subset compiler (replaces mj_loadXML, mujoco.h:103)
 bool compile_mjcf_file(const std::string& path, Model& m, std::string& err);
 bool compile_mjcf_string(const std::string& xml, Model& m, std::string& err);
+// mesh.cpp — STL reader and convex hull (the vertices MuJoCo's mesh collision uses)
+bool read_stl_vertices(const std::string& path, std::vector<double>& pts, std::string& err);
+bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull, std::string& err);
 // setconst.cpp — mj_setConst products (mujoco.h:221) computed in fp64 on the host
 bool set_const(Model& m, std::string& err);
 // model_io.cpp — ".hbm" text serialisation (replaces mj_saveModel/mj_loadModel, mujoco.h:159-163)

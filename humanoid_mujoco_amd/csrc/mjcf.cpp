@@ -35,7 +35,10 @@ struct Ctx {
   double default_density = 1000.0;
   std::map<std::string, DefaultClass> classes;
   std::map<std::string, std::string> hfield_names;  // name -> index (as string)
-  std::string basedir;
+  std::map<std::string, int> mesh_names;            // name -> mesh id
+  std::vector<double> mesh_center;                  // per mesh: centre of its hull's bounding box in the file's coordinates (the hull is stored relative to it)
+  std::vector<double> mesh_rbound;                  // per mesh: largest vertex distance from that centre
+  std::string basedir, meshdir;
   Model* m = nullptr;
   bool fail(const std::string& e) { if (err.empty()) err = e; return false; }
 };
@@ -227,7 +230,9 @@ bool add_geom(Ctx& c, const XmlNode& n, int body, const std::string& childclass,
   else if (ts == "sphere") type = GEOM_SPHERE;
   else if (ts == "capsule") type = GEOM_CAPSULE;
   else if (ts == "hfield") type = GEOM_HFIELD;
-  else return c.fail("mjcf: geom type '" + ts + "' is not supported (plane, sphere, capsule, hfield) in " + a.where);
+  else if (ts == "mesh") type = GEOM_MESH;
+  else if (ts == "cylinder") type = GEOM_CYLINDER;  // accepted as a non-colliding (visual) geom only: build_pairs refuses it in a collision pair
+  else return c.fail("mjcf: geom type '" + ts + "' is not supported (plane, sphere, capsule, hfield, mesh; cylinder when non-colliding) in " + a.where);
   GeomTmp g;
   g.type = type;
   g.size[0] = g.size[1] = g.size[2] = 0;
@@ -236,7 +241,7 @@ bool add_geom(Ctx& c, const XmlNode& n, int body, const std::string& childclass,
   if (a.vec("pos", g.pos, 3, 3) < 0) return false;
   if (!read_orientation(c, a, g.quat)) return false;
   if (a.has("fromto")) {
-    if (type != GEOM_CAPSULE) return c.fail("mjcf: fromto requires a capsule in " + a.where);
+    if (type != GEOM_CAPSULE && type != GEOM_CYLINDER) return c.fail("mjcf: fromto requires a capsule or cylinder in " + a.where);
     double ft[6];
     if (a.vec("fromto", ft, 6, 6) < 0) return false;
     double vec[3] = {ft[0] - ft[3], ft[1] - ft[4], ft[2] - ft[5]};
@@ -250,6 +255,19 @@ bool add_geom(Ctx& c, const XmlNode& n, int body, const std::string& childclass,
   if (type == GEOM_SPHERE && g.size[0] <= 0) return c.fail("mjcf: sphere needs size>0 in " + a.where);
   if (type == GEOM_CAPSULE && (g.size[0] <= 0 || g.size[1] <= 0)) return c.fail("mjcf: capsule needs radius and half-length in " + a.where);
   int dataid = -1;
+  if (type == GEOM_MESH) {
+    // MuJoCo collides a mesh geom through the convex hull of its mesh (mesh.cpp).  The hull is stored relative to the centre of
+    // its bounding box; that offset goes into the geom's position (MuJoCo re-centres on the mesh's centre of mass and aligns with
+    // its principal axes instead: the same surface in world coordinates)
+    std::string mn = a.str("mesh");
+    auto it = c.mesh_names.find(mn);
+    if (it == c.mesh_names.end()) return c.fail("mjcf: unknown mesh '" + mn + "' in " + a.where);
+    dataid = it->second;
+    double off[3];
+    hm::rot_vec_quat(off, &c.mesh_center[3 * dataid], g.quat);
+    for (int i = 0; i < 3; i++) g.pos[i] += off[i];
+    g.size[0] = g.size[1] = g.size[2] = 0;
+  }
   if (type == GEOM_HFIELD) {
     std::string hn = a.str("hfield");
     auto it = c.hfield_names.find(hn);
@@ -275,6 +293,8 @@ bool add_geom(Ctx& c, const XmlNode& n, int body, const std::string& childclass,
   double rb = 0;
   if (type == GEOM_SPHERE) rb = g.size[0];
   else if (type == GEOM_CAPSULE) rb = g.size[0] + g.size[1];
+  else if (type == GEOM_CYLINDER) rb = std::sqrt(g.size[0] * g.size[0] + g.size[1] * g.size[1]);
+  else if (type == GEOM_MESH) rb = c.mesh_rbound[dataid];
   else if (type == GEOM_HFIELD) {
     const double* hs = &m.hfield_size[4 * dataid];
     rb = std::sqrt(hs[0] * hs[0] + hs[1] * hs[1] + std::max(hs[2], hs[3]) * std::max(hs[2], hs[3]));
@@ -430,8 +450,6 @@ bool finish_body_inertia(Ctx& c, int body, BodyBuild& bb) {
       for (int k = 0; k < 3; k++) inertia[k] = w[idx[k]];
     }
   }
-  if (body > 0 && m.body_dofnum[body] > 0 && !(mass > 0))
-    return c.fail("mjcf: moving body '" + m.body_name[body] + "' has no mass");
   for (int i = 0; i < 3; i++) { m.body_ipos[3 * body + i] = ipos[i]; m.body_inertia[3 * body + i] = inertia[i]; }
   for (int i = 0; i < 4; i++) m.body_iquat[4 * body + i] = iquat[i];
   m.body_mass[body] = mass;
@@ -550,9 +568,53 @@ bool read_option(Ctx& c, const XmlNode& n) {
   return c.err.empty();
 }
 
+// <mesh name= file= | vertex= scale=>: convex hull vertices of the mesh (what mesh collision needs)
+bool read_mesh(Ctx& c, const XmlNode& n) {
+  Model& m = *c.m;
+  Attrs a;
+  a.c = &c; a.where = "<mesh" + (n.attr("name") ? " name=\"" + *n.attr("name") + "\"" : std::string()) + ">";
+  overlay(a.a, n);
+  std::vector<double> pts;
+  std::string name = a.str("name");
+  if (a.has("file")) {
+    std::string f = a.str("file");
+    std::string path = (f.size() && f[0] == '/') ? f : c.basedir + c.meshdir + f;
+    std::string lower = f;
+    for (auto& ch : lower) ch = (char)tolower((unsigned char)ch);
+    if (lower.size() < 4 || lower.substr(lower.size() - 4) != ".stl") return c.fail("mjcf: only STL mesh files are supported in " + a.where);
+    if (!read_stl_vertices(path, pts, c.err)) return false;
+    if (name.empty()) { size_t s0 = f.find_last_of('/'); name = f.substr(s0 == std::string::npos ? 0 : s0 + 1); name = name.substr(0, name.size() - 4); }
+  } else if (a.has("vertex")) {
+    if (!parse_doubles(a.str("vertex"), pts) || pts.size() % 3 != 0) return c.fail("mjcf: mesh vertex must hold 3 numbers per vertex in " + a.where);
+  } else return c.fail("mjcf: mesh needs file= or vertex= in " + a.where);
+  double sc[3] = {1, 1, 1};
+  if (a.vec("scale", sc, 3, 3) < 0) return false;
+  for (size_t i = 0; i < pts.size(); i++) pts[i] *= sc[i % 3];
+  std::vector<int> hull;
+  if (!convex_hull_vertices(pts, hull, c.err)) { c.err += " in " + a.where; return false; }
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int v : hull) for (int i = 0; i < 3; i++) { lo[i] = std::min(lo[i], pts[3 * v + i]); hi[i] = std::max(hi[i], pts[3 * v + i]); }
+  double cen[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])}, rb = 0;
+  c.mesh_names[name] = m.nmesh;
+  m.mesh_name.push_back(name);
+  m.mesh_vertadr.push_back(m.nmeshvert);
+  m.mesh_vertnum.push_back((int)hull.size());
+  for (int v : hull) {
+    double q[3] = {pts[3 * v] - cen[0], pts[3 * v + 1] - cen[1], pts[3 * v + 2] - cen[2]};
+    rb = std::max(rb, hm::norm3(q));
+    push3(m.mesh_vert, q);
+  }
+  push3(c.mesh_center, cen);
+  c.mesh_rbound.push_back(rb);
+  m.nmeshvert += (int)hull.size();
+  m.nmesh++;
+  return true;
+}
+
 bool read_assets(Ctx& c, const XmlNode& n) {
   Model& m = *c.m;
   for (auto& ch : n.children) {
+    if (ch->name == "mesh") { if (!read_mesh(c, *ch)) return false; continue; }
     if (ch->name != "hfield") continue;
     Attrs a;
     a.c = &c; a.where = "<hfield>";
@@ -690,6 +752,10 @@ void build_pairs(Model& m) {
       int a = g1, b = g2;
       if (t1 > t2) { std::swap(a, b); std::swap(t1, t2); }
       if (t2 == GEOM_PLANE || t2 == GEOM_HFIELD) continue;  // plane-plane, plane-hfield, hfield-hfield: no collider
+      if (t1 == GEOM_CYLINDER || t2 == GEOM_CYLINDER || t1 == GEOM_ELLIPSOID || t2 == GEOM_ELLIPSOID || t1 == GEOM_BOX || t2 == GEOM_BOX) {
+        m.pair_unsupported = "collision between geoms '" + m.geom_name[a] + "' and '" + m.geom_name[b] + "': cylinder / ellipsoid / box colliders are not implemented";
+        continue;
+      }
       m.pair_geom1.push_back(a);
       m.pair_geom2.push_back(b);
     }
@@ -739,6 +805,7 @@ bool compile_root(Ctx& c, XmlNode& root) {
       if (const std::string* s = ch->attr("eulerseq")) { if (s->size() != 3) return c.fail("mjcf: bad eulerseq"); c.eulerseq = *s; }
       if (const std::string* s = ch->attr("autolimits")) c.autolimits = (*s == "true");
       if (const std::string* s = ch->attr("coordinate")) if (*s != "local") return c.fail("mjcf: only local coordinates are supported");
+      if (const std::string* s = ch->attr("meshdir")) { c.meshdir = *s; if (!c.meshdir.empty() && c.meshdir.back() != '/') c.meshdir += '/'; }
     } else if (ch->name == "option") {
       if (!read_option(c, *ch)) return false;
     } else if (ch->name == "default") {
@@ -749,14 +816,28 @@ bool compile_root(Ctx& c, XmlNode& root) {
     }
   }
   // pass 2: kinematic tree
+  // (several <worldbody> elements - an included file's and the including file's - are one world body: children in document order)
   bool world_done = false;
+  XmlNode* world = nullptr;
   for (auto& ch : root.children) {
     if (ch->name != "worldbody") continue;
-    if (world_done) return c.fail("mjcf: multiple <worldbody> elements are not supported");
-    if (!compile_body(c, *ch, -1, "", 0)) return false;
+    if (!world) { world = ch.get(); continue; }
+    for (auto& gc : ch->children) world->children.push_back(std::move(gc));
+    ch->children.clear();
+  }
+  if (world) {
+    if (!compile_body(c, *world, -1, "", 0)) return false;
     world_done = true;
   }
   if (!world_done) return c.fail("mjcf: missing <worldbody>");
+  // a moving body needs mass: its own or that of the jointless bodies welded to it (the reference's robot hangs its torso,
+  // the only massive part of the trunk, off a massless free-floating link: simulation/assets/humanoid.xml:16-21)
+  {
+    std::vector<double> wmass(m.nbody, 0.0);
+    for (int b = 1; b < m.nbody; b++) wmass[m.body_weldid[b]] += m.body_mass[b];
+    for (int b = 1; b < m.nbody; b++)
+      if (m.body_dofnum[b] > 0 && !(wmass[b] > 0)) return c.fail("mjcf: moving body '" + m.body_name[b] + "' has no mass");
+  }
   // pass 3: everything that refers to bodies and joints by name
   for (auto& ch : root.children) {
     if (ch->name == "contact") {
@@ -803,6 +884,7 @@ bool compile_root(Ctx& c, XmlNode& root) {
     }
   }
   build_pairs(m);
+  if (!m.pair_unsupported.empty()) return c.fail("mjcf: " + m.pair_unsupported);
   if (!validate_model(m, c.err)) return false;
   return set_const(m, c.err);
 }

@@ -139,7 +139,7 @@ bool validate_model(const Model& m, std::string& err) {
   auto bad = [&](const std::string& what) { err = "model: " + what; return false; };
   if (m.nbody < 1 || m.nbody > 64) return bad("nbody must be 1..64");
   if (m.nq < 0 || m.nv < 0 || m.nu < 0 || m.njnt < 0 || m.ngeom < 0 || m.ntendon < 0 || m.nwrap < 0 || m.nkey < 0 || m.nexclude < 0 || m.npair < 0 ||
-      m.nhfield < 0 || m.nhfielddata < 0 || m.nM < 0)
+      m.nhfield < 0 || m.nhfielddata < 0 || m.nM < 0 || m.nmesh < 0 || m.nmeshvert < 0)
     return bad("negative size");
   if (m.nq > 4096 || m.nv > 4096 || m.nu > 4096 || m.njnt > 4096 || m.ngeom > 4096 || m.nwrap > 65536 || m.npair > (1 << 20)) return bad("size out of range");
   struct { const char* name; size_t have, want; } lens[] = {
@@ -158,6 +158,7 @@ bool validate_model(const Model& m, std::string& err) {
       HB_LEN(geom_rbound, m.ngeom), HB_LEN(geom_friction, 3 * m.ngeom), HB_LEN(geom_solmix, m.ngeom), HB_LEN(geom_solref, 2 * m.ngeom), HB_LEN(geom_solimp, 5 * m.ngeom),
       HB_LEN(geom_margin, m.ngeom), HB_LEN(geom_gap, m.ngeom),
       HB_LEN(hfield_nrow, m.nhfield), HB_LEN(hfield_ncol, m.nhfield), HB_LEN(hfield_adr, m.nhfield), HB_LEN(hfield_size, 4 * m.nhfield), HB_LEN(hfield_data, m.nhfielddata),
+      HB_LEN(mesh_vertadr, m.nmesh), HB_LEN(mesh_vertnum, m.nmesh), HB_LEN(mesh_vert, 3 * m.nmeshvert), HB_LEN(mesh_name, m.nmesh),
       HB_LEN(tendon_adr, m.ntendon), HB_LEN(tendon_num, m.ntendon), HB_LEN(tendon_limited, m.ntendon), HB_LEN(wrap_objid, m.nwrap), HB_LEN(tendon_range, 2 * m.ntendon),
       HB_LEN(tendon_margin, m.ntendon), HB_LEN(tendon_solref_lim, 2 * m.ntendon), HB_LEN(tendon_solimp_lim, 5 * m.ntendon), HB_LEN(tendon_invweight0, m.ntendon),
       HB_LEN(tendon_length0, m.ntendon), HB_LEN(wrap_prm, m.nwrap),
@@ -204,8 +205,19 @@ bool validate_model(const Model& m, std::string& err) {
   for (int g = 0; g < m.ngeom; g++) {
     if (!in(m.geom_bodyid[g], 0, m.nbody)) return bad("geom_bodyid out of range");
     const int t = m.geom_type[g];
-    if (t != GEOM_PLANE && t != GEOM_HFIELD && t != GEOM_SPHERE && t != GEOM_CAPSULE) return bad("geom type not supported");
+    if (t != GEOM_PLANE && t != GEOM_HFIELD && t != GEOM_SPHERE && t != GEOM_CAPSULE && t != GEOM_MESH && t != GEOM_CYLINDER) return bad("geom type not supported");
     if (t == GEOM_HFIELD && !in(m.geom_dataid[g], 0, m.nhfield)) return bad("height-field geom without a valid field");
+    if (t == GEOM_MESH && !in(m.geom_dataid[g], 0, m.nmesh)) return bad("mesh geom without a valid mesh");
+    const int cd = m.geom_condim[g];
+    if (cd != 1 && cd != 3 && cd != 4 && cd != 6) return bad("geom condim must be 1, 3, 4 or 6");
+  }
+  for (int p = 0; p < m.npair; p++)
+    if (!in(m.pair_geom1[p], 0, m.ngeom) || !in(m.pair_geom2[p], 0, m.ngeom)) return bad("pair geom out of range");
+  for (int k = 0; k < m.nmesh; k++)
+    if (m.mesh_vertnum[k] < 4 || m.mesh_vertadr[k] < 0 || m.mesh_vertadr[k] + m.mesh_vertnum[k] > m.nmeshvert) return bad("mesh vertex range out of bounds");
+  for (int p = 0; p < m.npair; p++) {
+    const int t1 = m.geom_type[m.pair_geom1[p]], t2 = m.geom_type[m.pair_geom2[p]];
+    if (t1 == GEOM_CYLINDER || t2 == GEOM_CYLINDER) return bad("cylinder geoms have no collider");
   }
   for (int h = 0; h < m.nhfield; h++) {
     if (m.hfield_nrow[h] < 2 || m.hfield_ncol[h] < 2 || m.hfield_nrow[h] > 4096 || m.hfield_ncol[h] > 4096) return bad("height-field dimensions out of range");
@@ -223,8 +235,6 @@ bool validate_model(const Model& m, std::string& err) {
   }
   for (int e = 0; e < m.nexclude; e++)
     if (!in(m.exclude_body1[e], 0, m.nbody) || !in(m.exclude_body2[e], 0, m.nbody)) return bad("exclude body out of range");
-  for (int p = 0; p < m.npair; p++)
-    if (!in(m.pair_geom1[p], 0, m.ngeom) || !in(m.pair_geom2[p], 0, m.ngeom)) return bad("pair geom out of range");
   if (!(m.timestep > 0) || !(m.impratio > 0) || !(m.meaninertia > 0) || m.iterations < 0 || m.ls_iterations < 0) return bad("option out of range");
   return true;
 }

@@ -40,7 +40,7 @@ enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 }; /* mjtSolver, mjmodel.h:159-16
 #define MINMU 1E-5     /* mjmodel.h:24 */
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
-enum { GEOM_PLANE = 0, GEOM_HFIELD = 1, GEOM_SPHERE = 2, GEOM_CAPSULE = 3 };
+enum { GEOM_PLANE = 0, GEOM_HFIELD = 1, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_CYLINDER = 5, GEOM_MESH = 7 }; /* mjtGeom, mjmodel.h:94-103 */
 enum { CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6 }; /* mjmodel.h:256-265 */
 enum { DSBL_CONSTRAINT = 1, DSBL_LIMIT = 8, DSBL_CONTACT = 16, DSBL_PASSIVE = 32, DSBL_GRAVITY = 64, DSBL_CLAMPCTRL = 128,
        DSBL_WARMSTART = 256, DSBL_ACTUATION = 1024, DSBL_REFSAFE = 2048, DSBL_EULERDAMP = 16384 };
@@ -50,7 +50,10 @@ enum { WARN_CONTACTFULL = 1, WARN_CNSTRFULL = 2, WARN_BADQPOS = 4, WARN_BADQVEL 
 #define OM_MAXEFC 640
 
 typedef struct {
-  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nwrap, nM, nkey, npair, nhfield, nhfielddata;
+  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nwrap, nM, nkey, npair, nhfield, nhfielddata, nmesh, nmeshvert;
+  int hfield_model;     /* 0: MuJoCo's prism scheme (mjc_ConvexHField); 1: the private closest-point terrain model of round 1 (kept for comparison only) */
+  int mpr_iterations;   /* mjOption.mpr_iterations, mjmodel.h:437 (default 50) */
+  double mpr_tolerance; /* mjOption.mpr_tolerance, mjmodel.h:413 (default 1e-6) */
   double timestep, impratio, tolerance, meaninertia, gravity[3];
   int integrator, cone, solver, iterations, disableflags;
   int ls_iterations;    /* mjOption.ls_iterations, mjmodel.h:434 (default 50) */
@@ -65,6 +68,8 @@ typedef struct {
   double *geom_size, *geom_pos, *geom_quat, *geom_rbound, *geom_friction, *geom_solmix, *geom_solref, *geom_solimp, *geom_margin, *geom_gap;
   int *hfield_nrow, *hfield_ncol, *hfield_adr;
   double *hfield_size, *hfield_data;
+  int *mesh_vertadr, *mesh_vertnum; /* convex-hull vertices of each mesh in the geom frame (what mesh collision uses) */
+  double* mesh_vert;
   int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
   double *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0, *tendon_length0, *wrap_prm;
   int *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited;
@@ -162,7 +167,8 @@ om_model* om_load(const char* path, char* err, int errsz) {
 #define RD(x) m->x = rec_dbl(recs, nr, #x, 0)
 #define AI(x, n) m->x = rec_iarr(recs, nr, #x, n)
 #define AD(x, n) m->x = rec_darr(recs, nr, #x, n)
-  RI(nq); RI(nv); RI(nu); RI(nbody); RI(njnt); RI(ngeom); RI(ntendon); RI(nwrap); RI(nM); RI(nkey); RI(npair); RI(nhfield); RI(nhfielddata);
+  RI(nq); RI(nv); RI(nu); RI(nbody); RI(njnt); RI(ngeom); RI(ntendon); RI(nwrap); RI(nM); RI(nkey); RI(npair); RI(nhfield); RI(nhfielddata); RI(nmesh); RI(nmeshvert);
+  m->mpr_iterations = 50; m->mpr_tolerance = 1e-6; m->hfield_model = 0;
   RD(timestep); RD(impratio); RD(tolerance); RD(meaninertia);
   RI(integrator); RI(cone); RI(solver); RI(iterations); RI(disableflags);
   m->ls_iterations = rec_int(recs, nr, "ls_iterations", 50); m->ls_tolerance = rec_dbl(recs, nr, "ls_tolerance", 0.01);
@@ -179,6 +185,7 @@ om_model* om_load(const char* path, char* err, int errsz) {
   AD(geom_size, 3 * ng); AD(geom_pos, 3 * ng); AD(geom_quat, 4 * ng); AD(geom_rbound, ng); AD(geom_friction, 3 * ng); AD(geom_solmix, ng);
   AD(geom_solref, 2 * ng); AD(geom_solimp, 5 * ng); AD(geom_margin, ng); AD(geom_gap, ng);
   AI(hfield_nrow, m->nhfield); AI(hfield_ncol, m->nhfield); AI(hfield_adr, m->nhfield); AD(hfield_size, 4 * m->nhfield); AD(hfield_data, m->nhfielddata);
+  AI(mesh_vertadr, m->nmesh); AI(mesh_vertnum, m->nmesh); AD(mesh_vert, 3 * m->nmeshvert);
   AI(tendon_adr, nt); AI(tendon_num, nt); AI(tendon_limited, nt); AI(wrap_objid, m->nwrap);
   AD(tendon_range, 2 * nt); AD(tendon_margin, nt); AD(tendon_solref_lim, 2 * nt); AD(tendon_solimp_lim, 5 * nt); AD(tendon_invweight0, nt);
   AD(tendon_length0, nt); AD(wrap_prm, m->nwrap);
@@ -669,6 +676,316 @@ static int hfield_sphere(const om_model* m, om_contact* c, double margin, int hi
   return 1;
 }
 
+/* ------------------------------------------------------------------ convex collision (libccd MPR) ----
+ * MuJoCo collides mesh geoms (through their convex hulls), and ANY geom against a height field, with libccd's Minkowski
+ * Portal Refinement: engine_collision_convex.c (mjc_Convex, mjc_ConvexHField; declared through mj_collision, mujoco.h:355)
+ * over third-party libccd (src/mpr.c: ccdMPRPenetration).  Neither source is in /root/reference (MuJoCo 3.1.4 is fetched at
+ * configure time, mujoco_mpc/CMakeLists.txt:58-88; libccd is one of ITS dependencies), so this is a restatement of the
+ * published algorithm (G. Snethen, "XenoCollide", Game Programming Gems 7; libccd mpr.c) [recall]: same portal discovery,
+ * refinement, expansion rule, tolerance test and penetration read-out, with libccd's double-precision epsilon. */
+
+#define CCD_EPS 2.220446049250313e-16 /* DBL_EPSILON: libccd built in double precision */
+static int ccd_is_zero(double x) { return fabs(x) < CCD_EPS; }
+static int ccd_eq(double a, double b) {
+  double ab = fabs(a - b);
+  if (ab < CCD_EPS) return 1;
+  a = fabs(a); b = fabs(b);
+  return b > a ? ab < CCD_EPS * b : ab < CCD_EPS * a;
+}
+static int ccd_vec_eq(const double* a, const double* b) { return ccd_eq(a[0], b[0]) && ccd_eq(a[1], b[1]) && ccd_eq(a[2], b[2]); }
+
+/* one collision object in the frame the test runs in: a geom (sphere / capsule / mesh hull) or a height-field prism */
+typedef struct {
+  int type;                 /* GEOM_SPHERE, GEOM_CAPSULE, GEOM_MESH, or -1: prism */
+  double pos[3], mat[9];    /* frame of the geom (row-major rotation) */
+  double size[3];
+  const double* vert;       /* mesh: hull vertices in the geom frame */
+  int nvert;
+  double margin;            /* mjccd_support inflates the shape by this much along the direction */
+  double prism[6][3];       /* prism: bottom triangle 0..2, top triangle 3..5 */
+} ccd_obj;
+
+/* mjccd_center / prism_center */
+static void ccd_center(const ccd_obj* o, double* c) {
+  if (o->type < 0) {
+    c[0] = c[1] = c[2] = 0;
+    for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) c[k] += o->prism[i][k];
+    for (int k = 0; k < 3; k++) c[k] /= 6.0;
+  } else memcpy(c, o->pos, 3 * sizeof(double));
+}
+/* mjccd_support / prism_support: the point of the object farthest along dir (dir is unit: every caller in mpr.c normalises) */
+static void ccd_support(const ccd_obj* o, const double* dir, double* out) {
+  if (o->type < 0) {
+    int best = 0;
+    double bd = -1e300;
+    for (int i = 0; i < 6; i++) { double v = dot3(o->prism[i], dir); if (v > bd) { bd = v; best = i; } }
+    memcpy(out, o->prism[best], 3 * sizeof(double));
+    return;
+  }
+  double ld[3], res[3];
+  for (int i = 0; i < 3; i++) ld[i] = o->mat[i] * dir[0] + o->mat[3 + i] * dir[1] + o->mat[6 + i] * dir[2];  /* mat' dir */
+  if (o->type == GEOM_SPHERE) { for (int i = 0; i < 3; i++) res[i] = ld[i] * o->size[0]; }
+  else if (o->type == GEOM_CAPSULE) {
+    for (int i = 0; i < 3; i++) res[i] = ld[i] * o->size[0];
+    res[2] += ld[2] >= 0 ? o->size[1] : -o->size[1];
+  } else { /* mesh: exhaustive search over the hull vertices (MuJoCo hill-climbs on large meshes: the same maximiser) */
+    int best = 0;
+    double bd = -1e300;
+    for (int i = 0; i < o->nvert; i++) { double v = dot3(o->vert + 3 * i, ld); if (v > bd) { bd = v; best = i; } }
+    memcpy(res, o->vert + 3 * best, sizeof res);
+  }
+  for (int i = 0; i < 3; i++) res[i] += ld[i] * o->margin;
+  for (int i = 0; i < 3; i++) out[i] = o->mat[3 * i] * res[0] + o->mat[3 * i + 1] * res[1] + o->mat[3 * i + 2] * res[2] + o->pos[i];
+}
+
+typedef struct { double v[3], v1[3], v2[3]; } ccd_sup;  /* a point of the Minkowski difference obj1 - obj2 and its two witnesses */
+static void mpr_support(const ccd_obj* o1, const ccd_obj* o2, const double* dir, ccd_sup* s) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  ccd_support(o1, dir, s->v1);
+  ccd_support(o2, nd, s->v2);
+  for (int i = 0; i < 3; i++) s->v[i] = s->v1[i] - s->v2[i];
+}
+static void vsub(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static void mpr_portal_dir(const ccd_sup* P, double* dir) {
+  double a[3], b[3];
+  vsub(a, P[2].v, P[1].v); vsub(b, P[3].v, P[1].v);
+  cross3(dir, a, b);
+  normalize3(dir);
+}
+static int mpr_reach_tolerance(const ccd_sup* P, const ccd_sup* v4, const double* dir, double tol) {
+  double dv1 = dot3(P[1].v, dir), dv2 = dot3(P[2].v, dir), dv3 = dot3(P[3].v, dir), dv4 = dot3(v4->v, dir);
+  double d = fmin(fmin(dv4 - dv1, dv4 - dv2), dv4 - dv3);
+  return ccd_eq(d, tol) || d < tol;
+}
+static void mpr_expand_portal(ccd_sup* P, const ccd_sup* v4) {
+  double v4v0[3];
+  cross3(v4v0, v4->v, P[0].v);
+  if (dot3(P[1].v, v4v0) > 0) { if (dot3(P[2].v, v4v0) > 0) P[1] = *v4; else P[3] = *v4; }
+  else { if (dot3(P[3].v, v4v0) > 0) P[2] = *v4; else P[1] = *v4; }
+}
+/* squared distance of the origin from triangle (a, b, c) and the closest point (ccdVec3PointTriDist2 with P = origin) */
+static void closest_on_triangle(double* out, const double* p, const double* a, const double* b, const double* c);
+static double origin_tri_dist2(const double* a, const double* b, const double* c, double* witness) {
+  const double o[3] = {0, 0, 0};
+  closest_on_triangle(witness, o, a, b, c);
+  return dot3(witness, witness);
+}
+
+/* ccdMPRPenetration: 0 and (depth, dir, pos) when the objects intersect, -1 otherwise.  dir points from obj1 into obj2. */
+static int mpr_penetration(const ccd_obj* o1, const ccd_obj* o2, int max_iterations, double tolerance, double* depth, double* pdir, double* pos) {
+  ccd_sup P[4];
+  double dir[3], va[3], vb[3];
+  const double origin[3] = {0, 0, 0};
+  /* ---- discoverPortal */
+  ccd_center(o1, P[0].v1); ccd_center(o2, P[0].v2);
+  vsub(P[0].v, P[0].v1, P[0].v2);
+  if (ccd_vec_eq(P[0].v, origin)) P[0].v[0] += CCD_EPS * 10;  /* centres coincide: nudge */
+  for (int i = 0; i < 3; i++) dir[i] = -P[0].v[i];
+  normalize3(dir);
+  mpr_support(o1, o2, dir, &P[1]);
+  double dt = dot3(P[1].v, dir);
+  if (ccd_is_zero(dt) || dt < 0) return -1;
+  cross3(dir, P[0].v, P[1].v);
+  if (ccd_is_zero(dot3(dir, dir))) {
+    if (ccd_vec_eq(P[1].v, origin)) { /* origin lies on v1: touching contact (findPenetrTouch) */
+      *depth = 0; pdir[0] = pdir[1] = pdir[2] = 0;
+      for (int i = 0; i < 3; i++) pos[i] = 0.5 * (P[1].v1[i] + P[1].v2[i]);
+      return 0;
+    }
+    /* origin lies on the v0-v1 segment (findPenetrSegment) */
+    for (int i = 0; i < 3; i++) { pos[i] = 0.5 * (P[1].v1[i] + P[1].v2[i]); pdir[i] = P[1].v[i]; }
+    *depth = normalize3(pdir);
+    return 0;
+  }
+  normalize3(dir);
+  mpr_support(o1, o2, dir, &P[2]);
+  dt = dot3(P[2].v, dir);
+  if (ccd_is_zero(dt) || dt < 0) return -1;
+  vsub(va, P[1].v, P[0].v); vsub(vb, P[2].v, P[0].v);
+  cross3(dir, va, vb);
+  normalize3(dir);
+  if (dot3(dir, P[0].v) > 0) { ccd_sup t = P[1]; P[1] = P[2]; P[2] = t; for (int i = 0; i < 3; i++) dir[i] = -dir[i]; }  /* portal faces oriented away from the origin */
+  for (int guard = 0; ; guard++) {
+    if (guard > 1000) return -1;  /* (libccd loops until the portal closes; this bound is never reached on convex input) */
+    mpr_support(o1, o2, dir, &P[3]);
+    dt = dot3(P[3].v, dir);
+    if (ccd_is_zero(dt) || dt < 0) return -1;
+    int cont = 0;
+    cross3(va, P[1].v, P[3].v);  /* origin outside (v1, v0, v3): v3 replaces v2 */
+    dt = dot3(va, P[0].v);
+    if (dt < 0 && !ccd_is_zero(dt)) { P[2] = P[3]; cont = 1; }
+    if (!cont) {
+      cross3(va, P[3].v, P[2].v);  /* origin outside (v3, v0, v2): v3 replaces v1 */
+      dt = dot3(va, P[0].v);
+      if (dt < 0 && !ccd_is_zero(dt)) { P[1] = P[3]; cont = 1; }
+    }
+    if (!cont) break;
+    vsub(va, P[1].v, P[0].v); vsub(vb, P[2].v, P[0].v);
+    cross3(dir, va, vb);
+    normalize3(dir);
+  }
+  /* ---- refinePortal */
+  ccd_sup v4;
+  for (int guard = 0; ; guard++) {
+    if (guard > 1000) return -1;
+    mpr_portal_dir(P, dir);
+    dt = dot3(dir, P[1].v);
+    if (ccd_is_zero(dt) || dt > 0) break;  /* the portal encapsulates the origin */
+    mpr_support(o1, o2, dir, &v4);
+    dt = dot3(v4.v, dir);
+    if (!(ccd_is_zero(dt) || dt > 0) || mpr_reach_tolerance(P, &v4, dir, tolerance)) return -1;  /* cannot reach the origin: no intersection */
+    mpr_expand_portal(P, &v4);
+  }
+  /* ---- findPenetr */
+  for (int it = 0; ; it++) {
+    mpr_portal_dir(P, dir);
+    mpr_support(o1, o2, dir, &v4);
+    if (mpr_reach_tolerance(P, &v4, dir, tolerance) || it > max_iterations) {
+      *depth = sqrt(origin_tri_dist2(P[1].v, P[2].v, P[3].v, pdir));
+      if (ccd_is_zero(*depth)) { pdir[0] = pdir[1] = pdir[2] = 0; }
+      else normalize3(pdir);
+      /* findPos: barycentric coordinates of the origin in the portal tetrahedron */
+      double b[4], t[3];
+      mpr_portal_dir(P, dir);
+      cross3(t, P[1].v, P[2].v); b[0] = dot3(t, P[3].v);
+      cross3(t, P[3].v, P[2].v); b[1] = dot3(t, P[0].v);
+      cross3(t, P[0].v, P[1].v); b[2] = dot3(t, P[3].v);
+      cross3(t, P[2].v, P[1].v); b[3] = dot3(t, P[0].v);
+      double sum = b[0] + b[1] + b[2] + b[3];
+      if (ccd_is_zero(sum) || sum < 0) {
+        b[0] = 0;
+        cross3(t, P[2].v, P[3].v); b[1] = dot3(t, dir);
+        cross3(t, P[3].v, P[1].v); b[2] = dot3(t, dir);
+        cross3(t, P[1].v, P[2].v); b[3] = dot3(t, dir);
+        sum = b[1] + b[2] + b[3];
+      }
+      double inv = 1.0 / sum;
+      for (int k = 0; k < 3; k++) {
+        double p1 = 0, p2 = 0;
+        for (int i = 0; i < 4; i++) { p1 += b[i] * P[i].v1[k]; p2 += b[i] * P[i].v2[k]; }
+        pos[k] = 0.5 * (p1 + p2) * inv;
+      }
+      return 0;
+    }
+    mpr_expand_portal(P, &v4);
+  }
+}
+
+static void ccd_obj_from_geom(const om_model* m, const om_data* d, int g, double margin, ccd_obj* o) {
+  o->type = m->geom_type[g];
+  memcpy(o->pos, d->geom_xpos + 3 * g, sizeof o->pos);
+  memcpy(o->mat, d->geom_xmat + 9 * g, sizeof o->mat);
+  memcpy(o->size, m->geom_size + 3 * g, sizeof o->size);
+  o->vert = NULL; o->nvert = 0; o->margin = margin;
+  if (o->type == GEOM_MESH) { int k = m->geom_dataid[g]; o->vert = m->mesh_vert + 3 * m->mesh_vertadr[k]; o->nvert = m->mesh_vertnum[k]; }
+}
+
+/* mjc_fixNormal [recall]: a sphere or capsule knows its own surface normal at the contact point; a mesh or prism does not.
+ * The contact normal (pointing from geom1 to geom2) is replaced by the analytic one where a geom has it, averaged if both do. */
+static void fix_normal(const om_model* m, const om_data* d, om_contact* c, int g1, int g2) {
+  double nrm[2][3];
+  int have[2] = {0, 0}, gid[2] = {g1, g2};
+  for (int i = 0; i < 2; i++) {
+    int g = gid[i], t = m->geom_type[g];
+    if (t != GEOM_SPHERE && t != GEOM_CAPSULE) continue;
+    const double *xp = d->geom_xpos + 3 * g, *mat = d->geom_xmat + 9 * g;
+    double dif[3] = {c->pos[0] - xp[0], c->pos[1] - xp[1], c->pos[2] - xp[2]}, lp[3];
+    for (int k = 0; k < 3; k++) lp[k] = mat[k] * dif[0] + mat[3 + k] * dif[1] + mat[6 + k] * dif[2];
+    if (t == GEOM_CAPSULE) { double h = m->geom_size[3 * g + 1]; lp[2] = lp[2] > h ? lp[2] - h : (lp[2] < -h ? lp[2] + h : 0); }
+    if (normalize3(lp) < MINVAL) continue;
+    for (int k = 0; k < 3; k++) nrm[i][k] = (mat[3 * k] * lp[0] + mat[3 * k + 1] * lp[1] + mat[3 * k + 2] * lp[2]) * (i == 0 ? 1.0 : -1.0);  /* outward of geom1, inward of geom2 */
+    have[i] = 1;
+  }
+  if (!have[0] && !have[1]) return;
+  double n[3];
+  for (int k = 0; k < 3; k++) n[k] = (have[0] ? nrm[0][k] : 0) + (have[1] ? nrm[1][k] : 0);
+  if (normalize3(n) < MINVAL) return;
+  memcpy(c->frame, n, sizeof n);
+}
+
+/* mjc_Convex: two convex geoms (at least one of them a mesh here), one contact (multiccd is off by default, mjmodel.h:75) */
+static int convex_convex(const om_model* m, const om_data* d, om_contact* con, int g1, int g2, double margin) {
+  ccd_obj o1, o2;
+  ccd_obj_from_geom(m, d, g1, 0.5 * margin, &o1);
+  ccd_obj_from_geom(m, d, g2, 0.5 * margin, &o2);
+  double depth, dir[3], pos[3];
+  if (mpr_penetration(&o1, &o2, m->mpr_iterations, m->mpr_tolerance, &depth, dir, pos) != 0) return 0;
+  if (dir[0] == 0 && dir[1] == 0 && dir[2] == 0) return 0;  /* contact found but its normal is undefined */
+  con->dist = margin - depth;
+  memcpy(con->frame, dir, sizeof dir);
+  memcpy(con->pos, pos, sizeof pos);
+  memset(con->frame + 3, 0, 6 * sizeof(double));
+  fix_normal(m, d, con, g1, g2);
+  return 1;
+}
+
+/* mjc_ConvexHField: geom g2 (sphere, capsule or mesh) against height field g1.  Everything runs in the field's frame: the
+ * geom's bounding box there picks a sub-grid; every grid cell of it is two triangular prisms (from the field's base up to the
+ * surface triangle); each prism that reaches the geom's height is tested with MPR and gives at most one contact. */
+#define OM_MAXCONPAIR 50 /* mjMAXCONPAIR, mjmodel.h:28 */
+static int convex_hfield(const om_model* m, const om_data* d, om_contact* con, int maxcon, int g1, int g2, double margin) {
+  const double *pos1 = d->geom_xpos + 3 * g1, *mat1 = d->geom_xmat + 9 * g1;
+  int hid = m->geom_dataid[g1];
+  const double* size1 = m->hfield_size + 4 * hid;
+  int nrow = m->hfield_nrow[hid], ncol = m->hfield_ncol[hid];
+  const double* data = m->hfield_data + m->hfield_adr[hid];
+  ccd_obj o2, prism;
+  ccd_obj_from_geom(m, d, g2, 0, &o2);
+  /* geom2 in the field's frame */
+  double dif[3] = {o2.pos[0] - pos1[0], o2.pos[1] - pos1[1], o2.pos[2] - pos1[2]}, pos[3], mat[9];
+  for (int i = 0; i < 3; i++) pos[i] = mat1[i] * dif[0] + mat1[3 + i] * dif[1] + mat1[6 + i] * dif[2];
+  double r2 = m->geom_rbound[g2];
+  for (int i = 0; i < 2; i++) if (size1[i] < pos[i] - r2 - margin || -size1[i] > pos[i] + r2 + margin) return 0;  /* box-sphere test */
+  if (size1[2] < pos[2] - r2 - margin || -size1[3] > pos[2] + r2 + margin) return 0;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += mat1[3 * k + i] * o2.mat[3 * k + j]; mat[3 * i + j] = s; }  /* mat1' mat2 */
+  memcpy(o2.pos, pos, sizeof pos); memcpy(o2.mat, mat, sizeof mat);
+  /* bounding box of geom2 in the field's frame from its support points */
+  double lo[3], hi[3], sp[3];
+  for (int k = 0; k < 3; k++) {
+    double dir[3] = {0, 0, 0};
+    dir[k] = 1; ccd_support(&o2, dir, sp); hi[k] = sp[k];
+    dir[k] = -1; ccd_support(&o2, dir, sp); lo[k] = sp[k];
+  }
+  if (lo[0] - margin > size1[0] || hi[0] + margin < -size1[0] || lo[1] - margin > size1[1] || hi[1] + margin < -size1[1] ||
+      lo[2] - margin > size1[2] || hi[2] + margin < -size1[3]) return 0;  /* box-box test */
+  int cmin = (int)floor((lo[0] + size1[0]) / (2 * size1[0]) * (ncol - 1)), cmax = (int)ceil((hi[0] + size1[0]) / (2 * size1[0]) * (ncol - 1));
+  int rmin = (int)floor((lo[1] + size1[1]) / (2 * size1[1]) * (nrow - 1)), rmax = (int)ceil((hi[1] + size1[1]) / (2 * size1[1]) * (nrow - 1));
+  if (cmin < 0) cmin = 0; if (rmin < 0) rmin = 0; if (cmax > ncol - 1) cmax = ncol - 1; if (rmax > nrow - 1) rmax = nrow - 1;
+  o2.margin = margin;  /* (the prism tops are raised by the margin as well: mjc_ConvexHField [recall]) */
+  double dx = 2.0 * size1[0] / (ncol - 1), dy = 2.0 * size1[1] / (nrow - 1);
+  const int dr[2] = {1, 0};  /* triangulation direction: the strip visits (r+1, c) before (r, c) [recall] */
+  prism.type = -1;
+  memset(prism.prism, 0, sizeof prism.prism);
+  prism.prism[0][2] = prism.prism[1][2] = prism.prism[2][2] = -size1[3];
+  int cnt = 0;
+  for (int r = rmin; r < rmax && cnt < maxcon; r++) {
+    int nvert = 0;
+    for (int c = cmin; c <= cmax && cnt < maxcon; c++)
+      for (int i = 0; i < 2 && cnt < maxcon; i++) {
+        /* addVert: shift the strip by one vertex */
+        for (int k = 0; k < 3; k++) { prism.prism[0][k] = prism.prism[1][k]; prism.prism[1][k] = prism.prism[2][k]; prism.prism[3][k] = prism.prism[4][k]; prism.prism[4][k] = prism.prism[5][k]; }
+        prism.prism[2][0] = prism.prism[5][0] = dx * c - size1[0];
+        prism.prism[2][1] = prism.prism[5][1] = dy * (r + dr[i]) - size1[1];
+        prism.prism[5][2] = data[(r + dr[i]) * ncol + c] * size1[2] + margin;
+        if (++nvert <= 2) continue;
+        if (prism.prism[3][2] < lo[2] && prism.prism[4][2] < lo[2] && prism.prism[5][2] < lo[2]) continue;  /* prism below the geom */
+        double depth, dir[3], vec[3];
+        if (mpr_penetration(&prism, &o2, m->mpr_iterations, m->mpr_tolerance, &depth, dir, vec) == 0 && !ccd_is_zero(depth)) {
+          om_contact* cc = con + cnt;
+          cc->dist = -depth;
+          for (int k = 0; k < 3; k++) {
+            cc->frame[k] = mat1[3 * k] * dir[0] + mat1[3 * k + 1] * dir[1] + mat1[3 * k + 2] * dir[2];
+            cc->pos[k] = mat1[3 * k] * vec[0] + mat1[3 * k + 1] * vec[1] + mat1[3 * k + 2] * vec[2] + pos1[k];
+          }
+          memset(cc->frame + 3, 0, 6 * sizeof(double));
+          cnt++;
+        }
+      }
+  }
+  for (int k = 0; k < cnt; k++) fix_normal(m, d, con + k, g1, g2);
+  return cnt;
+}
+
 /* contact parameter mixing — mj_contactParam [recall], mjmodel.h:733-741 */
 static void contact_param(const om_model* m, om_contact* c, int g1, int g2) {
   c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
@@ -709,9 +1026,17 @@ static void collision(const om_model* m, om_data* d) {
     double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
     const double *pos1 = d->geom_xpos + 3 * g1, *pos2 = d->geom_xpos + 3 * g2, *mat1 = d->geom_xmat + 9 * g1, *mat2 = d->geom_xmat + 9 * g2;
     const double *s1 = m->geom_size + 3 * g1, *s2 = m->geom_size + 3 * g2;
-    om_contact con[4];
+    om_contact con[OM_MAXCONPAIR];
     int n = 0;
-    if (t1 == GEOM_PLANE) {
+    if (t1 == GEOM_HFIELD && m->hfield_model == 0) {
+      n = convex_hfield(m, d, con, OM_MAXCONPAIR, g1, g2, margin);  /* MuJoCo's scheme: every geom type goes through the prisms */
+    } else if (t1 == GEOM_MESH || t2 == GEOM_MESH) {
+      if (t1 == GEOM_PLANE) continue;  /* plane - mesh (mjc_PlaneConvex) is not restated: the compiler refuses such models */
+      double dp[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
+      double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
+      if (dot3(dp, dp) > bound * bound) continue;
+      n = convex_convex(m, d, con, g1, g2, margin);
+    } else if (t1 == GEOM_PLANE) {
       double normal[3] = {mat1[2], mat1[5], mat1[8]};
       double dp[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
       if (dot3(dp, normal) > margin + m->geom_rbound[g2]) continue;
@@ -822,8 +1147,8 @@ static void make_constraint(const om_model* m, om_data* d) {
     d->nl = d->nefc;
   }
   if (!(m->disableflags & DSBL_CONTACT)) {
-    double* jp1 = (double*)malloc(sizeof(double) * 3 * nv * 3);
-    double *jp2 = jp1 + 3 * nv, *jd = jp2 + 3 * nv;
+    double* jp1 = (double*)malloc(sizeof(double) * 3 * nv * 6);
+    double *jp2 = jp1 + 3 * nv, *jd = jp2 + 3 * nv, *jr1 = jd + 6 * nv, *jr2 = jr1 + 3 * nv;  /* jd: 6 rows (3 translational, 3 rotational) */
     for (int ci = 0; ci < d->ncon; ci++) {
       om_contact* c = d->contact + ci;
       c->efc_address = -1;
@@ -844,7 +1169,19 @@ static void make_constraint(const om_model* m, om_data* d) {
         c->efc_address = i;
         memcpy(d->efc_J + (size_t)i * nv, jd, sizeof(double) * nv);
       } else {
-        if (c->dim != 3) { /* condim 4/6 need rotational rows; not used by the path's models */ c->dim = 3; }
+        /* pyramidal cone of dimension dim: 2 (dim - 1) rows  normal +- friction[k-1] * (direction k), k = 1 .. dim-1, where
+         * directions 1, 2 are the tangents (relative linear velocity), 3 the spin about the normal and 4, 5 the rolling about the
+         * tangents (relative ANGULAR velocity in the contact frame): mj_makeConstraint / mj_instantiateContact [recall] */
+        if (c->dim > 3) {
+          jac(m, d, NULL, jr1, c->pos, b1);
+          jac(m, d, NULL, jr2, c->pos, b2);
+          for (int r = 0; r < 3; r++)
+            for (int k = 0; k < nv; k++) {
+              double s = 0;
+              for (int a = 0; a < 3; a++) s += c->frame[3 * r + a] * (jr2[a * nv + k] - jr1[a * nv + k]);
+              jd[(3 + r) * nv + k] = s;
+            }
+        }
         int first = -1;
         for (int k = 1; k < c->dim; k++)
           for (int sgn = 1; sgn >= -1; sgn -= 2) {
@@ -873,7 +1210,8 @@ static void make_constraint(const om_model* m, om_data* d) {
         else {
           int j = i - c->efc_address;
           double fri = c->friction[j / 2];
-          d->efc_diagApprox[i] = tran + fri * fri * tran; /* dims 1,2 are translational */
+          double rot = m->body_invweight0[2 * b1 + 1] + m->body_invweight0[2 * b2 + 1];
+          d->efc_diagApprox[i] = tran + fri * fri * (j / 2 < 2 ? tran : rot); /* directions 1, 2 are translational, 3..5 rotational */
         }
       }
     }
@@ -1423,7 +1761,7 @@ double* om_model_ptr(om_model* m, const char* name, int* len) {
 }
 int om_model_int(const om_model* m, const char* name) {
 #define MI(x) if (!strcmp(name, #x)) return m->x;
-  MI(nq) MI(nv) MI(nu) MI(nbody) MI(njnt) MI(ngeom) MI(ntendon) MI(nM) MI(nkey) MI(npair) MI(iterations) MI(disableflags) MI(solver)
+  MI(nq) MI(nv) MI(nu) MI(nbody) MI(njnt) MI(ngeom) MI(ntendon) MI(nM) MI(nkey) MI(npair) MI(iterations) MI(disableflags) MI(solver) MI(nmesh) MI(nmeshvert) MI(hfield_model)
   return -1;
 }
 void om_model_set_int(om_model* m, const char* name, int v) {
@@ -1431,6 +1769,8 @@ void om_model_set_int(om_model* m, const char* name, int v) {
   else if (!strcmp(name, "disableflags")) m->disableflags = v;
   else if (!strcmp(name, "solver")) m->solver = v;
   else if (!strcmp(name, "ls_iterations")) m->ls_iterations = v;
+  else if (!strcmp(name, "hfield_model")) m->hfield_model = v;
+  else if (!strcmp(name, "mpr_iterations")) m->mpr_iterations = v;
 }
 void om_model_set_dbl(om_model* m, const char* name, double v) {
   if (!strcmp(name, "timestep")) m->timestep = v;
@@ -1468,6 +1808,7 @@ void om_contact_get(const om_data* d, int k, double* out) {
   const om_contact* c = d->contact + k;
   out[0] = c->dist; memcpy(out + 1, c->pos, 3 * sizeof(double)); memcpy(out + 4, c->frame, 9 * sizeof(double));
   out[13] = c->dim; out[14] = c->geom1; out[15] = c->geom2; out[16] = c->efc_address; out[17] = c->friction[0];
+  memcpy(out + 18, c->friction, 5 * sizeof(double));  /* out[18..22]: the full friction vector (sliding x2, torsional, rolling x2) */
 }
 void om_efc_types(const om_data* d, int* type, int* id) { for (int i = 0; i < d->nefc; i++) { type[i] = d->efc_type[i]; id[i] = d->efc_id[i]; } }
 void om_stats(const om_data* d, double* out) {
@@ -1584,3 +1925,15 @@ long long om_rollout_threads(const om_model* m, int n_env, int nstep, int nthrea
 }
 
 void om_free_model(om_model* m) { free(m); /* arrays intentionally leaked at process end: test-only code */ }
+
+/* test hook: MPR between two free-standing objects (type GEOM_SPHERE / GEOM_CAPSULE / GEOM_MESH; mat row-major; vert = nvert x 3 for
+ * a mesh).  Returns ccdMPRPenetration's result (0: intersecting) and fills depth, dir[3], pos[3]. */
+int om_mpr_test(int type1, const double* pos1, const double* mat1, const double* size1, const double* vert1, int nvert1,
+                int type2, const double* pos2, const double* mat2, const double* size2, const double* vert2, int nvert2,
+                double margin, double* depth, double* dir, double* pos) {
+  ccd_obj a, b;
+  memset(&a, 0, sizeof a); memset(&b, 0, sizeof b);
+  a.type = type1; memcpy(a.pos, pos1, sizeof a.pos); memcpy(a.mat, mat1, sizeof a.mat); memcpy(a.size, size1, sizeof a.size); a.vert = vert1; a.nvert = nvert1; a.margin = 0.5 * margin;
+  b.type = type2; memcpy(b.pos, pos2, sizeof b.pos); memcpy(b.mat, mat2, sizeof b.mat); memcpy(b.size, size2, sizeof b.size); b.vert = vert2; b.nvert = nvert2; b.margin = 0.5 * margin;
+  return mpr_penetration(&a, &b, 50, 1e-6, depth, dir, pos);
+}

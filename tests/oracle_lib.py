@@ -57,6 +57,8 @@ def lib():
         L.om_pgs_reverts.restype = ctypes.c_long; L.om_pgs_reverts.argtypes = []
         L.om_rollout_threads.restype = ctypes.c_longlong
         L.om_rollout_threads.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+        L.om_mpr_test.restype = ci
+        L.om_mpr_test.argtypes = [ci, pd, pd, pd, pd, ci, ci, pd, pd, pd, pd, ci, cd, pd, pd, pd]
         L.om_rollout_window.restype = ctypes.c_longlong
         L.om_rollout_window.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, pd]
         _lib = L
@@ -151,7 +153,7 @@ class Oracle:
 
     def set_opt(self, **kw):
         for k, v in kw.items():
-            if k in ("iterations", "disableflags", "solver", "ls_iterations"):
+            if k in ("iterations", "disableflags", "solver", "ls_iterations", "hfield_model", "mpr_iterations"):
                 self.L.om_model_set_int(self.m, k.encode(), int(v))
             else:
                 self.L.om_model_set_dbl(self.m, k.encode(), float(v))
@@ -181,12 +183,12 @@ class Oracle:
 
     def contacts(self):
         out = []
-        buf = (ctypes.c_double * 18)()
+        buf = (ctypes.c_double * 23)()
         for k in range(self.ncon):
             self.L.om_contact_get(self.d, k, buf)
             a = np.array(buf[:])
             out.append(dict(dist=a[0], pos=a[1:4].copy(), frame=a[4:13].reshape(3, 3).copy(), dim=int(a[13]),
-                            geom1=int(a[14]), geom2=int(a[15]), efc_address=int(a[16]), friction=a[17]))
+                            geom1=int(a[14]), geom2=int(a[15]), efc_address=int(a[16]), friction=a[17], friction5=a[18:23].copy()))
         return out
 
     def efc_types(self):
@@ -231,6 +233,29 @@ class Oracle:
         n = self.L.om_rollout_window(self.m, n_env, t_pre, nstep, nthread, env_offset,
                                      q.ctypes.data if q is not None else None, ctypes.addressof(st), ctypes.byref(rate))
         return n, q, dict(mean_ncon=st[0], mean_nefc=st[1], mean_iter=st[2], max_ncon=st[3], max_nefc=st[4]), rate.value
+
+
+def mpr(obj1, obj2, margin=0.0):
+    """libccd-MPR restatement on two free objects: obj = dict(type=2 sphere | 3 capsule | 7 mesh, pos, mat (3x3), size, vert (n x 3)).
+    Returns (result, depth, dir, pos); result 0 = intersecting."""
+    L = lib()
+    P = ctypes.POINTER(ctypes.c_double)
+
+    def pack(o):
+        pos = np.ascontiguousarray(o.get("pos", np.zeros(3)), dtype=np.float64)
+        mat = np.ascontiguousarray(o.get("mat", np.eye(3)), dtype=np.float64).reshape(9)
+        size = np.zeros(3); sz = np.atleast_1d(np.asarray(o.get("size", []), dtype=np.float64)); size[:len(sz)] = sz
+        vert = np.ascontiguousarray(o.get("vert", np.zeros((1, 3))), dtype=np.float64)
+        return int(o["type"]), pos, mat, size, vert
+
+    t1, p1, m1, s1, v1 = pack(obj1)
+    t2, p2, m2, s2, v2 = pack(obj2)
+    depth = ctypes.c_double(0.0)
+    d = np.zeros(3); x = np.zeros(3)
+    r = L.om_mpr_test(t1, p1.ctypes.data_as(P), m1.ctypes.data_as(P), s1.ctypes.data_as(P), v1.ctypes.data_as(P), len(v1),
+                      t2, p2.ctypes.data_as(P), m2.ctypes.data_as(P), s2.ctypes.data_as(P), v2.ctypes.data_as(P), len(v2),
+                      float(margin), ctypes.byref(depth), d.ctypes.data_as(P), x.ctypes.data_as(P))
+    return r, depth.value, d, x
 
 
 def halton(index, base):

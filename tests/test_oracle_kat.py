@@ -352,19 +352,21 @@ def test_tendon_and_chain_model(compiled):
 
 
 def test_heightfield_contact_model(compiled):
-    """Terrain contact (this engine's own model, not MuJoCo's prisms): a ball dropped on a sloped field rolls
-    downhill, the contact normal is the facet normal, the contact point lies midway between the surfaces."""
+    """Terrain contact, MuJoCo's scheme (mjc_ConvexHField: the prisms under the geom's bounding box, MPR per prism, the sphere's
+    own normal): a ball dropped on a sloped field rolls downhill, the contact normal is the facet normal, the contact point
+    lies between the two surfaces.  (tests/test_oracle_convex.py holds the closed-form check against sphere-on-plane.)"""
     o = Oracle(compiled["ball_hfield"])
     o.reset()
     o.step(400)
     o.forward()
     ball = [c for c in o.contacts() if c["geom2"] == 1]
-    assert len(ball) == 1
-    c = ball[0]
+    assert 1 <= len(ball) <= 4
+    c = min(ball, key=lambda k: k["dist"])
     # facet under the ball: elevation falls 0.15 m per 1.333 m in +x -> normal ~ (0.112, +-0.033, 0.993)
     assert abs(c["frame"][0][0] - 0.112) < 5e-3 and c["frame"][0][2] > 0.99
     centre = o.qpos[0:3]
-    assert abs(np.linalg.norm(centre - c["pos"]) - (0.12 + c["dist"] / 2)) < 1e-9
+    along = (centre - c["pos"]) @ c["frame"][0]
+    assert 0.12 + c["dist"] - 1e-6 <= along <= 0.12 + 1e-6
     assert -0.01 < c["dist"] < 0
     x0 = o.qpos[0]
     o.step(400)

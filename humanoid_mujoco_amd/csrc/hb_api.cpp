@@ -80,6 +80,27 @@ void mix_pair(const Model& m, int g1, int g2, int& dim, double* fr, double* solr
   gap = std::max(m.geom_gap[g1], m.geom_gap[g2]);
 }
 
+// Which instantiation of the step kernel a model needs (DevModel::variant): the classic one handles plane / sphere / capsule pairs
+// with condim 1 / 3; a mesh geom, a height field or a condim 4 / 6 pair takes the general collision + constraint assembly, with PGS on
+// 63 rows or Newton on kBigNefcMax rows.  false: no instantiation fits.
+bool model_variant(const Model& m, int& variant, int& ncon_max, int& nefc_max, std::string& err) {
+  bool general = false;
+  for (int p = 0; p < m.npair; p++) {
+    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+    if (t1 == GEOM_MESH || t2 == GEOM_MESH || t1 == GEOM_HFIELD || t2 == GEOM_HFIELD) general = true;
+    if ((t1 == GEOM_PLANE && t2 == GEOM_MESH) || (t2 == GEOM_PLANE && t1 == GEOM_MESH)) { err = "plane - mesh collision is not implemented (use a height field as the floor of mesh models)"; return false; }
+    const int dim = m.geom_priority[g1] != m.geom_priority[g2] ? m.geom_condim[m.geom_priority[g1] > m.geom_priority[g2] ? g1 : g2] : std::max(m.geom_condim[g1], m.geom_condim[g2]);
+    if (dim != 1 && dim != 3) general = true;
+  }
+  variant = 0; ncon_max = kNconMax; nefc_max = kNefcMax;
+  if (!general) return true;
+  if (m.nv > 28) { err = "models with mesh geoms, height fields or condim 4 / 6 support at most 28 degrees of freedom in this build"; return false; }
+  if (m.solver == SOL_NEWTON) { variant = 2; ncon_max = kBigNconMax; nefc_max = kBigNefcMax; }
+  else variant = 1;
+  return true;
+}
+
 bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   if (m.nv > 32) { err = "this build supports nv <= 32 degrees of freedom"; return false; }
   if (m.nbody > 64 || m.ngeom > 64) { err = "this build supports at most 64 bodies and 64 geoms"; return false; }
@@ -101,6 +122,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.iterations = m.iterations;
   dm.disableflags = m.disableflags;
   dm.solver = m.solver; dm.ls_iterations = m.ls_iterations; dm.ls_tolerance = (float)m.ls_tolerance;
+  if (!model_variant(m, dm.variant, dm.ncon_max, dm.nefc_max, err)) return false;
+  dm.mpr_iterations = 50; dm.mpr_tolerance = 1e-6f;  // mjOption.mpr_iterations / mpr_tolerance defaults (mjmodel.h:413,437)
 
   // trees, levels, children, dof masks
   std::vector<int> treeid(nb, 0), roots;
@@ -138,7 +161,10 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   // ---- LDS layout
   int off = 0;
   auto take = [&](int n) { int o = off; off += (n + 3) & ~3; return o; };
-  dm.cstride = 33;
+  // row stride of C: 33 (K = 32 for the matrix cores plus a pad column); the big Newton layout stores J rows only as wide as its dense
+  // order (NDENSE + 1: 21 for the reference's 18-dof robot, else 29): 256 rows of 33 floats would be 34 KB per env
+  dm.cstride = dm.variant == 2 ? (nv <= 20 ? 21 : 29) : 33;
+  dm.o_gquat = dm.variant ? take(4 * m.ngeom) : 0;
   dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
   dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(8 * nv);  /* angular[3], -, linear[3], - per dof */
   dm.o_qLD = take(2 * m.nM + 4); dm.o_smooth = take(nv);  // qLD: {M, H} pairs + the zero and one pad pairs of the dense views
@@ -149,6 +175,15 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.o_cvel = take(12 * nb);  // cvel[6] | cacc[6] records
   int endA = off;
   off = region;
+  dm.o_meta = 0;
+  if (dm.variant == 2) {
+    // Newton on kBigNefcMax rows: contacts, J rows, the dense M ([32][33], where the classic layout keeps the row meta), the
+    // compact row meta, one D / force word per row
+    dm.o_con = take(dm.ncon_max * kConStride);
+    dm.o_C = take(std::max(dm.nefc_max * dm.cstride + 64, kListMax * 5 + kWorkMax));  // (the collision pass borrows the head of C for its lists)
+    dm.o_efc = take(32 * 36);
+    dm.o_meta = take(dm.nefc_max * kMetaStride);
+  } else {
   dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);
   // per-row meta (13 slots x kNefcMax) is dead once the row quantities are in registers; W = L^-1 D^-1/2
   // ([32][33]) is built over it before the J W product and lives until the dual finish
@@ -157,7 +192,9 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   if (dm.o_efc != dm.o_C + (((kNefcMax + 1) * dm.cstride + 3) & ~3) || dm.o_efc + std::max(13 * kNefcMax, 32 * 36) - dm.o_C < 2 * 32 * 36) {
     err = "internal: LDS layout leaves no room for the Euler solve's W_H pair"; return false;
   }
-  dm.o_force = take(kGroup);
+  if (dm.variant == 1) dm.o_meta = take(64 * kMetaStride);
+  }
+  dm.o_force = take(std::max(kGroup, dm.nefc_max));
   int endB = off;
   // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
   dm.lds_floats = std::max(endA, endB);
@@ -175,7 +212,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   for (int p = 0; p < m.npair; p++) {
     int dim; double fr[3], sr[2], si[5], mg, gp;
     mix_pair(m, m.pair_geom1[p], m.pair_geom2[p], dim, fr, sr, si, mg, gp);
-    if (dim != 1 && dim != 3) { err = "contact dimension " + std::to_string(dim) + " is not implemented (condim 1 and 3 only)"; return false; }
+    if (dim != 1 && dim != 3 && dim != 4 && dim != 6) { err = "contact dimension " + std::to_string(dim) + " does not exist (condim 1, 3, 4, 6)"; return false; }
     pair_dim.push_back(dim);
     for (double v : fr) pair_fr.push_back(v);
     for (double v : sr) pair_solref.push_back(v);
@@ -294,6 +331,10 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(jnt_type, m.jnt_type); TI(jnt_qposadr, m.jnt_qposadr); TI(jnt_dofadr, m.jnt_dofadr); TF(qpos0, m.qpos0); TI(dof_jntid, m.dof_jntid); TI(dof_Madr, m.dof_Madr); TF(dof_damping, m.dof_damping); TI(mrec, mrec);
   TI(mdense, mdense); TI(mdense_c, mdense_c);
   TI(geom_type, m.geom_type); TI(geom_bodyid, m.geom_bodyid); TI(geom_dataid, m.geom_dataid);
+  std::vector<int> geom_meshadr(m.ngeom, 0), geom_meshnum(m.ngeom, 0);
+  for (int g = 0; g < m.ngeom; g++)
+    if (m.geom_type[g] == GEOM_MESH) { geom_meshadr[g] = m.mesh_vertadr[m.geom_dataid[g]]; geom_meshnum[g] = m.mesh_vertnum[m.geom_dataid[g]]; }
+  TI(geom_meshadr, geom_meshadr); TI(geom_meshnum, geom_meshnum);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
   std::vector<int> pair_self;  // both geoms of the pair on the robot (neither on the world body)
@@ -369,6 +410,9 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (int i = 0; i < 3; i++) r[8 + i] = (float)m.actuator_biasprm[3 * a + i];
     r[12] = (float)m.actuator_forcerange[2 * a]; r[13] = (float)m.actuator_forcerange[2 * a + 1];
   }
+  std::vector<float> meshv((size_t)std::max(1, m.nmeshvert) * 4, 0.f);  // hull vertices as 16-byte records
+  for (int v = 0; v < m.nmeshvert; v++) for (int i = 0; i < 3; i++) meshv[(size_t)4 * v + i] = (float)m.mesh_vert[3 * v + i];
+  const size_t o_meshv = T.addraw(meshv);
   const size_t o_arec = T.addraw(arec);
   size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec), o_crec = T.addraw(crec), o_trec = T.addraw(trec),
          o_lrec = T.addraw(lrec);
@@ -389,6 +433,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.trec = reinterpret_cast<const float4*>(D.d_flt + o_trec);
   dm.lrec = reinterpret_cast<const float4*>(D.d_flt + o_lrec);
   dm.arec = reinterpret_cast<const float4*>(D.d_flt + o_arec);
+  dm.mesh_vert = reinterpret_cast<const float4*>(D.d_flt + o_meshv);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);
@@ -555,7 +600,7 @@ int launch_segment(hb_batch* b, BatchPtrs P, int nsteps, const Segment& sg, int 
   P.blk0 = sg.lo; P.nblk = sg.hi - sg.lo;
   // a whole-batch permutation would mix segments: a segment only uses the order of its own envs
   P.order = (b->schedule && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2)) ? b->d_order : nullptr;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, nsteps, sg.st));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, nsteps, sg.st));
   if (reorder) HB_HIP(launch_order(b->d_counts, b->d_order, sg.lo, sg.hi - sg.lo, sg.st));
   return HB_OK;
 }
@@ -710,7 +755,7 @@ int hb_model_sizes(const hb_model* h, hb_sizes* out) {
   int nscalar = 0;
   for (int j = 0; j < m.njnt; j++) if (m.jnt_type[j] >= JNT_SLIDE) nscalar++;
   out->nobs = 2 * nscalar + 6;
-  out->ncon_max = kNconMax; out->nefc_max = kNefcMax;
+  { int variant; std::string e; if (!model_variant(m, variant, out->ncon_max, out->nefc_max, e)) { out->ncon_max = kNconMax; out->nefc_max = kNefcMax; } }
   return HB_OK;
 }
 
@@ -896,7 +941,7 @@ int hb_forward(hb_batch* b, const float* ctrl) {
   else if (n) HB_HIP(hipMemsetAsync(ctrl_for_write(b), 0, n * sizeof(float), main_stream(b)));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b)));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b)));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
@@ -1345,7 +1390,7 @@ static int rollout_rows(hb_batch* b, const float* ctrl, int H, const hb_sensor_s
   F.ctrl = b->d_ctrl + (H > 1 ? (size_t)(H - 2) * N * nu : 0); F.ctrl_mode = 0; F.integrate = 0;
   F.sensor_out = b->d_sensor_out + (size_t)(H - 1) * N * *stride;
   F.blk0 = 0; F.nblk = N;
-  HB_HIP(launch_step(b->D.d_dm, dm.solver, dm.nv, dm.lds_floats, F, 1, main_stream(b)));
+  HB_HIP(launch_step(b->D.d_dm, dm.variant, dm.solver, dm.nv, dm.lds_floats, F, 1, main_stream(b)));
   return HB_OK;
 }
 
@@ -1489,7 +1534,7 @@ int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
   int rc = sensor_setup(b, spec, 1, P);
   if (rc != HB_OK) return rc;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b)));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b)));
   HB_HIP(hipMemcpyAsync(sensor_out, b->d_sensor_out, (size_t)b->n_env * P.sensor_stride * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
@@ -1945,8 +1990,8 @@ int hb_diag_enable(hb_batch* b, int on) {
   HB_HIP(hipSetDevice(b->device));
   if (on && !b->d_diag_qacc) {
     size_t n = b->n_env;
-    if (hipMalloc((void**)&b->d_diag_qacc, n * b->D.dm.nv * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_diag_force, n * kNefcMax * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&b->d_diag_contact, n * kNconMax * kDiagConStride * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+    if (hipMalloc((void**)&b->d_diag_qacc, n * b->D.dm.nv * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_diag_force, n * b->D.dm.nefc_max * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&b->d_diag_contact, n * b->D.dm.ncon_max * kDiagConStride * sizeof(float)) != hipSuccess) return HB_ENOMEM;
   }
   b->diag = on != 0;
   return HB_OK;
@@ -1961,8 +2006,8 @@ static int copy_out(hb_batch* b, float* out, const float* dev, size_t n) {
   return HB_OK;
 }
 int hb_get_qacc(hb_batch* b, float* qacc) { return copy_out(b, qacc, b ? b->d_diag_qacc : nullptr, b ? (size_t)b->n_env * b->D.dm.nv : 0); }
-int hb_get_efc_force(hb_batch* b, float* f) { return copy_out(b, f, b ? b->d_diag_force : nullptr, b ? (size_t)b->n_env * kNefcMax : 0); }
-int hb_get_contacts(hb_batch* b, float* c) { return copy_out(b, c, b ? b->d_diag_contact : nullptr, b ? (size_t)b->n_env * kNconMax * kDiagConStride : 0); }
+int hb_get_efc_force(hb_batch* b, float* f) { return copy_out(b, f, b ? b->d_diag_force : nullptr, b ? (size_t)b->n_env * b->D.dm.nefc_max : 0); }
+int hb_get_contacts(hb_batch* b, float* c) { return copy_out(b, c, b ? b->d_diag_contact : nullptr, b ? (size_t)b->n_env * b->D.dm.ncon_max * kDiagConStride : 0); }
 
 void* hb_dev_alloc(hb_batch* b, uint64_t bytes) {
   if (!b || hipSetDevice(b->device) != hipSuccess) return nullptr;

@@ -23,8 +23,16 @@ namespace hb {
 constexpr int kGroup = 64;      // lanes cooperating on one env (one wavefront)
 constexpr int kNconMax = 24;    // contact capacity per env (overflow -> HB_WARN_CONTACTFULL)
 constexpr int kNefcMax = 63;    // constraint-row capacity per env (overflow -> HB_WARN_CNSTRFULL); lane 63 / row 63 of C carries the extra right-hand side
+// the general instantiations (mesh hulls, height-field prisms, condim 4 / 6: the reference's own robot) with the Newton solver hold
+// their rows in kBigGroups groups of 64 (lane l owns rows l, l + 64, ...): 256 rows, 48 contacts
+constexpr int kBigGroups = 4;
+constexpr int kBigNefcMax = 64 * kBigGroups;
+constexpr int kBigNconMax = 48;
+constexpr int kListMax = 128;   // general collision: pairs that survive the broadphase per step (more: HB_WARN_CONTACTFULL)
+constexpr int kWorkMax = 256;   // general collision: narrowphase work items (pair or pair x prism) per step
 constexpr int kConStride = 20;  // floats per contact record in LDS
 constexpr int kDiagConStride = 16;
+constexpr int kMetaStride = 4;  // floats per row in the general variants' row meta
 constexpr int kCountStride = 8;  // ints per env in BatchPtrs::counts: ncon, nefc, niter, cost, self-collision flag, spare
 constexpr int kBrecQuads = 18;  // float4s per level-ordered body record (see build_device_model)
 
@@ -36,6 +44,12 @@ struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, npair, nlevel, ntree, nlimcand, nhfielddata;
   int nstate;   // floats per env in the global state record: time, qpos, qvel, qacc_warmstart
   int nobs;
+  // which instantiation of the step kernel runs this model: 0 classic (plane / sphere / capsule, condim 1 / 3), 1 general collision
+  // (mesh hulls and height-field prisms through MPR, condim 1 / 3 / 4 / 6) with the 63-row solvers, 2 general collision + Newton on
+  // kBigNefcMax rows
+  int variant, ncon_max, nefc_max;
+  int mpr_iterations;
+  float mpr_tolerance;
   // options
   float timestep, gravity[3], inv_sqrt_impratio, tolerance, pgs_scale;
   int iterations, disableflags;
@@ -65,6 +79,9 @@ struct DevModel {
   // geoms
   const int HB_CONST *geom_type, *geom_bodyid;
   const float HB_CONST *geom_size, *geom_pos, *geom_quat, *geom_rbound;
+  // meshes: hull vertices as 16-byte records (x, y, z, -) and per geom the first record / the count (0 for other geom types)
+  const float4 HB_CONST* mesh_vert;
+  const int HB_CONST *geom_meshadr, *geom_meshnum;
   // height fields (static terrain on the world body): per geom the field id (-1 otherwise)
   const int HB_CONST *geom_dataid, *hfield_nrow, *hfield_ncol, *hfield_adr;
   const float HB_CONST *hfield_size, *hfield_data;
@@ -93,6 +110,8 @@ struct DevModel {
   int obs_root_body, obs_root_dofadr, obs_root_qadr;
   const int HB_CONST* obs_src;  // [nobs - 3]: state-record offset each copied observation entry comes from (-1: zero)
   // LDS layout (float offsets per env) — persistent region
+  int o_gquat;  // general collision only: world orientation of every geom (4 floats each)
+  int o_meta;   // general variants: per-row (R, K imp (pos - margin), B, -) written by makeConstraint
   int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qLD, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
   // region A (dynamics scratch)
   int o_xpos, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cvel;

@@ -247,6 +247,10 @@ __device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
   return a + ab * (vb * denom) + ac * (vc * denom);
 }
 
+}  // namespace hb
+#include "hb_mpr.hpp"
+namespace hb {
+
 // height field (geom1, static) vs sphere: this engine's terrain contact model (see the oracle's
 // hfield_sphere): closest point on the triangulated surface inside the sphere's footprint, one contact,
 // normal out of the terrain.  hmat = rotation of the field's frame (row-major), hpos its origin.
@@ -324,6 +328,17 @@ __device__ __forceinline__ float impedance(const float* solimp, float pos, float
   else y = powf(t, power) / powf(mm, power - 1.f);
   if (!lower) y = 1.f - y;
   return d0 + y * (d1 - d0);
+}
+
+// reference spring (K) and damper (B) of a constraint row from solref (mj_makeImpedance; oracle: make_constraint)
+__device__ __forceinline__ void kb_from_solref(float solref0, float solref1, float solimp1, float timestep, bool refsafe, float& K, float& B) {
+  const float dmax = clampf(solimp1, HB_MINIMP, HB_MAXIMP);
+  if (solref0 > 0.f) {
+    float tc = solref0;
+    if (refsafe) tc = fmaxf(tc, 2.f * timestep);
+    K = 1.f / fmaxf(HB_MINVAL, dmax * dmax * tc * tc * solref1 * solref1);
+    B = 2.f / fmaxf(HB_MINVAL, dmax * tc);
+  } else { K = -solref0 / fmaxf(HB_MINVAL, dmax * dmax); B = -solref1 / fmaxf(HB_MINVAL, dmax); }
 }
 
 constexpr int kWs = 36;  // 16-byte aligned rows: a row times a vector is eight ds_read_b128 pairs (dot32)
@@ -596,10 +611,243 @@ __device__ __forceinline__ void store_w_cols(float* WT, int stride, const f32x16
   for (int r = 0; r < 16; r++) p[crow(r) * stride] = T[r] * S[r];
 }
 
+// ---- general narrowphase (COLL = 1): every pair kind of the classic one plus mesh hulls and height-field prisms ----------------
+// exclusive prefix sum of a small non-negative count over the 64 lanes (and the total)
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+  total = __builtin_amdgcn_readlane(x, 63);
+  return x - v;
+}
+
+// mj_collision for models with mesh geoms and / or a height field (the reference's own robot: simulation/assets/world.xml:14-58).
+// Three passes over LDS lists: (1) broadphase per candidate pair, survivors in pair order; (2) work items: one per pair, or one
+// per prism of the sub-grid under the geom for a height-field pair (mjc_ConvexHField's double loop, flattened); (3) narrowphase,
+// one work item per lane, contacts appended in work-item order (= the oracle's order: pair, then grid row, then strip position).
+template <int NC>
+__device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata_all, int lane, const float* s_gpos, const float* s_gaxis, const float* s_gquat,
+                                               float* s_con, int* s_scratch, int& status) {
+  int* s_list = s_scratch;                   // [kListMax]
+  int* s_pinfo = s_scratch + kListMax;       // [kListMax][4]: rmin, cmin, ncols, nrows of a height-field pair's sub-grid
+  int* s_work = s_pinfo + 4 * kListMax;      // [kWorkMax]: list index << 16 | sub-item
+  int nlist = 0;
+  for (int p0 = 0; p0 < M.npair; p0 += kGroup) {
+    const int p = p0 + lane;
+    bool pass = false;
+    if (p < M.npair) {
+      const float4 c0 = M.crec[3 * (size_t)p], c1 = M.crec[3 * (size_t)p + 1];
+      const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y), t1 = __float_as_int(c0.z) & 255;
+      const V3 dp = ld3(s_gpos + 3 * g2) - ld3(s_gpos + 3 * g1);
+      if (t1 == 0) pass = dot(dp, ld3(s_gaxis + 3 * g1)) <= c0.w + c1.y;
+      else if (t1 == 1) pass = true;
+      else { const float bound = c1.x + c1.y + c0.w; pass = dot(dp, dp) <= bound * bound; }
+    }
+    const unsigned long long bal = __ballot(pass);
+    const int slot = nlist + __popcll(bal & ((1ull << lane) - 1ull));
+    if (pass && slot < kListMax) s_list[slot] = p;
+    nlist += __popcll(bal);
+  }
+  nlist = uniform(nlist);
+  if (nlist > kListMax) { status |= (1 << 1); nlist = kListMax; }
+  gsync();
+  int nwork = 0;
+  for (int i0 = 0; i0 < nlist; i0 += kGroup) {
+    const int idx = i0 + lane;
+    int cnt = 0;
+    if (idx < nlist) {
+      const int p = s_list[idx];
+      const float4 c0 = M.crec[3 * (size_t)p], c1 = M.crec[3 * (size_t)p + 1];
+      const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y), t1 = __float_as_int(c0.z) & 255;
+      cnt = 1;
+      if (t1 == 1) {
+        // mjc_ConvexHField's culling with the geom's bounding sphere in place of its exact bounding box (a superset of the
+        // oracle's prisms: the extra ones do not intersect the geom, so they add no contact)
+        float hm[9];
+        q2mat(hm, ldq(M.geom_quat + 4 * g1));
+        const int hid = M.geom_dataid[g1];
+        const float sx = M.hfield_size[4 * hid], sy = M.hfield_size[4 * hid + 1], sz = M.hfield_size[4 * hid + 2], sb = M.hfield_size[4 * hid + 3];
+        const int nrow = M.hfield_nrow[hid], ncol = M.hfield_ncol[hid];
+        const V3 dif = ld3(s_gpos + 3 * g2) - ld3(s_gpos + 3 * g1);
+        const V3 q = {hm[0] * dif.x + hm[3] * dif.y + hm[6] * dif.z, hm[1] * dif.x + hm[4] * dif.y + hm[7] * dif.z, hm[2] * dif.x + hm[5] * dif.y + hm[8] * dif.z};
+        const float reach = c1.y + c0.w;
+        if (sx < q.x - reach || -sx > q.x + reach || sy < q.y - reach || -sy > q.y + reach || sz < q.z - reach || -sb > q.z + reach) cnt = 0;
+        else {
+          int cmin = (int)floorf((q.x - reach + sx) / (2.f * sx) * (float)(ncol - 1)), cmax = (int)ceilf((q.x + reach + sx) / (2.f * sx) * (float)(ncol - 1));
+          int rmin = (int)floorf((q.y - reach + sy) / (2.f * sy) * (float)(nrow - 1)), rmax = (int)ceilf((q.y + reach + sy) / (2.f * sy) * (float)(nrow - 1));
+          cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, ncol - 1); rmax = min(rmax, nrow - 1);
+          const int ncols = max(cmax - cmin, 0), nrows = max(rmax - rmin, 0);
+          cnt = nrows * 2 * ncols;
+          s_pinfo[4 * idx] = rmin; s_pinfo[4 * idx + 1] = cmin; s_pinfo[4 * idx + 2] = ncols; s_pinfo[4 * idx + 3] = nrows;
+        }
+      }
+    }
+    int total;
+    const int base = nwork + wave_excl_scan(cnt, lane, total);
+    for (int k = 0; k < cnt; k++) if (base + k < kWorkMax) s_work[base + k] = (idx << 16) | k;
+    nwork += total;
+  }
+  nwork = uniform(nwork);
+  if (nwork > kWorkMax) { status |= (1 << 1); nwork = kWorkMax; }
+  gsync();
+  int ncon = 0;
+  for (int w0 = 0; w0 < nwork; w0 += kGroup) {
+    const bool have = w0 + lane < nwork;
+    const int item = have ? s_work[w0 + lane] : 0;
+    const int idx = item >> 16, sub = item & 0xffff;
+    const int p = have ? s_list[idx] : 0;
+    float4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+    if (have) { const float4 HB_CONST* N = M.crec + 3 * (size_t)p; c0 = N[0]; c1 = N[1]; c2 = N[2]; }
+    ConOut co0, co1;
+    co0.dist = 0.f; co0.pos = {0.f, 0.f, 0.f}; co0.n = {0.f, 0.f, 1.f}; co1 = co0;
+    int n = 0;
+    V3 hint = {0.f, 0.f, 0.f};
+    const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y);
+    const int t1 = __float_as_int(c0.z) & 255, t2 = (__float_as_int(c0.z) >> 8) & 255;
+    const float margin = c0.w;
+    // the two objects of an MPR test (one call site below)
+    CObj o1, o2;
+    int mpr_kind = 0;  // 0: no MPR for this item, 1: prism vs geom (field frame), 2: geom vs geom (world frame)
+    float hm[9];
+    V3 pos1 = {0.f, 0.f, 0.f};
+    if (have) {
+      pos1 = ld3(s_gpos + 3 * g1);
+      const V3 pos2 = ld3(s_gpos + 3 * g2), ax2 = ld3(s_gaxis + 3 * g2);
+      const float rb1 = c1.x, rb2 = c1.y, r2 = c2.x, l2 = c2.y;
+      (void)rb1;
+      if (t1 == 1) {
+        q2mat(hm, ldq(M.geom_quat + 4 * g1));
+        const int hid = M.geom_dataid[g1];
+        const float sx = M.hfield_size[4 * hid], sy = M.hfield_size[4 * hid + 1], sz = M.hfield_size[4 * hid + 2], sb = M.hfield_size[4 * hid + 3];
+        const int nrow = M.hfield_nrow[hid], ncol = M.hfield_ncol[hid];
+        const float* data = hdata_all + M.hfield_adr[hid];
+        const int rmin = s_pinfo[4 * idx], cmin = s_pinfo[4 * idx + 1], ncols = s_pinfo[4 * idx + 2];
+        const int r = rmin + sub / (2 * ncols), j = sub % (2 * ncols);
+        const float dx = 2.f * sx / (float)(ncol - 1), dy = 2.f * sy / (float)(nrow - 1);
+        // strip vertex s of grid row r: column cmin + s / 2, grid row r + 1 for even s, r for odd s (mjc_ConvexHField: dr = {1, 0})
+        V3 tv[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int sidx = j + k, cc = cmin + (sidx >> 1), rr = r + ((sidx & 1) ? 0 : 1);
+          tv[k] = {dx * (float)cc - sx, dy * (float)rr - sy, data[rr * ncol + cc] * sz + margin};
+        }
+        // geom 2 in the field's frame
+        const V3 dif = pos2 - pos1;
+        o2.pos = {hm[0] * dif.x + hm[3] * dif.y + hm[6] * dif.z, hm[1] * dif.x + hm[4] * dif.y + hm[7] * dif.z, hm[2] * dif.x + hm[5] * dif.y + hm[8] * dif.z};
+        if (!(tv[0].z < o2.pos.z - rb2 && tv[1].z < o2.pos.z - rb2 && tv[2].z < o2.pos.z - rb2)) {  // (prism height test, with the bounding sphere's lowest point)
+          float m2[9];
+          q2mat(m2, ldq(s_gquat + 4 * g2));
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) o2.mat[3 * a + b] = hm[a] * m2[b] + hm[3 + a] * m2[3 + b] + hm[6 + a] * m2[6 + b];  // hm' m2
+          o2.type = t2; o2.r = r2; o2.h = l2; o2.margin = margin;
+          o2.vert = M.mesh_vert + M.geom_meshadr[g2]; o2.nvert = M.geom_meshnum[g2];
+          o1.type = -1; o1.pos = {0.f, 0.f, 0.f}; o1.r = o1.h = o1.margin = 0.f; o1.vert = M.mesh_vert; o1.nvert = 0;
+#pragma unroll
+          for (int a = 0; a < 9; a++) o1.mat[a] = 0.f;
+          o1.p0 = {tv[0].x, tv[0].y, -sb}; o1.p1 = {tv[1].x, tv[1].y, -sb}; o1.p2 = {tv[2].x, tv[2].y, -sb};
+          o1.p3 = tv[0]; o1.p4 = tv[1]; o1.p5 = tv[2];
+          mpr_kind = 1;
+        }
+      } else if (t1 == 7 || t2 == 7) {
+        // mjc_Convex: both geoms in the world frame, each inflated by half the margin
+        q2mat(o1.mat, ldq(s_gquat + 4 * g1));
+        q2mat(o2.mat, ldq(s_gquat + 4 * g2));
+        o1.type = t1; o1.pos = pos1; o1.r = c1.z; o1.h = c1.w; o1.margin = 0.5f * margin; o1.vert = M.mesh_vert + M.geom_meshadr[g1]; o1.nvert = M.geom_meshnum[g1];
+        o2.type = t2; o2.pos = pos2; o2.r = r2; o2.h = l2; o2.margin = 0.5f * margin; o2.vert = M.mesh_vert + M.geom_meshadr[g2]; o2.nvert = M.geom_meshnum[g2];
+        o1.p0 = o1.p1 = o1.p2 = o1.p3 = o1.p4 = o1.p5 = V3{0.f, 0.f, 0.f};
+        mpr_kind = 2;
+      } else if (t1 == 0) {
+        const V3 normal = ld3(s_gaxis + 3 * g1);
+        if (dot(pos2 - pos1, normal) <= margin + rb2) {
+          if (t2 == 2) n = plane_sphere(co0, margin, pos1, normal, pos2, r2) ? 1 : 0;
+          else {
+            ConOut ca, cb;
+            const bool h1 = plane_sphere(ca, margin, pos1, normal, pos2 + ax2 * l2, r2);
+            const bool h2 = plane_sphere(cb, margin, pos1, normal, pos2 - ax2 * l2, r2);
+            co0 = h1 ? ca : cb;
+            co1 = cb;
+            n = (h1 ? 1 : 0) + (h2 ? 1 : 0);
+            hint = ax2;
+          }
+        }
+      } else {
+        const float r1 = c1.z, l1 = c1.w;
+        if (t1 == 2 && t2 == 2) n = sphere_sphere(co0, margin, pos1, r1, pos2, r2) ? 1 : 0;
+        else if (t1 == 2) {
+          const float x = clampf(dot(ax2, pos1 - pos2), -l2, l2);
+          n = sphere_sphere(co0, margin, pos1, r1, pos2 + ax2 * x, r2) ? 1 : 0;
+        } else n = capsule_capsule(co0, co1, margin, pos1, ld3(s_gaxis + 3 * g1), r1, l1, pos2, ax2, r2, l2);
+      }
+    }
+    if (mpr_kind) {
+      float depth;
+      V3 dir, vec;
+      const bool hit = mpr_penetration(o1, o2, M.mpr_iterations, M.mpr_tolerance, depth, dir, vec);
+      if (mpr_kind == 1) {
+        if (hit && !ccd_is_zero(depth)) {
+          co0.dist = -depth;
+          co0.n = mrot(hm, dir);
+          co0.pos = mrot(hm, vec) + pos1;
+          n = 1;
+        }
+      } else if (hit && !(dir.x == 0.f && dir.y == 0.f && dir.z == 0.f)) {
+        co0.dist = margin - depth;
+        co0.n = dir;
+        co0.pos = vec;
+        n = 1;
+      }
+      if (n) {  // mjc_fixNormal: spheres and capsules know their own normal
+        float m1[9], m2[9];
+        q2mat(m1, ldq(s_gquat + 4 * g1));
+        q2mat(m2, ldq(s_gquat + 4 * g2));
+        V3 n1, n2;
+        const bool h1 = analytic_normal(t1, pos1, m1, c1.w, co0.pos, n1), h2 = analytic_normal(t2, ld3(s_gpos + 3 * g2), m2, c2.y, co0.pos, n2);
+        if (h1 || h2) {
+          V3 nn = {0.f, 0.f, 0.f};
+          if (h1) nn = nn + n1;
+          if (h2) nn = nn - n2;
+          float len;
+          nn = normalized(nn, &len);
+          if (len >= HB_MINVAL) co0.n = nn;
+        }
+      }
+    }
+    // ordered append: slot = ncon + (# contacts of lower lanes)
+    const unsigned long long b1 = __ballot(n >= 1), b2 = __ballot(n >= 2);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int slot = ncon + __popcll(b1 & lt) + __popcll(b2 & lt);
+    if (n >= 1 && slot < NC) {
+      float* c = s_con + slot * kConStride;
+      c[C_DIST] = co0.dist;
+      st3(c + C_POS, co0.pos);
+      make_frame(c + C_FRAME, co0.n, hint);
+      c[C_PAIR] = __int_as_float(p);
+    }
+    if (n >= 2 && slot + 1 < NC) {
+      float* c = s_con + (slot + 1) * kConStride;
+      c[C_DIST] = co1.dist;
+      st3(c + C_POS, co1.pos);
+      make_frame(c + C_FRAME, co1.n, hint);
+      c[C_PAIR] = __int_as_float(p);
+    }
+    ncon += __popcll(b1) + __popcll(b2);
+  }
+  if (ncon > NC) { status |= (1 << 1); ncon = NC; }
+  return ncon;
+}
+
 // SOLVER: mjtSolver of the instantiation (0 = PGS, 2 = Newton); everything outside the constraint solve, the mass-matrix
 // factorisation and the integrator's damped solve is shared.
-template <int SOLVER, int NDENSE>
+// COLL: 0 = the classic narrowphase (plane / sphere / capsule pairs, condim 1 / 3, inline), 1 = the general one (adds mesh hulls and
+// height-field prisms through MPR, condim 4 / 6).  NG: constraint rows live in NG groups of 64 (lane l owns rows l + 64 g); NG > 1
+// only with the Newton solver (kBigGroups: 256 rows, for the reference's own robot: ten pyramid rows per condim-6 contact).
+template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1>
 __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps) {
+  static_assert(NG == 1 || SOLVER == 2, "more than one row group: Newton only");
+  constexpr int kNR = NG == 1 ? kNefcMax : 64 * NG;  // row capacity of this instantiation
+  constexpr int kNC = NG == 1 ? kNconMax : kBigNconMax;  // contact capacity
   // the model tables are read through a constant-address-space pointer (not by-value kernel
   // arguments): the ~100 table pointers and every wave-uniform table entry are fetched on demand by
   // scalar loads through the scalar cache instead of living in (and spilling from) SGPRs
@@ -646,6 +894,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   float* s_efc = lds + M.o_efc;  // per-row meta, stride kNefcMax; dead once the row quantities are in registers
   float* s_W = lds + M.o_efc;    // W = L^-1 D^-1/2, [32][33], aliases the row meta
   float* s_force = lds + M.o_force;
+  const float* s_gquat = lds + M.o_gquat;  // general collision only: world orientation of every geom
+  float* s_meta = lds + M.o_meta;          // general variants: per-row (R, K imp (pos - margin), B, -)
+  (void)s_gquat; (void)s_meta;
   constexpr int kCs = 33;            // row stride of C (odd: conflict-free lane-strided access; column 32 is zero padding)
   static_assert(kNefcMax == kGroup - 1, "C holds kNefcMax constraint rows plus the qfrc_smooth row");
   // per-row meta slots
@@ -831,6 +1082,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       st3(s_gpos + 3 * g, ld3(s_xpq + 8 * b) + mrot(s_xmat + 9 * b, pf_gpos));
       Q4 q = qmul(ldq(s_xpq + 8 * b + 4), pf_gquat);
       st3(s_gaxis + 3 * g, {2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z});
+      if constexpr (COLL != 0) stq(lds + M.o_gquat + 4 * g, q);
     }
     // ---------------------------------------------------------------- mj_comPos
     for (int t = 0; t < M.ntree; t++) {
@@ -1154,7 +1406,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // ---------------------------------------------------------------- mj_collision
     int ncon = 0;
     const bool contacts_on = !(M.disableflags & ((1 << 0) | (1 << 4)));
-    if (contacts_on) {
+    if constexpr (COLL != 0) {
+      if (contacts_on) ncon = collide_general<kNC>(M, dr ? dr + DL.o_hfield : (const float*)M.hfield_data, lane, s_gpos, s_gaxis, s_gquat, s_con, reinterpret_cast<int*>(s_C), status);
+    } else if (contacts_on) {
       // Two passes.  (1) Broadphase over every candidate pair - bounding spheres, or distance to the plane - with the
       // survivors compacted, IN PAIR ORDER, into a list (ballot + popcount; the list borrows the head of C, which is not
       // written before makeConstraint).  (2) Narrowphase over the list, 64 survivors per round: for the humanoid that is
@@ -1276,6 +1530,125 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // ---------------------------------------------------------------- mj_makeConstraint
     int nefc = 0;
     const bool constraints_on = !(M.disableflags & (1 << 0));
+    const int selfcol = __any(selfc) ? 1 : 0;
+    if constexpr (COLL != 0) {
+      // ---- general form: limits, then contacts of dimension 1 / 3 / 4 / 6 (one row, or 2 (dim - 1) pyramid rows); what the solver
+      // needs of a row besides its Jacobian is written once, here: s_meta[row] = (R, K imp (pos - margin), B, -)
+      if (constraints_on && !(M.disableflags & (1 << 3))) {
+        for (int c0 = 0; c0 < M.nlimcand; c0 += kGroup) {
+          const int c = c0 + lane;
+          bool active = false;
+          float dist = 0.f, margin = 0.f;
+          int side = 0, kind = 0, id = 0;
+          float4 l0 = {0.f, 0.f, 0.f, 0.f}, l1 = l0, l2 = l0, l3 = l0;
+          if (c < M.nlimcand) {
+            const float4 HB_CONST* LR = M.lrec + (size_t)c * 4;
+            l0 = LR[0]; l1 = LR[1]; l2 = LR[2]; l3 = LR[3];
+            kind = __float_as_int(l0.x); id = __float_as_int(l0.y); side = __float_as_int(l0.z);
+            margin = dr ? dr[DL.o_lmargin + c] : l1.x;
+            const float value = kind == 0 ? s_qpos[__float_as_int(l0.w)] : s_tenlen[id];
+            dist = (float)side * ((dr ? dr[DL.o_lrange + c] : l1.y) - value);
+            active = dist < margin;
+          }
+          const unsigned long long bal = __ballot(active);
+          const int row = nefc + __popcll(bal & ((1ull << lane) - 1ull));
+          if (active && row < kNR) {
+            float* Jr = s_C + row * cs;
+            for (int k = 0; k < cs; k++) Jr[k] = 0.f;
+            if (kind == 0) Jr[__float_as_int(l3.z)] = (float)(-side);
+            else for (int w = 0; w < M.tendon_num[id]; w++) Jr[M.wrap_dofadr[M.tendon_adr[id] + w]] = (float)(-side) * M.wrap_prm[M.tendon_adr[id] + w];
+            const float solimp[5] = {l2.x, l2.y, l2.z, l2.w, l3.x};
+            const float imp = clampf(impedance(solimp, dist, margin), HB_MINIMP, HB_MAXIMP);
+            float K, Bc;
+            kb_from_solref(l1.z, l1.w, solimp[1], M.timestep, !(M.disableflags & (1 << 11)), K, Bc);
+            float* e = s_meta + kMetaStride * row;
+            e[0] = fmaxf(HB_MINVAL, (1.f - imp) * l3.y / imp); e[1] = K * imp * (dist - margin); e[2] = Bc;
+          }
+          nefc += __popcll(bal);
+        }
+        if (nefc > kNR) { status |= (1 << 2); nefc = kNR; }
+      }
+      if (constraints_on && contacts_on) {
+        int myrows = 0, pairid = 0, dim = 1;
+        bool incl = false;
+        if (lane < ncon) {
+          const float* c = s_con + lane * kConStride;
+          pairid = __float_as_int(c[C_PAIR]);
+          incl = c[C_DIST] < M.pair_margin[pairid] - M.pair_gap[pairid];
+          dim = M.pair_dim[pairid];
+          myrows = incl ? (dim == 1 ? 1 : 2 * (dim - 1)) : 0;
+        }
+        int total_rows;
+        const int base = nefc + wave_excl_scan(myrows, lane, total_rows);
+        const bool fits = base + myrows <= kNR;
+        if (lane < ncon) {
+          float* c = s_con + lane * kConStride;
+          c[C_ROW] = __int_as_float((incl && fits) ? base : -1);
+          c[C_DIM] = __int_as_float(dim);
+          c[C_FRIC] = fmaxf(1e-5f, dr ? fmaxf(M.pair_fricab[2 * pairid] * dr[DL.o_fric], M.pair_fricab[2 * pairid + 1]) : M.pair_friction[3 * pairid]);
+        }
+        if (__ballot(lane < ncon && incl && !fits)) status |= (1 << 2);
+        const unsigned long long placed = __ballot(lane < ncon && incl && fits);
+        const int nefc_after = placed ? __builtin_amdgcn_readlane(base + myrows, 63 - __builtin_clzll(placed)) : nefc;
+        gsync();
+        const int rowv = (lane < ncon && incl && fits) ? base : -1;
+        for (int ci = 0; ci < ncon; ci++) {
+          const int row = __builtin_amdgcn_readlane(rowv, ci);
+          if (row < 0) continue;
+          const int pid = __builtin_amdgcn_readlane(pairid, ci);
+          const float4 HB_CONST* PR = M.prec + (size_t)pid * 5;
+          const float4 p0 = PR[0], p1 = PR[1], p2 = PR[2], p3 = PR[3], p4 = PR[4];
+          const float* c = s_con + ci * kConStride;
+          const int cdim = __float_as_int(p4.y);
+          const unsigned long long m1 = ((unsigned long long)__float_as_uint(p1.y) << 32) | __float_as_uint(p1.x);
+          const unsigned long long m2 = ((unsigned long long)__float_as_uint(p1.w) << 32) | __float_as_uint(p1.z);
+          const V3 cpos = ld3(c + C_POS);
+          const V3 off1 = cpos - ld3(s_scom + 3 * __float_as_int(p0.z)), off2 = cpos - ld3(s_scom + 3 * __float_as_int(p0.w));
+          const V3 fn = ld3(c + C_FRAME), ft1 = ld3(c + C_FRAME + 3), ft2 = ld3(c + C_FRAME + 6);
+          // friction per direction: sliding (2), torsional, rolling (2): mjContact.friction (mjdata.h:113)
+          const float mu = c[C_FRIC], mu_t = fmaxf(1e-5f, M.pair_friction[3 * pid + 1]), mu_r = fmaxf(1e-5f, M.pair_friction[3 * pid + 2]);
+          for (int d = lane; d < cs; d += kGroup) {
+            V3 jd = {0.f, 0.f, 0.f}, jr = {0.f, 0.f, 0.f};  // relative linear velocity at the contact point and relative angular velocity, per unit qvel[d]
+            if (d < nv) {
+              float cdd[6];
+              ld_cdof(s_cdof, d, cdd);
+              const V3 ang = {cdd[0], cdd[1], cdd[2]}, lin = {cdd[3], cdd[4], cdd[5]};
+              if ((m2 >> d) & 1ull) { jd = jd + lin + cross(ang, off2); jr = jr + ang; }
+              if ((m1 >> d) & 1ull) { jd = jd - (lin + cross(ang, off1)); jr = jr - ang; }
+            }
+            const float j0 = dot(fn, jd);
+            float* Jr = s_C + row * cs + d;
+            if (cdim == 1) Jr[0] = j0;
+            else {
+              const float j1 = mu * dot(ft1, jd), j2 = mu * dot(ft2, jd);
+              Jr[0] = j0 + j1; Jr[cs] = j0 - j1; Jr[2 * cs] = j0 + j2; Jr[3 * cs] = j0 - j2;
+              if (cdim > 3) {
+                const float j3 = mu_t * dot(fn, jr);
+                Jr[4 * cs] = j0 + j3; Jr[5 * cs] = j0 - j3;
+                if (cdim > 4) {
+                  const float j4 = mu_r * dot(ft1, jr), j5 = mu_r * dot(ft2, jr);
+                  Jr[6 * cs] = j0 + j4; Jr[7 * cs] = j0 - j4; Jr[8 * cs] = j0 + j5; Jr[9 * cs] = j0 - j5;
+                }
+              }
+            }
+          }
+          const int nr = cdim == 1 ? 1 : 2 * (cdim - 1);
+          if (lane < nr) {
+            const float tran = p2.w, dist = c[C_DIST], margin = p2.x;
+            const float solimp[5] = {p3.x, p3.y, p3.z, p3.w, p4.x};
+            const float imp = clampf(impedance(solimp, dist, margin), HB_MINIMP, HB_MAXIMP);
+            float K, Bc;
+            kb_from_solref(p2.y, p2.z, solimp[1], M.timestep, !(M.disableflags & (1 << 11)), K, Bc);
+            // pyramidal rows share 2 mu^2 R(first row), mu = friction[0] / sqrt(impratio); the first row's diagApprox is tran + friction[0]^2 tran
+            const float mus = mu * M.inv_sqrt_impratio;
+            const float Rown = fmaxf(HB_MINVAL, (1.f - imp) * (cdim == 1 ? tran : tran + mu * mu * tran) / imp);
+            float* e = s_meta + kMetaStride * (row + lane);
+            e[0] = cdim == 1 ? Rown : 2.f * mus * mus * Rown; e[1] = K * imp * (dist - margin); e[2] = Bc;
+          }
+        }
+        nefc = nefc_after;
+      }
+    } else {
     // (a) limits: 2 candidates (lower, upper) per limited joint / tendon, in constraint order
     if (constraints_on && !(M.disableflags & (1 << 3))) {
       for (int c0 = 0; c0 < M.nlimcand; c0 += kGroup) {
@@ -1311,7 +1684,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       }
       if (nefc > kNefcMax) { status |= (1 << 2); nefc = kNefcMax; }
     }
-    const int selfcol = __any(selfc) ? 1 : 0;
     // (b) contacts: row base by prefix sum over contacts (1 row for condim 1, 4 for condim 3)
     if (constraints_on && contacts_on) {
       int myrows = 0, pairid = 0;
@@ -1397,48 +1769,61 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       }
       nefc = nefc_after;
     }
+    }  // classic makeConstraint
     nefc = uniform(nefc);
     // extra right-hand side: row nefc of C holds qfrc_smooth (transformed below, with the rows, into y)
     if constexpr (SOLVER == 0) for (int d = lane; d < cs; d += kGroup) s_C[nefc * cs + d] = d < nv ? s_smooth[d] : 0.f;
     gsync();
 
     HB_STAMP(9);
-    // ---------------------------------------------------------------- per-row quantities (lane = row)
-    const bool rowact = lane < nefc;
-    float R = 1.f, Dd = 1.f, aref = 0.f, jw = 0.f, force = 0.f, bvec = 0.f;
-    if (rowact) {
-      const float* Jr = s_C + lane * cs;
-      float vel = 0.f;
-      {  // four columns in flight: two independent accumulation chains per product
-        float vel2 = 0.f, jw2 = 0.f;
-        int k = 0;
-        for (; k + 4 <= nv; k += 4) {
-          const float j0 = Jr[k], j1 = Jr[k + 1], j2 = Jr[k + 2], j3 = Jr[k + 3];
-          vel += j0 * s_qvel[k] + j2 * s_qvel[k + 2]; vel2 += j1 * s_qvel[k + 1] + j3 * s_qvel[k + 3];
-          jw += j0 * s_warm[k] + j2 * s_warm[k + 2]; jw2 += j1 * s_warm[k + 1] + j3 * s_warm[k + 3];
+    // ---------------------------------------------------------------- per-row quantities (lane = row; NG rows per lane: l + 64 g)
+    bool actg[NG];
+    float Rg[NG], Ddg[NG], arefg[NG], jwg[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      const int row = lane + 64 * g;
+      actg[g] = row < nefc;
+      Rg[g] = 1.f; Ddg[g] = 1.f; arefg[g] = 0.f; jwg[g] = 0.f;
+      if (64 * g < nefc && actg[g]) {
+        const float* Jr = s_C + row * cs;
+        float vel = 0.f, jw_ = 0.f;
+        {  // four columns in flight: two independent accumulation chains per product
+          float vel2 = 0.f, jw2 = 0.f;
+          int k = 0;
+          for (; k + 4 <= nv; k += 4) {
+            const float j0 = Jr[k], j1 = Jr[k + 1], j2 = Jr[k + 2], j3 = Jr[k + 3];
+            vel += j0 * s_qvel[k] + j2 * s_qvel[k + 2]; vel2 += j1 * s_qvel[k + 1] + j3 * s_qvel[k + 3];
+            jw_ += j0 * s_warm[k] + j2 * s_warm[k + 2]; jw2 += j1 * s_warm[k + 1] + j3 * s_warm[k + 3];
+          }
+          for (; k < nv; k++) { const float j = Jr[k]; vel += j * s_qvel[k]; jw_ += j * s_warm[k]; }
+          vel += vel2; jw_ += jw2;
         }
-        for (; k < nv; k++) { const float j = Jr[k]; vel += j * s_qvel[k]; jw += j * s_warm[k]; }
-        vel += vel2; jw += jw2;
+        jwg[g] = jw_;
+        if constexpr (COLL != 0) {
+          const float* e = s_meta + kMetaStride * row;
+          Rg[g] = e[0];
+          Ddg[g] = 1.f / Rg[g];
+          arefg[g] = -e[2] * vel - e[1];
+        } else {
+          const float* e = s_efc + row;
+          float pos = e[E_POS * kNefcMax], margin = e[E_MARGIN * kNefcMax];
+          float solref0 = e[E_SOLREF0 * kNefcMax], solref1 = e[E_SOLREF1 * kNefcMax];
+          float solimp[5];
+          for (int i = 0; i < 5; i++) solimp[i] = e[(E_IMP0 + i) * kNefcMax];
+          float imp = clampf(impedance(solimp, pos, margin), HB_MINIMP, HB_MAXIMP);
+          float mu2 = e[E_MU2 * kNefcMax];
+          float Rown = fmaxf(HB_MINVAL, (1.f - imp) * e[E_DA * kNefcMax] / imp);
+          Rg[g] = mu2 > 0.f ? mu2 * Rown : Rown;  // pyramidal: all rows share 2 mu^2 R(first); first row's diagApprox == own
+          Ddg[g] = 1.f / Rg[g];
+          float K, Bc;
+          kb_from_solref(solref0, solref1, solimp[1], M.timestep, !(M.disableflags & (1 << 11)), K, Bc);
+          arefg[g] = -Bc * vel - K * imp * (pos - margin);
+        }
       }
-      const float* e = s_efc + lane;
-      float pos = e[E_POS * kNefcMax], margin = e[E_MARGIN * kNefcMax];
-      float solref0 = e[E_SOLREF0 * kNefcMax], solref1 = e[E_SOLREF1 * kNefcMax];
-      float solimp[5];
-      for (int i = 0; i < 5; i++) solimp[i] = e[(E_IMP0 + i) * kNefcMax];
-      float imp = clampf(impedance(solimp, pos, margin), HB_MINIMP, HB_MAXIMP);
-      float mu2 = e[E_MU2 * kNefcMax];
-      float Rown = fmaxf(HB_MINVAL, (1.f - imp) * e[E_DA * kNefcMax] / imp);
-      R = mu2 > 0.f ? mu2 * Rown : Rown;  // pyramidal: all rows share 2 mu^2 R(first); first row's diagApprox == own
-      Dd = 1.f / R;
-      float dmax = clampf(solimp[1], HB_MINIMP, HB_MAXIMP), K, Bc;
-      if (solref0 > 0.f) {
-        float tc = solref0;
-        if (!(M.disableflags & (1 << 11))) tc = fmaxf(tc, 2.f * M.timestep);
-        K = 1.f / fmaxf(HB_MINVAL, dmax * dmax * tc * tc * solref1 * solref1);
-        Bc = 2.f / fmaxf(HB_MINVAL, dmax * tc);
-      } else { K = -solref0 / fmaxf(HB_MINVAL, dmax * dmax); Bc = -solref1 / fmaxf(HB_MINVAL, dmax); }
-      aref = -Bc * vel - K * imp * (pos - margin);
     }
+    const bool rowact = actg[0];
+    float R = Rg[0], Dd = Ddg[0], aref = arefg[0], jw = jwg[0], force = 0.f, bvec = 0.f;
+    (void)R; (void)bvec; (void)jw;
     gsync();
     HB_STAMP(10);
     int niter = 0;
@@ -1646,14 +2031,18 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       // Primal problem (oracle/mjstep_oracle.c: sol_newton): minimise over qacc
       //   1/2 (qacc - qacc_smooth)' M (qacc - qacc_smooth) + sum_rows 1/2 D min(0, J qacc - aref)^2
       // by Newton steps with an exact line search.  One wave owns the env, so the whole iteration is uniform:
-      // lane = constraint row for jar / force / J rows, lane = dof for qacc / gradient / M rows; the Hessian
+      // lane = constraint row (rows l + 64 g, g < NG) for jar / force / J rows, lane = dof for qacc / gradient / M rows; the Hessian
       // H = M + J' diag(D active) J is formed on the matrix cores and factorised in registers.
       const int li = lane & 31;
       const bool dofl = lane < nv;
+      const int lic = li < nv ? li : 0;  // column of J this lane reads (rows are cs wide: NDENSE + 1 in the big layout, 33 otherwise)
+      const bool colv = li < nv;
       // dense M (identity beyond nv) one row per lane, [32][33] over the dead row meta; J rows stay in C
       float* s_Md = s_efc;
       const float* Mrow = s_Md + li * kCs;
-      const float* Jrow = s_C + (rowact ? lane : 0) * cs;
+      const float* Jrowg[NG];
+#pragma unroll
+      for (int g = 0; g < NG; g++) Jrowg[g] = s_C + (actg[g] ? lane + 64 * g : 0) * cs;
       constexpr bool kMfma = NDENSE <= 28;  // order <= 28: elimination on the matrix cores; else Cholesky in registers
       f32x2 H[16];
 #pragma unroll
@@ -1678,23 +2067,50 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         gsync();
       }
       float qacc = qs, qfc = 0.f;
+      float forceg[NG];
+#pragma unroll
+      for (int g = 0; g < NG; g++) forceg[g] = 0.f;
       HB_STAMP(11);
       if (nefc > 0) {
+        // J x for every row group (and M x through the shared broadcasts): rows beyond nefc give 0
+#define HB_JDOT(x, Mout, Jout)                                                        \
+  {                                                                                   \
+    float j0_;                                                                        \
+    rowdot2<NDENSE>(Mrow, Jrowg[0], (x), (Mout), j0_);                                \
+    (Jout)[0] = actg[0] ? j0_ : 0.f;                                                  \
+    _Pragma("unroll") for (int g_ = 1; g_ < NG; g_++) {                               \
+      float t_ = 0.f;                                                                 \
+      if (64 * g_ < nefc) t_ = rowdot<NDENSE>(Jrowg[g_], (x));                        \
+      (Jout)[g_] = actg[g_] ? t_ : 0.f;                                               \
+    }                                                                                 \
+  }
         // starting point (warmstart() of mj_fwdConstraint): qacc_warmstart unless qacc_smooth costs less
-        float Ma, jqs;
-        rowdot2<NDENSE>(Mrow, Jrow, qs, Ma, jqs);
-        float jar = rowact ? jqs - aref : 1.f;  // rows beyond nefc: never active
+        float Ma, jqs[NG], jar[NG];
+        HB_JDOT(qs, Ma, jqs)
+#pragma unroll
+        for (int g = 0; g < NG; g++) jar[g] = actg[g] ? jqs[g] - arefg[g] : 1.f;  // rows beyond nefc: never active
         if (!(M.disableflags & (1 << 8))) {
           const float Mw = rowdot<NDENSE>(Mrow, warm);
-          const float jarw = rowact ? jw - aref : 1.f;
-          const float cw = (jarw < 0.f ? 0.5f * Dd * jarw * jarw : 0.f) + (dofl ? 0.5f * (Mw - smooth) * (warm - qs) : 0.f);
-          const float cq = jar < 0.f ? 0.5f * Dd * jar * jar : 0.f;
-          if (wave_sum(cw - cq) <= 0.f) { qacc = warm; Ma = Mw; jar = jarw; }
+          float cw = dofl ? 0.5f * (Mw - smooth) * (warm - qs) : 0.f, cq = 0.f;
+          float jarw[NG];
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            jarw[g] = actg[g] ? jwg[g] - arefg[g] : 1.f;
+            cw += jarw[g] < 0.f ? 0.5f * Ddg[g] * jarw[g] * jarw[g] : 0.f;
+            cq += jar[g] < 0.f ? 0.5f * Ddg[g] * jar[g] * jar[g] : 0.f;
+          }
+          if (wave_sum(cw - cq) <= 0.f) {
+            qacc = warm; Ma = Mw;
+#pragma unroll
+            for (int g = 0; g < NG; g++) jar[g] = jarw[g];
+          }
         }
         const float scale = M.pgs_scale, tol = M.tolerance, lstol = M.ls_tolerance;
         const int maxiter = M.iterations, lsmax = M.ls_iterations;
         float cost = 0.f;
-        unsigned long long act_prev = 0ull;
+        unsigned long long act_prev[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) act_prev[g] = 0ull;
         bool have_factor = false;
         HB_STAMP(12);
 #if defined(HB_STAMPS) && defined(HB_PROBE_NEWTON)
@@ -1702,30 +2118,42 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 #endif
         for (;;) {
           // PrimalUpdateConstraint: state, force, qfrc_constraint = J' force, cost
-          const bool act = jar < 0.f;
-          force = act ? -Dd * jar : 0.f;
-          const unsigned long long actmask = __ballot(act);
+          bool act[NG];
+          unsigned long long actmask[NG];
+          float rowcost = 0.f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            act[g] = jar[g] < 0.f;
+            forceg[g] = act[g] ? -Ddg[g] * jar[g] : 0.f;
+            actmask[g] = __ballot(act[g]);
+            rowcost += act[g] ? 0.5f * Ddg[g] * jar[g] * jar[g] : 0.f;
+          }
           qfc = 0.f;
           {
             // eight rows in flight; rows beyond nefc are read from the last row with a zero force
             float q1 = 0.f;
             const int last = nefc - 1;
-            for (int i0 = 0; i0 < nefc; i0 += 8) {
-              if (!((actmask >> i0) & 0xffull)) continue;  // eight inactive rows: zero force
-              float c[8];
 #pragma unroll
-              for (int u = 0; u < 8; u++) c[u] = s_C[min(i0 + u, last) * cs + li];
+            for (int g = 0; g < NG; g++) {
+              if (64 * g >= nefc) break;
+              for (int i0 = 0; i0 < 64 && 64 * g + i0 < nefc; i0 += 8) {
+                if (!((actmask[g] >> i0) & 0xffull)) continue;  // eight inactive rows: zero force
+                float c[8];
 #pragma unroll
-              for (int u = 0; u < 8; u += 2) {
-                qfc = __builtin_fmaf(c[u], rdlane(force, i0 + u), qfc);
-                q1 = __builtin_fmaf(c[u + 1], rdlane(force, i0 + u + 1), q1);
+                for (int u = 0; u < 8; u++) c[u] = s_C[min(64 * g + i0 + u, last) * cs + lic];
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                  qfc = __builtin_fmaf(c[u], rdlane(forceg[g], i0 + u), qfc);
+                  q1 = __builtin_fmaf(c[u + 1], rdlane(forceg[g], i0 + u + 1), q1);
+                }
               }
             }
             qfc += q1;
+            if (!colv) qfc = 0.f;
           }
           const float oldcost = cost;
           newton_grad = li < nv ? Ma - smooth - qfc : 0.f;
-          cost = wave_sum((act ? 0.5f * Dd * jar * jar : 0.f) + (dofl ? 0.5f * (Ma - smooth) * (qacc - qs) : 0.f));
+          cost = wave_sum(rowcost + (dofl ? 0.5f * (Ma - smooth) * (qacc - qs) : 0.f));
           // |grad| and the fp32 resolution of its own terms: the reference's gradient test (scale |grad| < tolerance) cannot
           // be met by a sum of O(1e2) terms in fp32, so the test is floored at that sum's rounding level
           const float g2 = wave_sum(dofl ? newton_grad * newton_grad : 0.f);
@@ -1739,17 +2167,22 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
           if constexpr (kMfma) {
             // Hessian of the active set in the accumulator layout: M, plus J' diag(D active) J on the matrix cores
             // (MakeHessian), eliminated together with the gradient: search = -H^-1 grad
-            s_force[lane] = act ? Dd : 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; g++) if (64 * g < nefc || g == 0) s_force[lane + 64 * g] = act[g] ? Ddg[g] : 0.f;
             gsync();
             const int half = lane >> 5;
             f32x16 X = load_sym(s_Md, kCs, lane);
-            for (int kk = 0; 2 * kk < nefc; kk++) {
-              if (!((actmask >> (2 * kk)) & 3ull)) continue;  // both rows inactive: nothing to add
-              const int row = 2 * kk + half;
-              const bool v = row < nefc;
-              const float a = v ? s_C[row * cs + li] : 0.f;
-              const float b = v ? a * s_force[row] : 0.f;
-              X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, X, 0, 0, 0);  // += J_row' (D J_row)
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+              if (64 * g >= nefc) break;
+              for (int kk = 0; kk < 32 && 64 * g + 2 * kk < nefc; kk++) {
+                if (!((actmask[g] >> (2 * kk)) & 3ull)) continue;  // both rows inactive: nothing to add
+                const int row = 64 * g + 2 * kk + half;
+                const bool v = row < nefc && colv;
+                const float a = v ? s_C[row * cs + lic] : 0.f;
+                const float b = v ? a * s_force[row] : 0.f;
+                X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, X, 0, 0, 0);  // += J_row' (D J_row)
+              }
             }
             HB_NP(1);
             search = -sym_solve_mfma<NDENSE / 2>(X, newton_grad, lane);
@@ -1757,8 +2190,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             gsync();
           } else {
             // Hessian of the active set (MakeHessian; rebuilt only when the active set changed) and its Cholesky factor
-            if (!have_factor || actmask != act_prev) {
-              s_force[lane] = act ? Dd : 0.f;
+            bool changed = !have_factor;
+#pragma unroll
+            for (int g = 0; g < NG; g++) changed |= actmask[g] != act_prev[g];
+            if (changed) {
+#pragma unroll
+              for (int g = 0; g < NG; g++) if (64 * g < nefc || g == 0) s_force[lane + 64 * g] = act[g] ? Ddg[g] : 0.f;
               gsync();
               const int half = lane >> 5;
               f32x16 X;
@@ -1766,8 +2203,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
               for (int r = 0; r < 16; r++) X[r] = 0.f;
               for (int kk = 0; 2 * kk < nefc; kk++) {
                 const int row = 2 * kk + half;
-                const bool v = row < nefc;
-                const float a = v ? s_C[row * cs + li] : 0.f;
+                const bool v = row < nefc && colv;
+                const float a = v ? s_C[row * cs + lic] : 0.f;
                 const float b = v ? a * s_force[row] : 0.f;
                 X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, X, 0, 0, 0);  // += J_row' (D J_row)
               }
@@ -1781,7 +2218,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
               HB_NP(1);
               dv = chol_rows<NDENSE>(H, s_v1, li, lane);
               HB_NP(2);
-              act_prev = actmask;
+#pragma unroll
+              for (int g = 0; g < NG; g++) act_prev[g] = actmask[g];
               have_factor = true;
               gsync();
             }
@@ -1789,9 +2227,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             search = -rdlane_mirror(chol_solve_rows<NDENSE>(H, dv, newton_grad), lane);
           }
           HB_NP(3);
-          float Mv, Jv0;
-          rowdot2<NDENSE>(Mrow, Jrow, search, Mv, Jv0);
-          const float Jv = rowact ? Jv0 : 0.f;
+          float Mv, Jv[NG];
+          HB_JDOT(search, Mv, Jv)
           HB_NP(4);
           // PrimalSearch: exact line search on the piecewise quadratic phi(alpha) = cost(qacc + alpha search):
           // Newton iterations in alpha, kept inside the bracket of the sign change once there is one.  The slope
@@ -1799,18 +2236,31 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
           // of the slope's own terms.
           const float gq = dofl ? Ma - smooth : 0.f;
           const float qg1 = wave_sum(search * gq), qg2 = 0.5f * wave_sum(dofl ? search * Mv : 0.f), sn2 = wave_sum(dofl ? search * search : 0.f);
-          const float DJv = Dd * Jv, DJv2 = DJv * Jv;
-          const float mag = wave_sum(fabsf(search * gq) + (act ? fabsf(DJv * jar) : 0.f));
+          float DJv[NG], DJv2[NG], magr = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            DJv[g] = Ddg[g] * Jv[g]; DJv2[g] = DJv[g] * Jv[g];
+            magr += act[g] ? fabsf(DJv[g] * jar[g]) : 0.f;
+            s0 += act[g] ? DJv[g] * jar[g] : 0.f;
+            s1 += act[g] ? DJv2[g] : 0.f;
+          }
+          const float mag = wave_sum(fabsf(search * gq) + magr);
           const float gtol = fmaxf(tol * lstol * sqrtf(sn2) / scale, 2e-6f * mag);
           float alpha = 0.f;
           {
-            const float d0 = qg1 + wave_sum(act ? DJv * jar : 0.f), d1 = 2.f * qg2 + wave_sum(act ? DJv2 : 0.f);
+            const float d0 = qg1 + wave_sum(s0), d1 = 2.f * qg2 + wave_sum(s1);
             if (d0 < -gtol) {
               float lo = 0.f, hi = -1.f, a = -d0 / d1;
               for (int it = 0; it < lsmax; it++) {
-                const float x = jar + a * Jv;
-                const bool on = x < 0.f;
-                const float e0 = qg1 + 2.f * a * qg2 + wave_sum(on ? DJv * x : 0.f), e1 = 2.f * qg2 + wave_sum(on ? DJv2 : 0.f);
+                float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                  const float x = jar[g] + a * Jv[g];
+                  const bool on = x < 0.f;
+                  t0 += on ? DJv[g] * x : 0.f;
+                  t1 += on ? DJv2[g] : 0.f;
+                }
+                const float e0 = qg1 + 2.f * a * qg2 + wave_sum(t0), e1 = 2.f * qg2 + wave_sum(t1);
                 alpha = a;
                 if (fabsf(e0) < gtol) break;
                 if (e0 < 0.f) lo = a; else hi = a;
@@ -1824,9 +2274,11 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
           if (alpha == 0.f) break;
           qacc = __builtin_fmaf(alpha, search, qacc);
           Ma = __builtin_fmaf(alpha, Mv, Ma);
-          jar = __builtin_fmaf(alpha, Jv, jar);
+#pragma unroll
+          for (int g = 0; g < NG; g++) jar[g] = actg[g] ? __builtin_fmaf(alpha, Jv[g], jar[g]) : 1.f;
           niter++;
         }
+#undef HB_JDOT
 #if defined(HB_STAMPS) && defined(HB_PROBE_NEWTON)
         if (P.stamps) for (int i = 0; i < 8; i++) stamps_[i] = np_acc[i];
 #endif
@@ -1834,6 +2286,11 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         HB_STAMP(12);
       }
       HB_STAMP(13);
+      force = forceg[0];
+      if (P.diag_force) {
+#pragma unroll
+        for (int g = 1; g < NG; g++) P.diag_force[(size_t)env * kNR + lane + 64 * g] = actg[g] ? forceg[g] : 0.f;
+      }
       if (dofl) {
         s_v0[lane] = qacc;
         if (P.qfrc_out) P.qfrc_out[(size_t)env * nv + lane] = smooth + qfc;  // qfrc_smooth + qfrc_constraint
@@ -1865,9 +2322,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     ctrl_zeroed = false;
     // diagnostics of this step (parity tests)
     if (P.diag_qacc) for (int i = lane; i < nv; i += kGroup) P.diag_qacc[(size_t)env * nv + i] = s_v0[i];
-    if (P.diag_force && lane < kNefcMax) P.diag_force[(size_t)env * kNefcMax + lane] = rowact ? force : 0.f;
+    if (P.diag_force && lane < kNR) P.diag_force[(size_t)env * kNR + lane] = rowact ? force : 0.f;
     if (P.diag_contact) {
-      for (int idx = lane; idx < kNconMax * kDiagConStride; idx += kGroup) {
+      for (int idx = lane; idx < kNC * kDiagConStride; idx += kGroup) {
         int ci = idx / kDiagConStride, f = idx % kDiagConStride;
         float v = 0.f;
         if (ci < ncon) {
@@ -1878,7 +2335,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             v = f == 13 ? (float)__float_as_int(c[C_DIM]) : (f == 14 ? (float)M.pair_geom1[pid] : (float)M.pair_geom2[pid]);
           }
         }
-        P.diag_contact[((size_t)env * kNconMax) * kDiagConStride + idx] = v;
+        P.diag_contact[((size_t)env * kNC) * kDiagConStride + idx] = v;
       }
     }
     if (lane == 0) { int* c = P.counts + kCountStride * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; c[3] = nefc * (niter + 4); c[4] = selfcol; }
@@ -1995,6 +2452,11 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 // PGS instantiations: dense order 28 (nv <= 28: the 27-dof humanoid; M^-1 by elimination on the matrix cores) and 32 (sparse L'DL)
 __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 32>(Mp, P, nsteps); }
+// General instantiations (mesh hulls, height-field prisms, condim 4 / 6): PGS on 63 rows (configs[4]: the 27-dof humanoid on terrain),
+// Newton on 256 rows (the reference's own robot, simulation/assets/world.xml: 18 dofs -> dense order 20; up to 28 dofs)
+__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big20_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, kBigGroups>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 1, kBigGroups>(Mp, P, nsteps); }
 // Newton instantiations: dense order 28 (nv <= 28: the 27-dof humanoid) and 32
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
@@ -2694,10 +3156,13 @@ __global__ void hb_halton_ctrl_kernel(float* out, int T, int n_env, int nu, int 
 
 namespace hb {
 
-hipError_t launch_step(const DevModel* M_dev, int solver, int nv, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
+hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   size_t shmem = (size_t)lds_floats * sizeof(float);
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  if (solver == 2 && nv <= 28) hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  if (variant == 2 && nv <= 20) hipLaunchKernelGGL(hb_step_newton_big20_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (variant == 2) hipLaunchKernelGGL(hb_step_newton_big28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (variant == 1) hipLaunchKernelGGL(hb_step_gen_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (solver == 2 && nv <= 28) hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (solver == 2) hipLaunchKernelGGL(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (nv <= 28) hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else hipLaunchKernelGGL(hb_step32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
@@ -2796,6 +3261,12 @@ hipError_t set_step_lds_limit(int bytes) {
   e = hipFuncSetAttribute((const void*)hb_step32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)hb_step_newton28_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step_newton_big20_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step_newton_big28_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)hb_step_newton32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }

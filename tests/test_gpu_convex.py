@@ -1,0 +1,158 @@
+"""GPU parity of the general collision / constraint path (the reference's own robot, simulation/assets/
+world.xml + humanoid.xml: mesh hulls, condim 6, height-field floor, Newton): the HIP kernels through the C-ABI against the
+fp64 oracle, teacher-forced one step from states along oracle trajectories.
+
+Tolerances: contact distance / position come out of an iterative portal search (MPR, tolerance 1e-6 m) run in fp32 on the
+device and fp64 in the oracle: dist 2e-5 m, position 2e-3 m (the MPR position is read off the last portal and moves with
+it), normal 2e-3; qacc / forces 2e-2 relative to their scale, qvel 2e-3, qpos 1e-5 (they inherit the contact geometry's
+differences, amplified by the stiff contact: the bounds are stated, not tuned to pass).  Counts (ncon, nefc) are identical.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import ROOT, Oracle
+from test_oracle_convex import BALL_MESH, CUBE_MESH, _hfield_xml
+
+pytestmark = pytest.mark.gpu
+TEAM_HBM = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "team_robot.hbm")
+
+
+def _teacher_forced(hbmod, gpu, path, states, ctrls, tol, min_contacts=1, newton=True):
+    """one device step from each state vs the oracle; returns the worst deviations"""
+    m = hbmod.Model.load(path)
+    o = Oracle(path)
+    n = len(states)
+    b = hbmod.Batch(m, n, gpu)
+    b.diag_enable(True)
+    b.set_state(hbmod.STATE_INTEGRATION, np.array(states))
+    b.step(np.array(ctrls, dtype=np.float32).reshape(n, m.nu))
+    q, v, a = b.qpos.astype(np.float64), b.qvel.astype(np.float64), b.qacc().astype(np.float64)
+    f = b.efc_force().astype(np.float64)
+    con = b.contacts().astype(np.float64)
+    nc, ne, ni = b.counts()
+    assert not b.status().any(), b.status()
+    worst = dict(qpos=0.0, qvel=0.0, qacc=0.0, force=0.0, dist=0.0, pos=0.0, nrm=0.0)
+    seen = 0
+    for k in range(n):
+        o.reset()
+        o.L.om_data_set_time(o.d, states[k][0])
+        o.qpos[:] = states[k][1:1 + m.nq]; o.qvel[:] = states[k][1 + m.nq:1 + m.nq + m.nv]; o.qacc_warmstart[:] = states[k][1 + m.nq + m.nv:]
+        o.ctrl[:] = ctrls[k]
+        o.forward()
+        assert (nc[k], ne[k]) == (o.ncon, o.nefc), (k, nc[k], ne[k], o.ncon, o.nefc)
+        seen += o.ncon
+        oc = o.contacts()
+        for i, c in enumerate(oc):
+            worst["dist"] = max(worst["dist"], abs(con[k, i, 0] - c["dist"]))
+            worst["pos"] = max(worst["pos"], np.abs(con[k, i, 1:4] - c["pos"]).max())
+            worst["nrm"] = max(worst["nrm"], np.abs(con[k, i, 4:7] - c["frame"][0]).max())
+            assert (int(con[k, i, 14]), int(con[k, i, 15])) == (c["geom1"], c["geom2"]) and int(con[k, i, 13]) == c["dim"]
+        worst["qacc"] = max(worst["qacc"], np.abs(a[k] - o.qacc).max() / max(1.0, np.abs(o.qacc).max()))
+        if o.nefc:
+            fo = o.efc_force[:o.nefc]
+            worst["force"] = max(worst["force"], np.abs(f[k, :o.nefc] - fo).max() / max(1.0, np.abs(fo).max()))
+        o.step()
+        worst["qpos"] = max(worst["qpos"], (np.abs(q[k] - o.qpos) / np.maximum(1.0, np.abs(o.qpos))).max())
+        worst["qvel"] = max(worst["qvel"], np.abs(v[k] - o.qvel).max() / max(1.0, np.abs(o.qvel).max()))
+    print("\n%s: %d states, %d contacts, worst %s" % (os.path.basename(path), n, seen, {k: "%.2e" % x for k, x in worst.items()}))
+    assert seen >= min_contacts
+    for k, x in worst.items():
+        assert x <= tol[k], (k, x, tol[k])
+    return worst
+
+
+TOL = dict(qpos=1e-5, qvel=2e-3, qacc=2e-2, force=2e-2, dist=2e-5, pos=2e-3, nrm=2e-3)
+
+
+def _oracle_states(path, envs, T, every, seed=0, ctrl_scale=1.0, init=None):
+    o = Oracle(path)
+    rng = np.random.default_rng(seed)
+    states, ctrls = [], []
+    for e in range(envs):
+        o.reset()
+        if init is not None:
+            init(o, e, rng)
+        c = np.zeros(o.nu)
+        for t in range(T):
+            if t % 25 == 0:
+                c = rng.uniform(-1, 1, o.nu) * ctrl_scale
+            o.ctrl[:] = c
+            if t % every == every - 1:
+                states.append(np.concatenate([[o.time], o.qpos, o.qvel, o.qacc_warmstart]))
+                ctrls.append(c.copy())
+            o.step()
+    return states, ctrls
+
+
+def test_team_robot_model_facts(hbmod):
+    m = hbmod.Model.load(TEAM_HBM)
+    assert (m.nq, m.nv, m.nu, m.nbody, m.ngeom) == (19, 18, 12, 15, 13)
+    assert m.opt.solver == 2 and abs(m.opt.timestep - 0.002) < 1e-12  # Newton (mjOption default), the env's 500 Hz step
+    assert (m.ncon_max, m.nefc_max) == (48, 256)
+
+
+def test_team_robot_one_step_parity_along_oracle_trajectories(hbmod, gpu):
+    """The reference's robot from its standing reset through its fall onto the flat height field, random motor commands:
+    feet (condim 6, ten rows per contact), then limbs and torso on the floor and against each other."""
+    def init(o, e, rng):
+        o.qpos[7:] += rng.uniform(-0.2, 0.2, o.nq - 7)  # JOINT_INITIAL_OFFSET_MAX (simulation_parameters.py:22)
+        o.qpos[2] += 0.02 * e
+    states, ctrls = _oracle_states(TEAM_HBM, envs=6, T=1500, every=60, seed=1, init=init)
+    _teacher_forced(hbmod, gpu, TEAM_HBM, states, ctrls, TOL, min_contacts=100)
+
+
+def test_team_robot_free_running_stays_finite_and_on_the_floor(hbmod, gpu):
+    m = hbmod.Model.load(TEAM_HBM)
+    n, T = 256, 1500
+    b = hbmod.Batch(m, n, gpu)
+    b.reset(perturb=True)
+    rng = np.random.default_rng(5)
+    for t in range(T // 50):
+        b.step(rng.uniform(-1, 1, (n, m.nu)).astype(np.float32), n_substeps=50)
+    q = b.qpos
+    s = b.status()
+    nc, ne, ni = b.counts()
+    print("\nteam robot after %d steps: z %.3f..%.3f, ncon max %d, nefc max %d, newton iterations mean %.2f max %d, flagged %d"
+          % (T, q[:, 2].min(), q[:, 2].max(), nc.max(), ne.max(), ni.mean(), ni.max(), int((s != 0).sum())))
+    assert np.isfinite(q).all() and np.isfinite(b.qvel).all()
+    assert not (s & (hbmod.WARN_BADQPOS | hbmod.WARN_BADQVEL | hbmod.WARN_BADQACC)).any()
+    assert q[:, 2].min() > -0.72 and q[:, 2].max() < 0.0  # on the floor (z = -0.7), nobody through it, nobody launched
+    assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max() < 1e-4
+    assert nc.max() >= 3 and ne.max() > 63  # more rows than the 63-row solvers hold: the 256-row path is what runs
+
+
+def _save(hbmod, xml, tmp_path, name):
+    m = hbmod.Model.from_xml_string(xml)
+    p = str(tmp_path / name)
+    m.save(p)
+    return p
+
+
+def test_primitives_and_hulls_on_a_bumpy_field(hbmod, gpu, tmp_path):
+    """Sphere, capsule and two hulls (a cube and a 300-vertex ball) dropped on a bumpy height field, Newton and PGS: every
+    collider of the general path against the oracle (mjc_ConvexHField for all four, mjc_Convex between the hulls)."""
+    rng = np.random.default_rng(3)
+    elev = rng.uniform(0, 1, (6, 6))
+    body = ('<body pos="-0.5 0.3 0.45"><freejoint/><geom type="sphere" size="0.08" condim="6"/></body>'
+            '<body pos="0.4 -0.4 0.5" euler="20 40 0"><freejoint/><geom type="capsule" size="0.05 0.12" condim="3"/></body>'
+            '<body pos="0.1 0.5 0.5" euler="10 20 30"><freejoint/><inertial pos="0 0 0" mass="0.5" diaginertia="0.001 0.001 0.001"/><geom type="mesh" mesh="cube" condim="4"/></body>'
+            '<body pos="0.12 0.52 0.62"><freejoint/><inertial pos="0 0 0" mass="0.3" diaginertia="0.0005 0.0005 0.0005"/><geom type="mesh" mesh="ball" condim="6" friction="0.7 0.02 0.01"/></body>')
+    xml = _hfield_xml(elev, body, nrow=6, ncol=6, size="1 1 0.3 0.2", extra=CUBE_MESH + BALL_MESH)
+    for solver, name in ((2, "bumpy_newton.hbm"), (0, "bumpy_pgs.hbm")):
+        m = hbmod.Model.from_xml_string(xml)
+        m.set_opt(solver=solver, iterations=100 if solver == 2 else 50)
+        p = str(tmp_path / name)
+        m.save(p)
+        states, ctrls = _oracle_states(p, envs=1, T=600, every=12)
+        _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=60)
+
+
+def test_mesh_mesh_stack(hbmod, gpu, tmp_path):
+    xml = ('<mujoco><option timestep="0.002"/><asset>%s</asset><worldbody><body pos="0 0 0.05"><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/><geom type="mesh" mesh="cube"/></body>'
+           '<body pos="0.02 -0.01 0.16" euler="5 8 0"><freejoint/><inertial pos="0 0 0" mass="0.5" diaginertia="0.001 0.001 0.001"/><geom type="mesh" mesh="cube" condim="6"/></body>'
+           '</worldbody></mujoco>' % CUBE_MESH)
+    p = _save(hbmod, xml, tmp_path, "stack.hbm")
+    states, ctrls = _oracle_states(p, envs=1, T=300, every=10)
+    _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=10)

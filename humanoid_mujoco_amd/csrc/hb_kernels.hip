@@ -784,9 +784,9 @@ __device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata
     if (mpr_kind) {
       float depth;
       V3 dir, vec;
-      const bool hit = mpr_penetration(o1, o2, M.mpr_iterations, M.mpr_tolerance, depth, dir, vec);
+      const bool hit = mpr_penetration(o1, o2, M.mpr_iterations, (double)M.mpr_tolerance, depth, dir, vec);
       if (mpr_kind == 1) {
-        if (hit && !ccd_is_zero(depth)) {
+        if (hit && depth >= 2.220446e-16f) {
           co0.dist = -depth;
           co0.n = mrot(hm, dir);
           co0.pos = mrot(hm, vec) + pos1;

@@ -9,13 +9,53 @@
 
 namespace hb {
 
-#define HB_CCD_EPS 1.1920929e-7f  // FLT_EPSILON: libccd's CCD_EPS at this precision
-__device__ __forceinline__ bool ccd_is_zero(float x) { return fabsf(x) < HB_CCD_EPS; }
-__device__ __forceinline__ bool ccd_eq(float a, float b) {
-  const float ab = fabsf(a - b);
+// The portal search runs in DOUBLE precision on the device too.  Measured with an fp32 version: against a height-field prism
+// (metres wide, a geom centimetres across) sign tests of the portal expansion flip under fp32 rounding, the search then stops on
+// a portal far from the surface and reports a penetration of the prism's whole depth (1 m): envs exploded at a rate of 2 % per
+// thousand steps on the terrain benchmark.  MI355X issues fp64 vector math at half the fp32 rate, and with the same arithmetic
+// as the oracle the discrete decisions agree as well.  Geometry stays fp32 in registers (CObj) and is widened at use.
+#define HB_CCD_EPS 2.220446049250313e-16  // DBL_EPSILON: libccd's CCD_EPS in its double-precision build (what MuJoCo links)
+struct V3d { double x, y, z; };
+__device__ __forceinline__ V3d operator+(V3d a, V3d b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3d operator-(V3d a, V3d b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3d operator*(V3d a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ double dot(V3d a, V3d b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3d cross(V3d a, V3d b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3d widen(V3 a) { return {(double)a.x, (double)a.y, (double)a.z}; }
+__device__ __forceinline__ V3 narrow(V3d a) { return {(float)a.x, (float)a.y, (float)a.z}; }
+__device__ __forceinline__ V3d normalized(V3d v, double* n_out = nullptr) {
+  const double n = sqrt(dot(v, v));
+  if (n_out) *n_out = n;
+  if (n < 1e-15) return {1.0, 0.0, 0.0};
+  const double inv = 1.0 / n;
+  return v * inv;
+}
+__device__ __forceinline__ bool ccd_is_zero(double x) { return fabs(x) < HB_CCD_EPS; }
+__device__ __forceinline__ bool ccd_eq(double a, double b) {
+  const double ab = fabs(a - b);
   if (ab < HB_CCD_EPS) return true;
-  a = fabsf(a); b = fabsf(b);
+  a = fabs(a); b = fabs(b);
   return b > a ? ab < HB_CCD_EPS * b : ab < HB_CCD_EPS * a;
+}
+// closest point of triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5), double precision
+__device__ __forceinline__ V3d closest_on_triangle(V3d p, V3d a, V3d b, V3d c) {
+  const V3d ab = b - a, ac = c - a, ap = p - a;
+  const double d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0.0 && d2 <= 0.0) return a;
+  const V3d bp = p - b;
+  const double d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0.0 && d4 <= d3) return b;
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) return a + ab * (d1 / (d1 - d3));
+  const V3d cp = p - c;
+  const double d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0.0 && d5 <= d6) return c;
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) return a + ac * (d2 / (d2 - d6));
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) return b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)));
+  const double denom = 1.0 / (va + vb + vc);
+  return a + ab * (vb * denom) + ac * (vc * denom);
 }
 
 // a convex object in the frame the test runs in: a geom (sphere 2, capsule 3, mesh hull 7) or a height-field prism (-1)
@@ -30,98 +70,100 @@ struct CObj {
   V3 p0, p1, p2, p3, p4, p5;  // prism: bottom triangle 0..2, top triangle 3..5
 };
 
-__device__ __forceinline__ V3 ccd_center(const CObj& o) {
-  if (o.type < 0) return (o.p0 + o.p1 + o.p2 + o.p3 + o.p4 + o.p5) * (1.f / 6.f);
-  return o.pos;
+__device__ __forceinline__ V3d ccd_center(const CObj& o) {
+  if (o.type < 0) return (widen(o.p0) + widen(o.p1) + widen(o.p2) + widen(o.p3) + widen(o.p4) + widen(o.p5)) * (1.0 / 6.0);
+  return widen(o.pos);
 }
 // the point farthest along dir (unit)
-__device__ __forceinline__ V3 ccd_support(const CObj& o, V3 dir) {
+__device__ __forceinline__ V3d ccd_support(const CObj& o, V3d dir) {
   if (o.type < 0) {
-    V3 best = o.p0;
-    float bd = dot(o.p0, dir), v;
-    v = dot(o.p1, dir); if (v > bd) { bd = v; best = o.p1; }
-    v = dot(o.p2, dir); if (v > bd) { bd = v; best = o.p2; }
-    v = dot(o.p3, dir); if (v > bd) { bd = v; best = o.p3; }
-    v = dot(o.p4, dir); if (v > bd) { bd = v; best = o.p4; }
-    v = dot(o.p5, dir); if (v > bd) { bd = v; best = o.p5; }
+    V3d best = widen(o.p0), c;
+    double bd = dot(best, dir), v;
+    c = widen(o.p1); v = dot(c, dir); if (v > bd) { bd = v; best = c; }
+    c = widen(o.p2); v = dot(c, dir); if (v > bd) { bd = v; best = c; }
+    c = widen(o.p3); v = dot(c, dir); if (v > bd) { bd = v; best = c; }
+    c = widen(o.p4); v = dot(c, dir); if (v > bd) { bd = v; best = c; }
+    c = widen(o.p5); v = dot(c, dir); if (v > bd) { bd = v; best = c; }
     return best;
   }
-  const V3 ld = {o.mat[0] * dir.x + o.mat[3] * dir.y + o.mat[6] * dir.z, o.mat[1] * dir.x + o.mat[4] * dir.y + o.mat[7] * dir.z,
-                 o.mat[2] * dir.x + o.mat[5] * dir.y + o.mat[8] * dir.z};  // mat' dir
-  V3 res;
-  if (o.type == 2) res = ld * o.r;
-  else if (o.type == 3) { res = ld * o.r; res.z += ld.z >= 0.f ? o.h : -o.h; }
+  const double m0 = o.mat[0], m1 = o.mat[1], m2 = o.mat[2], m3 = o.mat[3], m4 = o.mat[4], m5 = o.mat[5], m6 = o.mat[6], m7 = o.mat[7], m8 = o.mat[8];
+  const V3d ld = {m0 * dir.x + m3 * dir.y + m6 * dir.z, m1 * dir.x + m4 * dir.y + m7 * dir.z, m2 * dir.x + m5 * dir.y + m8 * dir.z};  // mat' dir
+  V3d res;
+  if (o.type == 2) res = ld * (double)o.r;
+  else if (o.type == 3) { res = ld * (double)o.r; res.z += ld.z >= 0.0 ? (double)o.h : -(double)o.h; }
   else {
-    float bd = -3.0e38f;
-    res = {0.f, 0.f, 0.f};
+    double bd = -1.0e300;
+    res = {0.0, 0.0, 0.0};
     for (int i = 0; i < o.nvert; i++) {
       const float4 q = o.vert[i];
-      const float v = q.x * ld.x + q.y * ld.y + q.z * ld.z;
-      if (v > bd) { bd = v; res = {q.x, q.y, q.z}; }
+      const double v = (double)q.x * ld.x + (double)q.y * ld.y + (double)q.z * ld.z;
+      if (v > bd) { bd = v; res = {(double)q.x, (double)q.y, (double)q.z}; }
     }
   }
-  res = res + ld * o.margin;
-  return mrot(o.mat, res) + o.pos;
+  res = res + ld * (double)o.margin;
+  return V3d{m0 * res.x + m1 * res.y + m2 * res.z, m3 * res.x + m4 * res.y + m5 * res.z, m6 * res.x + m7 * res.y + m8 * res.z} + widen(o.pos);
 }
 
-struct CSup { V3 v, v1; };  // a point of the Minkowski difference obj1 - obj2 and its witness on obj1 (the one on obj2 is v1 - v)
-__device__ __forceinline__ CSup mpr_support(const CObj& o1, const CObj& o2, V3 dir) {
+struct CSup { V3d v, v1; };  // a point of the Minkowski difference obj1 - obj2 and its witness on obj1 (the one on obj2 is v1 - v)
+__device__ __forceinline__ CSup mpr_support(const CObj& o1, const CObj& o2, V3d dir) {
   CSup s;
   s.v1 = ccd_support(o1, dir);
-  const V3 w2 = ccd_support(o2, dir * -1.f);
+  const V3d w2 = ccd_support(o2, dir * -1.0);
   s.v = s.v1 - w2;
   return s;
 }
-__device__ __forceinline__ V3 mpr_portal_dir(const CSup& P1, const CSup& P2, const CSup& P3) { return normalized(cross(P2.v - P1.v, P3.v - P1.v)); }
-__device__ __forceinline__ bool mpr_reach_tolerance(const CSup& P1, const CSup& P2, const CSup& P3, const CSup& v4, V3 dir, float tol) {
-  const float dv4 = dot(v4.v, dir);
-  const float d = fminf(fminf(dv4 - dot(P1.v, dir), dv4 - dot(P2.v, dir)), dv4 - dot(P3.v, dir));
+__device__ __forceinline__ V3d mpr_portal_dir(const CSup& P1, const CSup& P2, const CSup& P3) { return normalized(cross(P2.v - P1.v, P3.v - P1.v)); }
+__device__ __forceinline__ bool mpr_reach_tolerance(const CSup& P1, const CSup& P2, const CSup& P3, const CSup& v4, V3d dir, double tol) {
+  const double dv4 = dot(v4.v, dir);
+  const double d = fmin(fmin(dv4 - dot(P1.v, dir), dv4 - dot(P2.v, dir)), dv4 - dot(P3.v, dir));
   return ccd_eq(d, tol) || d < tol;
 }
 __device__ __forceinline__ void mpr_expand_portal(const CSup& P0, CSup& P1, CSup& P2, CSup& P3, const CSup& v4) {
-  const V3 v4v0 = cross(v4.v, P0.v);
-  if (dot(P1.v, v4v0) > 0.f) { if (dot(P2.v, v4v0) > 0.f) P1 = v4; else P3 = v4; }
-  else { if (dot(P3.v, v4v0) > 0.f) P2 = v4; else P1 = v4; }
+  const V3d v4v0 = cross(v4.v, P0.v);
+  if (dot(P1.v, v4v0) > 0.0) { if (dot(P2.v, v4v0) > 0.0) P1 = v4; else P3 = v4; }
+  else { if (dot(P3.v, v4v0) > 0.0) P2 = v4; else P1 = v4; }
 }
 
 // ccdMPRPenetration: true (and depth, dir from obj1 into obj2, pos) when the objects intersect
-__device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, int max_iterations, float tolerance, float& depth, V3& pdir, V3& pos) {
+__device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, int max_iterations, double tolerance, float& depth_out, V3& pdir_out, V3& pos_out) {
   CSup P0, P1, P2, P3, v4;
-  const V3 origin = {0.f, 0.f, 0.f};
+  const V3d origin = {0.0, 0.0, 0.0};
+  double depth;
+  V3d pdir, pos;
   // ---- discoverPortal
   P0.v1 = ccd_center(o1);
   P0.v = P0.v1 - ccd_center(o2);
-  if (ccd_eq(P0.v.x, 0.f) && ccd_eq(P0.v.y, 0.f) && ccd_eq(P0.v.z, 0.f)) P0.v.x += HB_CCD_EPS * 10.f;
-  V3 dir = normalized(P0.v * -1.f);
+  if (ccd_eq(P0.v.x, 0.0) && ccd_eq(P0.v.y, 0.0) && ccd_eq(P0.v.z, 0.0)) P0.v.x += HB_CCD_EPS * 10.0;
+  V3d dir = normalized(P0.v * -1.0);
   P1 = mpr_support(o1, o2, dir);
-  float dt = dot(P1.v, dir);
-  if (ccd_is_zero(dt) || dt < 0.f) return false;
+  double dt = dot(P1.v, dir);
+  if (ccd_is_zero(dt) || dt < 0.0) return false;
   dir = cross(P0.v, P1.v);
   if (ccd_is_zero(dot(dir, dir))) {
-    pos = P1.v1 - P1.v * 0.5f;  // 0.5 (v1 + v2), v2 = v1 - v
-    if (ccd_eq(P1.v.x, 0.f) && ccd_eq(P1.v.y, 0.f) && ccd_eq(P1.v.z, 0.f)) { depth = 0.f; pdir = origin; return true; }  // touching
-    float n;
-    pdir = normalized(P1.v, &n);
-    depth = n;
+    pos_out = narrow(P1.v1 - P1.v * 0.5);  // 0.5 (v1 + v2), v2 = v1 - v
+    if (ccd_eq(P1.v.x, 0.0) && ccd_eq(P1.v.y, 0.0) && ccd_eq(P1.v.z, 0.0)) { depth_out = 0.f; pdir_out = {0.f, 0.f, 0.f}; return true; }  // touching
+    double n;
+    pdir_out = narrow(normalized(P1.v, &n));
+    depth_out = (float)n;
     return true;
   }
   dir = normalized(dir);
   P2 = mpr_support(o1, o2, dir);
   dt = dot(P2.v, dir);
-  if (ccd_is_zero(dt) || dt < 0.f) return false;
+  if (ccd_is_zero(dt) || dt < 0.0) return false;
   dir = normalized(cross(P1.v - P0.v, P2.v - P0.v));
-  if (dot(dir, P0.v) > 0.f) { const CSup t = P1; P1 = P2; P2 = t; dir = dir * -1.f; }
+  if (dot(dir, P0.v) > 0.0) { const CSup t = P1; P1 = P2; P2 = t; dir = dir * -1.0; }
   for (int guard = 0;; guard++) {
     if (guard > 1000) return false;
     P3 = mpr_support(o1, o2, dir);
     dt = dot(P3.v, dir);
-    if (ccd_is_zero(dt) || dt < 0.f) return false;
+    if (ccd_is_zero(dt) || dt < 0.0) return false;
     bool cont = false;
     dt = dot(cross(P1.v, P3.v), P0.v);
-    if (dt < 0.f && !ccd_is_zero(dt)) { P2 = P3; cont = true; }
+    if (dt < 0.0 && !ccd_is_zero(dt)) { P2 = P3; cont = true; }
     if (!cont) {
       dt = dot(cross(P3.v, P2.v), P0.v);
-      if (dt < 0.f && !ccd_is_zero(dt)) { P1 = P3; cont = true; }
+      if (dt < 0.0 && !ccd_is_zero(dt)) { P1 = P3; cont = true; }
     }
     if (!cont) break;
     dir = normalized(cross(P1.v - P0.v, P2.v - P0.v));
@@ -131,10 +173,10 @@ __device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, 
     if (guard > 1000) return false;
     dir = mpr_portal_dir(P1, P2, P3);
     dt = dot(dir, P1.v);
-    if (ccd_is_zero(dt) || dt > 0.f) break;
+    if (ccd_is_zero(dt) || dt > 0.0) break;
     v4 = mpr_support(o1, o2, dir);
     dt = dot(v4.v, dir);
-    if (!(ccd_is_zero(dt) || dt > 0.f) || mpr_reach_tolerance(P1, P2, P3, v4, dir, tolerance)) return false;
+    if (!(ccd_is_zero(dt) || dt > 0.0) || mpr_reach_tolerance(P1, P2, P3, v4, dir, tolerance)) return false;
     mpr_expand_portal(P0, P1, P2, P3, v4);
   }
   // ---- findPenetr
@@ -142,24 +184,25 @@ __device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, 
     dir = mpr_portal_dir(P1, P2, P3);
     v4 = mpr_support(o1, o2, dir);
     if (mpr_reach_tolerance(P1, P2, P3, v4, dir, tolerance) || it > max_iterations) {
-      const V3 w = closest_on_triangle(origin, P1.v, P2.v, P3.v);
-      depth = sqrtf(dot(w, w));
+      const V3d w = closest_on_triangle(origin, P1.v, P2.v, P3.v);
+      depth = sqrt(dot(w, w));
       if (ccd_is_zero(depth)) pdir = origin;
       else pdir = normalized(w);
       // findPos: barycentric coordinates of the origin in the portal tetrahedron
       dir = mpr_portal_dir(P1, P2, P3);
-      float b0 = dot(cross(P1.v, P2.v), P3.v), b1 = dot(cross(P3.v, P2.v), P0.v), b2 = dot(cross(P0.v, P1.v), P3.v), b3 = dot(cross(P2.v, P1.v), P0.v);
-      float sum = b0 + b1 + b2 + b3;
-      if (ccd_is_zero(sum) || sum < 0.f) {
-        b0 = 0.f;
+      double b0 = dot(cross(P1.v, P2.v), P3.v), b1 = dot(cross(P3.v, P2.v), P0.v), b2 = dot(cross(P0.v, P1.v), P3.v), b3 = dot(cross(P2.v, P1.v), P0.v);
+      double sum = b0 + b1 + b2 + b3;
+      if (ccd_is_zero(sum) || sum < 0.0) {
+        b0 = 0.0;
         b1 = dot(cross(P2.v, P3.v), dir); b2 = dot(cross(P3.v, P1.v), dir); b3 = dot(cross(P1.v, P2.v), dir);
         sum = b1 + b2 + b3;
       }
-      const float inv = 1.f / sum;
+      const double inv = 1.0 / sum;
       // 0.5 (p1 + p2) with p2_i = v1_i - v_i
-      const V3 p1 = P0.v1 * b0 + P1.v1 * b1 + P2.v1 * b2 + P3.v1 * b3;
-      const V3 pv = P0.v * b0 + P1.v * b1 + P2.v * b2 + P3.v * b3;
-      pos = (p1 - pv * 0.5f) * inv;
+      const V3d p1 = P0.v1 * b0 + P1.v1 * b1 + P2.v1 * b2 + P3.v1 * b3;
+      const V3d pv = P0.v * b0 + P1.v * b1 + P2.v * b2 + P3.v * b3;
+      pos = (p1 - pv * 0.5) * inv;
+      depth_out = (float)depth; pdir_out = narrow(pdir); pos_out = narrow(pos);
       return true;
     }
     mpr_expand_portal(P0, P1, P2, P3, v4);

@@ -2,10 +2,11 @@
 world.xml + humanoid.xml: mesh hulls, condim 6, height-field floor, Newton): the HIP kernels through the C-ABI against the
 fp64 oracle, teacher-forced one step from states along oracle trajectories.
 
-Tolerances: contact distance / position come out of an iterative portal search (MPR, tolerance 1e-6 m) run in fp32 on the
-device and fp64 in the oracle: dist 2e-5 m, position 2e-3 m (the MPR position is read off the last portal and moves with
-it), normal 2e-3; qacc / forces 2e-2 relative to their scale, qvel 2e-3, qpos 1e-5 (they inherit the contact geometry's
-differences, amplified by the stiff contact: the bounds are stated, not tuned to pass).  Counts (ncon, nefc) are identical.
+Tolerances (at most 3x the maxima measured on the MI355X, gpurun_out/r02f/pytest.log): contact distance 5e-7 m, position
+3e-6 m, normal 3e-5; qacc 2e-4 and forces 3e-4 relative to their scale, qvel 1.5e-5, qpos 1e-6.  Counts (ncon, nefc)
+identical.  The portal search (MPR) runs in double precision on the device as in the oracle (an fp32 search proved
+unstable against metre-sized prisms, hb_mpr.hpp), from fp32 poses: the few contacts whose search still ends on another
+portal (2 of 339 on the robot, hull against hull) are counted, not compared.
 """
 import os
 
@@ -19,7 +20,7 @@ pytestmark = pytest.mark.gpu
 TEAM_HBM = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "team_robot.hbm")
 
 
-def _teacher_forced(hbmod, gpu, path, states, ctrls, tol, min_contacts=1, max_divergent=0.05):
+def _teacher_forced(hbmod, gpu, path, states, ctrls, tol, min_contacts=1, max_divergent=0.02):
     """one device step from each state vs the oracle; returns the worst deviations"""
     m = hbmod.Model.load(path)
     o = Oracle(path)
@@ -77,7 +78,7 @@ def _teacher_forced(hbmod, gpu, path, states, ctrls, tol, min_contacts=1, max_di
     return worst
 
 
-TOL = dict(qpos=1e-5, qvel=2e-3, qacc=2e-2, force=2e-2, dist=2e-5, pos=2e-3, nrm=2e-3)
+TOL = dict(qpos=1e-6, qvel=1.5e-5, qacc=2e-4, force=3e-4, dist=5e-7, pos=3e-6, nrm=3e-5)
 
 
 def _oracle_states(path, envs, T, every, seed=0, ctrl_scale=1.0, init=None):
@@ -122,8 +123,7 @@ def test_team_robot_one_step_parity_along_oracle_trajectories(hbmod, gpu):
     states, ctrls = _oracle_states(TEAM_HBM, envs=6, T=1200, every=40, seed=1, init=init)  # motors at full swing: flailing, few contacts
     calm = _oracle_states(TEAM_HBM, envs=6, T=800, every=25, seed=2, init=init, ctrl_scale=0.15)  # gentle commands: resting contacts
     states += calm[0]; ctrls += calm[1]
-    # (hull-hull contacts between the legs and flat feet on the flat floor are where MPR's portal is least unique: measured 6.5 %)
-    _teacher_forced(hbmod, gpu, TEAM_HBM, states, ctrls, TOL, min_contacts=300, max_divergent=0.12)
+    _teacher_forced(hbmod, gpu, TEAM_HBM, states, ctrls, TOL, min_contacts=300, max_divergent=0.02)
 
 
 def test_team_robot_free_running_stays_finite(hbmod, gpu):
@@ -183,8 +183,7 @@ def test_primitives_and_hulls_on_a_bumpy_field(hbmod, gpu, tmp_path):
         p = str(tmp_path / name)
         m.save(p)
         states, ctrls = _oracle_states(p, envs=1, T=600, every=12)
-        # (PGS cut at 50 sweeps is not converged: its forces amplify the 1e-5 m differences of the contact geometry more than Newton's)
-        w = _teacher_forced(hbmod, gpu, p, states, ctrls, TOL if solver == 2 else dict(TOL, force=5e-2), min_contacts=60)
+        w = _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=60, max_divergent=0.02)
         if solver == 2:
             assert w["max_nefc"] > 64  # rows beyond the first group of 64 took part (ten rows per condim-6 contact)
 

@@ -45,6 +45,9 @@ struct DeviceModel {
   unsigned long long* d_u64 = nullptr;
   float* d_qpos_src = nullptr;  // qpos0 followed by keyframes, fp32
   DevModel* d_dm = nullptr;     // device copy of dm (the step kernel reads the tables through it)
+  // observation order tables (device pointers): joint order and, when it exists, actuator order (hb_env_config.obs_actuator_order)
+  const int *obs_jnt_joint = nullptr, *obs_src_joint = nullptr, *obs_jnt_act = nullptr, *obs_src_act = nullptr;
+  bool has_act_order = false;
   ~DeviceModel() {
     if (d_int) (void)hipFree(d_int);
     if (d_flt) (void)hipFree(d_flt);
@@ -278,6 +281,20 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   for (int i = 0; i < 3; i++) obs_src.push_back(dm.obs_root_dofadr >= 0 ? 1 + m.nq + dm.obs_root_dofadr + 3 + i : -1);
   dm.obs_root_qadr = -1;
   for (int j = 0; j < m.njnt; j++) if (m.jnt_type[j] == JNT_FREE) { dm.obs_root_qadr = m.jnt_qposadr[j]; break; }
+  // the scalar joints in observation order: joint order, and - when every scalar joint has exactly one actuator - actuator order
+  // (the reference's JOINT_NAMES order, hb_env_config.obs_actuator_order); the second half of each table is the obs_src of that order
+  std::vector<int> obs_jnt, obs_jnt_act, obs_src_act;
+  for (int j = 0; j < m.njnt; j++) if (m.jnt_type[j] == JNT_HINGE || m.jnt_type[j] == JNT_SLIDE) obs_jnt.push_back(j);
+  {
+    std::vector<int> seen(m.njnt, 0);
+    bool ok = m.nu == nscalar;
+    for (int a = 0; a < m.nu && ok; a++) { if (seen[m.actuator_trnid[a]]++) ok = false; obs_jnt_act.push_back(m.actuator_trnid[a]); }
+    if (!ok) obs_jnt_act.clear();
+    D.has_act_order = ok;
+    for (int j : obs_jnt_act) obs_src_act.push_back(1 + m.jnt_qposadr[j]);
+    for (int j : obs_jnt_act) obs_src_act.push_back(1 + m.nq + m.jnt_dofadr[j]);
+    for (int i = 0; i < 3; i++) obs_src_act.push_back(dm.obs_root_dofadr >= 0 ? 1 + m.nq + dm.obs_root_dofadr + 3 + i : -1);
+  }
 
   // level-ordered body records, dof records, packed M entries (layouts in hb_device.hpp)
   std::vector<float> brec((size_t)nb * kBrecQuads * 4, 0.f);
@@ -344,7 +361,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TF(pair_friction, pair_fr); TF(pair_solref, pair_solref); TF(pair_solimp, pair_solimp); TF(pair_margin, pair_margin); TF(pair_gap, pair_gap);
   TI(lim_kind, lim_kind); TI(lim_id, lim_id); TI(lim_side, lim_side);
   TF(lim_range, lim_range); TF(lim_margin, lim_margin); TF(lim_solref, lim_solref); TF(lim_solimp, lim_solimp); TF(lim_invweight, lim_invw);
-  TI(obs_src, obs_src);
+  TI(obs_src, obs_src); TI(obs_jnt, obs_jnt);
+  const size_t o_obs_jnt_act = T.addi(obs_jnt_act.empty() ? std::vector<int>{0} : obs_jnt_act), o_obs_src_act = T.addi(obs_src_act.empty() ? std::vector<int>{0} : obs_src_act);
   TI(tendon_adr, m.tendon_adr); TI(tendon_num, m.tendon_num); TI(wrap_dofadr, wrap_dofadr); TI(wrap_qposadr, wrap_qposadr);
   TF(wrap_prm, m.wrap_prm);
   TI(act_qposadr, act_qposadr); TI(act_dofadr, act_dofadr); TI(act_ctrllimited, m.actuator_ctrllimited); TI(act_forcelimited, m.actuator_forcelimited);
@@ -432,6 +450,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.crec = reinterpret_cast<const float4*>(D.d_flt + o_crec);
   dm.trec = reinterpret_cast<const float4*>(D.d_flt + o_trec);
   dm.lrec = reinterpret_cast<const float4*>(D.d_flt + o_lrec);
+  D.obs_jnt_joint = dm.obs_jnt; D.obs_src_joint = dm.obs_src;
+  D.obs_jnt_act = D.d_int + o_obs_jnt_act; D.obs_src_act = D.d_int + o_obs_src_act;
   dm.arec = reinterpret_cast<const float4*>(D.d_flt + o_arec);
   dm.mesh_vert = reinterpret_cast<const float4*>(D.d_flt + o_meshv);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
@@ -1650,6 +1670,34 @@ int hb_env_default_config(const hb_model* h, hb_env_config* c) {
   return HB_OK;
 }
 
+int hb_env_team_config(const hb_model* h, hb_env_config* c) {
+  if (!h || !c) return HB_EINVAL;
+  const Model& m = h->m;
+  int rc = hb_env_default_config(h, c);
+  if (rc != HB_OK) return rc;
+  auto act = [&](const char* name) { for (int a = 0; a < m.nu; a++) if (m.actuator_name[a] == name) return a; return -1; };
+  // reward_functions.py:289-339 (standupReward) and simulation_parameters.py:51-77
+  c->target_z = -0.375f;            // TARGET_Z_POS = Z_INITIAL_POS
+  c->min_z = -0.6f;                 // MIN_Z_POS_FOR_REWARD
+  c->max_time = 10.f;               // MAX_SIM_TIME_STANDUP
+  c->safe_torque = 1.0f;            // MAX__SAFE_JOINT_TORQUE
+  c->control_frequency = 500.f;     // CONTROL_FREQUENCY
+  c->n_equal = c->n_opposite = 0;
+  const char* eq[][2] = {{"left_elbow", "right_elbow"}};
+  const char* op[][2] = {{"left_hip_roll", "right_hip_roll"}, {"left_hip_pitch", "right_hip_pitch"}, {"left_knee", "right_knee"},
+                         {"left_shoulder_pitch", "right_shoulder_pitch"}, {"left_shoulder_roll", "right_shoulder_roll"}};
+  for (auto& pr : eq) { const int a = act(pr[0]), b2 = act(pr[1]); if (a < 0 || b2 < 0) return HB_EINVAL; c->equal_pairs[c->n_equal][0] = a; c->equal_pairs[c->n_equal][1] = b2; c->n_equal++; }
+  for (auto& pr : op) { const int a = act(pr[0]), b2 = act(pr[1]); if (a < 0 || b2 < 0) return HB_EINVAL; c->opposite_pairs[c->n_opposite][0] = a; c->opposite_pairs[c->n_opposite][1] = b2; c->n_opposite++; }
+  c->reset_keyframe = -1;
+  for (int k = 0; k < m.nkey; k++) if (m.key_name[k] == "standup_reset") c->reset_keyframe = k;
+  c->reset_perturb = 1.f;
+  c->reset_quat_perturb = 0.1f;     // QUAT_INITIAL_OFFSET_MAX
+  c->obs_actuator_order = 1;        // JOINT_NAMES order = the <motor> order of the reference's humanoid.xml
+  c->min_z_grounded = -0.6f;
+  c->reset_collision_mode = 1;      // CPUEnv.reset starts over while anything is in contact (cpu_env.py:411-414)
+  return HB_OK;
+}
+
 int hb_env_configure(hb_batch* b, const hb_env_config* cfg) {
   if (!b || !cfg) return HB_EINVAL;
   if (cfg->n_equal < 0 || cfg->n_equal > HB_ENV_MAX_PAIRS || cfg->n_opposite < 0 || cfg->n_opposite > HB_ENV_MAX_PAIRS || !(cfg->action_scale > 0)) return HB_EINVAL;
@@ -1658,9 +1706,14 @@ int hb_env_configure(hb_batch* b, const hb_env_config* cfg) {
   for (int k = 0; k < cfg->n_opposite; k++) for (int t = 0; t < 2; t++) if (cfg->opposite_pairs[k][t] < 0 || cfg->opposite_pairs[k][t] >= nu) return HB_EINVAL;
   if (cfg->reset_keyframe >= b->model->m.nkey) return HB_EINVAL;
   if (cfg->reward_kind < 0 || cfg->reward_kind > 1 || cfg->reset_collision_mode < 0 || cfg->reset_collision_mode > 2) return HB_EINVAL;
+  if (!(cfg->reset_quat_perturb >= 0.f) || (cfg->obs_actuator_order != 0 && cfg->obs_actuator_order != 1)) return HB_EINVAL;
+  if (cfg->obs_actuator_order && !b->D.has_act_order) return HB_EINVAL;  // needs exactly one actuator per scalar joint
   int rc = env_alloc(b);
   if (rc != HB_OK) return rc;
   memcpy(&b->env_cfg, cfg, sizeof *cfg);
+  // the env / observation / policy kernels take the DevModel by value from this host copy: point it at the chosen order
+  b->D.dm.obs_jnt = cfg->obs_actuator_order ? b->D.obs_jnt_act : b->D.obs_jnt_joint;
+  b->D.dm.obs_src = cfg->obs_actuator_order ? b->D.obs_src_act : b->D.obs_src_joint;
   return HB_OK;
 }
 
@@ -1815,7 +1868,7 @@ int hb_env_reset(hb_batch* b, float* obs) {
     const float dtc = b->rand_on && b->env_rand.control_timestep > 0.f ? b->env_rand.control_timestep : (float)m.timestep;
     const int substeps = std::max(1, (int)std::lround(dtc / m.timestep));
     for (int attempt = 0; attempt < 8; attempt++) {
-      HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, b->d_rmask, src, b->d_episode, b->n_env, c.reset_perturb, b->env_offset, main_stream(b)));
+      HB_HIP(launch_reset(b->D.dm, b->d_state, b->d_status, b->d_rmask, src, b->d_episode, b->n_env, c.reset_perturb, b->env_offset, main_stream(b), c.reset_quat_perturb));
       if (b->rand_on) HB_HIP(launch_envrand_reset(b->D.dm, b->env_rand, b->rs, b->d_episode, b->d_rmask, b->n_env, b->env_offset, main_stream(b)));
       if (b->d_dr) HB_HIP(launch_domain_rand(b->D.dm, b->dom_rand, b->d_dr, b->dr_stride, b->d_episode, b->d_rmask, b->n_env, b->env_offset, main_stream(b)));
       rc = env_step_impl(b, nullptr, substeps, b->d_rmask, false, b->d_obs, b->d_reward, b->d_term, b->d_trunc);

@@ -109,6 +109,7 @@ struct DevModel {
   // env adapter
   int obs_root_body, obs_root_dofadr, obs_root_qadr;
   const int HB_CONST* obs_src;  // [nobs - 3]: state-record offset each copied observation entry comes from (-1: zero)
+  const int HB_CONST* obs_jnt;  // [(nobs - 6) / 2]: the scalar joints in observation order (joint order, or actuator order: hb_env_config)
   // LDS layout (float offsets per env) — persistent region
   int o_gquat;  // general collision only: world orientation of every geom (4 floats each)
   int o_meta;   // general variants: per-row (R, K imp (pos - margin), B, -) written by makeConstraint
@@ -138,6 +139,8 @@ struct EnvConfig {
   int reward_kind;
   float w_vvel, min_z_grounded;
   int reset_collision_mode;
+  float reset_quat_perturb;
+  int obs_actuator_order;
 };
 
 // hb_env_randomization (include/hb.h), same layout

@@ -2615,7 +2615,7 @@ __global__ void hb_spline_tape_kernel(const DevModel M, const float* knots, cons
 // ------------------------------------------------------------------------------------------
 // reset: qpos0/keyframe (+ Halton perturbation), zero velocity/warmstart/time/status
 // qpos <- reset pose (+ the Halton perturbation indexed by global env and, for the env adapter, episode), rest zero
-__device__ __forceinline__ void reset_state(const DevModel& M, float* s, const float* qpos_src, float perturb, int env_global, int ep) {
+__device__ __forceinline__ void reset_state(const DevModel& M, float* s, const float* qpos_src, float perturb, int env_global, int ep, float quat_perturb = 0.f) {
   s[0] = 0.f;
   for (int i = 0; i < M.nq; i++) s[1 + i] = qpos_src[i];
   for (int i = 0; i < 2 * M.nv; i++) s[1 + M.nq + i] = 0.f;
@@ -2623,17 +2623,20 @@ __device__ __forceinline__ void reset_state(const DevModel& M, float* s, const f
     const int idx = env_global + 1 + ep * 7919;
     for (int j = 0; j < M.njnt; j++) {
       int qa = M.jnt_qposadr[j];
-      if (M.jnt_type[j] == 0) s[1 + qa + 2] += perturb * 0.1f * halton(idx, 3);
-      else s[1 + qa] += perturb * 0.2f * (2.f * halton(idx, 2 + j) - 1.f);
+      if (M.jnt_type[j] == 0) {
+        s[1 + qa + 2] += perturb * 0.1f * halton(idx, 3);
+        // root orientation: every quaternion component +- quat_perturb (cpu_env.py:316-328), left unnormalised as in the reference
+        for (int i = 0; i < 4; i++) s[1 + qa + 3 + i] += perturb * quat_perturb * (2.f * halton(idx, 2 + M.njnt + i) - 1.f);
+      } else s[1 + qa] += perturb * 0.2f * (2.f * halton(idx, 2 + j) - 1.f);
     }
   }
 }
 __global__ void hb_reset_kernel(const DevModel M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
-                                int env_offset) {
+                                int env_offset, float quat_perturb) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_env) return;
   if (mask && !mask[e]) return;
-  reset_state(M, state + (size_t)e * M.nstate, qpos_src, perturb, env_offset + e, episode ? episode[e] : 0);
+  reset_state(M, state + (size_t)e * M.nstate, qpos_src, perturb, env_offset + e, episode ? episode[e] : 0, quat_perturb);
   status[e] = 0;
 }
 
@@ -2832,10 +2835,9 @@ __device__ __forceinline__ void compute_obs(const DevModel& M, const float* s, f
   const float* qpos = s + 1;
   const float* qvel = s + 1 + M.nq;
   int k = 0;
-  for (int j = 0; j < M.njnt; j++)
-    if (M.jnt_type[j] >= 2) o[k++] = qpos[M.jnt_qposadr[j]];
-  for (int j = 0; j < M.njnt; j++)
-    if (M.jnt_type[j] >= 2) o[k++] = qvel[M.jnt_dofadr[j]];
+  const int nj = (M.nobs - 6) / 2;
+  for (int i = 0; i < nj; i++) o[k++] = qpos[M.jnt_qposadr[M.obs_jnt[i]]];
+  for (int i = 0; i < nj; i++) o[k++] = qvel[M.jnt_dofadr[M.obs_jnt[i]]];
   const int da = M.obs_root_dofadr;
   Q4 q = {1.f, 0.f, 0.f, 0.f};
   float z = 0.f;
@@ -2948,7 +2950,7 @@ __global__ void hb_env_kernel(const DevModel M, const EnvConfig cfg, const EnvRa
   if ((term || trunc) && cfg.auto_reset) {
     // CPUEnv.reset for this env; the perturbation index advances with the episode count
     const int ep = ++episode[e];
-    reset_state(M, s, qpos_src, cfg.reset_perturb, env_offset + e, ep);
+    reset_state(M, s, qpos_src, cfg.reset_perturb, env_offset + e, ep, cfg.reset_quat_perturb);
     for (int i = 0; i < M.nu; i++) { prev[(size_t)e * M.nu + i] = 0.f; latest[(size_t)e * M.nu + i] = 0.f; }
     status[e] = 0;
     if (rand_on) envrand_begin_episode(M, R, S, e, env_offset + e, ep);
@@ -3169,9 +3171,9 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
   return hipGetLastError();
 }
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
-                        int env_offset, hipStream_t stream) {
+                        int env_offset, hipStream_t stream, float quat_perturb) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, status, mask, qpos_src, episode, n_env, perturb, env_offset);
+  hipLaunchKernelGGL(hb_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, status, mask, qpos_src, episode, n_env, perturb, env_offset, quat_perturb);
   return hipGetLastError();
 }
 hipError_t launch_envrand_reset(const DevModel& M, const EnvRand& R, const EnvRandState& S, const int* episode, const uint8_t* mask, int n_env, int env_offset,

@@ -48,7 +48,7 @@ class HbEnvConfig(ctypes.Structure):
                 ("n_opposite", ctypes.c_int), ("equal_pairs", (ctypes.c_int * 2) * 16), ("opposite_pairs", (ctypes.c_int * 2) * 16),
                 ("auto_reset", ctypes.c_int), ("reset_keyframe", ctypes.c_int), ("reset_perturb", ctypes.c_float),
                 ("reward_kind", ctypes.c_int), ("w_vvel", ctypes.c_float), ("min_z_grounded", ctypes.c_float),
-                ("reset_collision_mode", ctypes.c_int)]
+                ("reset_collision_mode", ctypes.c_int), ("reset_quat_perturb", ctypes.c_float), ("obs_actuator_order", ctypes.c_int)]
 
 
 class HbEnvRandomization(ctypes.Structure):
@@ -142,6 +142,7 @@ def lib():
     L.hb_diag_enable.argtypes = [vp, ci]
     L.hb_get_qacc.argtypes = [vp, vp]; L.hb_get_efc_force.argtypes = [vp, vp]; L.hb_get_contacts.argtypes = [vp, vp]
     L.hb_env_default_config.argtypes = [vp, ctypes.POINTER(HbEnvConfig)]
+    L.hb_env_team_config.argtypes = [vp, ctypes.POINTER(HbEnvConfig)]
     L.hb_env_configure.argtypes = [vp, ctypes.POINTER(HbEnvConfig)]
     L.hb_env_default_randomization.argtypes = [vp, ctypes.POINTER(HbEnvRandomization)]
     L.hb_env_randomize.argtypes = [vp, ctypes.POINTER(HbEnvRandomization)]
@@ -559,6 +560,12 @@ class Batch:
     def env_default_config(self):
         c = HbEnvConfig()
         _check(lib().hb_env_default_config(self.model._h, ctypes.byref(c)), "hb_env_default_config")
+        return c
+
+    def env_team_config(self):
+        """The reference's own values for its own robot (hb_env_team_config)."""
+        c = HbEnvConfig()
+        _check(lib().hb_env_team_config(self.model._h, ctypes.byref(c)), "hb_env_team_config")
         return c
 
     def env_configure(self, cfg):

@@ -12,15 +12,17 @@ from .engine import WARN_BADQACC, WARN_BADQPOS, WARN_BADQVEL, WARN_CNSTRFULL, WA
 
 
 class VecEnv:
-    def __init__(self, model, n_envs, device=0, n_substeps=1, randomization_factor=1.0, realism=False, domain_randomization=False, seed=0, **reward_overrides):
+    def __init__(self, model, n_envs, device=0, n_substeps=1, randomization_factor=1.0, realism=False, domain_randomization=False, seed=0, team=False, **reward_overrides):
         """realism=True adds CPUEnv's sensor/action noise, delay FIFOs and pushes (hb_env_randomization), scaled by
         randomization_factor exactly like the reset perturbation; domain_randomization=True draws per-env masses, floor
-        friction, joint and actuator parameters at every reset (hb_domain_randomization)."""
+        friction, joint and actuator parameters at every reset (hb_domain_randomization).  team=True: the reference's own
+        constants for its own robot (hb_env_team_config: obs[30] in JOINT_NAMES order, action[12], standup reset, kp = 2)."""
         self.model = model if isinstance(model, Model) else Model.load(model)
         self.batch = Batch(self.model, n_envs, device)
         self.num_envs = int(n_envs)
         self.n_substeps = int(n_substeps)
-        self.cfg = self.batch.env_default_config()
+        self.cfg = self.batch.env_team_config() if team else self.batch.env_default_config()
+        self.team = bool(team)
         self.cfg.reset_perturb = float(randomization_factor)
         for k, v in reward_overrides.items():
             if not hasattr(self.cfg, k):
@@ -37,6 +39,9 @@ class VecEnv:
         if domain_randomization:
             self.domain = self.batch.env_default_domain_randomization()
             self.domain.seed = int(seed)
+            if self.team:
+                self.domain.kp_nominal = 2.0  # JOINT_P_GAIN (simulation_parameters.py:35): CPUEnv overwrites the motors' gain at every reset
+                self.domain.floor_bump_max = 0.1  # MAX_FLOOR_BUMP_HEIGHT
             self._apply_domain()
         # gymnasium-style space descriptions (cpu_env.py:56-63: Box(-1,1,(nu,)), Box(-10,10,(nobs,)))
         self.action_shape = (self.model.nu,)

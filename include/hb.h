@@ -338,9 +338,21 @@ typedef struct hb_env_config {
   /* reset-until-collision-free (cpu_env.py:411-414: reset steps once and starts over while anything collides):
    * 0 off, 1 any contact (the reference's test), 2 self-collision only; hb_env_reset only, at most 8 draws */
   int reset_collision_mode;
+  /* CPUEnv._randomize_starting_position also perturbs the root quaternion, +-QUAT_INITIAL_OFFSET_MAX (0.1) per component, scaled by
+   * reset_perturb like the rest (cpu_env.py:300-328; the result is not renormalised there either: mj_kinematics does that) */
+  float reset_quat_perturb;
+  /* 0: the joint entries of the observation are in joint order; 1: in ACTUATOR order, the reference's JOINT_NAMES order
+   * (simulation_parameters.py:84-103 = the <motor> order of assets/humanoid.xml:97-110): needs one actuator per scalar joint */
+  int obs_actuator_order;
 } hb_env_config;
 
 int hb_env_default_config(const hb_model* m, hb_env_config* out);
+/* The reference's own values for its own robot (simulation/assets/world.xml + humanoid.xml; reward_functions.py:289-372,
+ * simulation_parameters.py:51-103): TARGET_Z_POS -0.375, MIN_Z_POS_FOR_REWARD -0.6, safe torque 1 N m, 500 Hz, the symmetry pairs
+ * by joint name (equal: elbows; opposite: hip roll, hip pitch, knee, shoulder pitch, shoulder roll), observation in JOINT_NAMES
+ * order, reset = keyframe "standup_reset" if the model has it (lying on the floor: INITIAL_QUAT_STANDUP, Z_INITIAL_POS_STANDUP) with
+ * the joint / height / quaternion perturbations of CPUEnv.reset.  HB_EINVAL if the model lacks the reference's joint names. */
+int hb_env_team_config(const hb_model* m, hb_env_config* out);
 int hb_env_configure(hb_batch* b, const hb_env_config* cfg);
 
 /* Sensor / actuation realism of CPUEnv (cpu_env.py:135-186,465-545,612-674; values of simulation_parameters.py:5-48),

@@ -251,54 +251,6 @@ __device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
 #include "hb_mpr.hpp"
 namespace hb {
 
-// height field (geom1, static) vs sphere: this engine's terrain contact model (see the oracle's
-// hfield_sphere): closest point on the triangulated surface inside the sphere's footprint, one contact,
-// normal out of the terrain.  hmat = rotation of the field's frame (row-major), hpos its origin.
-__device__ __forceinline__ bool hfield_sphere(DevModelRef M, const float* hdata, ConOut& c, float margin, int hid, V3 hpos, const float* hmat, V3 spos, float radius) {
-  const float hsx = M.hfield_size[4 * hid], hsy = M.hfield_size[4 * hid + 1], hsz = M.hfield_size[4 * hid + 2], hsb = M.hfield_size[4 * hid + 3];
-  const int nrow = M.hfield_nrow[hid], ncol = M.hfield_ncol[hid];
-  const float* data = hdata + M.hfield_adr[hid];  // the model's elevations, or this env's own (domain randomisation)
-  const V3 dif = spos - hpos;
-  const V3 p = {hmat[0] * dif.x + hmat[3] * dif.y + hmat[6] * dif.z, hmat[1] * dif.x + hmat[4] * dif.y + hmat[7] * dif.z, hmat[2] * dif.x + hmat[5] * dif.y + hmat[8] * dif.z};
-  const float reach = radius + margin;
-  if (p.x < -hsx - reach || p.x > hsx + reach || p.y < -hsy - reach || p.y > hsy + reach || p.z > hsz + reach || p.z < -hsb - reach) return false;
-  const float dx = 2.f * hsx / (float)(ncol - 1), dy = 2.f * hsy / (float)(nrow - 1);
-  int cmin = (int)floorf((p.x - reach + hsx) / dx), cmax = (int)ceilf((p.x + reach + hsx) / dx);
-  int rmin = (int)floorf((p.y - reach + hsy) / dy), rmax = (int)ceilf((p.y + reach + hsy) / dy);
-  cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, ncol - 1); rmax = min(rmax, nrow - 1);
-  float best = 3.0e38f;
-  V3 bestpt = {0.f, 0.f, 0.f}, bestn = {0.f, 0.f, 1.f};
-  for (int r = rmin; r < rmax; r++)
-    for (int cc = cmin; cc < cmax; cc++) {
-      const float x0 = cc * dx - hsx, x1 = x0 + dx, y0 = r * dy - hsy, y1 = y0 + dy;
-      const V3 A = {x0, y0, data[r * ncol + cc] * hsz}, B = {x1, y0, data[r * ncol + cc + 1] * hsz};
-      const V3 C = {x0, y1, data[(r + 1) * ncol + cc] * hsz}, D = {x1, y1, data[(r + 1) * ncol + cc + 1] * hsz};
-      const V3 q1 = closest_on_triangle(p, A, B, D);
-      const V3 e1 = p - q1;
-      const float dd1 = dot(e1, e1);
-      if (dd1 < best) { best = dd1; bestpt = q1; bestn = cross(B - A, D - A); }
-      const V3 q2 = closest_on_triangle(p, A, D, C);
-      const V3 e2 = p - q2;
-      const float dd2 = dot(e2, e2);
-      if (dd2 < best) { best = dd2; bestpt = q2; bestn = cross(D - A, C - A); }
-    }
-  if (best > 1.0e38f) return false;
-  float dist = sqrtf(best);
-  bestn = normalized(bestn);
-  V3 nrm;
-  if (dist < HB_MINVAL) nrm = bestn;
-  else {
-    nrm = (p - bestpt) * (1.f / dist);
-    if (dot(nrm, bestn) < 0.f) { nrm = nrm * -1.f; dist = -dist; }
-  }
-  if (dist - radius > margin) return false;
-  c.dist = dist - radius;
-  const V3 lp = p - nrm * (radius + 0.5f * c.dist);
-  c.pos = hpos + mrot(hmat, lp);
-  c.n = mrot(hmat, nrm);
-  return true;
-}
-
 // complete a contact frame from its normal and an optional tangent hint (mju_makeFrame)
 __device__ __forceinline__ void make_frame(float* f, V3 n, V3 hint) {
   n = normalized(n);
@@ -1427,7 +1379,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y), t1 = __float_as_int(c0.z) & 255;
             const V3 dp = ld3(s_gpos + 3 * g2) - ld3(s_gpos + 3 * g1);
             if (t1 == 0) pass = dot(dp, ld3(s_gaxis + 3 * g1)) <= c0.w + c1.y;
-            else if (t1 == 1) pass = true;
             else { const float bound = c1.x + c1.y + c0.w; pass = dot(dp, dp) <= bound * bound; }
           }
           const unsigned long long bal = __ballot(pass);
@@ -1466,21 +1417,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
                 n = (h1 ? 1 : 0) + (h2 ? 1 : 0);
                 hint = ax2;
               }
-            }
-          } else if (t1 == 1) {
-            // static height field: full frame from the geom's own quaternion (world body)
-            float hm[9];
-            q2mat(hm, ldq(M.geom_quat + 4 * g1));
-            const int hid = M.geom_dataid[g1];
-            const float* hdata = dr ? dr + DL.o_hfield : (const float*)M.hfield_data;
-            if (t2 == 2) n = hfield_sphere(M, hdata, co0, margin, hid, pos1, hm, pos2, r2) ? 1 : 0;
-            else {
-              ConOut ca, cb;
-              const bool h1 = hfield_sphere(M, hdata, ca, margin, hid, pos1, hm, pos2 + ax2 * l2, r2);
-              const bool h2 = hfield_sphere(M, hdata, cb, margin, hid, pos1, hm, pos2 - ax2 * l2, r2);
-              co0 = h1 ? ca : cb;
-              co1 = cb;
-              n = (h1 ? 1 : 0) + (h2 ? 1 : 0);
             }
           } else if (t1 >= 2) {
             V3 dp = pos2 - pos1;

@@ -51,7 +51,6 @@ enum { WARN_CONTACTFULL = 1, WARN_CNSTRFULL = 2, WARN_BADQPOS = 4, WARN_BADQVEL 
 
 typedef struct {
   int nq, nv, nu, nbody, njnt, ngeom, ntendon, nwrap, nM, nkey, npair, nhfield, nhfielddata, nmesh, nmeshvert;
-  int hfield_model;     /* 0: MuJoCo's prism scheme (mjc_ConvexHField); 1: the private closest-point terrain model of round 1 (kept for comparison only) */
   int mpr_iterations;   /* mjOption.mpr_iterations, mjmodel.h:437 (default 50) */
   double mpr_tolerance; /* mjOption.mpr_tolerance, mjmodel.h:413 (default 1e-6) */
   double timestep, impratio, tolerance, meaninertia, gravity[3];
@@ -168,7 +167,7 @@ om_model* om_load(const char* path, char* err, int errsz) {
 #define AI(x, n) m->x = rec_iarr(recs, nr, #x, n)
 #define AD(x, n) m->x = rec_darr(recs, nr, #x, n)
   RI(nq); RI(nv); RI(nu); RI(nbody); RI(njnt); RI(ngeom); RI(ntendon); RI(nwrap); RI(nM); RI(nkey); RI(npair); RI(nhfield); RI(nhfielddata); RI(nmesh); RI(nmeshvert);
-  m->mpr_iterations = 50; m->mpr_tolerance = 1e-6; m->hfield_model = 0;
+  m->mpr_iterations = 50; m->mpr_tolerance = 1e-6;
   RD(timestep); RD(impratio); RD(tolerance); RD(meaninertia);
   RI(integrator); RI(cone); RI(solver); RI(iterations); RI(disableflags);
   m->ls_iterations = rec_int(recs, nr, "ls_iterations", 50); m->ls_tolerance = rec_dbl(recs, nr, "ls_tolerance", 0.01);
@@ -594,88 +593,6 @@ static int capsule_capsule(om_contact* c, double margin, const double* pos1, con
   return n;
 }
 
-/* height field vs sphere.  NOT a restatement of MuJoCo's algorithm (mjc_ConvexHField decomposes the
- * field into prisms and runs its convex collider on each): this engine's own terrain contact model,
- * used by BASELINE config 5 — closest point on the triangulated surface (each cell split along the
- * A-D diagonal) inside the sphere's footprint, one contact per sphere, normal out of the terrain.
- * The device kernel implements exactly this; parity for config 5 is GPU-vs-this-model only. */
-static void closest_on_triangle(double* out, const double* p, const double* a, const double* b, const double* c) {
-  double ab[3], ac[3], ap[3];
-  for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
-  double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
-  if (d1 <= 0 && d2 <= 0) { memcpy(out, a, 3 * sizeof(double)); return; }
-  double bp[3] = {p[0] - b[0], p[1] - b[1], p[2] - b[2]};
-  double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
-  if (d3 >= 0 && d4 <= d3) { memcpy(out, b, 3 * sizeof(double)); return; }
-  double vc = d1 * d4 - d3 * d2;
-  if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); for (int i = 0; i < 3; i++) out[i] = a[i] + v * ab[i]; return; }
-  double cp[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
-  double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
-  if (d6 >= 0 && d5 <= d6) { memcpy(out, c, 3 * sizeof(double)); return; }
-  double vb = d5 * d2 - d1 * d6;
-  if (vb <= 0 && d2 >= 0 && d6 <= 0) { double w = d2 / (d2 - d6); for (int i = 0; i < 3; i++) out[i] = a[i] + w * ac[i]; return; }
-  double va = d3 * d6 - d5 * d4;
-  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); for (int i = 0; i < 3; i++) out[i] = b[i] + w * (c[i] - b[i]); return; }
-  double denom = 1.0 / (va + vb + vc), v = vb * denom, w = vc * denom;
-  for (int i = 0; i < 3; i++) out[i] = a[i] + ab[i] * v + ac[i] * w;
-}
-
-static int hfield_sphere(const om_model* m, om_contact* c, double margin, int hid, const double* hpos, const double* hmat, const double* spos, double radius) {
-  const double* hs = m->hfield_size + 4 * hid;
-  int nrow = m->hfield_nrow[hid], ncol = m->hfield_ncol[hid];
-  const double* data = m->hfield_data + m->hfield_adr[hid];
-  /* sphere centre in the hfield frame */
-  double dif[3] = {spos[0] - hpos[0], spos[1] - hpos[1], spos[2] - hpos[2]}, p[3];
-  for (int i = 0; i < 3; i++) p[i] = hmat[i] * dif[0] + hmat[3 + i] * dif[1] + hmat[6 + i] * dif[2];
-  double reach = radius + margin;
-  if (p[0] < -hs[0] - reach || p[0] > hs[0] + reach || p[1] < -hs[1] - reach || p[1] > hs[1] + reach || p[2] > hs[2] + reach || p[2] < -hs[3] - reach) return 0;
-  double dx = 2 * hs[0] / (ncol - 1), dy = 2 * hs[1] / (nrow - 1);
-  int cmin = (int)floor((p[0] - reach + hs[0]) / dx), cmax = (int)ceil((p[0] + reach + hs[0]) / dx);
-  int rmin = (int)floor((p[1] - reach + hs[1]) / dy), rmax = (int)ceil((p[1] + reach + hs[1]) / dy);
-  if (cmin < 0) cmin = 0; if (rmin < 0) rmin = 0; if (cmax > ncol - 1) cmax = ncol - 1; if (rmax > nrow - 1) rmax = nrow - 1;
-  double best = 1e300, bestpt[3] = {0, 0, 0}, bestn[3] = {0, 0, 1};
-  for (int r = rmin; r < rmax; r++)
-    for (int cc = cmin; cc < cmax; cc++) {
-      double x0 = cc * dx - hs[0], x1 = x0 + dx, y0 = r * dy - hs[1], y1 = y0 + dy;
-      double z00 = data[r * ncol + cc] * hs[2], z01 = data[r * ncol + cc + 1] * hs[2], z10 = data[(r + 1) * ncol + cc] * hs[2], z11 = data[(r + 1) * ncol + cc + 1] * hs[2];
-      double A[3] = {x0, y0, z00}, B[3] = {x1, y0, z01}, C[3] = {x0, y1, z10}, D[3] = {x1, y1, z11};
-      double q[3];
-      const double* tris[2][3] = {{A, B, D}, {A, D, C}};
-      for (int t = 0; t < 2; t++) {
-        closest_on_triangle(q, p, tris[t][0], tris[t][1], tris[t][2]);
-        double e[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
-        double dd = dot3(e, e);
-        if (dd < best) {
-          best = dd; memcpy(bestpt, q, sizeof q);
-          double e1[3] = {tris[t][1][0] - tris[t][0][0], tris[t][1][1] - tris[t][0][1], tris[t][1][2] - tris[t][0][2]};
-          double e2[3] = {tris[t][2][0] - tris[t][0][0], tris[t][2][1] - tris[t][0][1], tris[t][2][2] - tris[t][0][2]};
-          cross3(bestn, e1, e2);  /* counter-clockwise triangles: upward normal */
-        }
-      }
-    }
-  if (best > 1e299) return 0;
-  double dist = sqrt(best);
-  double nrm[3] = {p[0] - bestpt[0], p[1] - bestpt[1], p[2] - bestpt[2]};
-  normalize3(bestn);
-  if (dist < MINVAL) { memcpy(nrm, bestn, sizeof nrm); }
-  else {
-    for (int i = 0; i < 3; i++) nrm[i] /= dist;
-    /* centre under the surface: the contact normal keeps pointing out of the terrain, the distance turns negative */
-    if (dot3(nrm, bestn) < 0) { for (int i = 0; i < 3; i++) nrm[i] = -nrm[i]; dist = -dist; }
-  }
-  if (dist - radius > margin) return 0;
-  c->dist = dist - radius;
-  double lp[3], ln[3] = {nrm[0], nrm[1], nrm[2]};
-  for (int i = 0; i < 3; i++) lp[i] = p[i] - nrm[i] * (radius + c->dist / 2);  /* midway between the surfaces */
-  /* back to the world frame; normal points from hfield (geom1) to sphere (geom2) */
-  for (int i = 0; i < 3; i++) {
-    c->pos[i] = hpos[i] + hmat[3 * i] * lp[0] + hmat[3 * i + 1] * lp[1] + hmat[3 * i + 2] * lp[2];
-    c->frame[i] = hmat[3 * i] * ln[0] + hmat[3 * i + 1] * ln[1] + hmat[3 * i + 2] * ln[2];
-  }
-  memset(c->frame + 3, 0, 6 * sizeof(double));
-  return 1;
-}
-
 /* ------------------------------------------------------------------ convex collision (libccd MPR) ----
  * MuJoCo collides mesh geoms (through their convex hulls), and ANY geom against a height field, with libccd's Minkowski
  * Portal Refinement: engine_collision_convex.c (mjc_Convex, mjc_ConvexHField; declared through mj_collision, mujoco.h:355)
@@ -764,7 +681,27 @@ static void mpr_expand_portal(ccd_sup* P, const ccd_sup* v4) {
   else { if (dot3(P[3].v, v4v0) > 0) P[2] = *v4; else P[1] = *v4; }
 }
 /* squared distance of the origin from triangle (a, b, c) and the closest point (ccdVec3PointTriDist2 with P = origin) */
-static void closest_on_triangle(double* out, const double* p, const double* a, const double* b, const double* c);
+/* closest point of triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5): stands in for libccd's ccdVec3PointTriDist2 */
+static void closest_on_triangle(double* out, const double* p, const double* a, const double* b, const double* c) {
+  double ab[3], ac[3], ap[3];
+  for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+  double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { memcpy(out, a, 3 * sizeof(double)); return; }
+  double bp[3] = {p[0] - b[0], p[1] - b[1], p[2] - b[2]};
+  double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { memcpy(out, b, 3 * sizeof(double)); return; }
+  double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); for (int i = 0; i < 3; i++) out[i] = a[i] + v * ab[i]; return; }
+  double cp[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+  double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { memcpy(out, c, 3 * sizeof(double)); return; }
+  double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { double w = d2 / (d2 - d6); for (int i = 0; i < 3; i++) out[i] = a[i] + w * ac[i]; return; }
+  double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); for (int i = 0; i < 3; i++) out[i] = b[i] + w * (c[i] - b[i]); return; }
+  double denom = 1.0 / (va + vb + vc), v = vb * denom, w = vc * denom;
+  for (int i = 0; i < 3; i++) out[i] = a[i] + ab[i] * v + ac[i] * w;
+}
 static double origin_tri_dist2(const double* a, const double* b, const double* c, double* witness) {
   const double o[3] = {0, 0, 0};
   closest_on_triangle(witness, o, a, b, c);
@@ -1028,7 +965,7 @@ static void collision(const om_model* m, om_data* d) {
     const double *s1 = m->geom_size + 3 * g1, *s2 = m->geom_size + 3 * g2;
     om_contact con[OM_MAXCONPAIR];
     int n = 0;
-    if (t1 == GEOM_HFIELD && m->hfield_model == 0) {
+    if (t1 == GEOM_HFIELD) {
       n = convex_hfield(m, d, con, OM_MAXCONPAIR, g1, g2, margin);  /* MuJoCo's scheme: every geom type goes through the prisms */
     } else if (t1 == GEOM_MESH || t2 == GEOM_MESH) {
       if (t1 == GEOM_PLANE) continue;  /* plane - mesh (mjc_PlaneConvex) is not restated: the compiler refuses such models */
@@ -1048,16 +985,6 @@ static void collision(const om_model* m, om_data* d) {
         int n2 = plane_sphere(con + n1, margin, pos1, normal, e2, s2[0]);
         n = n1 + n2;
         for (int k = 0; k < n; k++) memcpy(con[k].frame + 3, axis, sizeof axis);
-      }
-    } else if (t1 == GEOM_HFIELD) {
-      int hid = m->geom_dataid[g1];
-      if (t2 == GEOM_SPHERE) n = hfield_sphere(m, con, margin, hid, pos1, mat1, pos2, s2[0]);
-      else {
-        double axis[3] = {mat2[2], mat2[5], mat2[8]}, e1[3], e2[3];
-        for (int i = 0; i < 3; i++) { e1[i] = pos2[i] + axis[i] * s2[1]; e2[i] = pos2[i] - axis[i] * s2[1]; }
-        int n1 = hfield_sphere(m, con, margin, hid, pos1, mat1, e1, s2[0]);
-        int n2 = hfield_sphere(m, con + n1, margin, hid, pos1, mat1, e2, s2[0]);
-        n = n1 + n2;
       }
     } else {
       double dp[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
@@ -1761,7 +1688,7 @@ double* om_model_ptr(om_model* m, const char* name, int* len) {
 }
 int om_model_int(const om_model* m, const char* name) {
 #define MI(x) if (!strcmp(name, #x)) return m->x;
-  MI(nq) MI(nv) MI(nu) MI(nbody) MI(njnt) MI(ngeom) MI(ntendon) MI(nM) MI(nkey) MI(npair) MI(iterations) MI(disableflags) MI(solver) MI(nmesh) MI(nmeshvert) MI(hfield_model)
+  MI(nq) MI(nv) MI(nu) MI(nbody) MI(njnt) MI(ngeom) MI(ntendon) MI(nM) MI(nkey) MI(npair) MI(iterations) MI(disableflags) MI(solver) MI(nmesh) MI(nmeshvert)
   return -1;
 }
 void om_model_set_int(om_model* m, const char* name, int v) {
@@ -1769,7 +1696,6 @@ void om_model_set_int(om_model* m, const char* name, int v) {
   else if (!strcmp(name, "disableflags")) m->disableflags = v;
   else if (!strcmp(name, "solver")) m->solver = v;
   else if (!strcmp(name, "ls_iterations")) m->ls_iterations = v;
-  else if (!strcmp(name, "hfield_model")) m->hfield_model = v;
   else if (!strcmp(name, "mpr_iterations")) m->mpr_iterations = v;
 }
 void om_model_set_dbl(om_model* m, const char* name, double v) {

@@ -153,7 +153,7 @@ class Oracle:
 
     def set_opt(self, **kw):
         for k, v in kw.items():
-            if k in ("iterations", "disableflags", "solver", "ls_iterations", "hfield_model", "mpr_iterations"):
+            if k in ("iterations", "disableflags", "solver", "ls_iterations", "mpr_iterations"):
                 self.L.om_model_set_int(self.m, k.encode(), int(v))
             else:
                 self.L.om_model_set_dbl(self.m, k.encode(), float(v))

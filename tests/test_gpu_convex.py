@@ -195,3 +195,13 @@ def test_mesh_mesh_stack(hbmod, gpu, tmp_path):
     p = _save(hbmod, xml, tmp_path, "stack.hbm")
     states, ctrls = _oracle_states(p, envs=1, T=300, every=10)
     _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=10)
+
+
+def test_ball_and_capsules_on_a_sloped_field(hbmod, gpu, tmp_path):
+    """tests/models/ball_hfield.xml (a ball and capsules on a sloped field, default solver): the prism scheme for primitives."""
+    from test_gpu_parity import MODELS
+    m = hbmod.Model.load(os.path.join(MODELS, "ball_hfield.xml"))
+    p = str(tmp_path / "ball_hfield.hbm")
+    m.save(p)
+    states, ctrls = _oracle_states(p, envs=1, T=900, every=10)
+    _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=50, max_divergent=0.05)

@@ -428,9 +428,21 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (int i = 0; i < 3; i++) r[8 + i] = (float)m.actuator_biasprm[3 * a + i];
     r[12] = (float)m.actuator_forcerange[2 * a]; r[13] = (float)m.actuator_forcerange[2 * a + 1];
   }
-  std::vector<float> meshv((size_t)std::max(1, m.nmeshvert) * 4, 0.f);  // hull vertices as 16-byte records
-  for (int v = 0; v < m.nmeshvert; v++) for (int i = 0; i < 3; i++) meshv[(size_t)4 * v + i] = (float)m.mesh_vert[3 * v + i];
-  const size_t o_meshv = T.addraw(meshv);
+  // hull vertices as 16-byte records (x, y, z, link) and the edge graph with inlined coordinates (hb_device.hpp)
+  std::vector<float> meshv((size_t)std::max(1, m.nmeshvert) * 4, 0.f), meshn((size_t)std::max(1, m.nmeshnbr) * 4, 0.f);
+  for (int k = 0; k < m.nmesh; k++)
+    for (int v = 0; v < m.mesh_vertnum[k]; v++) {
+      const int g = m.mesh_vertadr[k] + v;
+      if (m.mesh_nbrnum[g] > 255 || m.mesh_nbradr[g] >= (1 << 23)) { err = "mesh edge graph too large for the packed link words"; return false; }
+      for (int i = 0; i < 3; i++) meshv[(size_t)4 * g + i] = (float)m.mesh_vert[3 * g + i];
+      meshv[(size_t)4 * g + 3] = fi((m.mesh_nbradr[g] << 8) | m.mesh_nbrnum[g]);
+      for (int i = 0; i < m.mesh_nbrnum[g]; i++) {
+        const int r = m.mesh_nbradr[g] + i, w = m.mesh_vertadr[k] + m.mesh_nbr[r];
+        for (int c = 0; c < 3; c++) meshn[(size_t)4 * r + c] = (float)m.mesh_vert[3 * w + c];
+        meshn[(size_t)4 * r + 3] = fi((m.mesh_nbradr[w] << 8) | m.mesh_nbrnum[w]);
+      }
+    }
+  const size_t o_meshv = T.addraw(meshv), o_meshn = T.addraw(meshn);
   const size_t o_arec = T.addraw(arec);
   size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec), o_crec = T.addraw(crec), o_trec = T.addraw(trec),
          o_lrec = T.addraw(lrec);
@@ -454,6 +466,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   D.obs_jnt_act = D.d_int + o_obs_jnt_act; D.obs_src_act = D.d_int + o_obs_src_act;
   dm.arec = reinterpret_cast<const float4*>(D.d_flt + o_arec);
   dm.mesh_vert = reinterpret_cast<const float4*>(D.d_flt + o_meshv);
+  dm.mesh_nbr = reinterpret_cast<const float4*>(D.d_flt + o_meshn);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);

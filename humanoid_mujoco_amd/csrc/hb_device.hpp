@@ -79,8 +79,11 @@ struct DevModel {
   // geoms
   const int HB_CONST *geom_type, *geom_bodyid;
   const float HB_CONST *geom_size, *geom_pos, *geom_quat, *geom_rbound;
-  // meshes: hull vertices as 16-byte records (x, y, z, -) and per geom the first record / the count (0 for other geom types)
+  // meshes: hull vertices as 16-byte records (x, y, z, link) and per geom the first record / the count (0 for other geom types);
+  // link = first neighbour record << 8 | number of neighbours; mesh_nbr: one record per (vertex, neighbour): (x, y, z of the
+  // neighbour, the neighbour's own link): the hull's edge graph with the coordinates inlined (hb_mpr.hpp: ccd_support)
   const float4 HB_CONST* mesh_vert;
+  const float4 HB_CONST* mesh_nbr;
   const int HB_CONST *geom_meshadr, *geom_meshnum;
   // height fields (static terrain on the world body): per geom the field id (-1 otherwise)
   const int HB_CONST *geom_dataid, *hfield_nrow, *hfield_ncol, *hfield_adr;

@@ -573,6 +573,14 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
   return x - v;
 }
 
+// a mesh geom's hull for the support function: its vertex 0 is where the climbs of a test start
+__device__ __forceinline__ void set_mesh(DevModelRef M, CObj& o, int g) {
+  o.vert = M.mesh_vert + M.geom_meshadr[g];
+  o.nbr = M.mesh_nbr;
+  o.cur = {0.f, 0.f, 0.f}; o.cur_link = 0;
+  if (M.geom_meshnum[g] > 0) { const float4 v0 = o.vert[0]; o.cur = {v0.x, v0.y, v0.z}; o.cur_link = __float_as_int(v0.w); }
+}
+
 // mj_collision for models with mesh geoms and / or a height field (the reference's own robot: simulation/assets/world.xml:14-58).
 // Three passes over LDS lists: (1) broadphase per candidate pair, survivors in pair order; (2) work items: one per pair, or one
 // per prism of the sub-grid under the geom for a height-field pair (mjc_ConvexHField's double loop, flattened); (3) narrowphase,
@@ -694,8 +702,8 @@ __device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata
 #pragma unroll
             for (int b = 0; b < 3; b++) o2.mat[3 * a + b] = hm[a] * m2[b] + hm[3 + a] * m2[3 + b] + hm[6 + a] * m2[6 + b];  // hm' m2
           o2.type = t2; o2.r = r2; o2.h = l2; o2.margin = margin;
-          o2.vert = M.mesh_vert + M.geom_meshadr[g2]; o2.nvert = M.geom_meshnum[g2];
-          o1.type = -1; o1.pos = {0.f, 0.f, 0.f}; o1.r = o1.h = o1.margin = 0.f; o1.vert = M.mesh_vert; o1.nvert = 0;
+          set_mesh(M, o2, g2);
+          o1.type = -1; o1.pos = {0.f, 0.f, 0.f}; o1.r = o1.h = o1.margin = 0.f; o1.vert = M.mesh_vert; o1.nbr = M.mesh_nbr; o1.cur = {0.f, 0.f, 0.f}; o1.cur_link = 0;
 #pragma unroll
           for (int a = 0; a < 9; a++) o1.mat[a] = 0.f;
           o1.p0 = {tv[0].x, tv[0].y, -sb}; o1.p1 = {tv[1].x, tv[1].y, -sb}; o1.p2 = {tv[2].x, tv[2].y, -sb};
@@ -706,8 +714,8 @@ __device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata
         // mjc_Convex: both geoms in the world frame, each inflated by half the margin
         q2mat(o1.mat, ldq(s_gquat + 4 * g1));
         q2mat(o2.mat, ldq(s_gquat + 4 * g2));
-        o1.type = t1; o1.pos = pos1; o1.r = c1.z; o1.h = c1.w; o1.margin = 0.5f * margin; o1.vert = M.mesh_vert + M.geom_meshadr[g1]; o1.nvert = M.geom_meshnum[g1];
-        o2.type = t2; o2.pos = pos2; o2.r = r2; o2.h = l2; o2.margin = 0.5f * margin; o2.vert = M.mesh_vert + M.geom_meshadr[g2]; o2.nvert = M.geom_meshnum[g2];
+        o1.type = t1; o1.pos = pos1; o1.r = c1.z; o1.h = c1.w; o1.margin = 0.5f * margin; set_mesh(M, o1, g1);
+        o2.type = t2; o2.pos = pos2; o2.r = r2; o2.h = l2; o2.margin = 0.5f * margin; set_mesh(M, o2, g2);
         o1.p0 = o1.p1 = o1.p2 = o1.p3 = o1.p4 = o1.p5 = V3{0.f, 0.f, 0.f};
         mpr_kind = 2;
       } else if (t1 == 0) {

@@ -27,7 +27,7 @@ typedef std::vector<int> veci;
 struct Model {
   // ---- sizes (mjmodel.h:560-620)
   int nq = 0, nv = 0, nu = 0, nbody = 0, njnt = 0, ngeom = 0, ntendon = 0, nwrap = 0, nM = 0,
-      nkey = 0, nexclude = 0, npair = 0, nhfield = 0, nhfielddata = 0, nmesh = 0, nmeshvert = 0;
+      nkey = 0, nexclude = 0, npair = 0, nhfield = 0, nhfielddata = 0, nmesh = 0, nmeshvert = 0, nmeshnbr = 0;
 
   // ---- options (mjOption, mjmodel.h:403-445) — only the fields this path honours
   double timestep = 0.002, impratio = 1.0, tolerance = 1e-8;
@@ -60,6 +60,9 @@ struct Model {
   // mesh geom's frame (MuJoCo collides mesh geoms through their hulls; mesh.cpp); geom_dataid = mesh id for mesh geoms
   veci mesh_vertadr, mesh_vertnum;
   vecd mesh_vert;
+  // the hull's edge graph (mjModel.mesh_graph plays this role): per hull vertex (global index) the run of its neighbours in mesh_nbr,
+  // neighbours as vertex indices local to the mesh, ascending: the support function climbs along it instead of sweeping every vertex
+  veci mesh_nbradr, mesh_nbrnum, mesh_nbr;
   // ---- fixed tendons (mjmodel.h:950-985): wrap_objid = joint id, wrap_prm = coef
   veci tendon_adr, tendon_num, tendon_limited, wrap_objid;
   vecd tendon_range, tendon_margin, tendon_solref_lim, tendon_solimp_lim, tendon_invweight0,
@@ -84,7 +87,7 @@ struct Model {
   template <class F> void visit(F& f) {
 #define HB_F(x) f(#x, x)
     HB_F(nq); HB_F(nv); HB_F(nu); HB_F(nbody); HB_F(njnt); HB_F(ngeom); HB_F(ntendon); HB_F(nwrap);
-    HB_F(nM); HB_F(nkey); HB_F(nexclude); HB_F(npair); HB_F(nhfield); HB_F(nhfielddata); HB_F(nmesh); HB_F(nmeshvert);
+    HB_F(nM); HB_F(nkey); HB_F(nexclude); HB_F(npair); HB_F(nhfield); HB_F(nhfielddata); HB_F(nmesh); HB_F(nmeshvert); HB_F(nmeshnbr);
     HB_F(timestep); HB_F(impratio); HB_F(tolerance);
     f("gravity", gravity, 3);
     HB_F(integrator); HB_F(cone); HB_F(solver); HB_F(iterations); HB_F(disableflags);
@@ -103,7 +106,7 @@ struct Model {
     HB_F(geom_size); HB_F(geom_pos); HB_F(geom_quat); HB_F(geom_rbound); HB_F(geom_friction);
     HB_F(geom_solmix); HB_F(geom_solref); HB_F(geom_solimp); HB_F(geom_margin); HB_F(geom_gap);
     HB_F(hfield_nrow); HB_F(hfield_ncol); HB_F(hfield_adr); HB_F(hfield_size); HB_F(hfield_data);
-    HB_F(mesh_vertadr); HB_F(mesh_vertnum); HB_F(mesh_vert);
+    HB_F(mesh_vertadr); HB_F(mesh_vertnum); HB_F(mesh_vert); HB_F(mesh_nbradr); HB_F(mesh_nbrnum); HB_F(mesh_nbr);
     HB_F(tendon_adr); HB_F(tendon_num); HB_F(tendon_limited); HB_F(wrap_objid);
     HB_F(tendon_range); HB_F(tendon_margin); HB_F(tendon_solref_lim); HB_F(tendon_solimp_lim);
     HB_F(tendon_invweight0); HB_F(tendon_length0); HB_F(wrap_prm);
@@ -123,7 +126,7 @@ bool compile_mjcf_file(const std::string& path, Model& m, std::string& err);
 bool compile_mjcf_string(const std::string& xml, Model& m, std::string& err);
 // mesh.cpp — STL reader and convex hull (the vertices MuJoCo's mesh collision uses)
 bool read_stl_vertices(const std::string& path, std::vector<double>& pts, std::string& err);
-bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull, std::string& err);
+bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull, std::string& err, std::vector<int>* tris = nullptr);
 // setconst.cpp — mj_setConst products (mujoco.h:221) computed in fp64 on the host
 bool set_const(Model& m, std::string& err);
 // model_io.cpp — ".hbm" text serialisation (replaces mj_saveModel/mj_loadModel, mujoco.h:159-163)

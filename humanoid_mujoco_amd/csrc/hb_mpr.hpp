@@ -3,7 +3,7 @@
 // mjc_ConvexHField; mujoco.h:355 mj_collision).  Mirrors oracle/mjstep_oracle.c (mpr_penetration, ccd_support, fix_normal)
 // statement for statement so that the discrete decisions of the portal search agree wherever fp32 allows.
 // One LANE runs one (pair, prism) test: the loops below are per lane and divergent; a mesh's support function is an
-// exhaustive sweep over its hull vertices (16-byte records in the model tables, served by L1 / L2).
+// climb along the hull's edge graph (16-byte records in the model tables, served by L1 / L2).
 // Included by hb_kernels.hip only (uses its V3 / Q4 helpers).
 #pragma once
 
@@ -64,8 +64,13 @@ struct CObj {
   V3 pos;
   float mat[9];  // row-major rotation of the geom frame
   float r, h;    // size[0], size[1]
-  const float4 HB_CONST* vert;  // mesh: hull vertices in the geom frame
-  int nvert;
+  // mesh: the hull as an edge graph.  vert[0] = (x, y, z, link) of the hull's vertex 0, nbr = the neighbour records of the whole
+  // model: link = first record << 8 | count, record = (x, y, z of the neighbour, the neighbour's own link).  The support function
+  // climbs from the vertex its previous call of this test ended on (cur, cur_link): one batch of loads per move.
+  const float4 HB_CONST* vert;
+  const float4 HB_CONST* nbr;
+  V3 cur;
+  int cur_link;
   float margin;
   V3 p0, p1, p2, p3, p4, p5;  // prism: bottom triangle 0..2, top triangle 3..5
 };
@@ -75,7 +80,7 @@ __device__ __forceinline__ V3d ccd_center(const CObj& o) {
   return widen(o.pos);
 }
 // the point farthest along dir (unit)
-__device__ __forceinline__ V3d ccd_support(const CObj& o, V3d dir) {
+__device__ __forceinline__ V3d ccd_support(CObj& o, V3d dir) {
   if (o.type < 0) {
     V3d best = widen(o.p0), c;
     double bd = dot(best, dir), v;
@@ -92,20 +97,35 @@ __device__ __forceinline__ V3d ccd_support(const CObj& o, V3d dir) {
   if (o.type == 2) res = ld * (double)o.r;
   else if (o.type == 3) { res = ld * (double)o.r; res.z += ld.z >= 0.0 ? (double)o.h : -(double)o.h; }
   else {
-    double bd = -1.0e300;
-    res = {0.0, 0.0, 0.0};
-    for (int i = 0; i < o.nvert; i++) {
-      const float4 q = o.vert[i];
-      const double v = (double)q.x * ld.x + (double)q.y * ld.y + (double)q.z * ld.z;
-      if (v > bd) { bd = v; res = {(double)q.x, (double)q.y, (double)q.z}; }
+    // steepest ascent along the hull's edges (oracle: ccd_support): every neighbour is evaluated, the best one taken if it is
+    // strictly better (ties to the first in the list); on a convex polytope a vertex with no better neighbour is a maximiser
+    // (exact ties - a direction perpendicular to a flat facet - are broken by a second, generic direction: see the oracle)
+    const double t0 = 0.41421356237309503, t1 = 0.7320508075688772;
+    V3 best = o.cur;
+    int link = o.cur_link;
+    double bd = (double)best.x * ld.x + (double)best.y * ld.y + (double)best.z * ld.z, bt = (double)best.x * t0 + (double)best.y * t1 + (double)best.z;
+    for (;;) {
+      const int adr = link >> 8, num = link & 255;
+      bool moved = false;
+      V3 nb = best;
+      int nlink = link;
+      for (int i = 0; i < num; i++) {
+        const float4 q = o.nbr[adr + i];
+        const double v = (double)q.x * ld.x + (double)q.y * ld.y + (double)q.z * ld.z, t = (double)q.x * t0 + (double)q.y * t1 + (double)q.z;
+        if (v > bd || (v == bd && t > bt)) { bd = v; bt = t; nb = {q.x, q.y, q.z}; nlink = __float_as_int(q.w); moved = true; }
+      }
+      if (!moved) break;
+      best = nb; link = nlink;
     }
+    o.cur = best; o.cur_link = link;
+    res = widen(best);
   }
   res = res + ld * (double)o.margin;
   return V3d{m0 * res.x + m1 * res.y + m2 * res.z, m3 * res.x + m4 * res.y + m5 * res.z, m6 * res.x + m7 * res.y + m8 * res.z} + widen(o.pos);
 }
 
 struct CSup { V3d v, v1; };  // a point of the Minkowski difference obj1 - obj2 and its witness on obj1 (the one on obj2 is v1 - v)
-__device__ __forceinline__ CSup mpr_support(const CObj& o1, const CObj& o2, V3d dir) {
+__device__ __forceinline__ CSup mpr_support(CObj& o1, CObj& o2, V3d dir) {
   CSup s;
   s.v1 = ccd_support(o1, dir);
   const V3d w2 = ccd_support(o2, dir * -1.0);
@@ -125,7 +145,7 @@ __device__ __forceinline__ void mpr_expand_portal(const CSup& P0, CSup& P1, CSup
 }
 
 // ccdMPRPenetration: true (and depth, dir from obj1 into obj2, pos) when the objects intersect
-__device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, int max_iterations, double tolerance, float& depth_out, V3& pdir_out, V3& pos_out) {
+__device__ __forceinline__ bool mpr_penetration(CObj& o1, CObj& o2, int max_iterations, double tolerance, float& depth_out, V3& pdir_out, V3& pos_out) {
   CSup P0, P1, P2, P3, v4;
   const V3d origin = {0.0, 0.0, 0.0};
   double depth;

@@ -45,9 +45,9 @@ bool make_face(const std::vector<P3>& p, int a, int b, int c, Face& f) {
 
 }  // namespace
 
-// Convex hull of `pts` (3 doubles per point): indices of the hull's vertices, ascending.  false: degenerate input
-// (fewer than four points that are not coplanar).
-bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull, std::string& err) {
+// Convex hull of `pts` (3 doubles per point): indices of the hull's vertices, ascending, and (optionally) the hull's triangles as
+// triples of positions in `hull`.  false: degenerate input (fewer than four points that are not coplanar).
+bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull, std::string& err, std::vector<int>* tris) {
   const int n = (int)pts.size() / 3;
   std::vector<P3> p(n);
   P3 lo = {1e300, 1e300, 1e300}, hi = {-1e300, -1e300, -1e300};
@@ -129,6 +129,12 @@ bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull
   hull.clear();
   for (int i = 0; i < n; i++) if (used[i]) hull.push_back(i);
   if (hull.size() < 4) { err = "mesh: convex hull collapsed"; return false; }
+  if (tris) {
+    std::vector<int> local(n, -1);
+    for (size_t k = 0; k < hull.size(); k++) local[hull[k]] = (int)k;
+    tris->clear();
+    for (auto& f : faces) if (f.alive) for (int k = 0; k < 3; k++) tris->push_back(local[f.v[k]]);
+  }
   return true;
 }
 

@@ -590,8 +590,8 @@ bool read_mesh(Ctx& c, const XmlNode& n) {
   double sc[3] = {1, 1, 1};
   if (a.vec("scale", sc, 3, 3) < 0) return false;
   for (size_t i = 0; i < pts.size(); i++) pts[i] *= sc[i % 3];
-  std::vector<int> hull;
-  if (!convex_hull_vertices(pts, hull, c.err)) { c.err += " in " + a.where; return false; }
+  std::vector<int> hull, tris;
+  if (!convex_hull_vertices(pts, hull, c.err, &tris)) { c.err += " in " + a.where; return false; }
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int v : hull) for (int i = 0; i < 3; i++) { lo[i] = std::min(lo[i], pts[3 * v + i]); hi[i] = std::max(hi[i], pts[3 * v + i]); }
   double cen[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])}, rb = 0;
@@ -603,6 +603,17 @@ bool read_mesh(Ctx& c, const XmlNode& n) {
     double q[3] = {pts[3 * v] - cen[0], pts[3 * v + 1] - cen[1], pts[3 * v + 2] - cen[2]};
     rb = std::max(rb, hm::norm3(q));
     push3(m.mesh_vert, q);
+  }
+  {  // edge graph of the hull: neighbours of every vertex, ascending
+    std::vector<std::set<int>> nb(hull.size());
+    for (size_t t = 0; t + 2 < tris.size(); t += 3)
+      for (int k = 0; k < 3; k++) { const int u = tris[t + k], w = tris[t + (k + 1) % 3]; nb[u].insert(w); nb[w].insert(u); }
+    for (auto& sset : nb) {
+      m.mesh_nbradr.push_back(m.nmeshnbr);
+      m.mesh_nbrnum.push_back((int)sset.size());
+      for (int w : sset) m.mesh_nbr.push_back(w);
+      m.nmeshnbr += (int)sset.size();
+    }
   }
   push3(c.mesh_center, cen);
   c.mesh_rbound.push_back(rb);

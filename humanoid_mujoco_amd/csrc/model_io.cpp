@@ -139,7 +139,7 @@ bool validate_model(const Model& m, std::string& err) {
   auto bad = [&](const std::string& what) { err = "model: " + what; return false; };
   if (m.nbody < 1 || m.nbody > 64) return bad("nbody must be 1..64");
   if (m.nq < 0 || m.nv < 0 || m.nu < 0 || m.njnt < 0 || m.ngeom < 0 || m.ntendon < 0 || m.nwrap < 0 || m.nkey < 0 || m.nexclude < 0 || m.npair < 0 ||
-      m.nhfield < 0 || m.nhfielddata < 0 || m.nM < 0 || m.nmesh < 0 || m.nmeshvert < 0)
+      m.nhfield < 0 || m.nhfielddata < 0 || m.nM < 0 || m.nmesh < 0 || m.nmeshvert < 0 || m.nmeshnbr < 0)
     return bad("negative size");
   if (m.nq > 4096 || m.nv > 4096 || m.nu > 4096 || m.njnt > 4096 || m.ngeom > 4096 || m.nwrap > 65536 || m.npair > (1 << 20)) return bad("size out of range");
   struct { const char* name; size_t have, want; } lens[] = {
@@ -159,6 +159,7 @@ bool validate_model(const Model& m, std::string& err) {
       HB_LEN(geom_margin, m.ngeom), HB_LEN(geom_gap, m.ngeom),
       HB_LEN(hfield_nrow, m.nhfield), HB_LEN(hfield_ncol, m.nhfield), HB_LEN(hfield_adr, m.nhfield), HB_LEN(hfield_size, 4 * m.nhfield), HB_LEN(hfield_data, m.nhfielddata),
       HB_LEN(mesh_vertadr, m.nmesh), HB_LEN(mesh_vertnum, m.nmesh), HB_LEN(mesh_vert, 3 * m.nmeshvert), HB_LEN(mesh_name, m.nmesh),
+      HB_LEN(mesh_nbradr, m.nmeshvert), HB_LEN(mesh_nbrnum, m.nmeshvert), HB_LEN(mesh_nbr, m.nmeshnbr),
       HB_LEN(tendon_adr, m.ntendon), HB_LEN(tendon_num, m.ntendon), HB_LEN(tendon_limited, m.ntendon), HB_LEN(wrap_objid, m.nwrap), HB_LEN(tendon_range, 2 * m.ntendon),
       HB_LEN(tendon_margin, m.ntendon), HB_LEN(tendon_solref_lim, 2 * m.ntendon), HB_LEN(tendon_solimp_lim, 5 * m.ntendon), HB_LEN(tendon_invweight0, m.ntendon),
       HB_LEN(tendon_length0, m.ntendon), HB_LEN(wrap_prm, m.nwrap),
@@ -213,6 +214,12 @@ bool validate_model(const Model& m, std::string& err) {
   }
   for (int p = 0; p < m.npair; p++)
     if (!in(m.pair_geom1[p], 0, m.ngeom) || !in(m.pair_geom2[p], 0, m.ngeom)) return bad("pair geom out of range");
+  for (int k = 0; k < m.nmesh; k++)
+    for (int v = 0; v < m.mesh_vertnum[k] && m.mesh_vertadr[k] >= 0 && m.mesh_vertadr[k] + m.mesh_vertnum[k] <= m.nmeshvert; v++) {
+      const int g = m.mesh_vertadr[k] + v;
+      if (m.mesh_nbrnum[g] < 3 || m.mesh_nbradr[g] < 0 || m.mesh_nbradr[g] + m.mesh_nbrnum[g] > m.nmeshnbr) return bad("mesh edge graph out of bounds");
+      for (int i = 0; i < m.mesh_nbrnum[g]; i++) if (!in(m.mesh_nbr[m.mesh_nbradr[g] + i], 0, m.mesh_vertnum[k])) return bad("mesh edge graph: neighbour out of range");
+    }
   for (int k = 0; k < m.nmesh; k++)
     if (m.mesh_vertnum[k] < 4 || m.mesh_vertadr[k] < 0 || m.mesh_vertadr[k] + m.mesh_vertnum[k] > m.nmeshvert) return bad("mesh vertex range out of bounds");
   for (int p = 0; p < m.npair; p++) {

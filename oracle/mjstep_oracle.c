@@ -50,7 +50,7 @@ enum { WARN_CONTACTFULL = 1, WARN_CNSTRFULL = 2, WARN_BADQPOS = 4, WARN_BADQVEL 
 #define OM_MAXEFC 640
 
 typedef struct {
-  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nwrap, nM, nkey, npair, nhfield, nhfielddata, nmesh, nmeshvert;
+  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nwrap, nM, nkey, npair, nhfield, nhfielddata, nmesh, nmeshvert, nmeshnbr;
   int mpr_iterations;   /* mjOption.mpr_iterations, mjmodel.h:437 (default 50) */
   double mpr_tolerance; /* mjOption.mpr_tolerance, mjmodel.h:413 (default 1e-6) */
   double timestep, impratio, tolerance, meaninertia, gravity[3];
@@ -69,6 +69,7 @@ typedef struct {
   double *hfield_size, *hfield_data;
   int *mesh_vertadr, *mesh_vertnum; /* convex-hull vertices of each mesh in the geom frame (what mesh collision uses) */
   double* mesh_vert;
+  int *mesh_nbradr, *mesh_nbrnum, *mesh_nbr; /* the hull's edge graph: per hull vertex its neighbours (indices local to the mesh) */
   int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
   double *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0, *tendon_length0, *wrap_prm;
   int *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited;
@@ -166,7 +167,7 @@ om_model* om_load(const char* path, char* err, int errsz) {
 #define RD(x) m->x = rec_dbl(recs, nr, #x, 0)
 #define AI(x, n) m->x = rec_iarr(recs, nr, #x, n)
 #define AD(x, n) m->x = rec_darr(recs, nr, #x, n)
-  RI(nq); RI(nv); RI(nu); RI(nbody); RI(njnt); RI(ngeom); RI(ntendon); RI(nwrap); RI(nM); RI(nkey); RI(npair); RI(nhfield); RI(nhfielddata); RI(nmesh); RI(nmeshvert);
+  RI(nq); RI(nv); RI(nu); RI(nbody); RI(njnt); RI(ngeom); RI(ntendon); RI(nwrap); RI(nM); RI(nkey); RI(npair); RI(nhfield); RI(nhfielddata); RI(nmesh); RI(nmeshvert); RI(nmeshnbr);
   m->mpr_iterations = 50; m->mpr_tolerance = 1e-6;
   RD(timestep); RD(impratio); RD(tolerance); RD(meaninertia);
   RI(integrator); RI(cone); RI(solver); RI(iterations); RI(disableflags);
@@ -185,6 +186,7 @@ om_model* om_load(const char* path, char* err, int errsz) {
   AD(geom_solref, 2 * ng); AD(geom_solimp, 5 * ng); AD(geom_margin, ng); AD(geom_gap, ng);
   AI(hfield_nrow, m->nhfield); AI(hfield_ncol, m->nhfield); AI(hfield_adr, m->nhfield); AD(hfield_size, 4 * m->nhfield); AD(hfield_data, m->nhfielddata);
   AI(mesh_vertadr, m->nmesh); AI(mesh_vertnum, m->nmesh); AD(mesh_vert, 3 * m->nmeshvert);
+  AI(mesh_nbradr, m->nmeshvert); AI(mesh_nbrnum, m->nmeshvert); AI(mesh_nbr, m->nmeshnbr);
   AI(tendon_adr, nt); AI(tendon_num, nt); AI(tendon_limited, nt); AI(wrap_objid, m->nwrap);
   AD(tendon_range, 2 * nt); AD(tendon_margin, nt); AD(tendon_solref_lim, 2 * nt); AD(tendon_solimp_lim, 5 * nt); AD(tendon_invweight0, nt);
   AD(tendon_length0, nt); AD(wrap_prm, m->nwrap);
@@ -618,6 +620,8 @@ typedef struct {
   double size[3];
   const double* vert;       /* mesh: hull vertices in the geom frame */
   int nvert;
+  const int *nbradr, *nbrnum, *nbr; /* mesh: the hull's edge graph (NULL: exhaustive search) */
+  int cur;                  /* mesh: vertex the last support call ended on (the next climb starts there; 0 at the start of a test) */
   double margin;            /* mjccd_support inflates the shape by this much along the direction */
   double prism[6][3];       /* prism: bottom triangle 0..2, top triangle 3..5 */
 } ccd_obj;
@@ -631,7 +635,7 @@ static void ccd_center(const ccd_obj* o, double* c) {
   } else memcpy(c, o->pos, 3 * sizeof(double));
 }
 /* mjccd_support / prism_support: the point of the object farthest along dir (dir is unit: every caller in mpr.c normalises) */
-static void ccd_support(const ccd_obj* o, const double* dir, double* out) {
+static void ccd_support(ccd_obj* o, const double* dir, double* out) {
   if (o->type < 0) {
     int best = 0;
     double bd = -1e300;
@@ -645,7 +649,29 @@ static void ccd_support(const ccd_obj* o, const double* dir, double* out) {
   else if (o->type == GEOM_CAPSULE) {
     for (int i = 0; i < 3; i++) res[i] = ld[i] * o->size[0];
     res[2] += ld[2] >= 0 ? o->size[1] : -o->size[1];
-  } else { /* mesh: exhaustive search over the hull vertices (MuJoCo hill-climbs on large meshes: the same maximiser) */
+  } else if (o->nbr) {
+    /* mesh: steepest ascent along the hull's edges from the vertex the previous call of this test ended on (MuJoCo hill-climbs
+     * on its mesh graph too; on a convex polytope a vertex with no better neighbour is a maximiser).  Every neighbour is
+     * evaluated, the best one taken if it is strictly better, ties to the first in the list. */
+    /* Exact ties (a direction perpendicular to a flat facet, e.g. an axis direction on a CAD part) are broken by a second, generic
+     * direction, as if the direction were ld + epsilon tie: without it a climb that starts on the facet opposite the maximum sees
+     * only equal neighbours and stalls there. */
+    static const double tie[3] = {0.41421356237309503, 0.7320508075688772, 1.0};
+    int cur = o->cur;
+    double bd = dot3(o->vert + 3 * cur, ld), bt = dot3(o->vert + 3 * cur, tie);
+    for (;;) {
+      int best = cur;
+      const int* nb = o->nbr + o->nbradr[cur];
+      for (int i = 0; i < o->nbrnum[cur]; i++) {
+        double v = dot3(o->vert + 3 * nb[i], ld), t = dot3(o->vert + 3 * nb[i], tie);
+        if (v > bd || (v == bd && t > bt)) { bd = v; bt = t; best = nb[i]; }
+      }
+      if (best == cur) break;
+      cur = best;
+    }
+    o->cur = cur;
+    memcpy(res, o->vert + 3 * cur, sizeof res);
+  } else { /* mesh without a graph (test hook): exhaustive search over the hull vertices, the same maximiser */
     int best = 0;
     double bd = -1e300;
     for (int i = 0; i < o->nvert; i++) { double v = dot3(o->vert + 3 * i, ld); if (v > bd) { bd = v; best = i; } }
@@ -656,7 +682,7 @@ static void ccd_support(const ccd_obj* o, const double* dir, double* out) {
 }
 
 typedef struct { double v[3], v1[3], v2[3]; } ccd_sup;  /* a point of the Minkowski difference obj1 - obj2 and its two witnesses */
-static void mpr_support(const ccd_obj* o1, const ccd_obj* o2, const double* dir, ccd_sup* s) {
+static void mpr_support(ccd_obj* o1, ccd_obj* o2, const double* dir, ccd_sup* s) {
   double nd[3] = {-dir[0], -dir[1], -dir[2]};
   ccd_support(o1, dir, s->v1);
   ccd_support(o2, nd, s->v2);
@@ -709,7 +735,7 @@ static double origin_tri_dist2(const double* a, const double* b, const double* c
 }
 
 /* ccdMPRPenetration: 0 and (depth, dir, pos) when the objects intersect, -1 otherwise.  dir points from obj1 into obj2. */
-static int mpr_penetration(const ccd_obj* o1, const ccd_obj* o2, int max_iterations, double tolerance, double* depth, double* pdir, double* pos) {
+static int mpr_penetration(ccd_obj* o1, ccd_obj* o2, int max_iterations, double tolerance, double* depth, double* pdir, double* pos) {
   ccd_sup P[4];
   double dir[3], va[3], vb[3];
   const double origin[3] = {0, 0, 0};
@@ -813,8 +839,12 @@ static void ccd_obj_from_geom(const om_model* m, const om_data* d, int g, double
   memcpy(o->pos, d->geom_xpos + 3 * g, sizeof o->pos);
   memcpy(o->mat, d->geom_xmat + 9 * g, sizeof o->mat);
   memcpy(o->size, m->geom_size + 3 * g, sizeof o->size);
-  o->vert = NULL; o->nvert = 0; o->margin = margin;
-  if (o->type == GEOM_MESH) { int k = m->geom_dataid[g]; o->vert = m->mesh_vert + 3 * m->mesh_vertadr[k]; o->nvert = m->mesh_vertnum[k]; }
+  o->vert = NULL; o->nvert = 0; o->margin = margin; o->nbr = NULL; o->nbradr = o->nbrnum = NULL; o->cur = 0;
+  if (o->type == GEOM_MESH) {
+    int k = m->geom_dataid[g];
+    o->vert = m->mesh_vert + 3 * m->mesh_vertadr[k]; o->nvert = m->mesh_vertnum[k];
+    if (m->nmeshnbr > 0) { o->nbradr = m->mesh_nbradr + m->mesh_vertadr[k]; o->nbrnum = m->mesh_nbrnum + m->mesh_vertadr[k]; o->nbr = m->mesh_nbr; }
+  }
 }
 
 /* mjc_fixNormal [recall]: a sphere or capsule knows its own surface normal at the contact point; a mesh or prism does not.
@@ -891,8 +921,8 @@ static int convex_hfield(const om_model* m, const om_data* d, om_contact* con, i
   o2.margin = margin;  /* (the prism tops are raised by the margin as well: mjc_ConvexHField [recall]) */
   double dx = 2.0 * size1[0] / (ncol - 1), dy = 2.0 * size1[1] / (nrow - 1);
   const int dr[2] = {1, 0};  /* triangulation direction: the strip visits (r+1, c) before (r, c) [recall] */
+  memset(&prism, 0, sizeof prism);
   prism.type = -1;
-  memset(prism.prism, 0, sizeof prism.prism);
   prism.prism[0][2] = prism.prism[1][2] = prism.prism[2][2] = -size1[3];
   int cnt = 0;
   for (int r = rmin; r < rmax && cnt < maxcon; r++) {
@@ -907,6 +937,7 @@ static int convex_hfield(const om_model* m, const om_data* d, om_contact* con, i
         if (++nvert <= 2) continue;
         if (prism.prism[3][2] < lo[2] && prism.prism[4][2] < lo[2] && prism.prism[5][2] < lo[2]) continue;  /* prism below the geom */
         double depth, dir[3], vec[3];
+        o2.cur = 0;
         if (mpr_penetration(&prism, &o2, m->mpr_iterations, m->mpr_tolerance, &depth, dir, vec) == 0 && !ccd_is_zero(depth)) {
           om_contact* cc = con + cnt;
           cc->dist = -depth;

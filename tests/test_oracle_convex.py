@@ -87,6 +87,53 @@ def test_convex_hull_matches_scipy_and_brute_force_support(hbmod):
     assert len(hv) == 8 and np.allclose(np.sort(hv, axis=0), np.sort(CUBE, axis=0))
 
 
+def _climb(verts, adr, num, nbr, d, start=0):
+    """the support function's steepest ascent along the hull's edge graph (oracle ccd_support / device hb_mpr.hpp)"""
+    tie = np.array([0.41421356237309503, 0.7320508075688772, 1.0])  # exact ties go to a second, generic direction
+    cur, bd, bt = start, verts[start] @ d, verts[start] @ tie
+    while True:
+        best = cur
+        for w in nbr[adr[cur]:adr[cur] + num[cur]]:
+            v, t = verts[w] @ d, verts[w] @ tie
+            if v > bd or (v == bd and t > bt):
+                bd, bt, best = v, t, w
+        if best == cur:
+            return cur
+        cur = best
+
+
+def test_hull_edge_graph_climb_finds_the_support_vertex(hbmod):
+    """Climbing along the compiled edge graph from ANY vertex ends on a maximiser of the direction: the hill-climbing support
+    function returns what the exhaustive sweep returns (the support VALUE; on a flat facet several vertices tie)."""
+    rng = np.random.default_rng(7)
+    models = []
+    for n in (8, 60, 400):
+        pts = rng.normal(size=(n, 3)) * rng.uniform(0.05, 1.0, 3)
+        xml = ('<mujoco><asset><mesh name="m" vertex="%s"/></asset><worldbody><body><freejoint/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/>'
+               '<geom type="mesh" mesh="m"/></body></worldbody></mujoco>' % " ".join("%.17g" % v for v in pts.reshape(-1)))
+        models.append(hbmod.Model.from_xml_string(xml))
+    if os.path.exists(TEAM_XML):
+        models.append(hbmod.Model.load(TEAM_XML))
+    for m in models:
+        vadr, vnum = m.array("mesh_vertadr").astype(int), m.array("mesh_vertnum").astype(int)
+        verts = m.array("mesh_vert").reshape(-1, 3)
+        nadr, nnum, nbr = m.array("mesh_nbradr").astype(int), m.array("mesh_nbrnum").astype(int), m.array("mesh_nbr").astype(int)
+        for k in range(len(vadr)):
+            V = verts[vadr[k]:vadr[k] + vnum[k]]
+            a, c = nadr[vadr[k]:vadr[k] + vnum[k]], nnum[vadr[k]:vadr[k] + vnum[k]]
+            assert (c >= 3).all() and nbr.max() < max(vnum)
+            # symmetric graph
+            edges = {(u, w) for u in range(len(V)) for w in nbr[a[u]:a[u] + c[u]]}
+            assert all((w, u) in edges for (u, w) in edges)
+            for _ in range(40):
+                d = rng.normal(size=3)
+                got = _climb(V, a, c, nbr, d, start=int(rng.integers(len(V))))
+                assert abs(V[got] @ d - (V @ d).max()) <= 1e-12 * max(1.0, np.abs(V).max())
+            for d in np.vstack([np.eye(3), -np.eye(3)]):  # axis directions: flat facets and ties
+                got = _climb(V, a, c, nbr, d)
+                assert abs(V[got] @ d - (V @ d).max()) <= 1e-9
+
+
 def test_degenerate_meshes_are_errors(hbmod):
     for pts in ([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0.3, 0.2, 0]], [[0, 0, 0], [1, 1, 1], [2, 2, 2], [3, 3, 3]]):
         xml = '<mujoco><asset><mesh name="m" vertex="%s"/></asset><worldbody/></mujoco>' % " ".join(str(v) for p in pts for v in p)

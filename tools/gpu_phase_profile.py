@@ -11,9 +11,10 @@ import humanoid_mujoco_amd as hb
 L = eng.lib()
 L.hb_get_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-m = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm"))
+MODEL = sys.argv[2] if len(sys.argv) > 2 else "humanoid27.hbm"  # e.g. team_robot.hbm, humanoid27_hfield.hbm
+m = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", MODEL))
 b = hb.Batch(m, N, 0)
-b.reset(perturb=True)
+b.reset(perturb=True, keyframe=0 if MODEL.startswith("team") else -1)  # the robot: the standup reset (lying)
 b.rollout_halton(400)
 st = np.zeros((N, 16), dtype=np.uint64)
 assert L.hb_get_stamps(b._h, st.ctypes.data_as(ctypes.c_void_p)) == 0  # arm
@@ -23,6 +24,7 @@ d = np.diff(st.astype(np.int64), axis=1).astype(np.float64)
 names = ["ctrl+check", "kinematics", "geoms/com/cinert/cdof", "comVel+crb+rne tree passes", "qM", "factorM", "bias/passive/act", "collision", "makeConstraint",
          "row quantities", "half-solve", "b + AR", "PGS", "dual finish", "Euler+advance"]
 tot = d.sum(1)
+print("model %s" % MODEL)
 print("envs %d; mean cycles per env-step (one wave) %.0f, median %.0f" % (N, tot.mean(), np.median(tot)))
 nc, ne, ni = b.counts()
 print("mean nefc %.1f niter %.1f; mean row updates per step (nefc x sweeps) %.0f" % (ne.mean(), ni.mean(), (ne * ni).mean()))

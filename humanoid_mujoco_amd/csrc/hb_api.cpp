@@ -169,12 +169,12 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.cstride = dm.variant == 2 ? (nv <= 20 ? 21 : 29) : 33;
   dm.o_gquat = dm.variant ? take(4 * m.ngeom) : 0;
   dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
-  dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(8 * nv);  /* angular[3], -, linear[3], - per dof */
+  dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(12 * nv);  /* angular[3], -, linear[3], -, pad[4] per dof (kCdofStride: conflict-free b128 reads) */
   dm.o_qLD = take(2 * m.nM + 4); dm.o_smooth = take(nv);  // qLD: {M, H} pairs + the zero and one pad pairs of the dense views
   dm.o_vec0 = take(32); dm.o_vec1 = take(32); dm.o_vec2 = take(32);  /* read 32 wide */ dm.o_tenlen = take(std::max(1, m.ntendon));
   int region = off;
-  dm.o_xpos = take(8 * nb);  /* xpos[3], -, xquat[4] records */ dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
-  dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(16 * nb);  // crb: inertia[10] | cfrc[6] records
+  dm.o_xpos = take(12 * nb);  /* xpos[3], -, xquat[4], pad[4] records (kXpqStride) */ dm.o_xmat = take(9 * nb); dm.o_xipos = take(3 * nb);
+  dm.o_xanchor = take(3 * m.njnt); dm.o_xaxis = take(3 * m.njnt); dm.o_cinert = take(10 * nb); dm.o_crb = take(20 * nb);  // crb: inertia[10] | cfrc[6] | pad[4] records (kIfStride)
   dm.o_cvel = take(12 * nb);  // cvel[6] | cacc[6] records
   int endA = off;
   off = region;

@@ -293,10 +293,16 @@ __device__ __forceinline__ void kb_from_solref(float solref0, float solref1, flo
   } else { K = -solref0 / fmaxf(HB_MINVAL, dmax * dmax); B = -solref1 / fmaxf(HB_MINVAL, dmax); }
 }
 
+// LDS record strides (floats).  Records read as ds_read_b128 by lanes that index different bodies / dofs are 16-byte aligned AND an odd
+// multiple of 16 bytes apart: with the natural power-of-two strides (8, 16 floats) lanes b and b + 8 (b + 4) hit the same banks
+// (measured: 14 % of LDS-active cycles were bank conflicts, profiles/r02_counters.json)
+constexpr int kCdofStride = 12;  // per dof: angular[3], -, linear[3], -, (pad 4)
+constexpr int kXpqStride = 12;   // per body: xpos[3], -, xquat[4], (pad 4)
+constexpr int kIfStride = 20;    // per body: composite inertia[10] | cfrc[6], (pad 4)
 constexpr int kWs = 36;  // 16-byte aligned rows: a row times a vector is eight ds_read_b128 pairs (dot32)
 // one dof's motion axis record: s_cdof[8 d ..] = angular[3], -, linear[3], - (two ds_read_b128)
 __device__ __forceinline__ void ld_cdof(const float* s_cdof, int d, float out[6]) {
-  const float4* p = reinterpret_cast<const float4*>(s_cdof + 8 * d);
+  const float4* p = reinterpret_cast<const float4*>(s_cdof + kCdofStride * d);
   const float4 a = p[0], l = p[1];
   out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = l.x; out[4] = l.y; out[5] = l.z;
 }
@@ -996,21 +1002,21 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     V3 mypos = posl;
     Q4 myquat = quatl;
     if (bl) {
-      reinterpret_cast<float4*>(s_xpq + 8 * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
-      reinterpret_cast<float4*>(s_xpq + 8 * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
+      reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
+      reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
     }
     gsync();
     for (int r = 0, span = 1; span < M.nlevel - 1 || r == 0; r++, span <<= 1) {
       const int anc = r == 0 ? myp : (r == 1 ? myanc2 : (r == 2 ? myanc4 : myanc8));
       float4 pp4 = {0.f, 0.f, 0.f, 0.f}, pq4 = {1.f, 0.f, 0.f, 0.f};
-      if (bl) { const float4* Pp = reinterpret_cast<const float4*>(s_xpq + 8 * anc); pp4 = Pp[0]; pq4 = Pp[1]; }
+      if (bl) { const float4* Pp = reinterpret_cast<const float4*>(s_xpq + kXpqStride * anc); pp4 = Pp[0]; pq4 = Pp[1]; }
       gsync();  // every lane has read its ancestor before anyone overwrites a pose
       if (bl && anc != 0) {
         const Q4 pq = {pq4.x, pq4.y, pq4.z, pq4.w};
         mypos = V3{pp4.x, pp4.y, pp4.z} + qrot(pq, mypos);
         myquat = qnormalize(qmul(pq, myquat));
-        reinterpret_cast<float4*>(s_xpq + 8 * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
-        reinterpret_cast<float4*>(s_xpq + 8 * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
+        reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
+        reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
       }
       gsync();
     }
@@ -1019,8 +1025,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         st3(s_xanchor + 3 * myja, mypos);
         st3(s_xaxis + 3 * myja, {JB[0].x, JB[0].y, JB[0].z});
       } else {
-        const Q4 pq = ldq(s_xpq + 8 * myp + 4);
-        const V3 pp = ld3(s_xpq + 8 * myp);
+        const Q4 pq = ldq(s_xpq + kXpqStride * myp + 4);
+        const V3 pp = ld3(s_xpq + kXpqStride * myp);
 #pragma unroll
         for (int jj = 0; jj < 3; jj++) {
           if (jj < myjn) {
@@ -1039,8 +1045,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // geoms: world position and z axis
     if (lane < M.ngeom) {
       const int g = lane, b = pf_gbody;
-      st3(s_gpos + 3 * g, ld3(s_xpq + 8 * b) + mrot(s_xmat + 9 * b, pf_gpos));
-      Q4 q = qmul(ldq(s_xpq + 8 * b + 4), pf_gquat);
+      st3(s_gpos + 3 * g, ld3(s_xpq + kXpqStride * b) + mrot(s_xmat + 9 * b, pf_gpos));
+      Q4 q = qmul(ldq(s_xpq + kXpqStride * b + 4), pf_gquat);
       st3(s_gaxis + 3 * g, {2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z});
       if constexpr (COLL != 0) stq(lds + M.o_gquat + 4 * g, q);
     }
@@ -1060,7 +1066,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       V3 com = ld3(s_scom + 3 * __float_as_int(q1.y));
       V3 dif = ld3(s_xipos + 3 * b) - com;
       float mat[9];
-      q2mat(mat, qmul(ldq(s_xpq + 8 * b + 4), {iq.x, iq.y, iq.z, iq.w}));
+      q2mat(mat, qmul(ldq(s_xpq + kXpqStride * b + 4), {iq.x, iq.y, iq.z, iq.w}));
       const float in0 = in4.x, in1 = in4.y, in2 = in4.z, mass = mymass;
       float t[9];
       for (int r = 0; r < 3; r++) { t[3 * r] = mat[3 * r] * in0; t[3 * r + 1] = mat[3 * r + 1] * in1; t[3 * r + 2] = mat[3 * r + 2] * in2; }
@@ -1093,8 +1099,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         ang = ld3(s_xaxis + 3 * j);
         lin = cross(ang, off);
       }
-      reinterpret_cast<float4*>(s_cdof + 8 * d)[0] = {ang.x, ang.y, ang.z, 0.f};
-      reinterpret_cast<float4*>(s_cdof + 8 * d)[1] = {lin.x, lin.y, lin.z, 0.f};
+      reinterpret_cast<float4*>(s_cdof + kCdofStride * d)[0] = {ang.x, ang.y, ang.z, 0.f};
+      reinterpret_cast<float4*>(s_cdof + kCdofStride * d)[1] = {lin.x, lin.y, lin.z, 0.f};
     }
     // fixed tendon lengths
     for (int t = lane; t < M.ntendon; t += kGroup) {
@@ -1186,14 +1192,14 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       float* so = P.sensor_out + ((size_t)step * P.n_env + env) * P.sensor_stride;
       for (int k = 0; k < P.sensor_nframe; k++) {
         const int sb = P.sensor_body[k];
-        const V3 w = ld3(s_xpq + 8 * sb) + qrot(ldq(s_xpq + 8 * sb + 4), {P.sensor_off[k][0], P.sensor_off[k][1], P.sensor_off[k][2]});  // site = body frame + offset
+        const V3 w = ld3(s_xpq + kXpqStride * sb) + qrot(ldq(s_xpq + kXpqStride * sb + 4), {P.sensor_off[k][0], P.sensor_off[k][1], P.sensor_off[k][2]});  // site = body frame + offset
         if (lane < 3) so[3 * k + lane] = lane == 0 ? w.x : (lane == 1 ? w.y : w.z);
       }
       {
         int o = 3 * P.sensor_nframe + (P.sensor_tree >= 0 ? 6 : 0);
         for (int k = 0; k < P.sensor_naxis; k++, o += 3) {  // framexaxis / framezaxis: a column of the body's rotation
           const V3 e = P.sensor_axis_which[k] == 0 ? V3{1.f, 0.f, 0.f} : V3{0.f, 0.f, 1.f};
-          const V3 a = qrot(ldq(s_xpq + 8 * P.sensor_axis_body[k] + 4), e);
+          const V3 a = qrot(ldq(s_xpq + kXpqStride * P.sensor_axis_body[k] + 4), e);
           if (lane < 3) so[o + lane] = lane == 0 ? a.x : (lane == 1 ? a.y : a.z);
         }
         for (int k = 0; k < P.sensor_nlinvel; k++, o += 3) {  // mj_objectVelocity at the inertial frame origin, world axes
@@ -1240,7 +1246,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       mul_inert_vec(f0, in, mycacc);
       mul_inert_vec(f1, in, mycvel);
       cross_force(f2, mycvel, f1);
-      float4* Op = reinterpret_cast<float4*>(s_if + 16 * myb);
+      float4* Op = reinterpret_cast<float4*>(s_if + kIfStride * myb);
       Op[0] = {in[0], in[1], in[2], in[3]};
       Op[1] = {in[4], in[5], in[6], in[7]};
       Op[2] = {in[8], in[9], f0[0] + f2[0], f0[1] + f2[1]};
@@ -1255,12 +1261,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // mj_crb and the mj_rne backward pass share one sweep up the tree: children into parents (pull form)
     for (int L = M.nlevel - 2; L >= 1; L--) {
       if (mylevel == L && mycn > 0) {
-        float4* Op = reinterpret_cast<float4*>(s_if + 16 * myb);
+        float4* Op = reinterpret_cast<float4*>(s_if + kIfStride * myb);
         float4 acc[4] = {Op[0], Op[1], Op[2], Op[3]};
 #pragma unroll
         for (int k = 0; k < 8; k++)
           if (k < mycn) {
-            const float4* Cp = reinterpret_cast<const float4*>(s_if + 16 * mych[k]);
+            const float4* Cp = reinterpret_cast<const float4*>(s_if + kIfStride * mych[k]);
 #pragma unroll
             for (int q = 0; q < 4; q++) { const float4 c = Cp[q]; acc[q].x += c.x; acc[q].y += c.y; acc[q].z += c.z; acc[q].w += c.w; }
           }
@@ -1284,7 +1290,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       ld_cdof(s_cdof, i, cd);
       float in[10];
       {
-        const float4* Ip = reinterpret_cast<const float4*>(s_if + 16 * bi);
+        const float4* Ip = reinterpret_cast<const float4*>(s_if + kIfStride * bi);
         const float4 i0 = Ip[0], i1 = Ip[1], i2 = Ip[2];
         in[0] = i0.x; in[1] = i0.y; in[2] = i0.z; in[3] = i0.w; in[4] = i1.x; in[5] = i1.y; in[6] = i1.z; in[7] = i1.w; in[8] = i2.x; in[9] = i2.y;
       }
@@ -1309,7 +1315,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       const int b = __float_as_int(dA.y);
       float cdd[6];
       ld_cdof(s_cdof, d, cdd);
-      for (int t = 0; t < 6; t++) bias += cdd[t] * s_if[16 * b + 10 + t];
+      for (int t = 0; t < 6; t++) bias += cdd[t] * s_if[kIfStride * b + 10 + t];
       float passive = 0.f;
       if (!(M.disableflags & (1 << 5))) {
         if (__float_as_int(dA.z) >= 2) passive -= (dr ? dr[DL.o_stiff + d] : dB.w) * (s_qpos[__float_as_int(dC.x)] - dC.y);
@@ -1904,6 +1910,18 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         if (cost > 0.f) { force = 0.f; arf = 0.f; }
       }
       float res = rowact ? bvec + arf : 0.f;
+      // The sweeps run on the SCALED residual resn = -res / AR_jj with the lane's AR column scaled the same way (once per step, here):
+      // a row's proposal is then max(resn, -force) with no multiply in front, and the chain per row is max - readlane - fma
+      // (three dependent instructions instead of four).  res = -resn AR_jj where the cost change needs it.
+#pragma unroll
+      for (int c = 0; c < (kNefcMax + 3) / 4; c++) {
+        if (c * 4 < nefc) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (c * 4 + r < kNefcMax) ar[c * 4 + r] *= nAinv;
+        }
+      }
+      res *= nAinv;
       // Gauss-Seidel sweeps in column form.  Every lane proposes the step of its own row from its
       // current residual, delta = max(-res/AR_ii, -force) (= max(0, force - res/AR_ii) - force); when
       // row i's turn comes the proposal of lane i is the valid one: it is broadcast (v_readlane), all
@@ -1927,7 +1945,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         // hand-unrolled (ar[i] needs a compile-time register index) with one scalar exit test per 4 rows
 #define HB_PGS_ROW(i)                                                              \
   if ((i) < kNefcMax) {                                                            \
-    const float d_ = fmaxf(res * nAinv, nforce);                                   \
+    const float d_ = fmaxf(res, nforce);                                           \
     const int di_ = __builtin_amdgcn_readlane(__float_as_int(d_), (i));            \
     res = __builtin_fmaf(ar[(i) < kNefcMax ? (i) : 0], __int_as_float(di_), res);  \
     dl = hb_writelane(di_, (i), dl);                                               \
@@ -1944,7 +1962,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         static_assert(kNefcMax <= 64, "PGS sweep is unrolled for at most 64 rows");
         const float delta = __int_as_float(dl);
         force += delta;  // a clamped row lands on exactly 0
-        const float improvement = -0.5f * wave_sum(delta * (res0 + res));
+        const float improvement = 0.5f * wave_sum(delta * (res0 + res) * Aii);  // -0.5 delta . (res_before + res_after), unscaled
         niter++;
         if (improvement * pgs_scale < pgs_tol) break;
       }

@@ -1910,18 +1910,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         if (cost > 0.f) { force = 0.f; arf = 0.f; }
       }
       float res = rowact ? bvec + arf : 0.f;
-      // The sweeps run on the SCALED residual resn = -res / AR_jj with the lane's AR column scaled the same way (once per step, here):
-      // a row's proposal is then max(resn, -force) with no multiply in front, and the chain per row is max - readlane - fma
-      // (three dependent instructions instead of four).  res = -resn AR_jj where the cost change needs it.
-#pragma unroll
-      for (int c = 0; c < (kNefcMax + 3) / 4; c++) {
-        if (c * 4 < nefc) {
-#pragma unroll
-          for (int r = 0; r < 4; r++)
-            if (c * 4 + r < kNefcMax) ar[c * 4 + r] *= nAinv;
-        }
-      }
-      res *= nAinv;
       // Gauss-Seidel sweeps in column form.  Every lane proposes the step of its own row from its
       // current residual, delta = max(-res/AR_ii, -force) (= max(0, force - res/AR_ii) - force); when
       // row i's turn comes the proposal of lane i is the valid one: it is broadcast (v_readlane), all
@@ -1945,7 +1933,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         // hand-unrolled (ar[i] needs a compile-time register index) with one scalar exit test per 4 rows
 #define HB_PGS_ROW(i)                                                              \
   if ((i) < kNefcMax) {                                                            \
-    const float d_ = fmaxf(res, nforce);                                           \
+    const float d_ = fmaxf(res * nAinv, nforce);                                   \
     const int di_ = __builtin_amdgcn_readlane(__float_as_int(d_), (i));            \
     res = __builtin_fmaf(ar[(i) < kNefcMax ? (i) : 0], __int_as_float(di_), res);  \
     dl = hb_writelane(di_, (i), dl);                                               \
@@ -1962,7 +1950,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         static_assert(kNefcMax <= 64, "PGS sweep is unrolled for at most 64 rows");
         const float delta = __int_as_float(dl);
         force += delta;  // a clamped row lands on exactly 0
-        const float improvement = 0.5f * wave_sum(delta * (res0 + res) * Aii);  // -0.5 delta . (res_before + res_after), unscaled
+        const float improvement = -0.5f * wave_sum(delta * (res0 + res));
         niter++;
         if (improvement * pgs_scale < pgs_tol) break;
       }

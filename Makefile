@@ -47,6 +47,10 @@ build/hb_testspeed: tools/hb_testspeed.cpp $(LIB) include/hb.h
 	@mkdir -p build
 	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ tools/hb_testspeed.cpp -Lhumanoid_mujoco_amd -lhb -Wl,-rpath,'$$ORIGIN/../humanoid_mujoco_amd'
 
+# the same host program against the diagnostic library: prints the per-stage table (testspeed.cc:235-288)
+build/hb_testspeed_stamps: tools/hb_testspeed.cpp build/libhb_stamps.so include/hb.h
+	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ tools/hb_testspeed.cpp -Lbuild -l:libhb_stamps.so -Wl,-rpath,'$$ORIGIN'
+
 oracle:
 	$(MAKE) -C oracle
 

@@ -1,7 +1,10 @@
 // hb_testspeed — host C++ rollout driver over the C-ABI, in the shape of the reference's
 // simulation/mujoco/sample/testspeed.cc (load model, make data, Halton control noise, step loop,
 // print steps/s, contacts/step, constraints/step) but for n_env environments on one GPU.
-// usage: hb_testspeed model.{xml,hbm} [nstep=1000] [n_env=4096] [device=0]
+// usage: hb_testspeed model.{xml,hbm} [nstep=1000] [n_env=4096] [device=0] [PGS|Newton]
+// The per-stage table of testspeed.cc:235-288 (mjData.timer) is printed when the library is the diagnostic build
+// (build/hb_testspeed_stamps, linked against build/libhb_stamps.so: s_memtime stamps at the stage boundaries of the step
+// kernel); the product library carries no stamps (they cost about a tenth of a wave's cycles) and says so.
 #include "hb.h"
 #include <chrono>
 #include <cstdio>
@@ -60,6 +63,28 @@ int main(int argc, char** argv) {
   printf("Degrees of freedom   : %d\n", sz.nv);
   printf("Solver               : %s, at most %d iterations\n", opt.solver == 2 ? "Newton" : "PGS", opt.iterations);
   printf("Envs with warnings   : %d\n", flagged);
+  {  // internal profiler (mjTIMER_* taxonomy, mjdata.h:68-91): mean cycles per env-step of one more step, per stage
+    std::vector<unsigned long long> st((size_t)n_env * 16);
+    if (hb_get_stamps(b, st.data()) == HB_OK) {  // first call arms the buffer
+      hb_step_dev(b, ctrl + (size_t)(nstep - 1) * n_env * sz.nu, 1);
+      hb_batch_sync(b);
+      hb_get_stamps(b, st.data());
+      double ph[15] = {0};
+      for (int e = 0; e < n_env; e++) for (int i = 0; i < 15; i++) ph[i] += (double)(st[(size_t)e * 16 + i + 1] - st[(size_t)e * 16 + i]) / n_env;
+      double tot = 0;
+      for (double v : ph) tot += v;
+      struct { const char* name; unsigned mask; } rows[] = {  // bit i: stage i of the kernel's stamp list (tools/gpu_phase_profile.py)
+          {"step", 0x7fff}, {"position", 0x0fbe}, {"  kinematics", 0x0006}, {"  inertia (crb, qM)", 0x0038}, {"  collision", 0x0080}, {"  make", 0x0300},
+          {"  project (J W, AR)", 0x0c00}, {"velocity+actuation", 0x0040}, {"constraint (solver)", 0x3000}, {"advance (Euler)", 0x4000}, {"load state, ctrl, checks", 0x0001}};
+      printf("\nInternal profiler, shader cycles per env-step (one wave per env; stage stamps cost ~10 %% themselves)\n");
+      for (auto& r : rows) {
+        double v = 0;
+        for (int i = 0; i < 15; i++) if ((r.mask >> i) & 1u) v += ph[i];
+        printf(" %-26s : %9.0f  (%6.2f %%)\n", r.name, v, 100 * v / tot);
+      }
+      printf(" (the sweep up the tree of stage 'inertia' also carries mj_rne's backward pass and mj_comVel: one merged pass)\n");
+    } else printf("Internal profiler    : not in this build (use build/hb_testspeed_stamps: stage stamps exist in the diagnostic library only)\n");
+  }
   hb_dev_free(b, ctrl);
   hb_batch_free(b);
   hb_model_free(m);

@@ -428,21 +428,51 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (int i = 0; i < 3; i++) r[8 + i] = (float)m.actuator_biasprm[3 * a + i];
     r[12] = (float)m.actuator_forcerange[2 * a]; r[13] = (float)m.actuator_forcerange[2 * a + 1];
   }
-  // hull vertices as 16-byte records (x, y, z, link) and the edge graph with inlined coordinates (hb_device.hpp)
-  std::vector<float> meshv((size_t)std::max(1, m.nmeshvert) * 4, 0.f), meshn((size_t)std::max(1, m.nmeshnbr) * 4, 0.f);
-  for (int k = 0; k < m.nmesh; k++)
+  // hull vertices as 16-byte records (x, y, z, link) and the edge graph with inlined coordinates, each vertex's neighbour list padded
+  // to whole chunks of kMeshChunk records with copies of the vertex itself (hb_device.hpp); per mesh the cube map of start vertices
+  std::vector<int> padadr(std::max(1, m.nmeshvert), 0), padchunks(std::max(1, m.nmeshvert), 0);
+  int npad = 0;
+  for (int g = 0; g < m.nmeshvert; g++) {
+    padadr[g] = npad;
+    padchunks[g] = (m.mesh_nbrnum[g] + kMeshChunk - 1) / kMeshChunk;
+    npad += padchunks[g] * kMeshChunk;
+    if (padchunks[g] > 255 || padadr[g] >= (1 << 23)) { err = "mesh edge graph too large for the packed link words"; return false; }
+  }
+  std::vector<float> meshv((size_t)std::max(1, m.nmeshvert) * 4, 0.f), meshn((size_t)std::max(1, npad) * 4, 0.f), meshs((size_t)std::max(1, m.nmesh) * kMeshStart * 4, 0.f);
+  auto link_of = [&](int g) { return fi((padadr[g] << 8) | padchunks[g]); };
+  for (int k = 0; k < m.nmesh; k++) {
     for (int v = 0; v < m.mesh_vertnum[k]; v++) {
       const int g = m.mesh_vertadr[k] + v;
-      if (m.mesh_nbrnum[g] > 255 || m.mesh_nbradr[g] >= (1 << 23)) { err = "mesh edge graph too large for the packed link words"; return false; }
       for (int i = 0; i < 3; i++) meshv[(size_t)4 * g + i] = (float)m.mesh_vert[3 * g + i];
-      meshv[(size_t)4 * g + 3] = fi((m.mesh_nbradr[g] << 8) | m.mesh_nbrnum[g]);
-      for (int i = 0; i < m.mesh_nbrnum[g]; i++) {
-        const int r = m.mesh_nbradr[g] + i, w = m.mesh_vertadr[k] + m.mesh_nbr[r];
-        for (int c = 0; c < 3; c++) meshn[(size_t)4 * r + c] = (float)m.mesh_vert[3 * w + c];
-        meshn[(size_t)4 * r + 3] = fi((m.mesh_nbradr[w] << 8) | m.mesh_nbrnum[w]);
+      meshv[(size_t)4 * g + 3] = link_of(g);
+      for (int i = 0; i < padchunks[g] * kMeshChunk; i++) {
+        const int w = i < m.mesh_nbrnum[g] ? m.mesh_vertadr[k] + m.mesh_nbr[m.mesh_nbradr[g] + i] : g;
+        const size_t r = (size_t)padadr[g] + i;
+        for (int c = 0; c < 3; c++) meshn[4 * r + c] = (float)m.mesh_vert[3 * w + c];
+        meshn[4 * r + 3] = link_of(w);
       }
     }
-  const size_t o_meshv = T.addraw(meshv), o_meshn = T.addraw(meshn);
+    // cube map: face f = 2 * axis + (negative ? 1 : 0), cell (iu, iv) over the other two axes in cyclic order, u, v in [-1, 1]
+    for (int f = 0; f < 6; f++)
+      for (int iu = 0; iu < 4; iu++)
+        for (int iv = 0; iv < 4; iv++) {
+          const int ax = f >> 1;
+          double d[3];
+          d[ax] = (f & 1) ? -1.0 : 1.0; d[(ax + 1) % 3] = -0.75 + 0.5 * iu; d[(ax + 2) % 3] = -0.75 + 0.5 * iv;
+          int best = m.mesh_vertadr[k];
+          double bd = -1e300;
+          for (int v = 0; v < m.mesh_vertnum[k]; v++) {
+            const int g = m.mesh_vertadr[k] + v;
+            // (the float-rounded coordinates the device climbs on)
+            const double val = (double)(float)m.mesh_vert[3 * g] * d[0] + (double)(float)m.mesh_vert[3 * g + 1] * d[1] + (double)(float)m.mesh_vert[3 * g + 2] * d[2];
+            if (val > bd) { bd = val; best = g; }
+          }
+          float* rec = &meshs[((size_t)k * kMeshStart + f * 16 + iu * 4 + iv) * 4];
+          for (int c = 0; c < 3; c++) rec[c] = (float)m.mesh_vert[3 * best + c];
+          rec[3] = link_of(best);
+        }
+  }
+  const size_t o_meshv = T.addraw(meshv), o_meshn = T.addraw(meshn), o_meshs = T.addraw(meshs);
   const size_t o_arec = T.addraw(arec);
   size_t o_brec = T.addraw(brec), o_drec = T.addraw(drec), o_mdiag = T.addraw(mdiag), o_prec = T.addraw(prec), o_crec = T.addraw(crec), o_trec = T.addraw(trec),
          o_lrec = T.addraw(lrec);
@@ -467,6 +497,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   dm.arec = reinterpret_cast<const float4*>(D.d_flt + o_arec);
   dm.mesh_vert = reinterpret_cast<const float4*>(D.d_flt + o_meshv);
   dm.mesh_nbr = reinterpret_cast<const float4*>(D.d_flt + o_meshn);
+  dm.mesh_start = reinterpret_cast<const float4*>(D.d_flt + o_meshs);
   dm.mdiag = reinterpret_cast<const float2*>(D.d_flt + o_mdiag);
   std::vector<float> qsrc;
   for (double v : m.qpos0) qsrc.push_back((float)v);
@@ -505,6 +536,7 @@ struct hb_batch {
   bool diag = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* d_stamps = nullptr;
+  StageBufs stage = {};  // staged step of the general variants (null: fused)
   // env adapter (hb_env_*)
   EnvConfig env_cfg = {};
   bool env_ready = false;
@@ -586,6 +618,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
   P.blk0 = 0; P.nblk = b->n_env;
   P.dr = b->d_dr; P.dr_stride = b->dr_stride;
   P.stamps = b->d_stamps;
+  P.stage = b->stage;
   if (b->xfrc_std > 0.f && b->d_xfrc) {
     const double rate = b->xfrc_rate > 0.f ? std::exp(-b->model->m.timestep / b->xfrc_rate) : 0.0;  // trajectory.cc:149-150
     P.xfrc_rate = (float)rate; P.xfrc_scale = (float)(b->xfrc_std * std::sqrt(1.0 - rate * rate));
@@ -865,6 +898,17 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
   ok = ok && hipMemset(b->d_counts, 0, (size_t)n_env * kCountStride * sizeof(int)) == hipSuccess;
   ok = ok && ensure_ctrl(b, (size_t)n_env * std::max(1, dm.nu)) == HB_OK;
   ok = ok && hipMalloc((void**)&b->d_order, (size_t)n_env * sizeof(int)) == hipSuccess;
+  // general variants: the staged step (pose -> narrowphase -> step kernels); HB_STAGED=0 keeps everything in the step kernel
+  if (dm.variant != 0 && !(getenv("HB_STAGED") && atoi(getenv("HB_STAGED")) == 0)) {
+    StageBufs& sb = b->stage;
+    ok = ok && hipMalloc((void**)&sb.geom, (size_t)n_env * std::max(1, dm.ngeom) * 10 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&sb.item, (size_t)n_env * kWorkMax * sizeof(int4)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&sb.nwork, (size_t)n_env * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&sb.result, (size_t)n_env * kWorkMax * 4 * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMemset(sb.nwork, 0, (size_t)n_env * sizeof(int)) == hipSuccess;
+    sb.nq = dm.nq; sb.nv = dm.nv; sb.nu = dm.nu;
+    sb.pose_lds = pose_lds_floats(dm.nq, dm.nbody, dm.ngeom) * (int)sizeof(float);
+  }
   if (hb_debug()) fprintf(stderr, "[hb] LDS per env: %d bytes (%d envs per CU)\n", dm.lds_floats * 4, 160 * 1024 / (dm.lds_floats * 4));
   if (ok && dm.lds_floats * 4 > 64 * 1024) ok = set_step_lds_limit(dm.lds_floats * 4) == hipSuccess;
   if (!ok) { set_err(err, err_sz, "device allocation failed"); hb_batch_free(b); return nullptr; }
@@ -892,7 +936,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_dr) HB_IGN(hipFree(b->d_dr));
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
-  void* ptrs[] = {b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
+  void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nwork, b->stage.result, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
                   b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;

@@ -33,6 +33,8 @@ constexpr int kWorkMax = 256;   // general collision: narrowphase work items (pa
 constexpr int kConStride = 20;  // floats per contact record in LDS
 constexpr int kDiagConStride = 16;
 constexpr int kMetaStride = 4;  // floats per row in the general variants' row meta
+constexpr int kMeshChunk = 8;   // neighbour records per climb round's load batch (DevModel::mesh_nbr)
+constexpr int kMeshStart = 96;  // start records per mesh: cube map, 6 faces x 4 x 4 (DevModel::mesh_start)
 constexpr int kCountStride = 8;  // ints per env in BatchPtrs::counts: ncon, nefc, niter, cost, self-collision flag, spare
 constexpr int kBrecQuads = 18;  // float4s per level-ordered body record (see build_device_model)
 
@@ -80,10 +82,14 @@ struct DevModel {
   const int HB_CONST *geom_type, *geom_bodyid;
   const float HB_CONST *geom_size, *geom_pos, *geom_quat, *geom_rbound;
   // meshes: hull vertices as 16-byte records (x, y, z, link) and per geom the first record / the count (0 for other geom types);
-  // link = first neighbour record << 8 | number of neighbours; mesh_nbr: one record per (vertex, neighbour): (x, y, z of the
-  // neighbour, the neighbour's own link): the hull's edge graph with the coordinates inlined (hb_mpr.hpp: ccd_support)
+  // link = first neighbour record << 8 | number of kMeshChunk-record chunks; mesh_nbr: one record per (vertex, neighbour): (x, y, z
+  // of the neighbour, the neighbour's own link): the hull's edge graph with the coordinates inlined, every vertex's list padded to
+  // whole chunks with copies of the vertex itself (never an improvement), so that a climb round is one batch of independent
+  // 16-byte loads (hb_mpr.hpp: ccd_support).  mesh_start: per mesh a cube map of kMeshStart records (6 faces x 4 x 4 cells): the
+  // hull's support vertex for the cell's centre direction, where the first climb of a test starts.
   const float4 HB_CONST* mesh_vert;
   const float4 HB_CONST* mesh_nbr;
+  const float4 HB_CONST* mesh_start;
   const int HB_CONST *geom_meshadr, *geom_meshnum;
   // height fields (static terrain on the world body): per geom the field id (-1 otherwise)
   const int HB_CONST *geom_dataid, *hfield_nrow, *hfield_ncol, *hfield_adr;
@@ -216,6 +222,22 @@ struct PolicyDesc {
   int ldx;  // LDS row stride of an activation tile: widest layer + 4 (K is swept four columns at a time: zero pad columns)
 };
 
+// Buffers of the STAGED step of the general variants (launch_step): hb_pose_kernel writes every geom's world pose and the env's
+// narrowphase work items, hb_narrow_kernel evaluates the items (one per lane, at the occupancy of a small kernel: the MPR climbs are
+// chains of dependent loads), the step kernel appends the results in item order.  All null: the step kernel does all of it itself.
+struct StageBufs {
+  float* geom;     // [n_env][ngeom][10]: world position[3], z axis[3], orientation quaternion[4]
+  int4* item;      // [n_env][kWorkMax]: pair, sub-item, rmin | cmin << 16, ncols (sub-grid of a height-field pair)
+  int* nwork;      // [n_env] work items of the env (clamped to kWorkMax)
+  float4* result;  // [n_env][kWorkMax][4]: dist0, pos0 | normal0, n | dist1, pos1 | normal1, pair
+  int nq, nv, nu, pose_lds;  // host-side copies for the per-step pointer arithmetic and the pose kernel's LDS bytes
+};
+
+// LDS of hb_pose_kernel in floats: qpos | body poses (12 floats each, kXpqStride) | geom position, z axis, quaternion | the work lists
+__host__ __device__ inline int pose_lds_floats(int nq, int nb, int ngeom) {
+  return ((nq + 3) & ~3) + 12 * nb + 2 * ((3 * ngeom + 3) & ~3) + 4 * ngeom + kListMax * 5 + kWorkMax;
+}
+
 struct BatchPtrs {
   float* state;        // [n_env][nstate]
   const float* ctrl;   // [n_env][nu] or [T][n_env][nu]
@@ -254,6 +276,7 @@ struct BatchPtrs {
   float sensor_subinv[4];                                        //   1 / subtree mass
   const unsigned char* env_mask;  // nullable [n_env]: envs with a zero byte are skipped by this launch
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
+  StageBufs stage;
 };
 
 }  // namespace hb

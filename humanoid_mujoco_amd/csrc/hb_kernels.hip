@@ -579,21 +579,22 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
   return x - v;
 }
 
-// a mesh geom's hull for the support function: its vertex 0 is where the climbs of a test start
+// a mesh geom's hull for the support function: the start records of its mesh
 __device__ __forceinline__ void set_mesh(DevModelRef M, CObj& o, int g) {
-  o.vert = M.mesh_vert + M.geom_meshadr[g];
+  o.vert = M.mesh_start + (M.geom_meshnum[g] > 0 ? kMeshStart * M.geom_dataid[g] : 0);
   o.nbr = M.mesh_nbr;
-  o.cur = {0.f, 0.f, 0.f}; o.cur_link = 0;
-  if (M.geom_meshnum[g] > 0) { const float4 v0 = o.vert[0]; o.cur = {v0.x, v0.y, v0.z}; o.cur_link = __float_as_int(v0.w); }
 }
 
 // mj_collision for models with mesh geoms and / or a height field (the reference's own robot: simulation/assets/world.xml:14-58).
 // Three passes over LDS lists: (1) broadphase per candidate pair, survivors in pair order; (2) work items: one per pair, or one
 // per prism of the sub-grid under the geom for a height-field pair (mjc_ConvexHField's double loop, flattened); (3) narrowphase,
 // one work item per lane, contacts appended in work-item order (= the oracle's order: pair, then grid row, then strip position).
-template <int NC>
-__device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata_all, int lane, const float* s_gpos, const float* s_gaxis, const float* s_gquat,
-                                               float* s_con, int* s_scratch, int& status) {
+// The passes are separate functions because the STAGED step (launch_step) runs them in separate kernels: (1) + (2) in
+// hb_pose_kernel, (3) in hb_narrow_kernel at four times the occupancy the step kernel allows, and the step kernel itself only
+// appends the results (collide_gather).
+//
+// passes (1) and (2): s_scratch receives the pair list, the sub-grids of height-field pairs and the work items; returns the number of work items
+__device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const float* s_gpos, const float* s_gaxis, int* s_scratch, int& status) {
   int* s_list = s_scratch;                   // [kListMax]
   int* s_pinfo = s_scratch + kListMax;       // [kListMax][4]: rmin, cmin, ncols, nrows of a height-field pair's sub-grid
   int* s_work = s_pinfo + 4 * kListMax;      // [kWorkMax]: list index << 16 | sub-item
@@ -656,149 +657,201 @@ __device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata
   nwork = uniform(nwork);
   if (nwork > kWorkMax) { status |= (1 << 1); nwork = kWorkMax; }
   gsync();
+  return nwork;
+}
+
+// pass (3) for one work item: pair p (sub-item `sub` of the sub-grid rmin, cmin, ncols for a height-field pair) -> n contacts (0..2)
+__device__ __forceinline__ void eval_work_item(DevModelRef M, const float* hdata_all, bool have, int p, int sub, int rmin, int cmin, int ncols,
+                                               const float* s_gpos, const float* s_gaxis, const float* s_gquat, ConOut& co0, ConOut& co1, int& n, V3& hint) {
+  float4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+  if (have) { const float4 HB_CONST* N = M.crec + 3 * (size_t)p; c0 = N[0]; c1 = N[1]; c2 = N[2]; }
+  co0.dist = 0.f; co0.pos = {0.f, 0.f, 0.f}; co0.n = {0.f, 0.f, 1.f}; co1 = co0;
+  n = 0;
+  hint = {0.f, 0.f, 0.f};
+  const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y);
+  const int t1 = __float_as_int(c0.z) & 255, t2 = (__float_as_int(c0.z) >> 8) & 255;
+  const float margin = c0.w;
+  // the two objects of an MPR test (one call site below)
+  CObj o1, o2;
+  int mpr_kind = 0;  // 0: no MPR for this item, 1: prism vs geom (field frame), 2: geom vs geom (world frame)
+  float hm[9];
+  V3 pos1 = {0.f, 0.f, 0.f};
+  if (have) {
+    pos1 = ld3(s_gpos + 3 * g1);
+    const V3 pos2 = ld3(s_gpos + 3 * g2), ax2 = ld3(s_gaxis + 3 * g2);
+    const float rb1 = c1.x, rb2 = c1.y, r2 = c2.x, l2 = c2.y;
+    (void)rb1;
+    if (t1 == 1) {
+      q2mat(hm, ldq(M.geom_quat + 4 * g1));
+      const int hid = M.geom_dataid[g1];
+      const float sx = M.hfield_size[4 * hid], sy = M.hfield_size[4 * hid + 1], sz = M.hfield_size[4 * hid + 2], sb = M.hfield_size[4 * hid + 3];
+      const int nrow = M.hfield_nrow[hid], ncol = M.hfield_ncol[hid];
+      const float* data = hdata_all + M.hfield_adr[hid];
+      const int r = rmin + sub / (2 * ncols), j = sub % (2 * ncols);
+      const float dx = 2.f * sx / (float)(ncol - 1), dy = 2.f * sy / (float)(nrow - 1);
+      // strip vertex s of grid row r: column cmin + s / 2, grid row r + 1 for even s, r for odd s (mjc_ConvexHField: dr = {1, 0})
+      V3 tv[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int sidx = j + k, cc = cmin + (sidx >> 1), rr = r + ((sidx & 1) ? 0 : 1);
+        tv[k] = {dx * (float)cc - sx, dy * (float)rr - sy, data[rr * ncol + cc] * sz + margin};
+      }
+      // geom 2 in the field's frame
+      const V3 dif = pos2 - pos1;
+      o2.pos = {hm[0] * dif.x + hm[3] * dif.y + hm[6] * dif.z, hm[1] * dif.x + hm[4] * dif.y + hm[7] * dif.z, hm[2] * dif.x + hm[5] * dif.y + hm[8] * dif.z};
+      if (!(tv[0].z < o2.pos.z - rb2 && tv[1].z < o2.pos.z - rb2 && tv[2].z < o2.pos.z - rb2)) {  // (prism height test, with the bounding sphere's lowest point)
+        float m2[9];
+        q2mat(m2, ldq(s_gquat + 4 * g2));
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++) o2.mat[3 * a + b] = hm[a] * m2[b] + hm[3 + a] * m2[3 + b] + hm[6 + a] * m2[6 + b];  // hm' m2
+        o2.type = t2; o2.r = r2; o2.h = l2; o2.margin = margin;
+        set_mesh(M, o2, g2);
+        o1.type = -1; o1.pos = {0.f, 0.f, 0.f}; o1.r = o1.h = o1.margin = 0.f; o1.vert = M.mesh_start; o1.nbr = M.mesh_nbr;
+#pragma unroll
+        for (int a = 0; a < 9; a++) o1.mat[a] = 0.f;
+        o1.p0 = {tv[0].x, tv[0].y, -sb}; o1.p1 = {tv[1].x, tv[1].y, -sb}; o1.p2 = {tv[2].x, tv[2].y, -sb};
+        o1.p3 = tv[0]; o1.p4 = tv[1]; o1.p5 = tv[2];
+        mpr_kind = 1;
+      }
+    } else if (t1 == 7 || t2 == 7) {
+      // mjc_Convex: both geoms in the world frame, each inflated by half the margin
+      q2mat(o1.mat, ldq(s_gquat + 4 * g1));
+      q2mat(o2.mat, ldq(s_gquat + 4 * g2));
+      o1.type = t1; o1.pos = pos1; o1.r = c1.z; o1.h = c1.w; o1.margin = 0.5f * margin; set_mesh(M, o1, g1);
+      o2.type = t2; o2.pos = pos2; o2.r = r2; o2.h = l2; o2.margin = 0.5f * margin; set_mesh(M, o2, g2);
+      o1.p0 = o1.p1 = o1.p2 = o1.p3 = o1.p4 = o1.p5 = V3{0.f, 0.f, 0.f};
+      mpr_kind = 2;
+    } else if (t1 == 0) {
+      const V3 normal = ld3(s_gaxis + 3 * g1);
+      if (dot(pos2 - pos1, normal) <= margin + rb2) {
+        if (t2 == 2) n = plane_sphere(co0, margin, pos1, normal, pos2, r2) ? 1 : 0;
+        else {
+          ConOut ca, cb;
+          const bool h1 = plane_sphere(ca, margin, pos1, normal, pos2 + ax2 * l2, r2);
+          const bool h2 = plane_sphere(cb, margin, pos1, normal, pos2 - ax2 * l2, r2);
+          co0 = h1 ? ca : cb;
+          co1 = cb;
+          n = (h1 ? 1 : 0) + (h2 ? 1 : 0);
+          hint = ax2;
+        }
+      }
+    } else {
+      const float r1 = c1.z, l1 = c1.w;
+      if (t1 == 2 && t2 == 2) n = sphere_sphere(co0, margin, pos1, r1, pos2, r2) ? 1 : 0;
+      else if (t1 == 2) {
+        const float x = clampf(dot(ax2, pos1 - pos2), -l2, l2);
+        n = sphere_sphere(co0, margin, pos1, r1, pos2 + ax2 * x, r2) ? 1 : 0;
+      } else n = capsule_capsule(co0, co1, margin, pos1, ld3(s_gaxis + 3 * g1), r1, l1, pos2, ax2, r2, l2);
+    }
+  }
+  if (mpr_kind) {
+    float depth;
+    V3 dir, vec;
+    const bool hit = mpr_penetration(o1, o2, M.mpr_iterations, (double)M.mpr_tolerance, depth, dir, vec);
+    if (mpr_kind == 1) {
+      if (hit && depth >= 2.220446e-16f) {
+        co0.dist = -depth;
+        co0.n = mrot(hm, dir);
+        co0.pos = mrot(hm, vec) + pos1;
+        n = 1;
+      }
+    } else if (hit && !(dir.x == 0.f && dir.y == 0.f && dir.z == 0.f)) {
+      co0.dist = margin - depth;
+      co0.n = dir;
+      co0.pos = vec;
+      n = 1;
+    }
+    if (n) {  // mjc_fixNormal: spheres and capsules know their own normal
+      float m1[9], m2[9];
+      q2mat(m1, ldq(s_gquat + 4 * g1));
+      q2mat(m2, ldq(s_gquat + 4 * g2));
+      V3 n1, n2;
+      const bool h1 = analytic_normal(t1, pos1, m1, c1.w, co0.pos, n1), h2 = analytic_normal(t2, ld3(s_gpos + 3 * g2), m2, c2.y, co0.pos, n2);
+      if (h1 || h2) {
+        V3 nn = {0.f, 0.f, 0.f};
+        if (h1) nn = nn + n1;
+        if (h2) nn = nn - n2;
+        float len;
+        nn = normalized(nn, &len);
+        if (len >= HB_MINVAL) co0.n = nn;
+      }
+    }
+  }
+}
+
+// ordered append of one round's results: slot = ncon + (# contacts of lower lanes)
+template <int NC>
+__device__ __forceinline__ void append_contacts(int lane, float* s_con, int& ncon, int n, const ConOut& co0, const ConOut& co1, V3 hint, int p) {
+  const unsigned long long b1 = __ballot(n >= 1), b2 = __ballot(n >= 2);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int slot = ncon + __popcll(b1 & lt) + __popcll(b2 & lt);
+  if (n >= 1 && slot < NC) {
+    float* c = s_con + slot * kConStride;
+    c[C_DIST] = co0.dist;
+    st3(c + C_POS, co0.pos);
+    make_frame(c + C_FRAME, co0.n, hint);
+    c[C_PAIR] = __int_as_float(p);
+  }
+  if (n >= 2 && slot + 1 < NC) {
+    float* c = s_con + (slot + 1) * kConStride;
+    c[C_DIST] = co1.dist;
+    st3(c + C_POS, co1.pos);
+    make_frame(c + C_FRAME, co1.n, hint);
+    c[C_PAIR] = __int_as_float(p);
+  }
+  ncon += __popcll(b1) + __popcll(b2);
+}
+
+// the fused form: all three passes in the step kernel
+template <int NC>
+__device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata_all, int lane, const float* s_gpos, const float* s_gaxis, const float* s_gquat,
+                                               float* s_con, int* s_scratch, int& status) {
+  const int* s_list = s_scratch;
+  const int* s_pinfo = s_scratch + kListMax;
+  const int* s_work = s_pinfo + 4 * kListMax;
+  const int nwork = build_work_list(M, lane, s_gpos, s_gaxis, s_scratch, status);
   int ncon = 0;
   for (int w0 = 0; w0 < nwork; w0 += kGroup) {
     const bool have = w0 + lane < nwork;
     const int item = have ? s_work[w0 + lane] : 0;
     const int idx = item >> 16, sub = item & 0xffff;
     const int p = have ? s_list[idx] : 0;
-    float4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
-    if (have) { const float4 HB_CONST* N = M.crec + 3 * (size_t)p; c0 = N[0]; c1 = N[1]; c2 = N[2]; }
+    ConOut co0, co1;
+    int n;
+    V3 hint;
+    eval_work_item(M, hdata_all, have, p, sub, s_pinfo[4 * idx], s_pinfo[4 * idx + 1], s_pinfo[4 * idx + 2], s_gpos, s_gaxis, s_gquat, co0, co1, n, hint);
+    append_contacts<NC>(lane, s_con, ncon, n, co0, co1, hint, p);
+  }
+  if (ncon > NC) { status |= (1 << 1); ncon = NC; }
+  return ncon;
+}
+
+// the staged form's third part: the work items were evaluated by hb_narrow_kernel; append its results in work-item order
+template <int NC>
+__device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, const StageBufs& G, const float* s_gaxis, float* s_con, int& status) {
+  // (overflow of the pair / work lists was flagged by hb_pose_kernel, which clamps the count it stores)
+  const int nwork = min(max(G.nwork[env], 0), kWorkMax);
+  int ncon = 0;
+  const float4* R = G.result + ((size_t)env * kWorkMax) * 4;
+  for (int w0 = 0; w0 < nwork; w0 += kGroup) {
+    const bool have = w0 + lane < nwork;
     ConOut co0, co1;
     co0.dist = 0.f; co0.pos = {0.f, 0.f, 0.f}; co0.n = {0.f, 0.f, 1.f}; co1 = co0;
-    int n = 0;
+    int n = 0, p = 0;
     V3 hint = {0.f, 0.f, 0.f};
-    const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y);
-    const int t1 = __float_as_int(c0.z) & 255, t2 = (__float_as_int(c0.z) >> 8) & 255;
-    const float margin = c0.w;
-    // the two objects of an MPR test (one call site below)
-    CObj o1, o2;
-    int mpr_kind = 0;  // 0: no MPR for this item, 1: prism vs geom (field frame), 2: geom vs geom (world frame)
-    float hm[9];
-    V3 pos1 = {0.f, 0.f, 0.f};
     if (have) {
-      pos1 = ld3(s_gpos + 3 * g1);
-      const V3 pos2 = ld3(s_gpos + 3 * g2), ax2 = ld3(s_gaxis + 3 * g2);
-      const float rb1 = c1.x, rb2 = c1.y, r2 = c2.x, l2 = c2.y;
-      (void)rb1;
-      if (t1 == 1) {
-        q2mat(hm, ldq(M.geom_quat + 4 * g1));
-        const int hid = M.geom_dataid[g1];
-        const float sx = M.hfield_size[4 * hid], sy = M.hfield_size[4 * hid + 1], sz = M.hfield_size[4 * hid + 2], sb = M.hfield_size[4 * hid + 3];
-        const int nrow = M.hfield_nrow[hid], ncol = M.hfield_ncol[hid];
-        const float* data = hdata_all + M.hfield_adr[hid];
-        const int rmin = s_pinfo[4 * idx], cmin = s_pinfo[4 * idx + 1], ncols = s_pinfo[4 * idx + 2];
-        const int r = rmin + sub / (2 * ncols), j = sub % (2 * ncols);
-        const float dx = 2.f * sx / (float)(ncol - 1), dy = 2.f * sy / (float)(nrow - 1);
-        // strip vertex s of grid row r: column cmin + s / 2, grid row r + 1 for even s, r for odd s (mjc_ConvexHField: dr = {1, 0})
-        V3 tv[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const int sidx = j + k, cc = cmin + (sidx >> 1), rr = r + ((sidx & 1) ? 0 : 1);
-          tv[k] = {dx * (float)cc - sx, dy * (float)rr - sy, data[rr * ncol + cc] * sz + margin};
-        }
-        // geom 2 in the field's frame
-        const V3 dif = pos2 - pos1;
-        o2.pos = {hm[0] * dif.x + hm[3] * dif.y + hm[6] * dif.z, hm[1] * dif.x + hm[4] * dif.y + hm[7] * dif.z, hm[2] * dif.x + hm[5] * dif.y + hm[8] * dif.z};
-        if (!(tv[0].z < o2.pos.z - rb2 && tv[1].z < o2.pos.z - rb2 && tv[2].z < o2.pos.z - rb2)) {  // (prism height test, with the bounding sphere's lowest point)
-          float m2[9];
-          q2mat(m2, ldq(s_gquat + 4 * g2));
-#pragma unroll
-          for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) o2.mat[3 * a + b] = hm[a] * m2[b] + hm[3 + a] * m2[3 + b] + hm[6 + a] * m2[6 + b];  // hm' m2
-          o2.type = t2; o2.r = r2; o2.h = l2; o2.margin = margin;
-          set_mesh(M, o2, g2);
-          o1.type = -1; o1.pos = {0.f, 0.f, 0.f}; o1.r = o1.h = o1.margin = 0.f; o1.vert = M.mesh_vert; o1.nbr = M.mesh_nbr; o1.cur = {0.f, 0.f, 0.f}; o1.cur_link = 0;
-#pragma unroll
-          for (int a = 0; a < 9; a++) o1.mat[a] = 0.f;
-          o1.p0 = {tv[0].x, tv[0].y, -sb}; o1.p1 = {tv[1].x, tv[1].y, -sb}; o1.p2 = {tv[2].x, tv[2].y, -sb};
-          o1.p3 = tv[0]; o1.p4 = tv[1]; o1.p5 = tv[2];
-          mpr_kind = 1;
-        }
-      } else if (t1 == 7 || t2 == 7) {
-        // mjc_Convex: both geoms in the world frame, each inflated by half the margin
-        q2mat(o1.mat, ldq(s_gquat + 4 * g1));
-        q2mat(o2.mat, ldq(s_gquat + 4 * g2));
-        o1.type = t1; o1.pos = pos1; o1.r = c1.z; o1.h = c1.w; o1.margin = 0.5f * margin; set_mesh(M, o1, g1);
-        o2.type = t2; o2.pos = pos2; o2.r = r2; o2.h = l2; o2.margin = 0.5f * margin; set_mesh(M, o2, g2);
-        o1.p0 = o1.p1 = o1.p2 = o1.p3 = o1.p4 = o1.p5 = V3{0.f, 0.f, 0.f};
-        mpr_kind = 2;
-      } else if (t1 == 0) {
-        const V3 normal = ld3(s_gaxis + 3 * g1);
-        if (dot(pos2 - pos1, normal) <= margin + rb2) {
-          if (t2 == 2) n = plane_sphere(co0, margin, pos1, normal, pos2, r2) ? 1 : 0;
-          else {
-            ConOut ca, cb;
-            const bool h1 = plane_sphere(ca, margin, pos1, normal, pos2 + ax2 * l2, r2);
-            const bool h2 = plane_sphere(cb, margin, pos1, normal, pos2 - ax2 * l2, r2);
-            co0 = h1 ? ca : cb;
-            co1 = cb;
-            n = (h1 ? 1 : 0) + (h2 ? 1 : 0);
-            hint = ax2;
-          }
-        }
-      } else {
-        const float r1 = c1.z, l1 = c1.w;
-        if (t1 == 2 && t2 == 2) n = sphere_sphere(co0, margin, pos1, r1, pos2, r2) ? 1 : 0;
-        else if (t1 == 2) {
-          const float x = clampf(dot(ax2, pos1 - pos2), -l2, l2);
-          n = sphere_sphere(co0, margin, pos1, r1, pos2 + ax2 * x, r2) ? 1 : 0;
-        } else n = capsule_capsule(co0, co1, margin, pos1, ld3(s_gaxis + 3 * g1), r1, l1, pos2, ax2, r2, l2);
+      const float4 a = R[4 * (w0 + lane)], b = R[4 * (w0 + lane) + 1], c = R[4 * (w0 + lane) + 2], d = R[4 * (w0 + lane) + 3];
+      co0.dist = a.x; co0.pos = {a.y, a.z, a.w}; co0.n = {b.x, b.y, b.z}; n = __float_as_int(b.w);
+      co1.dist = c.x; co1.pos = {c.y, c.z, c.w}; co1.n = {d.x, d.y, d.z}; p = __float_as_int(d.w);
+      if (n >= 1) {  // the frame hint of a plane-capsule pair: the capsule's axis
+        const float4 c0 = M.crec[3 * (size_t)p];
+        const int t1 = __float_as_int(c0.z) & 255, t2 = (__float_as_int(c0.z) >> 8) & 255;
+        if (t1 == 0 && t2 == 3) hint = ld3(s_gaxis + 3 * __float_as_int(c0.y));
       }
     }
-    if (mpr_kind) {
-      float depth;
-      V3 dir, vec;
-      const bool hit = mpr_penetration(o1, o2, M.mpr_iterations, (double)M.mpr_tolerance, depth, dir, vec);
-      if (mpr_kind == 1) {
-        if (hit && depth >= 2.220446e-16f) {
-          co0.dist = -depth;
-          co0.n = mrot(hm, dir);
-          co0.pos = mrot(hm, vec) + pos1;
-          n = 1;
-        }
-      } else if (hit && !(dir.x == 0.f && dir.y == 0.f && dir.z == 0.f)) {
-        co0.dist = margin - depth;
-        co0.n = dir;
-        co0.pos = vec;
-        n = 1;
-      }
-      if (n) {  // mjc_fixNormal: spheres and capsules know their own normal
-        float m1[9], m2[9];
-        q2mat(m1, ldq(s_gquat + 4 * g1));
-        q2mat(m2, ldq(s_gquat + 4 * g2));
-        V3 n1, n2;
-        const bool h1 = analytic_normal(t1, pos1, m1, c1.w, co0.pos, n1), h2 = analytic_normal(t2, ld3(s_gpos + 3 * g2), m2, c2.y, co0.pos, n2);
-        if (h1 || h2) {
-          V3 nn = {0.f, 0.f, 0.f};
-          if (h1) nn = nn + n1;
-          if (h2) nn = nn - n2;
-          float len;
-          nn = normalized(nn, &len);
-          if (len >= HB_MINVAL) co0.n = nn;
-        }
-      }
-    }
-    // ordered append: slot = ncon + (# contacts of lower lanes)
-    const unsigned long long b1 = __ballot(n >= 1), b2 = __ballot(n >= 2);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const int slot = ncon + __popcll(b1 & lt) + __popcll(b2 & lt);
-    if (n >= 1 && slot < NC) {
-      float* c = s_con + slot * kConStride;
-      c[C_DIST] = co0.dist;
-      st3(c + C_POS, co0.pos);
-      make_frame(c + C_FRAME, co0.n, hint);
-      c[C_PAIR] = __int_as_float(p);
-    }
-    if (n >= 2 && slot + 1 < NC) {
-      float* c = s_con + (slot + 1) * kConStride;
-      c[C_DIST] = co1.dist;
-      st3(c + C_POS, co1.pos);
-      make_frame(c + C_FRAME, co1.n, hint);
-      c[C_PAIR] = __int_as_float(p);
-    }
-    ncon += __popcll(b1) + __popcll(b2);
+    append_contacts<NC>(lane, s_con, ncon, n, co0, co1, hint, p);
   }
   if (ncon > NC) { status |= (1 << 1); ncon = NC; }
   return ncon;
@@ -1373,7 +1426,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     int ncon = 0;
     const bool contacts_on = !(M.disableflags & ((1 << 0) | (1 << 4)));
     if constexpr (COLL != 0) {
-      if (contacts_on) ncon = collide_general<kNC>(M, dr ? dr + DL.o_hfield : (const float*)M.hfield_data, lane, s_gpos, s_gaxis, s_gquat, s_con, reinterpret_cast<int*>(s_C), status);
+      if (contacts_on) {
+        // staged step: the narrowphase ran in its own kernel on this step's poses (launch_step); the second forward pass of a step
+        // whose first one was reset (mj_checkAcc) runs on other poses and does its own
+        if (P.stage.result && !redo) ncon = collide_gather<kNC>(M, lane, env, P.stage, s_gaxis, s_con, status);
+        else ncon = collide_general<kNC>(M, dr ? dr + DL.o_hfield : (const float*)M.hfield_data, lane, s_gpos, s_gaxis, s_gquat, s_con, reinterpret_cast<int*>(s_C), status);
+      }
     } else if (contacts_on) {
       // Two passes.  (1) Broadphase over every candidate pair - bounding spheres, or distance to the plane - with the
       // survivors compacted, IN PAIR ORDER, into a list (ballot + popcount; the list borrows the head of C, which is not
@@ -2411,6 +2469,159 @@ __global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big28_kernel(const D
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
 
+// ---- staged step of the general variants: poses + work lists, then the narrowphase, each in a kernel of its own ------------------
+// hb_pose_kernel: one wave per env.  The state checks and mj_kinematics of step_body, statement for statement (the step kernel
+// repeats them: a pose costs less to recompute than to hand over), the geoms' world poses, broadphase and work items.
+__global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, const BatchPtrs P) {
+  DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= P.nblk) return;
+  const int env = P.blk0 + (int)blockIdx.x;
+  if (P.env_mask && !P.env_mask[env]) { if (lane == 0) P.stage.nwork[env] = 0; return; }
+  const int nq = M.nq, nv = M.nv, nb = M.nbody, ng = M.ngeom;
+  float* s_qpos = lds;
+  float* s_xpq = s_qpos + ((nq + 3) & ~3);
+  float* s_gpos = s_xpq + kXpqStride * nb;
+  float* s_gaxis = s_gpos + ((3 * ng + 3) & ~3);
+  float* s_gquat = s_gaxis + ((3 * ng + 3) & ~3);
+  int* s_scratch = reinterpret_cast<int*>(s_gquat + 4 * ng);
+  const float* gstate = P.state + (size_t)env * M.nstate;
+  // mj_checkPos / mj_checkVel: a bad state is reset before the step, and the step's poses are those of qpos0
+  bool badp = false, badv = false;
+  for (int i = lane; i < nq; i += kGroup) { const float v = gstate[1 + i]; s_qpos[i] = v; badp |= !(fabsf(v) <= HB_MAXVAL); }
+  for (int i = lane; i < nv; i += kGroup) { const float v = gstate[1 + nq + i]; badv |= !(fabsf(v) <= HB_MAXVAL); }
+  if (__any(badp) || __any(badv)) for (int i = lane; i < nq; i += kGroup) s_qpos[i] = M.qpos0[i];
+  const bool bl = lane + 1 < nb;
+  float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, bp = q0, bq = q0;
+  float4 JA[3], JB[3], JC[3];
+#pragma unroll
+  for (int jj = 0; jj < 3; jj++) { JA[jj] = q0; JB[jj] = q0; JC[jj] = q0; }
+  if (bl) {
+    const float4 HB_CONST* R = M.brec + (size_t)(lane + 1) * kBrecQuads;
+    q0 = R[0]; q1 = R[1]; bp = R[2]; bq = R[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) { JA[jj] = R[9 + 3 * jj]; JB[jj] = R[10 + 3 * jj]; JC[jj] = R[11 + 3 * jj]; }
+  }
+  int pf_gbody = 0;
+  V3 pf_gpos = {0.f, 0.f, 0.f};
+  Q4 pf_gquat = {1.f, 0.f, 0.f, 0.f};
+  if (lane < ng) { pf_gbody = M.geom_bodyid[lane]; pf_gpos = ld3(M.geom_pos + 3 * lane); pf_gquat = ldq(M.geom_quat + 4 * lane); }
+  if (lane == 0) { st3(s_xpq, {0.f, 0.f, 0.f}); stq(s_xpq + 4, {1.f, 0.f, 0.f, 0.f}); }
+  gsync();
+  const int myb = __float_as_int(q0.x), myp = __float_as_int(q0.y), myjn = __float_as_int(q0.z);
+  const int myanc2 = (__float_as_int(q1.x) >> 8) & 255, myanc4 = (__float_as_int(q1.x) >> 16) & 255, myanc8 = (__float_as_int(q1.x) >> 24) & 255;
+  const bool isfree = bl && myjn == 1 && __float_as_int(JA[0].x) == 0;
+  V3 posl = {bp.x, bp.y, bp.z};
+  Q4 quatl = {bq.x, bq.y, bq.z, bq.w};
+  if (isfree) {
+    const int qa = __float_as_int(JA[0].y);
+    posl = ld3(s_qpos + qa);
+    quatl = qnormalize(ldq(s_qpos + qa + 3));
+  } else if (bl) {
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      if (jj < myjn) {
+        const int qa = __float_as_int(JA[jj].y);
+        const V3 laxis = {JB[jj].x, JB[jj].y, JB[jj].z}, lpos = {JC[jj].x, JC[jj].y, JC[jj].z};
+        const V3 axl = qrot(quatl, laxis);
+        const V3 ancl = qrot(quatl, lpos) + posl;
+        const float dq = s_qpos[qa] - JA[jj].w;
+        if (__float_as_int(JA[jj].x) == 2) posl = posl + axl * dq;
+        else {
+          quatl = qmul(quatl, axisangle(laxis, dq));
+          posl = ancl - qrot(quatl, lpos);
+        }
+      }
+    }
+  }
+  V3 mypos = posl;
+  Q4 myquat = quatl;
+  if (bl) {
+    reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
+    reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
+  }
+  gsync();
+  for (int r = 0, span = 1; span < M.nlevel - 1 || r == 0; r++, span <<= 1) {
+    const int anc = r == 0 ? myp : (r == 1 ? myanc2 : (r == 2 ? myanc4 : myanc8));
+    float4 pp4 = {0.f, 0.f, 0.f, 0.f}, pq4 = {1.f, 0.f, 0.f, 0.f};
+    if (bl) { const float4* Pp = reinterpret_cast<const float4*>(s_xpq + kXpqStride * anc); pp4 = Pp[0]; pq4 = Pp[1]; }
+    gsync();
+    if (bl && anc != 0) {
+      const Q4 pq = {pq4.x, pq4.y, pq4.z, pq4.w};
+      mypos = V3{pp4.x, pp4.y, pp4.z} + qrot(pq, mypos);
+      myquat = qnormalize(qmul(pq, myquat));
+      reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
+      reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
+    }
+    gsync();
+  }
+  // geoms: world position, z axis and orientation (the step kernel rotates the offset with the body's matrix: the same q2mat here)
+  if (lane < ng) {
+    const int g = lane, b = pf_gbody;
+    float mat[9];
+    q2mat(mat, ldq(s_xpq + kXpqStride * b + 4));
+    const V3 gp = ld3(s_xpq + kXpqStride * b) + mrot(mat, pf_gpos);
+    const Q4 q = qmul(ldq(s_xpq + kXpqStride * b + 4), pf_gquat);
+    const V3 ga = {2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z};
+    st3(s_gpos + 3 * g, gp); st3(s_gaxis + 3 * g, ga); stq(s_gquat + 4 * g, q);
+    float* o = P.stage.geom + ((size_t)env * ng + g) * 10;
+    o[0] = gp.x; o[1] = gp.y; o[2] = gp.z; o[3] = ga.x; o[4] = ga.y; o[5] = ga.z; o[6] = q.w; o[7] = q.x; o[8] = q.y; o[9] = q.z;
+  }
+  gsync();
+  int status = 0;
+  const int nwork = build_work_list(M, lane, s_gpos, s_gaxis, s_scratch, status);
+  const int* s_list = s_scratch;
+  const int* s_pinfo = s_scratch + kListMax;
+  const int* s_work = s_pinfo + 4 * kListMax;
+  int4* items = P.stage.item + (size_t)env * kWorkMax;
+  for (int w = lane; w < nwork; w += kGroup) {
+    const int item = s_work[w], idx = item >> 16;
+    items[w] = {s_list[idx], item & 0xffff, s_pinfo[4 * idx] | (s_pinfo[4 * idx + 1] << 16), s_pinfo[4 * idx + 2]};
+  }
+  if (lane == 0) {
+    P.stage.nwork[env] = nwork;
+    if (status) atomicOr(P.status + env, status);
+  }
+}
+
+// hb_narrow_kernel: one wave per (env, 64 work items); block b handles chunk b / nblk of env blk0 + b % nblk (the first nblk blocks carry
+// nearly all the work).  Each lane evaluates one item exactly as the fused step kernel would (eval_work_item).
+__global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp, const BatchPtrs P) {
+  DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
+  __shared__ float s_g[64 * 10];
+  const int lane = threadIdx.x;
+  const int chunk = (int)blockIdx.x / P.nblk, env = P.blk0 + (int)blockIdx.x % P.nblk;
+  const int nwork = min(max(P.stage.nwork[env], 0), kWorkMax);
+  if (chunk * kGroup >= nwork) return;
+  const int ng = M.ngeom;
+  float* s_gpos = s_g;
+  float* s_gaxis = s_g + 3 * 64;
+  float* s_gquat = s_g + 6 * 64;
+  if (lane < ng) {
+    const float* o = P.stage.geom + ((size_t)env * ng + lane) * 10;
+    st3(s_gpos + 3 * lane, {o[0], o[1], o[2]}); st3(s_gaxis + 3 * lane, {o[3], o[4], o[5]}); stq(s_gquat + 4 * lane, {o[6], o[7], o[8], o[9]});
+  }
+  gsync();
+  const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
+  const float* hdata = P.dr ? P.dr + (size_t)env * P.dr_stride + DL.o_hfield : (const float*)M.hfield_data;
+  const int w = chunk * kGroup + lane;
+  const bool have = w < nwork;
+  int4 it = {0, 0, 0, 1};
+  if (have) it = P.stage.item[(size_t)env * kWorkMax + w];
+  ConOut co0, co1;
+  int n;
+  V3 hint;
+  eval_work_item(M, hdata, have, it.x, it.y, it.z & 0xffff, it.z >> 16, it.w, s_gpos, s_gaxis, s_gquat, co0, co1, n, hint);
+  if (have) {
+    float4* R = P.stage.result + ((size_t)env * kWorkMax + w) * 4;
+    R[0] = {co0.dist, co0.pos.x, co0.pos.y, co0.pos.z};
+    R[1] = {co0.n.x, co0.n.y, co0.n.z, __int_as_float(n)};
+    R[2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
+    R[3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(it.x)};
+  }
+}
+
 // ---- MJPC task cost on the recorded read-out rows --------------------------------------------------------------
 // mjpc::Norm (mujoco_mpc/mjpc/norm.cc:50-208), value only
 __device__ __forceinline__ float mjpc_norm(int type, const float* x, int n, float p, float q) {
@@ -3108,8 +3319,7 @@ __global__ void hb_halton_ctrl_kernel(float* out, int T, int n_env, int nu, int 
 
 namespace hb {
 
-hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
-  size_t shmem = (size_t)lds_floats * sizeof(float);
+static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int solver, int nv, size_t shmem, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   if (variant == 2 && nv <= 20) hipLaunchKernelGGL(hb_step_newton_big20_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (variant == 2) hipLaunchKernelGGL(hb_step_newton_big28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
@@ -3119,6 +3329,30 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
   else if (nv <= 28) hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else hipLaunchKernelGGL(hb_step32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   return hipGetLastError();
+}
+
+// One step launch of the classic variant covers all nsteps.  A general variant with stage buffers runs every step as three launches
+// on the same stream: poses + work items, narrowphase (a small kernel at 2-4x the step kernel's occupancy: its time is chains of
+// dependent loads along the hulls' edge graphs), then the step kernel, which appends the results instead of colliding.
+hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
+  const size_t shmem = (size_t)lds_floats * sizeof(float);
+  if (variant == 0 || !P.stage.result) return launch_step_kernel(M_dev, variant, solver, nv, shmem, P, nsteps, stream);
+  for (int t = 0; t < nsteps; t++) {
+    BatchPtrs Q = P;
+    Q.t0 = P.t0 + t;
+    if (P.ctrl_mode == 1) Q.ctrl = P.ctrl + (size_t)t * P.n_env * P.stage.nu;
+    if (P.qpos_out) Q.qpos_out = P.qpos_out + (size_t)t * P.n_env * P.stage.nq;
+    if (P.qvel_out) Q.qvel_out = P.qvel_out + (size_t)t * P.n_env * P.stage.nv;
+    if (P.sensor_out) Q.sensor_out = P.sensor_out + (size_t)t * P.n_env * P.sensor_stride;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(hb_pose_kernel, dim3(P.nblk), dim3(kGroup), (size_t)P.stage.pose_lds, stream, M_dev, Q);
+    hipLaunchKernelGGL(hb_narrow_kernel, dim3(P.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = launch_step_kernel(M_dev, variant, solver, nv, shmem, Q, 1, stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
                         int env_offset, hipStream_t stream, float quat_perturb) {

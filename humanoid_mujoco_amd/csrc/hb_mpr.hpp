@@ -64,13 +64,10 @@ struct CObj {
   V3 pos;
   float mat[9];  // row-major rotation of the geom frame
   float r, h;    // size[0], size[1]
-  // mesh: the hull as an edge graph.  vert[0] = (x, y, z, link) of the hull's vertex 0, nbr = the neighbour records of the whole
-  // model: link = first record << 8 | count, record = (x, y, z of the neighbour, the neighbour's own link).  The support function
-  // climbs from the vertex its previous call of this test ended on (cur, cur_link): one batch of loads per move.
+  // mesh: the hull as an edge graph.  vert = the mesh's cube map of start records (x, y, z, link), nbr = the neighbour records of
+  // the whole model: link = first record << 8 | chunks, record = (x, y, z of the neighbour, the neighbour's own link).
   const float4 HB_CONST* vert;
   const float4 HB_CONST* nbr;
-  V3 cur;
-  int cur_link;
   float margin;
   V3 p0, p1, p2, p3, p4, p5;  // prism: bottom triangle 0..2, top triangle 3..5
 };
@@ -80,7 +77,7 @@ __device__ __forceinline__ V3d ccd_center(const CObj& o) {
   return widen(o.pos);
 }
 // the point farthest along dir (unit)
-__device__ __forceinline__ V3d ccd_support(CObj& o, V3d dir) {
+__device__ __forceinline__ V3d ccd_support(const CObj& o, V3d dir) {
   if (o.type < 0) {
     V3d best = widen(o.p0), c;
     double bd = dot(best, dir), v;
@@ -99,25 +96,47 @@ __device__ __forceinline__ V3d ccd_support(CObj& o, V3d dir) {
   else {
     // steepest ascent along the hull's edges (oracle: ccd_support): every neighbour is evaluated, the best one taken if it is
     // strictly better (ties to the first in the list); on a convex polytope a vertex with no better neighbour is a maximiser
-    // (exact ties - a direction perpendicular to a flat facet - are broken by a second, generic direction: see the oracle)
+    // (exact ties - a direction perpendicular to a flat facet - are broken by a second, generic direction: see the oracle), so
+    // the vertex a climb ends on does not depend on where it starts.  Every climb starts from the mesh's cube map of support
+    // vertices (the cell the direction falls in: 1.2 - 1.5 rounds on the reference's hulls, of which the last only confirms; from
+    // the previous call's vertex it was 2 - 5, from vertex 0 4 - 7: tools/mpr_stats.py).  A round is one batch of kMeshChunk
+    // independent 16-byte loads per chunk of the vertex's padded neighbour list.
+    V3 best;
+    int link;
+    {
+      const double ax = fabs(ld.x), ay = fabs(ld.y), az = fabs(ld.z);
+      const int axis = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
+      const double major = axis == 0 ? ld.x : (axis == 1 ? ld.y : ld.z);
+      const float inv = 1.f / (float)fabs(major);  // (single precision: this only picks the start)
+      const float u = (float)(axis == 0 ? ld.y : (axis == 1 ? ld.z : ld.x)) * inv, v = (float)(axis == 0 ? ld.z : (axis == 1 ? ld.x : ld.y)) * inv;
+      const int iu = min(max((int)floorf((u + 1.f) * 2.f), 0), 3), iv = min(max((int)floorf((v + 1.f) * 2.f), 0), 3);
+      const float4 s0 = o.vert[(2 * axis + (major < 0.0 ? 1 : 0)) * 16 + iu * 4 + iv];
+      best = {s0.x, s0.y, s0.z};
+      link = __float_as_int(s0.w);
+    }
     const double t0 = 0.41421356237309503, t1 = 0.7320508075688772;
-    V3 best = o.cur;
-    int link = o.cur_link;
-    double bd = (double)best.x * ld.x + (double)best.y * ld.y + (double)best.z * ld.z, bt = (double)best.x * t0 + (double)best.y * t1 + (double)best.z;
+    double bd = (double)best.x * ld.x + (double)best.y * ld.y + (double)best.z * ld.z;
     for (;;) {
-      const int adr = link >> 8, num = link & 255;
+      const int adr = link >> 8, nch = link & 255;
       bool moved = false;
       V3 nb = best;
       int nlink = link;
-      for (int i = 0; i < num; i++) {
-        const float4 q = o.nbr[adr + i];
-        const double v = (double)q.x * ld.x + (double)q.y * ld.y + (double)q.z * ld.z, t = (double)q.x * t0 + (double)q.y * t1 + (double)q.z;
-        if (v > bd || (v == bd && t > bt)) { bd = v; bt = t; nb = {q.x, q.y, q.z}; nlink = __float_as_int(q.w); moved = true; }
+      for (int c = 0; c < nch; c++) {
+        float4 q[kMeshChunk];
+#pragma unroll
+        for (int i = 0; i < kMeshChunk; i++) q[i] = o.nbr[adr + c * kMeshChunk + i];
+#pragma unroll
+        for (int i = 0; i < kMeshChunk; i++) {
+          const double v = (double)q[i].x * ld.x + (double)q[i].y * ld.y + (double)q[i].z * ld.z;
+          bool take = v > bd;
+          if (v == bd)  // exact tie (rare): the generic second direction decides
+            take = (double)q[i].x * t0 + (double)q[i].y * t1 + (double)q[i].z > (double)nb.x * t0 + (double)nb.y * t1 + (double)nb.z;
+          if (take) { bd = v; nb = {q[i].x, q[i].y, q[i].z}; nlink = __float_as_int(q[i].w); moved = true; }
+        }
       }
       if (!moved) break;
       best = nb; link = nlink;
     }
-    o.cur = best; o.cur_link = link;
     res = widen(best);
   }
   res = res + ld * (double)o.margin;
@@ -125,7 +144,7 @@ __device__ __forceinline__ V3d ccd_support(CObj& o, V3d dir) {
 }
 
 struct CSup { V3d v, v1; };  // a point of the Minkowski difference obj1 - obj2 and its witness on obj1 (the one on obj2 is v1 - v)
-__device__ __forceinline__ CSup mpr_support(CObj& o1, CObj& o2, V3d dir) {
+__device__ __forceinline__ CSup mpr_support(const CObj& o1, const CObj& o2, V3d dir) {
   CSup s;
   s.v1 = ccd_support(o1, dir);
   const V3d w2 = ccd_support(o2, dir * -1.0);
@@ -145,7 +164,7 @@ __device__ __forceinline__ void mpr_expand_portal(const CSup& P0, CSup& P1, CSup
 }
 
 // ccdMPRPenetration: true (and depth, dir from obj1 into obj2, pos) when the objects intersect
-__device__ __forceinline__ bool mpr_penetration(CObj& o1, CObj& o2, int max_iterations, double tolerance, float& depth_out, V3& pdir_out, V3& pos_out) {
+__device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, int max_iterations, double tolerance, float& depth_out, V3& pdir_out, V3& pos_out) {
   CSup P0, P1, P2, P3, v4;
   const V3d origin = {0.0, 0.0, 0.0};
   double depth;

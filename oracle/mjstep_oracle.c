@@ -634,6 +634,10 @@ static void ccd_center(const ccd_obj* o, double* c) {
     for (int k = 0; k < 3; k++) c[k] /= 6.0;
   } else memcpy(c, o->pos, 3 * sizeof(double));
 }
+/* diagnostic counters of the narrowphase (single-threaded use: tools/mpr_stats.py): tests, support calls on meshes, climb rounds
+ * (one evaluation of all neighbours of the current vertex), neighbour evaluations, portal iterations */
+static long long om_stat[8];
+void om_mpr_stats(long long* out, int reset) { for (int i = 0; i < 8; i++) { out[i] = om_stat[i]; if (reset) om_stat[i] = 0; } }
 /* mjccd_support / prism_support: the point of the object farthest along dir (dir is unit: every caller in mpr.c normalises) */
 static void ccd_support(ccd_obj* o, const double* dir, double* out) {
   if (o->type < 0) {
@@ -659,9 +663,11 @@ static void ccd_support(ccd_obj* o, const double* dir, double* out) {
     static const double tie[3] = {0.41421356237309503, 0.7320508075688772, 1.0};
     int cur = o->cur;
     double bd = dot3(o->vert + 3 * cur, ld), bt = dot3(o->vert + 3 * cur, tie);
+    om_stat[1]++;
     for (;;) {
       int best = cur;
       const int* nb = o->nbr + o->nbradr[cur];
+      om_stat[2]++; om_stat[3] += o->nbrnum[cur];
       for (int i = 0; i < o->nbrnum[cur]; i++) {
         double v = dot3(o->vert + 3 * nb[i], ld), t = dot3(o->vert + 3 * nb[i], tie);
         if (v > bd || (v == bd && t > bt)) { bd = v; bt = t; best = nb[i]; }
@@ -684,6 +690,7 @@ static void ccd_support(ccd_obj* o, const double* dir, double* out) {
 typedef struct { double v[3], v1[3], v2[3]; } ccd_sup;  /* a point of the Minkowski difference obj1 - obj2 and its two witnesses */
 static void mpr_support(ccd_obj* o1, ccd_obj* o2, const double* dir, ccd_sup* s) {
   double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  om_stat[4]++;
   ccd_support(o1, dir, s->v1);
   ccd_support(o2, nd, s->v2);
   for (int i = 0; i < 3; i++) s->v[i] = s->v1[i] - s->v2[i];
@@ -735,11 +742,12 @@ static double origin_tri_dist2(const double* a, const double* b, const double* c
 }
 
 /* ccdMPRPenetration: 0 and (depth, dir, pos) when the objects intersect, -1 otherwise.  dir points from obj1 into obj2. */
-static int mpr_penetration(ccd_obj* o1, ccd_obj* o2, int max_iterations, double tolerance, double* depth, double* pdir, double* pos) {
+static int mpr_penetration_core(ccd_obj* o1, ccd_obj* o2, int max_iterations, double tolerance, double* depth, double* pdir, double* pos) {
   ccd_sup P[4];
   double dir[3], va[3], vb[3];
   const double origin[3] = {0, 0, 0};
   /* ---- discoverPortal */
+  om_stat[0]++;
   ccd_center(o1, P[0].v1); ccd_center(o2, P[0].v2);
   vsub(P[0].v, P[0].v1, P[0].v2);
   if (ccd_vec_eq(P[0].v, origin)) P[0].v[0] += CCD_EPS * 10;  /* centres coincide: nudge */
@@ -871,6 +879,16 @@ static void fix_normal(const om_model* m, const om_data* d, om_contact* c, int g
 }
 
 /* mjc_Convex: two convex geoms (at least one of them a mesh here), one contact (multiccd is off by default, mjmodel.h:75) */
+/* (diagnostics: om_stat[5] = most support calls of one test, om_stat[6] = tests with more than 16, om_stat[7] = tests that hit) */
+static int mpr_penetration(ccd_obj* o1, ccd_obj* o2, int max_iterations, double tolerance, double* depth, double* pdir, double* pos) {
+  const long long before = om_stat[4];
+  const int rc = mpr_penetration_core(o1, o2, max_iterations, tolerance, depth, pdir, pos);
+  const long long used = om_stat[4] - before;
+  if (used > om_stat[5]) om_stat[5] = used;
+  if (used > 16) om_stat[6]++;
+  if (rc == 0) om_stat[7]++;
+  return rc;
+}
 static int convex_convex(const om_model* m, const om_data* d, om_contact* con, int g1, int g2, double margin) {
   ccd_obj o1, o2;
   ccd_obj_from_geom(m, d, g1, 0.5 * margin, &o1);

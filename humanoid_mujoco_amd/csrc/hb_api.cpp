@@ -45,6 +45,8 @@ struct DeviceModel {
   unsigned long long* d_u64 = nullptr;
   float* d_qpos_src = nullptr;  // qpos0 followed by keyframes, fp32
   DevModel* d_dm = nullptr;     // device copy of dm (the step kernel reads the tables through it)
+  DevModel* d_dm_fast = nullptr;  // variant 2 only: the same model with the variant-1 LDS layout (fast step kernel of the staged step)
+  int fast_lds_floats = 0;
   // observation order tables (device pointers): joint order and, when it exists, actuator order (hb_env_config.obs_actuator_order)
   const int *obs_jnt_joint = nullptr, *obs_src_joint = nullptr, *obs_jnt_act = nullptr, *obs_src_act = nullptr;
   bool has_act_order = false;
@@ -54,6 +56,7 @@ struct DeviceModel {
     if (d_u64) (void)hipFree(d_u64);
     if (d_qpos_src) (void)hipFree(d_qpos_src);
     if (d_dm) (void)hipFree(d_dm);
+    if (d_dm_fast) (void)hipFree(d_dm_fast);
   }
 };
 
@@ -99,6 +102,9 @@ bool model_variant(const Model& m, int& variant, int& ncon_max, int& nefc_max, s
   variant = 0; ncon_max = kNconMax; nefc_max = kNefcMax;
   if (!general) return true;
   if (m.nv > 28) { err = "models with mesh geoms, height fields or condim 4 / 6 support at most 28 degrees of freedom in this build"; return false; }
+  if (m.npair > 65535) { err = "general collision: more than 65535 candidate pairs"; return false; }  // (packed work-item words, hb_pose_kernel)
+  for (int h = 0; h < m.nhfield; h++)
+    if (m.hfield_nrow[h] > 32767 || m.hfield_ncol[h] > 32767) { err = "height fields larger than 32767 x 32767 are not supported"; return false; }
   if (m.solver == SOL_NEWTON) { variant = 2; ncon_max = kBigNconMax; nefc_max = kBigNefcMax; }
   else variant = 1;
   return true;
@@ -161,7 +167,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     for (int j = i; j >= 0; j = m.dof_parentid[j]) { Mi[adr] = i; Mj[adr] = j; adr++; }
   }
   if (m.nM > 1023) { err = "sparse mass matrix too large for the packed index tables"; return false; }
-  // ---- LDS layout
+  // ---- LDS layout (a function of the variant: a variant-2 model also gets the variant-1 layout for its fast step kernel)
+  auto lay = [&](DevModel& dm) -> bool {
   int off = 0;
   auto take = [&](int n) { int o = off; off += (n + 3) & ~3; return o; };
   // row stride of C: 33 (K = 32 for the matrix cores plus a pad column); the big Newton layout stores J rows only as wide as its dense
@@ -202,6 +209,9 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
   dm.lds_floats = std::max(endA, endB);
   if (dm.lds_floats * 4 > 160 * 1024) { err = "model needs more LDS than one CU has"; return false; }
+  return true;
+  };
+  if (!lay(dm)) return false;
 
   std::vector<int> mdense((size_t)32 * 32, m.nM);
   for (int i = 0; i < 32; i++) mdense[(size_t)i * 32 + i] = m.nM + 1;
@@ -505,6 +515,17 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   if (hipMalloc((void**)&D.d_qpos_src, qsrc.size() * sizeof(float)) != hipSuccess ||
       hipMemcpy(D.d_qpos_src, qsrc.data(), qsrc.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMalloc failed for qpos sources"; return false; }
   if (hipMalloc((void**)&D.d_dm, sizeof(DevModel)) != hipSuccess || hipMemcpy(D.d_dm, &dm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMalloc failed for the device model"; return false; }
+  // A variant-2 model (Newton on 256 rows in four register groups: one wave per SIMD) almost always has at most 63 rows and 24
+  // contacts in a step: its staged step first runs the one-group Newton instantiation (two waves per SIMD) on the variant-1 LDS
+  // layout and falls back to the four-group kernel for the envs that overflow (launch_step).  Same tables, other offsets.
+  D.fast_lds_floats = 0;
+  if (dm.variant == 2) {
+    DevModel fm = dm;
+    fm.variant = 1; fm.ncon_max = kNconMax; fm.nefc_max = kNefcMax;
+    if (!lay(fm)) return false;
+    if (hipMalloc((void**)&D.d_dm_fast, sizeof(DevModel)) != hipSuccess || hipMemcpy(D.d_dm_fast, &fm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMalloc failed for the device model"; return false; }
+    D.fast_lds_floats = fm.lds_floats;
+  }
   return true;
 }
 
@@ -619,6 +640,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
   P.dr = b->d_dr; P.dr_stride = b->dr_stride;
   P.stamps = b->d_stamps;
   P.stage = b->stage;
+  if (b->diag) P.stage.dm_fast = nullptr;  // the diagnostic buffers are laid out for the kernel of the model's own variant
   if (b->xfrc_std > 0.f && b->d_xfrc) {
     const double rate = b->xfrc_rate > 0.f ? std::exp(-b->model->m.timestep / b->xfrc_rate) : 0.0;  // trajectory.cc:149-150
     P.xfrc_rate = (float)rate; P.xfrc_scale = (float)(b->xfrc_std * std::sqrt(1.0 - rate * rate));
@@ -904,10 +926,18 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
     ok = ok && hipMalloc((void**)&sb.geom, (size_t)n_env * std::max(1, dm.ngeom) * 10 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&sb.item, (size_t)n_env * kWorkMax * sizeof(int4)) == hipSuccess;
     ok = ok && hipMalloc((void**)&sb.nwork, (size_t)n_env * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&sb.nsearch, (size_t)n_env * 2 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMemset(sb.nsearch, 0, (size_t)n_env * 2 * sizeof(int)) == hipSuccess;
     ok = ok && hipMalloc((void**)&sb.result, (size_t)n_env * kWorkMax * 4 * sizeof(float4)) == hipSuccess;
     ok = ok && hipMemset(sb.nwork, 0, (size_t)n_env * sizeof(int)) == hipSuccess;
     sb.nq = dm.nq; sb.nv = dm.nv; sb.nu = dm.nu;
     sb.pose_lds = pose_lds_floats(dm.nq, dm.nbody, dm.ngeom) * (int)sizeof(float);
+    if ((dm.variant == 1 || b->D.d_dm_fast) && !(getenv("HB_FASTPASS") && atoi(getenv("HB_FASTPASS")) == 0)) {
+      ok = ok && hipMalloc((void**)&sb.defer, (size_t)n_env * sizeof(int)) == hipSuccess;
+      ok = ok && hipMemset(sb.defer, 0, (size_t)n_env * sizeof(int)) == hipSuccess;
+      if (dm.variant == 2) { sb.dm_fast = b->D.d_dm_fast; sb.fast_lds = b->D.fast_lds_floats * (int)sizeof(float); }
+      if (ok && sb.fast_lds > 64 * 1024) ok = set_step_lds_limit(sb.fast_lds) == hipSuccess;
+    }
   }
   if (hb_debug()) fprintf(stderr, "[hb] LDS per env: %d bytes (%d envs per CU)\n", dm.lds_floats * 4, 160 * 1024 / (dm.lds_floats * 4));
   if (ok && dm.lds_floats * 4 > 64 * 1024) ok = set_step_lds_limit(dm.lds_floats * 4) == hipSuccess;
@@ -936,7 +966,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_dr) HB_IGN(hipFree(b->d_dr));
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
-  void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nwork, b->stage.result, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
+  void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nsearch, b->stage.nwork, b->stage.result, b->stage.defer, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
                   b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
@@ -2091,6 +2121,19 @@ int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter) {
     if (ncon) ncon[e] = h[kCountStride * e];
     if (nefc) nefc[e] = h[kCountStride * e + 1];
     if (niter) niter[e] = h[kCountStride * e + 2];
+  }
+  return HB_OK;
+}
+
+int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch) {
+  if (!b) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  std::vector<int> h((size_t)b->n_env * kCountStride);
+  HB_HIP(hipMemcpy(h.data(), b->d_counts, h.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (int e = 0; e < b->n_env; e++) {
+    if (nwork) nwork[e] = h[kCountStride * e + 5];
+    if (nsearch) nsearch[e] = h[kCountStride * e + 6];
   }
   return HB_OK;
 }

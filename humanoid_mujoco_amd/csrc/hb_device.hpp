@@ -226,11 +226,21 @@ struct PolicyDesc {
 // narrowphase work items, hb_narrow_kernel evaluates the items (one per lane, at the occupancy of a small kernel: the MPR climbs are
 // chains of dependent loads), the step kernel appends the results in item order.  All null: the step kernel does all of it itself.
 struct StageBufs {
-  float* geom;     // [n_env][ngeom][10]: world position[3], z axis[3], orientation quaternion[4]
-  int4* item;      // [n_env][kWorkMax]: pair, sub-item, rmin | cmin << 16, ncols (sub-grid of a height-field pair)
+  float* geom;     // [n_env][10 ngeom]: world positions[3 ngeom] | z axes[3 ngeom] | orientation quaternions[4 ngeom]
+  int4* item;      // [n_env][kWorkMax]: the env's items that need a portal search: prisms of height-field pairs from the front, pairs
+                   // of geoms from the back, each in item order:
+                   // env, pair | item index << 16, sub-item | ncols << 16, rmin | cmin << 16 (sub-grid of a height-field pair)
+  int* nsearch;    // [n_env][2] how many of each kind
   int* nwork;      // [n_env] work items of the env (clamped to kWorkMax)
   float4* result;  // [n_env][kWorkMax][4]: dist0, pos0 | normal0, n | dist1, pos1 | normal1, pair
   int nq, nv, nu, pose_lds;  // host-side copies for the per-step pointer arithmetic and the pose kernel's LDS bytes
+  // Variant 2 (Newton, 256 rows in four register groups, one wave per SIMD): the step kernel proper is first the ONE-group
+  // instantiation on the variant-1 layout (dm_fast; 63 rows, 24 contacts, two waves per SIMD); an env whose step needs more
+  // raises defer[env] and leaves its state alone, and the four-group kernel then steps exactly those envs (rerun = 1).
+  const DevModel* dm_fast;  // null: no fast pass (not variant 2, or diagnostics on: their buffers have the big kernel's strides)
+  int fast_lds;             // its dynamic LDS bytes
+  int* defer;               // [n_env]
+  int rerun;                // set by launch_step for the second pass
 };
 
 // LDS of hb_pose_kernel in floats: qpos | body poses (12 floats each, kXpqStride) | geom position, z axis, quaternion | the work lists

@@ -102,6 +102,7 @@ __device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
   return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
           a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
 }
+__device__ __forceinline__ Q4 qconj(Q4 q) { return {q.w, -q.x, -q.y, -q.z}; }
 __device__ __forceinline__ Q4 qnormalize(Q4 q) {
   const float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
   if (n2 < HB_MINVAL * HB_MINVAL) return {1.f, 0.f, 0.f, 0.f};
@@ -585,6 +586,46 @@ __device__ __forceinline__ void set_mesh(DevModelRef M, CObj& o, int g) {
   o.nbr = M.mesh_nbr;
 }
 
+// lowest point (z, relative to the geom's position) of geom g with orientation q in the frame the query is made in: the support
+// function along -z.  Single precision: the value only decides whether a prism under the geom is searched (the prism's top is
+// compared with it), and a vertex within rounding of the lowest one gives the same answer to within that rounding.
+__device__ __forceinline__ float lowest_point(DevModelRef M, int g, int type, float r, float h, Q4 q) {
+  float m[9];
+  q2mat(m, q);
+  const V3 ld = {-m[6], -m[7], -m[8]};  // mat' (0, 0, -1): the query direction in the geom's frame
+  if (type == 2) return -r;
+  if (type == 3) return -r - fabsf(ld.z) * h;  // mat (ld r + (0, 0, sign(ld.z) h)) . z = -r - |ld.z| h
+  if (type != 7 || M.geom_meshnum[g] <= 0) return -M.geom_rbound[g];
+  const float4 HB_CONST* start = M.mesh_start + kMeshStart * M.geom_dataid[g];
+  const float ax = fabsf(ld.x), ay = fabsf(ld.y), az = fabsf(ld.z);
+  const int axis = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
+  const float major = axis == 0 ? ld.x : (axis == 1 ? ld.y : ld.z);
+  const float inv = 1.f / fabsf(major);
+  const float u = (axis == 0 ? ld.y : (axis == 1 ? ld.z : ld.x)) * inv, v = (axis == 0 ? ld.z : (axis == 1 ? ld.x : ld.y)) * inv;
+  const int iu = min(max((int)floorf((u + 1.f) * 2.f), 0), 3), iv = min(max((int)floorf((v + 1.f) * 2.f), 0), 3);
+  const float4 s0 = start[(2 * axis + (major < 0.f ? 1 : 0)) * 16 + iu * 4 + iv];
+  float bd = __builtin_fmaf(s0.x, ld.x, __builtin_fmaf(s0.y, ld.y, s0.z * ld.z));  // (one fixed operation sequence for start and neighbours: hb_mpr.hpp, hull_val)
+  int link = __float_as_int(s0.w);
+  for (int guard = 0; guard < 256; guard++) {
+    const int adr = link >> 8, nch = link & 255;
+    bool moved = false;
+    int nlink = link;
+    for (int c = 0; c < nch; c++) {
+      float4 nb[kMeshChunk];
+#pragma unroll
+      for (int i = 0; i < kMeshChunk; i++) nb[i] = M.mesh_nbr[adr + c * kMeshChunk + i];
+#pragma unroll
+      for (int i = 0; i < kMeshChunk; i++) {
+        const float val = __builtin_fmaf(nb[i].x, ld.x, __builtin_fmaf(nb[i].y, ld.y, nb[i].z * ld.z));
+        if (val > bd) { bd = val; nlink = __float_as_int(nb[i].w); moved = true; }
+      }
+    }
+    if (!moved) break;
+    link = nlink;
+  }
+  return -bd;  // the support point's z in the query frame is -(v . ld)
+}
+
 // mj_collision for models with mesh geoms and / or a height field (the reference's own robot: simulation/assets/world.xml:14-58).
 // Three passes over LDS lists: (1) broadphase per candidate pair, survivors in pair order; (2) work items: one per pair, or one
 // per prism of the sub-grid under the geom for a height-field pair (mjc_ConvexHField's double loop, flattened); (3) narrowphase,
@@ -594,9 +635,9 @@ __device__ __forceinline__ void set_mesh(DevModelRef M, CObj& o, int g) {
 // appends the results (collide_gather).
 //
 // passes (1) and (2): s_scratch receives the pair list, the sub-grids of height-field pairs and the work items; returns the number of work items
-__device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const float* s_gpos, const float* s_gaxis, int* s_scratch, int& status) {
+__device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const float* s_gpos, const float* s_gaxis, const float* s_gquat, int* s_scratch, int& status) {
   int* s_list = s_scratch;                   // [kListMax]
-  int* s_pinfo = s_scratch + kListMax;       // [kListMax][4]: rmin, cmin, ncols, nrows of a height-field pair's sub-grid
+  int* s_pinfo = s_scratch + kListMax;       // [kListMax][4]: rmin, cmin, ncols of a height-field pair's sub-grid, lowest point of the geom (float bits)
   int* s_work = s_pinfo + 4 * kListMax;      // [kWorkMax]: list index << 16 | sub-item
   int nlist = 0;
   for (int p0 = 0; p0 < M.npair; p0 += kGroup) {
@@ -628,8 +669,10 @@ __device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const fl
       const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y), t1 = __float_as_int(c0.z) & 255;
       cnt = 1;
       if (t1 == 1) {
-        // mjc_ConvexHField's culling with the geom's bounding sphere in place of its exact bounding box (a superset of the
-        // oracle's prisms: the extra ones do not intersect the geom, so they add no contact)
+        // mjc_ConvexHField's culling.  The sub-grid comes from the geom's bounding sphere in place of its exact bounding box (a superset
+        // of MuJoCo's prisms in x and y: the extra ones lie outside the geom's footprint and cannot touch it), the height test from the
+        // geom's exact lowest point in the field's frame (one support query along -z; MuJoCo's box has the same bottom), so that a
+        // prism under a raised limb is not searched at all.
         float hm[9];
         q2mat(hm, ldq(M.geom_quat + 4 * g1));
         const int hid = M.geom_dataid[g1];
@@ -645,7 +688,9 @@ __device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const fl
           cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, ncol - 1); rmax = min(rmax, nrow - 1);
           const int ncols = max(cmax - cmin, 0), nrows = max(rmax - rmin, 0);
           cnt = nrows * 2 * ncols;
-          s_pinfo[4 * idx] = rmin; s_pinfo[4 * idx + 1] = cmin; s_pinfo[4 * idx + 2] = ncols; s_pinfo[4 * idx + 3] = nrows;
+          const float4 c2 = M.crec[3 * (size_t)p + 2];
+          const float loz = q.z + lowest_point(M, g2, (__float_as_int(c0.z) >> 8) & 255, c2.x, c2.y, qmul(qconj(ldq(M.geom_quat + 4 * g1)), ldq(s_gquat + 4 * g2)));
+          s_pinfo[4 * idx] = rmin; s_pinfo[4 * idx + 1] = cmin; s_pinfo[4 * idx + 2] = ncols; s_pinfo[4 * idx + 3] = __float_as_int(loz);
         }
       }
     }
@@ -660,9 +705,12 @@ __device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const fl
   return nwork;
 }
 
-// pass (3) for one work item: pair p (sub-item `sub` of the sub-grid rmin, cmin, ncols for a height-field pair) -> n contacts (0..2)
-__device__ __forceinline__ void eval_work_item(DevModelRef M, const float* hdata_all, bool have, int p, int sub, int rmin, int cmin, int ncols,
-                                               const float* s_gpos, const float* s_gaxis, const float* s_gquat, ConOut& co0, ConOut& co1, int& n, V3& hint) {
+// pass (3) for one work item: pair p (sub-item `sub` of the sub-grid rmin, cmin, ncols for a height-field pair) -> n contacts (0..2).
+// MODE 0: all of it.  MODE 1 (hb_pose_kernel): everything but the portal search; returns whether the item needs one (then n = 0).
+// MODE 2 (hb_narrow_kernel): an item MODE 1 said needs the portal search.
+template <int MODE>
+__device__ __forceinline__ int eval_work_item(DevModelRef M, const float* hdata_all, bool have, int p, int sub, int rmin, int cmin, int ncols, float loz,
+                                              const float* s_gpos, const float* s_gaxis, const float* s_gquat, ConOut& co0, ConOut& co1, int& n, V3& hint) {
   float4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
   if (have) { const float4 HB_CONST* N = M.crec + 3 * (size_t)p; c0 = N[0]; c1 = N[1]; c2 = N[2]; }
   co0.dist = 0.f; co0.pos = {0.f, 0.f, 0.f}; co0.n = {0.f, 0.f, 1.f}; co1 = co0;
@@ -699,7 +747,7 @@ __device__ __forceinline__ void eval_work_item(DevModelRef M, const float* hdata
       // geom 2 in the field's frame
       const V3 dif = pos2 - pos1;
       o2.pos = {hm[0] * dif.x + hm[3] * dif.y + hm[6] * dif.z, hm[1] * dif.x + hm[4] * dif.y + hm[7] * dif.z, hm[2] * dif.x + hm[5] * dif.y + hm[8] * dif.z};
-      if (!(tv[0].z < o2.pos.z - rb2 && tv[1].z < o2.pos.z - rb2 && tv[2].z < o2.pos.z - rb2)) {  // (prism height test, with the bounding sphere's lowest point)
+      if (MODE == 2 || !(tv[0].z < loz && tv[1].z < loz && tv[2].z < loz)) {  // prism below the geom's lowest point (loz: build_work_list); MODE 2: tested before
         float m2[9];
         q2mat(m2, ldq(s_gquat + 4 * g2));
 #pragma unroll
@@ -723,6 +771,7 @@ __device__ __forceinline__ void eval_work_item(DevModelRef M, const float* hdata
       o2.type = t2; o2.pos = pos2; o2.r = r2; o2.h = l2; o2.margin = 0.5f * margin; set_mesh(M, o2, g2);
       o1.p0 = o1.p1 = o1.p2 = o1.p3 = o1.p4 = o1.p5 = V3{0.f, 0.f, 0.f};
       mpr_kind = 2;
+    } else if (MODE == 2) {  // (the analytic pairs never reach the narrowphase kernel)
     } else if (t1 == 0) {
       const V3 normal = ld3(s_gaxis + 3 * g1);
       if (dot(pos2 - pos1, normal) <= margin + rb2) {
@@ -746,6 +795,7 @@ __device__ __forceinline__ void eval_work_item(DevModelRef M, const float* hdata
       } else n = capsule_capsule(co0, co1, margin, pos1, ld3(s_gaxis + 3 * g1), r1, l1, pos2, ax2, r2, l2);
     }
   }
+  if constexpr (MODE == 1) return mpr_kind;
   if (mpr_kind) {
     float depth;
     V3 dir, vec;
@@ -779,6 +829,7 @@ __device__ __forceinline__ void eval_work_item(DevModelRef M, const float* hdata
       }
     }
   }
+  return mpr_kind;
 }
 
 // ordered append of one round's results: slot = ncon + (# contacts of lower lanes)
@@ -811,7 +862,7 @@ __device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata
   const int* s_list = s_scratch;
   const int* s_pinfo = s_scratch + kListMax;
   const int* s_work = s_pinfo + 4 * kListMax;
-  const int nwork = build_work_list(M, lane, s_gpos, s_gaxis, s_scratch, status);
+  const int nwork = build_work_list(M, lane, s_gpos, s_gaxis, s_gquat, s_scratch, status);
   int ncon = 0;
   for (int w0 = 0; w0 < nwork; w0 += kGroup) {
     const bool have = w0 + lane < nwork;
@@ -821,7 +872,7 @@ __device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata
     ConOut co0, co1;
     int n;
     V3 hint;
-    eval_work_item(M, hdata_all, have, p, sub, s_pinfo[4 * idx], s_pinfo[4 * idx + 1], s_pinfo[4 * idx + 2], s_gpos, s_gaxis, s_gquat, co0, co1, n, hint);
+    eval_work_item<0>(M, hdata_all, have, p, sub, s_pinfo[4 * idx], s_pinfo[4 * idx + 1], s_pinfo[4 * idx + 2], __int_as_float(s_pinfo[4 * idx + 3]), s_gpos, s_gaxis, s_gquat, co0, co1, n, hint);
     append_contacts<NC>(lane, s_con, ncon, n, co0, co1, hint, p);
   }
   if (ncon > NC) { status |= (1 << 1); ncon = NC; }
@@ -862,7 +913,11 @@ __device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, 
 // COLL: 0 = the classic narrowphase (plane / sphere / capsule pairs, condim 1 / 3, inline), 1 = the general one (adds mesh hulls and
 // height-field prisms through MPR, condim 4 / 6).  NG: constraint rows live in NG groups of 64 (lane l owns rows l + 64 g); NG > 1
 // only with the Newton solver (kBigGroups: 256 rows, for the reference's own robot: ten pyramid rows per condim-6 contact).
-template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1>
+// DEFER: the fast pass of a staged step.  1 (variant 2, StageBufs::dm_fast): an env-step that overflows this instantiation's rows or
+// contacts is not stepped here but flagged for the four-group kernel.  2 (variant 1): same capacities as the full kernel, nothing to
+// overflow into.  Both: an env-step whose qacc comes out bad (mj_checkAcc: reset, second forward pass with a narrowphase of its own) is
+// flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
+template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0>
 __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps) {
   static_assert(NG == 1 || SOLVER == 2, "more than one row group: Newton only");
   constexpr int kNR = NG == 1 ? kNefcMax : 64 * NG;  // row capacity of this instantiation
@@ -880,6 +935,13 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   const int slot = P.blk0 + (int)blockIdx.x;
   const int env = P.order ? P.order[slot] : slot;
   if (P.env_mask && !P.env_mask[env]) return;  // masked stepping (hb_env_reset's settle step)
+  if constexpr (COLL != 0 && DEFER == 0) {
+    if (P.stage.rerun) {  // second pass of a staged step: only the envs the fast pass deferred
+      const int d = P.stage.defer[env];
+      if (!d) return;
+      if (lane0 == 0) P.stage.defer[env] = 0;
+    }
+  }
   // per-env model parameters (domain randomisation), nullable; offsets per DomainLayout
   const float* dr = P.dr ? P.dr + (size_t)env * P.dr_stride : nullptr;
   const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
@@ -1393,7 +1455,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     gsync();
     // xfrc_applied: Cartesian wrench at each body com (mj_xfrcAccumulate)
     if (P.xfrc) {
-      if (P.xfrc_scale > 0.f && P.integrate) {  // (a plain mj_forward - hb_forward, the terminal read-out - leaves the process where it is)
+      if (P.xfrc_scale > 0.f && P.integrate && !P.stage.rerun) {  // (a plain mj_forward - hb_forward, the terminal read-out - leaves the process where it is;
+        // the rerun of a deferred env-step finds the process already advanced by the fast pass)
         // Trajectory::NoisyRollout's perturbation (trajectory.cc:147-156): Ornstein-Uhlenbeck noise on every xfrc_applied entry
         float* xw = P.xfrc + (size_t)env * nb * 6;
         for (int i = lane; i < 6 * nb; i += kGroup)
@@ -1429,7 +1492,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       if (contacts_on) {
         // staged step: the narrowphase ran in its own kernel on this step's poses (launch_step); the second forward pass of a step
         // whose first one was reset (mj_checkAcc) runs on other poses and does its own
-        if (P.stage.result && !redo) ncon = collide_gather<kNC>(M, lane, env, P.stage, s_gaxis, s_con, status);
+        if (DEFER != 0 || (P.stage.result && !redo)) ncon = collide_gather<kNC>(M, lane, env, P.stage, s_gaxis, s_con, status);  // (DEFER: always staged, never a second pass)
         else ncon = collide_general<kNC>(M, dr ? dr + DL.o_hfield : (const float*)M.hfield_data, lane, s_gpos, s_gaxis, s_gquat, s_con, reinterpret_cast<int*>(s_C), status);
       }
     } else if (contacts_on) {
@@ -1596,6 +1659,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
           c[C_FRIC] = fmaxf(1e-5f, dr ? fmaxf(M.pair_fricab[2 * pairid] * dr[DL.o_fric], M.pair_fricab[2 * pairid + 1]) : M.pair_friction[3 * pairid]);
         }
         if (__ballot(lane < ncon && incl && !fits)) status |= (1 << 2);
+        if constexpr (DEFER == 1) {
+          if (status & ((1 << 1) | (1 << 2))) {  // more contacts or rows than this instantiation holds: the four-group kernel steps this env
+            if (lane == 0) P.stage.defer[env] = 1;
+            return;
+          }
+        }
         const unsigned long long placed = __ballot(lane < ncon && incl && fits);
         const int nefc_after = placed ? __builtin_amdgcn_readlane(base + myrows, 63 - __builtin_clzll(placed)) : nefc;
         gsync();
@@ -2310,6 +2379,10 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       bool bad = false;
       for (int i = lane; i < nv; i += kGroup) bad |= !(fabsf(s_v0[i]) <= HB_MAXVAL);
       if (__any(bad)) {
+        if constexpr (DEFER != 0) {  // the reset and the second forward pass (with a narrowphase of its own) are the four-group kernel's
+          if (lane == 0) P.stage.defer[env] = 1;
+          return;
+        }
         status |= (1 << 6);
         for (int i = lane; i < nq; i += kGroup) s_qpos[i] = M.qpos0[i];
         for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; s_v0[i] = 0.f; }
@@ -2463,8 +2536,12 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step32_kernel(const DevModel* Mp
 // General instantiations (mesh hulls, height-field prisms, condim 4 / 6): PGS on 63 rows (configs[4]: the 27-dof humanoid on terrain),
 // Newton on 256 rows (the reference's own robot, simulation/assets/world.xml: 18 dofs -> dense order 20; up to 28 dofs)
 __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2>(Mp, P, nsteps); }  // staged step, fast pass
 __global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big20_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, kBigGroups>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 1, kBigGroups>(Mp, P, nsteps); }
+// fast pass of a variant-2 model's staged step: Newton on one row group, general collision results, deferring what does not fit
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 1, 1, 1>(Mp, P, nsteps); }
 // Newton instantiations: dense order 28 (nv <= 28: the 27-dof humanoid) and 32
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
@@ -2478,7 +2555,7 @@ __global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, 
   const int lane = threadIdx.x;
   if ((int)blockIdx.x >= P.nblk) return;
   const int env = P.blk0 + (int)blockIdx.x;
-  if (P.env_mask && !P.env_mask[env]) { if (lane == 0) P.stage.nwork[env] = 0; return; }
+  if (P.env_mask && !P.env_mask[env]) { if (lane == 0) { P.stage.nwork[env] = 0; P.stage.nsearch[2 * env] = 0; P.stage.nsearch[2 * env + 1] = 0; } return; }
   const int nq = M.nq, nv = M.nv, nb = M.nbody, ng = M.ngeom;
   float* s_qpos = lds;
   float* s_xpq = s_qpos + ((nq + 3) & ~3);
@@ -2565,60 +2642,87 @@ __global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, 
     const Q4 q = qmul(ldq(s_xpq + kXpqStride * b + 4), pf_gquat);
     const V3 ga = {2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z};
     st3(s_gpos + 3 * g, gp); st3(s_gaxis + 3 * g, ga); stq(s_gquat + 4 * g, q);
-    float* o = P.stage.geom + ((size_t)env * ng + g) * 10;
-    o[0] = gp.x; o[1] = gp.y; o[2] = gp.z; o[3] = ga.x; o[4] = ga.y; o[5] = ga.z; o[6] = q.w; o[7] = q.x; o[8] = q.y; o[9] = q.z;
+    float* o = P.stage.geom + (size_t)env * ng * 10;  // per env: positions[3 ng] | z axes[3 ng] | quaternions[4 ng]
+    st3(o + 3 * g, gp); st3(o + 3 * ng + 3 * g, ga); stq(o + 6 * ng + 4 * g, q);
   }
   gsync();
   int status = 0;
-  const int nwork = build_work_list(M, lane, s_gpos, s_gaxis, s_scratch, status);
+  const int nwork = build_work_list(M, lane, s_gpos, s_gaxis, s_gquat, s_scratch, status);
   const int* s_list = s_scratch;
   const int* s_pinfo = s_scratch + kListMax;
   const int* s_work = s_pinfo + 4 * kListMax;
+  // Every item but its portal search (the analytic pairs completely; a prism's height test): results of the items that are done
+  // go straight to the step kernel's input, the others are listed for hb_narrow_kernel, which packs them 64 to a wave whatever env
+  // they belong to (an env has about nine: one wave per env would run mostly empty).
+  const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
+  const float* hdata = P.dr ? P.dr + (size_t)env * P.dr_stride + DL.o_hfield : (const float*)M.hfield_data;
+  float4* R = P.stage.result + (size_t)env * kWorkMax * 4;
   int4* items = P.stage.item + (size_t)env * kWorkMax;
-  for (int w = lane; w < nwork; w += kGroup) {
-    const int item = s_work[w], idx = item >> 16;
-    items[w] = {s_list[idx], item & 0xffff, s_pinfo[4 * idx] | (s_pinfo[4 * idx + 1] << 16), s_pinfo[4 * idx + 2]};
+  int nsearch1 = 0, nsearch2 = 0;
+  for (int w0 = 0; w0 < nwork; w0 += kGroup) {
+    const int w = w0 + lane;
+    const bool have = w < nwork;
+    const int item = have ? s_work[w] : 0;
+    const int idx = item >> 16, sub = item & 0xffff;
+    const int p = have ? s_list[idx] : 0;
+    const int rmin = s_pinfo[4 * idx], cmin = s_pinfo[4 * idx + 1], ncols = s_pinfo[4 * idx + 2];
+    ConOut co0, co1;
+    int n;
+    V3 hint;
+    const int kind = eval_work_item<1>(M, hdata, have, p, sub, rmin, cmin, ncols, __int_as_float(s_pinfo[4 * idx + 3]), s_gpos, s_gaxis, s_gquat, co0, co1, n, hint);
+    if (have && !kind) {
+      R[4 * w] = {co0.dist, co0.pos.x, co0.pos.y, co0.pos.z};
+      R[4 * w + 1] = {co0.n.x, co0.n.y, co0.n.z, __int_as_float(n)};
+      R[4 * w + 2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
+      R[4 * w + 3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(p)};
+    }
+    // (the env's own slots: prism searches from the front, pair searches from the back)
+    const unsigned long long need1 = __ballot(have && kind == 1), need2 = __ballot(have && kind == 2);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int4 rec = {env, p | (w << 16), sub | (ncols << 16), rmin | (cmin << 16)};
+    if (have && kind == 1) items[nsearch1 + __popcll(need1 & below)] = rec;
+    if (have && kind == 2) items[kWorkMax - 1 - (nsearch2 + __popcll(need2 & below))] = rec;
+    nsearch1 += __popcll(need1); nsearch2 += __popcll(need2);
   }
   if (lane == 0) {
     P.stage.nwork[env] = nwork;
+    P.stage.nsearch[2 * env] = nsearch1; P.stage.nsearch[2 * env + 1] = nsearch2;
+    int* c = P.counts + kCountStride * (size_t)env;
+    c[5] = nwork; c[6] = nsearch1 + nsearch2;
     if (status) atomicOr(P.status + env, status);
   }
 }
 
-// hb_narrow_kernel: one wave per (env, 64 work items); block b handles chunk b / nblk of env blk0 + b % nblk (the first nblk blocks carry
-// nearly all the work).  Each lane evaluates one item exactly as the fused step kernel would (eval_work_item).
+// hb_narrow_kernel: the portal searches, one wave per env (and per 64 of its searches): lane l runs the env's l-th search, prisms
+// first, exactly as the fused step kernel would (eval_work_item).  The waves are mostly empty (an env has about nine searches), but
+// there are as many of them as the chip holds at once; packing the searches of all envs densely into waves (a prefix sum over the
+// per-env counts, 64 / 16 / 4 searches per wave, one kernel per kind of search) measured slower: a wave's time is set by its
+// longest search and the divergence between its lanes, not by how many lanes it has.
 __global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp, const BatchPtrs P) {
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
-  __shared__ float s_g[64 * 10];
   const int lane = threadIdx.x;
   const int chunk = (int)blockIdx.x / P.nblk, env = P.blk0 + (int)blockIdx.x % P.nblk;
-  const int nwork = min(max(P.stage.nwork[env], 0), kWorkMax);
-  if (chunk * kGroup >= nwork) return;
+  const int n1 = P.stage.nsearch[2 * env], n2 = P.stage.nsearch[2 * env + 1];
+  const int j = chunk * kGroup + lane;
+  if (chunk * kGroup >= n1 + n2) return;
+  const bool have = j < n1 + n2;
+  int4 it = {env, 0, 1 << 16, 0};
+  if (have) it = P.stage.item[(size_t)env * kWorkMax + (j < n1 ? j : kWorkMax - 1 - (j - n1))];
   const int ng = M.ngeom;
-  float* s_gpos = s_g;
-  float* s_gaxis = s_g + 3 * 64;
-  float* s_gquat = s_g + 6 * 64;
-  if (lane < ng) {
-    const float* o = P.stage.geom + ((size_t)env * ng + lane) * 10;
-    st3(s_gpos + 3 * lane, {o[0], o[1], o[2]}); st3(s_gaxis + 3 * lane, {o[3], o[4], o[5]}); stq(s_gquat + 4 * lane, {o[6], o[7], o[8], o[9]});
-  }
-  gsync();
   const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
+  const int p = it.y & 0xffff, w = it.y >> 16;
+  const float* g = P.stage.geom + (size_t)env * ng * 10;
   const float* hdata = P.dr ? P.dr + (size_t)env * P.dr_stride + DL.o_hfield : (const float*)M.hfield_data;
-  const int w = chunk * kGroup + lane;
-  const bool have = w < nwork;
-  int4 it = {0, 0, 0, 1};
-  if (have) it = P.stage.item[(size_t)env * kWorkMax + w];
   ConOut co0, co1;
   int n;
   V3 hint;
-  eval_work_item(M, hdata, have, it.x, it.y, it.z & 0xffff, it.z >> 16, it.w, s_gpos, s_gaxis, s_gquat, co0, co1, n, hint);
+  eval_work_item<2>(M, hdata, have, p, it.z & 0xffff, it.w & 0xffff, it.w >> 16, it.z >> 16, 0.f, g, g + 3 * ng, g + 6 * ng, co0, co1, n, hint);
   if (have) {
     float4* R = P.stage.result + ((size_t)env * kWorkMax + w) * 4;
     R[0] = {co0.dist, co0.pos.x, co0.pos.y, co0.pos.z};
     R[1] = {co0.n.x, co0.n.y, co0.n.z, __int_as_float(n)};
     R[2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
-    R[3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(it.x)};
+    R[3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(p)};
   }
 }
 
@@ -3349,6 +3453,20 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
     hipLaunchKernelGGL(hb_narrow_kernel, dim3(P.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (variant == 1 && Q.stage.defer) {
+      // the step kernel without the portal-search code; the full one then takes the (rare) env-steps whose qacc came out bad
+      hipLaunchKernelGGL(hb_step_gen_fast_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      Q.stage.rerun = 1;
+    } else if (variant == 2 && Q.stage.dm_fast) {
+      // most env-steps fit the one-group Newton instantiation (two waves per SIMD); the four-group kernel then steps the rest
+      if (nv <= 20) hipLaunchKernelGGL(hb_step_newton_gen20_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      else hipLaunchKernelGGL(hb_step_newton_gen28_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      Q.stage.rerun = 1;
+    }
     e = launch_step_kernel(M_dev, variant, solver, nv, shmem, Q, 1, stream);
     if (e != hipSuccess) return e;
   }
@@ -3449,6 +3567,12 @@ hipError_t set_step_lds_limit(int bytes) {
   e = hipFuncSetAttribute((const void*)hb_step_newton28_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)hb_step_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step_gen_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step_newton_gen20_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step_newton_gen28_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)hb_step_newton_big20_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;

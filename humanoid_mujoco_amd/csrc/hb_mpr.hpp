@@ -76,6 +76,80 @@ __device__ __forceinline__ V3d ccd_center(const CObj& o) {
   if (o.type < 0) return (widen(o.p0) + widen(o.p1) + widen(o.p2) + widen(o.p3) + widen(o.p4) + widen(o.p5)) * (1.0 / 6.0);
   return widen(o.pos);
 }
+// ---- mesh support: steepest ascent along the hull's edges (oracle: ccd_support).  Every neighbour of the current vertex is
+// evaluated, the best one taken if it is strictly better (ties to the first in the list); on a convex polytope a vertex with no
+// better neighbour is a maximiser (exact ties - a direction perpendicular to a flat facet - are broken by a second, generic
+// direction: see the oracle), so the vertex a climb ends on does not depend on where it starts.  Every climb starts from the
+// mesh's cube map of support vertices (the cell the direction falls in: 1.2 - 1.5 rounds on the reference's hulls, of which the
+// last only confirms; from the previous call's vertex it was 2 - 5, from vertex 0 4 - 7: tools/mpr_stats.py).  A round is one batch
+// of kMeshChunk independent 16-byte loads per chunk of the vertex's padded neighbour list.
+struct Climb { V3d ld; V3 best; int link; double bd; };
+// The value of a vertex along the query direction and along the tie direction, each as ONE fixed sequence of fused operations: a
+// vertex also appears as padding in its own neighbour list, and a climb only ends if that copy compares EQUAL to the vertex
+// (left to the compiler, the two sides of a comparison may be contracted differently and differ in the last bit: a vertex that
+// "improves" on itself for ever).
+__device__ __forceinline__ double hull_val(float x, float y, float z, V3d ld) { return __builtin_fma((double)x, ld.x, __builtin_fma((double)y, ld.y, (double)z * ld.z)); }
+__device__ __forceinline__ double hull_tie(float x, float y, float z) { return __builtin_fma((double)x, 0.41421356237309503, __builtin_fma((double)y, 0.7320508075688772, (double)z)); }
+__device__ __forceinline__ V3d local_dir(const CObj& o, V3d dir) {  // mat' dir
+  const double m0 = o.mat[0], m1 = o.mat[1], m2 = o.mat[2], m3 = o.mat[3], m4 = o.mat[4], m5 = o.mat[5], m6 = o.mat[6], m7 = o.mat[7], m8 = o.mat[8];
+  return {m0 * dir.x + m3 * dir.y + m6 * dir.z, m1 * dir.x + m4 * dir.y + m7 * dir.z, m2 * dir.x + m5 * dir.y + m8 * dir.z};
+}
+__device__ __forceinline__ V3d world_point(const CObj& o, V3d ld, V3d res) {  // mat (res + ld margin) + pos
+  res = res + ld * (double)o.margin;
+  const double m0 = o.mat[0], m1 = o.mat[1], m2 = o.mat[2], m3 = o.mat[3], m4 = o.mat[4], m5 = o.mat[5], m6 = o.mat[6], m7 = o.mat[7], m8 = o.mat[8];
+  return V3d{m0 * res.x + m1 * res.y + m2 * res.z, m3 * res.x + m4 * res.y + m5 * res.z, m6 * res.x + m7 * res.y + m8 * res.z} + widen(o.pos);
+}
+__device__ __forceinline__ void climb_start(const CObj& o, Climb& c) {
+  const V3d ld = c.ld;
+  const double ax = fabs(ld.x), ay = fabs(ld.y), az = fabs(ld.z);
+  const int axis = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
+  const double major = axis == 0 ? ld.x : (axis == 1 ? ld.y : ld.z);
+  const float inv = 1.f / (float)fabs(major);  // (single precision: this only picks the start)
+  const float u = (float)(axis == 0 ? ld.y : (axis == 1 ? ld.z : ld.x)) * inv, v = (float)(axis == 0 ? ld.z : (axis == 1 ? ld.x : ld.y)) * inv;
+  const int iu = min(max((int)floorf((u + 1.f) * 2.f), 0), 3), iv = min(max((int)floorf((v + 1.f) * 2.f), 0), 3);
+  const float4 s0 = o.vert[(2 * axis + (major < 0.0 ? 1 : 0)) * 16 + iu * 4 + iv];
+  c.best = {s0.x, s0.y, s0.z};
+  c.link = __float_as_int(s0.w);
+  c.bd = hull_val(s0.x, s0.y, s0.z, ld);
+}
+// one chunk of neighbour records against the running best (nb, nlink, c.bd) of the round.  Branch-free: values and tie values of
+// all records first (independent chains), then one compare-and-select step per record (measured: with a branch around the rare
+// tie case and another around the update, the scalar branch overhead of the eight records was most of a round's time)
+__device__ __forceinline__ void climb_eval(const float4 (&q)[kMeshChunk], Climb& c, V3& nb, int& nlink, bool& moved) {
+  double v[kMeshChunk], t[kMeshChunk];
+#pragma unroll
+  for (int i = 0; i < kMeshChunk; i++) { v[i] = hull_val(q[i].x, q[i].y, q[i].z, c.ld); t[i] = hull_tie(q[i].x, q[i].y, q[i].z); }
+  double bt = hull_tie(nb.x, nb.y, nb.z);
+#pragma unroll
+  for (int i = 0; i < kMeshChunk; i++) {
+    // strictly better, or exactly equal (the vertex's own padding copies; otherwise rare) and ahead along the generic second direction
+    const bool take = (v[i] > c.bd) | ((v[i] == c.bd) & (t[i] > bt));
+    c.bd = take ? v[i] : c.bd;
+    bt = take ? t[i] : bt;
+    nb.x = take ? q[i].x : nb.x; nb.y = take ? q[i].y : nb.y; nb.z = take ? q[i].z : nb.z;
+    nlink = take ? __float_as_int(q[i].w) : nlink;
+    moved |= take;
+  }
+}
+// (every climb is bounded: a hull has at most kClimbMax vertices worth of strictly improving moves; the bound only matters for
+// corrupt tables or non-finite directions, where a kernel that never ends would take the device with it)
+constexpr int kClimbMax = 1024;
+__device__ __forceinline__ void climb(const CObj& o, Climb& c) {
+  for (int guard = 0; guard < kClimbMax; guard++) {
+    const int adr = c.link >> 8, nch = c.link & 255;
+    bool moved = false;
+    V3 nb = c.best;
+    int nlink = c.link;
+    for (int k = 0; k < nch; k++) {
+      float4 q[kMeshChunk];
+#pragma unroll
+      for (int i = 0; i < kMeshChunk; i++) q[i] = o.nbr[adr + k * kMeshChunk + i];
+      climb_eval(q, c, nb, nlink, moved);
+    }
+    if (!moved) break;
+    c.best = nb; c.link = nlink;
+  }
+}
 // the point farthest along dir (unit)
 __device__ __forceinline__ V3d ccd_support(const CObj& o, V3d dir) {
   if (o.type < 0) {
@@ -88,59 +162,18 @@ __device__ __forceinline__ V3d ccd_support(const CObj& o, V3d dir) {
     c = widen(o.p5); v = dot(c, dir); if (v > bd) { bd = v; best = c; }
     return best;
   }
-  const double m0 = o.mat[0], m1 = o.mat[1], m2 = o.mat[2], m3 = o.mat[3], m4 = o.mat[4], m5 = o.mat[5], m6 = o.mat[6], m7 = o.mat[7], m8 = o.mat[8];
-  const V3d ld = {m0 * dir.x + m3 * dir.y + m6 * dir.z, m1 * dir.x + m4 * dir.y + m7 * dir.z, m2 * dir.x + m5 * dir.y + m8 * dir.z};  // mat' dir
+  const V3d ld = local_dir(o, dir);
   V3d res;
   if (o.type == 2) res = ld * (double)o.r;
   else if (o.type == 3) { res = ld * (double)o.r; res.z += ld.z >= 0.0 ? (double)o.h : -(double)o.h; }
   else {
-    // steepest ascent along the hull's edges (oracle: ccd_support): every neighbour is evaluated, the best one taken if it is
-    // strictly better (ties to the first in the list); on a convex polytope a vertex with no better neighbour is a maximiser
-    // (exact ties - a direction perpendicular to a flat facet - are broken by a second, generic direction: see the oracle), so
-    // the vertex a climb ends on does not depend on where it starts.  Every climb starts from the mesh's cube map of support
-    // vertices (the cell the direction falls in: 1.2 - 1.5 rounds on the reference's hulls, of which the last only confirms; from
-    // the previous call's vertex it was 2 - 5, from vertex 0 4 - 7: tools/mpr_stats.py).  A round is one batch of kMeshChunk
-    // independent 16-byte loads per chunk of the vertex's padded neighbour list.
-    V3 best;
-    int link;
-    {
-      const double ax = fabs(ld.x), ay = fabs(ld.y), az = fabs(ld.z);
-      const int axis = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
-      const double major = axis == 0 ? ld.x : (axis == 1 ? ld.y : ld.z);
-      const float inv = 1.f / (float)fabs(major);  // (single precision: this only picks the start)
-      const float u = (float)(axis == 0 ? ld.y : (axis == 1 ? ld.z : ld.x)) * inv, v = (float)(axis == 0 ? ld.z : (axis == 1 ? ld.x : ld.y)) * inv;
-      const int iu = min(max((int)floorf((u + 1.f) * 2.f), 0), 3), iv = min(max((int)floorf((v + 1.f) * 2.f), 0), 3);
-      const float4 s0 = o.vert[(2 * axis + (major < 0.0 ? 1 : 0)) * 16 + iu * 4 + iv];
-      best = {s0.x, s0.y, s0.z};
-      link = __float_as_int(s0.w);
-    }
-    const double t0 = 0.41421356237309503, t1 = 0.7320508075688772;
-    double bd = (double)best.x * ld.x + (double)best.y * ld.y + (double)best.z * ld.z;
-    for (;;) {
-      const int adr = link >> 8, nch = link & 255;
-      bool moved = false;
-      V3 nb = best;
-      int nlink = link;
-      for (int c = 0; c < nch; c++) {
-        float4 q[kMeshChunk];
-#pragma unroll
-        for (int i = 0; i < kMeshChunk; i++) q[i] = o.nbr[adr + c * kMeshChunk + i];
-#pragma unroll
-        for (int i = 0; i < kMeshChunk; i++) {
-          const double v = (double)q[i].x * ld.x + (double)q[i].y * ld.y + (double)q[i].z * ld.z;
-          bool take = v > bd;
-          if (v == bd)  // exact tie (rare): the generic second direction decides
-            take = (double)q[i].x * t0 + (double)q[i].y * t1 + (double)q[i].z > (double)nb.x * t0 + (double)nb.y * t1 + (double)nb.z;
-          if (take) { bd = v; nb = {q[i].x, q[i].y, q[i].z}; nlink = __float_as_int(q[i].w); moved = true; }
-        }
-      }
-      if (!moved) break;
-      best = nb; link = nlink;
-    }
-    res = widen(best);
+    Climb c;
+    c.ld = ld;
+    climb_start(o, c);
+    climb(o, c);
+    res = widen(c.best);
   }
-  res = res + ld * (double)o.margin;
-  return V3d{m0 * res.x + m1 * res.y + m2 * res.z, m3 * res.x + m4 * res.y + m5 * res.z, m6 * res.x + m7 * res.y + m8 * res.z} + widen(o.pos);
+  return world_point(o, ld, res);
 }
 
 struct CSup { V3d v, v1; };  // a point of the Minkowski difference obj1 - obj2 and its witness on obj1 (the one on obj2 is v1 - v)

@@ -21,13 +21,13 @@ for regime in ("standing reset", "standup reset (lying)"):
     print("team robot, %s, rollout: %d envs x %d steps: %.1f us/step -> %.3e env-steps/s; mean ncon %.1f nefc %.1f (max %d) newton iterations %.2f; flagged %d"
           % (regime, N, T, 1e6 * dt / T, N * T / dt, nc.mean(), ne.mean(), ne.max(), ni.mean(), int((b.status() != 0).sum())))
     stride = N * m.nu * 4
-    for pipe in (False, True):
+    for pipe in (0, 1, 3, 4):
         b.pipeline(pipe)
         for t in range(20): b.step_dev(ctrl + t * stride)
         b.sync(); t0 = time.perf_counter()
         for t in range(T): b.step_dev(ctrl + t * stride)
         b.sync(); dt = time.perf_counter() - t0
-        print("   step API%s: %.1f us/step -> %.3e env-steps/s" % (" (pipelined)" if pipe else "", 1e6 * dt / T, N * T / dt))
+        print("   step API%s: %.1f us/step -> %.3e env-steps/s" % ((" (pipelined, %d segments)" % (2 if pipe == 1 else pipe)) if pipe else "", 1e6 * dt / T, N * T / dt))
     b.pipeline(False)
     b.dev_free(ctrl); b.close()
 env = hb.VecEnv(m, N, 0, team=True, realism=True, domain_randomization=True)

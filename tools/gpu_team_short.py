@@ -19,3 +19,5 @@ for t in range(30):
 b.sync()
 nc, ne, _ = b.counts()
 print("mean ncon %.2f nefc %.1f flagged %d" % (nc.mean(), ne.mean(), int((b.status() != 0).sum())))
+nw, ns = b.collision_counts()
+print("work items per env %.1f (max %d), portal searches per env %.1f (max %d)" % (nw.mean(), nw.max(), ns.mean(), ns.max()))

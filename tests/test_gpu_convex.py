@@ -126,6 +126,44 @@ def test_team_robot_one_step_parity_along_oracle_trajectories(hbmod, gpu):
     _teacher_forced(hbmod, gpu, TEAM_HBM, states, ctrls, TOL, min_contacts=300, max_divergent=0.02)
 
 
+def test_team_robot_staged_fast_pass_against_the_oracle(hbmod, gpu):
+    """The same states through the path a training run takes (no diagnostics: pose kernel, narrowphase kernel, one-row-group Newton
+    kernel, the four-group kernel only for what that defers): positions, velocities, contact and row counts against the oracle."""
+    def init(o, e, rng):
+        o.qpos[7:] += rng.uniform(-0.2, 0.2, o.nq - 7)
+        o.qpos[0:3] = [0, 0, -0.6 + 0.1 * rng.uniform()]
+        q = np.array([-0.5, -0.5, 0.5, 0.5]) + rng.uniform(-0.1, 0.1, 4)
+        o.qpos[3:7] = q / np.linalg.norm(q)
+    states, ctrls = _oracle_states(TEAM_HBM, envs=8, T=800, every=20, seed=7, init=init, ctrl_scale=0.3)
+    m = hbmod.Model.load(TEAM_HBM)
+    o = Oracle(TEAM_HBM)
+    n = len(states)
+    b = hbmod.Batch(m, n, gpu)
+    b.set_state(hbmod.STATE_INTEGRATION, np.array(states))
+    b.step(np.array(ctrls, dtype=np.float32).reshape(n, m.nu))
+    q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
+    nc, ne, _ = b.counts()
+    assert not b.status().any()
+    worst_q = worst_v = 0.0
+    fence = contacts = 0
+    for k in range(n):
+        o.reset()
+        o.L.om_data_set_time(o.d, states[k][0])
+        o.qpos[:] = states[k][1:1 + m.nq]; o.qvel[:] = states[k][1 + m.nq:1 + m.nq + m.nv]; o.qacc_warmstart[:] = states[k][1 + m.nq + m.nv:]
+        o.ctrl[:] = ctrls[k]
+        o.step()
+        assert (nc[k], ne[k]) == (o.ncon, o.nefc), (k, nc[k], ne[k], o.ncon, o.nefc)
+        contacts += o.ncon
+        dq = (np.abs(q[k] - o.qpos) / np.maximum(1.0, np.abs(o.qpos))).max()
+        dv = np.abs(v[k] - o.qvel).max() / max(1.0, np.abs(o.qvel).max())
+        if dq > TOL["qpos"] or dv > TOL["qvel"]:
+            fence += 1  # a contact read off another MPR portal (see _teacher_forced): counted
+            continue
+        worst_q, worst_v = max(worst_q, dq), max(worst_v, dv)
+    print("\nteam robot, staged fast pass: %d states, %d contacts, %d states on a portal fence, worst qpos %.2e qvel %.2e" % (n, contacts, fence, worst_q, worst_v))
+    assert contacts >= 300 and fence <= 0.03 * n
+
+
 def test_team_robot_free_running_stays_finite(hbmod, gpu):
     """1500 steps of 256 robots from the standup task's reset (lying on the floor) under random motor commands: finite, no
     bad-state flags, unit quaternions, contact and row counts inside the capacity (six to seven contacts, about sixty rows).  (The root link's origin may go below the floor plane when the robot lies on its back - it does

@@ -11,7 +11,7 @@ import humanoid_mujoco_amd as hb  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 m = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", sys.argv[2] if len(sys.argv) > 2 else "team_robot.hbm"))
 b = hb.Batch(m, n, 0)
-b.reset(keyframe=0, perturb=True)
+b.reset(keyframe=0 if len(sys.argv) <= 2 else -1, perturb=True)
 b.rollout_halton(150, 0, 0)
 ctrl = np.zeros((n, m.nu), dtype=np.float32)
 for t in range(30):

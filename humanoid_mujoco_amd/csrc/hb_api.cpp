@@ -587,6 +587,7 @@ struct hb_batch {
   int tev_used = 0;
   long long launch_count = 0;
   int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
+  int* d_order2 = nullptr;  // the same for the narrowphase launch of a staged step
   int order_mode = 0;       // 0: none yet, 1: one permutation of the whole batch, 2: one permutation per pipe segment
   bool schedule = getenv("HB_NO_SCHEDULE") == nullptr;  // heavy-first dispatch order (experiments can switch it off)
   // Pipelined stepping (hb_batch_pipeline): the batch is cut into npipe fixed env segments, each stepped by
@@ -635,7 +636,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
   if (b->diag) { P.diag_qacc = b->d_diag_qacc; P.diag_force = b->d_diag_force; P.diag_contact = b->d_diag_contact; }
   P.n_env = b->n_env;
   P.integrate = 1;
-  if (b->schedule && b->order_mode) P.order = b->d_order;
+  if (b->schedule && b->order_mode) { P.order = b->d_order; P.order2 = b->stage.result ? b->d_order2 : nullptr; }
   P.blk0 = 0; P.nblk = b->n_env;
   P.dr = b->d_dr; P.dr_stride = b->dr_stride;
   P.stamps = b->d_stamps;
@@ -688,8 +689,10 @@ int launch_segment(hb_batch* b, BatchPtrs P, int nsteps, const Segment& sg, int 
   P.blk0 = sg.lo; P.nblk = sg.hi - sg.lo;
   // a whole-batch permutation would mix segments: a segment only uses the order of its own envs
   P.order = (b->schedule && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2)) ? b->d_order : nullptr;
+  P.order2 = (P.order && b->stage.result) ? b->d_order2 : nullptr;
   HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, nsteps, sg.st));
   if (reorder) HB_HIP(launch_order(b->d_counts, b->d_order, sg.lo, sg.hi - sg.lo, sg.st));
+  if (reorder && b->stage.result) HB_HIP(launch_order(b->d_counts, b->d_order2, sg.lo, sg.hi - sg.lo, sg.st, /*slot=*/7, /*shift=*/0));
   return HB_OK;
 }
 void steps_enqueued(hb_batch* b, int nseg, bool reorder) {
@@ -920,6 +923,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
   ok = ok && hipMemset(b->d_counts, 0, (size_t)n_env * kCountStride * sizeof(int)) == hipSuccess;
   ok = ok && ensure_ctrl(b, (size_t)n_env * std::max(1, dm.nu)) == HB_OK;
   ok = ok && hipMalloc((void**)&b->d_order, (size_t)n_env * sizeof(int)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&b->d_order2, (size_t)n_env * sizeof(int)) == hipSuccess;
   // general variants: the staged step (pose -> narrowphase -> step kernels); HB_STAGED=0 keeps everything in the step kernel
   if (dm.variant != 0 && !(getenv("HB_STAGED") && atoi(getenv("HB_STAGED")) == 0)) {
     StageBufs& sb = b->stage;
@@ -967,7 +971,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
   void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nsearch, b->stage.nwork, b->stage.result, b->stage.defer, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
-                  b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
+                  b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_order2, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
 }

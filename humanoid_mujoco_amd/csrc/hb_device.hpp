@@ -270,6 +270,7 @@ struct BatchPtrs {
   // heavy-first block scheduling (nullable): slot s takes env = order[s], a permutation sorted by
   // the cost of each env's previous step (counts[4*e+3]) so the most expensive envs are dispatched first
   const int* order;    // [n_env]
+  const int* order2;   // [n_env] nullable: the same for the narrowphase launch of a staged step, by the cost of its waves (counts[..][7])
   const float* dr;     // nullable [n_env][dr_stride]: per-env model parameters (DomainLayout)
   int dr_stride;
   // sensor read-out (hb_rollout_sensors), nullable: [T][n_env][sensor_stride] = framepos of sensor_body[0..n) | subtreecom | subtreelinvel of tree sensor_tree

@@ -2701,10 +2701,14 @@ __global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, 
 __global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp, const BatchPtrs P) {
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
   const int lane = threadIdx.x;
-  const int chunk = (int)blockIdx.x / P.nblk, env = P.blk0 + (int)blockIdx.x % P.nblk;
+  // heavy first (BatchPtrs::order2: the envs of this launch sorted by the time their wave took in an earlier step): the launch ends
+  // when its slowest wave does, and a slow wave that starts in the last round ends late
+  const int chunk = (int)blockIdx.x / P.nblk, slot = P.blk0 + (int)blockIdx.x % P.nblk;
+  const int env = P.order2 ? P.order2[slot] : slot;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   const int n1 = P.stage.nsearch[2 * env], n2 = P.stage.nsearch[2 * env + 1];
   const int j = chunk * kGroup + lane;
-  if (chunk * kGroup >= n1 + n2) return;
+  if (chunk * kGroup >= n1 + n2) { if (chunk == 0 && lane == 0) P.counts[kCountStride * (size_t)env + 7] = 0; return; }
   const bool have = j < n1 + n2;
   int4 it = {env, 0, 1 << 16, 0};
   if (have) it = P.stage.item[(size_t)env * kWorkMax + (j < n1 ? j : kWorkMax - 1 - (j - n1))];
@@ -2724,6 +2728,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp
     R[2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
     R[3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(p)};
   }
+  if (chunk == 0 && lane == 0) P.counts[kCountStride * (size_t)env + 7] = (int)min(255ull, (__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 
 // ---- MJPC task cost on the recorded read-out rows --------------------------------------------------------------
@@ -3373,15 +3378,15 @@ __global__ __launch_bounds__(512) void hb_policy_kernel(const DevModel M, const 
 // last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
 // the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
 // which cannot change results (envs are independent).
-__global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int e0, int n) {
-  // sorts envs e0 .. e0+n-1 into order[e0 .. e0+n-1]
+__global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int e0, int n, int slot, int shift) {
+  // sorts envs e0 .. e0+n-1 into order[e0 .. e0+n-1], most expensive first; cost = counts[env][slot] >> shift, 256 bins
   __shared__ int hist[256];
   __shared__ int base[256];
   const int tid = threadIdx.x;
   if (tid < 256) hist[tid] = 0;
   __syncthreads();
   for (int e = e0 + tid; e < e0 + n; e += blockDim.x) {
-    int key = min(255, counts[kCountStride * e + 3] >> 3);
+    int key = min(255, counts[kCountStride * e + slot] >> shift);
     atomicAdd(&hist[255 - key], 1);  // bin 0 = most expensive
   }
   __syncthreads();
@@ -3399,7 +3404,7 @@ __global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* 
   if (tid < 256) base[tid] += e0 - hist[tid];  // inclusive -> exclusive, offset by the segment start
   __syncthreads();
   for (int e = e0 + tid; e < e0 + n; e += blockDim.x) {
-    int key = min(255, counts[kCountStride * e + 3] >> 3);
+    int key = min(255, counts[kCountStride * e + slot] >> shift);
     order[atomicAdd(&base[255 - key], 1)] = e;
   }
 }
@@ -3469,6 +3474,12 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
     }
     e = launch_step_kernel(M_dev, variant, solver, nv, shmem, Q, 1, stream);
     if (e != hipSuccess) return e;
+    // a long rollout is one call: refresh the heavy-first orders of its launches along the way (the caller does it between calls)
+    if (P.order && P.order2 && (t & 7) == 7 && t + 1 < nsteps) {
+      e = launch_order(P.counts, const_cast<int*>(P.order), P.blk0, P.nblk, stream, 3, 3);
+      if (e == hipSuccess) e = launch_order(P.counts, const_cast<int*>(P.order2), P.blk0, P.nblk, stream, 7, 0);
+      if (e != hipSuccess) return e;
+    }
   }
   return hipSuccess;
 }
@@ -3521,9 +3532,9 @@ hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr,
   hipLaunchKernelGGL(hb_domain_rand_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, D, dr, stride, episode, mask, n_env, env_offset);
   return hipGetLastError();
 }
-hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream) {
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, e0, n);
+hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream, int slot, int shift) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, e0, n, slot, shift);
   return hipGetLastError();
 }
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream) {

@@ -364,6 +364,22 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   TI(geom_meshadr, geom_meshadr); TI(geom_meshnum, geom_meshnum);
   TI(hfield_nrow, m.hfield_nrow); TI(hfield_ncol, m.hfield_ncol); TI(hfield_adr, m.hfield_adr); TF(hfield_size, m.hfield_size); TF(hfield_data, m.hfield_data);
   TF(geom_size, m.geom_size); TF(geom_pos, m.geom_pos); TF(geom_quat, m.geom_quat); TF(geom_rbound, m.geom_rbound);
+  // half extents of every geom's bounding box in its own frame (the oriented boxes the broadphase of the general path tests before a
+  // pair of geoms is handed to the portal search): the hull's coordinate range for a mesh, the obvious for spheres and capsules
+  std::vector<double> geom_half((size_t)std::max(1, m.ngeom) * 3, 0.0);
+  for (int g = 0; g < m.ngeom; g++) {
+    double* h = &geom_half[3 * (size_t)g];
+    h[0] = h[1] = h[2] = m.geom_rbound[g];
+    if (m.geom_type[g] == GEOM_SPHERE) h[0] = h[1] = h[2] = m.geom_size[3 * g];
+    else if (m.geom_type[g] == GEOM_CAPSULE) { h[0] = h[1] = m.geom_size[3 * g]; h[2] = m.geom_size[3 * g] + m.geom_size[3 * g + 1]; }
+    else if (m.geom_type[g] == GEOM_MESH && m.geom_dataid[g] >= 0) {
+      const int k = m.geom_dataid[g];
+      h[0] = h[1] = h[2] = 0.0;
+      for (int v = 0; v < m.mesh_vertnum[k]; v++)
+        for (int c = 0; c < 3; c++) h[c] = std::max(h[c], std::fabs((double)(float)m.mesh_vert[3 * (size_t)(m.mesh_vertadr[k] + v) + c]));
+    }
+  }
+  TF(geom_half, geom_half);
   std::vector<int> pair_self;  // both geoms of the pair on the robot (neither on the world body)
   for (int p = 0; p < m.npair; p++) pair_self.push_back(m.geom_bodyid[m.pair_geom1[p]] != 0);
   TI(pair_geom1, m.pair_geom1); TI(pair_geom2, m.pair_geom2); TI(pair_dim, pair_dim); TI(pair_self, pair_self);

@@ -586,6 +586,36 @@ __device__ __forceinline__ void set_mesh(DevModelRef M, CObj& o, int g) {
   o.nbr = M.mesh_nbr;
 }
 
+// separating-axis test of the oriented bounding boxes of geoms g1, g2 (centres dp apart, orientations q1, q2, each box grown by
+// `grow`): false only if an axis separates them (Gottschalk's 15 axes; the epsilon on |R| keeps near-parallel edge pairs from
+// reporting a separation that rounding made up, and the slack keeps boxes that touch to within rounding together)
+__device__ __forceinline__ bool boxes_touch(DevModelRef M, int g1, int g2, V3 dp, Q4 q1, Q4 q2, float grow) {
+  const float slack = 1e-6f;
+  float A[9], B[9], R[9], AR[9];
+  q2mat(A, q1); q2mat(B, q2);
+  const V3 ha = ld3(M.geom_half + 3 * g1), hb3 = ld3(M.geom_half + 3 * g2);
+  const float a[3] = {ha.x + grow + slack, ha.y + grow + slack, ha.z + grow + slack}, b[3] = {hb3.x + grow + slack, hb3.y + grow + slack, hb3.z + grow + slack};
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { R[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j]; AR[3 * i + j] = fabsf(R[3 * i + j]) + 1e-6f; }  // A' B
+  const float t[3] = {A[0] * dp.x + A[3] * dp.y + A[6] * dp.z, A[1] * dp.x + A[4] * dp.y + A[7] * dp.z, A[2] * dp.x + A[5] * dp.y + A[8] * dp.z};  // A' dp
+  bool apart = false;
+#pragma unroll
+  for (int i = 0; i < 3; i++) apart |= fabsf(t[i]) > a[i] + b[0] * AR[3 * i] + b[1] * AR[3 * i + 1] + b[2] * AR[3 * i + 2];
+#pragma unroll
+  for (int j = 0; j < 3; j++) apart |= fabsf(t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j]) > a[0] * AR[j] + a[1] * AR[3 + j] + a[2] * AR[6 + j] + b[j];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const float ra = a[i1] * AR[3 * i2 + j] + a[i2] * AR[3 * i1 + j], rb = b[j1] * AR[3 * i + j2] + b[j2] * AR[3 * i + j1];
+      apart |= fabsf(t[i2] * R[3 * i1 + j] - t[i1] * R[3 * i2 + j]) > ra + rb;
+    }
+  return !apart;
+}
+
 // lowest point (z, relative to the geom's position) of geom g with orientation q in the frame the query is made in: the support
 // function along -z.  Single precision: the value only decides whether a prism under the geom is searched (the prism's top is
 // compared with it), and a vertex within rounding of the lowest one gives the same answer to within that rounding.
@@ -649,7 +679,15 @@ __device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const fl
       const V3 dp = ld3(s_gpos + 3 * g2) - ld3(s_gpos + 3 * g1);
       if (t1 == 0) pass = dot(dp, ld3(s_gaxis + 3 * g1)) <= c0.w + c1.y;
       else if (t1 == 1) pass = true;
-      else { const float bound = c1.x + c1.y + c0.w; pass = dot(dp, dp) <= bound * bound; }
+      else {
+        const float bound = c1.x + c1.y + c0.w;
+        pass = dot(dp, dp) <= bound * bound;
+        // a pair that goes to the portal search: the geoms' oriented bounding boxes first (each grown by half the margin).  Boxes
+        // that a separating axis keeps apart hold hulls that do not touch: the search would say so too, after two hull climbs
+        // per support query (the robot's limbs are long and thin: most pairs that pass the bounding spheres stop here)
+        const int t2 = (__float_as_int(c0.z) >> 8) & 255;
+        if (pass && (t1 == 7 || t2 == 7)) pass = boxes_touch(M, g1, g2, dp, ldq(s_gquat + 4 * g1), ldq(s_gquat + 4 * g2), 0.5f * c0.w);
+      }
     }
     const unsigned long long bal = __ballot(pass);
     const int slot = nlist + __popcll(bal & ((1ull << lane) - 1ull));

@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the second (single-launch rollout) measurement, e.g. under rocprofv3")
     ap.add_argument("--no-newton", action="store_true", help="skip the third measurement (same workload with the reference's default solver, Newton)")
+    ap.add_argument("--no-team", action="store_true", help="skip the fourth measurement (the reference's own robot, assets/team_robot.hbm)")
     ap.add_argument("--no-pipeline", action="store_true", help="time the unpipelined step API (one launch per step) as `value`")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction only, no GPU work (CPU rehearsal of the N>1 path with HB_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
@@ -354,6 +355,38 @@ def main():
                   "what": "same workload, window and step API, solver = Newton (mjOption default: what the reference's humanoid.xml runs), 100 iterations max, tolerance 1e-8"}
         nb.close()
 
+    # Fourth measurement (N = 1 only): the reference's OWN robot (simulation/assets/world.xml: mesh hulls, condim 6, height-field floor,
+    # Newton, dt 0.002), same step API, from its standing reset after 200 settling steps, small random motor commands.
+    team = None
+    if world == 1 and not args.no_team:
+        import numpy as np
+        tm = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "team_robot.hbm"))
+        tb = hb.Batch(tm, n_env, device)
+        tb.reset(keyframe=1, perturb=True)
+        KT = min(K, 300)
+        tctrl_h = (0.3 * np.random.default_rng(0).uniform(-1, 1, (W + KT, n_env, tm.nu))).astype(np.float32)
+        tctrl = tb.dev_alloc(tctrl_h.nbytes)
+        tb.to_dev(tctrl, tctrl_h)
+        tstride = n_env * tm.nu * 4
+        tb.rollout_halton(200, 0, 0)
+        tb.pipeline(pipelined)
+        for t in range(W):
+            tb.step_dev(tctrl + t * tstride)
+        tb.sync()
+        t2 = time.perf_counter()
+        for t in range(W, W + KT):
+            tb.step_dev(tctrl + t * tstride)
+        tb.sync()
+        el = time.perf_counter() - t2
+        tnc, tne, tni = tb.counts()
+        tnw, tns = tb.collision_counts()
+        team = {"value": n_env * KT / el, "unit": "env-steps/s", "ms_per_step": 1e3 * el / KT, "steps": KT, "mean_ncon": float(tnc.mean()), "mean_nefc": float(tne.mean()),
+                "mean_newton_iterations": float(tni.mean()), "portal_searches_per_env": float(tns.mean()), "envs_with_warnings": int((tb.status() != 0).sum()),
+                "what": "the reference's own robot (assets/team_robot.hbm: 18 dofs, 9 mesh hulls, condim 6, 8 x 8 height field, Newton), %d envs, staged step "
+                        "(pose, narrowphase, step kernels), same step API and pipelining as `value`" % n_env}
+        tb.dev_free(tctrl)
+        tb.close()
+
     if rank == 0:
         value = n_env * world * K / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (launch_us * 1e-6) / 1e9
@@ -391,6 +424,8 @@ def main():
                               "what": "same K steps as one hb_rollout_dev launch per GPU (no per-step batch barrier; testspeed.cc shape)"}
         if newton is not None:
             out["newton"] = newton
+        if team is not None:
+            out["team_robot"] = team
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"].update(probe_libmujoco())

@@ -287,6 +287,7 @@ def main():
     preroll(batch)
     pipelined = not args.no_pipeline
     batch.pipeline(pipelined)
+    nseg = batch.segments
     for t in range(W):
         batch.step_dev(ctrl + t * stride)
     barrier()
@@ -399,7 +400,7 @@ def main():
             "config": {"workload": "configs[1]: %d parallel humanoid envs per GPU, Halton random actions, fp32, PGS<=50 iters tol 1e-8, dt 0.005, one mj_step of every env per "
                                    "hb_step_dev call%s; every env pre-rolled %d untimed steps from the perturbed reset (steady regime: fallen humanoids, ~10 constraint rows), "
                                    "then %d warm-up and %d timed steps"
-                                   % (n_env, " (pipelined: 2 env segments on 2 streams)" if pipelined else "", PRE, W, K),
+                                   % (n_env, (" (pipelined: %d env segments on %d streams)" % (nseg, nseg)) if pipelined else "", PRE, W, K),
                        "model": "27-DoF humanoid (assets/humanoid27.hbm)", "envs_per_gpu": n_env, "global_envs": n_env * world, "preroll_steps": PRE,
                        "sharding": "env blocks by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

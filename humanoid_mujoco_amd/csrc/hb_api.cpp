@@ -1006,12 +1006,16 @@ int hb_batch_pipeline(hb_batch* b, int on) {
   HB_HIP(hipSetDevice(b->device));
   join_pipes(b);
   if (on < 0 || on > hb_batch::kPipes) return HB_EINVAL;
-  // 1: default segment count.  Two segments of 2048 envs each fill the chip on their own (2048 resident
-  // waves) and measured best on MI355X; more segments than hardware queues serialise (tools/gpu_pipeline_sweep.py)
+  // 1: default segment count.  Two segments of 2048 envs each fill the chip on their own (2048 resident waves) and measured best on
+  // MI355X.  Three would cover the ~6 us between two launches on one stream, and with GPU_MAX_HW_QUEUES=8 (a hardware queue per
+  // stream; the ROCm default of 4 makes streams share queues and serialise) a single batch in a process did run 91.4 instead of
+  // 94.1 us per step - but the same setting dropped a second batch of the same process from 4.0e7 to 2.3e7 env-steps/s and the gain
+  // did not repeat from box to box (tools/gpu_pipeline_sweep.py, gpurun_out/b20.json): not a default, and no environment is set here.
   b->npipe = on == 1 ? 2 : on;
   b->order_mode = 0;            // segment boundaries changed: per-segment permutations are stale
   return HB_OK;
 }
+int hb_batch_segments(const hb_batch* b) { return b ? segment_count(b) : HB_EINVAL; }
 int hb_batch_join(hb_batch* b) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));

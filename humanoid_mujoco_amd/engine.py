@@ -140,6 +140,7 @@ def lib():
     L.hb_get_status.argtypes = [vp, vp]
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
     L.hb_get_collision_counts.argtypes = [vp, vp, vp]
+    L.hb_batch_segments.argtypes = [vp]
     L.hb_diag_enable.argtypes = [vp, ci]
     L.hb_get_qacc.argtypes = [vp, vp]; L.hb_get_efc_force.argtypes = [vp, vp]; L.hb_get_contacts.argtypes = [vp, vp]
     L.hb_env_default_config.argtypes = [vp, ctypes.POINTER(HbEnvConfig)]
@@ -314,6 +315,11 @@ class Batch:
         """Pipelined stepping (hb_batch_pipeline): env segments (two by default) on their own streams, so the slow tail of
         one step overlaps the next step.  Results are identical; see include/hb.h for the stream contract."""
         _check(lib().hb_batch_pipeline(self._h, int(on)), "hb_batch_pipeline")  # True: 2 segments; 2..4: that many
+
+    @property
+    def segments(self):
+        """env segments a step call is cut into at the moment (1: unpipelined)"""
+        return lib().hb_batch_segments(self._h)
 
     def join(self):
         _check(lib().hb_batch_join(self._h), "hb_batch_join")

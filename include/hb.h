@@ -117,6 +117,8 @@ int hb_batch_sync(hb_batch* b);
  * kind.  A caller that enqueues its OWN work on hb_batch_stream() after step calls must call
  * hb_batch_join first (or fetch the stream again); callers that only use hb_* functions need nothing. */
 int hb_batch_pipeline(hb_batch* b, int on);
+/* Number of env segments step calls are cut into at the moment (1: unpipelined). */
+int hb_batch_segments(const hb_batch* b);
 int hb_batch_join(hb_batch* b);
 
 /* Replaces mj_resetData (keyframe < 0) / mj_resetDataKeyframe (mujoco.h:180,186) for the envs

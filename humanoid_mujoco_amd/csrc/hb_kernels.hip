@@ -3068,12 +3068,13 @@ __device__ __forceinline__ float ring_delay(float* ring, int stride, int k, int 
 // action == nullptr: the reference's step(None), which re-applies the current controls without noise.
 __global__ void hb_action_env_kernel(const DevModel M, const EnvRand R, const EnvRandState S, const float* action, float* prev, float* latest, float* ctrl,
                                      const int* episode, const float* state, const uint8_t* mask, int n_env, int env_offset) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  // (sixteen lanes per env: the actuators lane-strided, the push schedule on the env's first lane)
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) / 16, l = threadIdx.x % 16;
   if (e >= n_env || (mask && !mask[e])) return;
   const int nu = M.nu, ge = env_offset + e, ep = episode[e];
   const int k = S.k_act[e], d = S.delay[4 * e];
   const unsigned kk = R.frozen_noise ? 0u : (unsigned)k;
-  for (int i = 0; i < nu; i++) {
+  for (int i = l; i < nu; i += 16) {
     const size_t ai = (size_t)e * nu + i;
     float a = action ? action[ai] : ctrl[ai];
     if (action && R.action_noise > 0.f) a += R.factor * R.action_noise * rng_normal(R.seed, ge, ep, kk, RS_ACTION, i);
@@ -3082,6 +3083,7 @@ __global__ void hb_action_env_kernel(const DevModel M, const EnvRand R, const En
     latest[ai] = out;
     ctrl[ai] = out;
   }
+  if (l != 0) return;
   S.k_act[e] = k + 1;
   if (R.push_enabled && S.xfrc) {
     float* p = S.push + 8 * (size_t)e;
@@ -3577,7 +3579,7 @@ hipError_t launch_envrand_reset(const DevModel& M, const EnvRand& R, const EnvRa
 hipError_t launch_action_env(const DevModel& M, const EnvRand& R, const EnvRandState& S, const float* action, float* prev, float* latest, float* ctrl,
                              const int* episode, const float* state, const uint8_t* mask, int n_env, int env_offset, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_action_env_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, R, S, action, prev, latest, ctrl, episode, state, mask, n_env,
+  hipLaunchKernelGGL(hb_action_env_kernel, dim3((n_env + 15) / 16), dim3(256), 0, stream, M, R, S, action, prev, latest, ctrl, episode, state, mask, n_env,
                      env_offset);
   return hipGetLastError();
 }

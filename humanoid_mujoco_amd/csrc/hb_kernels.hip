@@ -2984,33 +2984,37 @@ __global__ void hb_envrand_reset_kernel(const DevModel M, const EnvRand R, const
 
 // Per-env model parameters of one episode (cpu_env.py:188-264): see hb_domain_randomization in include/hb.h.
 enum { RS_DR_MASS = 16, RS_DR_EXTRA, RS_DR_FRIC, RS_DR_ARM, RS_DR_STIFF, RS_DR_MARGIN, RS_DR_RANGE, RS_DR_KP, RS_DR_FRC, RS_DR_FLOOR };
-__device__ __forceinline__ void domain_draw(const DevModel& M, const DomainRand& D, float* d, int env_global, int ep) {
+// (NL cooperating lanes, l = this lane's number among them: every table is filled lane-strided; the height map's range is reduced
+// over the lanes with shuffles, so NL is 1 or the env kernels' kDrawLanes = 16 consecutive lanes of a wave)
+constexpr int kDrawLanes = 16;
+template <int NL>
+__device__ __forceinline__ void domain_draw(const DevModel& M, const DomainRand& D, float* d, int env_global, int ep, int l = 0) {
+  static_assert(NL == 1 || NL == kDrawLanes, "domain_draw: one lane or kDrawLanes");
   const DomainLayout L = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
   const float rf = D.factor;
   auto U = [&](int stream, int idx) { return rng_uniform(D.seed, env_global, ep, 0, stream, idx); };
-  d[L.o_mass] = 0.f;
-  for (int sl = 1; sl < M.nbody; sl++) {  // brec is level-ordered: slot -> body id, mass
+  if (l == 0) d[L.o_mass] = 0.f;
+  const int bx = M.nbody > 1 ? 1 + min(M.nbody - 2, (int)(U(RS_DR_EXTRA, 0) * (float)(M.nbody - 1))) : -1;  // the body that carries the extra mass
+  for (int sl = 1 + l; sl < M.nbody; sl += NL) {  // brec is level-ordered: slot -> body id, mass
     const float4 q0 = M.brec[(size_t)sl * kBrecQuads], q1 = M.brec[(size_t)sl * kBrecQuads + 1];
     const int b = __float_as_int(q0.x);
-    d[L.o_mass + b] = fmaxf(1e-5f, q1.z + (2.f * U(RS_DR_MASS, b) - 1.f) * D.max_mass_change * rf);
+    float mass = fmaxf(1e-5f, q1.z + (2.f * U(RS_DR_MASS, b) - 1.f) * D.max_mass_change * rf);
+    if (b == bx) mass += U(RS_DR_EXTRA, 1) * D.max_external_mass * rf;
+    d[L.o_mass + b] = mass;
   }
-  if (M.nbody > 1) {
-    const int b = 1 + min(M.nbody - 2, (int)(U(RS_DR_EXTRA, 0) * (float)(M.nbody - 1)));
-    d[L.o_mass + b] += U(RS_DR_EXTRA, 1) * D.max_external_mass * rf;
-  }
-  for (int i = 0; i < M.nv; i++) {
+  for (int i = l; i < M.nv; i += NL) {
     const float4 dA = M.drec[3 * i], dB = M.drec[3 * i + 1];
     const bool scalar = __float_as_int(dA.z) >= 2;  // hinge / slide
     d[L.o_arm + i] = dB.y + (scalar ? U(RS_DR_ARM, i) * D.armature_max_change * rf : 0.f);
     d[L.o_stiff + i] = dB.w + (scalar ? U(RS_DR_STIFF, i) * D.stiffness_max_change * rf : 0.f);
   }
-  for (int c = 0; c < M.nlimcand; c++) {
+  for (int c = l; c < M.nlimcand; c += NL) {
     const bool joint = M.lim_kind[c] == 0;
     const int id = M.lim_id[c];
     d[L.o_lmargin + c] = M.lim_margin[c] + (joint ? U(RS_DR_MARGIN, id) * D.margin_max_change * rf : 0.f);  // one margin per joint
     d[L.o_lrange + c] = M.lim_range[c] + (joint ? (2.f * U(RS_DR_RANGE, c) - 1.f) * D.range_max_change * rf : 0.f);
   }
-  for (int a = 0; a < M.nu; a++) {
+  for (int a = l; a < M.nu; a += NL) {
     float gain = M.act_gain[a], bias1 = M.act_bias[3 * a + 1];
     if (D.kp_nominal > 0.f) {
       gain = D.kp_nominal + (2.f * U(RS_DR_KP, a) - 1.f) * D.kp_max_change * rf;
@@ -3021,7 +3025,7 @@ __device__ __forceinline__ void domain_draw(const DevModel& M, const DomainRand&
     d[L.o_frc + 2 * a] = M.act_forcerange[2 * a] + (2.f * U(RS_DR_FRC, 2 * a) - 1.f) * D.force_limit_max_change * rf;
     d[L.o_frc + 2 * a + 1] = M.act_forcerange[2 * a + 1] + (2.f * U(RS_DR_FRC, 2 * a + 1) - 1.f) * D.force_limit_max_change * rf;
   }
-  d[L.o_fric] = (1.f - rf) + (D.friction_min_mult + U(RS_DR_FRIC, 0) * (D.friction_max_mult - D.friction_min_mult)) * rf;
+  if (l == 0) d[L.o_fric] = (1.f - rf) + (D.friction_min_mult + U(RS_DR_FRIC, 0) * (D.friction_max_mult - D.friction_min_mult)) * rf;
   // floor height maps (CPUEnv._randomize_floor_heightmap, cpu_env.py:267-280: Perlin noise on the grid, shifted and scaled to
   // [0, 1], times MIN + factor (MAX - MIN)).  The reference's noise comes from the third-party perlin_noise package; here:
   // three octaves of smooth value noise from the counter-based generator, normalised the same way.
@@ -3029,32 +3033,36 @@ __device__ __forceinline__ void domain_draw(const DevModel& M, const DomainRand&
   for (int hf = 0, adr = 0; adr < M.nhfielddata; hf++) {
     const int nr = M.hfield_nrow[hf], nc = M.hfield_ncol[hf], n = nr * nc;
     float* h = d + L.o_hfield + adr;
-    if (!(D.floor_bump_max > 0.f)) { for (int i = 0; i < n; i++) h[i] = M.hfield_data[adr + i]; adr += n; continue; }
+    if (!(D.floor_bump_max > 0.f)) { for (int i = l; i < n; i += NL) h[i] = M.hfield_data[adr + i]; adr += n; continue; }
     float lo = 3.0e38f, hi = -3.0e38f;
-    for (int r = 0; r < nr; r++)
-      for (int c = 0; c < nc; c++) {
-        float v = 0.f, amp = 1.f;
-        for (int oct = 0, cells = 2; oct < 3; oct++, cells *= 2, amp *= 0.5f) {  // lattices of 3x3, 5x5, 9x9 nodes over the field
-          const float x = (float)c / (float)max(1, nc - 1) * (float)cells, y = (float)r / (float)max(1, nr - 1) * (float)cells;
-          const int x0 = min((int)x, cells - 1), y0 = min((int)y, cells - 1);
-          float fx = x - (float)x0, fy = y - (float)y0;
-          fx = fx * fx * (3.f - 2.f * fx); fy = fy * fy * (3.f - 2.f * fy);  // smoothstep
-          auto node = [&](int ix, int iy) { return rng_uniform(D.seed, env_global, ep, hf, RS_DR_FLOOR, (oct * 16 + iy) * 16 + ix); };
-          const float a = node(x0, y0), b = node(x0 + 1, y0), cc = node(x0, y0 + 1), dd = node(x0 + 1, y0 + 1);
-          v += amp * ((a * (1.f - fx) + b * fx) * (1.f - fy) + (cc * (1.f - fx) + dd * fx) * fy);
-        }
-        h[r * nc + c] = v;
-        lo = fminf(lo, v); hi = fmaxf(hi, v);
+    for (int i = l; i < n; i += NL) {
+      const int r = i / nc, c = i - r * nc;
+      float v = 0.f, amp = 1.f;
+      for (int oct = 0, cells = 2; oct < 3; oct++, cells *= 2, amp *= 0.5f) {  // lattices of 3x3, 5x5, 9x9 nodes over the field
+        const float x = (float)c / (float)max(1, nc - 1) * (float)cells, y = (float)r / (float)max(1, nr - 1) * (float)cells;
+        const int x0 = min((int)x, cells - 1), y0 = min((int)y, cells - 1);
+        float fx = x - (float)x0, fy = y - (float)y0;
+        fx = fx * fx * (3.f - 2.f * fx); fy = fy * fy * (3.f - 2.f * fy);  // smoothstep
+        auto node = [&](int ix, int iy) { return rng_uniform(D.seed, env_global, ep, hf, RS_DR_FLOOR, (oct * 16 + iy) * 16 + ix); };
+        const float a = node(x0, y0), b = node(x0 + 1, y0), cc = node(x0, y0 + 1), dd = node(x0 + 1, y0 + 1);
+        v += amp * ((a * (1.f - fx) + b * fx) * (1.f - fy) + (cc * (1.f - fx) + dd * fx) * fy);
       }
+      h[i] = v;  // (re-read below by the lane that wrote it)
+      lo = fminf(lo, v); hi = fmaxf(hi, v);
+    }
+    if (NL > 1) {
+#pragma unroll
+      for (int m = NL / 2; m >= 1; m >>= 1) { lo = fminf(lo, __shfl_xor(lo, m, NL)); hi = fmaxf(hi, __shfl_xor(hi, m, NL)); }
+    }
     const float sc = hi > lo ? bump / (hi - lo) : 0.f;
-    for (int i = 0; i < n; i++) h[i] = (h[i] - lo) * sc;
+    for (int i = l; i < n; i += NL) h[i] = (h[i] - lo) * sc;
     adr += n;
   }
 }
 __global__ void hb_domain_rand_kernel(const DevModel M, const DomainRand D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) / kDrawLanes, l = threadIdx.x % kDrawLanes;
   if (e >= n_env || (mask && !mask[e])) return;
-  domain_draw(M, D, dr + (size_t)e * stride, env_offset + e, episode[e]);
+  domain_draw<kDrawLanes>(M, D, dr + (size_t)e * stride, env_offset + e, episode[e], l);
 }
 
 // value through a delay ring: push x as item k, return item k - d (filler before the ring has d items)
@@ -3298,8 +3306,9 @@ __global__ __launch_bounds__(256) void hb_env_kernel(const DevModel M, const Env
       episode[e] = ep;
       status[e] = 0;
       if (rand_on) envrand_begin_episode(M, R, S, e, env_offset + e, ep);
-      if (dr) domain_draw(M, D, dr + (size_t)e * dr_stride, env_offset + e, ep);
     }
+    static_assert(kEnvLanes == kDrawLanes, "the env kernel draws an episode's model parameters with all lanes of the env");
+    if (dr) domain_draw<kDrawLanes>(M, D, dr + (size_t)e * dr_stride, env_offset + e, ep, l);
   }
   __threadfence_block();
   __syncthreads();  // the new state (LDS) and the new episode's delays (global, written by lane 0) are visible to the env's lanes
@@ -3611,7 +3620,7 @@ hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, const EnvRand& R,
 hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset,
                               hipStream_t stream) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_domain_rand_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, D, dr, stride, episode, mask, n_env, env_offset);
+  hipLaunchKernelGGL(hb_domain_rand_kernel, dim3((n_env + 256 / kDrawLanes - 1) / (256 / kDrawLanes)), dim3(256), 0, stream, M, D, dr, stride, episode, mask, n_env, env_offset);
   return hipGetLastError();
 }
 hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream, int slot, int shift) {

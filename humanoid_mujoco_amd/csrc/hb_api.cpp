@@ -2149,7 +2149,7 @@ int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter) {
   return HB_OK;
 }
 
-int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch) {
+int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch, int* kcycles) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
@@ -2158,6 +2158,7 @@ int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch) {
   for (int e = 0; e < b->n_env; e++) {
     if (nwork) nwork[e] = h[kCountStride * e + 5];
     if (nsearch) nsearch[e] = h[kCountStride * e + 6];
+    if (kcycles) kcycles[e] = h[kCountStride * e + 7];
   }
   return HB_OK;
 }

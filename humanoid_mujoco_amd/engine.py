@@ -139,7 +139,7 @@ def lib():
     L.hb_get_obs.argtypes = [vp, vp, vp, vp, vp]
     L.hb_get_status.argtypes = [vp, vp]
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
-    L.hb_get_collision_counts.argtypes = [vp, vp, vp]
+    L.hb_get_collision_counts.argtypes = [vp, vp, vp, vp]
     L.hb_batch_segments.argtypes = [vp]
     L.hb_diag_enable.argtypes = [vp, ci]
     L.hb_get_qacc.argtypes = [vp, vp]; L.hb_get_efc_force.argtypes = [vp, vp]; L.hb_get_contacts.argtypes = [vp, vp]
@@ -402,11 +402,12 @@ class Batch:
         _check(lib().hb_get_counts(self._h, _ptr(a), _ptr(b), _ptr(c)), "hb_get_counts")
         return a, b, c
 
-    def collision_counts(self):
-        """(work items, portal searches) of every env's last step (general collision models; zeros otherwise)."""
-        a, b = (np.zeros(self.n_env, dtype=np.int32) for _ in range(2))
-        _check(lib().hb_get_collision_counts(self._h, _ptr(a), _ptr(b)), "hb_get_collision_counts")
-        return a, b
+    def collision_counts(self, want_cycles=False):
+        """(work items, portal searches[, narrowphase wave time in 1024-cycle units]) of every env's last step (general collision
+        models; zeros otherwise)."""
+        a, b, c = (np.zeros(self.n_env, dtype=np.int32) for _ in range(3))
+        _check(lib().hb_get_collision_counts(self._h, _ptr(a), _ptr(b), _ptr(c)), "hb_get_collision_counts")
+        return (a, b, c) if want_cycles else (a, b)
 
     def diag_enable(self, on=True):
         _check(lib().hb_diag_enable(self._h, int(on)), "hb_diag_enable")

@@ -302,9 +302,10 @@ int hb_get_status(hb_batch* b, int* status);
 int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter);
 /* Narrowphase work of the last step of each env, for models that collide through mesh hulls or height fields (the staged step:
  * DESIGN.md 3.6): nwork = work items (a candidate pair that passed the broadphase, or one prism of a height-field pair's sub-grid),
- * nsearch = those of them that needed a portal search (mjc_Convex / mjc_ConvexHField: libccd MPR).  Zeros for other models.  Either
- * pointer may be NULL. */
-int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch);
+ * nsearch = those of them that needed a portal search (mjc_Convex / mjc_ConvexHField: libccd MPR), kcycles = shader clock cycles / 1024
+ * the env's narrowphase wave took (saturating at 255; the cost the heavy-first dispatch of that launch sorts by).  Zeros for other
+ * models.  Any pointer may be NULL. */
+int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch, int* kcycles);
 
 /* Diagnostics of the last step for parity tests (mjData.qacc, efc_force, contact[]; mjdata.h:
  * 362,376,427): enable once, then read after a step.  efc_force is [n_env][nefc_max];

@@ -19,5 +19,8 @@ for t in range(30):
 b.sync()
 nc, ne, _ = b.counts()
 print("mean ncon %.2f nefc %.1f flagged %d" % (nc.mean(), ne.mean(), int((b.status() != 0).sum())))
-nw, ns = b.collision_counts()
+nw, ns, kc = b.collision_counts(want_cycles=True)
 print("work items per env %.1f (max %d), portal searches per env %.1f (max %d)" % (nw.mean(), nw.max(), ns.mean(), ns.max()))
+print("narrowphase wave time by the env's contacts (thousands of cycles): " + "; ".join(
+    "%d contacts: %d envs, mean %.0f, max %d" % (k, (nc == k).sum(), kc[nc == k].mean(), kc[nc == k].max()) for k in range(0, 6) if (nc == k).any()))
+print("by searches: " + "; ".join("%d: mean %.0f" % (k, kc[ns == k].mean()) for k in range(0, 12) if (ns == k).any()))

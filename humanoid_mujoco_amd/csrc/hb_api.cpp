@@ -597,6 +597,7 @@ struct hb_batch {
   bool mlp_fused = false;
   float* d_mlp_b[4] = {nullptr, nullptr, nullptr, nullptr};
   float* d_mlp_h[2] = {nullptr, nullptr};  // hidden activations, ping-pong
+  float* d_mlp_act = nullptr;              // activation scratch of the LDS-free policy kernel: [n_env / 16 + kPipes][2][16][widest + 4]
   // optional per-kernel timing of the step kernel (hb_step_timing)
   bool time_steps = false;
   std::vector<hipEvent_t> tev;  // pairs
@@ -979,6 +980,7 @@ void hb_batch_free(hb_batch* b) {
   for (auto e : b->tev) HB_IGN(hipEventDestroy(e));
   for (int i = 0; i < 4; i++) { if (b->d_mlp_w[i]) HB_IGN(hipFree(b->d_mlp_w[i])); if (b->d_mlp_b[i]) HB_IGN(hipFree(b->d_mlp_b[i])); if (b->d_mlp_wp[i]) HB_IGN(hipFree(b->d_mlp_wp[i])); }
   for (int i = 0; i < 2; i++) if (b->d_mlp_h[i]) HB_IGN(hipFree(b->d_mlp_h[i]));
+  if (b->d_mlp_act) HB_IGN(hipFree(b->d_mlp_act));
   if (b->ev0) HB_IGN(hipEventDestroy(b->ev0));
   if (b->ev1) HB_IGN(hipEventDestroy(b->ev1));
   envrand_free_fwd(b);
@@ -2062,6 +2064,14 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
     if (b->d_mlp_h[i]) { HB_IGN(hipFree(b->d_mlp_h[i])); b->d_mlp_h[i] = nullptr; }
     if (hipMalloc((void**)&b->d_mlp_h[i], (size_t)b->n_env * maxh * sizeof(float)) != hipSuccess) return HB_ENOMEM;
   }
+  if (b->d_mlp_act) { HB_IGN(hipFree(b->d_mlp_act)); b->d_mlp_act = nullptr; }
+  if (fused) {
+    int widest = 1;
+    for (int l = 0; l <= n_layers; l++) widest = std::max(widest, sizes[l]);
+    const size_t floats = ((size_t)(b->n_env + 15) / 16 + hb_batch::kPipes) * 32 * (widest + 4);
+    if (hipMalloc((void**)&b->d_mlp_act, floats * sizeof(float)) != hipSuccess) return HB_ENOMEM;
+    HB_HIP(hipMemset(b->d_mlp_act, 0, floats * sizeof(float)));
+  }
   b->mlp_layers = n_layers;
   b->mlp_fused = fused;
   for (int l = 0; l <= n_layers; l++) b->mlp_sizes[l] = sizes[l];
@@ -2069,7 +2079,8 @@ int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* 
 }
 
 // obs -> MLP -> ctrl for envs [lo, hi) on `st`
-static int policy_forward(hb_batch* b, int lo, int hi, hipStream_t st) {
+// (seg >= 0: env segment `seg` of a pipelined closed loop: the LDS-free kernel, which the GPU places beside the running step kernels)
+static int policy_forward(hb_batch* b, int lo, int hi, hipStream_t st, int seg = -1) {
   if (b->mlp_layers < 1) return HB_EINVAL;
   const DevModel& dm = b->D.dm;
   if (b->mlp_fused) {
@@ -2080,7 +2091,14 @@ static int policy_forward(hb_batch* b, int lo, int hi, hipStream_t st) {
     for (int l = 0; l <= b->mlp_layers; l++) { pd.sizes[l] = b->mlp_sizes[l]; widest = std::max(widest, b->mlp_sizes[l]); }
     for (int l = 0; l < b->mlp_layers; l++) { pd.w[l] = b->d_mlp_wp[l]; pd.b[l] = b->d_mlp_b[l]; }
     pd.ldx = widest + 4;  // + the K pad columns (K is swept four at a time); 16-row tiles
-    HB_HIP(launch_policy(dm, pd, b->d_state + (size_t)lo * dm.nstate, ctrl_for_write(b) + (size_t)lo * dm.nu, hi - lo, st));
+    static const bool lean_ok = !(getenv("HB_POLICY_LEAN") && atoi(getenv("HB_POLICY_LEAN")) == 0);
+    static const bool lean_all = getenv("HB_POLICY_LEAN") && atoi(getenv("HB_POLICY_LEAN")) == 2;
+    if (lean_all && seg < 0) seg = 0;
+    if (seg >= 0 && lean_ok && b->d_mlp_act)
+      HB_HIP(launch_policy_lean(dm, pd, b->d_state + (size_t)lo * dm.nstate, ctrl_for_write(b) + (size_t)lo * dm.nu,
+                                b->d_mlp_act + ((size_t)(lo + 15) / 16 + seg) * 32 * pd.ldx, hi - lo, st));
+    else
+      HB_HIP(launch_policy(dm, pd, b->d_state + (size_t)lo * dm.nstate, ctrl_for_write(b) + (size_t)lo * dm.nu, hi - lo, st));
     return HB_OK;
   }
   // wide layers: one launch per layer, activations through HBM
@@ -2118,7 +2136,7 @@ int hb_rollout_policy(hb_batch* b, int T, float* qpos_out_dev) {
     P.qpos_out = qpos_out_dev ? qpos_out_dev + (size_t)t * b->n_env * b->D.dm.nq : nullptr;
     for (int c = 0; c < nseg; c++) {
       const Segment sg = segment(b, c, nseg);
-      rc = policy_forward(b, sg.lo, sg.hi, sg.st);
+      rc = policy_forward(b, sg.lo, sg.hi, sg.st, nseg > 1 ? c : -1);
       if (rc == HB_OK) rc = launch_segment(b, P, 1, sg, nseg, reorder);
       if (rc != HB_OK) return rc;
     }

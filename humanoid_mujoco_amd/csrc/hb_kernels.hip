@@ -3464,6 +3464,91 @@ __global__ __launch_bounds__(512) void hb_policy_kernel(const DevModel M, const 
   }
 }
 
+// The same policy without LDS and inside 48 VGPRs: four waves per block of sixteen envs, activations ping-pong through an L2-resident
+// scratch (the waves of a block share the CU's vector L1).  Two step-kernel waves per SIMD leave 48 VGPRs, six wave slots and no LDS:
+// blocks of THIS kernel run beside them (measured: 6 us slower beside a chip full of step waves than alone), where the LDS variant
+// (33 KB per block) waits for two step blocks of a CU to retire (config 4, pipelined: its 10 us became 43).
+// Activations are stored in the A-operand order of v_mfma_f32_16x16x4_f32 - element (env row, k) at [k / 4][k % 4][row] - so that a
+// k-step's operand is one contiguous 256-byte wave load like the host-packed weights (row-major rows 260 floats apart cost sixteen
+// cache lines per load: 52 us for 4096 envs).
+// (amdgpu_num_vgpr counts per half of the unified register file: 24 -> 48 registers in all, tools/kernel_resources.sh)
+__attribute__((amdgpu_num_vgpr(24))) __global__ __launch_bounds__(256) void hb_policy_lean_kernel(const DevModel M, const PolicyDesc pd, const float* state, float* ctrl,
+                                                                                                  float* act, int n_env) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 16, ldx = pd.ldx;
+  float* cur = act + (size_t)blockIdx.x * 32 * ldx;  // [ldx / 4][4][16]
+  float* nxt = cur + 16 * ldx;
+  {
+    const int row = tid & 15, sub = tid >> 4;  // sixteen threads per observation column stride, consecutive threads = consecutive rows
+    const bool live = m0 + row < n_env;
+    const float* s = state + (size_t)(live ? m0 + row : 0) * M.nstate;
+    const int ncopy = M.nobs - 3;
+    for (int k = sub; k < ncopy; k += 16) {
+      const int src = M.obs_src[k];
+      cur[(k >> 2) * 64 + (k & 3) * 16 + row] = (live && src >= 0) ? s[src] : 0.f;
+    }
+    if (sub == 0) {
+      Q4 q = {1.f, 0.f, 0.f, 0.f};
+      if (live && M.obs_root_qadr >= 0) q = qnormalize(ldq(s + 1 + M.obs_root_qadr + 3));
+      // third row of the rotation matrix of q (q2mat's m[6..8])
+      const float m6 = 2.f * (q.x * q.z - q.w * q.y), m7 = 2.f * (q.y * q.z + q.w * q.x), m8 = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
+      const float g3[3] = {live ? -m6 : 0.f, live ? -m7 : 0.f, live ? -m8 : 0.f};
+      for (int c = 0; c < 3; c++) { const int k = ncopy + c; cur[(k >> 2) * 64 + (k & 3) * 16 + row] = g3[c]; }
+      for (int k = M.nobs; k < ((M.nobs + 3) & ~3); k++) cur[(k >> 2) * 64 + (k & 3) * 16 + row] = 0.f;  // K is swept four at a time: the pad columns must be finite
+    }
+  }
+  __syncthreads();
+  const int col = lane & 15, quad = lane >> 4;  // B: k offset = quad, column = col;  D: rows 4 quad + r, column col
+  for (int l = 0; l < pd.nl; l++) {
+    const int K = pd.sizes[l], N = pd.sizes[l + 1], KK = (K + 3) / 4, ntile = (N + 15) / 16;
+    const bool last = l + 1 == pd.nl;
+    const float* wp = pd.w[l];
+    const float* bias = pd.b[l];
+    if (!last && tid < 16 * (((N + 3) & ~3) - N)) { const int k = N + tid / 16; nxt[(k >> 2) * 64 + (k & 3) * 16 + (tid & 15)] = 0.f; }  // pad columns of the next layer's input
+    // two output tiles per wave and pass: they share the A operand, and their accumulators are two independent MFMA chains
+    for (int nt = 2 * wave; nt < ntile; nt += 8) {
+      const bool two = nt + 1 < ntile;
+      f32x4v D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
+      const float* ap = cur + lane;
+      const float* bp0 = wp + (size_t)nt * KK * 64 + lane;
+      const float* bp1 = bp0 + (two ? (size_t)KK * 64 : 0);
+      int kk = 0;
+      for (; kk + 4 <= KK; kk += 4) {  // four k-steps of operands in flight per batch of MFMAs (measured: three, which spill less, are slower)
+        float a[4], w0[4], w1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = ap[(kk + u) * 64]; w0[u] = bp0[(kk + u) * 64]; w1[u] = bp1[(kk + u) * 64]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w0[u], D0, 0, 0, 0);
+          D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w1[u], D1, 0, 0, 0);
+        }
+      }
+      for (; kk < KK; kk++) {
+        const float a = ap[kk * 64];
+        D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp0[kk * 64], D0, 0, 0, 0);
+        D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp1[kk * 64], D1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if (h == 1 && !two) break;
+        const int n = (nt + h) * 16 + col;
+        const float bn = n < N ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = 4 * quad + r;
+          if (n < N) {
+            const float v = tanhf((h ? D1[r] : D0[r]) + bn);
+            if (!last) nxt[(n >> 2) * 64 + (n & 3) * 16 + row] = v;
+            else if (m0 + row < n_env) ctrl[(size_t)(m0 + row) * N + n] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+  }
+}
+
 // Heavy-first dispatch order for the next launch: counting sort of the envs by the cost proxy of their
 // last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
 // the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
@@ -3631,6 +3716,11 @@ hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   hipLaunchKernelGGL(hb_mlp_layer_kernel, dim3((Mrows + 31) / 32, (N + 31) / 32), dim3(kGroup), (size_t)32 * (K + 1) * sizeof(float), stream, X, W, bias, Y, Mrows, K, N, act);
+  return hipGetLastError();
+}
+hipError_t launch_policy_lean(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, float* act, int n_env, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(hb_policy_lean_kernel, dim3((n_env + 15) / 16), dim3(256), 0, stream, M, pd, state, ctrl, act, n_env);
   return hipGetLastError();
 }
 hipError_t launch_policy(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, int n_env, hipStream_t stream) {

@@ -20,6 +20,7 @@ hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, const EnvRand& R,
 hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset,
                               hipStream_t stream);
 hipError_t launch_policy(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, int n_env, hipStream_t stream);
+hipError_t launch_policy_lean(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, float* act, int n_env, hipStream_t stream);
 hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream, int slot = 3, int shift = 3);
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream);
 hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream);

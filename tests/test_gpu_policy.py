@@ -88,23 +88,30 @@ def test_closed_loop_rollout_matches_host_loop(hbmod, humanoid_model, gpu):
     assert np.abs(d.qpos - e.qpos).max() < 1e-4
 
 
-def test_pipelined_policy_rollout_is_bit_identical(hbmod, humanoid_model, gpu):
-    """With hb_batch_pipeline on, every env segment runs its own obs -> MLP -> mj_step chain on its own
-    stream; the closed-loop result is the unpipelined one bit for bit."""
+def test_pipelined_policy_rollout(hbmod, humanoid_model, gpu):
+    """With hb_batch_pipeline on, every env segment runs its own obs -> MLP -> mj_step chain on its own stream.  The segments'
+    policy kernel is the LDS-free one (it runs beside the other segment's step kernel instead of waiting for its LDS): the closed
+    loop is bit-identical for any number of segments, and equal to the unpipelined loop (the LDS kernel: another summation order
+    in the last layer) to rounding - a few steps on, before the contact dynamics amplifies the last bits."""
     m = humanoid_model
     n, T = 600, 30
     ws, bs = make_policy(m.nobs, m.nu)
-    out = []
+    out, early = [], []
     for segs in (0, 2, 3):
         b = hbmod.Batch(m, n, gpu)
         b.reset(perturb=True)
         b.set_policy_mlp(ws, bs)
         b.pipeline(segs)
+        b.rollout_policy(4)
+        early.append(b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64))
         b.rollout_policy(T)
         b.rollout_policy(3)
         out.append(b.get_state(hbmod.STATE_INTEGRATION))
-    assert np.array_equal(out[0], out[1])
-    assert np.array_equal(out[0], out[2])
+        assert not b.status().any()
+    assert np.array_equal(out[1], out[2])
+    nq = m.nq
+    assert np.abs(early[0][:, 1:1 + nq] - early[1][:, 1:1 + nq]).max() < 1e-4  # (measured 1.3e-5: the bound of the numpy-policy comparison above)
+    assert np.isfinite(out[0]).all() and np.isfinite(out[1]).all()
 
 
 def test_policy_argument_checks(hbmod, humanoid_model, gpu):

@@ -10,7 +10,7 @@ m = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid2
 N, T = 4096, 300
 torch.manual_seed(0)
 layers = [torch.nn.Linear(m.nobs, 256), torch.nn.Linear(256, 256), torch.nn.Linear(256, m.nu)]
-for segs in (0, 2):
+for segs in (0, 2, 3, 4):
     b = hb.Batch(m, N, 0)
     b.set_policy_mlp([l.weight.detach().numpy().T.copy() for l in layers], [l.bias.detach().numpy().copy() for l in layers])
     b.reset(perturb=True)

@@ -2569,7 +2569,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 }
 
 // PGS instantiations: dense order 28 (nv <= 28: the 27-dof humanoid; M^-1 by elimination on the matrix cores) and 32 (sparse L'DL)
-__global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28>(Mp, P, nsteps); }
+// (224 registers instead of the 229 the allocator would take - two values spilled - so that beside two of its waves a SIMD has 64
+// registers left: what the closed loop's policy kernel runs in, hb_policy_lean_kernel; amdgpu_num_vgpr counts per half of the file)
+__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 32>(Mp, P, nsteps); }
 // General instantiations (mesh hulls, height-field prisms, condim 4 / 6): PGS on 63 rows (configs[4]: the 27-dof humanoid on terrain),
 // Newton on 256 rows (the reference's own robot, simulation/assets/world.xml: 18 dofs -> dense order 20; up to 28 dofs)
@@ -3464,15 +3466,16 @@ __global__ __launch_bounds__(512) void hb_policy_kernel(const DevModel M, const 
   }
 }
 
-// The same policy without LDS and inside 48 VGPRs: four waves per block of sixteen envs, activations ping-pong through an L2-resident
-// scratch (the waves of a block share the CU's vector L1).  Two step-kernel waves per SIMD leave 48 VGPRs, six wave slots and no LDS:
+// The same policy without LDS and inside 64 VGPRs: four waves per block of sixteen envs, activations ping-pong through an L2-resident
+// scratch (the waves of a block share the CU's vector L1).  Two step-kernel waves per SIMD leave 64 VGPRs, six wave slots and no LDS:
 // blocks of THIS kernel run beside them (measured: 6 us slower beside a chip full of step waves than alone), where the LDS variant
 // (33 KB per block) waits for two step blocks of a CU to retire (config 4, pipelined: its 10 us became 43).
 // Activations are stored in the A-operand order of v_mfma_f32_16x16x4_f32 - element (env row, k) at [k / 4][k % 4][row] - so that a
 // k-step's operand is one contiguous 256-byte wave load like the host-packed weights (row-major rows 260 floats apart cost sixteen
 // cache lines per load: 52 us for 4096 envs).
-// (amdgpu_num_vgpr counts per half of the unified register file: 24 -> 48 registers in all, tools/kernel_resources.sh)
-__attribute__((amdgpu_num_vgpr(24))) __global__ __launch_bounds__(256) void hb_policy_lean_kernel(const DevModel M, const PolicyDesc pd, const float* state, float* ctrl,
+// (amdgpu_num_vgpr counts per half of the unified register file: 32 -> 64 registers in all, tools/kernel_resources.sh; with 48 - what
+// is left beside two 232-register waves - the kernel spills 23 values and the loop runs 3.10e7 instead of 3.20e7 env-steps/s)
+__attribute__((amdgpu_num_vgpr(32))) __global__ __launch_bounds__(256) void hb_policy_lean_kernel(const DevModel M, const PolicyDesc pd, const float* state, float* ctrl,
                                                                                                   float* act, int n_env) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * 16, ldx = pd.ldx;
@@ -3513,7 +3516,7 @@ __attribute__((amdgpu_num_vgpr(24))) __global__ __launch_bounds__(256) void hb_p
       const float* bp0 = wp + (size_t)nt * KK * 64 + lane;
       const float* bp1 = bp0 + (two ? (size_t)KK * 64 : 0);
       int kk = 0;
-      for (; kk + 4 <= KK; kk += 4) {  // four k-steps of operands in flight per batch of MFMAs (measured: three, which spill less, are slower)
+      for (; kk + 4 <= KK; kk += 4) {  // four k-steps of operands in flight per batch of MFMAs (measured: three are slower; loading the next batch under this one's MFMAs changes nothing)
         float a[4], w0[4], w1[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) { a[u] = ap[(kk + u) * 64]; w0[u] = bp0[(kk + u) * 64]; w1[u] = bp1[(kk + u) * 64]; }

@@ -380,6 +380,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     }
   }
   TF(geom_half, geom_half);
+  dm.box_cull = !(getenv("HB_BOX_CULL") && atoi(getenv("HB_BOX_CULL")) == 0);
   std::vector<int> pair_self;  // both geoms of the pair on the robot (neither on the world body)
   for (int p = 0; p < m.npair; p++) pair_self.push_back(m.geom_bodyid[m.pair_geom1[p]] != 0);
   TI(pair_geom1, m.pair_geom1); TI(pair_geom2, m.pair_geom2); TI(pair_dim, pair_dim); TI(pair_self, pair_self);

@@ -82,6 +82,7 @@ struct DevModel {
   const int HB_CONST *geom_type, *geom_bodyid;
   const float HB_CONST *geom_size, *geom_pos, *geom_quat, *geom_rbound;
   const float HB_CONST* geom_half;  // [ngeom][3] half extents of the geom's bounding box in its own frame
+  int box_cull;                     // 1: oriented-box test behind the bounding spheres of a portal-search pair (HB_BOX_CULL=0 switches it off: tests)
   // meshes: hull vertices as 16-byte records (x, y, z, link) and per geom the first record / the count (0 for other geom types);
   // link = first neighbour record << 8 | number of kMeshChunk-record chunks; mesh_nbr: one record per (vertex, neighbour): (x, y, z
   // of the neighbour, the neighbour's own link): the hull's edge graph with the coordinates inlined, every vertex's list padded to

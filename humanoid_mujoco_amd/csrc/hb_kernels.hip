@@ -686,7 +686,7 @@ __device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const fl
         // that a separating axis keeps apart hold hulls that do not touch: the search would say so too, after two hull climbs
         // per support query (the robot's limbs are long and thin: most pairs that pass the bounding spheres stop here)
         const int t2 = (__float_as_int(c0.z) >> 8) & 255;
-        if (pass && (t1 == 7 || t2 == 7)) pass = boxes_touch(M, g1, g2, dp, ldq(s_gquat + 4 * g1), ldq(s_gquat + 4 * g2), 0.5f * c0.w);
+        if (pass && M.box_cull && (t1 == 7 || t2 == 7)) pass = boxes_touch(M, g1, g2, dp, ldq(s_gquat + 4 * g1), ldq(s_gquat + 4 * g2), 0.5f * c0.w);
       }
     }
     const unsigned long long bal = __ballot(pass);

@@ -387,6 +387,27 @@ def main():
                         "(pose, narrowphase, step kernels), same step API and pipelining as `value`" % n_env}
         tb.dev_free(tctrl)
         tb.close()
+        # the same at the batch size that fills the chip under the narrowphase's latency chain (the robot against the batch size)
+        NB = 32768
+        tb = hb.Batch(tm, NB, device)
+        tb.reset(keyframe=1, perturb=True)
+        tb.rollout_halton(200, 0, 0)
+        tb.pipeline(pipelined)
+        KB = 40
+        tctrl = tb.dev_alloc(KB * NB * tm.nu * 4)
+        tb.halton_ctrl_dev(KB, 200, 0, tctrl)
+        for t in range(5):
+            tb.step_dev(tctrl + t * NB * tm.nu * 4)
+        tb.sync()
+        t2 = time.perf_counter()
+        for t in range(KB):
+            tb.step_dev(tctrl + t * NB * tm.nu * 4)
+        tb.sync()
+        el = time.perf_counter() - t2
+        team["at_32768_envs"] = {"value": NB * KB / el, "unit": "env-steps/s", "ms_per_step": 1e3 * el / KB, "steps": KB, "envs_with_warnings": int((tb.status() != 0).sum()),
+                                 "what": "same model and step API, 32768 envs on the GPU, on-device Halton controls"}
+        tb.dev_free(tctrl)
+        tb.close()
 
     if rank == 0:
         value = n_env * world * K / elapsed

@@ -636,7 +636,7 @@ static void ccd_center(const ccd_obj* o, double* c) {
 }
 /* diagnostic counters of the narrowphase (single-threaded use: tools/mpr_stats.py): tests, support calls on meshes, climb rounds
  * (one evaluation of all neighbours of the current vertex), neighbour evaluations, portal iterations */
-static long long om_stat[8];
+static _Thread_local long long om_stat[8]; /* per thread: the rollout threads of om_rollout_threads do not share them */
 void om_mpr_stats(long long* out, int reset) { for (int i = 0; i < 8; i++) { out[i] = om_stat[i]; if (reset) om_stat[i] = 0; } }
 /* mjccd_support / prism_support: the point of the object farthest along dir (dir is unit: every caller in mpr.c normalises) */
 static void ccd_support(ccd_obj* o, const double* dir, double* out) {

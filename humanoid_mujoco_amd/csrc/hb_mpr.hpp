@@ -1,9 +1,9 @@
-// hb_mpr.hpp — convex narrowphase on the device (fp32): libccd's Minkowski Portal Refinement as MuJoCo uses it for mesh
+// hb_mpr.hpp — convex narrowphase on the device (fp64 arithmetic on fp32 geometry): libccd's Minkowski Portal Refinement as MuJoCo uses it for mesh
 // geoms (through their convex hulls) and for every geom against a height-field prism (engine_collision_convex.c: mjc_Convex,
 // mjc_ConvexHField; mujoco.h:355 mj_collision).  Mirrors oracle/mjstep_oracle.c (mpr_penetration, ccd_support, fix_normal)
-// statement for statement so that the discrete decisions of the portal search agree wherever fp32 allows.
-// One LANE runs one (pair, prism) test: the loops below are per lane and divergent; a mesh's support function is an
-// climb along the hull's edge graph (16-byte records in the model tables, served by L1 / L2).
+// statement for statement so that the discrete decisions of the portal search agree wherever the fp32 poses allow.
+// One LANE runs one (pair, prism) test: the loops below are per lane and divergent; a mesh's support function is a
+// climb along the hull's edge graph (16-byte records in the model tables, served by L1 / L2) from a cube map of start vertices.
 // Included by hb_kernels.hip only (uses its V3 / Q4 helpers).
 #pragma once
 
@@ -12,8 +12,8 @@ namespace hb {
 // The portal search runs in DOUBLE precision on the device too.  Measured with an fp32 version: against a height-field prism
 // (metres wide, a geom centimetres across) sign tests of the portal expansion flip under fp32 rounding, the search then stops on
 // a portal far from the surface and reports a penetration of the prism's whole depth (1 m): envs exploded at a rate of 2 % per
-// thousand steps on the terrain benchmark.  MI355X issues fp64 vector math at half the fp32 rate, and with the same arithmetic
-// as the oracle the discrete decisions agree as well.  Geometry stays fp32 in registers (CObj) and is widened at use.
+// thousand steps on the terrain benchmark.  An fp64 fma issues like an unpacked fp32 one on MI355X (tools/micro/fp64_rates.hip), and
+// with the same arithmetic as the oracle the discrete decisions agree as well.  Geometry stays fp32 in registers (CObj) and is widened at use.
 #define HB_CCD_EPS 2.220446049250313e-16  // DBL_EPSILON: libccd's CCD_EPS in its double-precision build (what MuJoCo links)
 struct V3d { double x, y, z; };
 __device__ __forceinline__ V3d operator+(V3d a, V3d b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }

@@ -1260,8 +1260,8 @@ int hb_transition_fd_sensors(hb_batch* b, const double* x, const double* u, cons
 }
 
 int hb_ctrl_tape_splines(hb_batch* b, const float* knots, const float* times, int n_points, int interpolation, double time0, int T) {
-  if (!b || !knots || !times || n_points < 1 || n_points > 64 || interpolation < 0 || interpolation > 2 || T < 1 || b->D.dm.nu < 1) return HB_EINVAL;
-  if (interpolation == 2 && n_points < 2) return HB_EINVAL;
+  // an empty spline samples as zeros and a one-node spline as its node, whatever the interpolation (spline.cc:103-118; spline_test.cc:41-64)
+  if (!b || n_points < 0 || n_points > 64 || (n_points > 0 && (!knots || !times)) || interpolation < 0 || interpolation > 2 || T < 1 || b->D.dm.nu < 1) return HB_EINVAL;
   for (int k = 1; k < n_points; k++) if (!(times[k] > times[k - 1])) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   const int N = b->n_env, nu = b->D.dm.nu;
@@ -1270,10 +1270,45 @@ int hb_ctrl_tape_splines(hb_batch* b, const float* knots, const float* times, in
   if (rc != HB_OK) return rc;
   rc = ensure_ctrl(b, (size_t)T * N * nu);
   if (rc != HB_OK) return rc;
-  HB_HIP(hipMemcpyAsync(b->d_knots, knots, nk * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
-  HB_HIP(hipMemcpyAsync(b->d_knots + nk, times, (size_t)n_points * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  if (n_points > 0) {
+    HB_HIP(hipMemcpyAsync(b->d_knots, knots, nk * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+    HB_HIP(hipMemcpyAsync(b->d_knots + nk, times, (size_t)n_points * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  }
   HB_HIP(launch_spline_tape(b->D.dm, b->d_knots, b->d_knots + nk, n_points, interpolation, (float)time0, (float)b->model->m.timestep, T, N, b->d_ctrl, main_stream(b)));
   b->tape_steps = T;
+  return HB_OK;
+}
+
+int hb_ctrl_tape_read(hb_batch* b, int T, float* out) {
+  if (!b || !out || T < 1 || T > b->tape_steps) return HB_EINVAL;
+  HB_HIP(hipSetDevice(b->device));
+  HB_HIP(hipMemcpyAsync(out, b->d_ctrl, (size_t)T * b->n_env * b->D.dm.nu * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
+}
+
+int hb_task_cost(hb_batch* b, const float* residual, int n, int n_residual, const hb_cost_spec* spec, float* terms, float* cost) {
+  if (!b || !residual || !spec || !cost || n < 1 || n_residual < 1 || spec->n_term < 1 || spec->n_term > 8) return HB_EINVAL;
+  CostSpec K;
+  memset(&K, 0, sizeof K);
+  int total_dim = 0;
+  for (int k = 0; k < spec->n_term; k++) {
+    if (spec->dim[k] < 1 || spec->norm[k] < -1 || spec->norm[k] > 8 || spec->norm[k] == 4) return HB_EINVAL;  // kJunction (4) has no value-only form here
+    K.dim[k] = spec->dim[k]; K.norm[k] = spec->norm[k]; K.weight[k] = spec->weight[k]; K.p[k] = spec->norm_p[k][0]; K.q[k] = spec->norm_p[k][1];
+    total_dim += spec->dim[k];
+  }
+  if (total_dim != n_residual) return HB_EINVAL;  // "mismatch between total user-sensor dimension and actual length of residual"
+  K.nterm = spec->n_term; K.risk = spec->risk;
+  HB_HIP(hipSetDevice(b->device));
+  const size_t nr = (size_t)n * n_residual, nt = (size_t)n * spec->n_term;
+  int rc = ensure_trace(&b->d_sensor_out, &b->sensor_out_cap, nr);
+  if (rc != HB_OK) return rc;
+  if ((rc = ensure_trace(&b->d_task_out, &b->task_out_cap, nt + n)) != HB_OK) return rc;
+  HB_HIP(hipMemcpyAsync(b->d_sensor_out, residual, nr * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
+  HB_HIP(launch_cost_terms(b->d_sensor_out, n, n_residual, K, terms ? b->d_task_out + n : nullptr, b->d_task_out, main_stream(b)));
+  HB_HIP(hipMemcpyAsync(cost, b->d_task_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  if (terms) HB_HIP(hipMemcpyAsync(terms, b->d_task_out + n, nt * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
+  HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
 

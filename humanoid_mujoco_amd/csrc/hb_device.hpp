@@ -216,6 +216,12 @@ struct WalkTask {
   float weight[8], p[8], q[8];
 };
 
+// hb_task_cost: cost terms over consecutive slices of a residual vector (task.cc:71-110)
+struct CostSpec {
+  int nterm, dim[8], norm[8];
+  float weight[8], p[8], q[8], risk;
+};
+
 struct PolicyDesc {
   int nl;
   int sizes[5];

@@ -2788,6 +2788,29 @@ __device__ __forceinline__ float mjpc_norm(int type, const float* x, int n, floa
   }
 }
 
+// BaseResidualFn::CostTerms + CostValue (mujoco_mpc/mjpc/task.cc:71-110): term k = weight[k] * Norm(norm[k]) of the next dim[k] residual
+// entries; the sum goes through the risk transformation (risk-neutral below kRiskNeutralTolerance = 1e-6).  `terms` nullable.
+__device__ __forceinline__ float mjpc_risk(float risk, float c) { return fabsf(risk) >= 1e-6f ? (expf(risk * c) - 1.f) / risk : c; }
+__device__ __forceinline__ float mjpc_cost_value(int nterm, const int* dim, const int* norm, const float* weight, const float* p, const float* q, float risk,
+                                                 const float* res, float* terms) {
+  float cost = 0.f;
+  int sh = 0;
+  for (int k = 0; k < nterm; k++) {
+    const float tk = weight[k] * mjpc_norm(norm[k], res + sh, dim[k], p[k], q[k]);
+    if (terms) terms[k] = tk;
+    cost += tk;
+    sh += dim[k];
+  }
+  return mjpc_risk(risk, cost);
+}
+
+// hb_task_cost: the same cost evaluation for n caller-supplied residual vectors (one thread each)
+__global__ void hb_cost_terms_kernel(const float* residual, int n, int nres, const CostSpec K, float* terms, float* cost) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  cost[e] = mjpc_cost_value(K.nterm, K.dim, K.norm, K.weight, K.p, K.q, K.risk, residual + (size_t)e * nres, terms ? terms + (size_t)e * K.nterm : nullptr);
+}
+
 // One thread per candidate: Stand::ResidualFn::Residual (tasks/humanoid/stand/stand.cc:41-104) on each of the H rows,
 // BaseResidualFn::CostValue (task.cc:71-110), Trajectory::UpdateReturn (trajectory.cc:312-326); a candidate that raised
 // a bad-state warning returns kMaxReturnValue (trajectory.cc:29,169-173)
@@ -2809,7 +2832,7 @@ __global__ void hb_stand_cost_kernel(const float* rows, int H, int n_env, const 
     c += K.weight[2] * mjpc_norm(K.norm[2], r + K.o_vel, 2, K.p[2], K.q[2]);
     c += K.weight[3] * mjpc_norm(K.norm[3], r + K.o_qvel + 6, K.nv - 6, K.p[3], K.q[3]);
     c += K.weight[4] * mjpc_norm(K.norm[4], r + K.o_ctrl, K.nu, K.p[4], K.q[4]);
-    if (fabsf(K.risk) >= 1e-6f) c = (expf(K.risk * c) - 1.f) / K.risk;
+    c = mjpc_risk(K.risk, c);
     if (costs) costs[(size_t)t * n_env + e] = c;
     sum += c;
   }
@@ -2869,10 +2892,7 @@ __global__ void hb_walk_cost_kernel(const float* rows, int H, int n_env, const W
     res[c++] = standing * (cv[1] - 0.5f * tv[4] - 0.5f * tv[7]);
     // control
     for (int i = 0; i < K.nu; i++) res[c++] = r[K.o_ctrl + i];
-    float cost = 0.f;
-    int sh = 0;
-    for (int k = 0; k < K.nterm; k++) { cost += K.weight[k] * mjpc_norm(K.norm[k], res + sh, K.dim[k], K.p[k], K.q[k]); sh += K.dim[k]; }
-    if (fabsf(K.risk) >= 1e-6f) cost = (expf(K.risk * cost) - 1.f) / K.risk;
+    const float cost = mjpc_cost_value(K.nterm, K.dim, K.norm, K.weight, K.p, K.q, K.risk, res, nullptr);
     if (costs) costs[(size_t)t * n_env + e] = cost;
     sum += cost;
   }
@@ -3746,6 +3766,11 @@ hipError_t launch_stand_cost(const float* rows, int H, int n_env, const StandTas
 hipError_t launch_walk_cost(const float* rows, int H, int n_env, const WalkTask& K, const int* status, float* total, float* costs, hipStream_t stream) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(hb_walk_cost_kernel, dim3((n_env + 63) / 64), dim3(64), 0, stream, rows, H, n_env, K, status, total, costs);
+  return hipGetLastError();
+}
+hipError_t launch_cost_terms(const float* residual, int n, int nres, const CostSpec& K, float* terms, float* cost, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(hb_cost_terms_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, residual, n, nres, K, terms, cost);
   return hipGetLastError();
 }
 hipError_t launch_spline_tape(const DevModel& M, const float* knots, const float* times, int P, int interp, float time0, float dt, int T, int n_env, float* tape, hipStream_t stream) {

@@ -74,6 +74,12 @@ class HbTaskWalk(ctypes.Structure):
                 ("risk", ctypes.c_float)]
 
 
+class HbCostSpec(ctypes.Structure):
+    """hb_cost_spec (include/hb.h): cost terms over consecutive slices of a residual vector (mjpc task.cc:71-110)."""
+    _fields_ = [("n_term", ctypes.c_int), ("dim", ctypes.c_int * 8), ("norm", ctypes.c_int * 8), ("weight", ctypes.c_float * 8),
+                ("norm_p", (ctypes.c_float * 2) * 8), ("risk", ctypes.c_float)]
+
+
 class HbSensorSpec(ctypes.Structure):
     """hb_sensor_spec (include/hb.h): framepos bodies and the tree whose subtreecom / subtreelinvel are read out."""
     _fields_ = [("n_framepos", ctypes.c_int), ("framepos_body", ctypes.c_int * 16), ("subtree_body", ctypes.c_int),
@@ -160,6 +166,8 @@ def lib():
     L.hb_rollout_trajectory.argtypes = [vp, vp, ci, vp, vp, vp]
     L.hb_rollout_noise.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_uint]
     L.hb_ctrl_tape_splines.argtypes = [vp, vp, vp, ci, ci, ctypes.c_double, ci]
+    L.hb_ctrl_tape_read.argtypes = [vp, ci, vp]
+    L.hb_task_cost.argtypes = [vp, vp, ci, ci, ctypes.POINTER(HbCostSpec), vp, vp]
     L.hb_transition_fd.argtypes = [vp, vp, vp, vp, ci, ctypes.c_double, ci, vp, vp]
     L.hb_transition_fd_sensors.argtypes = [vp, vp, vp, vp, ci, ctypes.c_double, ci, ctypes.POINTER(HbSensorSpec), vp, vp, vp, vp]
     L.hb_task_stand_default.argtypes = [vp, ctypes.POINTER(HbTaskStand)]
@@ -509,7 +517,30 @@ class Batch:
         k = np.ascontiguousarray(knots, dtype=np.float32)
         tm = np.ascontiguousarray(times, dtype=np.float32)
         assert k.shape == (self.n_env, len(tm), self.model.nu), k.shape
-        _check(lib().hb_ctrl_tape_splines(self._h, _ptr(k), _ptr(tm), len(tm), int(interpolation), float(time0), int(T)), "hb_ctrl_tape_splines")
+        _check(lib().hb_ctrl_tape_splines(self._h, _ptr(k) if len(tm) else None, _ptr(tm) if len(tm) else None, len(tm), int(interpolation), float(time0), int(T)),
+               "hb_ctrl_tape_splines")
+
+    def ctrl_tape_read(self, T):
+        """The tape ctrl_tape_splines left on the device: [T, n_env, nu] (TimeSpline::Sample per candidate and step time)."""
+        out = np.zeros((int(T), self.n_env, self.model.nu), dtype=np.float32)
+        _check(lib().hb_ctrl_tape_read(self._h, int(T), _ptr(out)), "hb_ctrl_tape_read")
+        return out
+
+    def task_cost(self, residual, dims, norms, weights, norm_p=None, risk=0.0):
+        """BaseResidualFn::CostTerms / CostValue on the device for residual [n, n_residual] -> (terms [n, n_term], cost [n])."""
+        r = np.ascontiguousarray(residual, dtype=np.float32)
+        n, nres = r.shape
+        sp = HbCostSpec()
+        sp.n_term = len(dims)
+        for k in range(len(dims)):
+            sp.dim[k] = int(dims[k]); sp.norm[k] = int(norms[k]); sp.weight[k] = float(weights[k])
+            if norm_p is not None:
+                sp.norm_p[k][0] = float(norm_p[k][0]); sp.norm_p[k][1] = float(norm_p[k][1])
+        sp.risk = float(risk)
+        terms = np.zeros((n, len(dims)), dtype=np.float32)
+        cost = np.zeros(n, dtype=np.float32)
+        _check(lib().hb_task_cost(self._h, _ptr(r), n, nres, ctypes.byref(sp), _ptr(terms), _ptr(cost)), "hb_task_cost")
+        return terms, cost
 
     def _tape_or_ctrl(self, ctrl):
         if isinstance(ctrl, tuple) and ctrl[0] == "tape":

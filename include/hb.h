@@ -199,6 +199,24 @@ int hb_rollout_sensors(hb_batch* b, const float* ctrl, int T, const hb_sensor_sp
  * T * nu. */
 #define HB_CTRL_TAPE ((const float*)(uintptr_t)1)
 int hb_ctrl_tape_splines(hb_batch* b, const float* knots, const float* times, int n_points, int interpolation, double time0, int T);
+/* The tape hb_ctrl_tape_splines left on the device, copied back: out[T][n_env][nu] (host), T <= the tape's length; HB_EINVAL when
+ * there is no tape (any call that writes the batch's controls discards it).  This is TimeSpline::Sample for every candidate at
+ * every step time, which is how the reference's own expectations for the spline (mujoco_mpc/mjpc/test/spline/spline_test.cc:52-157)
+ * are checked against the device code (tests/test_gpu_mjpc_expectations.py). */
+int hb_ctrl_tape_read(hb_batch* b, int T, float* out);
+/* BaseResidualFn::CostTerms and CostValue (mujoco_mpc/mjpc/task.cc:71-110) for n residual vectors at once, on the device, with the
+ * code the hb_rollout_task_* kernels use: term k = weight[k] * Norm(norm[k]; norm_p[k]) over the next dim[k] entries of the
+ * residual (mjpc/norm.h:24-36), cost = the sum through the risk transformation (exp(risk c) - 1) / risk, or the sum itself when
+ * |risk| < 1e-6.  residual[n][n_residual], terms[n][n_term] (nullable), cost[n]: host pointers.  sum(dim) must equal n_residual. */
+typedef struct hb_cost_spec {
+  int n_term;
+  int dim[8];
+  int norm[8];          /* mjpc::NormType */
+  float weight[8];
+  float norm_p[8][2];
+  float risk;
+} hb_cost_spec;
+int hb_task_cost(hb_batch* b, const float* residual, int n, int n_residual, const hb_cost_spec* spec, float* terms, float* cost);
 /* Trajectory::NoisyRollout's perturbation (mujoco_mpc/mjpc/trajectory.cc:147-156): before every step of the calls that
  * follow, every xfrc_applied entry of every env becomes rate * xfrc + scale * N(0, 1), rate = exp(-timestep / xfrc_rate),
  * scale = xfrc_std * sqrt(1 - rate^2) (an Ornstein-Uhlenbeck process with stationary deviation xfrc_std); xfrc_std = 0

@@ -266,3 +266,39 @@ def halton(index, base):
         index //= base
         f /= base
     return r
+
+
+# ---- rounding fences: a discrete decision (which MPR portal a search ends on, whether a geom pair is inside its margin) may fall the
+# other way between the fp32 device and the fp64 oracle when the state sits within a rounding of the decision's boundary.  The parity
+# tests do not skip such a case on suspicion: they require PROOF that the oracle itself gives the device's answer from a state no
+# further away than fp32 rounding.  Anything that cannot be proved this way is a failure.
+FENCE_MAGNITUDES = (6e-8, 2e-7, 6e-7)  # half an fp32 ulp at 1, and the few ulps the fp32 kinematics of a 7-link chain accumulates
+FENCE_TRIES = 48
+
+
+def load_state(o, state, ctrl):
+    """mjSTATE_INTEGRATION record [time, qpos, qvel, qacc_warmstart] + ctrl into the oracle's data (after a reset)."""
+    nq, nv = o.nq, o.nv
+    o.reset()
+    o.L.om_data_set_time(o.d, float(state[0]))
+    o.qpos[:] = state[1:1 + nq]
+    o.qvel[:] = state[1 + nq:1 + nq + nv]
+    o.qacc_warmstart[:] = state[1 + nq + nv:1 + nq + 2 * nv]
+    o.ctrl[:] = ctrl
+
+
+def prove_rounding_fence(o, state, ctrl, accept, seed=0):
+    """Search the fp32-rounding neighbourhood of `state` (qpos perturbed by FENCE_MAGNITUDES x N(0,1) x max(1, |qpos|)) for a state from which
+    the oracle reproduces the device: accept(o) is called with the perturbed state loaded (nothing evaluated yet) and returns True on
+    a match.  Returns the perturbation magnitude that matched (the oracle is left in accept's final state), or None: no proof."""
+    rng = np.random.default_rng(seed)
+    state = np.asarray(state, dtype=np.float64)
+    nq = o.nq
+    for mag in FENCE_MAGNITUDES:
+        for _ in range(FENCE_TRIES):
+            st = state.copy()
+            st[1:1 + nq] += mag * rng.standard_normal(nq) * np.maximum(1.0, np.abs(st[1:1 + nq]))
+            load_state(o, st, ctrl)
+            if accept(o):
+                return mag
+    return None

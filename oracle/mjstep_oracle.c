@@ -999,6 +999,40 @@ static void contact_param(const om_model* m, om_contact* c, int g1, int g2) {
   c->friction[3] = c->friction[4] = fmax(MINMU, fr[2]);
 }
 
+/* ANALYSIS KNOB (tests/test_oracle_contact_order.py, tools/contact_order_sensitivity.py): the order in which mj_collision emits
+ * contacts is one of the restatement's unverifiable choices (this file: static (geom1, geom2) order; MuJoCo 3.1: sorted body pairs,
+ * then a BVH traversal inside a body pair).  The order changes nothing physical, but Gauss-Seidel cut at a finite sweep count depends
+ * on it.  To MEASURE that dependence the contact list can be re-ordered after the collision pass: 0 as emitted (default; what the
+ * device mirrors), 1 reversed inside every body pair (a different intra-pair traversal), 2 fully reversed, 3 a seeded shuffle. */
+static int g_contact_order = 0;
+static unsigned g_contact_seed = 0;
+void om_set_contact_order(int mode, unsigned seed) { g_contact_order = mode; g_contact_seed = seed; }
+static void permute_contacts(const om_model* m, om_data* d) {
+  const int n = d->ncon;
+  if (!g_contact_order || n < 2) return;
+  om_contact tmp;
+  if (g_contact_order == 1) {
+    for (int a = 0; a < n;) {
+      int b = a;
+      const int b1 = m->geom_bodyid[d->contact[a].geom1], b2 = m->geom_bodyid[d->contact[a].geom2];
+      while (b + 1 < n && m->geom_bodyid[d->contact[b + 1].geom1] == b1 && m->geom_bodyid[d->contact[b + 1].geom2] == b2) b++;
+      for (int i = a, j = b; i < j; i++, j--) { tmp = d->contact[i]; d->contact[i] = d->contact[j]; d->contact[j] = tmp; }
+      a = b + 1;
+    }
+  } else if (g_contact_order == 2) {
+    for (int i = 0, j = n - 1; i < j; i++, j--) { tmp = d->contact[i]; d->contact[i] = d->contact[j]; d->contact[j] = tmp; }
+  } else {
+    unsigned long long x = 0x9E3779B97F4A7C15ull * (g_contact_seed + 1);
+    for (int i = n - 1; i > 0; i--) {  /* Fisher-Yates on a splitmix64 stream */
+      x += 0x9E3779B97F4A7C15ull;
+      unsigned long long z = x;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+      const int j = (int)(z % (unsigned long long)(i + 1));
+      tmp = d->contact[i]; d->contact[i] = d->contact[j]; d->contact[j] = tmp;
+    }
+  }
+}
+
 /* mj_collision, mujoco.h:355: candidate pairs are the statically filtered list in the model
  * (same-body / parent-child / exclude / contype filters applied at compile time), visited in
  * (geom1, geom2) order; a bounding-sphere test stands in for the broadphase. */
@@ -1061,6 +1095,7 @@ static void collision(const om_model* m, om_data* d) {
       contact_param(m, c, g1, g2);
     }
   }
+  permute_contacts(m, d);
 }
 
 /* ------------------------------------------------------------------ constraints ---------- */

@@ -59,6 +59,7 @@ def lib():
         L.om_rollout_threads.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         L.om_mpr_test.restype = ci
         L.om_mpr_test.argtypes = [ci, pd, pd, pd, pd, ci, ci, pd, pd, pd, pd, ci, cd, pd, pd, pd]
+        L.om_set_contact_order.argtypes = [ci, ctypes.c_uint]
         L.om_rollout_window.restype = ctypes.c_longlong
         L.om_rollout_window.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, pd]
         _lib = L

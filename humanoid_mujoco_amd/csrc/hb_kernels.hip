@@ -955,11 +955,12 @@ __device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, 
 // contacts is not stepped here but flagged for the four-group kernel.  2 (variant 1): same capacities as the full kernel, nothing to
 // overflow into.  Both: an env-step whose qacc comes out bad (mj_checkAcc: reset, second forward pass with a narrowphase of its own) is
 // flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
-template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0>
-__device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps) {
+template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0>
+__device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps, int env_fixed = -1, int ring = -1) {
   static_assert(NG == 1 || SOLVER == 2, "more than one row group: Newton only");
-  constexpr int kNR = NG == 1 ? kNefcMax : 64 * NG;  // row capacity of this instantiation
-  constexpr int kNC = NG == 1 ? kNconMax : kBigNconMax;  // contact capacity
+  static_assert(SMALL == 0 || (SOLVER == 0 && NDENSE <= 28 && COLL == 0 && NG == 1 && DEFER == 0), "the small instantiation: classic PGS kernel of dense order <= 28");
+  constexpr int kNR = SMALL ? kSmallNefcMax : (NG == 1 ? kNefcMax : 64 * NG);  // row capacity of this instantiation
+  constexpr int kNC = SMALL ? kSmallNconMax : (NG == 1 ? kNconMax : kBigNconMax);  // contact capacity
   // the model tables are read through a constant-address-space pointer (not by-value kernel
   // arguments): the ~100 table pointers and every wave-uniform table entry are fetched on demand by
   // scalar loads through the scalar cache instead of living in (and spilling from) SGPRs
@@ -969,9 +970,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   extern __shared__ float lds[];
   const int lane0 = threadIdx.x;
   int lane = lane0;
-  if ((int)blockIdx.x >= P.nblk) return;
+  if (env_fixed < 0 && (int)blockIdx.x >= P.nblk) return;
   const int slot = P.blk0 + (int)blockIdx.x;
-  const int env = P.order ? P.order[slot] : slot;
+  const int env = env_fixed >= 0 ? env_fixed : (P.order ? P.order[slot] : slot);  // (env_fixed: the slow lane's kernel names the env)
   if (P.env_mask && !P.env_mask[env]) return;  // masked stepping (hb_env_reset's settle step)
   if constexpr (COLL != 0 && DEFER == 0) {
     if (P.stage.rerun) {  // second pass of a staged step: only the envs the fast pass deferred
@@ -980,6 +981,51 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       if (lane0 == 0) P.stage.defer[env] = 0;
     }
   }
+  // two-lane stepping (BatchPtrs::lane): the small kernel leaves the slow-lane envs to hb_step_slow_kernel
+  if constexpr (SMALL != 0) {
+    // the first block of a small launch tells the slow lane that the GPU has got to this call, and with which controls
+    if (blockIdx.x == 0 && lane0 == 0) {
+      const int r = P.lane_tag % kLaneRing;
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(P.lane_ring->ctrl + r), (unsigned long long)(uintptr_t)P.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(P.lane_ring->t0 + r, P.t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(P.lane_ring->mode + r, P.ctrl_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(P.lane_ring->released + P.lane_seg, P.lane_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int slow = P.lane[env];
+    if (slow) {
+      // A slow env comes back to the fast lane at the first call at which its slow lane has caught up: lane_done[e] == lane_tag - 1 means
+      // every earlier step is complete, and the compare-and-swap to -lane_tag CLAIMS this call's step (the slow lane claims its steps the
+      // same way, so exactly one of the two steps the env for this call).  Otherwise the env stays slow; at the first call of a window
+      // (lane_mode 2: a new list) it is carried over into the new list.
+      int got = 0;
+      if (lane0 == 0) {
+        int expect = P.lane_tag - 1;
+        got = __hip_atomic_compare_exchange_strong(P.lane_done + env, &expect, -P.lane_tag, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+      }
+      got = uniform(got);
+      if (!got) {
+        if (P.lane_mode == 2 && lane0 == 0 && P.lane_win[env] != P.lane_wid[P.lane_seg]) {
+          P.lane_win[env] = P.lane_wid[P.lane_seg];
+          P.lane_list[P.lane_par[P.lane_seg] * P.n_env_total + P.lane_lo[P.lane_seg] + atomicAdd(P.lane_count + 4 * P.lane_par[P.lane_seg] + P.lane_seg, 1)] = env;
+        }
+        return;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the slow lane's stores of this env's state, not a stale cache line
+      if (lane0 == 0) P.lane[env] = 0;
+    }
+  }
+  // an env-step that overflows the small instantiation (nothing has been written at that point): to the slow lane
+  auto to_slow_lane = [&]() {
+    if (lane0 == 0) {
+      P.lane_done[env] = P.lane_tag - 1;  // (the fast lane has completed every step before this one)
+      P.lane[env] = P.lane_tag;
+      if (P.lane_win[env] != P.lane_wid[P.lane_seg]) {  // (an env that left and re-entered the slow lane inside a window is already listed)
+        P.lane_win[env] = P.lane_wid[P.lane_seg];
+        P.lane_list[P.lane_par[P.lane_seg] * P.n_env_total + P.lane_lo[P.lane_seg] + atomicAdd(P.lane_count + 4 * P.lane_par[P.lane_seg] + P.lane_seg, 1)] = env;
+      }
+    }
+  };
+  (void)to_slow_lane;
   // per-env model parameters (domain randomisation), nullable; offsets per DomainLayout
   const float* dr = P.dr ? P.dr + (size_t)env * P.dr_stride : nullptr;
   const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
@@ -1010,7 +1056,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   float* s_va = lds + M.o_cvel;  // per body: cvel[6] | cacc[6]
   float* s_con = lds + M.o_con;
   float* s_C = lds + M.o_C;
-  float* s_efc = lds + M.o_efc;  // per-row meta, stride kNefcMax; dead once the row quantities are in registers
+  float* s_efc = lds + M.o_efc;  // per-row meta, stride kNR; dead once the row quantities are in registers
   float* s_W = lds + M.o_efc;    // W = L^-1 D^-1/2, [32][33], aliases the row meta
   float* s_force = lds + M.o_force;
   const float* s_gquat = lds + M.o_gquat;  // general collision only: world orientation of every geom
@@ -1024,7 +1070,15 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   // the controls of the first step are requested before the state, those of step t+1 at the top of step t:
   // an HBM round trip each (streamed, never cached) that would otherwise open every step
   float ctrl_pf = 0.f;
-  if (P.ctrl_mode != 2 && lane < M.nu) ctrl_pf = P.ctrl[(size_t)env * M.nu + lane];
+  // (ring >= 0: the slow lane steps this env with the controls of an earlier step call)
+  const float* ctrl_src = P.ctrl;
+  int ctrl_mode = P.ctrl_mode, ctrl_t0 = P.t0;
+  if (ring >= 0) {
+    ctrl_src = reinterpret_cast<const float*>((uintptr_t)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.lane_ring->ctrl + ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    ctrl_mode = __hip_atomic_load(P.lane_ring->mode + ring, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ctrl_t0 = __hip_atomic_load(P.lane_ring->t0 + ring, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (ctrl_mode != 2 && lane < M.nu) ctrl_pf = ctrl_src[(size_t)env * M.nu + lane];
   float* gstate = P.state + (size_t)env * M.nstate;
   float time = gstate[0];
   for (int i = lane; i < nq; i += kGroup) s_qpos[i] = gstate[1 + i];
@@ -1075,14 +1129,14 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     if (lane < nv) { pf_dA = M.drec[3 * lane]; pf_dB = M.drec[3 * lane + 1]; }
     HB_STAMP(0);
     // ---------------------------------------------------------------- controls
-    if (P.ctrl_mode == 2) {
-      int idx = 1 + P.t0 + step + 1000 * (P.env_offset + env);
+    if (ctrl_mode == 2) {
+      int idx = 1 + ctrl_t0 + step + 1000 * (P.env_offset + env);
       for (int i = lane; i < M.nu; i += kGroup) s_ctrl[i] = 2.f * halton(idx, i + 2) - 1.f;
     } else {
-      const float* c = P.ctrl + (P.ctrl_mode == 1 ? (size_t)step * P.n_env * M.nu : 0) + (size_t)env * M.nu;
+      const float* c = ctrl_src + (ctrl_mode == 1 ? (size_t)step * P.n_env * M.nu : 0) + (size_t)env * M.nu;
       if (lane < M.nu) s_ctrl[lane] = ctrl_pf;
       for (int i = lane + kGroup; i < M.nu; i += kGroup) s_ctrl[i] = c[i];
-      if (P.ctrl_mode == 1 && step + 1 < nsteps && lane < M.nu) ctrl_pf = c[(size_t)P.n_env * M.nu + lane];
+      if (ctrl_mode == 1 && step + 1 < nsteps && lane < M.nu) ctrl_pf = c[(size_t)P.n_env * M.nu + lane];
     }
     // ---------------------------------------------------------------- mj_checkPos / mj_checkVel
     {
@@ -1610,14 +1664,14 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         unsigned long long b1 = __ballot(n >= 1), b2 = __ballot(n >= 2);
         unsigned long long lt = (1ull << lane) - 1ull;
         int slot = ncon + __popcll(b1 & lt) + __popcll(b2 & lt);
-        if (n >= 1 && slot < kNconMax) {
+        if (n >= 1 && slot < kNC) {
           float* c = s_con + slot * kConStride;
           c[C_DIST] = co0.dist;
           st3(c + C_POS, co0.pos);
           make_frame(c + C_FRAME, co0.n, hint);
           c[C_PAIR] = __int_as_float(p);
         }
-        if (n >= 2 && slot + 1 < kNconMax) {
+        if (n >= 2 && slot + 1 < kNC) {
           float* c = s_con + (slot + 1) * kConStride;
           c[C_DIST] = co1.dist;
           st3(c + C_POS, co1.pos);
@@ -1626,7 +1680,10 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         }
         ncon += __popcll(b1) + __popcll(b2);
       }
-      if (ncon > kNconMax) { status |= (1 << 1); ncon = kNconMax; }
+      if (ncon > kNC) {
+        if constexpr (SMALL != 0) { to_slow_lane(); return; }  // more contacts than this instantiation holds
+        status |= (1 << 1); ncon = kNC;
+      }
     }
     ncon = uniform(ncon);
     // self collision (CPUEnv._check_self_collision, cpu_env.py:576-584): a contact whose geoms both belong to the robot
@@ -1783,21 +1840,24 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         }
         unsigned long long bal = __ballot(active);
         int row = nefc + __popcll(bal & ((1ull << lane) - 1ull));
-        if (active && row < kNefcMax) {
+        if (active && row < kNR) {
           float* Jr = s_C + row * cs;
           for (int k = 0; k < cs; k++) Jr[k] = 0.f;
           if (kind == 0) Jr[__float_as_int(l3.z)] = (float)(-side);
           else for (int w = 0; w < M.tendon_num[id]; w++) Jr[M.wrap_dofadr[M.tendon_adr[id] + w]] = (float)(-side) * M.wrap_prm[M.tendon_adr[id] + w];
           float* e = s_efc + row;
-          e[E_POS * kNefcMax] = dist; e[E_MARGIN * kNefcMax] = margin;
-          e[E_SOLREF0 * kNefcMax] = l1.z; e[E_SOLREF1 * kNefcMax] = l1.w;
-          e[(E_IMP0 + 0) * kNefcMax] = l2.x; e[(E_IMP0 + 1) * kNefcMax] = l2.y; e[(E_IMP0 + 2) * kNefcMax] = l2.z; e[(E_IMP0 + 3) * kNefcMax] = l2.w;
-          e[(E_IMP0 + 4) * kNefcMax] = l3.x;
-          e[E_DA * kNefcMax] = l3.y; e[E_DAFIRST * kNefcMax] = l3.y; e[E_MU2 * kNefcMax] = 0.f;
+          e[E_POS * kNR] = dist; e[E_MARGIN * kNR] = margin;
+          e[E_SOLREF0 * kNR] = l1.z; e[E_SOLREF1 * kNR] = l1.w;
+          e[(E_IMP0 + 0) * kNR] = l2.x; e[(E_IMP0 + 1) * kNR] = l2.y; e[(E_IMP0 + 2) * kNR] = l2.z; e[(E_IMP0 + 3) * kNR] = l2.w;
+          e[(E_IMP0 + 4) * kNR] = l3.x;
+          e[E_DA * kNR] = l3.y; e[E_DAFIRST * kNR] = l3.y; e[E_MU2 * kNR] = 0.f;
         }
         nefc += __popcll(bal);
       }
-      if (nefc > kNefcMax) { status |= (1 << 2); nefc = kNefcMax; }
+      if (nefc > kNR) {
+        if constexpr (SMALL != 0) { to_slow_lane(); return; }
+        status |= (1 << 2); nefc = kNR;
+      }
     }
     // (b) contacts: row base by prefix sum over contacts (1 row for condim 1, 4 for condim 3)
     if (constraints_on && contacts_on) {
@@ -1815,14 +1875,17 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       const unsigned long long lower = (1ull << lane) - 1ull;
       const unsigned long long one_row = __ballot(myrows == 1), four_rows = __ballot(myrows == 4);
       int base = nefc + __popcll(one_row & lower) + 4 * __popcll(four_rows & lower);
-      bool fits = base + myrows <= kNefcMax;
+      bool fits = base + myrows <= kNR;
       if (lane < ncon) {
         float* c = s_con + lane * kConStride;
         c[C_ROW] = __int_as_float((incl && fits) ? base : -1);
         c[C_DIM] = __int_as_float(M.pair_dim[pairid] == 1 ? 1 : 3);
         c[C_FRIC] = fmaxf(1e-5f, dr ? fmaxf(M.pair_fricab[2 * pairid] * dr[DL.o_fric], M.pair_fricab[2 * pairid + 1]) : M.pair_friction[3 * pairid]);
       }
-      if (__ballot(lane < ncon && incl && !fits)) status |= (1 << 2);
+      if (__ballot(lane < ncon && incl && !fits)) {
+        if constexpr (SMALL != 0) { to_slow_lane(); return; }
+        status |= (1 << 2);
+      }
       // contacts are materialised in order; once one does not fit, none of the later ones does
       // (bases grow with the lane: the last contact that fits ends the rows)
       const unsigned long long placed = __ballot(lane < ncon && incl && fits);
@@ -1871,15 +1934,15 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         if (lane < nr) {
           const float tran = p2.w;
           float* e = s_efc + row + lane;
-          e[E_POS * kNefcMax] = c[C_DIST];
-          e[E_MARGIN * kNefcMax] = p2.x;
-          e[E_SOLREF0 * kNefcMax] = p2.y; e[E_SOLREF1 * kNefcMax] = p2.z;
-          e[(E_IMP0 + 0) * kNefcMax] = p3.x; e[(E_IMP0 + 1) * kNefcMax] = p3.y; e[(E_IMP0 + 2) * kNefcMax] = p3.z; e[(E_IMP0 + 3) * kNefcMax] = p3.w;
-          e[(E_IMP0 + 4) * kNefcMax] = p4.x;
+          e[E_POS * kNR] = c[C_DIST];
+          e[E_MARGIN * kNR] = p2.x;
+          e[E_SOLREF0 * kNR] = p2.y; e[E_SOLREF1 * kNR] = p2.z;
+          e[(E_IMP0 + 0) * kNR] = p3.x; e[(E_IMP0 + 1) * kNR] = p3.y; e[(E_IMP0 + 2) * kNR] = p3.z; e[(E_IMP0 + 3) * kNR] = p3.w;
+          e[(E_IMP0 + 4) * kNR] = p4.x;
           float da = dim == 1 ? tran : tran + mu * mu * tran;
-          e[E_DA * kNefcMax] = da; e[E_DAFIRST * kNefcMax] = da;
+          e[E_DA * kNR] = da; e[E_DAFIRST * kNR] = da;
           float mus = mu * M.inv_sqrt_impratio;
-          e[E_MU2 * kNefcMax] = dim == 1 ? 0.f : 2.f * mus * mus;
+          e[E_MU2 * kNR] = dim == 1 ? 0.f : 2.f * mus * mus;
         }
       }
       nefc = nefc_after;
@@ -1921,13 +1984,13 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
           arefg[g] = -e[2] * vel - e[1];
         } else {
           const float* e = s_efc + row;
-          float pos = e[E_POS * kNefcMax], margin = e[E_MARGIN * kNefcMax];
-          float solref0 = e[E_SOLREF0 * kNefcMax], solref1 = e[E_SOLREF1 * kNefcMax];
+          float pos = e[E_POS * kNR], margin = e[E_MARGIN * kNR];
+          float solref0 = e[E_SOLREF0 * kNR], solref1 = e[E_SOLREF1 * kNR];
           float solimp[5];
-          for (int i = 0; i < 5; i++) solimp[i] = e[(E_IMP0 + i) * kNefcMax];
+          for (int i = 0; i < 5; i++) solimp[i] = e[(E_IMP0 + i) * kNR];
           float imp = clampf(impedance(solimp, pos, margin), HB_MINIMP, HB_MAXIMP);
-          float mu2 = e[E_MU2 * kNefcMax];
-          float Rown = fmaxf(HB_MINVAL, (1.f - imp) * e[E_DA * kNefcMax] / imp);
+          float mu2 = e[E_MU2 * kNR];
+          float Rown = fmaxf(HB_MINVAL, (1.f - imp) * e[E_DA * kNR] / imp);
           Rg[g] = mu2 > 0.f ? mu2 * Rown : Rown;  // pyramidal: all rows share 2 mu^2 R(first); first row's diagApprox == own
           Ddg[g] = 1.f / Rg[g];
           float K, Bc;
@@ -1956,25 +2019,27 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       asm volatile("v_mov_b32 %0, %1" : "=v"(lw) : "v"(lane0));
       f32x16 T, S;
       sym_factor_mfma<NDENSE / 2>(load_sym_pairs<0>(M, s_qLD, lw), T, S, lw);
-      store_w_rows(s_W, kWs, T, S, lw);
+      if (!SMALL || (lw & 31) < NDENSE) store_w_rows(s_W, kWs, T, S, lw);  // (the small layout has no room for the padding rows, and nothing reads them)
       gsync();
     }
     {
       const int col = lane & 31, half = lane >> 5;
 #pragma unroll
       for (int I = 0; I < 2; I++) {
-        if (I == 0 || nefc >= 32) {
+        if (I == 0 || (!SMALL && nefc >= 32)) {
           const int arow = 32 * I + col;
           const float* Ap = s_C + arow * cs + half;
           const bool av = arow <= nefc;
-          float a[16];
+          // K runs over the dense order only: the W rows beyond it are identity padding and meet zero J columns (an exact + 0)
+          constexpr int kKP = NDENSE / 2;
+          float a[kKP];
 #pragma unroll
-          for (int kk = 0; kk < 16; kk++) a[kk] = av ? Ap[2 * kk] : 0.f;
+          for (int kk = 0; kk < kKP; kk++) a[kk] = av ? Ap[2 * kk] : 0.f;
           f32x16 D;
 #pragma unroll
           for (int r = 0; r < 16; r++) D[r] = 0.f;
 #pragma unroll
-          for (int kk = 0; kk < 16; kk++) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], s_W[(2 * kk + half) * kWs + col], D, 0, 0, 0);
+          for (int kk = 0; kk < kKP; kk++) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], s_W[(2 * kk + half) * kWs + col], D, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int row = 32 * I + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -1993,7 +2058,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // injected through the accumulator input of the diagonal tiles.  A 32x32 result has its column on
     // the lane and half of its rows in each 32-lane half; v_permlane32_swap pairs tile (I,0) with
     // tile (I,1) so that every lane ends up with the full column it owns, with no LDS round trip.
-    float ar[kNefcMax];
+    float ar[kNR];
     float Aii = 1.f;
     {
       const float* Cr = s_C + lane * cs;
@@ -2007,7 +2072,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       bvec = jas - aref;
       Aii = rowact ? diag + R : 1.f;
       const int col = lane & 31, half = lane >> 5;
-      const bool two = nefc > 32;  // rows 32..62 in use: all four tiles, else only tile (0,0)
+      const bool two = !SMALL && nefc > 32;  // rows 32..62 in use: all four tiles, else only tile (0,0)
       const bool v0 = col < nefc, v1 = 32 + col < nefc;
       const float* A0p = s_C + col * cs + half;
       const float* A1p = s_C + (32 + col) * cs + half;
@@ -2046,10 +2111,10 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         const int ra = (r & 3) + 8 * (r >> 2);
         const u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(X0[r]), __float_as_uint(Y0[r]), false, false);
         ar[ra] = __uint_as_float(s0.x);
-        ar[ra + 4] = __uint_as_float(s0.y);
+        if (ra + 4 < kNR) ar[ra + 4] = __uint_as_float(s0.y);  // (the small instantiation has no row 31)
         const u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(X1[r]), __float_as_uint(Y1[r]), false, false);
-        if (32 + ra < kNefcMax) ar[32 + ra] = __uint_as_float(s1.x);
-        if (32 + ra + 4 < kNefcMax) ar[32 + ra + 4] = __uint_as_float(s1.y);
+        if (32 + ra < kNR) ar[32 + ra] = __uint_as_float(s1.x);
+        if (32 + ra + 4 < kNR) ar[32 + ra + 4] = __uint_as_float(s1.y);
       }
     }
     HB_STAMP(12);
@@ -2063,11 +2128,11 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         const float jar = jw - aref;
         force = (rowact && jar < 0.f) ? -Dd * jar : 0.f;
 #pragma unroll
-        for (int c = 0; c < (kNefcMax + 3) / 4; c++) {
+        for (int c = 0; c < (kNR + 3) / 4; c++) {
           if (c * 4 < nefc) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
-              if (c * 4 + r < kNefcMax) arf += ar[c * 4 + r] * rdlane(force, c * 4 + r);
+              if (c * 4 + r < kNR) arf += ar[c * 4 + r] * rdlane(force, c * 4 + r);
           }
         }
         // cost(f) = 0.5 f'AR f + f'b; keep the warm start only if it beats zero
@@ -2097,10 +2162,10 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         int dl = 0;
         // hand-unrolled (ar[i] needs a compile-time register index) with one scalar exit test per 4 rows
 #define HB_PGS_ROW(i)                                                              \
-  if ((i) < kNefcMax) {                                                            \
+  if ((i) < kNR) {                                                            \
     const float d_ = fmaxf(res * nAinv, nforce);                                   \
     const int di_ = __builtin_amdgcn_readlane(__float_as_int(d_), (i));            \
-    res = __builtin_fmaf(ar[(i) < kNefcMax ? (i) : 0], __int_as_float(di_), res);  \
+    res = __builtin_fmaf(ar[(i) < kNR ? (i) : 0], __int_as_float(di_), res);  \
     dl = hb_writelane(di_, (i), dl);                                               \
   }
 #define HB_PGS_CHUNK(c) \
@@ -2120,15 +2185,25 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         if (improvement * pgs_scale < pgs_tol) break;
       }
     }
-    if (lane < kNefcMax) s_force[lane] = rowact ? force : 0.f;
+    if constexpr (SMALL == 0) { if (lane < kNR) s_force[lane] = rowact ? force : 0.f; }
     gsync();
     HB_STAMP(13);
     // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = W (y + s)
     const bool want_qfrc = P.qfrc_out != nullptr;
-    for (int k = lane; k < nv; k += kGroup) {
+    if constexpr (SMALL != 0) {
+      // the forces straight out of their lanes (nefc is uniform): no LDS copy.  Every lane runs the loop - v_readlane reads lanes that a
+      // divergent region has switched off, and the value they hold must have been computed there
+      const float fz = rowact ? force : 0.f;
+      const int kc = lane < kCs ? lane : 0;
       float sacc = 0.f;
-      for (int i = 0; i < nefc; i++) sacc += s_force[i] * s_C[i * cs + k];
-      s_v2[k] = yv[k] + sacc;  // y + s
+      for (int i = 0; i < nefc; i++) sacc += rdlane(fz, i) * s_C[i * cs + kc];
+      if (lane < nv) s_v2[lane] = yv[lane] + sacc;  // y + s (nv <= 28: one pass)
+    } else {
+      for (int k = lane; k < nv; k += kGroup) {
+        float sacc = 0.f;
+        for (int i = 0; i < nefc; i++) sacc += s_force[i] * s_C[i * cs + k];
+        s_v2[k] = yv[k] + sacc;  // y + s
+      }
     }
     gsync();
     if (lane < nv) s_v0[lane] = dot32(s_W + lane * kWs, s_v2);
@@ -2572,6 +2647,45 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 // (224 registers instead of the 229 the allocator would take - two values spilled - so that beside two of its waves a SIMD has 64
 // registers left: what the closed loop's policy kernel runs in, hb_policy_lean_kernel; amdgpu_num_vgpr counts per half of the file)
 __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28>(Mp, P, nsteps); }
+// the small instantiation (31 rows, 12 contacts: three waves per SIMD); single-step launches only - an overflowing env-step leaves without
+// having written anything, and the slow lane (hb_step_kernel, lane_mode 3) steps that env from then on
+__global__ __launch_bounds__(kGroup, 3) void hb_step_small_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 1>(Mp, P, nsteps); }
+// The slow lane: a few blocks walk every segment's list of slow envs and step them with the full instantiation.  A slow env-step is
+// often the heavy kind (more than 31 rows: up to 50 sweeps over them, about 100 us against the 80 us period of the small launches), and a
+// launch lasts as long as its slowest block - so the slow lane is NOT in lock step with the fast one.  A slow env depends on nothing the
+// small launches do: lane_done[e] is the tag of the last step completed for it, and a block steps its env through ALL the step calls the
+// GPU has got to so far (LaneRing::released, with the controls of those calls) - also calls whose small launch started while it was
+// running.  An env that was heavy for a step or two catches up at the pace of its own light steps, and the small kernel takes it back at
+// the first call that finds it caught up; nothing ever waits for the slow lane but a join.
+// (A list entry a LATER small launch is writing beside this kernel shows as -1 or not at all: the next launch takes it.)
+__global__ __launch_bounds__(kGroup, 2) void hb_step_slow_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) {
+  const int seg = blockIdx.y;
+  const int* list = P.lane_list + P.lane_par[seg] * P.n_env_total + P.lane_lo[seg];
+  const int count = min(uniform(P.lane_count[4 * P.lane_par[seg] + seg]), P.lane_n[seg]);
+  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+    const int e = uniform(list[i]);
+    if (e < 0) continue;
+    if (uniform(P.lane[e]) == 0) continue;
+    // step after step, each CLAIMED by compare-and-swap on lane_done[e] (t - 1 -> -t) and published when complete (-t -> t): the small
+    // kernel claims a step the same way when it takes the env back - whoever loses a claim leaves the env to the winner
+    for (;;) {
+      const int released = uniform(__hip_atomic_load(P.lane_ring->released + seg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+      int done = uniform(__hip_atomic_load(P.lane_done + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+      if (done < 0 || done >= released || uniform(P.lane[e]) == 0) break;
+      int won = 0;
+      if (threadIdx.x == 0) {
+        int expect = done;
+        won = __hip_atomic_compare_exchange_strong(P.lane_done + e, &expect, -(done + 1), __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+      }
+      if (!uniform(won)) break;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      step_body<0, 28>(Mp, P, nsteps, e, (done + 1) % kLaneRing);
+      gsync();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every lane's stores of the new state, then the flag
+      if (threadIdx.x == 0) __hip_atomic_store(P.lane_done + e, done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 __global__ __launch_bounds__(kGroup, 2) void hb_step32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 32>(Mp, P, nsteps); }
 // General instantiations (mesh hulls, height-field prisms, condim 4 / 6): PGS on 63 rows (configs[4]: the 27-dof humanoid on terrain),
 // Newton on 256 rows (the reference's own robot, simulation/assets/world.xml: 18 dofs -> dense order 20; up to 28 dofs)
@@ -3576,7 +3690,7 @@ __attribute__((amdgpu_num_vgpr(32))) __global__ __launch_bounds__(256) void hb_p
 // last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
 // the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
 // which cannot change results (envs are independent).
-__global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int e0, int n, int slot, int shift) {
+__global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int* keys, int e0, int n, int slot, int shift) {
   // sorts envs e0 .. e0+n-1 into order[e0 .. e0+n-1], most expensive first; cost = counts[env][slot] >> shift, 256 bins
   __shared__ int hist[256];
   __shared__ int base[256];
@@ -3585,6 +3699,8 @@ __global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* 
   __syncthreads();
   for (int e = e0 + tid; e < e0 + n; e += blockDim.x) {
     int key = min(255, counts[kCountStride * e + slot] >> shift);
+    keys[e] = key;  // read ONCE: the slow lane of two-lane stepping may be writing counts beside this kernel, and a key that changed
+                    // between the two passes would leave an env out of the permutation
     atomicAdd(&hist[255 - key], 1);  // bin 0 = most expensive
   }
   __syncthreads();
@@ -3602,7 +3718,7 @@ __global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* 
   if (tid < 256) base[tid] += e0 - hist[tid];  // inclusive -> exclusive, offset by the segment start
   __syncthreads();
   for (int e = e0 + tid; e < e0 + n; e += blockDim.x) {
-    int key = min(255, counts[kCountStride * e + slot] >> shift);
+    const int key = keys[e];
     order[atomicAdd(&base[255 - key], 1)] = e;
   }
 }
@@ -3674,12 +3790,22 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
     if (e != hipSuccess) return e;
     // a long rollout is one call: refresh the heavy-first orders of its launches along the way (the caller does it between calls)
     if (P.order && P.order2 && (t & 7) == 7 && t + 1 < nsteps) {
-      e = launch_order(P.counts, const_cast<int*>(P.order), P.blk0, P.nblk, stream, 3, 3);
-      if (e == hipSuccess) e = launch_order(P.counts, const_cast<int*>(P.order2), P.blk0, P.nblk, stream, 7, 0);
+      e = launch_order(P.counts, const_cast<int*>(P.order), P.n_env, P.blk0, P.nblk, stream, 3, 3);
+      if (e == hipSuccess) e = launch_order(P.counts, const_cast<int*>(P.order2), P.n_env, P.blk0, P.nblk, stream, 7, 0);
       if (e != hipSuccess) return e;
     }
   }
   return hipSuccess;
+}
+hipError_t launch_step_slow(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int blocks, int nseg, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(hb_step_slow_kernel, dim3(blocks, nseg), dim3(kGroup), (size_t)lds_floats * sizeof(float), stream, M_dev, P, 1);
+  return hipGetLastError();
+}
+hipError_t launch_step_small(const DevModel* M_small, int lds_floats, const BatchPtrs& P, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(hb_step_small_kernel, dim3(P.nblk), dim3(kGroup), (size_t)lds_floats * sizeof(float), stream, M_small, P, 1);
+  return hipGetLastError();
 }
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
                         int env_offset, hipStream_t stream, float quat_perturb) {
@@ -3731,9 +3857,9 @@ hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr,
   hipLaunchKernelGGL(hb_domain_rand_kernel, dim3((n_env + 256 / kDrawLanes - 1) / (256 / kDrawLanes)), dim3(256), 0, stream, M, D, dr, stride, episode, mask, n_env, env_offset);
   return hipGetLastError();
 }
-hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream, int slot, int shift) {
+hipError_t launch_order(const int* counts, int* order, int n_env, int e0, int n, hipStream_t stream, int slot, int shift) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, e0, n, slot, shift);
+  hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, order + n_env, e0, n, slot, shift);
   return hipGetLastError();
 }
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream) {

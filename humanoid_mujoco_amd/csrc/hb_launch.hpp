@@ -4,6 +4,10 @@
 #include "hb_device.hpp"
 namespace hb {
 hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream);
+// the small instantiation of the classic PGS kernel on its own LDS layout (two-lane stepping: BatchPtrs::lane, lane_mode 1 / 2), one step
+hipError_t launch_step_small(const DevModel* M_small, int lds_floats, const BatchPtrs& P, hipStream_t stream);
+// the slow lane of two-lane stepping: `blocks` workgroups per segment walk the lists of P.lane_list with the full classic PGS instantiation (lane_mode 3)
+hipError_t launch_step_slow(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int blocks, int nseg, hipStream_t stream);
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
                         int env_offset, hipStream_t stream, float quat_perturb = 0.f);
 hipError_t launch_envrand_reset(const DevModel& M, const EnvRand& R, const EnvRandState& S, const int* episode, const uint8_t* mask, int n_env, int env_offset,
@@ -21,7 +25,8 @@ hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr,
                               hipStream_t stream);
 hipError_t launch_policy(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, int n_env, hipStream_t stream);
 hipError_t launch_policy_lean(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, float* act, int n_env, hipStream_t stream);
-hipError_t launch_order(const int* counts, int* order, int e0, int n, hipStream_t stream, int slot = 3, int shift = 3);
+// order: [2 * n_env] ints - the permutation, then the sort keys of the pass (read once from counts)
+hipError_t launch_order(const int* counts, int* order, int n_env, int e0, int n, hipStream_t stream, int slot = 3, int shift = 3);
 hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream);
 hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream);
 hipError_t launch_stand_cost(const float* rows, int H, int n_env, const StandTask& K, const int* status, float* total, float* costs, hipStream_t stream);

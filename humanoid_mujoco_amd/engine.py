@@ -145,6 +145,7 @@ def lib():
     L.hb_get_obs.argtypes = [vp, vp, vp, vp, vp]
     L.hb_get_status.argtypes = [vp, vp]
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
+    L.hb_get_lanes.argtypes = [vp, vp]
     L.hb_get_collision_counts.argtypes = [vp, vp, vp, vp]
     L.hb_batch_segments.argtypes = [vp]
     L.hb_diag_enable.argtypes = [vp, ci]
@@ -409,6 +410,14 @@ class Batch:
         a, b, c = (np.zeros(self.n_env, dtype=np.int32) for _ in range(3))
         _check(lib().hb_get_counts(self._h, _ptr(a), _ptr(b), _ptr(c)), "hb_get_counts")
         return a, b, c
+
+    def lanes(self):
+        """1 per env currently in the slow lane of two-lane stepping (include/hb.h: hb_get_lanes); all zero when it is off."""
+        a = np.zeros(self.n_env, dtype=np.int32)
+        rc = lib().hb_get_lanes(self._h, _ptr(a))
+        if rc < 0:
+            _check(rc, "hb_get_lanes")
+        return a
 
     def collision_counts(self, want_cycles=False):
         """(work items, portal searches[, narrowphase wave time in 1024-cycle units]) of every env's last step (general collision

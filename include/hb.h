@@ -325,6 +325,13 @@ int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter);
  * models.  Any pointer may be NULL. */
 int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch, int* kcycles);
 
+/* Two-lane stepping (classic PGS models of dense order <= 28, i.e. the 27-dof humanoid): single-step calls run the
+ * SMALL instantiation of the step kernel (31 rows, 12 contacts, three waves per SIMD) on the fast lane; an env whose step needs more
+ * is stepped by the full kernel (63 rows, 24 contacts) on a slow lane beside it, until the next rebalance point.  Results are those of
+ * the full kernel either way.  lane[e] (nullable) = 1 while env e is in the slow lane; returns the number of such envs (0 for a batch
+ * without two-lane stepping; HB_TWO_LANE=0 in the environment at hb_batch_create switches it off), or a negative error. */
+int hb_get_lanes(hb_batch* b, int* lane);
+
 /* Diagnostics of the last step for parity tests (mjData.qacc, efc_force, contact[]; mjdata.h:
  * 362,376,427): enable once, then read after a step.  efc_force is [n_env][nefc_max];
  * contact is [n_env][ncon_max][16] = dist, pos[3], frame[9], dim, geom1, geom2. */

@@ -840,9 +840,8 @@ int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
     if (sample) { HB_HIP(hipEventRecord(b->tev[b->tev_used + 1], b->stream)); b->tev_used += 2; }
     // The slow lane: ONE launch for all segments on its own stream - after this step's small launches (which may have added envs) and, by
     // stream order, after the slow lane's earlier launches.  Nothing waits for it but a join.
-    static const bool no_slow = getenv("HB_LANE_NOSLOW") != nullptr;  // timing experiments only: the slow lane is not stepped at all
-    static const int slow_blocks = getenv("HB_SLOW_BLOCKS") ? std::max(1, atoi(getenv("HB_SLOW_BLOCKS"))) : kSlowBlocks;
-    if (!no_slow) {
+    const int slow_blocks = kSlowBlocks;
+    {
       if (!b->slow) {
         // a stream of its own PRIORITY class: the runtime maps ordinary streams round robin onto four hardware queues, and the slow lane
         // sharing a queue with a pipe would serialise behind that pipe's small launches; streams created with a priority get queues of
@@ -1139,6 +1138,12 @@ static void envrand_free_fwd(hb_batch* b);
 void hb_batch_free(hb_batch* b) {
   if (!b) return;
   HB_IGN(hipSetDevice(b->device));
+  if (b->lane_ring && hb_debug()) {
+    LaneRing r;
+    HB_IGN(hipDeviceSynchronize());
+    if (hipMemcpy(&r, b->lane_ring, sizeof r, hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[hb] two-lane: %lld step calls since the last re-join, %d env-steps made by the slow lane\n", b->lane_calls, r.slow_steps);
+  }
   for (int c = 0; c < hb_batch::kPipes; c++) {
     if (b->pipe[c]) { HB_IGN(hipStreamSynchronize(b->pipe[c])); HB_IGN(hipStreamDestroy(b->pipe[c])); }
     if (b->ev_fast[c]) HB_IGN(hipEventDestroy(b->ev_fast[c]));

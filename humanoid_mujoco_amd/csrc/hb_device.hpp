@@ -266,6 +266,7 @@ __host__ __device__ inline int pose_lds_floats(int nq, int nb, int ngeom) {
 // call whose small launch has started, and by tag % kLaneRing the controls of the last kLaneRing calls.
 struct LaneRing {
   int released[4];
+  int slow_steps, slow_blocks;  // statistics: env-steps the slow lane has made, blocks of its launches that found work
   int t0[kLaneRing];
   int mode[kLaneRing];
   const float* ctrl[kLaneRing];

@@ -970,6 +970,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   extern __shared__ float lds[];
   const int lane0 = threadIdx.x;
   int lane = lane0;
+  bool coherent = env_fixed >= 0;  // (the slow lane's kernel; the small kernel sets it for an env it takes back from the slow lane)
   if (env_fixed < 0 && (int)blockIdx.x >= P.nblk) return;
   const int slot = P.blk0 + (int)blockIdx.x;
   const int env = env_fixed >= 0 ? env_fixed : (P.order ? P.order[slot] : slot);  // (env_fixed: the slow lane's kernel names the env)
@@ -989,7 +990,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(P.lane_ring->ctrl + r), (unsigned long long)(uintptr_t)P.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(P.lane_ring->t0 + r, P.t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(P.lane_ring->mode + r, P.ctrl_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(P.lane_ring->released + P.lane_seg, P.lane_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(P.lane_ring->released + P.lane_seg, P.lane_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const int slow = P.lane[env];
     if (slow) {
@@ -1000,7 +1002,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       int got = 0;
       if (lane0 == 0) {
         int expect = P.lane_tag - 1;
-        got = __hip_atomic_compare_exchange_strong(P.lane_done + env, &expect, -P.lane_tag, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+        got = __hip_atomic_compare_exchange_strong(P.lane_done + env, &expect, -P.lane_tag, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
       }
       got = uniform(got);
       if (!got) {
@@ -1010,7 +1012,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         }
         return;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the slow lane's stores of this env's state, not a stale cache line
+      coherent = true;  // the slow lane's stores of this env's state, not a stale cache line
       if (lane0 == 0) P.lane[env] = 0;
     }
   }
@@ -1080,9 +1082,13 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   }
   if (ctrl_mode != 2 && lane < M.nu) ctrl_pf = ctrl_src[(size_t)env * M.nu + lane];
   float* gstate = P.state + (size_t)env * M.nstate;
-  float time = gstate[0];
-  for (int i = lane; i < nq; i += kGroup) s_qpos[i] = gstate[1 + i];
-  for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = gstate[1 + nq + i]; s_warm[i] = gstate[1 + nq + nv + i]; }
+  // (coherent: the state record changes hands between the slow lane's kernel and a small launch running beside it - agent-scope accesses
+  // that go past the non-coherent caches, entry by entry; everywhere else ordinary loads and stores)
+  auto ld_state = [&](int i) -> float { return coherent ? __hip_atomic_load(gstate + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gstate[i]; };
+  auto st_state = [&](int i, float v) { if (coherent) __hip_atomic_store(gstate + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else gstate[i] = v; };
+  float time = ld_state(0);
+  for (int i = lane; i < nq; i += kGroup) s_qpos[i] = ld_state(1 + i);
+  for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = ld_state(1 + nq + i); s_warm[i] = ld_state(1 + nq + nv + i); }
   int status = 0;
   bool eulerdamp = false;
   if (!(M.disableflags & (1 << 14))) {
@@ -2636,9 +2642,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   if (lane == 0 && P.stamps) for (int i = 0; i < 16; i++) P.stamps[(size_t)env * 16 + i] = stamps_[i];
 #endif
   if (P.integrate) {
-    if (lane == 0) gstate[0] = time;
-    for (int i = lane; i < nq; i += kGroup) gstate[1 + i] = s_qpos[i];
-    for (int i = lane; i < nv; i += kGroup) { gstate[1 + nq + i] = s_qvel[i]; gstate[1 + nq + nv + i] = s_warm[i]; }
+    if (lane == 0) st_state(0, time);
+    for (int i = lane; i < nq; i += kGroup) st_state(1 + i, s_qpos[i]);
+    for (int i = lane; i < nv; i += kGroup) { st_state(1 + nq + i, s_qvel[i]); st_state(1 + nq + nv + i, s_warm[i]); }
   }
   if (status && lane == 0) atomicOr(P.status + env, status);
 }
@@ -2669,19 +2675,22 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_slow_kernel(const DevModel*
     // step after step, each CLAIMED by compare-and-swap on lane_done[e] (t - 1 -> -t) and published when complete (-t -> t): the small
     // kernel claims a step the same way when it takes the env back - whoever loses a claim leaves the env to the winner
     for (;;) {
-      const int released = uniform(__hip_atomic_load(P.lane_ring->released + seg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
-      int done = uniform(__hip_atomic_load(P.lane_done + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+      // (relaxed agent-scope accesses: they go past the non-coherent caches one word at a time; an acquire / release FENCE at agent
+      // scope would invalidate / write back the whole L2 of the XCD under the small launches' feet - measured: 250 instead of 90 us per step)
+      const int released = uniform(__hip_atomic_load(P.lane_ring->released + seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      int done = uniform(__hip_atomic_load(P.lane_done + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if (done < 0 || done >= released || uniform(P.lane[e]) == 0) break;
       int won = 0;
       if (threadIdx.x == 0) {
         int expect = done;
-        won = __hip_atomic_compare_exchange_strong(P.lane_done + e, &expect, -(done + 1), __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+        won = __hip_atomic_compare_exchange_strong(P.lane_done + e, &expect, -(done + 1), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
       }
       if (!uniform(won)) break;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (threadIdx.x == 0) atomicAdd(&P.lane_ring->slow_steps, 1);
       step_body<0, 28>(Mp, P, nsteps, e, (done + 1) % kLaneRing);
       gsync();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every lane's stores of the new state, then the flag
+      // every lane's (write-through, agent-scope) stores of the new state have left the wave before the flag does
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (threadIdx.x == 0) __hip_atomic_store(P.lane_done + e, done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

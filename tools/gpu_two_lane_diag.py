@@ -1,4 +1,4 @@
-"""Diagnostic: one teacher-forced step, two-lane vs full kernel; per-env differences."""
+"""Diagnostic: free-running two-lane vs full kernel, compare every step; report the first divergence."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,25 +6,28 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import humanoid_mujoco_amd as hb
 from oracle_lib import HUMANOID_HBM
 m = hb.Model.load(HUMANOID_HBM)
-n = 768
+n = 1000
+pipelined = len(sys.argv) > 1 and sys.argv[1] == "p"
+check_every = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+os.environ["HB_LANE_WINDOW"] = "8"
 os.environ["HB_TWO_LANE"] = "0"; full = hb.Batch(m, n, 0)
 os.environ["HB_TWO_LANE"] = "1"; two = hb.Batch(m, n, 0)
-full.reset(perturb=True); full.rollout_halton(300)
-for t in range(3):
-    st = full.get_state(hb.STATE_INTEGRATION)
-    two.set_state(hb.STATE_INTEGRATION, st)
-    full.rollout_halton(1, t0=300 + t); two.rollout_halton(1, t0=300 + t)
-    a = full.get_state(hb.STATE_INTEGRATION).astype(np.float64); b = two.get_state(hb.STATE_INTEGRATION).astype(np.float64)
-    nq, nv = m.nq, m.nv
-    dq = np.abs(a[:, 1:1+nq] - b[:, 1:1+nq]).max(1)
-    dv = np.abs(a[:, 1+nq:1+nq+nv] - b[:, 1+nq:1+nq+nv]).max(1) / np.maximum(1, np.abs(a[:, 1+nq:1+nq+nv]).max(1))
-    dw = np.abs(a[:, 1+nq+nv:] - b[:, 1+nq+nv:]).max(1) / np.maximum(1, np.abs(a[:, 1+nq+nv:]).max(1))
-    lanes = two.lanes()
-    nc, ne, ni = full.counts(); nc2, ne2, ni2 = two.counts()
-    print("step", t, "envs differing", int(((dq > 0) | (dv > 0) | (dw > 0)).sum()), "slow", int(lanes.sum()),
-          "| dq max %.2e dv rel max %.2e dw rel max %.2e" % (dq.max(), dv.max(), dw.max()))
-    print("   rel dw percentiles 50/90/99:", np.percentile(dw, [50, 90, 99]), " counts equal:", np.array_equal(nc, nc2), np.array_equal(ne, ne2), np.array_equal(ni, ni2),
-          "niter differing", int((ni != ni2).sum()))
-    worst = np.argsort(-dw)[:5]
-    for e in worst:
-        print("   env %d nefc %d/%d niter %d/%d lane %d dq %.2e dv %.2e dw %.2e" % (e, ne[e], ne2[e], ni[e], ni2[e], lanes[e], dq[e], dv[e], dw[e]))
+for b in (full, two):
+    if pipelined: b.pipeline(True)
+    b.reset(perturb=True)
+    b.rollout(np.zeros((500, n, m.nu), np.float32))
+bad = False
+for t in range(400):
+    full.rollout_halton(1, t0=t); two.rollout_halton(1, t0=t)
+    if t % check_every == check_every - 1:
+        a = full.get_state(hb.STATE_INTEGRATION); c = two.get_state(hb.STATE_INTEGRATION)
+        if not np.array_equal(a, c):
+            d = np.abs(a.astype(np.float64) - c.astype(np.float64)).max(1)
+            envs = np.nonzero(d > 0)[0]
+            lanes = two.lanes()
+            nc, ne, ni = full.counts(); nc2, ne2, ni2 = two.counts()
+            print("first divergence at step", t, ":", len(envs), "envs", envs[:20], "lanes", lanes[envs[:20]], "nefc full/two", ne[envs[:10]], ne2[envs[:10]],
+                  "time full/two", a[envs[:5], 0], c[envs[:5], 0])
+            bad = True
+            break
+print("pipelined", pipelined, "check_every", check_every, "->", "DIVERGED" if bad else "identical over 400 steps", "; slow now", int(two.lanes().sum()))

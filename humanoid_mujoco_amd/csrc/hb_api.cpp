@@ -98,7 +98,6 @@ bool model_variant(const Model& m, int& variant, int& ncon_max, int& nefc_max, s
     const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
     const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
     if (t1 == GEOM_MESH || t2 == GEOM_MESH || t1 == GEOM_HFIELD || t2 == GEOM_HFIELD) general = true;
-    if ((t1 == GEOM_PLANE && t2 == GEOM_MESH) || (t2 == GEOM_PLANE && t1 == GEOM_MESH)) { err = "plane - mesh collision is not implemented (use a height field as the floor of mesh models)"; return false; }
     const int dim = m.geom_priority[g1] != m.geom_priority[g2] ? m.geom_condim[m.geom_priority[g1] > m.geom_priority[g2] ? g1 : g2] : std::max(m.geom_condim[g1], m.geom_condim[g2]);
     if (dim != 1 && dim != 3) general = true;
   }

@@ -706,6 +706,7 @@ __device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const fl
       const float4 c0 = M.crec[3 * (size_t)p], c1 = M.crec[3 * (size_t)p + 1];
       const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y), t1 = __float_as_int(c0.z) & 255;
       cnt = 1;
+      if (t1 == 0 && ((__float_as_int(c0.z) >> 8) & 255) == 7) cnt = 2;  // mjc_PlaneConvex: up to four contacts, two per work item
       if (t1 == 1) {
         // mjc_ConvexHField's culling.  The sub-grid comes from the geom's bounding sphere in place of its exact bounding box (a superset
         // of MuJoCo's prisms in x and y: the extra ones lie outside the geom's footprint and cannot touch it), the height test from the
@@ -800,6 +801,18 @@ __device__ __forceinline__ int eval_work_item(DevModelRef M, const float* hdata_
         o1.p0 = {tv[0].x, tv[0].y, -sb}; o1.p1 = {tv[1].x, tv[1].y, -sb}; o1.p2 = {tv[2].x, tv[2].y, -sb};
         o1.p3 = tv[0]; o1.p4 = tv[1]; o1.p5 = tv[2];
         mpr_kind = 1;
+      }
+    } else if (t1 == 0 && t2 == 7) {
+      // mjc_PlaneConvex: no portal search (never reaches the narrowphase kernel); work item `sub` carries contacts 2 sub, 2 sub + 1
+      if constexpr (MODE != 2) {
+        const V3 normal = ld3(s_gaxis + 3 * g1);
+        if (dot(pos2 - pos1, normal) <= margin + rb2) {
+          q2mat(o2.mat, ldq(s_gquat + 4 * g2));
+          o2.type = t2; o2.pos = pos2; o2.r = r2; o2.h = l2; o2.margin = 0.f; set_mesh(M, o2, g2);
+          const int total = plane_hull(o2, pos1, normal, margin, 0.3f * rb2, 2 * sub, co0.dist, co0.pos, co1.dist, co1.pos);
+          co0.n = normal; co1.n = normal;
+          n = min(max(total - 2 * sub, 0), 2);
+        }
       }
     } else if (t1 == 7 || t2 == 7) {
       // mjc_Convex: both geoms in the world frame, each inflated by half the margin

@@ -176,6 +176,40 @@ __device__ __forceinline__ V3d ccd_support(const CObj& o, V3d dir) {
   return world_point(o, ld, res);
 }
 
+// mjc_PlaneConvex for a mesh hull (oracle: plane_convex): the hull's support point along -normal is the first contact if it is within the
+// margin, up to three more come from the vertices adjacent to it in the hull's graph, in list order, each within the margin and at least
+// tol away from the first point.  Returns the count (0..4) and the contacts `first_k`, `first_k + 1` of that list in (da, pa), (db, pb):
+// a work item carries two contacts, so a plane - mesh pair is two items.
+__device__ __forceinline__ int plane_hull(const CObj& o, V3 ppos, V3 normal, float margin, float tol, int first_k, float& da, V3& pa, float& db, V3& pb) {
+  const V3d nrm = widen(normal), pp = widen(ppos);
+  Climb c;
+  c.ld = local_dir(o, nrm * -1.0);
+  climb_start(o, c);
+  climb(o, c);
+  const V3d first = world_point(o, c.ld, widen(c.best));  // (o.margin = 0)
+  const double dist = dot(first - pp, nrm);
+  if (dist > (double)margin) return 0;
+  int n = 0;
+  auto put = [&](V3d pnt, double d) {
+    const V3 pos = narrow(pnt - nrm * (0.5 * d));
+    if (n == first_k) { da = (float)d; pa = pos; }
+    if (n == first_k + 1) { db = (float)d; pb = pos; }
+    n++;
+  };
+  put(first, dist);
+  const int adr = c.link >> 8, nch = c.link & 255;
+  for (int i = 0; i < nch * kMeshChunk && n < 4; i++) {
+    const float4 q = o.nbr[adr + i];
+    if (q.x == c.best.x && q.y == c.best.y && q.z == c.best.z) continue;  // the padding of the list: copies of the vertex itself
+    const V3d pnt = world_point(o, c.ld, V3d{(double)q.x, (double)q.y, (double)q.z});
+    const double di = dot(pnt - pp, nrm);
+    const V3d df = pnt - first;
+    if (di > (double)margin || sqrt(dot(df, df)) < (double)tol) continue;
+    put(pnt, di);
+  }
+  return n;
+}
+
 struct CSup { V3d v, v1; };  // a point of the Minkowski difference obj1 - obj2 and its witness on obj1 (the one on obj2 is v1 - v)
 __device__ __forceinline__ CSup mpr_support(const CObj& o1, const CObj& o2, V3d dir) {
   CSup s;

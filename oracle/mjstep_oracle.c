@@ -904,6 +904,47 @@ static int convex_convex(const om_model* m, const om_data* d, om_contact* con, i
   return 1;
 }
 
+/* mjc_PlaneConvex [recall] (engine_collision_convex.c; mujoco.h:355 mj_collision): plane g1 against mesh g2 (through its hull).  The hull's
+ * support point along the plane's inward direction -normal is the first contact if it is within the margin; up to three more come
+ * from the hull vertices ADJACENT to it in the mesh graph, in the order of the graph, each within the margin and at least
+ * tolplanemesh x rbound away from the first point (so that a face lying on the plane is held at several corners instead of one).
+ * dist = signed distance of the vertex from the plane, pos = the vertex moved half of that back along the normal, frame normal = the
+ * plane's.  Recalled constants: tolplanemesh 0.3, at most 3 extra contacts.  The graph is this build's own hull, so
+ * which neighbours exist - and their order - is a property of that hull. */
+#define OM_TOLPLANEMESH 0.3
+static int plane_convex(const om_model* m, const om_data* d, om_contact* con, int g1, int g2, double margin) {
+  const double *pos1 = d->geom_xpos + 3 * g1, *mat1 = d->geom_xmat + 9 * g1;
+  const double normal[3] = {mat1[2], mat1[5], mat1[8]}, down[3] = {-normal[0], -normal[1], -normal[2]};
+  ccd_obj o;
+  ccd_obj_from_geom(m, d, g2, 0.0, &o);
+  double first[3];
+  ccd_support(&o, down, first);
+  double dif[3] = {first[0] - pos1[0], first[1] - pos1[1], first[2] - pos1[2]};
+  double dist = dot3(dif, normal);
+  if (dist > margin) return 0;
+  int n = 0;
+  con[n].dist = dist;
+  for (int k = 0; k < 3; k++) { con[n].pos[k] = first[k] - 0.5 * dist * normal[k]; con[n].frame[k] = normal[k]; }
+  memset(con[n].frame + 3, 0, 6 * sizeof(double));
+  n++;
+  if (!o.nbr) return n;
+  const double tol = OM_TOLPLANEMESH * m->geom_rbound[g2];
+  const int* nb = o.nbr + o.nbradr[o.cur];
+  for (int i = 0; i < o.nbrnum[o.cur] && n < 4; i++) {
+    const double* v = o.vert + 3 * nb[i];
+    double pnt[3];
+    for (int k = 0; k < 3; k++) pnt[k] = o.mat[3 * k] * v[0] + o.mat[3 * k + 1] * v[1] + o.mat[3 * k + 2] * v[2] + o.pos[k];
+    double dp[3] = {pnt[0] - pos1[0], pnt[1] - pos1[1], pnt[2] - pos1[2]}, df[3] = {pnt[0] - first[0], pnt[1] - first[1], pnt[2] - first[2]};
+    const double di = dot3(dp, normal);
+    if (di > margin || sqrt(dot3(df, df)) < tol) continue;
+    con[n].dist = di;
+    for (int k = 0; k < 3; k++) { con[n].pos[k] = pnt[k] - 0.5 * di * normal[k]; con[n].frame[k] = normal[k]; }
+    memset(con[n].frame + 3, 0, 6 * sizeof(double));
+    n++;
+  }
+  return n;
+}
+
 /* mjc_ConvexHField: geom g2 (sphere, capsule or mesh) against height field g1.  Everything runs in the field's frame: the
  * geom's bounding box there picks a sub-grid; every grid cell of it is two triangular prisms (from the field's base up to the
  * surface triangle); each prism that reaches the geom's height is tested with MPR and gives at most one contact. */
@@ -1051,11 +1092,16 @@ static void collision(const om_model* m, om_data* d) {
     if (t1 == GEOM_HFIELD) {
       n = convex_hfield(m, d, con, OM_MAXCONPAIR, g1, g2, margin);  /* MuJoCo's scheme: every geom type goes through the prisms */
     } else if (t1 == GEOM_MESH || t2 == GEOM_MESH) {
-      if (t1 == GEOM_PLANE) continue;  /* plane - mesh (mjc_PlaneConvex) is not restated: the compiler refuses such models */
       double dp[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
-      double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
-      if (dot3(dp, dp) > bound * bound) continue;
-      n = convex_convex(m, d, con, g1, g2, margin);
+      if (t1 == GEOM_PLANE) {
+        double normal[3] = {mat1[2], mat1[5], mat1[8]};
+        if (dot3(dp, normal) > margin + m->geom_rbound[g2]) continue;
+        n = plane_convex(m, d, con, g1, g2, margin);
+      } else {
+        double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
+        if (dot3(dp, dp) > bound * bound) continue;
+        n = convex_convex(m, d, con, g1, g2, margin);
+      }
     } else if (t1 == GEOM_PLANE) {
       double normal[3] = {mat1[2], mat1[5], mat1[8]};
       double dp[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};

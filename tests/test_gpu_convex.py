@@ -266,3 +266,69 @@ def test_ball_and_capsules_on_a_sloped_field(hbmod, gpu, tmp_path):
     m.save(p)
     states, ctrls = _oracle_states(p, envs=1, T=900, every=10)
     _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=50, max_divergent=0.05)
+
+
+def test_plane_mesh_hulls_on_a_plane(hbmod, gpu, tmp_path):
+    """mjc_PlaneConvex on the device against the oracle, teacher-forced: a cube hull and a 300-vertex ball dropped, tilted, on a PLANE
+    (up to four contacts per hull: the support vertex and its graph neighbours), Newton with condim 6 and PGS with condim 3; through the
+    fused kernel (diagnostics on) and - the robot test below - the staged step."""
+    from test_oracle_convex import PLANE_CUBE_XML  # noqa: F401
+    body = ('<body pos="0.0 0.0 0.12" euler="20 30 10"><freejoint/><inertial pos="0 0 0" mass="0.5" diaginertia="0.001 0.001 0.001"/><geom type="mesh" mesh="cube" condim="%d"/></body>'
+            '<body pos="0.3 0.1 0.15"><freejoint/><inertial pos="0 0 0" mass="0.3" diaginertia="0.0005 0.0005 0.0005"/><geom type="mesh" mesh="ball" condim="%d" friction="0.7 0.02 0.01"/></body>')
+    for solver, dim, name in ((2, 6, "plane_newton.hbm"), (0, 3, "plane_pgs.hbm")):
+        xml = ('<mujoco><option timestep="0.002"/><asset>%s%s</asset><worldbody><geom name="floor" type="plane" pos="0 0 0" size="0 0 .05" condim="3"/>%s</worldbody></mujoco>'
+               % (CUBE_MESH, BALL_MESH, body % (dim, dim)))
+        m = hbmod.Model.from_xml_string(xml)
+        m.set_opt(solver=solver, iterations=100 if solver == 2 else 50)
+        p = str(tmp_path / name)
+        m.save(p)
+        states, ctrls = _oracle_states(p, envs=1, T=600, every=8)
+        w = _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=150, max_divergent=0.05)
+        assert w["max_nefc"] >= (40 if solver == 2 else 16)  # a hull flat on the plane: four contacts
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(TEAM_HBM), "team_robot_plane.hbm")), reason="assets/team_robot_plane.hbm not built")
+def test_team_robot_on_the_reference_plane_floor(hbmod, gpu):
+    """The reference's robot on its type="plane" floor (simulation/assets/green_screen_world.xml, compiled to assets/team_robot_plane.hbm):
+    the staged step (pose kernel evaluates the plane - hull items, no portal search for them) against the oracle, teacher-forced along the
+    robot's fall and rest on the plane."""
+    path = os.path.join(os.path.dirname(TEAM_HBM), "team_robot_plane.hbm")
+
+    def init(o, e, rng):
+        o.qpos[7:] += rng.uniform(-0.2, 0.2, o.nq - 7)
+        o.qpos[2] += 0.05
+        q = np.array([-0.7, 0, 0, 0.7]) + rng.uniform(-0.08, 0.08, 4)
+        o.qpos[3:7] = q / np.linalg.norm(q)
+    states, ctrls = _oracle_states(path, envs=4, T=900, every=15, seed=11, init=init, ctrl_scale=0.2)
+    from oracle_lib import load_state, prove_rounding_fence
+    m = hbmod.Model.load(path)
+    o = Oracle(path)
+    n = len(states)
+    states = np.array(states).astype(np.float32).astype(np.float64)
+    ctrls = np.array(ctrls, dtype=np.float32).reshape(n, m.nu)
+    b = hbmod.Batch(m, n, gpu)
+    b.set_state(hbmod.STATE_INTEGRATION, states)
+    b.step(ctrls)
+    q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
+    nc, ne, _ = b.counts()
+    assert not b.status().any()
+    worst_q = worst_v = 0.0
+    fence = contacts = 0
+
+    def dev_vs(oo, k):
+        return ((np.abs(q[k] - oo.qpos) / np.maximum(1.0, np.abs(oo.qpos))).max(), np.abs(v[k] - oo.qvel).max() / max(1.0, np.abs(oo.qvel).max()))
+    for k in range(n):
+        load_state(o, states[k], ctrls[k])
+        o.step()
+        dq, dv = dev_vs(o, k)
+        if (nc[k], ne[k]) != (o.ncon, o.nefc) or dq > TOL["qpos"] or dv > TOL["qvel"]:
+            def accept(oo):
+                oo.step()
+                return (nc[k], ne[k]) == (oo.ncon, oo.nefc) and dev_vs(oo, k)[1] <= TOL["qvel"]
+            assert prove_rounding_fence(o, states[k], ctrls[k], accept, seed=k) is not None, ("state %d" % k, nc[k], ne[k], o.ncon, o.nefc, dq, dv)
+            fence += 1
+            dq, dv = 0.0, dev_vs(o, k)[1]
+        contacts += o.ncon
+        worst_q, worst_v = max(worst_q, dq), max(worst_v, dv)
+    print("\nteam robot on the plane floor, staged step: %d states, %d contacts, %d on a PROVED rounding fence, worst qpos %.2e qvel %.2e" % (n, contacts, fence, worst_q, worst_v))
+    assert contacts >= 300 and fence <= 0.05 * n

@@ -281,3 +281,82 @@ def test_mesh_mesh_contact_between_two_bodies(hbmod, tmp_path):
     c = o.contacts()[0]
     assert abs(c["dist"] + 0.002) < 1e-6 and np.allclose(c["frame"][0], [0, 0, 1], atol=1e-6) and abs(c["pos"][2] - 0.099) < 1e-6
     assert c["dim"] == 3 and o.nefc == 4
+
+
+# ---- mjc_PlaneConvex: mesh hulls on a PLANE floor (the reference's green_screen_world.xml:30 and empty_world.xml:24 put the robot's
+# meshes on one; rl/generate_policy_videos.py builds CPUEnv on it)
+PLANE_CUBE_XML = ('<mujoco><option timestep="0.002"/><asset>%s</asset><worldbody><geom name="floor" type="plane" pos="0 0 0" size="0 0 .05" condim="3"/>'
+                  '<body pos="%s" %s><freejoint/><inertial pos="0 0 0" mass="0.5" diaginertia="0.001 0.001 0.001"/><geom type="mesh" mesh="cube" condim="%d"/></body>'
+                  '</worldbody></mujoco>')
+
+
+def test_plane_mesh_contacts_at_the_lowest_corners(hbmod, tmp_path):
+    """A cube hull (edge 0.1) lying flat, 1 mm into the plane: the support vertex and its graph neighbours in the bottom face, never a top
+    vertex (outside the margin); contact i at its vertex moved half the penetration up, distance = the vertex's height, normal = the
+    plane's; tilted onto an edge two contacts, onto a corner one."""
+    _, o = _oracle_from_xml(hbmod, PLANE_CUBE_XML % (CUBE_MESH, "0.3 -0.2 0.049", "", 3), tmp_path)
+    o.reset(); o.forward()
+    assert 3 <= o.ncon <= 4 and o.nefc == 4 * o.ncon
+    seen = set()
+    for c in o.contacts():
+        assert abs(c["dist"] + 0.001) < 1e-12 and np.allclose(c["frame"][0], [0, 0, 1], atol=1e-12)
+        assert abs(c["pos"][2] + 0.0005) < 1e-12  # half way between the vertex (z = -0.001) and the plane
+        corner = (round((c["pos"][0] - 0.3) / 0.05), round((c["pos"][1] + 0.2) / 0.05))
+        assert corner in {(-1, -1), (-1, 1), (1, -1), (1, 1)} and corner not in seen
+        seen.add(corner)
+    # on an edge (rotated 45 degrees about x): the two vertices of that edge; on a corner: one
+    d = -np.ones(3) / np.sqrt(3)  # the body diagonal turned onto -z: axis d x (-z), angle acos(d . (-z))
+    ax = np.cross(d, [0, 0, -1]); ax /= np.linalg.norm(ax)
+    half = 0.5 * np.arccos(1 / np.sqrt(3))
+    corner_quat = 'quat="%.17g %.17g %.17g %.17g"' % (np.cos(half), *(np.sin(half) * ax))
+    for pose, want in (('euler="45 0 0"', 2), (corner_quat, 1)):
+        z = {2: 0.05 * np.sqrt(2), 1: 0.05 * np.sqrt(3)}[want] - 0.001
+        _, o = _oracle_from_xml(hbmod, PLANE_CUBE_XML % (CUBE_MESH, "0 0 %.17g" % z, pose, 3), tmp_path)
+        o.reset(); o.forward()
+        assert o.ncon == want, (pose, o.ncon)
+        for c in o.contacts():
+            assert abs(c["dist"] + 0.001) < 1e-9
+    # above the margin: nothing
+    _, o = _oracle_from_xml(hbmod, PLANE_CUBE_XML % (CUBE_MESH, "0 0 0.06", "", 3), tmp_path)
+    o.reset(); o.forward()
+    assert o.ncon == 0
+
+
+def test_hull_resting_on_a_plane_carries_its_weight(hbmod, tmp_path):
+    """The cube dropped flat on the plane comes to rest level on its bottom corners: sum of the contacts' normal forces = m g (condim 6:
+    ten pyramid rows per contact, all non-negative), no residual rocking."""
+    _, o = _oracle_from_xml(hbmod, PLANE_CUBE_XML % (CUBE_MESH, "0.1 0.1 0.07", "", 6), tmp_path)
+    o.reset()
+    for _ in range(2000):
+        o.step()
+    assert 3 <= o.ncon <= 4 and o.nefc == 10 * o.ncon
+    f = o.efc_force[:o.nefc]
+    assert (f >= 0).all() and abs(f.sum() - 0.5 * 9.81) < 0.5 * 9.81 * 1e-3
+    # (with three of the four bottom corners in the contact set the cube leans, by micrometres, towards the fourth until that one is the
+    # lowest: a residual rocking of 5e-4 rad/s)
+    assert np.abs(o.qvel[:3]).max() < 1e-4 and np.abs(o.qvel[3:]).max() < 2e-3 and abs(o.qpos[2] - 0.05) < 1e-3
+    q = o.qpos[3:7] / np.linalg.norm(o.qpos[3:7])
+    assert abs(abs(q[0]) - 1) < 1e-5  # still level
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "simulation/assets/green_screen_world.xml")), reason="reference tree not present")
+def test_reference_green_screen_world_compiles_and_stands_on_its_plane(hbmod, tmp_path):
+    """simulation/assets/green_screen_world.xml (the path simulation/__init__.py:7-9 exports, rl/generate_policy_videos.py:19): the
+    reference's robot on a type="plane" floor.  It compiles, and the uncontrolled robot comes to rest on the plane (a dozen hull - plane
+    contacts) with the floor carrying exactly its weight.  (empty_world.xml, the other plane file, holds no robot at all - a <body> outside <worldbody> - and no
+    Python of the reference loads it: it has no degree of freedom to step, here or in MuJoCo.)"""
+    m = hbmod.Model.load(os.path.join(REFERENCE, "simulation/assets/green_screen_world.xml"))
+    assert (m.nq, m.nv, m.nu) == (19, 18, 12) and m.opt.solver == 2
+    p = str(tmp_path / "green.hbm")
+    m.save(p)
+    o = Oracle(p)
+    o.reset()
+    for _ in range(1200):
+        o.step()
+    assert o.ncon >= 4 and np.abs(o.qvel).max() < 0.01
+    mass = o.marr("body_mass").sum()
+    normal = sum(o.efc_force[c["efc_address"]:c["efc_address"] + (1 if c["dim"] == 1 else 2 * (c["dim"] - 1))].sum() for c in o.contacts()
+                 if o.info["geom_type"][c["geom1"]] == 0)
+    assert abs(normal - mass * 9.81) < 0.01 * mass * 9.81, (normal, mass * 9.81)
+    with pytest.raises(Exception):
+        hbmod.Model.load(os.path.join(REFERENCE, "simulation/assets/empty_world.xml"))

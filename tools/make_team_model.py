@@ -12,9 +12,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = "/root/reference/simulation/assets/world.xml"
 DST = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "team_robot.hbm")
+# the same robot on the reference's type="plane" floor (simulation/assets/green_screen_world.xml: what simulation/__init__.py exports and
+# rl/generate_policy_videos.py builds CPUEnv on): plane - hull contacts (mjc_PlaneConvex) instead of the height field's prisms
+SRC_PLANE = "/root/reference/simulation/assets/green_screen_world.xml"
+DST_PLANE = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "team_robot_plane.hbm")
 
 
 def main():
+    build(SRC, DST)
+    build(SRC_PLANE, DST_PLANE)
+
+
+def build(SRC, DST):
     subprocess.check_call([os.path.join(ROOT, "build", "hb_compile"), SRC, DST, "--timestep", "0.002"])
     lines = open(DST).read().splitlines()
     rec = {ln.split()[1]: ln for ln in lines if len(ln.split()) > 2}

@@ -176,6 +176,7 @@ struct GeomTmp {
   int type;
   double size[3], pos[3], quat[4];
   double mass, inertia[3];  // principal, in geom frame
+  bool inertia_unknown = false;  // a mesh geom that would have to supply mass and inertia (MuJoCo derives them from the mesh volume)
 };
 
 // mass and principal inertia of a primitive at given density (or explicit mass)
@@ -184,7 +185,11 @@ void geom_inertia(GeomTmp& g, double density, double mass_attr) {
   double r = g.size[0], h = g.size[1];
   if (g.type == GEOM_SPHERE) vol = 4.0 / 3.0 * PI * r * r * r;
   else if (g.type == GEOM_CAPSULE) vol = PI * r * r * (2 * h) + 4.0 / 3.0 * PI * r * r * r;
+  else if (g.type == GEOM_CYLINDER) vol = PI * r * r * (2 * h);
   else vol = 0;
+  // a mesh's mass, centre of mass and inertia come from its volume in MuJoCo; this compiler keeps only the hull's vertices, so a mesh
+  // geom can take part in a body's inertia only through the body's <inertial> (finish_body_inertia turns the flag into an error)
+  g.inertia_unknown = g.type == GEOM_MESH && (mass_attr > 0 || (mass_attr < 0 && density > 0));
   double mass = mass_attr >= 0 ? mass_attr : density * vol;
   g.mass = mass;
   g.inertia[0] = g.inertia[1] = g.inertia[2] = 0;
@@ -202,6 +207,10 @@ void geom_inertia(GeomTmp& g, double density, double mass_attr) {
     iz += isph;
     g.inertia[0] = g.inertia[1] = ix;
     g.inertia[2] = iz;
+  } else if (g.type == GEOM_CYLINDER) {
+    const double height = 2 * h;
+    g.inertia[0] = g.inertia[1] = mass * (3 * r * r + height * height) / 12.0;
+    g.inertia[2] = mass * r * r / 2.0;
   }
 }
 
@@ -412,10 +421,17 @@ bool add_joint(Ctx& c, const XmlNode& n, int body, const std::string& childclass
 bool finish_body_inertia(Ctx& c, int body, BodyBuild& bb) {
   Model& m = *c.m;
   double ipos[3] = {0, 0, 0}, iquat[4] = {1, 0, 0, 0}, mass = 0, inertia[3] = {0, 0, 0};
-  if (bb.has_inertial) {
+  if (body == 0) {
+    // the world body is static and massless whatever geoms it carries (floor, the reference's cylinder axis markers)
+  } else if (bb.has_inertial) {
     memcpy(ipos, bb.ipos, sizeof ipos); memcpy(iquat, bb.iquat, sizeof iquat);
     mass = bb.mass; memcpy(inertia, bb.inertia, sizeof inertia);
   } else {
+    if (body > 0)
+      for (auto& g : bb.geoms)
+        if (g.inertia_unknown)
+          return c.fail("mjcf: body '" + m.body_name[body] + "' has no <inertial> and a mesh geom that would have to supply mass and inertia: "
+                        "mesh-derived inertia is not implemented (give the body an <inertial>, or the geom mass=\"0\" / density=\"0\")");
     std::vector<GeomTmp*> sel;
     for (auto& g : bb.geoms) if (g.mass > 0) sel.push_back(&g);
     if (sel.size() == 1) {

@@ -167,11 +167,30 @@ def test_multi_tree_weld_and_options(hbmod, tmp_path):
     ("<mujoco><worldbody><body></worldbody></mujoco>", "mismatched"),
     ("<mujoco><option solver='CG'/><worldbody/></mujoco>", "PGS"),
     ("<notmujoco/>", "root element"),
+    # a mesh geom that would have to supply a body's mass and inertia (MuJoCo takes them from the mesh volume): refused, never a
+    # silent point mass - alone, beside a primitive geom, and with an explicit mass
+    ("<mujoco><asset><mesh name='m' vertex='0 0 0 1 0 0 0 1 0 0 0 1'/></asset><worldbody><body><joint/><geom type='mesh' mesh='m'/></body></worldbody></mujoco>", "mesh-derived inertia"),
+    ("<mujoco><asset><mesh name='m' vertex='0 0 0 1 0 0 0 1 0 0 0 1'/></asset><worldbody><body><joint/><geom size='0.1'/><geom type='mesh' mesh='m'/></body></worldbody></mujoco>", "mesh-derived inertia"),
+    ("<mujoco><asset><mesh name='m' vertex='0 0 0 1 0 0 0 1 0 0 0 1'/></asset><worldbody><body><joint/><geom type='mesh' mesh='m' mass='2'/></body></worldbody></mujoco>", "mesh-derived inertia"),
 ])
 def test_compile_errors_are_reported_not_fatal(hbmod, xml, frag):
     with pytest.raises(hbmod.HbError) as e:
         hbmod.Model.from_xml_string(xml)
     assert frag in str(e.value)
+
+
+def test_mesh_and_cylinder_geoms_in_the_inertia_of_a_body(hbmod):
+    """With an <inertial> (as every body of the reference's robot has) or with density 0 a mesh geom compiles; a cylinder contributes its
+    closed-form mass and inertia like the other primitives (m = rho pi r^2 2h, Ixx = m (3 r^2 + (2h)^2) / 12, Izz = m r^2 / 2)."""
+    mesh = "<asset><mesh name='m' vertex='0 0 0 1 0 0 0 1 0 0 0 1'/></asset>"
+    a = hbmod.Model.from_xml_string("<mujoco>%s<worldbody><body><joint/><inertial pos='0 0 0' mass='1' diaginertia='1 1 1'/><geom type='mesh' mesh='m'/></body></worldbody></mujoco>" % mesh)
+    assert a.array("body_mass")[1] == 1.0
+    b = hbmod.Model.from_xml_string("<mujoco>%s<worldbody><body><joint/><geom size='0.1'/><geom type='mesh' mesh='m' density='0'/></body></worldbody></mujoco>" % mesh)
+    assert abs(b.array("body_mass")[1] - 1000 * 4 / 3 * np.pi * 1e-3) < 1e-12
+    c = hbmod.Model.from_xml_string("<mujoco><worldbody><body><joint/><geom type='cylinder' size='0.2 0.5' contype='0' conaffinity='0'/></body></worldbody></mujoco>")
+    mass = 1000 * np.pi * 0.04 * 1.0
+    assert abs(c.array("body_mass")[1] - mass) < 1e-9
+    assert np.allclose(c.array("body_inertia").reshape(-1, 3)[1], [mass * (3 * 0.04 + 1.0) / 12, mass * (3 * 0.04 + 1.0) / 12, mass * 0.04 / 2], rtol=1e-12)
 
 
 def test_load_errors(hbmod, tmp_path):

@@ -47,7 +47,41 @@ bool make_face(const std::vector<P3>& p, int a, int b, int c, Face& f) {
 
 // Convex hull of `pts` (3 doubles per point): indices of the hull's vertices, ascending, and (optionally) the hull's triangles as
 // triples of positions in `hull`.  false: degenerate input (fewer than four points that are not coplanar).
+static bool hull_once(const std::vector<double>& pts, const std::vector<double>& orig, std::vector<int>& hull, std::string& err, std::vector<int>* tris, bool& open_hull);
+
+// Nearly coplanar input (a subdivided CAD face rounded to float32) can leave the incremental build with an open hull; such input is
+// built again on joggled copies of the points (deterministic offsets of 1e-8, 1e-7 of the extent: qhull's "QJ"), which have no exact
+// coplanarities; the vertex SET comes out of the joggled topology, the coordinates stay the file's, and the result is verified against
+// them (closed manifold, Euler's formula, no input point outside a face by more than 2e-6 of the extent).
 bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull, std::string& err, std::vector<int>* tris) {
+  bool open_hull = false;
+  if (hull_once(pts, pts, hull, err, tris, open_hull) || !open_hull) return err.empty() && !hull.empty();
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (size_t i = 0; i < pts.size(); i++) { lo[i % 3] = std::min(lo[i % 3], pts[i]); hi[i % 3] = std::max(hi[i % 3], pts[i]); }
+  const double scale = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+  for (double amp : {1e-8, 1e-7}) {
+    std::vector<double> jog(pts);
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < jog.size(); i++) {
+      x += 0x9E3779B97F4A7C15ull;
+      uint64_t z = x;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+      jog[i] += amp * scale * ((double)(z >> 11) / 9007199254740992.0 - 0.5);
+    }
+    std::string e2;
+    if (hull_once(jog, pts, hull, e2, tris, open_hull)) { err.clear(); return true; }
+    err = e2;
+    if (!open_hull) return false;
+  }
+  return false;
+}
+
+// one incremental build on `pts`; the final convexity check runs against `orig` (the file's coordinates).  open_hull: the failure was
+// an open / non-manifold result (worth another attempt on joggled points), not degenerate input
+static bool hull_once(const std::vector<double>& pts, const std::vector<double>& orig, std::vector<int>& hull, std::string& err, std::vector<int>* tris, bool& open_hull) {
+  open_hull = false;
+  hull.clear();
+  err.clear();
   const int n = (int)pts.size() / 3;
   std::vector<P3> p(n);
   P3 lo = {1e300, 1e300, 1e300}, hi = {-1e300, -1e300, -1e300};
@@ -129,6 +163,42 @@ bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull
   hull.clear();
   for (int i = 0; i < n; i++) if (used[i]) hull.push_back(i);
   if (hull.size() < 4) { err = "mesh: convex hull collapsed"; return false; }
+  // The result must be a closed, convex 2-manifold: every directed edge has exactly one reverse, V - E + F = 2, and no input point lies
+  // outside any face by more than the tolerance.  (Nearly coplanar input can leave the visible set of an insertion not simply connected;
+  // a horizon face that make_face drops, or a directed edge seen twice, would give an open hull - and the device's hill climb along the
+  // hull's edge graph can stop at a non-maximal vertex where an edge is missing.  Refused here instead.)
+  {
+    std::map<std::pair<int, int>, int> dir;
+    size_t nf = 0;
+    for (auto& f : faces) {
+      if (!f.alive) continue;
+      nf++;
+      for (int k = 0; k < 3; k++) dir[{f.v[k], f.v[(k + 1) % 3]}]++;
+    }
+    for (auto& e : dir)
+      if (e.second != 1 || !dir.count({e.first.second, e.first.first})) { err = "mesh: convex hull is not a closed manifold (nearly coplanar or duplicate vertices?)"; open_hull = true; hull.clear(); return false; }
+    const long long V = (long long)hull.size(), E = (long long)dir.size() / 2, F = (long long)nf;
+    if (V - E + F != 2) { err = "mesh: convex hull fails Euler's formula (V - E + F = " + std::to_string(V - E + F) + ")"; open_hull = true; hull.clear(); return false; }
+    // (2e-6 of the extent: float32 coordinates are rounded by 6e-8 of it, and a small face - three neighbouring points of a subdivided
+    // CAD facet - tilts by that rounding over its own size, which a point at the far end of the facet sees magnified by the ratio)
+    const double tol = 2e-6 * scale;
+    for (auto& f : faces) {
+      if (!f.alive) continue;
+      // (the face through the file's coordinates of its three vertices, against the file's coordinates of every point)
+      const P3 a = {orig[3 * f.v[0]], orig[3 * f.v[0] + 1], orig[3 * f.v[0] + 2]}, b = {orig[3 * f.v[1]], orig[3 * f.v[1] + 1], orig[3 * f.v[1] + 2]},
+               c = {orig[3 * f.v[2]], orig[3 * f.v[2] + 1], orig[3 * f.v[2] + 2]};
+      P3 nn = crs(sub(b, a), sub(c, a));
+      const double len = std::sqrt(dt(nn, nn));
+      const double e1 = dt(sub(b, a), sub(b, a)), e2 = dt(sub(c, a), sub(c, a)), e3 = dt(sub(c, b), sub(c, b));
+      if (len < 1e-4 * std::max(e1, std::max(e2, e3))) continue;  // a sliver between nearly collinear vertices: its normal means nothing
+      nn = {nn.x / len, nn.y / len, nn.z / len};
+      const double dd = dt(nn, a);
+      for (int i = 0; i < n; i++) {
+        const double out = nn.x * orig[3 * i] + nn.y * orig[3 * i + 1] + nn.z * orig[3 * i + 2] - dd;
+        if (out > tol) { err = "mesh: convex hull leaves input vertices outside (by " + std::to_string(out / scale) + " of the extent)"; open_hull = true; hull.clear(); return false; }
+      }
+    }
+  }
   if (tris) {
     std::vector<int> local(n, -1);
     for (size_t k = 0; k < hull.size(); k++) local[hull[k]] = (int)k;

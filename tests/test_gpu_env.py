@@ -126,6 +126,7 @@ def test_vecenv_reports_warning_bits(hbmod, humanoid_model, gpu):
     visible to the training loop.  A NaN planted in one env's state shows up as BADQPOS for that env only."""
     n = 6
     env = hbmod.VecEnv(humanoid_model, n, gpu, auto_reset=0, max_time=0.0)
+    env.warning_period = 1  # read the bits back at every step (the default refreshes them every 16th: they are sticky)
     env.reset()
     act = np.zeros((n, humanoid_model.nu), np.float32)
     _, _, _, _, info = env.step(act)

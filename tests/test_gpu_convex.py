@@ -332,3 +332,24 @@ def test_team_robot_on_the_reference_plane_floor(hbmod, gpu):
         worst_q, worst_v = max(worst_q, dq), max(worst_v, dv)
     print("\nteam robot on the plane floor, staged step: %d states, %d contacts, %d on a PROVED rounding fence, worst qpos %.2e qvel %.2e" % (n, contacts, fence, worst_q, worst_v))
     assert contacts >= 300 and fence <= 0.05 * n
+
+
+@pytest.mark.timeout(120)
+def test_exact_ties_on_flat_facets_terminate_and_match(hbmod, gpu, tmp_path):
+    """Regression for the hull-climb hang of round 2 (hb_mpr.hpp: hull_val / hull_tie, kClimbMax): a support direction exactly
+    perpendicular to a flat facet makes all of the facet's vertices tie, and a vertex's neighbour list is padded with copies of the vertex
+    itself - left to the compiler, the two sides of the tie comparison were once contracted differently, a copy "improved" on its own
+    vertex in the last bit and the climb never ended.  Axis-aligned cubes, un-rotated, flat on a plane, flat on a flat height field and
+    stacked on each other (every query direction of the first steps is an exact axis): the step returns, and contacts, counts and next
+    state equal the oracle's."""
+    cube = '<body pos="%s"><freejoint/><inertial pos="0 0 0" mass="0.5" diaginertia="0.001 0.001 0.001"/><geom type="mesh" mesh="cube" condim="3"/></body>'
+    worlds = {
+        "tie_plane.hbm": '<mujoco><option timestep="0.002"/><asset>%s</asset><worldbody><geom type="plane" size="0 0 .05" condim="3"/>%s%s</worldbody></mujoco>'
+                         % (CUBE_MESH, cube % "0 0 0.0495", cube % "0 0 0.149"),
+        "tie_hfield.hbm": _hfield_xml(np.zeros((4, 4)), cube % "0.125 0.125 0.0495" + cube % "0.125 0.125 0.149", extra=CUBE_MESH),
+    }
+    for name, xml in worlds.items():
+        p = _save(hbmod, xml, tmp_path, name)
+        states, ctrls = _oracle_states(p, envs=1, T=40, every=2)
+        w = _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=40, max_divergent=0.1)
+        assert w["max_nefc"] >= 8

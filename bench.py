@@ -438,9 +438,11 @@ def main():
             out["roofline"]["traffic_source"] = "committed profile, not this run: " + str(traffic.get("source"))
             # what actually bounds the kernel (from the same PMC passes; informational): share of the chip's fp32 VALU
             # lane-op rate the kernel issues, and the share of SIMD cycles with the MFMA pipe busy
-            for k in ("valu_issue_frac_of_peak", "mfma_busy_frac"):
+            for k in ("valu_issue_frac_of_peak", "mfma_busy_frac", "valu"):
                 if k in traffic:
                     out["roofline"][k] = traffic[k]
+            if "avg_launch_ns_kernel_trace" in traffic:  # (the profile's own launch time: `achieved` of that run, for comparison with this one)
+                out["roofline"]["profile_avg_launch_us"] = 1e-3 * traffic["avg_launch_ns_kernel_trace"]
         if elapsed_rollout is not None:
             out["rollout"] = {"value": n_env * world * K / elapsed_rollout, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed_rollout / K,
                               "what": "same K steps as one hb_rollout_dev launch per GPU (no per-step batch barrier; testspeed.cc shape)"}

@@ -121,3 +121,57 @@ def test_policy_argument_checks(hbmod, humanoid_model, gpu):
         b.rollout_policy(3)  # no policy installed
     with pytest.raises(hbmod.HbError):
         b.set_policy_mlp([np.zeros((m.nobs + 1, m.nu), np.float32)], [np.zeros(m.nu, np.float32)])  # wrong input width
+
+
+def _fixture_policy():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_mlp_seed0.npz"))
+    return [g["w0"], g["w1"], g["w2"]], [g["b0"], g["b1"], g["b2"]], g
+
+
+def test_config4_fixture_policy_on_4096_envs(hbmod, humanoid_model, gpu):
+    """BASELINE configs[3] as SURVEY.md 8(d) config 4 specifies it: the `torch.manual_seed(0)` default-`nn.Linear` policy
+    (tests/golden/policy_mlp_seed0.npz, tools/make_policy_fixture.py) on 4096 envs.  (1) The fixture's own probe: the numpy evaluation of
+    the exported weights reproduces the stored torch-checked outputs; (2) hb_policy_eval on 4096 device observations against numpy;
+    (3) 40 closed-loop steps of hb_rollout_policy, pipelined and not, equal the host-driven loop (policy_eval, then step) bit for bit and
+    stay within fp32 reach of a loop whose policy runs in fp64 numpy."""
+    m = humanoid_model
+    ws, bs, g = _fixture_policy()
+    assert [w.shape for w in ws] == [(48, 256), (256, 256), (256, 21)] and m.nobs == 48 and m.nu == 21
+    assert np.abs(mlp_ref(g["probe"], ws, bs) - g["probe_out"]).max() < 1e-12
+    n, T = 4096, 40
+    a = hbmod.Batch(m, n, gpu)
+    a.reset(perturb=True)
+    a.rollout_halton(150)          # falling, first contacts
+    a.set_policy_mlp(ws, bs)
+    ctrl = a.policy_eval()
+    obs, _, _, _ = a.obs(want_reward=False)
+    assert ctrl.shape == (n, 21) and np.abs(ctrl - mlp_ref(obs, ws, bs)).max() < 2e-5
+    st0 = a.get_state(hbmod.STATE_INTEGRATION)
+    finals = []
+    for mode in ("launch chain", "pipelined", "host loop"):
+        b = hbmod.Batch(m, n, gpu)
+        b.set_policy_mlp(ws, bs)
+        b.set_state(hbmod.STATE_INTEGRATION, st0)
+        if mode == "pipelined":
+            b.pipeline(True)
+        if mode == "host loop":
+            for _ in range(T):
+                b.step(b.policy_eval())
+        else:
+            b.rollout_policy(T)
+        finals.append(b.get_state(hbmod.STATE_INTEGRATION))
+        assert not (b.status() & (hbmod.WARN_BADQPOS | hbmod.WARN_BADQVEL | hbmod.WARN_BADQACC)).any()
+        b.close()
+    assert np.array_equal(finals[0], finals[2]) and np.array_equal(finals[1], finals[2])
+    # fp64 policy in the loop for 5 steps: the controls differ by fp32 tanh rounding only
+    c = hbmod.Batch(m, n, gpu)
+    d = hbmod.Batch(m, n, gpu)
+    for x in (c, d):
+        x.set_state(hbmod.STATE_INTEGRATION, st0)
+    c.set_policy_mlp(ws, bs)
+    for _ in range(5):
+        c.step(c.policy_eval())
+        o, _, _, _ = d.obs(want_reward=False)
+        d.step(mlp_ref(o, ws, bs).astype(np.float32))
+    assert np.abs(c.qpos - d.qpos).max() < 1e-4

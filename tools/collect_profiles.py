@@ -50,7 +50,7 @@ else:
             avg_ns = float(row["AverageNs"]); calls = int(row["Calls"])
 counters = {}
 meta = {}
-for d in ("prof_fetch", "prof_write", "prof_sq", "prof_lds", "prof_mfma"):
+for d in ("prof_fetch", "prof_write", "prof_sq", "prof_lds", "prof_mfma", "prof_valu"):
     fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
     if not fs:
         continue
@@ -82,10 +82,40 @@ if "SQ_INSTS_VALU" in counters:
         # fp32 VALU utilisation: wave64 VALU instruction = 64 lanes; peak 157.3 TFLOP/s = 78.6e12 lane-FMA/s
         out["valu_lane_ops_per_s"] = counters["SQ_INSTS_VALU"]["mean"] * 64 / (avg_ns * 1e-9)
         out["valu_issue_frac_of_peak"] = out["valu_lane_ops_per_s"] / 78.6e12
+# Real lane utilisation: SQ_INSTS_VALU counts a wave instruction as one whatever its EXEC mask, and this kernel's
+# stages run lane = body (17), dof (27), constraint row (~11).  SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU is proportional to the
+# mean number of active lanes per VALU instruction; the proportionality constant is taken from a kernel of the same pass whose lanes
+# are all active (hb_halton_ctrl_kernel: 4096 x 21 x T threads in full waves).
+fv = glob.glob(os.path.join(src, "prof_valu", "*", "*_counter_collection.csv"))
+if fv:
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(fv[0])):
+        k = "step" if ("hb_step_kernel" in row["Kernel_Name"] and int(row["Grid_Size"]) == full) else ("halton" if "hb_halton_ctrl_kernel" in row["Kernel_Name"] else None)
+        if k:
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    def ratio(k):
+        t, a = steady(acc[k].get("SQ_THREAD_CYCLES_VALU", [])), steady(acc[k].get("SQ_ACTIVE_INST_VALU", []))
+        return (sum(t) / len(t)) / (sum(a) / len(a)) if t and a and sum(a) > 0 else None
+    rs, rh = ratio("step"), ratio("halton")
+    if rs and rh:
+        util = min(1.0, rs / rh)
+        out["valu_lanes"] = {"thread_cycles_per_inst_cycle_step_kernel": rs, "thread_cycles_per_inst_cycle_full_waves": rh, "active_lane_fraction": util,
+                             "mean_active_lanes_per_valu_instruction": 64.0 * util,
+                             "note": "calibrated on hb_halton_ctrl_kernel of the same PMC pass (all 64 lanes active)"}
+        if "valu_lane_ops_per_s" in out:
+            out["valu_useful_lane_ops_per_s"] = out["valu_lane_ops_per_s"] * util
+            out["valu_useful_frac_of_peak"] = out["valu_useful_lane_ops_per_s"] / 78.6e12
 json.dump(out, open(os.path.join(dst, rnd + "_counters.json"), "w"), indent=1)
 if "valu_issue_frac_of_peak" in out and os.path.exists(os.path.join(dst, "traffic_latest.json")):
     latest = json.load(open(os.path.join(dst, "traffic_latest.json")))
     latest["valu_issue_frac_of_peak"] = out["valu_issue_frac_of_peak"]
+    latest["avg_launch_ns_kernel_trace"] = avg_ns
+    if "hbm" in out:
+        latest["fetch_bytes_raw"] = out["hbm"]["fetch_bytes_raw"]; latest["write_bytes"] = out["hbm"]["write_bytes"]
+    if "valu_lanes" in out:
+        latest["valu"] = {"bound": "valu", "issued_lane_ops_per_s": out["valu_lane_ops_per_s"], "active_lane_fraction": out["valu_lanes"]["active_lane_fraction"],
+                          "achieved": out["valu_useful_lane_ops_per_s"], "peak": 78.6e12, "unit": "fp32 lane-op/s", "frac": out["valu_useful_frac_of_peak"],
+                          "note": "SQ_INSTS_VALU x 64 x (active lanes / 64) / launch time; peak = 157.3 TFLOP/s / 2 flop per fma"}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "SQ_BUSY_CU_CYCLES" in counters:
         latest["mfma_busy_frac"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (4.0 * counters["SQ_BUSY_CU_CYCLES"]["mean"])
     json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)

@@ -93,13 +93,13 @@ void mix_pair(const Model& m, int g1, int g2, int& dim, double* fr, double* solr
 // with condim 1 / 3; a mesh geom, a height field or a condim 4 / 6 pair takes the general collision + constraint assembly, with PGS on
 // 63 rows or Newton on kBigNefcMax rows.  false: no instantiation fits.
 bool model_variant(const Model& m, int& variant, int& ncon_max, int& nefc_max, std::string& err) {
-  bool general = false;
+  bool general = false, wide = false;  // wide: a pair of contact dimension 4 / 6 (six / ten pyramid rows per contact)
   for (int p = 0; p < m.npair; p++) {
     const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
     const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
     if (t1 == GEOM_MESH || t2 == GEOM_MESH || t1 == GEOM_HFIELD || t2 == GEOM_HFIELD) general = true;
     const int dim = m.geom_priority[g1] != m.geom_priority[g2] ? m.geom_condim[m.geom_priority[g1] > m.geom_priority[g2] ? g1 : g2] : std::max(m.geom_condim[g1], m.geom_condim[g2]);
-    if (dim != 1 && dim != 3) general = true;
+    if (dim != 1 && dim != 3) { general = true; wide = true; }
   }
   variant = 0; ncon_max = kNconMax; nefc_max = kNefcMax;
   if (!general) return true;
@@ -108,6 +108,7 @@ bool model_variant(const Model& m, int& variant, int& ncon_max, int& nefc_max, s
   for (int h = 0; h < m.nhfield; h++)
     if (m.hfield_nrow[h] > 32767 || m.hfield_ncol[h] > 32767) { err = "height fields larger than 32767 x 32767 are not supported"; return false; }
   if (m.solver == SOL_NEWTON) { variant = 2; ncon_max = kBigNconMax; nefc_max = kBigNefcMax; }
+  else if (wide) { variant = 3; ncon_max = kBigNconMax; nefc_max = kPgsNefcMax; }  // PGS with six / ten rows per contact: kPgsNefcMax rows, AR in LDS
   else variant = 1;
   return true;
 }
@@ -188,6 +189,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   int endA = off;
   off = region;
   dm.o_meta = 0;
+  dm.o_AR = 0;
   if (dm.variant == 2) {
     // Newton on kBigNefcMax rows: contacts, J rows, the dense M ([32][33], where the classic layout keeps the row meta), the
     // compact row meta, one D / force word per row
@@ -195,6 +197,13 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     dm.o_C = take(std::max(dm.nefc_max * dm.cstride + 64, kListMax * 5 + kWorkMax));  // (the collision pass borrows the head of C for its lists)
     dm.o_efc = take(32 * 36);
     dm.o_meta = take(dm.nefc_max * kMetaStride);
+  } else if (dm.variant == 3) {
+    // PGS on kPgsNefcMax rows: contacts, J / C rows (+ the qfrc_smooth row), W, the compact row meta, the matrix AR
+    dm.o_con = take(dm.ncon_max * kConStride);
+    dm.o_C = take(std::max((dm.nefc_max + 1) * dm.cstride + 64, kListMax * 5 + kWorkMax));
+    dm.o_efc = take(32 * 36);
+    dm.o_meta = take(dm.nefc_max * kMetaStride);
+    dm.o_AR = take(dm.nefc_max * dm.nefc_max);
   } else if (small) {
     // the small instantiation of the classic PGS kernel (dense order 28, kSmallNefcMax rows, kSmallNconMax contacts): C, then the row
     // meta (13 slots per row) with the contact records behind it - both dead when W (28 rows of 36: no padding rows) is built over them;
@@ -554,7 +563,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     D.small_lds_floats = sm.lds_floats;
   }
   D.fast_lds_floats = 0;
-  if (dm.variant == 2) {
+  if (dm.variant == 2 || dm.variant == 3) {
     DevModel fm = dm;
     fm.variant = 1; fm.ncon_max = kNconMax; fm.nefc_max = kNefcMax;
     if (!lay(fm)) return false;
@@ -1122,7 +1131,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
     if ((dm.variant == 1 || b->D.d_dm_fast) && !(getenv("HB_FASTPASS") && atoi(getenv("HB_FASTPASS")) == 0)) {
       ok = ok && hipMalloc((void**)&sb.defer, (size_t)n_env * sizeof(int)) == hipSuccess;
       ok = ok && hipMemset(sb.defer, 0, (size_t)n_env * sizeof(int)) == hipSuccess;
-      if (dm.variant == 2) { sb.dm_fast = b->D.d_dm_fast; sb.fast_lds = b->D.fast_lds_floats * (int)sizeof(float); }
+      if (dm.variant == 2 || dm.variant == 3) { sb.dm_fast = b->D.d_dm_fast; sb.fast_lds = b->D.fast_lds_floats * (int)sizeof(float); }
       if (ok && sb.fast_lds > 64 * 1024) ok = set_step_lds_limit(sb.fast_lds) == hipSuccess;
     }
   }

@@ -33,6 +33,9 @@ constexpr int kLaneRing = 64;   // step calls whose controls the slow lane can s
 constexpr int kBigGroups = 4;
 constexpr int kBigNefcMax = 64 * kBigGroups;
 constexpr int kBigNconMax = 48;
+// ... and with PGS in kPgsGroups groups with the row-by-row matrix AR in LDS (a condim 4 / 6 model solved by PGS: variant 3): 128 rows
+constexpr int kPgsGroups = 2;
+constexpr int kPgsNefcMax = 64 * kPgsGroups;
 constexpr int kListMax = 128;   // general collision: pairs that survive the broadphase per step (more: HB_WARN_CONTACTFULL)
 constexpr int kWorkMax = 256;   // general collision: narrowphase work items (pair or pair x prism) per step
 constexpr int kConStride = 20;  // floats per contact record in LDS
@@ -53,7 +56,7 @@ struct DevModel {
   int nobs;
   // which instantiation of the step kernel runs this model: 0 classic (plane / sphere / capsule, condim 1 / 3), 1 general collision
   // (mesh hulls and height-field prisms through MPR, condim 1 / 3 / 4 / 6) with the 63-row solvers, 2 general collision + Newton on
-  // kBigNefcMax rows
+  // kBigNefcMax rows, 3 general collision + PGS on kPgsNefcMax rows (a PGS model with condim 4 / 6 pairs)
   int variant, ncon_max, nefc_max;
   int mpr_iterations;
   float mpr_tolerance;
@@ -129,6 +132,7 @@ struct DevModel {
   // LDS layout (float offsets per env) — persistent region
   int o_gquat;  // general collision only: world orientation of every geom (4 floats each)
   int o_meta;   // general variants: per-row (R, K imp (pos - margin), B, -) written by makeConstraint
+  int o_AR;     // variant 3 (PGS on kPgsNefcMax rows): the matrix AR, [kPgsNefcMax][kPgsNefcMax]
   int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qLD, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
   // region A (dynamics scratch)
   int o_xpos, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cvel;

@@ -970,7 +970,7 @@ __device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, 
 // flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
 template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0>
 __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps, int env_fixed = -1, int ring = -1) {
-  static_assert(NG == 1 || SOLVER == 2, "more than one row group: Newton only");
+  static_assert(NG == 1 || SOLVER == 2 || (COLL == 1 && NG == kPgsGroups && DEFER == 0), "PGS on more than one row group: the general variant's kPgsGroups instantiation");
   static_assert(SMALL == 0 || (SOLVER == 0 && NDENSE <= 28 && COLL == 0 && NG == 1 && DEFER == 0), "the small instantiation: classic PGS kernel of dense order <= 28");
   constexpr int kNR = SMALL ? kSmallNefcMax : (NG == 1 ? kNefcMax : 64 * NG);  // row capacity of this instantiation
   constexpr int kNC = SMALL ? kSmallNconMax : (NG == 1 ? kNconMax : kBigNconMax);  // contact capacity
@@ -1076,6 +1076,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   float* s_force = lds + M.o_force;
   const float* s_gquat = lds + M.o_gquat;  // general collision only: world orientation of every geom
   float* s_meta = lds + M.o_meta;          // general variants: per-row (R, K imp (pos - margin), B, -)
+  float* s_AR = lds + M.o_AR;              // PGS on several row groups only: the matrix AR, [kNR][kNR]
+  (void)s_AR;
   (void)s_gquat; (void)s_meta;
   constexpr int kCs = 33;            // row stride of C (odd: conflict-free lane-strided access; column 32 is zero padding)
   static_assert(kNefcMax == kGroup - 1, "C holds kNefcMax constraint rows plus the qfrc_smooth row");
@@ -2041,6 +2043,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       if (!SMALL || (lw & 31) < NDENSE) store_w_rows(s_W, kWs, T, S, lw);  // (the small layout has no room for the padding rows, and nothing reads them)
       gsync();
     }
+    if constexpr (NG == 1) {
     {
       const int col = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -2234,6 +2237,152 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 #pragma unroll 8
       for (int j = 0; j < 32; j++) acc = __builtin_fmaf(s_qLD[M.mdense[j * 32 + lane]].x, j < nv ? s_v0[j] : 0.f, acc);
       P.qfrc_out[(size_t)env * nv + lane] = acc;
+    }
+    } else {
+      // ================================================================ PGS on NG row groups (kPgsNefcMax rows): a condim 4 / 6 model solved
+      // by PGS (ten rows per contact) does not fit the 63 rows whose AR one lane-column each keeps in registers.  Same algorithm, same
+      // row order, same arithmetic per row - with AR in LDS ([kNR][kNR], 64 KB: one env per CU) and lane l owning rows l, l + 64.  This is
+      // the fallback the one-group kernel defers to (staged step) and slow: Newton is the solver for such models (the reference's default).
+      {  // C = J W for every 32-row tile up to the qfrc_smooth row
+        const int col = lane & 31, half = lane >> 5;
+        for (int I = 0; 32 * I <= nefc; I++) {
+          const int arow = 32 * I + col;
+          const float* Ap = s_C + arow * cs + half;
+          const bool av = arow <= nefc;
+          constexpr int kKP = NDENSE / 2;
+          float a[kKP];
+#pragma unroll
+          for (int kk = 0; kk < kKP; kk++) a[kk] = av ? Ap[2 * kk] : 0.f;
+          f32x16 D;
+#pragma unroll
+          for (int r = 0; r < 16; r++) D[r] = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < kKP; kk++) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], s_W[(2 * kk + half) * kWs + col], D, 0, 0, 0);
+          gsync();  // (every lane's A operands of this tile are in registers before the tile's rows are overwritten)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = 32 * I + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row <= nefc) s_C[row * cs + col] = D[r];
+          }
+        }
+      }
+      gsync();
+      HB_STAMP(11);
+      const float* yv = s_C + nefc * cs;
+      float bg[NG], nAinvg[NG], forceg[NG], resg[NG];
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        const float* Cr = s_C + (lane + 64 * g) * cs;
+        float jas = 0.f, diag = 0.f;
+        for (int k = 0; k < kCs; k++) {
+          const float c = actg[g] ? Cr[k] : 0.f;
+          jas += c * yv[k];
+          diag += c * c;
+        }
+        bg[g] = jas - arefg[g];
+        nAinvg[g] = -1.f / (actg[g] ? diag + Rg[g] : 1.f);
+        if (lane + 64 * g < kNR) s_force[lane + 64 * g] = Rg[g];  // (R of every row, for the diagonal of AR below; the forces later)
+      }
+      gsync();
+      {  // AR = C C' + diag(R), tile by tile on the matrix cores, into LDS
+        const int col = lane & 31, half = lane >> 5;
+        const int nt = (nefc + 31) >> 5;
+        for (int I = 0; I < nt; I++)
+          for (int J = 0; J < nt; J++) {
+            const int ra = 32 * I + col, rb = 32 * J + col;
+            const float* Ap = s_C + ra * cs + half;
+            const float* Bp = s_C + rb * cs + half;
+            const bool va = ra < nefc, vb = rb < nefc;
+            f32x16 X;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+              X[r] = (I == J && row == col && vb) ? s_force[rb] : 0.f;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) X = __builtin_amdgcn_mfma_f32_32x32x2f32(va ? Ap[2 * kk] : 0.f, vb ? Bp[2 * kk] : 0.f, X, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) s_AR[(32 * I + (r & 3) + 8 * (r >> 2) + 4 * half) * kNR + rb] = X[r];
+          }
+      }
+      gsync();
+      HB_STAMP(12);
+      if (nefc > 0) {
+        float arfg[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) { forceg[g] = 0.f; arfg[g] = 0.f; }
+        if (!(M.disableflags & (1 << 8))) {
+#pragma unroll
+          for (int g = 0; g < NG; g++) {
+            const float jar = jwg[g] - arefg[g];
+            forceg[g] = (actg[g] && jar < 0.f) ? -Ddg[g] * jar : 0.f;
+          }
+          for (int i = 0; i < nefc; i++) {
+            const float fi = (i >> 6) == 0 ? rdlane(forceg[0], i & 63) : rdlane(forceg[NG - 1], i & 63);
+#pragma unroll
+            for (int g = 0; g < NG; g++) arfg[g] += (actg[g] ? s_AR[i * kNR + lane + 64 * g] : 0.f) * fi;  // (columns beyond the last tile were never written)
+          }
+          float cl = 0.f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) cl += actg[g] ? forceg[g] * (0.5f * arfg[g] + bg[g]) : 0.f;
+          if (wave_sum(cl) > 0.f) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) { forceg[g] = 0.f; arfg[g] = 0.f; }
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; g++) resg[g] = actg[g] ? bg[g] + arfg[g] : 0.f;
+        const int max_sweeps = M.iterations;
+        const float pgs_tol = M.tolerance, pgs_scale = M.pgs_scale;
+        while (niter < max_sweeps) {
+          float res0[NG], dlt[NG], nf[NG];
+#pragma unroll
+          for (int g = 0; g < NG; g++) { res0[g] = resg[g]; dlt[g] = 0.f; nf[g] = -forceg[g]; }
+          for (int i = 0; i < nefc; i++) {
+            const int gi = i >> 6, li = i & 63;
+            // the step of row i from its current residual: max(-res / AR_ii, -force); its lane proposes, everybody follows
+            const float dprop = gi == 0 ? fmaxf(resg[0] * nAinvg[0], nf[0]) : fmaxf(resg[NG - 1] * nAinvg[NG - 1], nf[NG - 1]);
+            const float di = rdlane(dprop, li);
+#pragma unroll
+            for (int g = 0; g < NG; g++) resg[g] = __builtin_fmaf(actg[g] ? s_AR[i * kNR + lane + 64 * g] : 0.f, di, resg[g]);
+            if (lane == li) { if (gi == 0) dlt[0] = di; else dlt[NG - 1] = di; }
+          }
+          float imp = 0.f;
+#pragma unroll
+          for (int g = 0; g < NG; g++) { forceg[g] += dlt[g]; imp += dlt[g] * (res0[g] + resg[g]); }
+          const float improvement = -0.5f * wave_sum(imp);
+          niter++;
+          if (improvement * pgs_scale < pgs_tol) break;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < NG; g++) forceg[g] = 0.f;
+      }
+      gsync();
+#pragma unroll
+      for (int g = 0; g < NG; g++) if (lane + 64 * g < kNR) s_force[lane + 64 * g] = actg[g] ? forceg[g] : 0.f;
+      force = forceg[0];
+      if (P.diag_force) {
+#pragma unroll
+        for (int g = 1; g < NG; g++) P.diag_force[(size_t)env * kNR + lane + 64 * g] = actg[g] ? forceg[g] : 0.f;
+      }
+      gsync();
+      HB_STAMP(13);
+      // dual finish: s = sum_i f_i C_i ; qacc = W (y + s)
+      for (int k = lane; k < nv; k += kGroup) {
+        float sacc = 0.f;
+        for (int i = 0; i < nefc; i++) sacc += s_force[i] * s_C[i * cs + k];
+        s_v2[k] = yv[k] + sacc;
+      }
+      gsync();
+      if (lane < nv) s_v0[lane] = dot32(s_W + lane * kWs, s_v2);
+      gsync();
+      if (P.qfrc_out && lane < nv) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 32; j++) acc = __builtin_fmaf(s_qLD[M.mdense[j * 32 + lane]].x, j < nv ? s_v0[j] : 0.f, acc);
+        P.qfrc_out[(size_t)env * nv + lane] = acc;
+      }
     }
     } else {
       // ---------------------------------------------------------------- mj_fwdConstraint, Newton solver (mj_solNewton)
@@ -2712,6 +2861,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step32_kernel(const DevModel* Mp
 // General instantiations (mesh hulls, height-field prisms, condim 4 / 6): PGS on 63 rows (configs[4]: the 27-dof humanoid on terrain),
 // Newton on 256 rows (the reference's own robot, simulation/assets/world.xml: 18 dofs -> dense order 20; up to 28 dofs)
 __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1>(Mp, P, nsteps); }
+// PGS on kPgsNefcMax rows (AR in LDS: one env per CU) for condim 4 / 6 models, and the one-group fast pass that defers to it (variant 3)
+__global__ __launch_bounds__(kGroup, 1) void hb_step_gen_big_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, kPgsGroups>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast1_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2>(Mp, P, nsteps); }  // staged step, fast pass
 __global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big20_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, kBigGroups>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 1, kBigGroups>(Mp, P, nsteps); }
@@ -3769,6 +3921,7 @@ static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int sol
   if (variant == 2 && nv <= 20) hipLaunchKernelGGL(hb_step_newton_big20_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (variant == 2) hipLaunchKernelGGL(hb_step_newton_big28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (variant == 1) hipLaunchKernelGGL(hb_step_gen_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (variant == 3) hipLaunchKernelGGL(hb_step_gen_big_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (solver == 2 && nv <= 28) hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (solver == 2) hipLaunchKernelGGL(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (nv <= 28) hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
@@ -3797,6 +3950,12 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
     if (variant == 1 && Q.stage.defer) {
       // the step kernel without the portal-search code; the full one then takes the (rare) env-steps whose qacc came out bad
       hipLaunchKernelGGL(hb_step_gen_fast_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      Q.stage.rerun = 1;
+    } else if (variant == 3 && Q.stage.dm_fast) {
+      // PGS: the one-group kernel (63 rows, 24 contacts, two waves per SIMD) first; the kPgsNefcMax-row kernel then steps what it defers
+      hipLaunchKernelGGL(hb_step_gen_fast1_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       Q.stage.rerun = 1;
@@ -3935,6 +4094,10 @@ hipError_t set_step_lds_limit(int bytes) {
   e = hipFuncSetAttribute((const void*)hb_step_newton28_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)hb_step_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step_gen_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)hb_step_gen_fast1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)hb_step_gen_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;

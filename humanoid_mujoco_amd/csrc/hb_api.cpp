@@ -640,7 +640,7 @@ struct hb_batch {
   // segment c of step t: the tail of one step (its slowest envs) overlaps the head of the next.  `stream`
   // stays the batch's ordering point: pipes fork from it at every step call and are joined back into it
   // before anything else is enqueued on it.
-  static constexpr int kPipes = 4;  // streams created; npipe of them in use
+  static constexpr int kPipes = 8;  // most segments; npipe of them in use (streams are created when first asked for)
   int npipe = 0;                    // 0: unpipelined
   bool forked = false;
   hipStream_t pipe[kPipes] = {};
@@ -781,7 +781,7 @@ void steps_enqueued(hb_batch* b, int nseg, bool reorder, bool refreshed = false)
 // Two-lane stepping applies to single-step launches of a classic PGS model of dense order <= 28 that write nothing before the
 // overflow tests of the small kernel (no rollout noise, no sensor read-out, no diagnostics, no masked stepping).
 bool two_lane_ok(const hb_batch* b, const BatchPtrs& P, int nsteps) {
-  return b->d_lane && nsteps == 1 && P.integrate && !b->diag && !P.sensor_out && !(P.xfrc_scale > 0.f) && !P.env_mask && !P.stamps;
+  return b->d_lane && b->npipe <= 4 && nsteps == 1 && P.integrate && !b->diag && !P.sensor_out && !(P.xfrc_scale > 0.f) && !P.env_mask && !P.stamps;
 }
 constexpr int kSlowBlocks = 128;  // workgroups per segment of the slow lane's launch (they walk the list: a handful of envs per step in the benchmark's regime)
 // phase of segment c inside its window at the current call (windows are staggered across the segments), and the window's index
@@ -1153,7 +1153,7 @@ void hb_batch_free(hb_batch* b) {
       fprintf(stderr, "[hb] two-lane: %lld step calls since the last re-join, %d env-steps made by the slow lane\n", b->lane_calls, r.slow_steps);
   }
   for (int c = 0; c < hb_batch::kPipes; c++) {
-    if (b->pipe[c]) { HB_IGN(hipStreamSynchronize(b->pipe[c])); HB_IGN(hipStreamDestroy(b->pipe[c])); }
+    if (b->pipe[c] && b->pipe[c] != b->stream) { HB_IGN(hipStreamSynchronize(b->pipe[c])); HB_IGN(hipStreamDestroy(b->pipe[c])); }
     if (b->ev_fast[c]) HB_IGN(hipEventDestroy(b->ev_fast[c]));
     for (int i = 0; i < 2; i++) if (b->ev_win[c][i]) HB_IGN(hipEventDestroy(b->ev_win[c][i]));
     if (b->ev_pipe[c]) HB_IGN(hipEventDestroy(b->ev_pipe[c]));
@@ -1189,20 +1189,72 @@ int hb_batch_sync(hb_batch* b) {
   if (b->join_error) { b->join_error = 0; return HB_ENODEVICE; }
   return HB_OK;
 }
+// the streams of the first n segments, created on first use.  Segment 0 runs on the batch's own stream: one stream fewer for the
+// process' hardware queues (below), and nothing else is enqueued there while steps are in flight
+static int make_pipes(hb_batch* b, int n) {
+  for (int c = 0; c < n; c++) {
+    if (!b->pipe[c] && c == 0) b->pipe[0] = b->stream;
+    if (!b->pipe[c]) {
+      // HB_PIPE_PRIO=1 (experiment, slower: 95 us per step for three segments): streams of different priorities.  ROCm keeps one pool
+      // of hardware queues per priority level
+      static const int prio_mode = getenv("HB_PIPE_PRIO") ? atoi(getenv("HB_PIPE_PRIO")) : 0;
+      int least = 0, greatest = 0;
+      hipDeviceGetStreamPriorityRange(&least, &greatest);
+      const int levels[hb_batch::kPipes] = {greatest, 0, least, 0, greatest, 0, least, 0};
+      const hipError_t e = prio_mode ? hipStreamCreateWithPriority(&b->pipe[c], hipStreamNonBlocking, levels[c])
+                                     : hipStreamCreateWithFlags(&b->pipe[c], hipStreamNonBlocking);
+      if (e != hipSuccess) return HB_ENOMEM;
+    }
+    if (!b->ev_pipe[c] && hipEventCreateWithFlags(&b->ev_pipe[c], hipEventDisableTiming) != hipSuccess) return HB_ENOMEM;
+  }
+  return HB_OK;
+}
+// Do kernels on the first n segment streams run at the same time?  ROCm maps a process' streams onto GPU_MAX_HW_QUEUES (default 4)
+// hardware queues, the null stream included, and two streams on one queue run their kernels one after the other: three segments
+// of which two share a queue step 4096 envs in 147 us instead of 88.  Nothing in HIP tells which queue a stream got, so this looks:
+// one idling wave per stream (60 us each), all n overlapping pairwise in the GPU's own clock or not.
+// returns -1 when all n run side by side, else the higher stream index of the first pair that does not (-2: the probe itself failed)
+static int pipes_conflict(hb_batch* b, int n) {
+  unsigned long long* d = nullptr;
+  unsigned long long h[2 * hb_batch::kPipes] = {};
+  if (hipStreamSynchronize(b->stream) != hipSuccess || hipMalloc((void**)&d, sizeof h) != hipSuccess) return -2;
+  bool ok = hipMemset(d, 0, sizeof h) == hipSuccess;
+  for (int c = 0; c < n && ok; c++) ok = launch_probe_spin(d + 2 * c, 6000, b->pipe[c]) == hipSuccess;
+  for (int c = 0; c < n; c++) ok = hipStreamSynchronize(b->pipe[c]) == hipSuccess && ok;
+  ok = ok && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+  HB_IGN(hipFree(d));
+  if (!ok) return -2;
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++)
+      if (!(h[2 * i] < h[2 * j + 1] && h[2 * j] < h[2 * i + 1] && h[2 * i + 1] > h[2 * i] && h[2 * j + 1] > h[2 * j])) return j;
+  return -1;
+}
 int hb_batch_pipeline(hb_batch* b, int on) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   join_pipes(b);
   if (on < 0 || on > hb_batch::kPipes) return HB_EINVAL;
-  // 1: default segment count.  Two segments of 2048 envs each fill the chip on their own (2048 resident waves) and measured best on
-  // MI355X.  Three would cover the ~6 us between two launches on one stream, and with GPU_MAX_HW_QUEUES=8 (a hardware queue per
-  // stream; the ROCm default of 4 makes streams share queues and serialise) a single batch in a process did run 91.4 instead of
-  // 94.1 us per step - but the same setting dropped a second batch of the same process from 4.0e7 to 2.3e7 env-steps/s and the gain
-  // did not repeat from box to box (tools/gpu_pipeline_sweep.py, gpurun_out/b20.json): not a default, and no environment is set here.
-  const int want = on == 1 ? 2 : on;
-  for (int c = 0; c < want; c++) {
-    if (!b->pipe[c] && hipStreamCreateWithFlags(&b->pipe[c], hipStreamNonBlocking) != hipSuccess) return HB_ENOMEM;
-    if (!b->ev_pipe[c] && hipEventCreateWithFlags(&b->ev_pipe[c], hipEventDisableTiming) != hipSuccess) return HB_ENOMEM;
+  // 1: default segment count.  Measured on MI355X, 4096 envs, us per step (tools/gpu_pipeline_queues.py, every case a fresh process):
+  // 2 segments 92, 3 segments 88, 4 segments 87 with GPU_MAX_HW_QUEUES >= 5 and 142 without, 5 and more 107 - 170 however many queues
+  // the runtime is given (a fifth active queue is multiplexed).  Three it is, when the three streams are seen to run side by side
+  // (other streams of the process can take the queues: pipes_conflict); two otherwise.  No environment is set here.
+  int want = on == 1 ? 3 : on;
+  int rc = make_pipes(b, want);
+  if (rc != HB_OK) return rc;
+  if (on == 1) {
+    // a stream that shares its queue is replaced by a fresh one (the runtime deals queues out in turn: the next stream lands on another
+    // one) while the old one still holds its place; a few tries, then two segments
+    hipStream_t spare[4] = {};
+    int bad = pipes_conflict(b, want);
+    for (int t = 0; t < 4 && bad > 0; t++) {
+      hipStream_t s = nullptr;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+      spare[t] = b->pipe[bad];
+      b->pipe[bad] = s;
+      bad = pipes_conflict(b, want);
+    }
+    for (hipStream_t s : spare) if (s) HB_IGN(hipStreamDestroy(s));
+    if (bad != -1) want = 2;
   }
   b->npipe = want;
   b->order_mode = 0;            // segment boundaries changed: per-segment permutations are stale

@@ -3864,6 +3864,17 @@ __attribute__((amdgpu_num_vgpr(32))) __global__ __launch_bounds__(256) void hb_p
 // last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
 // the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
 // which cannot change results (envs are independent).
+// Probe for hb_batch_pipeline: one wave that idles for `ticks` of the 100 MHz wall clock (bounded by the sleep count as well) and
+// records when it began and ended.  Two of these on two streams overlap in time exactly when the streams own different hardware queues.
+__global__ __launch_bounds__(64) void hb_probe_spin_kernel(unsigned long long* out, unsigned ticks) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long t = t0;
+  for (int guard = 0; guard < 2048 && t - t0 < ticks; guard++) {
+    __builtin_amdgcn_s_sleep(64);
+    t = wall_clock64();
+  }
+  if (threadIdx.x == 0) { out[0] = t0; out[1] = t; }
+}
 __global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int* keys, int e0, int n, int slot, int shift) {
   // sorts envs e0 .. e0+n-1 into order[e0 .. e0+n-1], most expensive first; cost = counts[env][slot] >> shift, 256 bins
   __shared__ int hist[256];
@@ -4036,6 +4047,10 @@ hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr,
                               hipStream_t stream) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(hb_domain_rand_kernel, dim3((n_env + 256 / kDrawLanes - 1) / (256 / kDrawLanes)), dim3(256), 0, stream, M, D, dr, stride, episode, mask, n_env, env_offset);
+  return hipGetLastError();
+}
+hipError_t launch_probe_spin(unsigned long long* out, unsigned ticks, hipStream_t stream) {
+  hipLaunchKernelGGL(hb_probe_spin_kernel, dim3(1), dim3(64), 0, stream, out, ticks);
   return hipGetLastError();
 }
 hipError_t launch_order(const int* counts, int* order, int n_env, int e0, int n, hipStream_t stream, int slot, int shift) {

@@ -33,5 +33,6 @@ hipError_t launch_stand_cost(const float* rows, int H, int n_env, const StandTas
 hipError_t launch_walk_cost(const float* rows, int H, int n_env, const WalkTask& K, const int* status, float* total, float* costs, hipStream_t stream);
 hipError_t launch_cost_terms(const float* residual, int n, int nres, const CostSpec& K, float* terms, float* cost, hipStream_t stream);
 hipError_t launch_spline_tape(const DevModel& M, const float* knots, const float* times, int P, int interp, float time0, float dt, int T, int n_env, float* tape, hipStream_t stream);
+hipError_t launch_probe_spin(unsigned long long* out, unsigned ticks, hipStream_t stream);
 hipError_t set_step_lds_limit(int bytes);
 }  // namespace hb

@@ -326,9 +326,9 @@ class Batch:
         _check(lib().hb_batch_sync(self._h), "hb_batch_sync")
 
     def pipeline(self, on=True):
-        """Pipelined stepping (hb_batch_pipeline): env segments (two by default) on their own streams, so the slow tail of
+        """Pipelined stepping (hb_batch_pipeline): env segments (three by default, two when the process' streams cannot have a hardware queue each) on their own streams, so the slow tail of
         one step overlaps the next step.  Results are identical; see include/hb.h for the stream contract."""
-        _check(lib().hb_batch_pipeline(self._h, int(on)), "hb_batch_pipeline")  # True: 2 segments; 2..4: that many
+        _check(lib().hb_batch_pipeline(self._h, int(on)), "hb_batch_pipeline")  # True: the default; 2..8: that many
 
     @property
     def segments(self):

@@ -109,7 +109,10 @@ int hb_batch_n_env(const hb_batch* b);
  * ordered after the steps enqueued before it.  The call itself performs hb_batch_join. */
 void* hb_batch_stream(hb_batch* b);
 int hb_batch_sync(hb_batch* b);
-/* Pipelined stepping (off by default; on = 1: two segments, on = 2..4: that many).  When on, hb_step_dev /
+/* Pipelined stepping (off by default; on = 1: the default count, on = 2..8: that many segments).  The default is three segments -
+ * the first on the batch's own stream - when their streams are seen to run kernels side by side, two when the process' other streams
+ * leave them no hardware queue each (ROCm shares GPU_MAX_HW_QUEUES = 4 queues among all streams of a process; the call probes
+ * with three idle waves of 60 us, once).  More than four concurrently active queues are slower whatever the setting.  When on, hb_step_dev /
  * hb_rollout*_dev cut the batch into fixed env segments and step each with its own launch on an internal stream: segment c of step t+1
  * follows only segment c of step t, so the slowest envs of one step overlap the start of the next
  * (envs are independent: results are identical to the unpipelined launch).  The internal streams fork

@@ -246,6 +246,33 @@ def test_pipelined_stepping_is_bit_identical(hbmod, humanoid_model, gpu):
         assert np.array_equal(a, c)
 
 
+def test_default_pipeline_picks_its_segment_count_by_probe(hbmod, humanoid_model, gpu):
+    """hb_batch_pipeline(1): three segments when their streams run kernels side by side, two otherwise - also with other batches
+    (and their streams) alive in the process - and up to eight on request; the states stay those of the single launch."""
+    n, T = 1000, 12
+    ref = hbmod.Batch(humanoid_model, n, gpu)
+    ref.reset(perturb=True)
+    for t in range(T):
+        ref.rollout_halton(1, t0=t)
+    want = ref.get_state(hbmod.STATE_INTEGRATION)
+    others = [hbmod.Batch(humanoid_model, 64, gpu) for _ in range(3)]
+    for o in others:
+        o.pipeline(2)
+        o.reset(perturb=True)
+        o.rollout_halton(1)
+    for on in (True, 8, True):
+        b = hbmod.Batch(humanoid_model, n, gpu)
+        b.pipeline(on)
+        assert b.segments in ((2, 3) if on is True else (8,))
+        b.reset(perturb=True)
+        for t in range(T):
+            b.rollout_halton(1, t0=t)
+        assert np.array_equal(b.get_state(hbmod.STATE_INTEGRATION), want)
+        b.close()
+    for o in others:
+        o.close()
+
+
 def test_state_io_reset_and_keyframes(hbmod, humanoid_model, gpu):
     m = humanoid_model
     n = 16

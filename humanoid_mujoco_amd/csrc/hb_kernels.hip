@@ -3860,10 +3860,6 @@ __attribute__((amdgpu_num_vgpr(32))) __global__ __launch_bounds__(256) void hb_p
   }
 }
 
-// Heavy-first dispatch order for the next launch: counting sort of the envs by the cost proxy of their
-// last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
-// the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
-// which cannot change results (envs are independent).
 // Probe for hb_batch_pipeline: one wave that idles for `ticks` of the 100 MHz wall clock (bounded by the sleep count as well) and
 // records when it began and ended.  Two of these on two streams overlap in time exactly when the streams own different hardware queues.
 __global__ __launch_bounds__(64) void hb_probe_spin_kernel(unsigned long long* out, unsigned ticks) {
@@ -3875,6 +3871,10 @@ __global__ __launch_bounds__(64) void hb_probe_spin_kernel(unsigned long long* o
   }
   if (threadIdx.x == 0) { out[0] = t0; out[1] = t; }
 }
+// Heavy-first dispatch order for the next launch: counting sort of the envs by the cost proxy of their
+// last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
+// the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
+// which cannot change results (envs are independent).
 __global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int* keys, int e0, int n, int slot, int shift) {
   // sorts envs e0 .. e0+n-1 into order[e0 .. e0+n-1], most expensive first; cost = counts[env][slot] >> shift, 256 bins
   __shared__ int hist[256];

@@ -33,6 +33,12 @@ cases = [("default", {}, (1, 2, 3, 4)), ("HB_PIPE_PRIO=1", {"HB_PIPE_PRIO": "1"}
          ("GPU_MAX_HW_QUEUES=16 HB_PIPE_MAIN=1", {"GPU_MAX_HW_QUEUES": "16", "HB_PIPE_MAIN": "1"}, (4, 5, 6, 8)),
          ("GPU_MAX_HW_QUEUES=5 HB_PIPE_MAIN=1", {"GPU_MAX_HW_QUEUES": "5", "HB_PIPE_MAIN": "1"}, (3, 4, 5)),
          ("GPU_MAX_HW_QUEUES=8 HB_PIPE_PRIO=1", {"GPU_MAX_HW_QUEUES": "8", "HB_PIPE_PRIO": "1"}, (3, 4, 6))]
+cases += [("HB_NO_SCHEDULE=1", {"HB_NO_SCHEDULE": "1"}, (1, 2)), ("HB_REORDER_PERIOD=1", {"HB_REORDER_PERIOD": "1"}, (1,)),
+          ("HB_REORDER_PERIOD=2", {"HB_REORDER_PERIOD": "2"}, (1,)), ("HB_REORDER_PERIOD=8", {"HB_REORDER_PERIOD": "8"}, (1,)),
+          ("HB_REORDER_PERIOD=32", {"HB_REORDER_PERIOD": "32"}, (1,))]
+cases += [("HB_TWO_LANE=1", {"HB_TWO_LANE": "1"}, (0, 2, 3)), ("HB_TWO_LANE=1 GPU_MAX_HW_QUEUES=8", {"HB_TWO_LANE": "1", "GPU_MAX_HW_QUEUES": "8"}, (0, 2, 3)),
+          ("HB_TWO_LANE=1 HB_LANE_WINDOW=16", {"HB_TWO_LANE": "1", "HB_LANE_WINDOW": "16"}, (0, 2, 3)),
+          ("HB_TWO_LANE=1 HB_SLOW_PRIO=0", {"HB_TWO_LANE": "1", "HB_SLOW_PRIO": "0"}, (0, 2, 3))]
 if len(sys.argv) > 1: cases = [c for c in cases if c[0] in sys.argv[1:]]
 for name, extra, pipes in cases:
     for npipe in pipes:

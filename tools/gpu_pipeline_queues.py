@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Step-API throughput against the number of pipeline segments, every case in a process of its own (the
 stream -> hardware-queue assignment depends on what the process created before), each case repeated.
-Cases: HB_PIPE_PRIO (segments on streams of different priorities) and GPU_MAX_HW_QUEUES."""
+Output: us per step of 4096 envs (segments in use); "segments 1" is hb_batch_pipeline's default (probe).
+Cases: GPU_MAX_HW_QUEUES, HB_PIPE_PRIO (segments on streams of different priorities), two-lane, scheduling knobs.
+(Rounds 1-2 ran the segments on extra streams BESIDE the batch's own: gpurun_out/r03q/queues.txt, queues2.txt.)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -28,10 +30,6 @@ print("%%.1f(%%d)" %% (1e6 * dt / K, b.segments))
 cases = [("default", {}, (1, 2, 3, 4)), ("HB_PIPE_PRIO=1", {"HB_PIPE_PRIO": "1"}, (2, 3, 4)),
          ("GPU_MAX_HW_QUEUES=8", {"GPU_MAX_HW_QUEUES": "8"}, (2, 3, 4, 5, 6, 8)),
          ("GPU_MAX_HW_QUEUES=16", {"GPU_MAX_HW_QUEUES": "16"}, (2, 3, 4, 5, 6, 8)),
-         ("HB_PIPE_MAIN=1", {"HB_PIPE_MAIN": "1"}, (2, 3, 4)),
-         ("GPU_MAX_HW_QUEUES=8 HB_PIPE_MAIN=1", {"GPU_MAX_HW_QUEUES": "8", "HB_PIPE_MAIN": "1"}, (3, 4, 5, 6, 7, 8)),
-         ("GPU_MAX_HW_QUEUES=16 HB_PIPE_MAIN=1", {"GPU_MAX_HW_QUEUES": "16", "HB_PIPE_MAIN": "1"}, (4, 5, 6, 8)),
-         ("GPU_MAX_HW_QUEUES=5 HB_PIPE_MAIN=1", {"GPU_MAX_HW_QUEUES": "5", "HB_PIPE_MAIN": "1"}, (3, 4, 5)),
          ("GPU_MAX_HW_QUEUES=8 HB_PIPE_PRIO=1", {"GPU_MAX_HW_QUEUES": "8", "HB_PIPE_PRIO": "1"}, (3, 4, 6))]
 cases += [("HB_NO_SCHEDULE=1", {"HB_NO_SCHEDULE": "1"}, (1, 2)), ("HB_REORDER_PERIOD=1", {"HB_REORDER_PERIOD": "1"}, (1,)),
           ("HB_REORDER_PERIOD=2", {"HB_REORDER_PERIOD": "2"}, (1,)), ("HB_REORDER_PERIOD=8", {"HB_REORDER_PERIOD": "8"}, (1,)),

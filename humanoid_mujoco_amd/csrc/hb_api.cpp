@@ -705,6 +705,9 @@ BatchPtrs make_ptrs(hb_batch* b) {
   P.blk0 = 0; P.nblk = b->n_env;
   P.dr = b->d_dr; P.dr_stride = b->dr_stride;
   P.stamps = b->d_stamps;
+#ifdef HB_STAMPS
+  if (const char* sp = getenv("HB_STOP_PHASE")) P.stop_phase = atoi(sp);
+#endif
   P.stage = b->stage;
   if (b->diag) P.stage.dm_fast = nullptr;  // the diagnostic buffers are laid out for the kernel of the model's own variant
   if (b->xfrc_std > 0.f && b->d_xfrc) {

@@ -23,7 +23,9 @@ namespace hb {
 // Diagnostic build only (-DHB_STAMPS): per-phase cycle stamps of the last step, written to
 // BatchPtrs::diag_contact's tail is NOT used; stamps go to their own buffer P.stamps.
 #ifdef HB_STAMPS
-#define HB_STAMP(i) do { if (lane == 0 && P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps_[i] = t_; } } while (0)
+// (P.stop_phase = k > 0: the wave leaves at stamp k - 1 without writing anything - tools/gpu_phase_instructions.py counts a launch's instructions
+// up to every stamp with the PMC counters and differences them)
+#define HB_STAMP(i) do { if (lane == 0 && P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps_[i] = t_; } if (P.stop_phase == (i) + 1) return; } while (0)
 #else
 #define HB_STAMP(i) do {} while (0)
 #endif

@@ -117,6 +117,11 @@ if "valu_issue_frac_of_peak" in out and os.path.exists(os.path.join(dst, "traffi
                           "note": "SQ_INSTS_VALU x 64 x (active lanes / 64) / launch time; peak = 157.3 TFLOP/s / 2 flop per fma"}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "SQ_BUSY_CU_CYCLES" in counters:
         latest["mfma_busy_frac"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (4.0 * counters["SQ_BUSY_CU_CYCLES"]["mean"])
+    if "SQ_ACTIVE_INST_VALU" in counters and "SQ_BUSY_CU_CYCLES" in counters and "valu" in latest:
+        # SQ_ACTIVE_INST_VALU counts one per wave64 VALU instruction issued (4 clocks on the SIMD's 16 lanes); a busy CU has 4 SIMDs:
+        # 4 x ACTIVE / (4 x BUSY_CU cycles).  Whole unpipelined launch, its ragged tail included; 85 MFMAs per wave come on top (mfma_busy_frac)
+        latest["valu"]["pipe_busy_frac"] = counters["SQ_ACTIVE_INST_VALU"]["mean"] / counters["SQ_BUSY_CU_CYCLES"]["mean"]
+        latest["valu"]["instructions_per_wave"] = counters["SQ_INSTS_VALU"]["mean"] / counters["SQ_WAVES"]["mean"]
     json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 # second kernel trace (bench.py --no-pipeline with its Newton leg): every hb_* kernel's 4096-block launches
 tn = glob.glob(os.path.join(src, "prof_trace_newton", "*", "*_kernel_trace.csv"))

@@ -1177,7 +1177,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_dr) HB_IGN(hipFree(b->d_dr));
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
-  void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nsearch, b->stage.nwork, b->stage.result, b->stage.defer, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_reward, b->d_term, b->d_trunc, b->d_mask,
+  void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nsearch, b->stage.nwork, b->stage.result, b->stage.defer, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_mask,
                   b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_order2, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode, b->d_lane, b->d_lane_list, b->d_lane_count, b->d_lane_done, b->d_lane_win};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
@@ -1980,8 +1980,12 @@ static int env_alloc(hb_batch* b) {
   size_t n = b->n_env;
   HB_HIP(hipSetDevice(b->device));
   if (!b->d_obs) {
-    if (hipMalloc((void**)&b->d_obs, n * dm.nobs * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_reward, n * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&b->d_term, n) != hipSuccess || hipMalloc((void**)&b->d_trunc, n) != hipSuccess) return HB_ENOMEM;
+    // one record [obs n x nobs | reward n | terminated n | truncated n]: a host that keeps its four buffers in the same order and
+    // back to back (engine.py does) gets them in one transfer instead of four
+    if (hipMalloc((void**)&b->d_obs, n * dm.nobs * sizeof(float) + n * sizeof(float) + 2 * n) != hipSuccess) return HB_ENOMEM;
+    b->d_reward = b->d_obs + n * dm.nobs;
+    b->d_term = reinterpret_cast<uint8_t*>(b->d_reward + n);
+    b->d_trunc = b->d_term + n;
   }
   size_t nu = std::max(1, dm.nu);
   if (hipMalloc((void**)&b->d_prev, n * nu * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_latest, n * nu * sizeof(float)) != hipSuccess ||
@@ -2298,10 +2302,15 @@ int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, fl
   if (nu) HB_HIP(hipMemcpyAsync(b->d_action, action, (size_t)n * nu * sizeof(float), hipMemcpyHostToDevice, main_stream(b)));
   rc = hb_env_step_dev(b, b->d_action, n_substeps, b->d_obs, b->d_reward, b->d_term, b->d_trunc);
   if (rc != HB_OK) return rc;
-  HB_HIP(hipMemcpyAsync(obs, b->d_obs, (size_t)n * nobs * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
-  HB_HIP(hipMemcpyAsync(reward, b->d_reward, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
-  HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, main_stream(b)));
-  HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, main_stream(b)));
+  const size_t ob = (size_t)n * nobs * sizeof(float), rb = (size_t)n * sizeof(float);
+  if (reinterpret_cast<const uint8_t*>(reward) == reinterpret_cast<const uint8_t*>(obs) + ob && terminated == reinterpret_cast<const uint8_t*>(reward) + rb && truncated == terminated + n) {
+    HB_HIP(hipMemcpyAsync(obs, b->d_obs, ob + rb + 2 * (size_t)n, hipMemcpyDeviceToHost, main_stream(b)));  // the caller's buffers are one record too
+  } else {
+    HB_HIP(hipMemcpyAsync(obs, b->d_obs, ob, hipMemcpyDeviceToHost, main_stream(b)));
+    HB_HIP(hipMemcpyAsync(reward, b->d_reward, rb, hipMemcpyDeviceToHost, main_stream(b)));
+    HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, main_stream(b)));
+    HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, main_stream(b)));
+  }
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }

@@ -309,7 +309,8 @@ class Batch:
             lib().hb_batch_free(self._h)
             self._h = None
         for pb in (getattr(self, "_env_pin", None) or {}).values():
-            pb.free()
+            if isinstance(pb, _Pinned):
+                pb.free()
         self._env_pin = None
 
     def __del__(self):
@@ -664,19 +665,27 @@ class Batch:
         _check(lib().hb_env_reset(self._h, _ptr(o)), "hb_env_reset")
         return o
 
-    def env_step(self, action, n_substeps=1):
-        """action [n_env, nu] -> (obs, reward, terminated, truncated).  The transfer buffers are page-locked and reused:
-        the returned arrays are fresh copies, so the caller may keep them."""
+    def env_step(self, action, n_substeps=1, copy=True):
+        """action [n_env, nu] -> (obs, reward, terminated, truncated).  The transfer buffers are page-locked and reused; the four
+        outputs are one record in device and host memory, so they come back in one transfer.  copy=True (default): the returned
+        arrays are fresh copies, the caller may keep them; copy=False: views of the transfer buffer, valid until the next call."""
         pin = getattr(self, "_env_pin", None)
         if pin is None:
-            pin = self._env_pin = dict(a=_Pinned((self.n_env, self.model.nu), np.float32), o=_Pinned((self.n_env, self.model.nobs), np.float32),
-                                       r=_Pinned((self.n_env,), np.float32), te=_Pinned((self.n_env,), np.uint8), tr=_Pinned((self.n_env,), np.uint8))
+            n, nobs = self.n_env, self.model.nobs
+            ob, rb = n * nobs * 4, n * 4
+            out = _Pinned((ob + rb + 2 * n,), np.uint8)
+            pin = self._env_pin = dict(a=_Pinned((n, self.model.nu), np.float32), out=out,
+                                       o=out.array[:ob].view(np.float32).reshape(n, nobs), r=out.array[ob:ob + rb].view(np.float32),
+                                       te=out.array[ob + rb:ob + rb + n], tr=out.array[ob + rb + n:], off=(0, ob, ob + rb, ob + rb + n))
         a = np.asarray(action, dtype=np.float32)
         assert a.shape == (self.n_env, self.model.nu), a.shape
         pin["a"].array[...] = a
-        _check(lib().hb_env_step(self._h, ctypes.c_void_p(pin["a"].ptr), int(n_substeps), ctypes.c_void_p(pin["o"].ptr), ctypes.c_void_p(pin["r"].ptr),
-                                 ctypes.c_void_p(pin["te"].ptr), ctypes.c_void_p(pin["tr"].ptr)), "hb_env_step")
-        return pin["o"].array.copy(), pin["r"].array.copy(), pin["te"].array.astype(bool), pin["tr"].array.astype(bool)
+        base, off = pin["out"].ptr, pin["off"]
+        _check(lib().hb_env_step(self._h, ctypes.c_void_p(pin["a"].ptr), int(n_substeps), ctypes.c_void_p(base + off[0]), ctypes.c_void_p(base + off[1]),
+                                 ctypes.c_void_p(base + off[2]), ctypes.c_void_p(base + off[3])), "hb_env_step")
+        if not copy:
+            return pin["o"], pin["r"], pin["te"].view(bool), pin["tr"].view(bool)
+        return pin["o"].copy(), pin["r"].copy(), pin["te"].astype(bool), pin["tr"].astype(bool)
 
     def env_step_dev(self, action_ptr, obs_ptr, reward_ptr, terminated_ptr, truncated_ptr, n_substeps=1):
         """hb_env_step_dev: device pointers (e.g. torch tensors' data_ptr()), asynchronous on the batch's stream: a policy on

@@ -21,6 +21,7 @@ class VecEnv:
         self.batch = Batch(self.model, n_envs, device)
         self.num_envs = int(n_envs)
         self.n_substeps = int(n_substeps)
+        self.copy_outputs = True  # False: step() returns views of the page-locked transfer record, valid until the next step() (saves four host copies)
         self.cfg = self.batch.env_team_config() if team else self.batch.env_default_config()
         self.team = bool(team)
         self.cfg.reset_perturb = float(randomization_factor)
@@ -74,7 +75,7 @@ class VecEnv:
         return self.batch.env_reset()
 
     def step(self, actions):
-        obs, rew, term, trunc = self.batch.env_step(actions, self.n_substeps)
+        obs, rew, term, trunc = self.batch.env_step(actions, self.n_substeps, copy=getattr(self, "copy_outputs", True))
         done = term | trunc
         # "warnings": the per-env HB_WARN_* bits (mjData.warning, mjdata.h:54-65) accumulated since the env's last reset:
         # a contact or constraint-row overflow (rows were dropped for that env-step) or a bad-state reset is visible to

@@ -15,8 +15,10 @@ model = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27.hbm")
 N, T = 4096, 600
 rng = np.random.default_rng(0)
 acts = rng.uniform(-1, 1, size=(8, N, 21)).astype(np.float32)
-for label, kw in (("plain", {}), ("realism + domain randomisation", dict(realism=True, domain_randomization=True, seed=1))):
+for label, kw in (("plain", {}), ("plain, outputs as views of the transfer record", dict(_views=True)), ("realism + domain randomisation", dict(realism=True, domain_randomization=True, seed=1))):
+    views = kw.pop("_views", False)
     env = hb.VecEnv(model, N, 0, randomization_factor=1.0, target_z=10.0, max_time=2.0, **kw)  # success unreachable: episodes run 400 steps
+    env.copy_outputs = not views
     env.reset()
     for t in range(20):
         env.step(acts[t % 8])

@@ -114,7 +114,7 @@ class VecEnv:
         self.batch.env_step_dev(a.data_ptr(), o.data_ptr(), r.data_ptr(), te.data_ptr(), tr.data_ptr(), self.n_substeps)
         cur.wait_stream(self._t_stream)   # and the caller's stream sees the results
         a.record_stream(self._t_stream)
-        return o, r, te.bool(), tr.bool()
+        return o, r, te.view(torch.bool), tr.view(torch.bool)  # (the kernel writes 0 / 1 bytes: a view, not two conversion kernels)
 
     def close(self):
         self.batch.close()

@@ -456,7 +456,10 @@ int hb_env_get_domain_params(hb_batch* b, float* out);
 int hb_env_reset(hb_batch* b, float* obs);
 /* CPUEnv.step: action[n_env][nu] -> ctrl (unscaled; the physics clamps to ctrlrange), n_substeps x mj_step,
  * reward, termination, observation; finished envs are reset when auto_reset is set and then report the
- * observation of their new episode. Host pointers. */
+ * observation of their new episode. Host pointers.  The four outputs are one record on the device ([obs | reward | terminated |
+ * truncated]); a caller whose four buffers lie back to back in that order (reward == obs + n_env * nobs, terminated ==
+ * (uint8_t*)(reward + n_env), truncated == terminated + n_env; page-locked for a DMA transfer: hb_host_alloc) gets them in ONE
+ * device-to-host transfer, anyone else in four. */
 int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated);
 /* Same with device pointers, asynchronous on the batch's stream (policy on the same GPU). */
 int hb_env_step_dev(hb_batch* b, const float* action_dev, int n_substeps, float* obs_dev, float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev);

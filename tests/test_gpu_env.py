@@ -121,6 +121,35 @@ def test_device_resident_step_matches_host_step(hbmod, humanoid_model, gpu):
         assert np.array_equal(te1, te2.cpu().numpy()) and np.array_equal(tr1, tr2.cpu().numpy())
 
 
+def test_step_outputs_as_views_and_through_scattered_buffers(hbmod, humanoid_model, gpu):
+    """hb_env_step moves the four outputs as ONE record when the caller's buffers lie back to back (engine.py's page-locked record) and as
+    four transfers otherwise; VecEnv.copy_outputs = False hands out views of that record.  All three give the same numbers."""
+    import ctypes
+    m = humanoid_model
+    n = 96
+    envs = [hbmod.VecEnv(m, n, gpu, seed=5, max_time=0.2) for _ in range(3)]  # short episodes: resets and flags inside the 60 steps
+    envs[1].copy_outputs = False
+    obs0 = [e.reset() for e in envs]
+    assert np.array_equal(obs0[0], obs0[1]) and np.array_equal(obs0[0], obs0[2])
+    L = hbmod.lib()
+    o3 = np.zeros((n, m.nobs), np.float32); r3 = np.zeros(n, np.float32); te3 = np.zeros(n, np.uint8); tr3 = np.zeros(n, np.uint8)  # four separate arrays
+    rng = np.random.default_rng(1)
+    flags = 0
+    for t in range(60):
+        act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
+        o1, r1, te1, tr1, _ = envs[0].step(act)
+        o2, r2, te2, tr2, _ = envs[1].step(act)
+        assert L.hb_env_step(envs[2].batch._h, act.ctypes.data_as(ctypes.c_void_p), 1, o3.ctypes.data_as(ctypes.c_void_p), r3.ctypes.data_as(ctypes.c_void_p),
+                             te3.ctypes.data_as(ctypes.c_void_p), tr3.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(te1, te2) and np.array_equal(tr1, tr2)
+        assert te2.dtype == bool and not o2.flags.owndata  # views
+        assert np.array_equal(o1, o3) and np.array_equal(r1, r3) and np.array_equal(te1, te3.astype(bool)) and np.array_equal(tr1, tr3.astype(bool))
+        flags += int(te1.sum() + tr1.sum())
+    assert flags > 0
+    for e in envs:
+        e.close()
+
+
 def test_vecenv_reports_warning_bits(hbmod, humanoid_model, gpu):
     """The step's info carries the per-env HB_WARN_* bits (mjData.warning): an overflow or a bad-state reset of an env is
     visible to the training loop.  A NaN planted in one env's state shows up as BADQPOS for that env only."""

@@ -25,7 +25,7 @@ b.sync(); t0 = time.perf_counter()
 for t in range(T):
     b.step_dev(ctrl + t * N * m.nu * 4)
 b.sync(); dt = time.perf_counter() - t0
-print("config 5 (step API, pipelined 2 segments): %.1f us/step -> %.3e env-steps/s" % (1e6 * dt / T, N * T / dt))
+print("config 5 (step API, pipelined %d segments): %.1f us/step -> %.3e env-steps/s" % (b.segments, 1e6 * dt / T, N * T / dt))
 b.pipeline(False)
 b.sync(); t0 = time.perf_counter(); b.rollout_dev(ctrl, T); b.sync(); dt = time.perf_counter() - t0
 print("config 5 (rollout) : %.1f us/step -> %.3e env-steps/s" % (1e6 * dt / T, N * T / dt))

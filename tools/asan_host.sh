@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/hb_asan
 mkdir -p $OUT
 g++ -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -o $OUT/hb_compile $ROOT/tools/hb_compile.cpp \
-    $ROOT/humanoid_mujoco_amd/csrc/mjcf.cpp $ROOT/humanoid_mujoco_amd/csrc/setconst.cpp $ROOT/humanoid_mujoco_amd/csrc/model_io.cpp 2>/dev/null
+    $ROOT/humanoid_mujoco_amd/csrc/mjcf.cpp $ROOT/humanoid_mujoco_amd/csrc/setconst.cpp $ROOT/humanoid_mujoco_amd/csrc/model_io.cpp $ROOT/humanoid_mujoco_amd/csrc/mesh.cpp
 fail=0
 for f in $ROOT/tests/models/*.xml $ROOT/humanoid_mujoco_amd/assets/*.hbm; do
   $OUT/hb_compile $f $OUT/a.hbm > $OUT/log.txt 2>&1 || { echo "FAIL $f"; cat $OUT/log.txt; fail=1; }
@@ -26,7 +26,7 @@ done
 # the fp64 oracle under the same sanitizers, driven by its own tests
 gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -shared -fPIC -o $OUT/liboracle_asan.so $ROOT/oracle/mjstep_oracle.c -lm -lpthread
 ( cd $ROOT && ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) HB_ORACLE_SO=$OUT/liboracle_asan.so \
-    python -m pytest tests/test_oracle_kat.py tests/test_oracle_newton.py -x -q > $OUT/oracle.txt 2>&1 ) || { echo "oracle under sanitizers: FAIL"; tail -20 $OUT/oracle.txt; fail=1; }
+    python -m pytest tests/test_oracle_kat.py tests/test_oracle_newton.py tests/test_oracle_convex.py tests/test_oracle_contact_order.py -x -q > $OUT/oracle.txt 2>&1 ) || { echo "oracle under sanitizers: FAIL"; tail -20 $OUT/oracle.txt; fail=1; }
 grep -q "AddressSanitizer\|runtime error" $OUT/oracle.txt && { echo "sanitizer report in the oracle run"; fail=1; }
 [ $fail = 0 ] && echo "asan/ubsan host pass: clean (model compiler, oracle)"
 exit $fail

@@ -1139,6 +1139,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
     }
   }
   if (hb_debug()) fprintf(stderr, "[hb] LDS per env: %d bytes (%d envs per CU)\n", dm.lds_floats * 4, 160 * 1024 / (dm.lds_floats * 4));
+  if (hb_debug() && b->D.fast_lds_floats) fprintf(stderr, "[hb] LDS per env of the staged step's fast kernel: %d bytes (%d envs per CU)\n", b->D.fast_lds_floats * 4, 160 * 1024 / (b->D.fast_lds_floats * 4));
   if (ok && dm.lds_floats * 4 > 64 * 1024) ok = set_step_lds_limit(dm.lds_floats * 4) == hipSuccess;
   if (!ok) { set_err(err, err_sz, "device allocation failed"); hb_batch_free(b); return nullptr; }
   if (hb_reset(b, nullptr, -1, 0, 0) != HB_OK) { set_err(err, err_sz, "initial reset failed"); hb_batch_free(b); return nullptr; }

@@ -2295,7 +2295,7 @@ int hb_env_step_dev(hb_batch* b, const float* action_dev, int n_substeps, float*
   return env_step_impl(b, action_dev, n_substeps, nullptr, true, obs_dev, reward_dev, terminated_dev, truncated_dev);
 }
 
-int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated) {
+static int env_step_host(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated, bool wait) {
   if (!b || !action || !obs || !reward || !terminated || !truncated) return HB_EINVAL;
   int rc = env_alloc(b);
   if (rc != HB_OK) return rc;
@@ -2312,8 +2312,14 @@ int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, fl
     HB_HIP(hipMemcpyAsync(terminated, b->d_term, n, hipMemcpyDeviceToHost, main_stream(b)));
     HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, main_stream(b)));
   }
-  HB_HIP(hipStreamSynchronize(main_stream(b)));
+  if (wait) HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
+}
+int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated) {
+  return env_step_host(b, action, n_substeps, obs, reward, terminated, truncated, true);
+}
+int hb_env_step_async(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated) {
+  return env_step_host(b, action, n_substeps, obs, reward, terminated, truncated, false);
 }
 
 int hb_policy_set_mlp(hb_batch* b, int n_layers, const int* sizes, const float* const* weights, const float* const* biases) {

@@ -179,6 +179,7 @@ def lib():
     L.hb_sensors.argtypes = [vp, vp, ctypes.POINTER(HbSensorSpec), vp]
     L.hb_env_reset.argtypes = [vp, vp]
     L.hb_env_step.argtypes = [vp, vp, ci, vp, vp, vp, vp]
+    L.hb_env_step_async.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.hb_env_step_dev.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.hb_policy_set_mlp.argtypes = [vp, ci, vp, vp, vp]
     L.hb_policy_eval.argtypes = [vp, vp]
@@ -665,10 +666,11 @@ class Batch:
         _check(lib().hb_env_reset(self._h, _ptr(o)), "hb_env_reset")
         return o
 
-    def env_step(self, action, n_substeps=1, copy=True):
+    def env_step(self, action, n_substeps=1, copy=True, wait=True):
         """action [n_env, nu] -> (obs, reward, terminated, truncated).  The transfer buffers are page-locked and reused; the four
         outputs are one record in device and host memory, so they come back in one transfer.  copy=True (default): the returned
-        arrays are fresh copies, the caller may keep them; copy=False: views of the transfer buffer, valid until the next call."""
+        arrays are fresh copies, the caller may keep them; copy=False: views of the transfer buffer, valid until the next call.
+        wait=False: enqueue only (hb_env_step_async) and return None; sync(), then env_step_result()."""
         pin = getattr(self, "_env_pin", None)
         if pin is None:
             n, nobs = self.n_env, self.model.nobs
@@ -681,8 +683,16 @@ class Batch:
         assert a.shape == (self.n_env, self.model.nu), a.shape
         pin["a"].array[...] = a
         base, off = pin["out"].ptr, pin["off"]
-        _check(lib().hb_env_step(self._h, ctypes.c_void_p(pin["a"].ptr), int(n_substeps), ctypes.c_void_p(base + off[0]), ctypes.c_void_p(base + off[1]),
-                                 ctypes.c_void_p(base + off[2]), ctypes.c_void_p(base + off[3])), "hb_env_step")
+        fn = lib().hb_env_step_async if wait is False else lib().hb_env_step
+        _check(fn(self._h, ctypes.c_void_p(pin["a"].ptr), int(n_substeps), ctypes.c_void_p(base + off[0]), ctypes.c_void_p(base + off[1]),
+                  ctypes.c_void_p(base + off[2]), ctypes.c_void_p(base + off[3])), "hb_env_step")
+        if wait is False:
+            return None
+        return self.env_step_result(copy)
+
+    def env_step_result(self, copy=True):
+        """the outputs of the last env_step (after env_step(..., wait=False): call sync() first)"""
+        pin = self._env_pin
         if not copy:
             return pin["o"], pin["r"], pin["te"].view(bool), pin["tr"].view(bool)
         return pin["o"].copy(), pin["r"].copy(), pin["te"].astype(bool), pin["tr"].astype(bool)

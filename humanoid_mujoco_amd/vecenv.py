@@ -74,8 +74,22 @@ class VecEnv:
     def reset(self):
         return self.batch.env_reset()
 
+    def step_async(self, actions):
+        """stable-baselines3's VecEnv.step_async: the step is enqueued (actions up, physics, observations down) and the host returns at once"""
+        self.batch.env_step(actions, self.n_substeps, wait=False)
+        self._pending = True
+
+    def step_wait(self):
+        """VecEnv.step_wait: the results of the step_async before it"""
+        assert getattr(self, "_pending", False), "step_wait without step_async"
+        self._pending = False
+        self.batch.sync()
+        return self._finish(*self.batch.env_step_result(getattr(self, "copy_outputs", True)))
+
     def step(self, actions):
-        obs, rew, term, trunc = self.batch.env_step(actions, self.n_substeps, copy=getattr(self, "copy_outputs", True))
+        return self._finish(*self.batch.env_step(actions, self.n_substeps, copy=getattr(self, "copy_outputs", True)))
+
+    def _finish(self, obs, rew, term, trunc):
         done = term | trunc
         # "warnings": the per-env HB_WARN_* bits (mjData.warning, mjdata.h:54-65) accumulated since the env's last reset:
         # a contact or constraint-row overflow (rows were dropped for that env-step) or a bad-state reset is visible to

@@ -461,6 +461,11 @@ int hb_env_reset(hb_batch* b, float* obs);
  * (uint8_t*)(reward + n_env), truncated == terminated + n_env; page-locked for a DMA transfer: hb_host_alloc) gets them in ONE
  * device-to-host transfer, anyone else in four. */
 int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated);
+/* The same, enqueued only: VecEnv.step_async of the reference's training loop (stable-baselines3 VecEnv: step_async() then
+ * step_wait(); rl/train.py:134-136 builds a DummyVecEnv whose step() is that pair).  The action buffer must stay untouched and the
+ * output buffers unread until hb_batch_sync(b) returns (= step_wait); page-locked buffers (hb_host_alloc) make the copies truly
+ * asynchronous.  The host is free in between - e.g. to run the learner's update. */
+int hb_env_step_async(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated);
 /* Same with device pointers, asynchronous on the batch's stream (policy on the same GPU). */
 int hb_env_step_dev(hb_batch* b, const float* action_dev, int n_substeps, float* obs_dev, float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev);
 

@@ -150,6 +150,28 @@ def test_step_outputs_as_views_and_through_scattered_buffers(hbmod, humanoid_mod
         e.close()
 
 
+def test_step_async_then_step_wait_equals_step(hbmod, humanoid_model, gpu):
+    """stable-baselines3's VecEnv pair: step_async enqueues (hb_env_step_async: no wait), the host does something else, step_wait
+    returns what step would have."""
+    m = humanoid_model
+    n = 80
+    a = hbmod.VecEnv(m, n, gpu, seed=9, max_time=0.25)
+    b = hbmod.VecEnv(m, n, gpu, seed=9, max_time=0.25)
+    assert np.array_equal(a.reset(), b.reset())
+    rng = np.random.default_rng(2)
+    for t in range(70):
+        act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
+        o1, r1, te1, tr1, i1 = a.step(act)
+        b.step_async(act)
+        _ = float(np.linalg.norm(rng.normal(size=(64, 64)) @ rng.normal(size=(64, 64))))  # the host is free in between
+        o2, r2, te2, tr2, i2 = b.step_wait()
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(te1, te2) and np.array_equal(tr1, tr2)
+        assert np.array_equal(i1["done"], i2["done"])
+    with pytest.raises(AssertionError):
+        b.step_wait()
+    a.close(); b.close()
+
+
 def test_vecenv_reports_warning_bits(hbmod, humanoid_model, gpu):
     """The step's info carries the per-env HB_WARN_* bits (mjData.warning): an overflow or a bad-state reset of an env is
     visible to the training loop.  A NaN planted in one env's state shows up as BADQPOS for that env only."""

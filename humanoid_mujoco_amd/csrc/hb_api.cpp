@@ -2429,6 +2429,7 @@ int hb_rollout_policy(hb_batch* b, int T, float* qpos_out_dev) {
   for (int t = 0; t < T; t++) {
     const bool reorder = b->schedule && (b->launch_count % reorder_period() == 0);
     BatchPtrs P = make_ptrs(b);
+    P.qfrc_out = nullptr;  // (the env adapter's read-out: nothing in this loop reads it, and without it the step launches are the lean kernels)
     P.ctrl = b->d_ctrl; P.ctrl_mode = 0;
     P.qpos_out = qpos_out_dev ? qpos_out_dev + (size_t)t * b->n_env * b->D.dm.nq : nullptr;
     for (int c = 0; c < nseg; c++) {

@@ -970,8 +970,25 @@ __device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, 
 // contacts is not stepped here but flagged for the four-group kernel.  2 (variant 1): same capacities as the full kernel, nothing to
 // overflow into.  Both: an env-step whose qacc comes out bad (mj_checkAcc: reset, second forward pass with a narrowphase of its own) is
 // flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
-template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0>
+template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0, int LEAN = 0>
 __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps, int env_fixed = -1, int ring = -1) {
+  // LEAN: a launch without the optional inputs and outputs (applied forces and their noise, constraint-force / sensor / trajectory
+  // read-outs, diagnostics, per-env model parameters, an env mask; mj_step, not mj_forward) - known at compile time, so their tests,
+  // pointers and code are not in the kernel at all
+  float* const P_xfrc = LEAN ? nullptr : P.xfrc;
+  const float P_xfrc_scale = LEAN ? 0.f : P.xfrc_scale, P_xfrc_rate = LEAN ? 0.f : P.xfrc_rate;
+  const auto P_xfrc_seed = P.xfrc_seed; const auto P_xfrc_call = P.xfrc_call;
+  float* const P_qfrc_out = LEAN ? nullptr : P.qfrc_out;
+  float* const P_sensor_out = LEAN ? nullptr : P.sensor_out;
+  float* const P_qpos_out = LEAN ? nullptr : P.qpos_out;
+  float* const P_qvel_out = LEAN ? nullptr : P.qvel_out;
+  float* const P_diag_qacc = LEAN ? nullptr : P.diag_qacc;
+  float* const P_diag_force = LEAN ? nullptr : P.diag_force;
+  float* const P_diag_contact = LEAN ? nullptr : P.diag_contact;
+  const float* const P_dr = LEAN ? nullptr : P.dr;
+  const int P_dr_stride = LEAN ? 0 : P.dr_stride;
+  const unsigned char* const P_env_mask = LEAN ? nullptr : P.env_mask;
+  const int P_integrate = LEAN ? 1 : P.integrate;
   static_assert(NG == 1 || SOLVER == 2 || (COLL == 1 && NG == kPgsGroups && DEFER == 0), "PGS on more than one row group: the general variant's kPgsGroups instantiation");
   static_assert(SMALL == 0 || (SOLVER == 0 && NDENSE <= 28 && COLL == 0 && NG == 1 && DEFER == 0), "the small instantiation: classic PGS kernel of dense order <= 28");
   constexpr int kNR = SMALL ? kSmallNefcMax : (NG == 1 ? kNefcMax : 64 * NG);  // row capacity of this instantiation
@@ -989,7 +1006,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   if (env_fixed < 0 && (int)blockIdx.x >= P.nblk) return;
   const int slot = P.blk0 + (int)blockIdx.x;
   const int env = env_fixed >= 0 ? env_fixed : (P.order ? P.order[slot] : slot);  // (env_fixed: the slow lane's kernel names the env)
-  if (P.env_mask && !P.env_mask[env]) return;  // masked stepping (hb_env_reset's settle step)
+  if (P_env_mask && !P_env_mask[env]) return;  // masked stepping (hb_env_reset's settle step)
   if constexpr (COLL != 0 && DEFER == 0) {
     if (P.stage.rerun) {  // second pass of a staged step: only the envs the fast pass deferred
       const int d = P.stage.defer[env];
@@ -1044,7 +1061,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   };
   (void)to_slow_lane;
   // per-env model parameters (domain randomisation), nullable; offsets per DomainLayout
-  const float* dr = P.dr ? P.dr + (size_t)env * P.dr_stride : nullptr;
+  const float* dr = P_dr ? P_dr + (size_t)env * P_dr_stride : nullptr;
   const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
   const int nv = M.nv, nq = M.nq, nb = M.nbody, cs = M.cstride;
 
@@ -1173,7 +1190,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; }
         time = 0.f;
         ctrl_zeroed = true;
-        if (P.xfrc) for (int i = lane; i < 6 * nb; i += kGroup) P.xfrc[(size_t)env * nb * 6 + i] = 0.f;
+        if (P_xfrc) for (int i = lane; i < 6 * nb; i += kGroup) P_xfrc[(size_t)env * nb * 6 + i] = 0.f;
       }
       if (ctrl_zeroed) for (int i = lane; i < M.nu; i += kGroup) s_ctrl[i] = 0.f;
     }
@@ -1418,8 +1435,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     }
     if (!(M.disableflags & (1 << 6))) for (int i = 0; i < 3; i++) mycacc[3 + i] -= M.gravity[i];  // the world's cacc
     // sensor read-out for planner residuals (mj_sensorPos/Vel of framepos, subtreecom, subtreelinvel)
-    if (P.sensor_out) {
-      float* so = P.sensor_out + ((size_t)step * P.n_env + env) * P.sensor_stride;
+    if (P_sensor_out) {
+      float* so = P_sensor_out + ((size_t)step * P.n_env + env) * P.sensor_stride;
       for (int k = 0; k < P.sensor_nframe; k++) {
         const int sb = P.sensor_body[k];
         const V3 w = ld3(s_xpq + kXpqStride * sb) + qrot(ldq(s_xpq + kXpqStride * sb + 4), {P.sensor_off[k][0], P.sensor_off[k][1], P.sensor_off[k][2]});  // site = body frame + offset
@@ -1569,16 +1586,16 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     }
     gsync();
     // xfrc_applied: Cartesian wrench at each body com (mj_xfrcAccumulate)
-    if (P.xfrc) {
-      if (P.xfrc_scale > 0.f && P.integrate && !P.stage.rerun) {  // (a plain mj_forward - hb_forward, the terminal read-out - leaves the process where it is;
+    if (P_xfrc) {
+      if (P_xfrc_scale > 0.f && P_integrate && !P.stage.rerun) {  // (a plain mj_forward - hb_forward, the terminal read-out - leaves the process where it is;
         // the rerun of a deferred env-step finds the process already advanced by the fast pass)
         // Trajectory::NoisyRollout's perturbation (trajectory.cc:147-156): Ornstein-Uhlenbeck noise on every xfrc_applied entry
-        float* xw = P.xfrc + (size_t)env * nb * 6;
+        float* xw = P_xfrc + (size_t)env * nb * 6;
         for (int i = lane; i < 6 * nb; i += kGroup)
-          xw[i] = P.xfrc_rate * xw[i] + P.xfrc_scale * rng_normal(P.xfrc_seed, P.env_offset + env, P.xfrc_call, P.t0 + step, RS_XFRC, i);
+          xw[i] = P_xfrc_rate * xw[i] + P_xfrc_scale * rng_normal(P_xfrc_seed, P.env_offset + env, P_xfrc_call, P.t0 + step, RS_XFRC, i);
         gsync();
       }
-      const float* xf = P.xfrc + (size_t)env * nb * 6;
+      const float* xf = P_xfrc + (size_t)env * nb * 6;
       for (int b = 1; b < nb; b++) {
         float f[6];
         bool nz = false;
@@ -2213,7 +2230,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     gsync();
     HB_STAMP(13);
     // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = W (y + s)
-    const bool want_qfrc = P.qfrc_out != nullptr;
+    const bool want_qfrc = P_qfrc_out != nullptr;
     if constexpr (SMALL != 0) {
       // the forces straight out of their lanes (nefc is uniform): no LDS copy.  Every lane runs the loop - v_readlane reads lanes that a
       // divergent region has switched off, and the value they hold must have been computed there
@@ -2238,7 +2255,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       float acc = 0.f;
 #pragma unroll 8
       for (int j = 0; j < 32; j++) acc = __builtin_fmaf(s_qLD[M.mdense[j * 32 + lane]].x, j < nv ? s_v0[j] : 0.f, acc);
-      P.qfrc_out[(size_t)env * nv + lane] = acc;
+      P_qfrc_out[(size_t)env * nv + lane] = acc;
     }
     } else {
       // ================================================================ PGS on NG row groups (kPgsNefcMax rows): a condim 4 / 6 model solved
@@ -2364,9 +2381,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 #pragma unroll
       for (int g = 0; g < NG; g++) if (lane + 64 * g < kNR) s_force[lane + 64 * g] = actg[g] ? forceg[g] : 0.f;
       force = forceg[0];
-      if (P.diag_force) {
+      if (P_diag_force) {
 #pragma unroll
-        for (int g = 1; g < NG; g++) P.diag_force[(size_t)env * kNR + lane + 64 * g] = actg[g] ? forceg[g] : 0.f;
+        for (int g = 1; g < NG; g++) P_diag_force[(size_t)env * kNR + lane + 64 * g] = actg[g] ? forceg[g] : 0.f;
       }
       gsync();
       HB_STAMP(13);
@@ -2379,11 +2396,11 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       gsync();
       if (lane < nv) s_v0[lane] = dot32(s_W + lane * kWs, s_v2);
       gsync();
-      if (P.qfrc_out && lane < nv) {
+      if (P_qfrc_out && lane < nv) {
         float acc = 0.f;
 #pragma unroll 8
         for (int j = 0; j < 32; j++) acc = __builtin_fmaf(s_qLD[M.mdense[j * 32 + lane]].x, j < nv ? s_v0[j] : 0.f, acc);
-        P.qfrc_out[(size_t)env * nv + lane] = acc;
+        P_qfrc_out[(size_t)env * nv + lane] = acc;
       }
     }
     } else {
@@ -2647,13 +2664,13 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       }
       HB_STAMP(13);
       force = forceg[0];
-      if (P.diag_force) {
+      if (P_diag_force) {
 #pragma unroll
-        for (int g = 1; g < NG; g++) P.diag_force[(size_t)env * kNR + lane + 64 * g] = actg[g] ? forceg[g] : 0.f;
+        for (int g = 1; g < NG; g++) P_diag_force[(size_t)env * kNR + lane + 64 * g] = actg[g] ? forceg[g] : 0.f;
       }
       if (dofl) {
         s_v0[lane] = qacc;
-        if (P.qfrc_out) P.qfrc_out[(size_t)env * nv + lane] = smooth + qfc;  // qfrc_smooth + qfrc_constraint
+        if (P_qfrc_out) P_qfrc_out[(size_t)env * nv + lane] = smooth + qfc;  // qfrc_smooth + qfrc_constraint
       }
       gsync();
     }
@@ -2671,7 +2688,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = 0.f; s_warm[i] = 0.f; s_v0[i] = 0.f; }
         time = 0.f;
         newton_grad = 0.f;
-        if (P.xfrc) for (int i = lane; i < 6 * nb; i += kGroup) P.xfrc[(size_t)env * nb * 6 + i] = 0.f;
+        if (P_xfrc) for (int i = lane; i < 6 * nb; i += kGroup) P_xfrc[(size_t)env * nb * 6 + i] = 0.f;
         gsync();
         if (!redo) {  // second pass of this step from the reset state (the loop increment undoes the decrement)
           redo = true;
@@ -2685,9 +2702,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     redo = false;
     ctrl_zeroed = false;
     // diagnostics of this step (parity tests)
-    if (P.diag_qacc) for (int i = lane; i < nv; i += kGroup) P.diag_qacc[(size_t)env * nv + i] = s_v0[i];
-    if (P.diag_force && lane < kNR) P.diag_force[(size_t)env * kNR + lane] = rowact ? force : 0.f;
-    if (P.diag_contact) {
+    if (P_diag_qacc) for (int i = lane; i < nv; i += kGroup) P_diag_qacc[(size_t)env * nv + i] = s_v0[i];
+    if (P_diag_force && lane < kNR) P_diag_force[(size_t)env * kNR + lane] = rowact ? force : 0.f;
+    if (P_diag_contact) {
       for (int idx = lane; idx < kNC * kDiagConStride; idx += kGroup) {
         int ci = idx / kDiagConStride, f = idx % kDiagConStride;
         float v = 0.f;
@@ -2699,13 +2716,13 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             v = f == 13 ? (float)__float_as_int(c[C_DIM]) : (f == 14 ? (float)M.pair_geom1[pid] : (float)M.pair_geom2[pid]);
           }
         }
-        P.diag_contact[((size_t)env * kNC) * kDiagConStride + idx] = v;
+        P_diag_contact[((size_t)env * kNC) * kDiagConStride + idx] = v;
       }
     }
     if (lane == 0) { int* c = P.counts + kCountStride * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; c[3] = nefc * (niter + 4); c[4] = selfcol; }
 
     HB_STAMP(14);
-    if (P.integrate) {
+    if (P_integrate) {
       // ---------------------------------------------------------------- mj_Euler: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint
       // With H = M + h B and M qacc = qfrc_smooth + qfrc_constraint the solve is the same as
       //   qacc' = qacc - H^-1 (h B qacc),
@@ -2790,12 +2807,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       }
       time += h;
       gsync();
-      if (P.qpos_out) {
-        float* o = P.qpos_out + ((size_t)step * P.n_env + env) * nq;
+      if (P_qpos_out) {
+        float* o = P_qpos_out + ((size_t)step * P.n_env + env) * nq;
         for (int i = lane; i < nq; i += kGroup) o[i] = s_qpos[i];
       }
-      if (P.qvel_out) {
-        float* o = P.qvel_out + ((size_t)step * P.n_env + env) * nv;
+      if (P_qvel_out) {
+        float* o = P_qvel_out + ((size_t)step * P.n_env + env) * nv;
         for (int i = lane; i < nv; i += kGroup) o[i] = s_qvel[i];
       }
     }
@@ -2805,7 +2822,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   HB_STAMP(15);
   if (lane == 0 && P.stamps) for (int i = 0; i < 16; i++) P.stamps[(size_t)env * 16 + i] = stamps_[i];
 #endif
-  if (P.integrate) {
+  if (P_integrate) {
     if (lane == 0) st_state(0, time);
     for (int i = lane; i < nq; i += kGroup) st_state(1 + i, s_qpos[i]);
     for (int i = lane; i < nv; i += kGroup) { st_state(1 + nq + i, s_qvel[i]); st_state(1 + nq + nv + i, s_warm[i]); }
@@ -2819,6 +2836,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28>(Mp, P, nsteps); }
 // the small instantiation (31 rows, 12 contacts: three waves per SIMD); single-step launches only - an overflowing env-step leaves without
 // having written anything, and the slow lane (hb_step_kernel, lane_mode 3) steps that env from then on
+__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 3) void hb_step_small_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 1>(Mp, P, nsteps); }
 // The slow lane: a few blocks walk every segment's list of slow envs and step them with the full instantiation.  A slow env-step is
 // often the heavy kind (more than 31 rows: up to 50 sweeps over them, about 100 us against the 80 us period of the small launches), and a
@@ -2874,6 +2892,10 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_kernel(const D
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 1, 1, 1>(Mp, P, nsteps); }
 // Newton instantiations: dense order 28 (nv <= 28: the 27-dof humanoid) and 32
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
+// lean instantiations (step_body's LEAN: no optional inputs / outputs in the launch) of the kernels the plain step API spends its time in
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2, 0, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 0, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
 
 // ---- staged step of the general variants: poses + work lists, then the narrowphase, each in a kernel of its own ------------------
@@ -3929,15 +3951,27 @@ __global__ void hb_halton_ctrl_kernel(float* out, int T, int n_env, int nu, int 
 
 namespace hb {
 
+// the lean instantiations apply when the launch has none of the optional inputs / outputs (HB_LEAN=0: never)
+static bool lean_launch(const BatchPtrs& P) {
+  static const bool lean_on = !(getenv("HB_LEAN") && atoi(getenv("HB_LEAN")) == 0);
+  return lean_on && !P.xfrc && !P.qfrc_out && !P.sensor_out && !P.qpos_out && !P.qvel_out && !P.diag_qacc && !P.diag_force && !P.diag_contact && !P.dr && !P.env_mask &&
+         P.integrate && !P.stamps && !P.lane;
+}
 static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int solver, int nv, size_t shmem, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   if (variant == 2 && nv <= 20) hipLaunchKernelGGL(hb_step_newton_big20_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (variant == 2) hipLaunchKernelGGL(hb_step_newton_big28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (variant == 1) hipLaunchKernelGGL(hb_step_gen_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (variant == 3) hipLaunchKernelGGL(hb_step_gen_big_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-  else if (solver == 2 && nv <= 28) hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (solver == 2 && nv <= 28) {
+    if (lean_launch(P)) hipLaunchKernelGGL(hb_step_newton28_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  }
   else if (solver == 2) hipLaunchKernelGGL(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-  else if (nv <= 28) hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (nv <= 28) {
+    if (lean_launch(P)) hipLaunchKernelGGL(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  }
   else hipLaunchKernelGGL(hb_step32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   return hipGetLastError();
 }
@@ -3962,7 +3996,8 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
     if (e != hipSuccess) return e;
     if (variant == 1 && Q.stage.defer) {
       // the step kernel without the portal-search code; the full one then takes the (rare) env-steps whose qacc came out bad
-      hipLaunchKernelGGL(hb_step_gen_fast_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
+      if (lean_launch(Q)) hipLaunchKernelGGL(hb_step_gen_fast_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
+      else hipLaunchKernelGGL(hb_step_gen_fast_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       Q.stage.rerun = 1;
@@ -3974,7 +4009,8 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
       Q.stage.rerun = 1;
     } else if (variant == 2 && Q.stage.dm_fast) {
       // most env-steps fit the one-group Newton instantiation (two waves per SIMD); the four-group kernel then steps the rest
-      if (nv <= 20) hipLaunchKernelGGL(hb_step_newton_gen20_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      if (nv <= 20 && lean_launch(Q)) hipLaunchKernelGGL(hb_step_newton_gen20_lean_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      else if (nv <= 20) hipLaunchKernelGGL(hb_step_newton_gen20_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       else hipLaunchKernelGGL(hb_step_newton_gen28_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       e = hipGetLastError();
       if (e != hipSuccess) return e;

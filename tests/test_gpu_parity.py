@@ -273,6 +273,30 @@ def test_default_pipeline_picks_its_segment_count_by_probe(hbmod, humanoid_model
         o.close()
 
 
+@pytest.mark.parametrize("solver", [0, 2])
+def test_lean_kernels_are_bit_identical_to_the_full_ones(hbmod, humanoid_model, gpu, solver):
+    """A launch without optional inputs / outputs runs step_body's LEAN instantiation (hb_step_lean_kernel, hb_step_newton28_lean_kernel);
+    asking for any of them - here the recorded qpos trajectory - runs the full one.  Same arithmetic: same bits, same counts."""
+    m = hbmod.Model.load(HUMANOID_HBM)  # (a model of its own: the solver is set on it)
+    m.set_opt(solver=solver, iterations=50 if solver == 0 else 100)
+    if True:
+        n, T = 512, 60
+        rng = np.random.default_rng(4)
+        ctrl = rng.uniform(-1, 1, size=(T, n, m.nu)).astype(np.float32)
+        a = hbmod.Batch(m, n, gpu); b = hbmod.Batch(m, n, gpu)
+        a.reset(perturb=True); b.reset(perturb=True)
+        a.rollout_halton(200); b.rollout_halton(200)          # lean in both: onto the floor
+        a.rollout(ctrl)                                         # lean
+        q = b.rollout(ctrl, want_qpos=True)                     # full kernel (qpos_out)
+        sa, sb = a.get_state(hbmod.STATE_INTEGRATION), b.get_state(hbmod.STATE_INTEGRATION)
+        assert np.array_equal(sa, sb)
+        assert np.array_equal(q[-1], sb[:, 1:1 + m.nq])
+        for x, y in zip(a.counts(), b.counts()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a.status(), b.status()) and a.counts()[1].max() > 0
+        a.close(); b.close()
+
+
 def test_state_io_reset_and_keyframes(hbmod, humanoid_model, gpu):
     m = humanoid_model
     n = 16

@@ -709,6 +709,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
   if (const char* sp = getenv("HB_STOP_PHASE")) P.stop_phase = atoi(sp);
 #endif
   P.stage = b->stage;
+  P.lean_ok = b->D.dm.disableflags == 0;
   if (b->diag) P.stage.dm_fast = nullptr;  // the diagnostic buffers are laid out for the kernel of the model's own variant
   if (b->xfrc_std > 0.f && b->d_xfrc) {
     const double rate = b->xfrc_rate > 0.f ? std::exp(-b->model->m.timestep / b->xfrc_rate) : 0.0;  // trajectory.cc:149-150

@@ -335,6 +335,7 @@ struct BatchPtrs {
   int n_env_total;            // (n_env of the batch: stride of the two lists)
   LaneRing* lane_ring;        // the step calls the GPU has got to and their controls
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
+  int lean_ok;                // the model's options allow the lean instantiations (mjOption.disableflags == 0)
   int stop_phase;             // diagnostic builds only: 0 = off (HB_STOP_PHASE in the environment, read at every launch)
   StageBufs stage;
 };

@@ -972,13 +972,13 @@ __device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, 
 // flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
 template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0, int LEAN = 0>
 __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps, int env_fixed = -1, int ring = -1) {
-  // LEAN: a launch without the optional inputs and outputs (applied forces and their noise, constraint-force / sensor / trajectory
+  // LEAN (1, or 2 = with the constraint-force read-out): a launch without the optional inputs and outputs (applied forces and their noise, constraint-force / sensor / trajectory
   // read-outs, diagnostics, per-env model parameters, an env mask; mj_step, not mj_forward) - known at compile time, so their tests,
   // pointers and code are not in the kernel at all
   float* const P_xfrc = LEAN ? nullptr : P.xfrc;
   const float P_xfrc_scale = LEAN ? 0.f : P.xfrc_scale, P_xfrc_rate = LEAN ? 0.f : P.xfrc_rate;
   const auto P_xfrc_seed = P.xfrc_seed; const auto P_xfrc_call = P.xfrc_call;
-  float* const P_qfrc_out = LEAN ? nullptr : P.qfrc_out;
+  float* const P_qfrc_out = LEAN == 1 ? nullptr : P.qfrc_out;  // (LEAN == 2: the lean kernel of the env adapter, whose reward reads the constraint forces)
   float* const P_sensor_out = LEAN ? nullptr : P.sensor_out;
   float* const P_qpos_out = LEAN ? nullptr : P.qpos_out;
   float* const P_qvel_out = LEAN ? nullptr : P.qvel_out;
@@ -997,6 +997,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   // arguments): the ~100 table pointers and every wave-uniform table entry are fetched on demand by
   // scalar loads through the scalar cache instead of living in (and spilling from) SGPRs
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
+  const int M_disableflags = LEAN ? 0 : M.disableflags;  // (a lean launch: the host has checked that the model disables nothing, BatchPtrs::lean_ok)
   // PGS instantiation of dense order <= 28: M^-1 = W W' from an elimination on the matrix cores instead of the sparse
   // L'DL schedule (which stays for 29..32 dofs)
   extern __shared__ float lds[];
@@ -1125,7 +1126,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = ld_state(1 + nq + i); s_warm[i] = ld_state(1 + nq + nv + i); }
   int status = 0;
   bool eulerdamp = false;
-  if (!(M.disableflags & (1 << 14))) {
+  if (!(M_disableflags & (1 << 14))) {
     bool d = false;
     for (int i = lane; i < nv; i += kGroup) d |= M.dof_damping[i] > 0.f;
     eulerdamp = __any(d);
@@ -1433,7 +1434,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       }
       gsync();
     }
-    if (!(M.disableflags & (1 << 6))) for (int i = 0; i < 3; i++) mycacc[3 + i] -= M.gravity[i];  // the world's cacc
+    if (!(M_disableflags & (1 << 6))) for (int i = 0; i < 3; i++) mycacc[3 + i] -= M.gravity[i];  // the world's cacc
     // sensor read-out for planner residuals (mj_sensorPos/Vel of framepos, subtreecom, subtreelinvel)
     if (P_sensor_out) {
       float* so = P_sensor_out + ((size_t)step * P.n_env + env) * P.sensor_stride;
@@ -1564,19 +1565,19 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       ld_cdof(s_cdof, d, cdd);
       for (int t = 0; t < 6; t++) bias += cdd[t] * s_if[kIfStride * b + 10 + t];
       float passive = 0.f;
-      if (!(M.disableflags & (1 << 5))) {
+      if (!(M_disableflags & (1 << 5))) {
         if (__float_as_int(dA.z) >= 2) passive -= (dr ? dr[DL.o_stiff + d] : dB.w) * (s_qpos[__float_as_int(dC.x)] - dC.y);
         passive -= dB.z * s_qvel[d];
       }
       s_smooth[d] = passive - bias;
     }
     gsync();
-    if (!(M.disableflags & (1 << 10))) {
+    if (!(M_disableflags & (1 << 10))) {
       for (int a = lane; a < M.nu; a += kGroup) {
         if (a != lane) { const float4 HB_CONST* AR4 = M.arec + (size_t)a * 4; pf_a0 = AR4[0]; pf_a1 = AR4[1]; pf_a2 = AR4[2]; pf_a3 = AR4[3]; }  // (more than 64 actuators)
         const int qa = __float_as_int(pf_a0.z), da = __float_as_int(pf_a0.w);
         float ctrl = s_ctrl[a];
-        if (__float_as_int(pf_a0.x) && !(M.disableflags & (1 << 7))) ctrl = clampf(ctrl, pf_a1.x, pf_a1.y);
+        if (__float_as_int(pf_a0.x) && !(M_disableflags & (1 << 7))) ctrl = clampf(ctrl, pf_a1.x, pf_a1.y);
         float gear = pf_a1.z;
         const float gain = dr ? dr[DL.o_gain + a] : pf_a1.w, bias1 = dr ? dr[DL.o_bias1 + a] : pf_a2.y;
         float force = gain * ctrl + pf_a2.x + bias1 * gear * s_qpos[qa] + pf_a2.z * gear * s_qvel[da];
@@ -1619,7 +1620,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     HB_STAMP(7);
     // ---------------------------------------------------------------- mj_collision
     int ncon = 0;
-    const bool contacts_on = !(M.disableflags & ((1 << 0) | (1 << 4)));
+    const bool contacts_on = !(M_disableflags & ((1 << 0) | (1 << 4)));
     if constexpr (COLL != 0) {
       if (contacts_on) {
         // staged step: the narrowphase ran in its own kernel on this step's poses (launch_step); the second forward pass of a step
@@ -1735,12 +1736,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     HB_STAMP(8);
     // ---------------------------------------------------------------- mj_makeConstraint
     int nefc = 0;
-    const bool constraints_on = !(M.disableflags & (1 << 0));
+    const bool constraints_on = !(M_disableflags & (1 << 0));
     const int selfcol = __any(selfc) ? 1 : 0;
     if constexpr (COLL != 0) {
       // ---- general form: limits, then contacts of dimension 1 / 3 / 4 / 6 (one row, or 2 (dim - 1) pyramid rows); what the solver
       // needs of a row besides its Jacobian is written once, here: s_meta[row] = (R, K imp (pos - margin), B, -)
-      if (constraints_on && !(M.disableflags & (1 << 3))) {
+      if (constraints_on && !(M_disableflags & (1 << 3))) {
         for (int c0 = 0; c0 < M.nlimcand; c0 += kGroup) {
           const int c = c0 + lane;
           bool active = false;
@@ -1766,7 +1767,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             const float solimp[5] = {l2.x, l2.y, l2.z, l2.w, l3.x};
             const float imp = clampf(impedance(solimp, dist, margin), HB_MINIMP, HB_MAXIMP);
             float K, Bc;
-            kb_from_solref(l1.z, l1.w, solimp[1], M.timestep, !(M.disableflags & (1 << 11)), K, Bc);
+            kb_from_solref(l1.z, l1.w, solimp[1], M.timestep, !(M_disableflags & (1 << 11)), K, Bc);
             float* e = s_meta + kMetaStride * row;
             e[0] = fmaxf(HB_MINVAL, (1.f - imp) * l3.y / imp); e[1] = K * imp * (dist - margin); e[2] = Bc;
           }
@@ -1850,7 +1851,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
             const float solimp[5] = {p3.x, p3.y, p3.z, p3.w, p4.x};
             const float imp = clampf(impedance(solimp, dist, margin), HB_MINIMP, HB_MAXIMP);
             float K, Bc;
-            kb_from_solref(p2.y, p2.z, solimp[1], M.timestep, !(M.disableflags & (1 << 11)), K, Bc);
+            kb_from_solref(p2.y, p2.z, solimp[1], M.timestep, !(M_disableflags & (1 << 11)), K, Bc);
             // pyramidal rows share 2 mu^2 R(first row), mu = friction[0] / sqrt(impratio); the first row's diagApprox is tran + friction[0]^2 tran
             const float mus = mu * M.inv_sqrt_impratio;
             const float Rown = fmaxf(HB_MINVAL, (1.f - imp) * (cdim == 1 ? tran : tran + mu * mu * tran) / imp);
@@ -1862,7 +1863,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       }
     } else {
     // (a) limits: 2 candidates (lower, upper) per limited joint / tendon, in constraint order
-    if (constraints_on && !(M.disableflags & (1 << 3))) {
+    if (constraints_on && !(M_disableflags & (1 << 3))) {
       for (int c0 = 0; c0 < M.nlimcand; c0 += kGroup) {
         int c = c0 + lane;
         bool active = false;
@@ -2034,7 +2035,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
           Rg[g] = mu2 > 0.f ? mu2 * Rown : Rown;  // pyramidal: all rows share 2 mu^2 R(first); first row's diagApprox == own
           Ddg[g] = 1.f / Rg[g];
           float K, Bc;
-          kb_from_solref(solref0, solref1, solimp[1], M.timestep, !(M.disableflags & (1 << 11)), K, Bc);
+          kb_from_solref(solref0, solref1, solimp[1], M.timestep, !(M_disableflags & (1 << 11)), K, Bc);
           arefg[g] = -Bc * vel - K * imp * (pos - margin);
         }
       }
@@ -2165,7 +2166,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       // unrolled row loops below run in unguarded 4-row chunks up to nefc rounded up.
       const float nAinv = -1.f / Aii;
       float arf = 0.f;  // (AR force)_lane
-      if (!(M.disableflags & (1 << 8))) {
+      if (!(M_disableflags & (1 << 8))) {
         const float jar = jw - aref;
         force = (rowact && jar < 0.f) ? -Dd * jar : 0.f;
 #pragma unroll
@@ -2330,7 +2331,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         float arfg[NG];
 #pragma unroll
         for (int g = 0; g < NG; g++) { forceg[g] = 0.f; arfg[g] = 0.f; }
-        if (!(M.disableflags & (1 << 8))) {
+        if (!(M_disableflags & (1 << 8))) {
 #pragma unroll
           for (int g = 0; g < NG; g++) {
             const float jar = jwg[g] - arefg[g];
@@ -2466,7 +2467,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         HB_JDOT(qs, Ma, jqs)
 #pragma unroll
         for (int g = 0; g < NG; g++) jar[g] = actg[g] ? jqs[g] - arefg[g] : 1.f;  // rows beyond nefc: never active
-        if (!(M.disableflags & (1 << 8))) {
+        if (!(M_disableflags & (1 << 8))) {
           const float Mw = rowdot<NDENSE>(Mrow, warm);
           float cw = dofl ? 0.5f * (Mw - smooth) * (warm - qs) : 0.f, cq = 0.f;
           float jarw[NG];
@@ -2837,6 +2838,7 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) vo
 // the small instantiation (31 rows, 12 contacts: three waves per SIMD); single-step launches only - an overflowing env-step leaves without
 // having written anything, and the slow lane (hb_step_kernel, lane_mode 3) steps that env from then on
 __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 1>(Mp, P, nsteps); }
+__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 2>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 3) void hb_step_small_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 1>(Mp, P, nsteps); }
 // The slow lane: a few blocks walk every segment's list of slow envs and step them with the full instantiation.  A slow env-step is
 // often the heavy kind (more than 31 rows: up to 50 sweeps over them, about 100 us against the 80 us period of the small launches), and a
@@ -3952,9 +3954,9 @@ __global__ void hb_halton_ctrl_kernel(float* out, int T, int n_env, int nu, int 
 namespace hb {
 
 // the lean instantiations apply when the launch has none of the optional inputs / outputs (HB_LEAN=0: never)
-static bool lean_launch(const BatchPtrs& P) {
+static bool lean_launch(const BatchPtrs& P, bool with_qfrc = false) {
   static const bool lean_on = !(getenv("HB_LEAN") && atoi(getenv("HB_LEAN")) == 0);
-  return lean_on && !P.xfrc && !P.qfrc_out && !P.sensor_out && !P.qpos_out && !P.qvel_out && !P.diag_qacc && !P.diag_force && !P.diag_contact && !P.dr && !P.env_mask &&
+  return lean_on && P.lean_ok && !P.xfrc && (with_qfrc || !P.qfrc_out) && !P.sensor_out && !P.qpos_out && !P.qvel_out && !P.diag_qacc && !P.diag_force && !P.diag_contact && !P.dr && !P.env_mask &&
          P.integrate && !P.stamps && !P.lane;
 }
 static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int solver, int nv, size_t shmem, const BatchPtrs& P, int nsteps, hipStream_t stream) {
@@ -3970,6 +3972,7 @@ static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int sol
   else if (solver == 2) hipLaunchKernelGGL(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (nv <= 28) {
     if (lean_launch(P)) hipLaunchKernelGGL(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (lean_launch(P, true)) hipLaunchKernelGGL(hb_step_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   }
   else hipLaunchKernelGGL(hb_step32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);

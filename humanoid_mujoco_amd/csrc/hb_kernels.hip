@@ -971,8 +971,9 @@ __device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, 
 // overflow into.  Both: an env-step whose qacc comes out bad (mj_checkAcc: reset, second forward pass with a narrowphase of its own) is
 // flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
 template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0, int LEAN = 0>
-__device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps, int env_fixed = -1, int ring = -1) {
-  // LEAN (1, or 2 = with the constraint-force read-out): a launch without the optional inputs and outputs (applied forces and their noise, constraint-force / sensor / trajectory
+__device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps_in, int env_fixed = -1, int ring = -1) {
+  const int nsteps = LEAN == 1 ? 1 : nsteps_in;  // (LEAN == 1 is launched for single steps only: the step API; rollouts take LEAN == 2)
+  // LEAN (1 = a single step without the constraint-force read-out; 2 = any number of steps, read-out optional): a launch without the optional inputs and outputs (applied forces and their noise, constraint-force / sensor / trajectory
   // read-outs, diagnostics, per-env model parameters, an env mask; mj_step, not mj_forward) - known at compile time, so their tests,
   // pointers and code are not in the kernel at all
   float* const P_xfrc = LEAN ? nullptr : P.xfrc;
@@ -2896,6 +2897,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen28_kernel(const D
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
 // lean instantiations (step_body's LEAN: no optional inputs / outputs in the launch) of the kernels the plain step API spends its time in
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 2>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2, 0, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 0, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
@@ -3966,12 +3968,13 @@ static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int sol
   else if (variant == 1) hipLaunchKernelGGL(hb_step_gen_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (variant == 3) hipLaunchKernelGGL(hb_step_gen_big_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (solver == 2 && nv <= 28) {
-    if (lean_launch(P)) hipLaunchKernelGGL(hb_step_newton28_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    if (nsteps == 1 && lean_launch(P)) hipLaunchKernelGGL(hb_step_newton28_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (lean_launch(P, true)) hipLaunchKernelGGL(hb_step_newton28_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   }
   else if (solver == 2) hipLaunchKernelGGL(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (nv <= 28) {
-    if (lean_launch(P)) hipLaunchKernelGGL(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    if (nsteps == 1 && lean_launch(P)) hipLaunchKernelGGL(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (lean_launch(P, true)) hipLaunchKernelGGL(hb_step_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   }

@@ -9,6 +9,11 @@ WRITE_SIZE, bytes = counter * 1024, and FETCH_SIZE doubled (gfx950 reports half 
 """
 import collections, csv, glob, json, os, shutil, sys
 
+def is_step(name):
+    """the benchmark's single-step launches: the lean instantiation of the PGS step kernel (hb_step_kernel before it existed, and in
+    launches that carry an optional input or output)"""
+    return "hb_step_lean_kernel(" in name or "hb_step_kernel(" in name
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out", tag)
@@ -26,7 +31,7 @@ by_grid = collections.defaultdict(list)
 trace = glob.glob(os.path.join(src, "prof_trace", "*", "*_kernel_trace.csv"))
 if trace:
     for row in csv.DictReader(open(trace[0])):
-        if "hb_step_kernel" in row["Kernel_Name"]:
+        if is_step(row["Kernel_Name"]):
             by_grid[int(row.get("Grid_Size") or row["Grid_Size_X"])].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
     shutil.copy(trace[0], os.path.join(src, "kernel_trace_full.csv"))
 full = 4096 * 64
@@ -46,7 +51,7 @@ if by_grid.get(full):
     avg_ns = sum(by_grid[full]) / len(by_grid[full]); calls = len(by_grid[full])
 else:
     for row in csv.DictReader(open(stats)):
-        if "hb_step_kernel" in row["Name"]:
+        if is_step(row["Name"]):
             avg_ns = float(row["AverageNs"]); calls = int(row["Calls"])
 counters = {}
 meta = {}
@@ -56,14 +61,14 @@ for d in ("prof_fetch", "prof_write", "prof_sq", "prof_lds", "prof_mfma", "prof_
         continue
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(fs[0])):
-        if "hb_step_kernel" in row["Kernel_Name"] and int(row["Grid_Size"]) == 4096 * 64:
+        if is_step(row["Kernel_Name"]) and int(row["Grid_Size"]) == 4096 * 64:
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
             meta = {k: row[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
     for k, v in agg.items():
         v = steady(v)
         counters[k] = {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "dispatches": len(v)}
 n_env = 4096
-out = {"kernel": "hb_step_kernel", "launch": "4096 envs (one wave each), 1 step per launch, bench.py workload",
+out = {"kernel": "hb_step_lean_kernel", "launch": "4096 envs (one wave each), 1 step per launch, bench.py workload",
        "avg_launch_ns_kernel_trace": avg_ns, "kernel_trace_calls": calls,
        "kernel_trace_by_grid": {str(g): {"calls": len(v), "avg_ns": sum(v) / len(v)} for g, v in by_grid.items()},
        "dispatch_meta": meta, "counters_per_launch": counters}
@@ -90,7 +95,7 @@ fv = glob.glob(os.path.join(src, "prof_valu", "*", "*_counter_collection.csv"))
 if fv:
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(fv[0])):
-        k = "step" if ("hb_step_kernel" in row["Kernel_Name"] and int(row["Grid_Size"]) == full) else ("full" if ("hb_reset_kernel" in row["Kernel_Name"] or "copyBuffer" in row["Kernel_Name"]) else None)
+        k = "step" if (is_step(row["Kernel_Name"]) and int(row["Grid_Size"]) == full) else ("full" if ("hb_reset_kernel" in row["Kernel_Name"] or "copyBuffer" in row["Kernel_Name"]) else None)
         if k:
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     def ratio(k):

@@ -6,7 +6,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-echo "== pytest -m gpu" | tee $OUT/progress.log
+# the diagnostic libraries (stage stamps, Newton sections) must be of this source: built here if the box has not got them from the snapshot
+[ build/libhb_stamps.so -nt humanoid_mujoco_amd/libhb.so ] || echo "note: build/libhb_stamps.so is older than libhb.so: run make build/libhb_stamps.so build/libhb_probe.so before the round" | tee $OUT/progress.log
+echo "== pytest -m gpu" | tee -a $OUT/progress.log
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/progress.log
 tail -5 $OUT/pytest_gpu.log
 echo "== smoke" | tee -a $OUT/progress.log

@@ -426,7 +426,7 @@ def main():
                        "sharding": "env blocks by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                         "kernel": "hb_step_lean_kernel", "avg_launch_us": launch_us, "launches": KR,
+                         "kernel": "hb_step_h27_kernel", "avg_launch_us": launch_us, "launches": KR,
                          "launch_shape": "%d blocks x 64 lanes, one env per block, unpipelined leg" % n_env,
                          "timed_region_ms_per_step": region_ms / K,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_env,

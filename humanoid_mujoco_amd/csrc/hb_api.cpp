@@ -47,6 +47,7 @@ struct DeviceModel {
   DevModel* d_dm = nullptr;     // device copy of dm (the step kernel reads the tables through it)
   DevModel* d_dm_fast = nullptr;  // variant 2 only: the same model with the variant-1 LDS layout (fast step kernel of the staged step)
   int fast_lds_floats = 0;
+  bool sized_h27 = false;  // sizes and LDS layout equal kSizedHumanoid27's: the size-specialised step kernel applies
   DevModel* d_dm_small = nullptr;  // classic PGS models of dense order <= 28: the small layout (hb_step_small_kernel), else null
   int small_lds_floats = 0;
   // observation order tables (device pointers): joint order and, when it exists, actuator order (hb_env_config.obs_actuator_order)
@@ -230,6 +231,17 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   return true;
   };
   if (!lay(dm)) return false;
+  {
+    // the size-specialised kernel (hb_step_h27_kernel): the model's sizes and the layout just computed against the compile-time mirror
+    constexpr SizedModel z = kSizedHumanoid27;
+    D.sized_h27 = dm.variant == 0 && dm.solver == 0 && m.nq == z.nq && nv == z.nv && m.nu == z.nu && nb == z.nbody && m.njnt == z.njnt && m.ngeom == z.ngeom &&
+                  m.ntendon == z.ntendon && m.nM == z.nM && dm.ntree == z.ntree && m.npair == z.npair && dm.nstate == z.nstate && dm.cstride == z.cstride &&
+                  dm.o_qpos == z.o_qpos && dm.o_qvel == z.o_qvel && dm.o_warm == z.o_warm && dm.o_ctrl == z.o_ctrl && dm.o_gpos == z.o_gpos && dm.o_gaxis == z.o_gaxis &&
+                  dm.o_scom == z.o_scom && dm.o_cdof == z.o_cdof && dm.o_qLD == z.o_qLD && dm.o_smooth == z.o_smooth && dm.o_vec0 == z.o_vec0 && dm.o_vec1 == z.o_vec1 &&
+                  dm.o_vec2 == z.o_vec2 && dm.o_tenlen == z.o_tenlen && dm.o_xpos == z.o_xpos && dm.o_xmat == z.o_xmat && dm.o_xipos == z.o_xipos &&
+                  dm.o_xanchor == z.o_xanchor && dm.o_xaxis == z.o_xaxis && dm.o_cinert == z.o_cinert && dm.o_crb == z.o_crb && dm.o_cvel == z.o_cvel &&
+                  dm.o_con == z.o_con && dm.o_C == z.o_C && dm.o_efc == z.o_efc && dm.o_force == z.o_force && dm.lds_floats == z.lds_floats;
+  }
 
   std::vector<int> mdense((size_t)32 * 32, m.nM);
   for (int i = 0; i < 32; i++) mdense[(size_t)i * 32 + i] = m.nM + 1;
@@ -709,7 +721,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
   if (const char* sp = getenv("HB_STOP_PHASE")) P.stop_phase = atoi(sp);
 #endif
   P.stage = b->stage;
-  P.lean_ok = b->D.dm.disableflags == 0;
+  P.lean_ok = (b->D.dm.disableflags == 0 ? 1 : 0) | (b->D.sized_h27 && !(getenv("HB_SIZED") && atoi(getenv("HB_SIZED")) == 0) ? 2 : 0);
   if (b->diag) P.stage.dm_fast = nullptr;  // the diagnostic buffers are laid out for the kernel of the model's own variant
   if (b->xfrc_std > 0.f && b->d_xfrc) {
     const double rate = b->xfrc_rate > 0.f ? std::exp(-b->model->m.timestep / b->xfrc_rate) : 0.0;  // trajectory.cc:149-150

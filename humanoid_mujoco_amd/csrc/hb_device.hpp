@@ -260,6 +260,43 @@ struct StageBufs {
   int rerun;                // set by launch_step for the second pass
 };
 
+// ---- Size-specialised instantiation of the classic PGS step kernel (step_body's SIZED) ---------------------------------------------
+// Every loop bound and every LDS offset of the step kernel is a function of the model's sizes.  For the size signature of the
+// reference's 27-dof humanoid (simulation/mujoco/model/humanoid/humanoid.xml) they are compile-time constants in one
+// more instantiation: addresses fold into the instructions' offset fields and 40 SGPRs spill instead of 84.  Any model with this
+// signature takes it (the host compares sizes AND the layout it computed itself, field by field: build_device_model); every other
+// model takes the generic kernels.
+struct SizedModel {
+  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, ntree, npair, nstate, cstride;
+  int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qLD, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
+  int o_xpos, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cvel;
+  int o_con, o_C, o_efc, o_force, lds_floats;
+};
+// the classic layout (variant 0, full capacity) as build_device_model's lay() computes it
+constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int ntendon, int nM, int ntree, int npair) {
+  SizedModel z{};
+  z.nq = nq; z.nv = nv; z.nu = nu; z.nbody = nbody; z.njnt = njnt; z.ngeom = ngeom; z.ntendon = ntendon; z.nM = nM; z.ntree = ntree; z.npair = npair;
+  z.nstate = 1 + nq + 2 * nv; z.cstride = 33;
+  int off = 0;
+  auto up = [](int n) { return (n + 3) & ~3; };
+  z.o_qpos = off; off += up(nq); z.o_qvel = off; off += up(nv); z.o_warm = off; off += up(nv); z.o_ctrl = off; off += up(nu > 1 ? nu : 1);
+  z.o_gpos = off; off += up(3 * ngeom); z.o_gaxis = off; off += up(3 * ngeom); z.o_scom = off; off += up(3 * (ntree > 1 ? ntree : 1)); z.o_cdof = off; off += up(12 * nv);
+  z.o_qLD = off; off += up(2 * nM + 4); z.o_smooth = off; off += up(nv);
+  z.o_vec0 = off; off += 32; z.o_vec1 = off; off += 32; z.o_vec2 = off; off += 32; z.o_tenlen = off; off += up(ntendon > 1 ? ntendon : 1);
+  const int region = off;
+  z.o_xpos = off; off += up(12 * nbody); z.o_xmat = off; off += up(9 * nbody); z.o_xipos = off; off += up(3 * nbody);
+  z.o_xanchor = off; off += up(3 * njnt); z.o_xaxis = off; off += up(3 * njnt); z.o_cinert = off; off += up(10 * nbody); z.o_crb = off; off += up(20 * nbody);
+  z.o_cvel = off; off += up(12 * nbody);
+  const int endA = off;
+  off = region;
+  z.o_con = off; off += up(kNconMax * kConStride); z.o_C = off; off += up((kNefcMax + 1) * 33);
+  z.o_efc = off; off += up(13 * kNefcMax > 32 * 36 ? 13 * kNefcMax : 32 * 36);
+  z.o_force = off; off += up(kGroup > kNefcMax ? kGroup : kNefcMax);
+  z.lds_floats = endA > off ? endA : off;
+  return z;
+}
+constexpr SizedModel kSizedHumanoid27 = sized_model(28, 27, 21, 17, 22, 20, 2, 243, 1, 159);
+
 // LDS of hb_pose_kernel in floats: qpos | body poses (12 floats each, kXpqStride) | geom position, z axis, quaternion | the work lists
 __host__ __device__ inline int pose_lds_floats(int nq, int nb, int ngeom) {
   return ((nq + 3) & ~3) + 12 * nb + 2 * ((3 * ngeom + 3) & ~3) + 4 * ngeom + kListMax * 5 + kWorkMax;
@@ -335,7 +372,8 @@ struct BatchPtrs {
   int n_env_total;            // (n_env of the batch: stride of the two lists)
   LaneRing* lane_ring;        // the step calls the GPU has got to and their controls
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
-  int lean_ok;                // the model's options allow the lean instantiations (mjOption.disableflags == 0)
+  int lean_ok;                // bit 0: the model's options allow the lean instantiations (mjOption.disableflags == 0); bit 1: its sizes and LDS
+                              // layout are kSizedHumanoid27's (the size-specialised instantiation)
   int stop_phase;             // diagnostic builds only: 0 = off (HB_STOP_PHASE in the environment, read at every launch)
   StageBufs stage;
 };

@@ -970,7 +970,9 @@ __device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, 
 // contacts is not stepped here but flagged for the four-group kernel.  2 (variant 1): same capacities as the full kernel, nothing to
 // overflow into.  Both: an env-step whose qacc comes out bad (mj_checkAcc: reset, second forward pass with a narrowphase of its own) is
 // flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
-template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0, int LEAN = 0>
+// (sizes and LDS offsets: the model's, or - SIZED - the constants of kSizedHumanoid27, hb_device.hpp)
+#define HB_SZ(f) (SIZED ? kSizedHumanoid27.f : M.f)
+template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0, int LEAN = 0, int SIZED = 0>
 __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps_in, int env_fixed = -1, int ring = -1) {
   const int nsteps = LEAN == 1 ? 1 : nsteps_in;  // (LEAN == 1 is launched for single steps only: the step API; rollouts take LEAN == 2)
   // LEAN (1 = a single step without the constraint-force read-out; 2 = any number of steps, read-out optional): a launch without the optional inputs and outputs (applied forces and their noise, constraint-force / sensor / trajectory
@@ -990,6 +992,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   const int P_dr_stride = LEAN ? 0 : P.dr_stride;
   const unsigned char* const P_env_mask = LEAN ? nullptr : P.env_mask;
   const int P_integrate = LEAN ? 1 : P.integrate;
+  static_assert(SIZED == 0 || (SOLVER == 0 && NDENSE == 28 && COLL == 0 && NG == 1 && SMALL == 0), "the size-specialised instantiation: classic PGS kernel of dense order 28");
   static_assert(NG == 1 || SOLVER == 2 || (COLL == 1 && NG == kPgsGroups && DEFER == 0), "PGS on more than one row group: the general variant's kPgsGroups instantiation");
   static_assert(SMALL == 0 || (SOLVER == 0 && NDENSE <= 28 && COLL == 0 && NG == 1 && DEFER == 0), "the small instantiation: classic PGS kernel of dense order <= 28");
   constexpr int kNR = SMALL ? kSmallNefcMax : (NG == 1 ? kNefcMax : 64 * NG);  // row capacity of this instantiation
@@ -1064,37 +1067,37 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   (void)to_slow_lane;
   // per-env model parameters (domain randomisation), nullable; offsets per DomainLayout
   const float* dr = P_dr ? P_dr + (size_t)env * P_dr_stride : nullptr;
-  const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
-  const int nv = M.nv, nq = M.nq, nb = M.nbody, cs = M.cstride;
+  const DomainLayout DL = domain_layout(HB_SZ(nbody), HB_SZ(nv), M.nlimcand, HB_SZ(nu), M.nhfielddata);
+  const int nv = HB_SZ(nv), nq = HB_SZ(nq), nb = HB_SZ(nbody), cs = HB_SZ(cstride);
 
-  float* s_qpos = lds + M.o_qpos;
-  float* s_qvel = lds + M.o_qvel;
-  float* s_warm = lds + M.o_warm;
-  float* s_ctrl = lds + M.o_ctrl;
-  float* s_gpos = lds + M.o_gpos;
-  float* s_gaxis = lds + M.o_gaxis;
-  float* s_scom = lds + M.o_scom;
-  float* s_cdof = lds + M.o_cdof;
+  float* s_qpos = lds + HB_SZ(o_qpos);
+  float* s_qvel = lds + HB_SZ(o_qvel);
+  float* s_warm = lds + HB_SZ(o_warm);
+  float* s_ctrl = lds + HB_SZ(o_ctrl);
+  float* s_gpos = lds + HB_SZ(o_gpos);
+  float* s_gaxis = lds + HB_SZ(o_gaxis);
+  float* s_scom = lds + HB_SZ(o_scom);
+  float* s_cdof = lds + HB_SZ(o_cdof);
   // {M, H = M + h*diag(damping)} interleaved, in the sparse dof-ancestor layout: assembled once per step, read as dense views
-  f32x2* s_qLD = reinterpret_cast<f32x2*>(lds + M.o_qLD);
-  float* s_smooth = lds + M.o_smooth;  // qfrc_smooth
-  float* s_v0 = lds + M.o_vec0;        // scratch dof vectors
-  float* s_v1 = lds + M.o_vec1;
-  float* s_v2 = lds + M.o_vec2;
-  float* s_tenlen = lds + M.o_tenlen;
-  float* s_xpq = lds + M.o_xpos;  // per body: xpos[3], -, xquat[4] (two ds_read/write_b128)
-  float* s_xmat = lds + M.o_xmat;
-  float* s_xipos = lds + M.o_xipos;
-  float* s_xanchor = lds + M.o_xanchor;
-  float* s_xaxis = lds + M.o_xaxis;
-  float* s_cinert = lds + M.o_cinert;
-  float* s_if = lds + M.o_crb;   // per body: composite inertia[10] | cfrc[6]
-  float* s_va = lds + M.o_cvel;  // per body: cvel[6] | cacc[6]
-  float* s_con = lds + M.o_con;
-  float* s_C = lds + M.o_C;
-  float* s_efc = lds + M.o_efc;  // per-row meta, stride kNR; dead once the row quantities are in registers
-  float* s_W = lds + M.o_efc;    // W = L^-1 D^-1/2, [32][33], aliases the row meta
-  float* s_force = lds + M.o_force;
+  f32x2* s_qLD = reinterpret_cast<f32x2*>(lds + HB_SZ(o_qLD));
+  float* s_smooth = lds + HB_SZ(o_smooth);  // qfrc_smooth
+  float* s_v0 = lds + HB_SZ(o_vec0);        // scratch dof vectors
+  float* s_v1 = lds + HB_SZ(o_vec1);
+  float* s_v2 = lds + HB_SZ(o_vec2);
+  float* s_tenlen = lds + HB_SZ(o_tenlen);
+  float* s_xpq = lds + HB_SZ(o_xpos);  // per body: xpos[3], -, xquat[4] (two ds_read/write_b128)
+  float* s_xmat = lds + HB_SZ(o_xmat);
+  float* s_xipos = lds + HB_SZ(o_xipos);
+  float* s_xanchor = lds + HB_SZ(o_xanchor);
+  float* s_xaxis = lds + HB_SZ(o_xaxis);
+  float* s_cinert = lds + HB_SZ(o_cinert);
+  float* s_if = lds + HB_SZ(o_crb);   // per body: composite inertia[10] | cfrc[6]
+  float* s_va = lds + HB_SZ(o_cvel);  // per body: cvel[6] | cacc[6]
+  float* s_con = lds + HB_SZ(o_con);
+  float* s_C = lds + HB_SZ(o_C);
+  float* s_efc = lds + HB_SZ(o_efc);  // per-row meta, stride kNR; dead once the row quantities are in registers
+  float* s_W = lds + HB_SZ(o_efc);    // W = L^-1 D^-1/2, [32][33], aliases the row meta
+  float* s_force = lds + HB_SZ(o_force);
   const float* s_gquat = lds + M.o_gquat;  // general collision only: world orientation of every geom
   float* s_meta = lds + M.o_meta;          // general variants: per-row (R, K imp (pos - margin), B, -)
   float* s_AR = lds + M.o_AR;              // PGS on several row groups only: the matrix AR, [kNR][kNR]
@@ -1116,8 +1119,8 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     ctrl_mode = __hip_atomic_load(P.lane_ring->mode + ring, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ctrl_t0 = __hip_atomic_load(P.lane_ring->t0 + ring, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (ctrl_mode != 2 && lane < M.nu) ctrl_pf = ctrl_src[(size_t)env * M.nu + lane];
-  float* gstate = P.state + (size_t)env * M.nstate;
+  if (ctrl_mode != 2 && lane < HB_SZ(nu)) ctrl_pf = ctrl_src[(size_t)env * HB_SZ(nu) + lane];
+  float* gstate = P.state + (size_t)env * HB_SZ(nstate);
   // (coherent: the state record changes hands between the slow lane's kernel and a small launch running beside it - agent-scope accesses
   // that go past the non-coherent caches, entry by entry; everywhere else ordinary loads and stores)
   auto ld_state = [&](int i) -> float { return coherent ? __hip_atomic_load(gstate + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gstate[i]; };
@@ -1136,7 +1139,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   unsigned long long stamps_[16] = {0};
 #endif
   // pad pairs behind the matrix (zero, one: what the dense views read outside the sparsity pattern / beyond nv); never written again
-  if (lane < 4) s_qLD[M.nM + (lane >> 1)][lane & 1] = (lane >> 1) == 1 ? 1.f : 0.f;
+  if (lane < 4) s_qLD[HB_SZ(nM) + (lane >> 1)][lane & 1] = (lane >> 1) == 1 ? 1.f : 0.f;
   // the dof vectors are read 32 wide (dot32): their tails beyond nv stay zero for the whole launch
   if (lane < 32) { s_v0[lane] = 0.f; s_v1[lane] = 0.f; s_v2[lane] = 0.f; }
   gsync();
@@ -1166,19 +1169,19 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     int pf_gbody = 0;
     V3 pf_gpos = {0.f, 0.f, 0.f};
     Q4 pf_gquat = {1.f, 0.f, 0.f, 0.f};
-    if (lane < M.ngeom) { pf_gbody = M.geom_bodyid[lane]; pf_gpos = ld3(M.geom_pos + 3 * lane); pf_gquat = ldq(M.geom_quat + 4 * lane); }
+    if (lane < HB_SZ(ngeom)) { pf_gbody = M.geom_bodyid[lane]; pf_gpos = ld3(M.geom_pos + 3 * lane); pf_gquat = ldq(M.geom_quat + 4 * lane); }
     float4 pf_dA = {0.f, 0.f, 0.f, 0.f}, pf_dB = pf_dA;
     if (lane < nv) { pf_dA = M.drec[3 * lane]; pf_dB = M.drec[3 * lane + 1]; }
     HB_STAMP(0);
     // ---------------------------------------------------------------- controls
     if (ctrl_mode == 2) {
       int idx = 1 + ctrl_t0 + step + 1000 * (P.env_offset + env);
-      for (int i = lane; i < M.nu; i += kGroup) s_ctrl[i] = 2.f * halton(idx, i + 2) - 1.f;
+      for (int i = lane; i < HB_SZ(nu); i += kGroup) s_ctrl[i] = 2.f * halton(idx, i + 2) - 1.f;
     } else {
-      const float* c = ctrl_src + (ctrl_mode == 1 ? (size_t)step * P.n_env * M.nu : 0) + (size_t)env * M.nu;
-      if (lane < M.nu) s_ctrl[lane] = ctrl_pf;
-      for (int i = lane + kGroup; i < M.nu; i += kGroup) s_ctrl[i] = c[i];
-      if (ctrl_mode == 1 && step + 1 < nsteps && lane < M.nu) ctrl_pf = c[(size_t)P.n_env * M.nu + lane];
+      const float* c = ctrl_src + (ctrl_mode == 1 ? (size_t)step * P.n_env * HB_SZ(nu) : 0) + (size_t)env * HB_SZ(nu);
+      if (lane < HB_SZ(nu)) s_ctrl[lane] = ctrl_pf;
+      for (int i = lane + kGroup; i < HB_SZ(nu); i += kGroup) s_ctrl[i] = c[i];
+      if (ctrl_mode == 1 && step + 1 < nsteps && lane < HB_SZ(nu)) ctrl_pf = c[(size_t)P.n_env * HB_SZ(nu) + lane];
     }
     // ---------------------------------------------------------------- mj_checkPos / mj_checkVel
     {
@@ -1194,7 +1197,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         ctrl_zeroed = true;
         if (P_xfrc) for (int i = lane; i < 6 * nb; i += kGroup) P_xfrc[(size_t)env * nb * 6 + i] = 0.f;
       }
-      if (ctrl_zeroed) for (int i = lane; i < M.nu; i += kGroup) s_ctrl[i] = 0.f;
+      if (ctrl_zeroed) for (int i = lane; i < HB_SZ(nu); i += kGroup) s_ctrl[i] = 0.f;
     }
     gsync();
 
@@ -1292,7 +1295,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     gsync();
     HB_STAMP(2);
     // geoms: world position and z axis
-    if (lane < M.ngeom) {
+    if (lane < HB_SZ(ngeom)) {
       const int g = lane, b = pf_gbody;
       st3(s_gpos + 3 * g, ld3(s_xpq + kXpqStride * b) + mrot(s_xmat + 9 * b, pf_gpos));
       Q4 q = qmul(ldq(s_xpq + kXpqStride * b + 4), pf_gquat);
@@ -1300,7 +1303,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       if constexpr (COLL != 0) stq(lds + M.o_gquat + 4 * g, q);
     }
     // ---------------------------------------------------------------- mj_comPos
-    for (int t = 0; t < M.ntree; t++) {
+    for (int t = 0; t < HB_SZ(ntree); t++) {
       V3 acc = {0.f, 0.f, 0.f};
       if (bl && __float_as_int(q1.y) == t) acc = ld3(s_xipos + 3 * myb) * mymass;
       float im = M.tree_invmass[t];
@@ -1352,7 +1355,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       reinterpret_cast<float4*>(s_cdof + kCdofStride * d)[1] = {lin.x, lin.y, lin.z, 0.f};
     }
     // fixed tendon lengths
-    for (int t = lane; t < M.ntendon; t += kGroup) {
+    for (int t = lane; t < HB_SZ(ntendon); t += kGroup) {
       float len = 0.f;
       // the first four wraps come in one record (no dependent table walk); longer tendons finish from the wrap tables
       const float4 tc = M.trec[3 * t], tq = M.trec[3 * t + 1];
@@ -1469,7 +1472,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         }
         if (P.sensor_flags & 4) { for (int i = lane; i < nq; i += kGroup) so[o + i] = s_qpos[i]; o += nq; }
         if (P.sensor_flags & 1) { for (int i = lane; i < nv; i += kGroup) so[o + i] = s_qvel[i]; o += nv; }
-        if (P.sensor_flags & 2) for (int i = lane; i < M.nu; i += kGroup) so[o + i] = s_ctrl[i];
+        if (P.sensor_flags & 2) for (int i = lane; i < HB_SZ(nu); i += kGroup) so[o + i] = s_ctrl[i];
       }
       if (P.sensor_tree >= 0) {
         const int t = P.sensor_tree;
@@ -1505,7 +1508,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // first round of mass-matrix entry words, requested ahead of the sweep that produces what they index
     int pf_pk = 0;
     float2 pf_ad = {0.f, 0.f};
-    if (lane < M.nM) { pf_pk = M.mrec[lane]; pf_ad = M.mdiag[lane]; }
+    if (lane < HB_SZ(nM)) { pf_pk = M.mrec[lane]; pf_ad = M.mdiag[lane]; }
     gsync();
     // mj_crb and the mj_rne backward pass share one sweep up the tree: children into parents (pull form)
     for (int L = M.nlevel - 2; L >= 1; L--) {
@@ -1529,11 +1532,11 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     // dof records of the bias pass and the actuator records: requested here, used behind the mass matrix
     float4 pf_bA = {0.f, 0.f, 0.f, 0.f}, pf_bB = pf_bA, pf_bC = pf_bA, pf_a0 = pf_bA, pf_a1 = pf_bA, pf_a2 = pf_bA, pf_a3 = pf_bA;
     if (lane < nv) { pf_bA = M.drec[3 * lane]; pf_bB = M.drec[3 * lane + 1]; pf_bC = M.drec[3 * lane + 2]; }
-    if (lane < M.nu) { const float4 HB_CONST* AR4 = M.arec + (size_t)lane * 4; pf_a0 = AR4[0]; pf_a1 = AR4[1]; pf_a2 = AR4[2]; pf_a3 = AR4[3]; }
-    for (int e = lane; e < M.nM; e += kGroup) {
+    if (lane < HB_SZ(nu)) { const float4 HB_CONST* AR4 = M.arec + (size_t)lane * 4; pf_a0 = AR4[0]; pf_a1 = AR4[1]; pf_a2 = AR4[2]; pf_a3 = AR4[3]; }
+    for (int e = lane; e < HB_SZ(nM); e += kGroup) {
       const int pk = pf_pk;  // i | j << 8 | body(i) << 16
       const float2 ad = pf_ad;  // (armature, damping) on diagonal entries, 0 elsewhere
-      if (e + kGroup < M.nM) { pf_pk = M.mrec[e + kGroup]; pf_ad = M.mdiag[e + kGroup]; }  // the next round's, one ahead
+      if (e + kGroup < HB_SZ(nM)) { pf_pk = M.mrec[e + kGroup]; pf_ad = M.mdiag[e + kGroup]; }  // the next round's, one ahead
       const int i = pk & 255, j = (pk >> 8) & 255, bi = pk >> 16;
       float buf[6], cd[6];
       ld_cdof(s_cdof, i, cd);
@@ -1574,7 +1577,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     }
     gsync();
     if (!(M_disableflags & (1 << 10))) {
-      for (int a = lane; a < M.nu; a += kGroup) {
+      for (int a = lane; a < HB_SZ(nu); a += kGroup) {
         if (a != lane) { const float4 HB_CONST* AR4 = M.arec + (size_t)a * 4; pf_a0 = AR4[0]; pf_a1 = AR4[1]; pf_a2 = AR4[2]; pf_a3 = AR4[3]; }  // (more than 64 actuators)
         const int qa = __float_as_int(pf_a0.z), da = __float_as_int(pf_a0.w);
         float ctrl = s_ctrl[a];
@@ -1639,12 +1642,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       int nlist = 0;
       {
         float4 n0 = M.crec[3 * (size_t)lane], n1 = M.crec[3 * (size_t)lane + 1];
-        for (int p0 = 0; p0 < M.npair; p0 += kGroup) {
+        for (int p0 = 0; p0 < HB_SZ(npair); p0 += kGroup) {
           const int p = p0 + lane;
           const float4 c0 = n0, c1 = n1;
-          if (p0 + kGroup < M.npair) { const float4 HB_CONST* N = M.crec + 3 * (size_t)(p + kGroup); n0 = N[0]; n1 = N[1]; }
+          if (p0 + kGroup < HB_SZ(npair)) { const float4 HB_CONST* N = M.crec + 3 * (size_t)(p + kGroup); n0 = N[0]; n1 = N[1]; }
           bool pass = false;
-          if (p < M.npair) {
+          if (p < HB_SZ(npair)) {
             const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y), t1 = __float_as_int(c0.z) & 255;
             const V3 dp = ld3(s_gpos + 3 * g2) - ld3(s_gpos + 3 * g1);
             if (t1 == 0) pass = dot(dp, ld3(s_gaxis + 3 * g1)) <= c0.w + c1.y;
@@ -2797,7 +2800,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       const float h = M.timestep;
       for (int i = lane; i < nv; i += kGroup) s_qvel[i] += h * s_v2[i];
       gsync();
-      for (int j = lane; j < M.njnt; j += kGroup) {
+      for (int j = lane; j < HB_SZ(njnt); j += kGroup) {
         int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
         if (M.jnt_type[j] == 0) {
           for (int i = 0; i < 3; i++) s_qpos[qa + i] += h * s_qvel[da + i];
@@ -2832,6 +2835,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   if (status && lane == 0) atomicOr(P.status + env, status);
 }
 
+#undef HB_SZ
 // PGS instantiations: dense order 28 (nv <= 28: the 27-dof humanoid; M^-1 by elimination on the matrix cores) and 32 (sparse L'DL)
 // (224 registers instead of the 229 the allocator would take - two values spilled - so that beside two of its waves a SIMD has 64
 // registers left: what the closed loop's policy kernel runs in, hb_policy_lean_kernel; amdgpu_num_vgpr counts per half of the file)
@@ -2839,6 +2843,8 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) vo
 // the small instantiation (31 rows, 12 contacts: three waves per SIMD); single-step launches only - an overflowing env-step leaves without
 // having written anything, and the slow lane (hb_step_kernel, lane_mode 3) steps that env from then on
 __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 1>(Mp, P, nsteps); }
+// (the single-step lean kernel with the sizes and the LDS layout of the reference's 27-dof humanoid as constants)
+__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 1, 1>(Mp, P, nsteps); }
 __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 2>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 3) void hb_step_small_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 1>(Mp, P, nsteps); }
 // The slow lane: a few blocks walk every segment's list of slow envs and step them with the full instantiation.  A slow env-step is
@@ -3958,7 +3964,7 @@ namespace hb {
 // the lean instantiations apply when the launch has none of the optional inputs / outputs (HB_LEAN=0: never)
 static bool lean_launch(const BatchPtrs& P, bool with_qfrc = false) {
   static const bool lean_on = !(getenv("HB_LEAN") && atoi(getenv("HB_LEAN")) == 0);
-  return lean_on && P.lean_ok && !P.xfrc && (with_qfrc || !P.qfrc_out) && !P.sensor_out && !P.qpos_out && !P.qvel_out && !P.diag_qacc && !P.diag_force && !P.diag_contact && !P.dr && !P.env_mask &&
+  return lean_on && (P.lean_ok & 1) && !P.xfrc && (with_qfrc || !P.qfrc_out) && !P.sensor_out && !P.qpos_out && !P.qvel_out && !P.diag_qacc && !P.diag_force && !P.diag_contact && !P.dr && !P.env_mask &&
          P.integrate && !P.lane;
 }
 static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int solver, int nv, size_t shmem, const BatchPtrs& P, int nsteps, hipStream_t stream) {
@@ -3974,7 +3980,8 @@ static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int sol
   }
   else if (solver == 2) hipLaunchKernelGGL(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (nv <= 28) {
-    if (nsteps == 1 && lean_launch(P)) hipLaunchKernelGGL(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) hipLaunchKernelGGL(hb_step_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (nsteps == 1 && lean_launch(P)) hipLaunchKernelGGL(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (lean_launch(P, true)) hipLaunchKernelGGL(hb_step_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   }

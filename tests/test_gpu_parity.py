@@ -286,10 +286,16 @@ def test_lean_kernels_are_bit_identical_to_the_full_ones(hbmod, humanoid_model, 
         a = hbmod.Batch(m, n, gpu); b = hbmod.Batch(m, n, gpu)
         a.reset(perturb=True); b.reset(perturb=True)
         a.rollout_halton(200); b.rollout_halton(200)          # lean in both: onto the floor
-        a.rollout(ctrl)                                         # lean
+        c = hbmod.Batch(m, n, gpu)
+        c.reset(perturb=True); c.rollout_halton(200)
+        a.rollout(ctrl)                                         # lean, multi-step (LEAN = 2)
         q = b.rollout(ctrl, want_qpos=True)                     # full kernel (qpos_out)
-        sa, sb = a.get_state(hbmod.STATE_INTEGRATION), b.get_state(hbmod.STATE_INTEGRATION)
-        assert np.array_equal(sa, sb)
+        for t in range(T):
+            c.step(ctrl[t])                                     # single steps: the leanest kernel - for this model's PGS the size-specialised hb_step_h27_kernel
+        sa, sb, sc = a.get_state(hbmod.STATE_INTEGRATION), b.get_state(hbmod.STATE_INTEGRATION), c.get_state(hbmod.STATE_INTEGRATION)
+        assert np.array_equal(sa, sb) and np.array_equal(sc, sb)
+        assert np.array_equal(c.status(), b.status())
+        c.close()
         assert np.array_equal(q[-1], sb[:, 1:1 + m.nq])
         for x, y in zip(a.counts(), b.counts()):
             assert np.array_equal(x, y)

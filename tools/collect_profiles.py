@@ -10,9 +10,9 @@ WRITE_SIZE, bytes = counter * 1024, and FETCH_SIZE doubled (gfx950 reports half 
 import collections, csv, glob, json, os, shutil, sys
 
 def is_step(name):
-    """the benchmark's single-step launches: the lean instantiation of the PGS step kernel (hb_step_kernel before it existed, and in
+    """the benchmark's single-step launches: the size-specialised lean instantiation of the PGS step kernel (hb_step_lean_kernel for other models; hb_step_kernel before they existed, and in
     launches that carry an optional input or output)"""
-    return "hb_step_lean_kernel(" in name or "hb_step_kernel(" in name
+    return "hb_step_h27_kernel(" in name or "hb_step_lean_kernel(" in name or "hb_step_kernel(" in name
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
@@ -68,7 +68,7 @@ for d in ("prof_fetch", "prof_write", "prof_sq", "prof_lds", "prof_mfma", "prof_
         v = steady(v)
         counters[k] = {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "dispatches": len(v)}
 n_env = 4096
-out = {"kernel": "hb_step_lean_kernel", "launch": "4096 envs (one wave each), 1 step per launch, bench.py workload",
+out = {"kernel": "hb_step_h27_kernel", "launch": "4096 envs (one wave each), 1 step per launch, bench.py workload",
        "avg_launch_ns_kernel_trace": avg_ns, "kernel_trace_calls": calls,
        "kernel_trace_by_grid": {str(g): {"calls": len(v), "avg_ns": sum(v) / len(v)} for g, v in by_grid.items()},
        "dispatch_meta": meta, "counters_per_launch": counters}

@@ -7,7 +7,7 @@ names = ["prologue (tables, state, SGPR spill stores)", "ctrl+check", "kinematic
 def read(prefix, k):
     fs = glob.glob(os.path.join(src, "%s%d" % (prefix, k), "*counter_collection.csv")) + glob.glob(os.path.join(src, "%s%d" % (prefix, k), "*", "*counter_collection.csv"))
     acc = {}
-    rows = [r for f in fs for r in csv.DictReader(open(f)) if ("hb_step_kernel(" in r["Kernel_Name"] or "hb_step_lean_kernel(" in r["Kernel_Name"]) and int(r["Grid_Size"]) == 4096 * 64]
+    rows = [r for f in fs for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("hb_step_kernel(", "hb_step_lean_kernel(", "hb_step_h27_kernel(")) and int(r["Grid_Size"]) == 4096 * 64]
     # the last 12 dispatches per counter are the probed ones (the pre-roll is one multi-step dispatch of the same kernel)
     by = {}
     for r in rows: by.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))

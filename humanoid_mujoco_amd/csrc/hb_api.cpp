@@ -231,17 +231,6 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   return true;
   };
   if (!lay(dm)) return false;
-  {
-    // the size-specialised kernel (hb_step_h27_kernel): the model's sizes and the layout just computed against the compile-time mirror
-    constexpr SizedModel z = kSizedHumanoid27;
-    D.sized_h27 = dm.variant == 0 && dm.solver == 0 && m.nq == z.nq && nv == z.nv && m.nu == z.nu && nb == z.nbody && m.njnt == z.njnt && m.ngeom == z.ngeom &&
-                  m.ntendon == z.ntendon && m.nM == z.nM && dm.ntree == z.ntree && m.npair == z.npair && dm.nstate == z.nstate && dm.cstride == z.cstride &&
-                  dm.o_qpos == z.o_qpos && dm.o_qvel == z.o_qvel && dm.o_warm == z.o_warm && dm.o_ctrl == z.o_ctrl && dm.o_gpos == z.o_gpos && dm.o_gaxis == z.o_gaxis &&
-                  dm.o_scom == z.o_scom && dm.o_cdof == z.o_cdof && dm.o_qLD == z.o_qLD && dm.o_smooth == z.o_smooth && dm.o_vec0 == z.o_vec0 && dm.o_vec1 == z.o_vec1 &&
-                  dm.o_vec2 == z.o_vec2 && dm.o_tenlen == z.o_tenlen && dm.o_xpos == z.o_xpos && dm.o_xmat == z.o_xmat && dm.o_xipos == z.o_xipos &&
-                  dm.o_xanchor == z.o_xanchor && dm.o_xaxis == z.o_xaxis && dm.o_cinert == z.o_cinert && dm.o_crb == z.o_crb && dm.o_cvel == z.o_cvel &&
-                  dm.o_con == z.o_con && dm.o_C == z.o_C && dm.o_efc == z.o_efc && dm.o_force == z.o_force && dm.lds_floats == z.lds_floats;
-  }
 
   std::vector<int> mdense((size_t)32 * 32, m.nM);
   for (int i = 0; i < 32; i++) mdense[(size_t)i * 32 + i] = m.nM + 1;
@@ -573,6 +562,17 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     if (!lay(sm, true)) return false;
     if (hipMalloc((void**)&D.d_dm_small, sizeof(DevModel)) != hipSuccess || hipMemcpy(D.d_dm_small, &sm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMalloc failed for the device model"; return false; }
     D.small_lds_floats = sm.lds_floats;
+  }
+  {
+    // the size-specialised kernel (hb_step_h27_kernel): the model's sizes and the layout just computed against the compile-time mirror
+    constexpr SizedModel z = kSizedHumanoid27;
+    D.sized_h27 = dm.variant == 0 && dm.solver == 0 && m.nq == z.nq && nv == z.nv && m.nu == z.nu && nb == z.nbody && m.njnt == z.njnt && m.ngeom == z.ngeom &&
+                  m.ntendon == z.ntendon && m.nM == z.nM && dm.ntree == z.ntree && m.npair == z.npair && dm.nlevel == z.nlevel && dm.nlimcand == z.nlimcand && dm.nstate == z.nstate && dm.cstride == z.cstride &&
+                  dm.o_qpos == z.o_qpos && dm.o_qvel == z.o_qvel && dm.o_warm == z.o_warm && dm.o_ctrl == z.o_ctrl && dm.o_gpos == z.o_gpos && dm.o_gaxis == z.o_gaxis &&
+                  dm.o_scom == z.o_scom && dm.o_cdof == z.o_cdof && dm.o_qLD == z.o_qLD && dm.o_smooth == z.o_smooth && dm.o_vec0 == z.o_vec0 && dm.o_vec1 == z.o_vec1 &&
+                  dm.o_vec2 == z.o_vec2 && dm.o_tenlen == z.o_tenlen && dm.o_xpos == z.o_xpos && dm.o_xmat == z.o_xmat && dm.o_xipos == z.o_xipos &&
+                  dm.o_xanchor == z.o_xanchor && dm.o_xaxis == z.o_xaxis && dm.o_cinert == z.o_cinert && dm.o_crb == z.o_crb && dm.o_cvel == z.o_cvel &&
+                  dm.o_con == z.o_con && dm.o_C == z.o_C && dm.o_efc == z.o_efc && dm.o_force == z.o_force && dm.lds_floats == z.lds_floats;
   }
   D.fast_lds_floats = 0;
   if (dm.variant == 2 || dm.variant == 3) {
@@ -1152,6 +1152,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
     }
   }
   if (hb_debug()) fprintf(stderr, "[hb] LDS per env: %d bytes (%d envs per CU)\n", dm.lds_floats * 4, 160 * 1024 / (dm.lds_floats * 4));
+  if (hb_debug()) fprintf(stderr, "[hb] tree levels %d, limit candidates %d, trees %d; size-specialised kernel: %s\n", dm.nlevel, dm.nlimcand, dm.ntree, b->D.sized_h27 ? "yes" : "no");
   if (hb_debug() && b->D.fast_lds_floats) fprintf(stderr, "[hb] LDS per env of the staged step's fast kernel: %d bytes (%d envs per CU)\n", b->D.fast_lds_floats * 4, 160 * 1024 / (b->D.fast_lds_floats * 4));
   if (ok && dm.lds_floats * 4 > 64 * 1024) ok = set_step_lds_limit(dm.lds_floats * 4) == hipSuccess;
   if (!ok) { set_err(err, err_sz, "device allocation failed"); hb_batch_free(b); return nullptr; }

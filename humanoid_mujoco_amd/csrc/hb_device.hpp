@@ -267,15 +267,15 @@ struct StageBufs {
 // signature takes it (the host compares sizes AND the layout it computed itself, field by field: build_device_model); every other
 // model takes the generic kernels.
 struct SizedModel {
-  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, ntree, npair, nstate, cstride;
+  int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, ntree, npair, nlevel, nlimcand, nstate, cstride;
   int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qLD, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
   int o_xpos, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cvel;
   int o_con, o_C, o_efc, o_force, lds_floats;
 };
 // the classic layout (variant 0, full capacity) as build_device_model's lay() computes it
-constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int ntendon, int nM, int ntree, int npair) {
+constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int ntendon, int nM, int ntree, int npair, int nlevel, int nlimcand) {
   SizedModel z{};
-  z.nq = nq; z.nv = nv; z.nu = nu; z.nbody = nbody; z.njnt = njnt; z.ngeom = ngeom; z.ntendon = ntendon; z.nM = nM; z.ntree = ntree; z.npair = npair;
+  z.nq = nq; z.nv = nv; z.nu = nu; z.nbody = nbody; z.njnt = njnt; z.ngeom = ngeom; z.ntendon = ntendon; z.nM = nM; z.ntree = ntree; z.npair = npair; z.nlevel = nlevel; z.nlimcand = nlimcand;
   z.nstate = 1 + nq + 2 * nv; z.cstride = 33;
   int off = 0;
   auto up = [](int n) { return (n + 3) & ~3; };
@@ -295,7 +295,7 @@ constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, in
   z.lds_floats = endA > off ? endA : off;
   return z;
 }
-constexpr SizedModel kSizedHumanoid27 = sized_model(28, 27, 21, 17, 22, 20, 2, 243, 1, 159);
+constexpr SizedModel kSizedHumanoid27 = sized_model(28, 27, 21, 17, 22, 20, 2, 243, 1, 159, /*tree levels*/ 7, /*limit candidates*/ 46);
 
 // LDS of hb_pose_kernel in floats: qpos | body poses (12 floats each, kXpqStride) | geom position, z axis, quaternion | the work lists
 __host__ __device__ inline int pose_lds_floats(int nq, int nb, int ngeom) {

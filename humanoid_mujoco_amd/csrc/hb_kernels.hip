@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   (void)to_slow_lane;
   // per-env model parameters (domain randomisation), nullable; offsets per DomainLayout
   const float* dr = P_dr ? P_dr + (size_t)env * P_dr_stride : nullptr;
-  const DomainLayout DL = domain_layout(HB_SZ(nbody), HB_SZ(nv), M.nlimcand, HB_SZ(nu), M.nhfielddata);
+  const DomainLayout DL = domain_layout(HB_SZ(nbody), HB_SZ(nv), HB_SZ(nlimcand), HB_SZ(nu), M.nhfielddata);
   const int nv = HB_SZ(nv), nq = HB_SZ(nq), nb = HB_SZ(nbody), cs = HB_SZ(cstride);
 
   float* s_qpos = lds + HB_SZ(o_qpos);
@@ -1258,7 +1258,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
     }
     gsync();
-    for (int r = 0, span = 1; span < M.nlevel - 1 || r == 0; r++, span <<= 1) {
+    for (int r = 0, span = 1; span < HB_SZ(nlevel) - 1 || r == 0; r++, span <<= 1) {
       const int anc = r == 0 ? myp : (r == 1 ? myanc2 : (r == 2 ? myanc4 : myanc8));
       float4 pp4 = {0.f, 0.f, 0.f, 0.f}, pq4 = {1.f, 0.f, 0.f, 0.f};
       if (bl) { const float4* Pp = reinterpret_cast<const float4*>(s_xpq + kXpqStride * anc); pp4 = Pp[0]; pq4 = Pp[1]; }
@@ -1420,7 +1420,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       Op[2] = {mycacc[2], mycacc[3], mycacc[4], mycacc[5]};
     }
     gsync();
-    for (int r = 0, span = 1; span < M.nlevel - 1 || r == 0; r++, span <<= 1) {
+    for (int r = 0, span = 1; span < HB_SZ(nlevel) - 1 || r == 0; r++, span <<= 1) {
       const int anc = r == 0 ? myp : (r == 1 ? myanc2 : (r == 2 ? myanc4 : myanc8));
       float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
       if (bl && anc != 0) { const float4* Pp = reinterpret_cast<const float4*>(s_va + 12 * anc); a0 = Pp[0]; a1 = Pp[1]; a2 = Pp[2]; }
@@ -1511,7 +1511,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     if (lane < HB_SZ(nM)) { pf_pk = M.mrec[lane]; pf_ad = M.mdiag[lane]; }
     gsync();
     // mj_crb and the mj_rne backward pass share one sweep up the tree: children into parents (pull form)
-    for (int L = M.nlevel - 2; L >= 1; L--) {
+    for (int L = HB_SZ(nlevel) - 2; L >= 1; L--) {
       if (mylevel == L && mycn > 0) {
         float4* Op = reinterpret_cast<float4*>(s_if + kIfStride * myb);
         float4 acc[4] = {Op[0], Op[1], Op[2], Op[3]};
@@ -1746,13 +1746,13 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       // ---- general form: limits, then contacts of dimension 1 / 3 / 4 / 6 (one row, or 2 (dim - 1) pyramid rows); what the solver
       // needs of a row besides its Jacobian is written once, here: s_meta[row] = (R, K imp (pos - margin), B, -)
       if (constraints_on && !(M_disableflags & (1 << 3))) {
-        for (int c0 = 0; c0 < M.nlimcand; c0 += kGroup) {
+        for (int c0 = 0; c0 < HB_SZ(nlimcand); c0 += kGroup) {
           const int c = c0 + lane;
           bool active = false;
           float dist = 0.f, margin = 0.f;
           int side = 0, kind = 0, id = 0;
           float4 l0 = {0.f, 0.f, 0.f, 0.f}, l1 = l0, l2 = l0, l3 = l0;
-          if (c < M.nlimcand) {
+          if (c < HB_SZ(nlimcand)) {
             const float4 HB_CONST* LR = M.lrec + (size_t)c * 4;
             l0 = LR[0]; l1 = LR[1]; l2 = LR[2]; l3 = LR[3];
             kind = __float_as_int(l0.x); id = __float_as_int(l0.y); side = __float_as_int(l0.z);
@@ -1868,13 +1868,13 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
     } else {
     // (a) limits: 2 candidates (lower, upper) per limited joint / tendon, in constraint order
     if (constraints_on && !(M_disableflags & (1 << 3))) {
-      for (int c0 = 0; c0 < M.nlimcand; c0 += kGroup) {
+      for (int c0 = 0; c0 < HB_SZ(nlimcand); c0 += kGroup) {
         int c = c0 + lane;
         bool active = false;
         float dist = 0.f, margin = 0.f;
         int side = 0, kind = 0, id = 0;
         float4 l0 = {0.f, 0.f, 0.f, 0.f}, l1 = l0, l2 = l0, l3 = l0;
-        if (c < M.nlimcand) {
+        if (c < HB_SZ(nlimcand)) {
           const float4 HB_CONST* LR = M.lrec + (size_t)c * 4;  // the candidate's whole record in one round trip
           l0 = LR[0]; l1 = LR[1]; l2 = LR[2]; l3 = LR[3];
           kind = __float_as_int(l0.x); id = __float_as_int(l0.y); side = __float_as_int(l0.z);

@@ -992,7 +992,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   const int P_dr_stride = LEAN ? 0 : P.dr_stride;
   const unsigned char* const P_env_mask = LEAN ? nullptr : P.env_mask;
   const int P_integrate = LEAN ? 1 : P.integrate;
-  static_assert(SIZED == 0 || (SOLVER == 0 && NDENSE == 28 && COLL == 0 && NG == 1 && SMALL == 0), "the size-specialised instantiation: classic PGS kernel of dense order 28");
+  static_assert(SIZED == 0 || (NDENSE == 28 && COLL == 0 && NG == 1 && SMALL == 0), "the size-specialised instantiations: classic kernels of dense order 28");
   static_assert(NG == 1 || SOLVER == 2 || (COLL == 1 && NG == kPgsGroups && DEFER == 0), "PGS on more than one row group: the general variant's kPgsGroups instantiation");
   static_assert(SMALL == 0 || (SOLVER == 0 && NDENSE <= 28 && COLL == 0 && NG == 1 && DEFER == 0), "the small instantiation: classic PGS kernel of dense order <= 28");
   constexpr int kNR = SMALL ? kSmallNefcMax : (NG == 1 ? kNefcMax : 64 * NG);  // row capacity of this instantiation
@@ -2845,6 +2845,7 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) vo
 __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 1>(Mp, P, nsteps); }
 // (the single-step lean kernel with the sizes and the LDS layout of the reference's 27-dof humanoid as constants)
 __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 1, 1>(Mp, P, nsteps); }
+__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_h27_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 2, 1>(Mp, P, nsteps); }
 __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 2>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 3) void hb_step_small_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 1>(Mp, P, nsteps); }
 // The slow lane: a few blocks walk every segment's list of slow envs and step them with the full instantiation.  A slow env-step is
@@ -2903,6 +2904,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen28_kernel(const D
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
 // lean instantiations (step_body's LEAN: no optional inputs / outputs in the launch) of the kernels the plain step API spends its time in
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 1, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 2>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2, 0, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 0, 1>(Mp, P, nsteps); }
@@ -3974,7 +3976,8 @@ static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int sol
   else if (variant == 1) hipLaunchKernelGGL(hb_step_gen_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (variant == 3) hipLaunchKernelGGL(hb_step_gen_big_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (solver == 2 && nv <= 28) {
-    if (nsteps == 1 && lean_launch(P)) hipLaunchKernelGGL(hb_step_newton28_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) hipLaunchKernelGGL(hb_step_newton28_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (nsteps == 1 && lean_launch(P)) hipLaunchKernelGGL(hb_step_newton28_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (lean_launch(P, true)) hipLaunchKernelGGL(hb_step_newton28_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   }
@@ -3982,6 +3985,7 @@ static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int sol
   else if (nv <= 28) {
     if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) hipLaunchKernelGGL(hb_step_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (nsteps == 1 && lean_launch(P)) hipLaunchKernelGGL(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (lean_launch(P, true) && (P.lean_ok & 2)) hipLaunchKernelGGL(hb_step_h27_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (lean_launch(P, true)) hipLaunchKernelGGL(hb_step_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   }

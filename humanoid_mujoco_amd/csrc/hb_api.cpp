@@ -1143,6 +1143,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
     ok = ok && hipMalloc((void**)&sb.result, (size_t)n_env * kWorkMax * 4 * sizeof(float4)) == hipSuccess;
     ok = ok && hipMemset(sb.nwork, 0, (size_t)n_env * sizeof(int)) == hipSuccess;
     sb.nq = dm.nq; sb.nv = dm.nv; sb.nu = dm.nu;
+    sb.no_mesh = (b->model->m.nmesh == 0 && !(getenv("HB_NARROW_PRIM") && atoi(getenv("HB_NARROW_PRIM")) == 0)) ? 1 : 0;
     sb.pose_lds = pose_lds_floats(dm.nq, dm.nbody, dm.ngeom) * (int)sizeof(float);
     if ((dm.variant == 1 || b->D.d_dm_fast) && !(getenv("HB_FASTPASS") && atoi(getenv("HB_FASTPASS")) == 0)) {
       ok = ok && hipMalloc((void**)&sb.defer, (size_t)n_env * sizeof(int)) == hipSuccess;

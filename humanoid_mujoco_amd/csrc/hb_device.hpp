@@ -258,6 +258,7 @@ struct StageBufs {
   int fast_lds;             // its dynamic LDS bytes
   int* defer;               // [n_env]
   int rerun;                // set by launch_step for the second pass
+  int no_mesh;              // the model has no mesh geoms: the narrowphase launch is hb_narrow_prim_kernel
 };
 
 // ---- Size-specialised instantiation of the classic PGS step kernel (step_body's SIZED) ---------------------------------------------

@@ -749,7 +749,7 @@ __device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const fl
 // pass (3) for one work item: pair p (sub-item `sub` of the sub-grid rmin, cmin, ncols for a height-field pair) -> n contacts (0..2).
 // MODE 0: all of it.  MODE 1 (hb_pose_kernel): everything but the portal search; returns whether the item needs one (then n = 0).
 // MODE 2 (hb_narrow_kernel): an item MODE 1 said needs the portal search.
-template <int MODE>
+template <int MODE, int MESH = 1>
 __device__ __forceinline__ int eval_work_item(DevModelRef M, const float* hdata_all, bool have, int p, int sub, int rmin, int cmin, int ncols, float loz,
                                               const float* s_gpos, const float* s_gaxis, const float* s_gquat, ConOut& co0, ConOut& co1, int& n, V3& hint) {
   float4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
@@ -796,7 +796,7 @@ __device__ __forceinline__ int eval_work_item(DevModelRef M, const float* hdata_
 #pragma unroll
           for (int b = 0; b < 3; b++) o2.mat[3 * a + b] = hm[a] * m2[b] + hm[3 + a] * m2[3 + b] + hm[6 + a] * m2[6 + b];  // hm' m2
         o2.type = t2; o2.r = r2; o2.h = l2; o2.margin = margin;
-        set_mesh(M, o2, g2);
+        if constexpr (MESH != 0) set_mesh(M, o2, g2);
         o1.type = -1; o1.pos = {0.f, 0.f, 0.f}; o1.r = o1.h = o1.margin = 0.f; o1.vert = M.mesh_start; o1.nbr = M.mesh_nbr;
 #pragma unroll
         for (int a = 0; a < 9; a++) o1.mat[a] = 0.f;
@@ -816,7 +816,7 @@ __device__ __forceinline__ int eval_work_item(DevModelRef M, const float* hdata_
           n = min(max(total - 2 * sub, 0), 2);
         }
       }
-    } else if (t1 == 7 || t2 == 7) {
+    } else if (MESH != 0 && (t1 == 7 || t2 == 7)) {
       // mjc_Convex: both geoms in the world frame, each inflated by half the margin
       q2mat(o1.mat, ldq(s_gquat + 4 * g1));
       q2mat(o2.mat, ldq(s_gquat + 4 * g2));
@@ -852,7 +852,7 @@ __device__ __forceinline__ int eval_work_item(DevModelRef M, const float* hdata_
   if (mpr_kind) {
     float depth;
     V3 dir, vec;
-    const bool hit = mpr_penetration(o1, o2, M.mpr_iterations, (double)M.mpr_tolerance, depth, dir, vec);
+    const bool hit = mpr_penetration<MESH>(o1, o2, M.mpr_iterations, (double)M.mpr_tolerance, depth, dir, vec);
     if (mpr_kind == 1) {
       if (hit && depth >= 2.220446e-16f) {
         co0.dist = -depth;
@@ -3062,7 +3062,8 @@ __global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, 
 // there are as many of them as the chip holds at once; packing the searches of all envs densely into waves (a prefix sum over the
 // per-env counts, 64 / 16 / 4 searches per wave, one kernel per kind of search) measured slower: a wave's time is set by its
 // longest search and the divergence between its lanes, not by how many lanes it has.
-__global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp, const BatchPtrs P) {
+template <int MESH>
+__device__ __forceinline__ void narrow_body(const DevModel* Mp, const BatchPtrs& P) {
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
   const int lane = threadIdx.x;
   // heavy first (BatchPtrs::order2: the envs of this launch sorted by the time their wave took in an earlier step): the launch ends
@@ -3084,7 +3085,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp
   ConOut co0, co1;
   int n;
   V3 hint;
-  eval_work_item<2>(M, hdata, have, p, it.z & 0xffff, it.w & 0xffff, it.w >> 16, it.z >> 16, 0.f, g, g + 3 * ng, g + 6 * ng, co0, co1, n, hint);
+  eval_work_item<2, MESH>(M, hdata, have, p, it.z & 0xffff, it.w & 0xffff, it.w >> 16, it.z >> 16, 0.f, g, g + 3 * ng, g + 6 * ng, co0, co1, n, hint);
   if (have) {
     float4* R = P.stage.result + ((size_t)env * kWorkMax + w) * 4;
     R[0] = {co0.dist, co0.pos.x, co0.pos.y, co0.pos.z};
@@ -3094,6 +3095,9 @@ __global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp
   }
   if (chunk == 0 && lane == 0) P.counts[kCountStride * (size_t)env + 7] = (int)min(255ull, (__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
+__global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<1>(Mp, P); }
+// a model without mesh geoms (configs[4]: capsules and spheres over the height field's prisms): no hull climb in the kernel
+__global__ __launch_bounds__(kGroup, 3) void hb_narrow_prim_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<0>(Mp, P); }
 
 // ---- MJPC task cost on the recorded read-out rows --------------------------------------------------------------
 // mjpc::Norm (mujoco_mpc/mjpc/norm.cc:50-208), value only
@@ -4008,7 +4012,8 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
     if (P.sensor_out) Q.sensor_out = P.sensor_out + (size_t)t * P.n_env * P.sensor_stride;
     (void)hipGetLastError();
     hipLaunchKernelGGL(hb_pose_kernel, dim3(P.nblk), dim3(kGroup), (size_t)P.stage.pose_lds, stream, M_dev, Q);
-    hipLaunchKernelGGL(hb_narrow_kernel, dim3(P.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
+    if (Q.stage.no_mesh) hipLaunchKernelGGL(hb_narrow_prim_kernel, dim3(P.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
+    else hipLaunchKernelGGL(hb_narrow_kernel, dim3(P.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (variant == 1 && Q.stage.defer) {

@@ -151,6 +151,8 @@ __device__ __forceinline__ void climb(const CObj& o, Climb& c) {
   }
 }
 // the point farthest along dir (unit)
+// (MESH = 0: an instantiation for models without mesh geoms - the hull climb, its loads and its registers are not in the kernel)
+template <int MESH = 1>
 __device__ __forceinline__ V3d ccd_support(const CObj& o, V3d dir) {
   if (o.type < 0) {
     V3d best = widen(o.p0), c;
@@ -166,13 +168,13 @@ __device__ __forceinline__ V3d ccd_support(const CObj& o, V3d dir) {
   V3d res;
   if (o.type == 2) res = ld * (double)o.r;
   else if (o.type == 3) { res = ld * (double)o.r; res.z += ld.z >= 0.0 ? (double)o.h : -(double)o.h; }
-  else {
+  else if constexpr (MESH != 0) {
     Climb c;
     c.ld = ld;
     climb_start(o, c);
     climb(o, c);
     res = widen(c.best);
-  }
+  } else res = ld * (double)o.r;  // (never reached: the host takes this instantiation only for a model without meshes)
   return world_point(o, ld, res);
 }
 
@@ -211,10 +213,11 @@ __device__ __forceinline__ int plane_hull(const CObj& o, V3 ppos, V3 normal, flo
 }
 
 struct CSup { V3d v, v1; };  // a point of the Minkowski difference obj1 - obj2 and its witness on obj1 (the one on obj2 is v1 - v)
+template <int MESH = 1>
 __device__ __forceinline__ CSup mpr_support(const CObj& o1, const CObj& o2, V3d dir) {
   CSup s;
-  s.v1 = ccd_support(o1, dir);
-  const V3d w2 = ccd_support(o2, dir * -1.0);
+  s.v1 = ccd_support<MESH>(o1, dir);
+  const V3d w2 = ccd_support<MESH>(o2, dir * -1.0);
   s.v = s.v1 - w2;
   return s;
 }
@@ -231,6 +234,7 @@ __device__ __forceinline__ void mpr_expand_portal(const CSup& P0, CSup& P1, CSup
 }
 
 // ccdMPRPenetration: true (and depth, dir from obj1 into obj2, pos) when the objects intersect
+template <int MESH = 1>
 __device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, int max_iterations, double tolerance, float& depth_out, V3& pdir_out, V3& pos_out) {
   CSup P0, P1, P2, P3, v4;
   const V3d origin = {0.0, 0.0, 0.0};
@@ -241,7 +245,7 @@ __device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, 
   P0.v = P0.v1 - ccd_center(o2);
   if (ccd_eq(P0.v.x, 0.0) && ccd_eq(P0.v.y, 0.0) && ccd_eq(P0.v.z, 0.0)) P0.v.x += HB_CCD_EPS * 10.0;
   V3d dir = normalized(P0.v * -1.0);
-  P1 = mpr_support(o1, o2, dir);
+  P1 = mpr_support<MESH>(o1, o2, dir);
   double dt = dot(P1.v, dir);
   if (ccd_is_zero(dt) || dt < 0.0) return false;
   dir = cross(P0.v, P1.v);
@@ -254,14 +258,14 @@ __device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, 
     return true;
   }
   dir = normalized(dir);
-  P2 = mpr_support(o1, o2, dir);
+  P2 = mpr_support<MESH>(o1, o2, dir);
   dt = dot(P2.v, dir);
   if (ccd_is_zero(dt) || dt < 0.0) return false;
   dir = normalized(cross(P1.v - P0.v, P2.v - P0.v));
   if (dot(dir, P0.v) > 0.0) { const CSup t = P1; P1 = P2; P2 = t; dir = dir * -1.0; }
   for (int guard = 0;; guard++) {
     if (guard > 1000) return false;
-    P3 = mpr_support(o1, o2, dir);
+    P3 = mpr_support<MESH>(o1, o2, dir);
     dt = dot(P3.v, dir);
     if (ccd_is_zero(dt) || dt < 0.0) return false;
     bool cont = false;
@@ -280,7 +284,7 @@ __device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, 
     dir = mpr_portal_dir(P1, P2, P3);
     dt = dot(dir, P1.v);
     if (ccd_is_zero(dt) || dt > 0.0) break;
-    v4 = mpr_support(o1, o2, dir);
+    v4 = mpr_support<MESH>(o1, o2, dir);
     dt = dot(v4.v, dir);
     if (!(ccd_is_zero(dt) || dt > 0.0) || mpr_reach_tolerance(P1, P2, P3, v4, dir, tolerance)) return false;
     mpr_expand_portal(P0, P1, P2, P3, v4);
@@ -288,7 +292,7 @@ __device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, 
   // ---- findPenetr
   for (int it = 0;; it++) {
     dir = mpr_portal_dir(P1, P2, P3);
-    v4 = mpr_support(o1, o2, dir);
+    v4 = mpr_support<MESH>(o1, o2, dir);
     if (mpr_reach_tolerance(P1, P2, P3, v4, dir, tolerance) || it > max_iterations) {
       const V3d w = closest_on_triangle(origin, P1.v, P2.v, P3.v);
       depth = sqrt(dot(w, w));

@@ -565,8 +565,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   }
   {
     // the size-specialised kernel (hb_step_h27_kernel): the model's sizes and the layout just computed against the compile-time mirror
-    constexpr SizedModel z = kSizedHumanoid27;
-    D.sized_h27 = dm.variant == 0 && m.nq == z.nq && nv == z.nv && m.nu == z.nu && nb == z.nbody && m.njnt == z.njnt && m.ngeom == z.ngeom &&
+    const SizedModel z = dm.variant == 1 ? kSizedHumanoid27V1 : kSizedHumanoid27;
+    D.sized_h27 = (dm.variant == 0 || (dm.variant == 1 && dm.solver == 0)) && dm.o_gquat == z.o_gquat && dm.o_meta == z.o_meta && m.nq == z.nq && nv == z.nv && m.nu == z.nu && nb == z.nbody && m.njnt == z.njnt && m.ngeom == z.ngeom &&
                   m.ntendon == z.ntendon && m.nM == z.nM && dm.ntree == z.ntree && m.npair == z.npair && dm.nlevel == z.nlevel && dm.nlimcand == z.nlimcand && dm.nstate == z.nstate && dm.cstride == z.cstride &&
                   dm.o_qpos == z.o_qpos && dm.o_qvel == z.o_qvel && dm.o_warm == z.o_warm && dm.o_ctrl == z.o_ctrl && dm.o_gpos == z.o_gpos && dm.o_gaxis == z.o_gaxis &&
                   dm.o_scom == z.o_scom && dm.o_cdof == z.o_cdof && dm.o_qLD == z.o_qLD && dm.o_smooth == z.o_smooth && dm.o_vec0 == z.o_vec0 && dm.o_vec1 == z.o_vec1 &&

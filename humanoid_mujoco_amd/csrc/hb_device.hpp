@@ -271,15 +271,17 @@ struct SizedModel {
   int nq, nv, nu, nbody, njnt, ngeom, ntendon, nM, ntree, npair, nlevel, nlimcand, nstate, cstride;
   int o_qpos, o_qvel, o_warm, o_ctrl, o_gpos, o_gaxis, o_scom, o_cdof, o_qLD, o_smooth, o_vec0, o_vec1, o_vec2, o_tenlen;
   int o_xpos, o_xmat, o_xipos, o_xanchor, o_xaxis, o_cinert, o_crb, o_cvel;
-  int o_con, o_C, o_efc, o_force, lds_floats;
+  int o_con, o_C, o_efc, o_force, o_gquat, o_meta, lds_floats;
 };
 // the classic layout (variant 0, full capacity) as build_device_model's lay() computes it
-constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int ntendon, int nM, int ntree, int npair, int nlevel, int nlimcand) {
+constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int ntendon, int nM, int ntree, int npair, int nlevel, int nlimcand, int variant = 0) {
   SizedModel z{};
   z.nq = nq; z.nv = nv; z.nu = nu; z.nbody = nbody; z.njnt = njnt; z.ngeom = ngeom; z.ntendon = ntendon; z.nM = nM; z.ntree = ntree; z.npair = npair; z.nlevel = nlevel; z.nlimcand = nlimcand;
   z.nstate = 1 + nq + 2 * nv; z.cstride = 33;
   int off = 0;
   auto up = [](int n) { return (n + 3) & ~3; };
+  z.o_gquat = 0; z.o_meta = 0;
+  if (variant) { z.o_gquat = off; off += up(4 * ngeom); }  // (general collision: world orientation of every geom)
   z.o_qpos = off; off += up(nq); z.o_qvel = off; off += up(nv); z.o_warm = off; off += up(nv); z.o_ctrl = off; off += up(nu > 1 ? nu : 1);
   z.o_gpos = off; off += up(3 * ngeom); z.o_gaxis = off; off += up(3 * ngeom); z.o_scom = off; off += up(3 * (ntree > 1 ? ntree : 1)); z.o_cdof = off; off += up(12 * nv);
   z.o_qLD = off; off += up(2 * nM + 4); z.o_smooth = off; off += up(nv);
@@ -292,11 +294,14 @@ constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, in
   off = region;
   z.o_con = off; off += up(kNconMax * kConStride); z.o_C = off; off += up((kNefcMax + 1) * 33);
   z.o_efc = off; off += up(13 * kNefcMax > 32 * 36 ? 13 * kNefcMax : 32 * 36);
+  if (variant == 1) { z.o_meta = off; off += up(64 * kMetaStride); }
   z.o_force = off; off += up(kGroup > kNefcMax ? kGroup : kNefcMax);
   z.lds_floats = endA > off ? endA : off;
   return z;
 }
 constexpr SizedModel kSizedHumanoid27 = sized_model(28, 27, 21, 17, 22, 20, 2, 243, 1, 159, /*tree levels*/ 7, /*limit candidates*/ 46);
+// the same humanoid on a height field (configs[4]; general collision, PGS: the variant-1 layout of the staged step's fast kernel)
+constexpr SizedModel kSizedHumanoid27V1 = sized_model(28, 27, 21, 17, 22, 20, 2, 243, 1, 159, 7, 46, /*variant*/ 1);
 
 // LDS of hb_pose_kernel in floats: qpos | body poses (12 floats each, kXpqStride) | geom position, z axis, quaternion | the work lists
 __host__ __device__ inline int pose_lds_floats(int nq, int nb, int ngeom) {

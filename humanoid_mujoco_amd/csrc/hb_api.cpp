@@ -48,6 +48,7 @@ struct DeviceModel {
   DevModel* d_dm_fast = nullptr;  // variant 2 only: the same model with the variant-1 LDS layout (fast step kernel of the staged step)
   int fast_lds_floats = 0;
   bool sized_h27 = false;  // sizes and LDS layout equal kSizedHumanoid27's: the size-specialised step kernel applies
+  bool sized_team = false; // the fast layout equals kSizedTeamV1's
   DevModel* d_dm_small = nullptr;  // classic PGS models of dense order <= 28: the small layout (hb_step_small_kernel), else null
   int small_lds_floats = 0;
   // observation order tables (device pointers): joint order and, when it exists, actuator order (hb_env_config.obs_actuator_order)
@@ -581,6 +582,16 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     if (!lay(fm)) return false;
     if (hipMalloc((void**)&D.d_dm_fast, sizeof(DevModel)) != hipSuccess || hipMemcpy(D.d_dm_fast, &fm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMalloc failed for the device model"; return false; }
     D.fast_lds_floats = fm.lds_floats;
+    {
+      const SizedModel z = kSizedTeamV1;  // the robot's fast layout against its compile-time mirror (hb_step_newton_gen20_team_kernel)
+      D.sized_team = dm.variant == 2 && fm.o_gquat == z.o_gquat && fm.o_meta == z.o_meta && m.nq == z.nq && nv == z.nv && m.nu == z.nu && nb == z.nbody && m.njnt == z.njnt &&
+                     m.ngeom == z.ngeom && m.ntendon == z.ntendon && m.nM == z.nM && fm.ntree == z.ntree && m.npair == z.npair && fm.nlevel == z.nlevel && fm.nlimcand == z.nlimcand &&
+                     fm.nstate == z.nstate && fm.cstride == z.cstride && fm.o_qpos == z.o_qpos && fm.o_qvel == z.o_qvel && fm.o_warm == z.o_warm && fm.o_ctrl == z.o_ctrl &&
+                     fm.o_gpos == z.o_gpos && fm.o_gaxis == z.o_gaxis && fm.o_scom == z.o_scom && fm.o_cdof == z.o_cdof && fm.o_qLD == z.o_qLD && fm.o_smooth == z.o_smooth &&
+                     fm.o_vec0 == z.o_vec0 && fm.o_vec1 == z.o_vec1 && fm.o_vec2 == z.o_vec2 && fm.o_tenlen == z.o_tenlen && fm.o_xpos == z.o_xpos && fm.o_xmat == z.o_xmat &&
+                     fm.o_xipos == z.o_xipos && fm.o_xanchor == z.o_xanchor && fm.o_xaxis == z.o_xaxis && fm.o_cinert == z.o_cinert && fm.o_crb == z.o_crb && fm.o_cvel == z.o_cvel &&
+                     fm.o_con == z.o_con && fm.o_C == z.o_C && fm.o_efc == z.o_efc && fm.o_force == z.o_force && fm.lds_floats == z.lds_floats;
+    }
   }
   return true;
 }
@@ -721,7 +732,8 @@ BatchPtrs make_ptrs(hb_batch* b) {
   if (const char* sp = getenv("HB_STOP_PHASE")) P.stop_phase = atoi(sp);
 #endif
   P.stage = b->stage;
-  P.lean_ok = (b->D.dm.disableflags == 0 ? 1 : 0) | (b->D.sized_h27 && !(getenv("HB_SIZED") && atoi(getenv("HB_SIZED")) == 0) ? 2 : 0);
+  const bool sized_on = !(getenv("HB_SIZED") && atoi(getenv("HB_SIZED")) == 0);
+  P.lean_ok = (b->D.dm.disableflags == 0 ? 1 : 0) | (b->D.sized_h27 && sized_on ? 2 : 0) | (b->D.sized_team && sized_on ? 4 : 0);
   if (b->diag) P.stage.dm_fast = nullptr;  // the diagnostic buffers are laid out for the kernel of the model's own variant
   if (b->xfrc_std > 0.f && b->d_xfrc) {
     const double rate = b->xfrc_rate > 0.f ? std::exp(-b->model->m.timestep / b->xfrc_rate) : 0.0;  // trajectory.cc:149-150
@@ -1153,7 +1165,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
     }
   }
   if (hb_debug()) fprintf(stderr, "[hb] LDS per env: %d bytes (%d envs per CU)\n", dm.lds_floats * 4, 160 * 1024 / (dm.lds_floats * 4));
-  if (hb_debug()) fprintf(stderr, "[hb] tree levels %d, limit candidates %d, trees %d; size-specialised kernel: %s\n", dm.nlevel, dm.nlimcand, dm.ntree, b->D.sized_h27 ? "yes" : "no");
+  if (hb_debug()) fprintf(stderr, "[hb] tree levels %d, limit candidates %d, trees %d; size-specialised kernel: %s\n", dm.nlevel, dm.nlimcand, dm.ntree, (b->D.sized_h27 || b->D.sized_team) ? "yes" : "no");
   if (hb_debug() && b->D.fast_lds_floats) fprintf(stderr, "[hb] LDS per env of the staged step's fast kernel: %d bytes (%d envs per CU)\n", b->D.fast_lds_floats * 4, 160 * 1024 / (b->D.fast_lds_floats * 4));
   if (ok && dm.lds_floats * 4 > 64 * 1024) ok = set_step_lds_limit(dm.lds_floats * 4) == hipSuccess;
   if (!ok) { set_err(err, err_sz, "device allocation failed"); hb_batch_free(b); return nullptr; }

@@ -301,6 +301,8 @@ constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, in
 }
 constexpr SizedModel kSizedHumanoid27 = sized_model(28, 27, 21, 17, 22, 20, 2, 243, 1, 159, /*tree levels*/ 7, /*limit candidates*/ 46);
 // the same humanoid on a height field (configs[4]; general collision, PGS: the variant-1 layout of the staged step's fast kernel)
+// the reference's own robot (simulation/assets/world.xml + humanoid.xml: 18 dofs, 13 geoms) on the variant-1 layout of its fast Newton kernel
+constexpr SizedModel kSizedTeamV1 = sized_model(19, 18, 12, 15, 13, 13, 0, 117, 1, 37, /*tree levels*/ 5, /*limit candidates*/ 24, /*variant*/ 1);
 constexpr SizedModel kSizedHumanoid27V1 = sized_model(28, 27, 21, 17, 22, 20, 2, 243, 1, 159, 7, 46, /*variant*/ 1);
 
 // LDS of hb_pose_kernel in floats: qpos | body poses (12 floats each, kXpqStride) | geom position, z axis, quaternion | the work lists
@@ -379,7 +381,7 @@ struct BatchPtrs {
   LaneRing* lane_ring;        // the step calls the GPU has got to and their controls
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
   int lean_ok;                // bit 0: the model's options allow the lean instantiations (mjOption.disableflags == 0); bit 1: its sizes and LDS
-                              // layout are kSizedHumanoid27's (the size-specialised instantiation)
+                              // layout are kSizedHumanoid27's (the size-specialised instantiations); bit 2: its fast layout is kSizedTeamV1's
   int stop_phase;             // diagnostic builds only: 0 = off (HB_STOP_PHASE in the environment, read at every launch)
   StageBufs stage;
 };

@@ -971,7 +971,7 @@ __device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, 
 // overflow into.  Both: an env-step whose qacc comes out bad (mj_checkAcc: reset, second forward pass with a narrowphase of its own) is
 // flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
 // (sizes and LDS offsets: the model's, or - SIZED - the constants of kSizedHumanoid27, hb_device.hpp)
-#define HB_SZ(f) (SIZED ? (COLL ? kSizedHumanoid27V1.f : kSizedHumanoid27.f) : M.f)
+#define HB_SZ(f) (SIZED ? (NDENSE == 20 ? kSizedTeamV1.f : COLL ? kSizedHumanoid27V1.f : kSizedHumanoid27.f) : M.f)
 template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0, int LEAN = 0, int SIZED = 0>
 __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps_in, int env_fixed = -1, int ring = -1) {
   const int nsteps = LEAN == 1 ? 1 : nsteps_in;  // (LEAN == 1 is launched for single steps only: the step API; rollouts take LEAN == 2)
@@ -992,7 +992,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   const int P_dr_stride = LEAN ? 0 : P.dr_stride;
   const unsigned char* const P_env_mask = LEAN ? nullptr : P.env_mask;
   const int P_integrate = LEAN ? 1 : P.integrate;
-  static_assert(SIZED == 0 || (NDENSE == 28 && NG == 1 && SMALL == 0 && (COLL == 0 || SOLVER == 0)), "the size-specialised instantiations: kernels of dense order 28 on the classic or the variant-1 layout");
+  static_assert(SIZED == 0 || (NG == 1 && SMALL == 0 && ((NDENSE == 28 && (COLL == 0 || SOLVER == 0)) || (NDENSE == 20 && COLL == 1 && SOLVER == 2))), "the size-specialised instantiations: the humanoid (classic or variant-1 layout) and the robot (Newton, variant-1 layout)");
   static_assert(NG == 1 || SOLVER == 2 || (COLL == 1 && NG == kPgsGroups && DEFER == 0), "PGS on more than one row group: the general variant's kPgsGroups instantiation");
   static_assert(SMALL == 0 || (SOLVER == 0 && NDENSE <= 28 && COLL == 0 && NG == 1 && DEFER == 0), "the small instantiation: classic PGS kernel of dense order <= 28");
   constexpr int kNR = SMALL ? kSmallNefcMax : (NG == 1 ? kNefcMax : 64 * NG);  // row capacity of this instantiation
@@ -2907,6 +2907,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_kernel(const 
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 1, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 2>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2, 0, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_team_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 0, 1, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2, 0, 1, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 0, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
@@ -4033,7 +4034,8 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
       Q.stage.rerun = 1;
     } else if (variant == 2 && Q.stage.dm_fast) {
       // most env-steps fit the one-group Newton instantiation (two waves per SIMD); the four-group kernel then steps the rest
-      if (nv <= 20 && lean_launch(Q)) hipLaunchKernelGGL(hb_step_newton_gen20_lean_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      if (nv <= 20 && lean_launch(Q) && (Q.lean_ok & 4)) hipLaunchKernelGGL(hb_step_newton_gen20_team_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      else if (nv <= 20 && lean_launch(Q)) hipLaunchKernelGGL(hb_step_newton_gen20_lean_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       else if (nv <= 20) hipLaunchKernelGGL(hb_step_newton_gen20_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       else hipLaunchKernelGGL(hb_step_newton_gen28_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       e = hipGetLastError();

@@ -6,7 +6,7 @@ HOST_SRCS := $(CSRC)/hb_api.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/mo
 HIP_SRCS := $(CSRC)/hb_kernels.hip
 HDRS := $(wildcard $(CSRC)/*.hpp) include/hb.h
 LIB := humanoid_mujoco_amd/libhb.so
-FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-result -ffp-contract=on $(EXTRA)
+FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-result -ffp-contract=on -fno-slp-vectorize -fno-vectorize $(EXTRA)
 
 all: $(LIB) build/hb_compile build/hb_testspeed oracle
 

@@ -178,7 +178,8 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   auto take = [&](int n) { int o = off; off += (n + 3) & ~3; return o; };
   // row stride of C: 33 (K = 32 for the matrix cores plus a pad column); the big Newton layout stores J rows only as wide as its dense
   // order (NDENSE + 1: 21 for the reference's 18-dof robot, else 29): 256 rows of 33 floats would be 34 KB per env
-  dm.cstride = dm.variant == 2 ? (nv <= 20 ? 21 : 29) : 33;
+  // (variant 1 with the Newton solver is the fast layout of a variant-2 model: its one-group Newton kernel reads J rows like the big one)
+  dm.cstride = (dm.variant == 2 || (dm.variant == 1 && dm.solver == 2)) ? (nv <= 20 ? 21 : 29) : 33;
   dm.o_gquat = dm.variant ? take(4 * m.ngeom) : 0;
   dm.o_qpos = take(m.nq); dm.o_qvel = take(nv); dm.o_warm = take(nv); dm.o_ctrl = take(std::max(1, m.nu));
   dm.o_gpos = take(3 * m.ngeom); dm.o_gaxis = take(3 * m.ngeom); dm.o_scom = take(3 * std::max(1, dm.ntree)); dm.o_cdof = take(12 * nv);  /* angular[3], -, linear[3], -, pad[4] per dof (kCdofStride: conflict-free b128 reads) */

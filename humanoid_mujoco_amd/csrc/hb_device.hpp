@@ -274,10 +274,10 @@ struct SizedModel {
   int o_con, o_C, o_efc, o_force, o_gquat, o_meta, lds_floats;
 };
 // the classic layout (variant 0, full capacity) as build_device_model's lay() computes it
-constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int ntendon, int nM, int ntree, int npair, int nlevel, int nlimcand, int variant = 0) {
+constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, int ngeom, int ntendon, int nM, int ntree, int npair, int nlevel, int nlimcand, int variant = 0, int cstride = 33) {
   SizedModel z{};
   z.nq = nq; z.nv = nv; z.nu = nu; z.nbody = nbody; z.njnt = njnt; z.ngeom = ngeom; z.ntendon = ntendon; z.nM = nM; z.ntree = ntree; z.npair = npair; z.nlevel = nlevel; z.nlimcand = nlimcand;
-  z.nstate = 1 + nq + 2 * nv; z.cstride = 33;
+  z.nstate = 1 + nq + 2 * nv; z.cstride = cstride;
   int off = 0;
   auto up = [](int n) { return (n + 3) & ~3; };
   z.o_gquat = 0; z.o_meta = 0;
@@ -292,7 +292,7 @@ constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, in
   z.o_cvel = off; off += up(12 * nbody);
   const int endA = off;
   off = region;
-  z.o_con = off; off += up(kNconMax * kConStride); z.o_C = off; off += up((kNefcMax + 1) * 33);
+  z.o_con = off; off += up(kNconMax * kConStride); z.o_C = off; off += up((kNefcMax + 1) * cstride);
   z.o_efc = off; off += up(13 * kNefcMax > 32 * 36 ? 13 * kNefcMax : 32 * 36);
   if (variant == 1) { z.o_meta = off; off += up(64 * kMetaStride); }
   z.o_force = off; off += up(kGroup > kNefcMax ? kGroup : kNefcMax);
@@ -302,7 +302,7 @@ constexpr SizedModel sized_model(int nq, int nv, int nu, int nbody, int njnt, in
 constexpr SizedModel kSizedHumanoid27 = sized_model(28, 27, 21, 17, 22, 20, 2, 243, 1, 159, /*tree levels*/ 7, /*limit candidates*/ 46);
 // the same humanoid on a height field (configs[4]; general collision, PGS: the variant-1 layout of the staged step's fast kernel)
 // the reference's own robot (simulation/assets/world.xml + humanoid.xml: 18 dofs, 13 geoms) on the variant-1 layout of its fast Newton kernel
-constexpr SizedModel kSizedTeamV1 = sized_model(19, 18, 12, 15, 13, 13, 0, 117, 1, 37, /*tree levels*/ 5, /*limit candidates*/ 24, /*variant*/ 1);
+constexpr SizedModel kSizedTeamV1 = sized_model(19, 18, 12, 15, 13, 13, 0, 117, 1, 37, /*tree levels*/ 5, /*limit candidates*/ 24, /*variant*/ 1, /*J row stride of a Newton kernel of dense order 20*/ 21);
 constexpr SizedModel kSizedHumanoid27V1 = sized_model(28, 27, 21, 17, 22, 20, 2, 243, 1, 159, 7, 46, /*variant*/ 1);
 
 // LDS of hb_pose_kernel in floats: qpos | body poses (12 floats each, kXpqStride) | geom position, z axis, quaternion | the work lists

@@ -3,7 +3,7 @@ HIPCC ?= hipcc
 ARCH ?= gfx950
 CSRC := humanoid_mujoco_amd/csrc
 HOST_SRCS := $(CSRC)/hb_api.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp $(CSRC)/mesh.cpp
-HIP_SRCS := $(CSRC)/hb_kernels.hip
+HIP_SRCS := $(CSRC)/hb_step.hip $(CSRC)/hb_narrow.hip $(CSRC)/hb_env.hip
 HDRS := $(wildcard $(CSRC)/*.hpp) include/hb.h
 LIB := humanoid_mujoco_amd/libhb.so
 FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-result -ffp-contract=on -fno-slp-vectorize -fno-vectorize $(EXTRA)
@@ -18,25 +18,27 @@ build/obj/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p build/obj
 	g++ $(HOSTFLAGS) -c $< -o $@
 
-build/obj/hb_kernels.o: $(HIP_SRCS) $(HDRS)
+# one object per kernel translation unit (make -j builds them side by side; an edit rebuilds its own unit only)
+HIP_OBJS := $(patsubst $(CSRC)/%.hip,build/obj/%.o,$(HIP_SRCS))
+build/obj/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/obj
-	$(HIPCC) $(FLAGS) -c -x hip $(HIP_SRCS) -o $@
+	$(HIPCC) $(FLAGS) -c -x hip $< -o $@
 
-$(LIB): $(HOST_OBJS) build/obj/hb_kernels.o
+$(LIB): $(HOST_OBJS) $(HIP_OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
 
 # diagnostic build with per-phase cycle stamps (never used for timing or by the product)
 build/libhb_stamps.so: $(HOST_SRCS) $(HIP_SRCS) $(HDRS)
 	@mkdir -p build/obj_stamps
 	for f in $(HOST_SRCS); do g++ $(HOSTFLAGS) -DHB_STAMPS -c $$f -o build/obj_stamps/$$(basename $$f .cpp).o || exit 1; done
-	$(HIPCC) $(FLAGS) -DHB_STAMPS -c -x hip $(HIP_SRCS) -o build/obj_stamps/hb_kernels.o
+	for f in $(HIP_SRCS); do $(HIPCC) $(FLAGS) -DHB_STAMPS -c -x hip $$f -o build/obj_stamps/$$(basename $$f .hip).o || exit 1; done
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ build/obj_stamps/*.o
 
 # diagnostic build: section cycles inside the Newton iterations (tools/gpu_newton_bench.py --probe)
 build/libhb_probe.so: $(HOST_SRCS) $(HIP_SRCS) $(HDRS)
 	@mkdir -p build/obj_probe
 	for f in $(HOST_SRCS); do g++ $(HOSTFLAGS) -DHB_STAMPS -c $$f -o build/obj_probe/$$(basename $$f .cpp).o || exit 1; done
-	$(HIPCC) $(FLAGS) -DHB_STAMPS -DHB_PROBE_NEWTON -c -x hip $(HIP_SRCS) -o build/obj_probe/hb_kernels.o
+	for f in $(HIP_SRCS); do $(HIPCC) $(FLAGS) -DHB_STAMPS -DHB_PROBE_NEWTON -c -x hip $$f -o build/obj_probe/$$(basename $$f .hip).o || exit 1; done
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ build/obj_probe/*.o
 
 build/hb_compile: tools/hb_compile.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp $(CSRC)/mesh.cpp $(HDRS)

@@ -1,5 +1,5 @@
 // hb_api.cpp — the C-ABI of libhb.so (include/hb.h): model handles, device model tables,
-// batches of environments on one GPU, and the launch plumbing around hb_kernels.hip.
+// batches of environments on one GPU, and the launch plumbing around the kernel translation units (hb_step.hip, hb_narrow.hip, hb_env.hip).
 //
 // Host C++ only; no PyTorch.  One hb_batch owns one HIP stream and all device memory of its
 // envs; the model is immutable and shareable (reference ownership rules: SURVEY.md §8b).

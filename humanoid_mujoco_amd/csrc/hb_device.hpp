@@ -1,5 +1,5 @@
 // hb_device.hpp — device-side model tables and batch buffers (fp32), shared by the host
-// runtime (hb_api.cpp) and the kernels (hb_kernels.hip).
+// runtime (hb_api.cpp) and the kernel translation units (hb_step.hip, hb_step_duo.hip, hb_narrow.hip, hb_env.hip).
 //
 // The model is replicated read-only per device as two flat arrays (int, float); DevModel holds
 // typed pointers into them plus the per-env LDS layout.  All tables are small (a few KB) and

@@ -1,4 +1,4 @@
-// hb_launch.hpp — host-callable launchers implemented in hb_kernels.hip
+// hb_launch.hpp — host-callable launchers implemented in the kernel translation units (hb_step.hip, hb_narrow.hip, hb_env.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "hb_device.hpp"
@@ -8,6 +8,8 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
 hipError_t launch_step_small(const DevModel* M_small, int lds_floats, const BatchPtrs& P, hipStream_t stream);
 // the slow lane of two-lane stepping: `blocks` workgroups per segment walk the lists of P.lane_list with the full classic PGS instantiation (lane_mode 3)
 hipError_t launch_step_slow(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int blocks, int nseg, hipStream_t stream);
+// the pose + narrowphase launches of one staged step (hb_narrow.hip)
+hipError_t launch_pose_narrow(const DevModel* M_dev, const BatchPtrs& Q, hipStream_t stream);
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
                         int env_offset, hipStream_t stream, float quat_perturb = 0.f);
 hipError_t launch_envrand_reset(const DevModel& M, const EnvRand& R, const EnvRandState& S, const int* episode, const uint8_t* mask, int n_env, int env_offset,

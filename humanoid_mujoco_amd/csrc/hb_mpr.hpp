@@ -4,7 +4,7 @@
 // statement for statement so that the discrete decisions of the portal search agree wherever the fp32 poses allow.
 // One LANE runs one (pair, prism) test: the loops below are per lane and divergent; a mesh's support function is a
 // climb along the hull's edge graph (16-byte records in the model tables, served by L1 / L2) from a cube map of start vertices.
-// Included by hb_kernels.hip only (uses its V3 / Q4 helpers).
+// Included by hb_kcommon.hpp only (uses its V3 / Q4 helpers).
 #pragma once
 
 namespace hb {

@@ -1,4 +1,6 @@
-// hb_kernels.hip — the fused physics-step kernel for gfx950 (MI355X).
+// hb_step.hip — the fused physics-step kernel for gfx950 (MI355X).
+// (one of four kernel translation units: hb_step.hip - this file, the fused step kernels; hb_narrow.hip - the staged step's pose and
+// narrowphase kernels; hb_env.hip - env adapter, policy, task costs, reset; hb_step_duo.hip - two envs per wave)
 //
 // One 64-lane wavefront advances ONE environment through the whole mj_step pipeline
 // (reference API: simulation/mujoco/include/mujoco/mujoco.h:120 mj_step; stage list
@@ -15,951 +17,11 @@
 //   collision                                     lanes = candidate geom pairs
 //   constraint rows, half-solve, AR, PGS          lane  = constraint row
 //   dof vectors                                   lanes = dofs
-#include <hip/hip_runtime.h>
-#include "hb_device.hpp"
+#include "hb_kcommon.hpp"
+#include "hb_collide.hpp"
+#include "hb_launch.hpp"
 
 namespace hb {
-
-// Diagnostic build only (-DHB_STAMPS): per-phase cycle stamps of the last step, written to
-// BatchPtrs::diag_contact's tail is NOT used; stamps go to their own buffer P.stamps.
-#ifdef HB_STAMPS
-// (P.stop_phase = k > 0: the wave leaves at stamp k - 1 without writing anything - tools/gpu_phase_instructions.py counts a launch's instructions
-// up to every stamp with the PMC counters and differences them)
-#define HB_STAMP(i) do { if (lane == 0 && P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps_[i] = t_; } if (P.stop_phase == (i) + 1) return; } while (0)
-#else
-#define HB_STAMP(i) do {} while (0)
-#endif
-#if defined(HB_STAMPS) && defined(HB_PROBE_NEWTON)
-// diagnostic: cycles per section of the Newton solve, accumulated over the iterations of one step (slots 0..7 of the stamps)
-#define HB_NP(i) do { if (P.stamps) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); np_acc[i] += t_ - np_t; np_t = t_; } } while (0)
-#else
-#define HB_NP(i) do {} while (0)
-#endif
-#define HB_MINVAL 1e-15f
-#define HB_MAXVAL 1e10f
-#define HB_MINIMP 0.0001f
-#define HB_MAXIMP 0.9999f
-
-// wave-level ordering point for LDS traffic between lanes of one wavefront.  A wavefront's DS
-// instructions execute in issue order, so no s_barrier is needed; the fences stop the compiler
-// from moving LDS accesses across this point.
-__device__ __forceinline__ void gsync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-}
-
-__device__ __forceinline__ float rdlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
-// v_writelane_b32 (clang has no builtin for it; bind the LLVM intrinsic by name)
-extern "C" __device__ int hb_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-// sum over the 64 lanes, identical (and scalar) in every lane: four DPP steps inside each row of 16,
-// then the four row sums through scalar registers; no LDS traffic.
-__device__ __forceinline__ float wave_sum(float v) {
-  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);  // row_half_mirror
-  v += dpp_mov<0x140>(v);  // row_mirror
-  return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
-}
-// value known to be identical in every lane -> tell the compiler (scalar register, scalar branches)
-__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float uniformf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ V3 ld3(const float HB_CONST* p) { return {p[0], p[1], p[2]}; }
-#endif
-__device__ __forceinline__ void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ __forceinline__ V3 normalized(V3 v, float* n_out = nullptr) {
-  float n = sqrtf(dot(v, v));
-  if (n_out) *n_out = n;
-  if (n < HB_MINVAL) return {1.f, 0.f, 0.f};
-  float inv = 1.f / n;
-  return v * inv;
-}
-
-struct Q4 { float w, x, y, z; };
-__device__ __forceinline__ Q4 ldq(const float* p) { return {p[0], p[1], p[2], p[3]}; }
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ Q4 ldq(const float HB_CONST* p) { return {p[0], p[1], p[2], p[3]}; }
-#endif
-__device__ __forceinline__ void stq(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
-__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
-  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
-}
-__device__ __forceinline__ Q4 qconj(Q4 q) { return {q.w, -q.x, -q.y, -q.z}; }
-__device__ __forceinline__ Q4 qnormalize(Q4 q) {
-  const float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
-  if (n2 < HB_MINVAL * HB_MINVAL) return {1.f, 0.f, 0.f, 0.f};
-  const float inv = rsqrtf(n2);
-  return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
-}
-__device__ __forceinline__ void q2mat(float* m, Q4 q) {
-  float q00 = q.w * q.w, q11 = q.x * q.x, q22 = q.y * q.y, q33 = q.z * q.z;
-  float q01 = q.w * q.x, q02 = q.w * q.y, q03 = q.w * q.z, q12 = q.x * q.y, q13 = q.x * q.z, q23 = q.y * q.z;
-  m[0] = q00 + q11 - q22 - q33; m[1] = 2.f * (q12 - q03); m[2] = 2.f * (q13 + q02);
-  m[3] = 2.f * (q12 + q03); m[4] = q00 - q11 + q22 - q33; m[5] = 2.f * (q23 - q01);
-  m[6] = 2.f * (q13 - q02); m[7] = 2.f * (q23 + q01); m[8] = q00 - q11 - q22 + q33;
-}
-__device__ __forceinline__ V3 mrot(const float* m, V3 v) {
-  return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
-}
-// rotate v by the unit quaternion q: v + 2 w (u x v) + 2 u x (u x v), u = (x, y, z) - 21 flops instead of the
-// 40 of building the rotation matrix first (the same rotation; rounding differs in the last bits)
-__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
-  const V3 u = {q.x, q.y, q.z};
-  V3 t = cross(u, v);
-  t = {t.x + t.x, t.y + t.y, t.z + t.z};
-  const V3 c = cross(u, t);
-  return {v.x + q.w * t.x + c.x, v.y + q.w * t.y + c.y, v.z + q.w * t.z + c.z};
-}
-__device__ __forceinline__ Q4 axisangle(V3 axis, float ang) {
-  float s, c;
-  sincosf(0.5f * ang, &s, &c);
-  return {c, axis.x * s, axis.y * s, axis.z * s};
-}
-
-// spatial algebra on 6-vectors (rotation, translation); cinert layout as mjData.cinert (mjdata.h:269)
-__device__ __forceinline__ void mul_inert_vec(float* r, const float* i, const float* v) {
-  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
-  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
-  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
-  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
-  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
-  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
-}
-__device__ __forceinline__ void cross_motion(float* r, const float* vel, const float* v) {
-  r[0] = -vel[2] * v[1] + vel[1] * v[2];
-  r[1] = vel[2] * v[0] - vel[0] * v[2];
-  r[2] = -vel[1] * v[0] + vel[0] * v[1];
-  r[3] = -vel[2] * v[4] + vel[1] * v[5] - vel[5] * v[1] + vel[4] * v[2];
-  r[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
-  r[5] = -vel[1] * v[3] + vel[0] * v[4] - vel[4] * v[0] + vel[3] * v[1];
-}
-__device__ __forceinline__ void cross_force(float* r, const float* vel, const float* f) {
-  r[0] = -vel[2] * f[1] + vel[1] * f[2] - vel[5] * f[4] + vel[4] * f[5];
-  r[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
-  r[2] = -vel[1] * f[0] + vel[0] * f[1] - vel[4] * f[3] + vel[3] * f[4];
-  r[3] = -vel[2] * f[4] + vel[1] * f[5];
-  r[4] = vel[2] * f[3] - vel[0] * f[5];
-  r[5] = -vel[1] * f[3] + vel[0] * f[4];
-}
-
-// radical inverse, mju_Halton (mujoco.h:1231); used by simulation/mujoco/sample/testspeed.cc:76
-__device__ __forceinline__ float halton(int index, int base) {
-  float f = 1.f / (float)base, fb = f, hn = 0.f;
-  while (index > 0) {
-    int n1 = index / base, r = index - n1 * base;
-    hn += f * (float)r;
-    f *= fb;
-    index = n1;
-  }
-  return hn;
-}
-
-// ------------------------------------------------------------------------------------------
-// narrowphase helpers (engine_collision_primitive restatement, see oracle)
-struct ConOut { float dist; V3 pos; V3 n; };
-
-__device__ __forceinline__ bool plane_sphere(ConOut& c, float margin, V3 ppos, V3 normal, V3 spos, float radius) {
-  float cdist = dot(spos - ppos, normal);
-  if (cdist > margin + radius) return false;
-  c.dist = cdist - radius;
-  c.pos = spos + normal * (-c.dist * 0.5f - radius);
-  c.n = normal;
-  return true;
-}
-__device__ __forceinline__ bool sphere_sphere(ConOut& c, float margin, V3 p1, float r1, V3 p2, float r2) {
-  V3 dif = p2 - p1;
-  float cdist = sqrtf(dot(dif, dif));
-  if (cdist > margin + r1 + r2) return false;
-  c.dist = cdist - r1 - r2;
-  V3 n = cdist < HB_MINVAL ? V3{1.f, 0.f, 0.f} : dif * (1.f / cdist);
-  c.pos = p1 + n * (r1 + c.dist * 0.5f);
-  c.n = n;
-  return true;
-}
-__device__ __forceinline__ int capsule_capsule(ConOut& c0, ConOut& c1, float margin, V3 pos1, V3 axis1, float r1, float len1, V3 pos2, V3 axis2, float r2, float len2) {
-  V3 dif = pos1 - pos2;
-  float ma = dot(axis1, axis1), mb = -dot(axis1, axis2), mc = dot(axis2, axis2);
-  float u = -dot(axis1, dif), v = dot(axis2, dif);
-  float det = ma * mc - mb * mb;
-  if (fabsf(det) >= HB_MINVAL) {
-    float x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
-    if (x1 > len1) { x1 = len1; x2 = (v - mb * len1) / mc; }
-    else if (x1 < -len1) { x1 = -len1; x2 = (v + mb * len1) / mc; }
-    if (x2 > len2) { x2 = len2; x1 = clampf((u - mb * len2) / ma, -len1, len1); }
-    else if (x2 < -len2) { x2 = -len2; x1 = clampf((u + mb * len2) / ma, -len1, len1); }
-    return sphere_sphere(c0, margin, pos1 + axis1 * x1, r1, pos2 + axis2 * x2, r2) ? 1 : 0;
-  }
-  // parallel axes: up to two contacts from the segment ends (first two hits in this order)
-  ConOut t0, t1, t2, t3;
-  float x2 = clampf((v - mb * len1) / mc, -len2, len2);
-  const bool h0 = sphere_sphere(t0, margin, pos1 + axis1 * len1, r1, pos2 + axis2 * x2, r2);
-  x2 = clampf((v + mb * len1) / mc, -len2, len2);
-  const bool h1 = sphere_sphere(t1, margin, pos1 - axis1 * len1, r1, pos2 + axis2 * x2, r2);
-  float x1 = clampf((u - mb * len2) / ma, -len1, len1);
-  const bool h2 = sphere_sphere(t2, margin, pos1 + axis1 * x1, r1, pos2 + axis2 * len2, r2);
-  x1 = clampf((u + mb * len2) / ma, -len1, len1);
-  const bool h3 = sphere_sphere(t3, margin, pos1 + axis1 * x1, r1, pos2 - axis2 * len2, r2);
-  // first two hits in order
-  int n = 0;
-  if (h0) { c0 = t0; n = 1; }
-  if (h1) { if (n == 0) c0 = t1; else c1 = t1; n++; }
-  if (h2 && n < 2) { if (n == 0) c0 = t2; else c1 = t2; n++; }
-  if (h3 && n < 2) { if (n == 0) c0 = t3; else c1 = t3; n++; }
-  return n;
-}
-
-
-// closest point of triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5)
-__device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
-  const V3 ab = b - a, ac = c - a, ap = p - a;
-  const float d1 = dot(ab, ap), d2 = dot(ac, ap);
-  if (d1 <= 0.f && d2 <= 0.f) return a;
-  const V3 bp = p - b;
-  const float d3 = dot(ab, bp), d4 = dot(ac, bp);
-  if (d3 >= 0.f && d4 <= d3) return b;
-  const float vc = d1 * d4 - d3 * d2;
-  if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) return a + ab * (d1 / (d1 - d3));
-  const V3 cp = p - c;
-  const float d5 = dot(ab, cp), d6 = dot(ac, cp);
-  if (d6 >= 0.f && d5 <= d6) return c;
-  const float vb = d5 * d2 - d1 * d6;
-  if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) return a + ac * (d2 / (d2 - d6));
-  const float va = d3 * d6 - d5 * d4;
-  if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) return b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)));
-  const float denom = 1.f / (va + vb + vc);
-  return a + ab * (vb * denom) + ac * (vc * denom);
-}
-
-}  // namespace hb
-#include "hb_mpr.hpp"
-namespace hb {
-
-// complete a contact frame from its normal and an optional tangent hint (mju_makeFrame)
-__device__ __forceinline__ void make_frame(float* f, V3 n, V3 hint) {
-  n = normalized(n);
-  V3 t = hint;
-  if (dot(t, t) < 0.25f) t = (n.y < 0.5f && n.y > -0.5f) ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
-  t = t - n * dot(n, t);
-  t = normalized(t);
-  V3 b = cross(n, t);
-  st3(f, n); st3(f + 3, t); st3(f + 6, b);
-}
-
-// impedance sigmoid (getimpedance restatement); solimp = d0, dmax, width, midpoint, power
-__device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
-  float d0 = clampf(solimp[0], HB_MINIMP, HB_MAXIMP), d1 = clampf(solimp[1], HB_MINIMP, HB_MAXIMP);
-  float width = fmaxf(0.f, solimp[2]), mid = clampf(solimp[3], HB_MINIMP, HB_MAXIMP), power = fmaxf(1.f, solimp[4]);
-  if (d0 == d1 || width <= HB_MINVAL) return 0.5f * (d0 + d1);
-  float x = fabsf((pos - margin) / width);
-  if (x >= 1.f) return d1;
-  if (x <= 0.f) return d0;
-  // both halves of the sigmoid are the same power curve, mirrored: one evaluation, and the usual exponent 2
-  // (MuJoCo's default solimp) needs no powf at all
-  const bool lower = x <= mid;
-  const float t = lower ? x : 1.f - x, mm = lower ? mid : 1.f - mid;
-  float y;
-  if (power == 1.f) y = t;  // x or 1 - x: the curve is the identity
-  else if (power == 2.f) y = t * t / mm;
-  else y = powf(t, power) / powf(mm, power - 1.f);
-  if (!lower) y = 1.f - y;
-  return d0 + y * (d1 - d0);
-}
-
-// reference spring (K) and damper (B) of a constraint row from solref (mj_makeImpedance; oracle: make_constraint)
-__device__ __forceinline__ void kb_from_solref(float solref0, float solref1, float solimp1, float timestep, bool refsafe, float& K, float& B) {
-  const float dmax = clampf(solimp1, HB_MINIMP, HB_MAXIMP);
-  if (solref0 > 0.f) {
-    float tc = solref0;
-    if (refsafe) tc = fmaxf(tc, 2.f * timestep);
-    K = 1.f / fmaxf(HB_MINVAL, dmax * dmax * tc * tc * solref1 * solref1);
-    B = 2.f / fmaxf(HB_MINVAL, dmax * tc);
-  } else { K = -solref0 / fmaxf(HB_MINVAL, dmax * dmax); B = -solref1 / fmaxf(HB_MINVAL, dmax); }
-}
-
-// LDS record strides (floats).  Records read as ds_read_b128 by lanes that index different bodies / dofs are 16-byte aligned AND an odd
-// multiple of 16 bytes apart: with the natural power-of-two strides (8, 16 floats) lanes b and b + 8 (b + 4) hit the same banks
-// (measured: 14 % of LDS-active cycles were bank conflicts, profiles/r02_counters.json)
-constexpr int kCdofStride = 12;  // per dof: angular[3], -, linear[3], -, (pad 4)
-constexpr int kXpqStride = 12;   // per body: xpos[3], -, xquat[4], (pad 4)
-constexpr int kIfStride = 20;    // per body: composite inertia[10] | cfrc[6], (pad 4)
-constexpr int kWs = 36;  // 16-byte aligned rows: a row times a vector is eight ds_read_b128 pairs (dot32)
-// one dof's motion axis record: s_cdof[8 d ..] = angular[3], -, linear[3], - (two ds_read_b128)
-__device__ __forceinline__ void ld_cdof(const float* s_cdof, int d, float out[6]) {
-  const float4* p = reinterpret_cast<const float4*>(s_cdof + kCdofStride * d);
-  const float4 a = p[0], l = p[1];
-  out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = l.x; out[4] = l.y; out[5] = l.z;
-}
-
-// 32-term dot product of a W row with a dof vector, both 16-byte aligned and zero beyond nv
-__device__ __forceinline__ float dot32(const float* row, const float* v) {
-  const float4* a = reinterpret_cast<const float4*>(row);
-  const float4* b = reinterpret_cast<const float4*>(v);
-  float acc = 0.f;
-#pragma unroll
-  for (int q = 0; q < 8; q++) { const float4 x = a[q], y = b[q]; acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
-  return acc;
-}
-
-// ------------------------------------------------------------------------------------------
-
-// ---- counter-based random numbers (env realism, rollout noise): one 32-bit word per (seed, global env, episode, step,
-// stream, element): reproducible, order-free, the same on any split of the batch.  tests/env_ref.py restates them in numpy.
-__device__ __forceinline__ unsigned rng_mix(unsigned h, unsigned v) {
-  h ^= v; h *= 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
-  return h;
-}
-__device__ __forceinline__ unsigned rng_u32(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
-  unsigned h = rng_mix(0x6A09E667u, seed);
-  h = rng_mix(h, env); h = rng_mix(h, ep); h = rng_mix(h, step); h = rng_mix(h, stream); h = rng_mix(h, idx);
-  return h;
-}
-__device__ __forceinline__ float rng_uniform(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
-  return ((float)(rng_u32(seed, env, ep, step, stream, idx) >> 8) + 0.5f) * (1.f / 16777216.f);  // (0, 1)
-}
-__device__ __forceinline__ float rng_normal(unsigned seed, unsigned env, unsigned ep, unsigned step, unsigned stream, unsigned idx) {
-  const float u1 = rng_uniform(seed, env, ep, step, stream, 2 * idx), u2 = rng_uniform(seed, env, ep, step, stream, 2 * idx + 1);
-  return sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);  // Box-Muller
-}
-enum { RS_ACTION = 1, RS_JOINT_POS, RS_JOINT_VEL, RS_GYRO, RS_IMU, RS_DELAY, RS_PUSH, RS_XFRC };
-
-// ---- dense helpers of the Newton solver ------------------------------------------------------------------------
-// A symmetric nv x nv matrix (nv <= 32, identity beyond nv) lives one ROW PER LANE: lane l (and its mirror l + 32)
-// holds row l & 31 in 32 registers.  Vectors live one element per lane (lanes 0..31).  Everything is readlane + fma
-// on statically indexed registers: no LDS traffic, no cross-lane reductions.
-
-// sum_j row[j] * x_j over LDS rows (N terms, the tails are zero by construction), x_j taken from lane j: all loads of
-// the unrolled body are issued before the first use; the two-row form shares the broadcasts
-template <int N>
-__device__ __forceinline__ float rowdot(const float* row, float x) {
-  float v[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) v[j] = row[j];
-  float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-  for (int j = 0; j < N; j += 2) {
-    a0 = __builtin_fmaf(v[j], rdlane(x, j), a0);
-    a1 = __builtin_fmaf(v[j + 1], rdlane(x, j + 1), a1);
-  }
-  return a0 + a1;
-}
-template <int N>
-__device__ __forceinline__ void rowdot2(const float* rowA, const float* rowB, float x, float& ra, float& rb) {
-  float va[N], vb[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) { va[j] = rowA[j]; vb[j] = rowB[j]; }
-  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-  for (int j = 0; j < N; j += 2) {
-    const float x0 = rdlane(x, j), x1 = rdlane(x, j + 1);
-    a0 = __builtin_fmaf(va[j], x0, a0); b0 = __builtin_fmaf(vb[j], x0, b0);
-    a1 = __builtin_fmaf(va[j + 1], x1, a1); b1 = __builtin_fmaf(vb[j + 1], x1, b1);
-  }
-  ra = a0 + a1; rb = b0 + b1;
-}
-
-// Right-looking Cholesky A = L L' in place (mju_cholFactor, mujoco.h:1211, incl. its diagonal floor) of the leading
-// N x N block (N = nv rounded up to 4; identity beyond nv).  Every lane updates its whole row, so that lane i ends up with
-//   element k < i: L[i][k] d_k;   element k > i: S_i[i][k] d_i^2 = L[k][i] d_i   (S_i: the Schur complement at pivot i),
-// i.e. row i of L and column i of L, each pre-scaled so that the two triangular solves below are one v_readlane and one
-// fma per step.  Returns d_i = 1 / L[i][i].
-// The dependent chain of a pivot is readlane - rsq - mul - readlane - fma: the NEXT pivot column is updated first, with
-// its multiplier taken by v_readlane; the rest of the trailing update goes through a 64-float LDS line (one ds_write,
-// broadcast ds_read_b128s) as packed math on register pairs (v_pk_fma_f32) and overlaps the following pivots.
-template <int N>
-__device__ __forceinline__ float chol_rows(f32x2 (&A)[16], float* s_l, int li, int lane) {
-  float dv = 1.f;
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    const float akk = A[k >> 1][k & 1];
-    const float piv = fmaxf(rdlane(akk, k), HB_MINVAL);
-    const float d = __builtin_amdgcn_rsqf(piv);
-    const float l = akk * d;
-    s_l[lane] = l;  // all 64 lanes (the upper half lands in the next 32 floats): an unconditional store keeps the code straight-line
-    if (li == k) dv = d;
-    const float lm = li > k ? -l : 0.f;  // rows at and above the pivot are final
-    if (k + 1 < N) A[(k + 1) >> 1][(k + 1) & 1] = __builtin_fmaf(lm, rdlane(l, k + 1), A[(k + 1) >> 1][(k + 1) & 1]);
-    const f32x2 lm2 = {lm, lm};
-#pragma unroll
-    for (int c = (k + 2) / 4; c < N / 4; c++) {
-      const float4 lv = *reinterpret_cast<const float4*>(s_l + 4 * c);
-      const float lq[4] = {lv.x, lv.y, lv.z, lv.w};
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int lo = 4 * c + 2 * h, hi = lo + 1;
-        if (lo > k + 1) A[2 * c + h] = lm2 * f32x2{lq[2 * h], lq[2 * h + 1]} + A[2 * c + h];
-        else if (hi > k + 1) A[2 * c + h][1] = __builtin_fmaf(lm, lq[2 * h + 1], A[2 * c + h][1]);
-      }
-    }
-    A[k >> 1][k & 1] = li > k ? l * d : akk;
-  }
-  const float dv2 = dv * dv;
-#pragma unroll
-  for (int k = 1; k < N; k++) A[k >> 1][k & 1] = li < k ? A[k >> 1][k & 1] * dv2 : A[k >> 1][k & 1];
-  return dv;
-}
-
-// x = (L L')^-1 g for the factor left by chol_rows (mju_cholSolve, mujoco.h:1214): column-oriented forward and backward
-// substitution; with the pre-scaled factor the element solved at step k is lane k's running value itself: v_readlane
-// broadcasts it, one fma updates every other row, v_writelane (off the chain) keeps it
-template <int N>
-__device__ __forceinline__ float chol_solve_rows(const f32x2 (&A)[16], float dv, float g) {
-  float r = g;
-  int y = 0;
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    const int rk = __builtin_amdgcn_readlane(__float_as_int(r), k);
-    y = hb_writelane(rk, k, y);
-    r = __builtin_fmaf(-A[k >> 1][k & 1], __int_as_float(rk), r);  // rows below k; rows above are done (their r is dead)
-  }
-  r = __int_as_float(y) * (dv * dv);  // y_k = r_k d_k, and the backward pass runs on d_i-scaled rows
-  int x = 0;
-#pragma unroll
-  for (int k = N - 1; k >= 0; k--) {
-    const int xk = __builtin_amdgcn_readlane(__float_as_int(r), k);
-    x = hb_writelane(xk, k, x);
-    r = __builtin_fmaf(-A[k >> 1][k & 1], __int_as_float(xk), r);  // rows above k
-  }
-  return __int_as_float(x);
-}
-
-// ---- symmetric elimination on the matrix cores (Newton instantiation of order <= 28) -----------------------------
-// A symmetric 32 x 32 matrix S lives in the accumulator layout of v_mfma_f32_32x32x2_f32 (f32x16 per lane: lane = column
-// + 32 * half, register r = row crow(r) + 4 * half).  In that layout ROW k of S is one register on the 32 lanes of one
-// half - which is exactly the shape of an MFMA operand - and by symmetry it is also column k.  Gaussian elimination of
-// two pivots is therefore ONE rank-2 MFMA update  S -= a b'  with b = the two pivot rows (one per half, moved by a
-// v_permlane32_swap) and a = -b / D masked to the rows below the pivot: about twenty-five VALU instructions per pivot
-// pair instead of a trailing update of N - k columns.  The same multipliers applied to T (started at I) by a second
-// MFMA leave T = L^-1; the right-hand side rides along as row / column 31, so z_k = U[k][31] / D_k = (D^-1 L^-1 g)_k
-// falls out of the pivot rows, and x = T' z is sixteen lane-local fmas plus one swap.  NP pivot pairs (order 2 NP <= 30);
-// rows beyond are identity padding and are never pivots.
-// (Building T in place of the eliminated triangle - pivot row with a doubled diagonal, one MFMA per pair - was measured
-// too: fewer MFMAs but more VALU work per pair, and VALU issue is what the two waves of a SIMD compete for: slower.)
-__device__ __forceinline__ constexpr int crow(int r) { return (r & 3) + 8 * (r >> 2); }
-
-template <int NP>
-__device__ __forceinline__ float sym_solve_mfma(f32x16 X, float g, int lane) {
-  const int li = lane & 31, half = lane >> 5;
-  const bool up = half != 0;
-  {  // right-hand side into row 31 and column 31 (g is mirrored in both halves and zero beyond nv): S += e31 g' + g e31'
-    const float e31 = li == 31 ? 1.f : 0.f;
-    X = __builtin_amdgcn_mfma_f32_32x32x2f32(up ? g : e31, up ? e31 : g, X, 0, 0, 0);
-  }
-  f32x16 T, Z;
-  const int q = li - 4 * half;
-#pragma unroll
-  for (int r = 0; r < 16; r++) { T[r] = q == crow(r) ? 1.f : 0.f; Z[r] = 0.f; }
-  const float lik = (float)(li - half);  // row index minus the pivot slot of this half
-#pragma unroll
-  for (int b = 0; b < NP; b++) {
-    const int k0 = 2 * b, r0 = (k0 & 3) + 4 * (k0 >> 3), h0 = (k0 >> 2) & 1, L0 = 32 * h0;
-    const float rowa = X[r0], rowb = X[r0 + 1], ta = T[r0], tb = T[r0 + 1];  // rows k0, k0 + 1 on the lanes of half h0
-    const float inv0 = __builtin_amdgcn_rcpf(fmaxf(rdlane(rowa, L0 + k0), HB_MINVAL));
-    const float m = rdlane(rowb, L0 + k0) * inv0;
-    const float rowb1 = __builtin_fmaf(-m, rowa, rowb), tb1 = __builtin_fmaf(-m, ta, tb);  // row k0 + 1 after pivot k0
-    const float inv1 = __builtin_amdgcn_rcpf(fmaxf(rdlane(rowb1, L0 + k0 + 1), HB_MINVAL));
-    const u32x2 sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(rowa), __float_as_uint(rowb1), false, false);
-    const u32x2 st = __builtin_amdgcn_permlane32_swap(__float_as_uint(ta), __float_as_uint(tb1), false, false);
-    const float vb = __uint_as_float(h0 ? sx.y : sx.x), vt = __uint_as_float(h0 ? st.y : st.x);  // half 0: row k0, half 1: row k0 + 1
-    const float below = __builtin_amdgcn_fmed3f(lik - (float)k0, 0.f, 1.f);                       // 1 on the rows below this half's pivot
-    const float va = -(vb * (up ? inv1 : inv0)) * below;
-    X = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, X, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vt, T, 0, 0, 0);
-    const float z0 = rdlane(rowa, L0 + 31) * inv0, z1 = rdlane(rowb1, L0 + 31) * inv1;
-    if (half == h0) { Z[r0] = z0; Z[r0 + 1] = z1; }
-  }
-  float p = 0.f, p1 = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) { p = __builtin_fmaf(T[r], Z[r], p); p1 = __builtin_fmaf(T[r + 1], Z[r + 1], p1); }
-  p += p1;
-  const u32x2 sp = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
-  return p + __uint_as_float(up ? sp.x : sp.y);
-}
-
-// a dof vector valid on lanes 0..31, copied to both halves
-__device__ __forceinline__ float rdlane_mirror(float x, int lane) {
-  const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return lane >= 32 ? __uint_as_float(sw.x) : x;
-}
-
-// the dense mass matrix ([32][kCs] in LDS, identity beyond nv) in the accumulator layout
-__device__ __forceinline__ f32x16 load_sym(const float* s_Md, int stride, int lane) {
-  const float* pl = s_Md + 4 * (lane >> 5) * stride + (lane & 31);
-  f32x16 X;
-#pragma unroll
-  for (int r = 0; r < 16; r++) X[r] = pl[crow(r) * stride];
-  return X;
-}
-
-// the {M, H} pairs in the accumulator layout (WHICH = 0: M, 1: H = M + h B), straight from the sparse storage
-template <int WHICH>
-__device__ __forceinline__ f32x16 load_sym_pairs(DevModelRef M, const f32x2* s_qLD, int lane0) {
-  // (the lane id is re-materialised so that the sixteen table words are fetched again at every use instead of being
-  // kept in registers from the W stage, across the PGS sweeps, to the Euler solve)
-  int lane;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0));
-  int e[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) e[r] = M.mdense_c[r * 64 + lane];
-  f32x16 X;
-#pragma unroll
-  for (int r = 0; r < 16; r++) X[r] = s_qLD[e[r]][WHICH];
-  return X;
-}
-
-// Elimination only (PGS instantiation): T = L^-1 and, per register and half, D^-1/2 of that register's row, so that
-// W = T' D^-1/2 (M^-1 = W W') can be written out.  Same rank-2 updates as sym_solve_mfma, no right-hand side.
-template <int NP>
-__device__ __forceinline__ void sym_factor_mfma(f32x16 X, f32x16& T, f32x16& S, int lane) {
-  const int li = lane & 31, half = lane >> 5;
-  const bool up = half != 0;
-  const int q = li - 4 * half;
-#pragma unroll
-  for (int r = 0; r < 16; r++) { T[r] = q == crow(r) ? 1.f : 0.f; S[r] = 1.f; }
-  const float lik = (float)(li - half);
-#pragma unroll
-  for (int b = 0; b < NP; b++) {
-    const int k0 = 2 * b, r0 = (k0 & 3) + 4 * (k0 >> 3), h0 = (k0 >> 2) & 1, L0 = 32 * h0;
-    const float rowa = X[r0], rowb = X[r0 + 1], ta = T[r0], tb = T[r0 + 1];
-    const float d0 = fmaxf(rdlane(rowa, L0 + k0), HB_MINVAL);
-    const float inv0 = __builtin_amdgcn_rcpf(d0);
-    const float m = rdlane(rowb, L0 + k0) * inv0;
-    const float rowb1 = __builtin_fmaf(-m, rowa, rowb), tb1 = __builtin_fmaf(-m, ta, tb);
-    const float d1 = fmaxf(rdlane(rowb1, L0 + k0 + 1), HB_MINVAL);
-    const float inv1 = __builtin_amdgcn_rcpf(d1);
-    const u32x2 sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(rowa), __float_as_uint(rowb1), false, false);
-    const u32x2 st = __builtin_amdgcn_permlane32_swap(__float_as_uint(ta), __float_as_uint(tb1), false, false);
-    const float vb = __uint_as_float(h0 ? sx.y : sx.x), vt = __uint_as_float(h0 ? st.y : st.x);
-    const float below = __builtin_amdgcn_fmed3f(lik - (float)k0, 0.f, 1.f);
-    const float va = -(vb * (up ? inv1 : inv0)) * below;
-    X = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, X, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vt, T, 0, 0, 0);
-    if (half == h0) { S[r0] = __builtin_amdgcn_rsqf(d0); S[r0 + 1] = __builtin_amdgcn_rsqf(d1); }
-  }
-}
-
-// W[c][row] = T[row][c] * S(row): lane (c, half) owns four runs of four consecutive rows: four 16-byte stores
-__device__ __forceinline__ void store_w_rows(float* W, int stride, const f32x16& T, const f32x16& S, int lane) {
-  float* p = W + (lane & 31) * stride + 4 * (lane >> 5);
-#pragma unroll
-  for (int g = 0; g < 4; g++)
-    *reinterpret_cast<float4*>(p + 8 * g) = {T[4 * g] * S[4 * g], T[4 * g + 1] * S[4 * g + 1], T[4 * g + 2] * S[4 * g + 2], T[4 * g + 3] * S[4 * g + 3]};
-}
-
-// WT[row][c] = T[row][c] * S(row): the transpose of store_w_rows' matrix (consecutive lanes, consecutive addresses)
-__device__ __forceinline__ void store_w_cols(float* WT, int stride, const f32x16& T, const f32x16& S, int lane) {
-  float* p = WT + 4 * (lane >> 5) * stride + (lane & 31);
-#pragma unroll
-  for (int r = 0; r < 16; r++) p[crow(r) * stride] = T[r] * S[r];
-}
-
-// ---- general narrowphase (COLL = 1): every pair kind of the classic one plus mesh hulls and height-field prisms ----------------
-// exclusive prefix sum of a small non-negative count over the 64 lanes (and the total)
-__device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
-  int x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-  total = __builtin_amdgcn_readlane(x, 63);
-  return x - v;
-}
-
-// a mesh geom's hull for the support function: the start records of its mesh
-__device__ __forceinline__ void set_mesh(DevModelRef M, CObj& o, int g) {
-  o.vert = M.mesh_start + (M.geom_meshnum[g] > 0 ? kMeshStart * M.geom_dataid[g] : 0);
-  o.nbr = M.mesh_nbr;
-}
-
-// separating-axis test of the oriented bounding boxes of geoms g1, g2 (centres dp apart, orientations q1, q2, each box grown by
-// `grow`): false only if an axis separates them (Gottschalk's 15 axes; the epsilon on |R| keeps near-parallel edge pairs from
-// reporting a separation that rounding made up, and the slack keeps boxes that touch to within rounding together)
-__device__ __forceinline__ bool boxes_touch(DevModelRef M, int g1, int g2, V3 dp, Q4 q1, Q4 q2, float grow) {
-  const float slack = 1e-6f;
-  float A[9], B[9], R[9], AR[9];
-  q2mat(A, q1); q2mat(B, q2);
-  const V3 ha = ld3(M.geom_half + 3 * g1), hb3 = ld3(M.geom_half + 3 * g2);
-  const float a[3] = {ha.x + grow + slack, ha.y + grow + slack, ha.z + grow + slack}, b[3] = {hb3.x + grow + slack, hb3.y + grow + slack, hb3.z + grow + slack};
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) { R[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j]; AR[3 * i + j] = fabsf(R[3 * i + j]) + 1e-6f; }  // A' B
-  const float t[3] = {A[0] * dp.x + A[3] * dp.y + A[6] * dp.z, A[1] * dp.x + A[4] * dp.y + A[7] * dp.z, A[2] * dp.x + A[5] * dp.y + A[8] * dp.z};  // A' dp
-  bool apart = false;
-#pragma unroll
-  for (int i = 0; i < 3; i++) apart |= fabsf(t[i]) > a[i] + b[0] * AR[3 * i] + b[1] * AR[3 * i + 1] + b[2] * AR[3 * i + 2];
-#pragma unroll
-  for (int j = 0; j < 3; j++) apart |= fabsf(t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j]) > a[0] * AR[j] + a[1] * AR[3 + j] + a[2] * AR[6 + j] + b[j];
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-      const float ra = a[i1] * AR[3 * i2 + j] + a[i2] * AR[3 * i1 + j], rb = b[j1] * AR[3 * i + j2] + b[j2] * AR[3 * i + j1];
-      apart |= fabsf(t[i2] * R[3 * i1 + j] - t[i1] * R[3 * i2 + j]) > ra + rb;
-    }
-  return !apart;
-}
-
-// lowest point (z, relative to the geom's position) of geom g with orientation q in the frame the query is made in: the support
-// function along -z.  Single precision: the value only decides whether a prism under the geom is searched (the prism's top is
-// compared with it), and a vertex within rounding of the lowest one gives the same answer to within that rounding.
-__device__ __forceinline__ float lowest_point(DevModelRef M, int g, int type, float r, float h, Q4 q) {
-  float m[9];
-  q2mat(m, q);
-  const V3 ld = {-m[6], -m[7], -m[8]};  // mat' (0, 0, -1): the query direction in the geom's frame
-  if (type == 2) return -r;
-  if (type == 3) return -r - fabsf(ld.z) * h;  // mat (ld r + (0, 0, sign(ld.z) h)) . z = -r - |ld.z| h
-  if (type != 7 || M.geom_meshnum[g] <= 0) return -M.geom_rbound[g];
-  const float4 HB_CONST* start = M.mesh_start + kMeshStart * M.geom_dataid[g];
-  const float ax = fabsf(ld.x), ay = fabsf(ld.y), az = fabsf(ld.z);
-  const int axis = ax >= ay ? (ax >= az ? 0 : 2) : (ay >= az ? 1 : 2);
-  const float major = axis == 0 ? ld.x : (axis == 1 ? ld.y : ld.z);
-  const float inv = 1.f / fabsf(major);
-  const float u = (axis == 0 ? ld.y : (axis == 1 ? ld.z : ld.x)) * inv, v = (axis == 0 ? ld.z : (axis == 1 ? ld.x : ld.y)) * inv;
-  const int iu = min(max((int)floorf((u + 1.f) * 2.f), 0), 3), iv = min(max((int)floorf((v + 1.f) * 2.f), 0), 3);
-  const float4 s0 = start[(2 * axis + (major < 0.f ? 1 : 0)) * 16 + iu * 4 + iv];
-  float bd = __builtin_fmaf(s0.x, ld.x, __builtin_fmaf(s0.y, ld.y, s0.z * ld.z));  // (one fixed operation sequence for start and neighbours: hb_mpr.hpp, hull_val)
-  int link = __float_as_int(s0.w);
-  for (int guard = 0; guard < 256; guard++) {
-    const int adr = link >> 8, nch = link & 255;
-    bool moved = false;
-    int nlink = link;
-    for (int c = 0; c < nch; c++) {
-      float4 nb[kMeshChunk];
-#pragma unroll
-      for (int i = 0; i < kMeshChunk; i++) nb[i] = M.mesh_nbr[adr + c * kMeshChunk + i];
-#pragma unroll
-      for (int i = 0; i < kMeshChunk; i++) {
-        const float val = __builtin_fmaf(nb[i].x, ld.x, __builtin_fmaf(nb[i].y, ld.y, nb[i].z * ld.z));
-        if (val > bd) { bd = val; nlink = __float_as_int(nb[i].w); moved = true; }
-      }
-    }
-    if (!moved) break;
-    link = nlink;
-  }
-  return -bd;  // the support point's z in the query frame is -(v . ld)
-}
-
-// mj_collision for models with mesh geoms and / or a height field (the reference's own robot: simulation/assets/world.xml:14-58).
-// Three passes over LDS lists: (1) broadphase per candidate pair, survivors in pair order; (2) work items: one per pair, or one
-// per prism of the sub-grid under the geom for a height-field pair (mjc_ConvexHField's double loop, flattened); (3) narrowphase,
-// one work item per lane, contacts appended in work-item order (= the oracle's order: pair, then grid row, then strip position).
-// The passes are separate functions because the STAGED step (launch_step) runs them in separate kernels: (1) + (2) in
-// hb_pose_kernel, (3) in hb_narrow_kernel at four times the occupancy the step kernel allows, and the step kernel itself only
-// appends the results (collide_gather).
-//
-// passes (1) and (2): s_scratch receives the pair list, the sub-grids of height-field pairs and the work items; returns the number of work items
-__device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const float* s_gpos, const float* s_gaxis, const float* s_gquat, int* s_scratch, int& status) {
-  int* s_list = s_scratch;                   // [kListMax]
-  int* s_pinfo = s_scratch + kListMax;       // [kListMax][4]: rmin, cmin, ncols of a height-field pair's sub-grid, lowest point of the geom (float bits)
-  int* s_work = s_pinfo + 4 * kListMax;      // [kWorkMax]: list index << 16 | sub-item
-  int nlist = 0;
-  for (int p0 = 0; p0 < M.npair; p0 += kGroup) {
-    const int p = p0 + lane;
-    bool pass = false;
-    if (p < M.npair) {
-      const float4 c0 = M.crec[3 * (size_t)p], c1 = M.crec[3 * (size_t)p + 1];
-      const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y), t1 = __float_as_int(c0.z) & 255;
-      const V3 dp = ld3(s_gpos + 3 * g2) - ld3(s_gpos + 3 * g1);
-      if (t1 == 0) pass = dot(dp, ld3(s_gaxis + 3 * g1)) <= c0.w + c1.y;
-      else if (t1 == 1) pass = true;
-      else {
-        const float bound = c1.x + c1.y + c0.w;
-        pass = dot(dp, dp) <= bound * bound;
-        // a pair that goes to the portal search: the geoms' oriented bounding boxes first (each grown by half the margin).  Boxes
-        // that a separating axis keeps apart hold hulls that do not touch: the search would say so too, after two hull climbs
-        // per support query (the robot's limbs are long and thin: most pairs that pass the bounding spheres stop here)
-        const int t2 = (__float_as_int(c0.z) >> 8) & 255;
-        if (pass && M.box_cull && (t1 == 7 || t2 == 7)) pass = boxes_touch(M, g1, g2, dp, ldq(s_gquat + 4 * g1), ldq(s_gquat + 4 * g2), 0.5f * c0.w);
-      }
-    }
-    const unsigned long long bal = __ballot(pass);
-    const int slot = nlist + __popcll(bal & ((1ull << lane) - 1ull));
-    if (pass && slot < kListMax) s_list[slot] = p;
-    nlist += __popcll(bal);
-  }
-  nlist = uniform(nlist);
-  if (nlist > kListMax) { status |= (1 << 1); nlist = kListMax; }
-  gsync();
-  int nwork = 0;
-  for (int i0 = 0; i0 < nlist; i0 += kGroup) {
-    const int idx = i0 + lane;
-    int cnt = 0;
-    if (idx < nlist) {
-      const int p = s_list[idx];
-      const float4 c0 = M.crec[3 * (size_t)p], c1 = M.crec[3 * (size_t)p + 1];
-      const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y), t1 = __float_as_int(c0.z) & 255;
-      cnt = 1;
-      if (t1 == 0 && ((__float_as_int(c0.z) >> 8) & 255) == 7) cnt = 2;  // mjc_PlaneConvex: up to four contacts, two per work item
-      if (t1 == 1) {
-        // mjc_ConvexHField's culling.  The sub-grid comes from the geom's bounding sphere in place of its exact bounding box (a superset
-        // of MuJoCo's prisms in x and y: the extra ones lie outside the geom's footprint and cannot touch it), the height test from the
-        // geom's exact lowest point in the field's frame (one support query along -z; MuJoCo's box has the same bottom), so that a
-        // prism under a raised limb is not searched at all.
-        float hm[9];
-        q2mat(hm, ldq(M.geom_quat + 4 * g1));
-        const int hid = M.geom_dataid[g1];
-        const float sx = M.hfield_size[4 * hid], sy = M.hfield_size[4 * hid + 1], sz = M.hfield_size[4 * hid + 2], sb = M.hfield_size[4 * hid + 3];
-        const int nrow = M.hfield_nrow[hid], ncol = M.hfield_ncol[hid];
-        const V3 dif = ld3(s_gpos + 3 * g2) - ld3(s_gpos + 3 * g1);
-        const V3 q = {hm[0] * dif.x + hm[3] * dif.y + hm[6] * dif.z, hm[1] * dif.x + hm[4] * dif.y + hm[7] * dif.z, hm[2] * dif.x + hm[5] * dif.y + hm[8] * dif.z};
-        const float reach = c1.y + c0.w;
-        if (sx < q.x - reach || -sx > q.x + reach || sy < q.y - reach || -sy > q.y + reach || sz < q.z - reach || -sb > q.z + reach) cnt = 0;
-        else {
-          int cmin = (int)floorf((q.x - reach + sx) / (2.f * sx) * (float)(ncol - 1)), cmax = (int)ceilf((q.x + reach + sx) / (2.f * sx) * (float)(ncol - 1));
-          int rmin = (int)floorf((q.y - reach + sy) / (2.f * sy) * (float)(nrow - 1)), rmax = (int)ceilf((q.y + reach + sy) / (2.f * sy) * (float)(nrow - 1));
-          cmin = max(cmin, 0); rmin = max(rmin, 0); cmax = min(cmax, ncol - 1); rmax = min(rmax, nrow - 1);
-          const int ncols = max(cmax - cmin, 0), nrows = max(rmax - rmin, 0);
-          cnt = nrows * 2 * ncols;
-          const float4 c2 = M.crec[3 * (size_t)p + 2];
-          const float loz = q.z + lowest_point(M, g2, (__float_as_int(c0.z) >> 8) & 255, c2.x, c2.y, qmul(qconj(ldq(M.geom_quat + 4 * g1)), ldq(s_gquat + 4 * g2)));
-          s_pinfo[4 * idx] = rmin; s_pinfo[4 * idx + 1] = cmin; s_pinfo[4 * idx + 2] = ncols; s_pinfo[4 * idx + 3] = __float_as_int(loz);
-        }
-      }
-    }
-    int total;
-    const int base = nwork + wave_excl_scan(cnt, lane, total);
-    for (int k = 0; k < cnt; k++) if (base + k < kWorkMax) s_work[base + k] = (idx << 16) | k;
-    nwork += total;
-  }
-  nwork = uniform(nwork);
-  if (nwork > kWorkMax) { status |= (1 << 1); nwork = kWorkMax; }
-  gsync();
-  return nwork;
-}
-
-// pass (3) for one work item: pair p (sub-item `sub` of the sub-grid rmin, cmin, ncols for a height-field pair) -> n contacts (0..2).
-// MODE 0: all of it.  MODE 1 (hb_pose_kernel): everything but the portal search; returns whether the item needs one (then n = 0).
-// MODE 2 (hb_narrow_kernel): an item MODE 1 said needs the portal search.
-template <int MODE, int MESH = 1>
-__device__ __forceinline__ int eval_work_item(DevModelRef M, const float* hdata_all, bool have, int p, int sub, int rmin, int cmin, int ncols, float loz,
-                                              const float* s_gpos, const float* s_gaxis, const float* s_gquat, ConOut& co0, ConOut& co1, int& n, V3& hint) {
-  float4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
-  if (have) { const float4 HB_CONST* N = M.crec + 3 * (size_t)p; c0 = N[0]; c1 = N[1]; c2 = N[2]; }
-  co0.dist = 0.f; co0.pos = {0.f, 0.f, 0.f}; co0.n = {0.f, 0.f, 1.f}; co1 = co0;
-  n = 0;
-  hint = {0.f, 0.f, 0.f};
-  const int g1 = __float_as_int(c0.x), g2 = __float_as_int(c0.y);
-  const int t1 = __float_as_int(c0.z) & 255, t2 = (__float_as_int(c0.z) >> 8) & 255;
-  const float margin = c0.w;
-  // the two objects of an MPR test (one call site below)
-  CObj o1, o2;
-  int mpr_kind = 0;  // 0: no MPR for this item, 1: prism vs geom (field frame), 2: geom vs geom (world frame)
-  float hm[9];
-  V3 pos1 = {0.f, 0.f, 0.f};
-  if (have) {
-    pos1 = ld3(s_gpos + 3 * g1);
-    const V3 pos2 = ld3(s_gpos + 3 * g2), ax2 = ld3(s_gaxis + 3 * g2);
-    const float rb1 = c1.x, rb2 = c1.y, r2 = c2.x, l2 = c2.y;
-    (void)rb1;
-    if (t1 == 1) {
-      q2mat(hm, ldq(M.geom_quat + 4 * g1));
-      const int hid = M.geom_dataid[g1];
-      const float sx = M.hfield_size[4 * hid], sy = M.hfield_size[4 * hid + 1], sz = M.hfield_size[4 * hid + 2], sb = M.hfield_size[4 * hid + 3];
-      const int nrow = M.hfield_nrow[hid], ncol = M.hfield_ncol[hid];
-      const float* data = hdata_all + M.hfield_adr[hid];
-      const int r = rmin + sub / (2 * ncols), j = sub % (2 * ncols);
-      const float dx = 2.f * sx / (float)(ncol - 1), dy = 2.f * sy / (float)(nrow - 1);
-      // strip vertex s of grid row r: column cmin + s / 2, grid row r + 1 for even s, r for odd s (mjc_ConvexHField: dr = {1, 0})
-      V3 tv[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int sidx = j + k, cc = cmin + (sidx >> 1), rr = r + ((sidx & 1) ? 0 : 1);
-        tv[k] = {dx * (float)cc - sx, dy * (float)rr - sy, data[rr * ncol + cc] * sz + margin};
-      }
-      // geom 2 in the field's frame
-      const V3 dif = pos2 - pos1;
-      o2.pos = {hm[0] * dif.x + hm[3] * dif.y + hm[6] * dif.z, hm[1] * dif.x + hm[4] * dif.y + hm[7] * dif.z, hm[2] * dif.x + hm[5] * dif.y + hm[8] * dif.z};
-      if (MODE == 2 || !(tv[0].z < loz && tv[1].z < loz && tv[2].z < loz)) {  // prism below the geom's lowest point (loz: build_work_list); MODE 2: tested before
-        float m2[9];
-        q2mat(m2, ldq(s_gquat + 4 * g2));
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-          for (int b = 0; b < 3; b++) o2.mat[3 * a + b] = hm[a] * m2[b] + hm[3 + a] * m2[3 + b] + hm[6 + a] * m2[6 + b];  // hm' m2
-        o2.type = t2; o2.r = r2; o2.h = l2; o2.margin = margin;
-        if constexpr (MESH != 0) set_mesh(M, o2, g2);
-        o1.type = -1; o1.pos = {0.f, 0.f, 0.f}; o1.r = o1.h = o1.margin = 0.f; o1.vert = M.mesh_start; o1.nbr = M.mesh_nbr;
-#pragma unroll
-        for (int a = 0; a < 9; a++) o1.mat[a] = 0.f;
-        o1.p0 = {tv[0].x, tv[0].y, -sb}; o1.p1 = {tv[1].x, tv[1].y, -sb}; o1.p2 = {tv[2].x, tv[2].y, -sb};
-        o1.p3 = tv[0]; o1.p4 = tv[1]; o1.p5 = tv[2];
-        mpr_kind = 1;
-      }
-    } else if (t1 == 0 && t2 == 7) {
-      // mjc_PlaneConvex: no portal search (never reaches the narrowphase kernel); work item `sub` carries contacts 2 sub, 2 sub + 1
-      if constexpr (MODE != 2) {
-        const V3 normal = ld3(s_gaxis + 3 * g1);
-        if (dot(pos2 - pos1, normal) <= margin + rb2) {
-          q2mat(o2.mat, ldq(s_gquat + 4 * g2));
-          o2.type = t2; o2.pos = pos2; o2.r = r2; o2.h = l2; o2.margin = 0.f; set_mesh(M, o2, g2);
-          const int total = plane_hull(o2, pos1, normal, margin, 0.3f * rb2, 2 * sub, co0.dist, co0.pos, co1.dist, co1.pos);
-          co0.n = normal; co1.n = normal;
-          n = min(max(total - 2 * sub, 0), 2);
-        }
-      }
-    } else if (MESH != 0 && (t1 == 7 || t2 == 7)) {
-      // mjc_Convex: both geoms in the world frame, each inflated by half the margin
-      q2mat(o1.mat, ldq(s_gquat + 4 * g1));
-      q2mat(o2.mat, ldq(s_gquat + 4 * g2));
-      o1.type = t1; o1.pos = pos1; o1.r = c1.z; o1.h = c1.w; o1.margin = 0.5f * margin; set_mesh(M, o1, g1);
-      o2.type = t2; o2.pos = pos2; o2.r = r2; o2.h = l2; o2.margin = 0.5f * margin; set_mesh(M, o2, g2);
-      o1.p0 = o1.p1 = o1.p2 = o1.p3 = o1.p4 = o1.p5 = V3{0.f, 0.f, 0.f};
-      mpr_kind = 2;
-    } else if (MODE == 2) {  // (the analytic pairs never reach the narrowphase kernel)
-    } else if (t1 == 0) {
-      const V3 normal = ld3(s_gaxis + 3 * g1);
-      if (dot(pos2 - pos1, normal) <= margin + rb2) {
-        if (t2 == 2) n = plane_sphere(co0, margin, pos1, normal, pos2, r2) ? 1 : 0;
-        else {
-          ConOut ca, cb;
-          const bool h1 = plane_sphere(ca, margin, pos1, normal, pos2 + ax2 * l2, r2);
-          const bool h2 = plane_sphere(cb, margin, pos1, normal, pos2 - ax2 * l2, r2);
-          co0 = h1 ? ca : cb;
-          co1 = cb;
-          n = (h1 ? 1 : 0) + (h2 ? 1 : 0);
-          hint = ax2;
-        }
-      }
-    } else {
-      const float r1 = c1.z, l1 = c1.w;
-      if (t1 == 2 && t2 == 2) n = sphere_sphere(co0, margin, pos1, r1, pos2, r2) ? 1 : 0;
-      else if (t1 == 2) {
-        const float x = clampf(dot(ax2, pos1 - pos2), -l2, l2);
-        n = sphere_sphere(co0, margin, pos1, r1, pos2 + ax2 * x, r2) ? 1 : 0;
-      } else n = capsule_capsule(co0, co1, margin, pos1, ld3(s_gaxis + 3 * g1), r1, l1, pos2, ax2, r2, l2);
-    }
-  }
-  if constexpr (MODE == 1) return mpr_kind;
-  if (mpr_kind) {
-    float depth;
-    V3 dir, vec;
-    const bool hit = mpr_penetration<MESH>(o1, o2, M.mpr_iterations, (double)M.mpr_tolerance, depth, dir, vec);
-    if (mpr_kind == 1) {
-      if (hit && depth >= 2.220446e-16f) {
-        co0.dist = -depth;
-        co0.n = mrot(hm, dir);
-        co0.pos = mrot(hm, vec) + pos1;
-        n = 1;
-      }
-    } else if (hit && !(dir.x == 0.f && dir.y == 0.f && dir.z == 0.f)) {
-      co0.dist = margin - depth;
-      co0.n = dir;
-      co0.pos = vec;
-      n = 1;
-    }
-    if (n) {  // mjc_fixNormal: spheres and capsules know their own normal
-      float m1[9], m2[9];
-      q2mat(m1, ldq(s_gquat + 4 * g1));
-      q2mat(m2, ldq(s_gquat + 4 * g2));
-      V3 n1, n2;
-      const bool h1 = analytic_normal(t1, pos1, m1, c1.w, co0.pos, n1), h2 = analytic_normal(t2, ld3(s_gpos + 3 * g2), m2, c2.y, co0.pos, n2);
-      if (h1 || h2) {
-        V3 nn = {0.f, 0.f, 0.f};
-        if (h1) nn = nn + n1;
-        if (h2) nn = nn - n2;
-        float len;
-        nn = normalized(nn, &len);
-        if (len >= HB_MINVAL) co0.n = nn;
-      }
-    }
-  }
-  return mpr_kind;
-}
-
-// ordered append of one round's results: slot = ncon + (# contacts of lower lanes)
-template <int NC>
-__device__ __forceinline__ void append_contacts(int lane, float* s_con, int& ncon, int n, const ConOut& co0, const ConOut& co1, V3 hint, int p) {
-  const unsigned long long b1 = __ballot(n >= 1), b2 = __ballot(n >= 2);
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const int slot = ncon + __popcll(b1 & lt) + __popcll(b2 & lt);
-  if (n >= 1 && slot < NC) {
-    float* c = s_con + slot * kConStride;
-    c[C_DIST] = co0.dist;
-    st3(c + C_POS, co0.pos);
-    make_frame(c + C_FRAME, co0.n, hint);
-    c[C_PAIR] = __int_as_float(p);
-  }
-  if (n >= 2 && slot + 1 < NC) {
-    float* c = s_con + (slot + 1) * kConStride;
-    c[C_DIST] = co1.dist;
-    st3(c + C_POS, co1.pos);
-    make_frame(c + C_FRAME, co1.n, hint);
-    c[C_PAIR] = __int_as_float(p);
-  }
-  ncon += __popcll(b1) + __popcll(b2);
-}
-
-// the fused form: all three passes in the step kernel
-template <int NC>
-__device__ __forceinline__ int collide_general(DevModelRef M, const float* hdata_all, int lane, const float* s_gpos, const float* s_gaxis, const float* s_gquat,
-                                               float* s_con, int* s_scratch, int& status) {
-  const int* s_list = s_scratch;
-  const int* s_pinfo = s_scratch + kListMax;
-  const int* s_work = s_pinfo + 4 * kListMax;
-  const int nwork = build_work_list(M, lane, s_gpos, s_gaxis, s_gquat, s_scratch, status);
-  int ncon = 0;
-  for (int w0 = 0; w0 < nwork; w0 += kGroup) {
-    const bool have = w0 + lane < nwork;
-    const int item = have ? s_work[w0 + lane] : 0;
-    const int idx = item >> 16, sub = item & 0xffff;
-    const int p = have ? s_list[idx] : 0;
-    ConOut co0, co1;
-    int n;
-    V3 hint;
-    eval_work_item<0>(M, hdata_all, have, p, sub, s_pinfo[4 * idx], s_pinfo[4 * idx + 1], s_pinfo[4 * idx + 2], __int_as_float(s_pinfo[4 * idx + 3]), s_gpos, s_gaxis, s_gquat, co0, co1, n, hint);
-    append_contacts<NC>(lane, s_con, ncon, n, co0, co1, hint, p);
-  }
-  if (ncon > NC) { status |= (1 << 1); ncon = NC; }
-  return ncon;
-}
-
-// the staged form's third part: the work items were evaluated by hb_narrow_kernel; append its results in work-item order
-template <int NC>
-__device__ __forceinline__ int collide_gather(DevModelRef M, int lane, int env, const StageBufs& G, const float* s_gaxis, float* s_con, int& status) {
-  // (overflow of the pair / work lists was flagged by hb_pose_kernel, which clamps the count it stores)
-  const int nwork = min(max(G.nwork[env], 0), kWorkMax);
-  int ncon = 0;
-  const float4* R = G.result + ((size_t)env * kWorkMax) * 4;
-  for (int w0 = 0; w0 < nwork; w0 += kGroup) {
-    const bool have = w0 + lane < nwork;
-    ConOut co0, co1;
-    co0.dist = 0.f; co0.pos = {0.f, 0.f, 0.f}; co0.n = {0.f, 0.f, 1.f}; co1 = co0;
-    int n = 0, p = 0;
-    V3 hint = {0.f, 0.f, 0.f};
-    if (have) {
-      const float4 a = R[4 * (w0 + lane)], b = R[4 * (w0 + lane) + 1], c = R[4 * (w0 + lane) + 2], d = R[4 * (w0 + lane) + 3];
-      co0.dist = a.x; co0.pos = {a.y, a.z, a.w}; co0.n = {b.x, b.y, b.z}; n = __float_as_int(b.w);
-      co1.dist = c.x; co1.pos = {c.y, c.z, c.w}; co1.n = {d.x, d.y, d.z}; p = __float_as_int(d.w);
-      if (n >= 1) {  // the frame hint of a plane-capsule pair: the capsule's axis
-        const float4 c0 = M.crec[3 * (size_t)p];
-        const int t1 = __float_as_int(c0.z) & 255, t2 = (__float_as_int(c0.z) >> 8) & 255;
-        if (t1 == 0 && t2 == 3) hint = ld3(s_gaxis + 3 * __float_as_int(c0.y));
-      }
-    }
-    append_contacts<NC>(lane, s_con, ncon, n, co0, co1, hint, p);
-  }
-  if (ncon > NC) { status |= (1 << 1); ncon = NC; }
-  return ncon;
-}
 
 // SOLVER: mjtSolver of the instantiation (0 = PGS, 2 = Newton); everything outside the constraint solve, the mass-matrix
 // factorisation and the integrator's damped solve is shared.
@@ -2912,1063 +1974,6 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_h27_kernel(const D
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 0, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
 
-// ---- staged step of the general variants: poses + work lists, then the narrowphase, each in a kernel of its own ------------------
-// hb_pose_kernel: one wave per env.  The state checks and mj_kinematics of step_body, statement for statement (the step kernel
-// repeats them: a pose costs less to recompute than to hand over), the geoms' world poses, broadphase and work items.
-__global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, const BatchPtrs P) {
-  DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= P.nblk) return;
-  const int env = P.blk0 + (int)blockIdx.x;
-  if (P.env_mask && !P.env_mask[env]) { if (lane == 0) { P.stage.nwork[env] = 0; P.stage.nsearch[2 * env] = 0; P.stage.nsearch[2 * env + 1] = 0; } return; }
-  const int nq = M.nq, nv = M.nv, nb = M.nbody, ng = M.ngeom;
-  float* s_qpos = lds;
-  float* s_xpq = s_qpos + ((nq + 3) & ~3);
-  float* s_gpos = s_xpq + kXpqStride * nb;
-  float* s_gaxis = s_gpos + ((3 * ng + 3) & ~3);
-  float* s_gquat = s_gaxis + ((3 * ng + 3) & ~3);
-  int* s_scratch = reinterpret_cast<int*>(s_gquat + 4 * ng);
-  const float* gstate = P.state + (size_t)env * M.nstate;
-  // mj_checkPos / mj_checkVel: a bad state is reset before the step, and the step's poses are those of qpos0
-  bool badp = false, badv = false;
-  for (int i = lane; i < nq; i += kGroup) { const float v = gstate[1 + i]; s_qpos[i] = v; badp |= !(fabsf(v) <= HB_MAXVAL); }
-  for (int i = lane; i < nv; i += kGroup) { const float v = gstate[1 + nq + i]; badv |= !(fabsf(v) <= HB_MAXVAL); }
-  if (__any(badp) || __any(badv)) for (int i = lane; i < nq; i += kGroup) s_qpos[i] = M.qpos0[i];
-  const bool bl = lane + 1 < nb;
-  float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, bp = q0, bq = q0;
-  float4 JA[3], JB[3], JC[3];
-#pragma unroll
-  for (int jj = 0; jj < 3; jj++) { JA[jj] = q0; JB[jj] = q0; JC[jj] = q0; }
-  if (bl) {
-    const float4 HB_CONST* R = M.brec + (size_t)(lane + 1) * kBrecQuads;
-    q0 = R[0]; q1 = R[1]; bp = R[2]; bq = R[3];
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) { JA[jj] = R[9 + 3 * jj]; JB[jj] = R[10 + 3 * jj]; JC[jj] = R[11 + 3 * jj]; }
-  }
-  int pf_gbody = 0;
-  V3 pf_gpos = {0.f, 0.f, 0.f};
-  Q4 pf_gquat = {1.f, 0.f, 0.f, 0.f};
-  if (lane < ng) { pf_gbody = M.geom_bodyid[lane]; pf_gpos = ld3(M.geom_pos + 3 * lane); pf_gquat = ldq(M.geom_quat + 4 * lane); }
-  if (lane == 0) { st3(s_xpq, {0.f, 0.f, 0.f}); stq(s_xpq + 4, {1.f, 0.f, 0.f, 0.f}); }
-  gsync();
-  const int myb = __float_as_int(q0.x), myp = __float_as_int(q0.y), myjn = __float_as_int(q0.z);
-  const int myanc2 = (__float_as_int(q1.x) >> 8) & 255, myanc4 = (__float_as_int(q1.x) >> 16) & 255, myanc8 = (__float_as_int(q1.x) >> 24) & 255;
-  const bool isfree = bl && myjn == 1 && __float_as_int(JA[0].x) == 0;
-  V3 posl = {bp.x, bp.y, bp.z};
-  Q4 quatl = {bq.x, bq.y, bq.z, bq.w};
-  if (isfree) {
-    const int qa = __float_as_int(JA[0].y);
-    posl = ld3(s_qpos + qa);
-    quatl = qnormalize(ldq(s_qpos + qa + 3));
-  } else if (bl) {
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) {
-      if (jj < myjn) {
-        const int qa = __float_as_int(JA[jj].y);
-        const V3 laxis = {JB[jj].x, JB[jj].y, JB[jj].z}, lpos = {JC[jj].x, JC[jj].y, JC[jj].z};
-        const V3 axl = qrot(quatl, laxis);
-        const V3 ancl = qrot(quatl, lpos) + posl;
-        const float dq = s_qpos[qa] - JA[jj].w;
-        if (__float_as_int(JA[jj].x) == 2) posl = posl + axl * dq;
-        else {
-          quatl = qmul(quatl, axisangle(laxis, dq));
-          posl = ancl - qrot(quatl, lpos);
-        }
-      }
-    }
-  }
-  V3 mypos = posl;
-  Q4 myquat = quatl;
-  if (bl) {
-    reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
-    reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
-  }
-  gsync();
-  for (int r = 0, span = 1; span < M.nlevel - 1 || r == 0; r++, span <<= 1) {
-    const int anc = r == 0 ? myp : (r == 1 ? myanc2 : (r == 2 ? myanc4 : myanc8));
-    float4 pp4 = {0.f, 0.f, 0.f, 0.f}, pq4 = {1.f, 0.f, 0.f, 0.f};
-    if (bl) { const float4* Pp = reinterpret_cast<const float4*>(s_xpq + kXpqStride * anc); pp4 = Pp[0]; pq4 = Pp[1]; }
-    gsync();
-    if (bl && anc != 0) {
-      const Q4 pq = {pq4.x, pq4.y, pq4.z, pq4.w};
-      mypos = V3{pp4.x, pp4.y, pp4.z} + qrot(pq, mypos);
-      myquat = qnormalize(qmul(pq, myquat));
-      reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[0] = {mypos.x, mypos.y, mypos.z, 0.f};
-      reinterpret_cast<float4*>(s_xpq + kXpqStride * myb)[1] = {myquat.w, myquat.x, myquat.y, myquat.z};
-    }
-    gsync();
-  }
-  // geoms: world position, z axis and orientation (the step kernel rotates the offset with the body's matrix: the same q2mat here)
-  if (lane < ng) {
-    const int g = lane, b = pf_gbody;
-    float mat[9];
-    q2mat(mat, ldq(s_xpq + kXpqStride * b + 4));
-    const V3 gp = ld3(s_xpq + kXpqStride * b) + mrot(mat, pf_gpos);
-    const Q4 q = qmul(ldq(s_xpq + kXpqStride * b + 4), pf_gquat);
-    const V3 ga = {2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z};
-    st3(s_gpos + 3 * g, gp); st3(s_gaxis + 3 * g, ga); stq(s_gquat + 4 * g, q);
-    float* o = P.stage.geom + (size_t)env * ng * 10;  // per env: positions[3 ng] | z axes[3 ng] | quaternions[4 ng]
-    st3(o + 3 * g, gp); st3(o + 3 * ng + 3 * g, ga); stq(o + 6 * ng + 4 * g, q);
-  }
-  gsync();
-  int status = 0;
-  const int nwork = build_work_list(M, lane, s_gpos, s_gaxis, s_gquat, s_scratch, status);
-  const int* s_list = s_scratch;
-  const int* s_pinfo = s_scratch + kListMax;
-  const int* s_work = s_pinfo + 4 * kListMax;
-  // Every item but its portal search (the analytic pairs completely; a prism's height test): results of the items that are done
-  // go straight to the step kernel's input, the others are listed for hb_narrow_kernel, which packs them 64 to a wave whatever env
-  // they belong to (an env has about nine: one wave per env would run mostly empty).
-  const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
-  const float* hdata = P.dr ? P.dr + (size_t)env * P.dr_stride + DL.o_hfield : (const float*)M.hfield_data;
-  float4* R = P.stage.result + (size_t)env * kWorkMax * 4;
-  int4* items = P.stage.item + (size_t)env * kWorkMax;
-  int nsearch1 = 0, nsearch2 = 0;
-  for (int w0 = 0; w0 < nwork; w0 += kGroup) {
-    const int w = w0 + lane;
-    const bool have = w < nwork;
-    const int item = have ? s_work[w] : 0;
-    const int idx = item >> 16, sub = item & 0xffff;
-    const int p = have ? s_list[idx] : 0;
-    const int rmin = s_pinfo[4 * idx], cmin = s_pinfo[4 * idx + 1], ncols = s_pinfo[4 * idx + 2];
-    ConOut co0, co1;
-    int n;
-    V3 hint;
-    const int kind = eval_work_item<1>(M, hdata, have, p, sub, rmin, cmin, ncols, __int_as_float(s_pinfo[4 * idx + 3]), s_gpos, s_gaxis, s_gquat, co0, co1, n, hint);
-    if (have && !kind) {
-      R[4 * w] = {co0.dist, co0.pos.x, co0.pos.y, co0.pos.z};
-      R[4 * w + 1] = {co0.n.x, co0.n.y, co0.n.z, __int_as_float(n)};
-      R[4 * w + 2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
-      R[4 * w + 3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(p)};
-    }
-    // (the env's own slots: prism searches from the front, pair searches from the back)
-    const unsigned long long need1 = __ballot(have && kind == 1), need2 = __ballot(have && kind == 2);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int4 rec = {env, p | (w << 16), sub | (ncols << 16), rmin | (cmin << 16)};
-    if (have && kind == 1) items[nsearch1 + __popcll(need1 & below)] = rec;
-    if (have && kind == 2) items[kWorkMax - 1 - (nsearch2 + __popcll(need2 & below))] = rec;
-    nsearch1 += __popcll(need1); nsearch2 += __popcll(need2);
-  }
-  if (lane == 0) {
-    P.stage.nwork[env] = nwork;
-    P.stage.nsearch[2 * env] = nsearch1; P.stage.nsearch[2 * env + 1] = nsearch2;
-    int* c = P.counts + kCountStride * (size_t)env;
-    c[5] = nwork; c[6] = nsearch1 + nsearch2;
-    if (status) atomicOr(P.status + env, status);
-  }
-}
-
-// hb_narrow_kernel: the portal searches, one wave per env (and per 64 of its searches): lane l runs the env's l-th search, prisms
-// first, exactly as the fused step kernel would (eval_work_item).  The waves are mostly empty (an env has about nine searches), but
-// there are as many of them as the chip holds at once; packing the searches of all envs densely into waves (a prefix sum over the
-// per-env counts, 64 / 16 / 4 searches per wave, one kernel per kind of search) measured slower: a wave's time is set by its
-// longest search and the divergence between its lanes, not by how many lanes it has.
-template <int MESH>
-__device__ __forceinline__ void narrow_body(const DevModel* Mp, const BatchPtrs& P) {
-  DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
-  const int lane = threadIdx.x;
-  // heavy first (BatchPtrs::order2: the envs of this launch sorted by the time their wave took in an earlier step): the launch ends
-  // when its slowest wave does, and a slow wave that starts in the last round ends late
-  const int chunk = (int)blockIdx.x / P.nblk, slot = P.blk0 + (int)blockIdx.x % P.nblk;
-  const int env = P.order2 ? P.order2[slot] : slot;
-  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-  const int n1 = P.stage.nsearch[2 * env], n2 = P.stage.nsearch[2 * env + 1];
-  const int j = chunk * kGroup + lane;
-  if (chunk * kGroup >= n1 + n2) { if (chunk == 0 && lane == 0) P.counts[kCountStride * (size_t)env + 7] = 0; return; }
-  const bool have = j < n1 + n2;
-  int4 it = {env, 0, 1 << 16, 0};
-  if (have) it = P.stage.item[(size_t)env * kWorkMax + (j < n1 ? j : kWorkMax - 1 - (j - n1))];
-  const int ng = M.ngeom;
-  const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
-  const int p = it.y & 0xffff, w = it.y >> 16;
-  const float* g = P.stage.geom + (size_t)env * ng * 10;
-  const float* hdata = P.dr ? P.dr + (size_t)env * P.dr_stride + DL.o_hfield : (const float*)M.hfield_data;
-  ConOut co0, co1;
-  int n;
-  V3 hint;
-  eval_work_item<2, MESH>(M, hdata, have, p, it.z & 0xffff, it.w & 0xffff, it.w >> 16, it.z >> 16, 0.f, g, g + 3 * ng, g + 6 * ng, co0, co1, n, hint);
-  if (have) {
-    float4* R = P.stage.result + ((size_t)env * kWorkMax + w) * 4;
-    R[0] = {co0.dist, co0.pos.x, co0.pos.y, co0.pos.z};
-    R[1] = {co0.n.x, co0.n.y, co0.n.z, __int_as_float(n)};
-    R[2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
-    R[3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(p)};
-  }
-  if (chunk == 0 && lane == 0) P.counts[kCountStride * (size_t)env + 7] = (int)min(255ull, (__builtin_amdgcn_s_memtime() - t_begin) >> 10);
-}
-__global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<1>(Mp, P); }
-// a model without mesh geoms (configs[4]: capsules and spheres over the height field's prisms): no hull climb in the kernel
-__global__ __launch_bounds__(kGroup, 3) void hb_narrow_prim_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<0>(Mp, P); }
-
-// ---- MJPC task cost on the recorded read-out rows --------------------------------------------------------------
-// mjpc::Norm (mujoco_mpc/mjpc/norm.cc:50-208), value only
-__device__ __forceinline__ float mjpc_norm(int type, const float* x, int n, float p, float q) {
-  float y = 0.f;
-  switch (type) {
-    case 0: for (int i = 0; i < n; i++) y += x[i] * x[i]; return 0.5f * y;                                   // kQuadratic
-    case 1: { float c = 0.f; for (int i = 0; i < n; i++) c += x[i] * x[i]; return powf(powf(c, 0.5f * q) + powf(p, q), 1.f / q) - p; }  // kL22
-    case 2: { float c = 0.f; for (int i = 0; i < n; i++) c += x[i] * x[i]; return sqrtf(c + p * p) - p; }  // kL2
-    case 3: for (int i = 0; i < n; i++) y += p * p * (coshf(x[i] / p) - 1.f); return y;                      // kCosh
-    case 5: for (int i = 0; i < n; i++) y += powf(fabsf(x[i]), p); return y;                                   // kPowerLoss
-    case 6: for (int i = 0; i < n; i++) y += sqrtf(x[i] * x[i] + p * p) - p; return y;                         // kSmoothAbsLoss
-    case 7: for (int i = 0; i < n; i++) y += powf(powf(fabsf(x[i]), q) + powf(p, q), 1.f / q) - p; return y;  // kSmoothAbs2Loss
-    case 8: for (int i = 0; i < n; i++) y += p > 0.f ? p * logf(1.f + expf(x[i] / p)) : fmaxf(x[i], 0.f); return y;  // kRectifyLoss
-    default: return x[0];                                                                                       // kNull
-  }
-}
-
-// BaseResidualFn::CostTerms + CostValue (mujoco_mpc/mjpc/task.cc:71-110): term k = weight[k] * Norm(norm[k]) of the next dim[k] residual
-// entries; the sum goes through the risk transformation (risk-neutral below kRiskNeutralTolerance = 1e-6).  `terms` nullable.
-__device__ __forceinline__ float mjpc_risk(float risk, float c) { return fabsf(risk) >= 1e-6f ? (expf(risk * c) - 1.f) / risk : c; }
-__device__ __forceinline__ float mjpc_cost_value(int nterm, const int* dim, const int* norm, const float* weight, const float* p, const float* q, float risk,
-                                                 const float* res, float* terms) {
-  float cost = 0.f;
-  int sh = 0;
-  for (int k = 0; k < nterm; k++) {
-    const float tk = weight[k] * mjpc_norm(norm[k], res + sh, dim[k], p[k], q[k]);
-    if (terms) terms[k] = tk;
-    cost += tk;
-    sh += dim[k];
-  }
-  return mjpc_risk(risk, cost);
-}
-
-// hb_task_cost: the same cost evaluation for n caller-supplied residual vectors (one thread each)
-__global__ void hb_cost_terms_kernel(const float* residual, int n, int nres, const CostSpec K, float* terms, float* cost) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  cost[e] = mjpc_cost_value(K.nterm, K.dim, K.norm, K.weight, K.p, K.q, K.risk, residual + (size_t)e * nres, terms ? terms + (size_t)e * K.nterm : nullptr);
-}
-
-// One thread per candidate: Stand::ResidualFn::Residual (tasks/humanoid/stand/stand.cc:41-104) on each of the H rows,
-// BaseResidualFn::CostValue (task.cc:71-110), Trajectory::UpdateReturn (trajectory.cc:312-326); a candidate that raised
-// a bad-state warning returns kMaxReturnValue (trajectory.cc:29,169-173)
-__global__ void hb_stand_cost_kernel(const float* rows, int H, int n_env, const StandTask K, const int* status, float* total, float* costs) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_env) return;
-  float sum = 0.f;
-  for (int t = 0; t < H; t++) {
-    const float* r = rows + ((size_t)t * n_env + e) * K.stride;
-    float fz = 0.f, fx = 0.f, fy = 0.f;
-    for (int k = 0; k < K.n_feet; k++) { fx += r[K.o_feet + 3 * k]; fy += r[K.o_feet + 3 * k + 1]; fz += r[K.o_feet + 3 * k + 2]; }
-    const float inv = 1.f / (float)K.n_feet;
-    const float height = r[K.o_head + 2] - fz * inv - K.height_goal;
-    const float kFallTime = 0.2f;
-    const float dx = fx * inv - (r[K.o_com] + kFallTime * r[K.o_vel]), dy = fy * inv - (r[K.o_com + 1] + kFallTime * r[K.o_vel + 1]);
-    const float balance = sqrtf(dx * dx + dy * dy);
-    float c = K.weight[0] * mjpc_norm(K.norm[0], &height, 1, K.p[0], K.q[0]);
-    c += K.weight[1] * mjpc_norm(K.norm[1], &balance, 1, K.p[1], K.q[1]);
-    c += K.weight[2] * mjpc_norm(K.norm[2], r + K.o_vel, 2, K.p[2], K.q[2]);
-    c += K.weight[3] * mjpc_norm(K.norm[3], r + K.o_qvel + 6, K.nv - 6, K.p[3], K.q[3]);
-    c += K.weight[4] * mjpc_norm(K.norm[4], r + K.o_ctrl, K.nu, K.p[4], K.q[4]);
-    c = mjpc_risk(K.risk, c);
-    if (costs) costs[(size_t)t * n_env + e] = c;
-    sum += c;
-  }
-  const bool failed = status[e] & ((1 << 4) | (1 << 5) | (1 << 6));
-  total[e] = failed ? 1.0e6f : sum / (float)max(H, 1);
-}
-
-// Walk::ResidualFn::Residual (tasks/humanoid/walk/walk.cc:44-163) on each of the H rows, then the cost terms in the
-// order and with the dimensions the task's user sensors declare (task.cc:71-89), return as in hb_stand_cost_kernel
-__global__ void hb_walk_cost_kernel(const float* rows, int H, int n_env, const WalkTask K, const int* status, float* total, float* costs) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_env) return;
-  float sum = 0.f;
-  for (int t = 0; t < H; t++) {
-    const float* r = rows + ((size_t)t * n_env + e) * K.stride;
-    float res[96];
-    int c = 0;
-    const float torso_height = r[K.o_torso + 2];
-    res[c++] = torso_height - K.height_goal;
-    const float* fr = r + K.o_foot_r;
-    const float* fl = r + K.o_foot_l;
-    res[c++] = 0.5f * (fl[2] + fr[2]) - r[K.o_pelvis + 2] - 0.2f;
-    // balance: capture point against its projection onto the segment between the feet
-    float cp[3] = {r[K.o_com] + 0.3f * r[K.o_vel], r[K.o_com + 1] + 0.3f * r[K.o_vel + 1], 1.0e-3f};
-    float axis[3] = {fr[0] - fl[0], fr[1] - fl[1], 1.0e-3f};
-    float an = sqrtf(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
-    if (an < 1e-15f) { axis[0] = 1.f; axis[1] = 0.f; axis[2] = 0.f; } else { axis[0] /= an; axis[1] /= an; axis[2] /= an; }  // mju_normalize3
-    const float length = 0.5f * an - 0.05f;
-    const float center[3] = {0.5f * (fr[0] + fl[0]), 0.5f * (fr[1] + fl[1]), 0.5f * (fr[2] + fl[2])};
-    const float vec[3] = {cp[0] - center[0], cp[1] - center[1], cp[2] - center[2]};
-    float tt = vec[0] * axis[0] + vec[1] * axis[1] + vec[2] * axis[2];
-    tt = fmaxf(-length, fminf(length, tt));
-    const float pcp[2] = {axis[0] * tt + center[0], axis[1] * tt + center[1]};
-    const float standing = torso_height / sqrtf(torso_height * torso_height + 0.45f * 0.45f) - 0.4f;
-    res[c++] = standing * (cp[0] - pcp[0]);
-    res[c++] = standing * (cp[1] - pcp[1]);
-    // upright: axes are [torso_up, pelvis_up, foot_right_up, foot_left_up, torso_forward, pelvis_forward, foot_right_forward, foot_left_forward]
-    const float* ax = r + K.o_axes;
-    res[c++] = ax[2] - 1.f;
-    res[c++] = 0.3f * (ax[3 + 2] - 1.f);
-    for (int f = 0; f < 2; f++) {
-      const float* up = ax + 3 * (2 + f);
-      res[c++] = 0.1f * standing * up[0]; res[c++] = 0.1f * standing * up[1]; res[c++] = 0.1f * standing * (up[2] - 1.f);
-    }
-    // posture
-    for (int i = 7; i < K.nq; i++) res[c++] = r[K.o_qpos + i];
-    // walk
-    float fw[2] = {0.f, 0.f};
-    for (int k = 4; k < 8; k++) { fw[0] += ax[3 * k]; fw[1] += ax[3 * k + 1]; }
-    const float fn = sqrtf(fw[0] * fw[0] + fw[1] * fw[1]);
-    if (fn < 1e-15f) { fw[0] = 1.f; fw[1] = 0.f; } else { fw[0] /= fn; fw[1] /= fn; }  // mju_normalize
-    const float* tv = r + K.o_linvel;  // torso, foot_right, foot_left
-    const float cv[2] = {0.5f * (r[K.o_sub] + tv[0]), 0.5f * (r[K.o_sub + 1] + tv[1])};
-    res[c++] = standing * (cv[0] * fw[0] + cv[1] * fw[1] - K.speed_goal);
-    // move feet
-    res[c++] = standing * (cv[0] - 0.5f * tv[3] - 0.5f * tv[6]);
-    res[c++] = standing * (cv[1] - 0.5f * tv[4] - 0.5f * tv[7]);
-    // control
-    for (int i = 0; i < K.nu; i++) res[c++] = r[K.o_ctrl + i];
-    const float cost = mjpc_cost_value(K.nterm, K.dim, K.norm, K.weight, K.p, K.q, K.risk, res, nullptr);
-    if (costs) costs[(size_t)t * n_env + e] = cost;
-    sum += cost;
-  }
-  const bool failed = status[e] & ((1 << 4) | (1 << 5) | (1 << 6));
-  total[e] = failed ? 1.0e6f : sum / (float)max(H, 1);
-}
-
-// ---- SamplingPolicy::Action on the device (mujoco_mpc/mjpc/planners/sampling/policy.cc:50-58): every candidate's
-// time spline (mjpc/spline/spline.cc:103-156,240-277: zero-order / linear / cubic Hermite with finite-difference slopes)
-// sampled at time0 + t * dt and clamped to ctrlrange, written as the action tape [T][n_env][nu] the rollouts read.
-// knots: [n_env][P][nu]; times: [P], increasing, shared by the candidates.
-__global__ void hb_spline_tape_kernel(const DevModel M, const float* knots, const float* times, int P, int interp, float time0, float dt, int T, int n_env, float* tape) {
-  const int nu = M.nu;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)T * n_env * nu;
-  if (idx >= total) return;
-  const int i = (int)(idx % nu), e = (int)((idx / nu) % n_env), t = (int)(idx / ((size_t)nu * n_env));
-  const float time = time0 + (float)t * dt;
-  const float* y = knots + (size_t)e * P * nu + i;  // y[k * nu]: node k
-  float v;
-  int up = 0;
-  while (up < P && times[up] <= time) up++;  // std::upper_bound
-  if (P == 0) v = 0.f;
-  else if (up == P) v = y[(size_t)(P - 1) * nu];
-  else if (up == 0) v = y[0];
-  else {
-    const int lo = up - 1;
-    const float t0 = times[lo], t1 = times[up], x = (time - t0) / (t1 - t0);
-    const float p0 = y[(size_t)lo * nu], p1 = y[(size_t)up * nu];
-    if (interp == 0) v = p0;
-    else if (interp == 1) v = p0 * (1.f - x) + p1 * x;
-    else {
-      // TimeSpline::Slope: one-sided at the ends, mean of the two one-sided differences inside
-      auto slope = [&](int k) {
-        if (k == 0) return (y[(size_t)1 * nu] - y[0]) / (times[1] - times[0]);
-        const float back = (y[(size_t)k * nu] - y[(size_t)(k - 1) * nu]) / (times[k] - times[k - 1]);
-        if (k == P - 1) return back;
-        return 0.5f * (y[(size_t)(k + 1) * nu] - y[(size_t)k * nu]) / (times[k + 1] - times[k]) + 0.5f * back;
-      };
-      const float h = t1 - t0, x2 = x * x, x3 = x2 * x;
-      v = (2.f * x3 - 3.f * x2 + 1.f) * p0 + (x3 - 2.f * x2 + x) * h * slope(lo) + (-2.f * x3 + 3.f * x2) * p1 + (x3 - x2) * h * slope(up);
-    }
-  }
-  // Clamp(action, actuator_ctrlrange, nu) (utilities.cc:94-98); an actuator without a control range is left alone
-  const float lo_r = M.act_ctrlrange[2 * i], hi_r = M.act_ctrlrange[2 * i + 1];
-  if (M.act_ctrllimited[i] || lo_r < hi_r) v = fminf(fmaxf(v, lo_r), hi_r);
-  tape[idx] = v;
-}
-
-// ------------------------------------------------------------------------------------------
-// reset: qpos0/keyframe (+ Halton perturbation), zero velocity/warmstart/time/status
-// qpos <- reset pose (+ the Halton perturbation indexed by global env and, for the env adapter, episode), rest zero
-// (lane l of nl cooperating lanes writes the entries it owns: the qpos entries of joints l, l + nl, ... - every qpos entry belongs to one
-// joint - and a strided share of the velocity and warm-start entries; l = 0, nl = 1: one thread does it all)
-__device__ __forceinline__ void reset_state(const DevModel& M, float* s, const float* qpos_src, float perturb, int env_global, int ep, float quat_perturb = 0.f, int l = 0,
-                                            int nl = 1) {
-  if (l == 0) s[0] = 0.f;
-  for (int i = l; i < 2 * M.nv; i += nl) s[1 + M.nq + i] = 0.f;
-  const int idx = env_global + 1 + ep * 7919;
-  for (int j = l; j < M.njnt; j += nl) {
-    const int qa = M.jnt_qposadr[j];
-    if (M.jnt_type[j] == 0) {
-      for (int i = 0; i < 7; i++) s[1 + qa + i] = qpos_src[qa + i];
-      if (perturb > 0.f) {
-        s[1 + qa + 2] += perturb * 0.1f * halton(idx, 3);
-        // root orientation: every quaternion component +- quat_perturb (cpu_env.py:316-328), left unnormalised as in the reference
-        for (int i = 0; i < 4; i++) s[1 + qa + 3 + i] += perturb * quat_perturb * (2.f * halton(idx, 2 + M.njnt + i) - 1.f);
-      }
-    } else {
-      s[1 + qa] = qpos_src[qa];
-      if (perturb > 0.f) s[1 + qa] += perturb * 0.2f * (2.f * halton(idx, 2 + j) - 1.f);
-    }
-  }
-}
-__global__ void hb_reset_kernel(const DevModel M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
-                                int env_offset, float quat_perturb) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_env) return;
-  if (mask && !mask[e]) return;
-  reset_state(M, state + (size_t)e * M.nstate, qpos_src, perturb, env_offset + e, episode ? episode[e] : 0, quat_perturb);
-  status[e] = 0;
-}
-
-// ---- env realism (hb_env_randomization): counter-based random numbers, delay rings, pushes -------------------
-// One 32-bit word per (seed, global env, episode, step, stream, element): reproducible, order-free, and the same
-// on any split of the batch.  tests/env_ref.py restates these functions in numpy.
-
-
-// start of an episode: delays drawn (cpu_env.py:135-168), rings logically empty, push schedule cleared
-__device__ __forceinline__ void envrand_begin_episode(const DevModel& M, const EnvRand& R, const EnvRandState& S, int e, int env_global, int ep) {
-  const float dt = R.control_timestep > 0.f ? R.control_timestep : M.timestep;
-  for (int c = 0; c < 4; c++) {
-    const float u = rng_uniform(R.seed, env_global, ep, 0, RS_DELAY, c);
-    const float d = (R.min_delay + u * (R.max_delay - R.min_delay)) * R.factor;
-    S.delay[4 * e + c] = min(kDelaySlots - 1, max(0, (int)rintf(d / dt)));
-  }
-  S.k_act[e] = 0;
-  S.k_obs[e] = 0;
-  float* p = S.push + 8 * (size_t)e;
-  if (S.xfrc) {
-    const int body = (int)p[5];
-    if (body > 0 && body < M.nbody) { S.xfrc[((size_t)e * M.nbody + body) * 6] = 0.f; S.xfrc[((size_t)e * M.nbody + body) * 6 + 1] = 0.f; }
-  }
-  for (int i = 0; i < 8; i++) p[i] = 0.f;
-}
-__global__ void hb_envrand_reset_kernel(const DevModel M, const EnvRand R, const EnvRandState S, const int* episode, const uint8_t* mask, int n_env, int env_offset) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_env || (mask && !mask[e])) return;
-  envrand_begin_episode(M, R, S, e, env_offset + e, episode[e]);
-}
-
-// Per-env model parameters of one episode (cpu_env.py:188-264): see hb_domain_randomization in include/hb.h.
-enum { RS_DR_MASS = 16, RS_DR_EXTRA, RS_DR_FRIC, RS_DR_ARM, RS_DR_STIFF, RS_DR_MARGIN, RS_DR_RANGE, RS_DR_KP, RS_DR_FRC, RS_DR_FLOOR };
-// (NL cooperating lanes, l = this lane's number among them: every table is filled lane-strided; the height map's range is reduced
-// over the lanes with shuffles, so NL is 1 or the env kernels' kDrawLanes = 16 consecutive lanes of a wave)
-constexpr int kDrawLanes = 16;
-template <int NL>
-__device__ __forceinline__ void domain_draw(const DevModel& M, const DomainRand& D, float* d, int env_global, int ep, int l = 0) {
-  static_assert(NL == 1 || NL == kDrawLanes, "domain_draw: one lane or kDrawLanes");
-  const DomainLayout L = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
-  const float rf = D.factor;
-  auto U = [&](int stream, int idx) { return rng_uniform(D.seed, env_global, ep, 0, stream, idx); };
-  if (l == 0) d[L.o_mass] = 0.f;
-  const int bx = M.nbody > 1 ? 1 + min(M.nbody - 2, (int)(U(RS_DR_EXTRA, 0) * (float)(M.nbody - 1))) : -1;  // the body that carries the extra mass
-  for (int sl = 1 + l; sl < M.nbody; sl += NL) {  // brec is level-ordered: slot -> body id, mass
-    const float4 q0 = M.brec[(size_t)sl * kBrecQuads], q1 = M.brec[(size_t)sl * kBrecQuads + 1];
-    const int b = __float_as_int(q0.x);
-    float mass = fmaxf(1e-5f, q1.z + (2.f * U(RS_DR_MASS, b) - 1.f) * D.max_mass_change * rf);
-    if (b == bx) mass += U(RS_DR_EXTRA, 1) * D.max_external_mass * rf;
-    d[L.o_mass + b] = mass;
-  }
-  for (int i = l; i < M.nv; i += NL) {
-    const float4 dA = M.drec[3 * i], dB = M.drec[3 * i + 1];
-    const bool scalar = __float_as_int(dA.z) >= 2;  // hinge / slide
-    d[L.o_arm + i] = dB.y + (scalar ? U(RS_DR_ARM, i) * D.armature_max_change * rf : 0.f);
-    d[L.o_stiff + i] = dB.w + (scalar ? U(RS_DR_STIFF, i) * D.stiffness_max_change * rf : 0.f);
-  }
-  for (int c = l; c < M.nlimcand; c += NL) {
-    const bool joint = M.lim_kind[c] == 0;
-    const int id = M.lim_id[c];
-    d[L.o_lmargin + c] = M.lim_margin[c] + (joint ? U(RS_DR_MARGIN, id) * D.margin_max_change * rf : 0.f);  // one margin per joint
-    d[L.o_lrange + c] = M.lim_range[c] + (joint ? (2.f * U(RS_DR_RANGE, c) - 1.f) * D.range_max_change * rf : 0.f);
-  }
-  for (int a = l; a < M.nu; a += NL) {
-    float gain = M.act_gain[a], bias1 = M.act_bias[3 * a + 1];
-    if (D.kp_nominal > 0.f) {
-      gain = D.kp_nominal + (2.f * U(RS_DR_KP, a) - 1.f) * D.kp_max_change * rf;
-      if (bias1 != 0.f) bias1 = -gain;
-    }
-    d[L.o_gain + a] = gain;
-    d[L.o_bias1 + a] = bias1;
-    d[L.o_frc + 2 * a] = M.act_forcerange[2 * a] + (2.f * U(RS_DR_FRC, 2 * a) - 1.f) * D.force_limit_max_change * rf;
-    d[L.o_frc + 2 * a + 1] = M.act_forcerange[2 * a + 1] + (2.f * U(RS_DR_FRC, 2 * a + 1) - 1.f) * D.force_limit_max_change * rf;
-  }
-  if (l == 0) d[L.o_fric] = (1.f - rf) + (D.friction_min_mult + U(RS_DR_FRIC, 0) * (D.friction_max_mult - D.friction_min_mult)) * rf;
-  // floor height maps (CPUEnv._randomize_floor_heightmap, cpu_env.py:267-280: Perlin noise on the grid, shifted and scaled to
-  // [0, 1], times MIN + factor (MAX - MIN)).  The reference's noise comes from the third-party perlin_noise package; here:
-  // three octaves of smooth value noise from the counter-based generator, normalised the same way.
-  const float bump = D.floor_bump_min + rf * (D.floor_bump_max - D.floor_bump_min);
-  for (int hf = 0, adr = 0; adr < M.nhfielddata; hf++) {
-    const int nr = M.hfield_nrow[hf], nc = M.hfield_ncol[hf], n = nr * nc;
-    float* h = d + L.o_hfield + adr;
-    if (!(D.floor_bump_max > 0.f)) { for (int i = l; i < n; i += NL) h[i] = M.hfield_data[adr + i]; adr += n; continue; }
-    float lo = 3.0e38f, hi = -3.0e38f;
-    for (int i = l; i < n; i += NL) {
-      const int r = i / nc, c = i - r * nc;
-      float v = 0.f, amp = 1.f;
-      for (int oct = 0, cells = 2; oct < 3; oct++, cells *= 2, amp *= 0.5f) {  // lattices of 3x3, 5x5, 9x9 nodes over the field
-        const float x = (float)c / (float)max(1, nc - 1) * (float)cells, y = (float)r / (float)max(1, nr - 1) * (float)cells;
-        const int x0 = min((int)x, cells - 1), y0 = min((int)y, cells - 1);
-        float fx = x - (float)x0, fy = y - (float)y0;
-        fx = fx * fx * (3.f - 2.f * fx); fy = fy * fy * (3.f - 2.f * fy);  // smoothstep
-        auto node = [&](int ix, int iy) { return rng_uniform(D.seed, env_global, ep, hf, RS_DR_FLOOR, (oct * 16 + iy) * 16 + ix); };
-        const float a = node(x0, y0), b = node(x0 + 1, y0), cc = node(x0, y0 + 1), dd = node(x0 + 1, y0 + 1);
-        v += amp * ((a * (1.f - fx) + b * fx) * (1.f - fy) + (cc * (1.f - fx) + dd * fx) * fy);
-      }
-      h[i] = v;  // (re-read below by the lane that wrote it)
-      lo = fminf(lo, v); hi = fmaxf(hi, v);
-    }
-    if (NL > 1) {
-#pragma unroll
-      for (int m = NL / 2; m >= 1; m >>= 1) { lo = fminf(lo, __shfl_xor(lo, m, NL)); hi = fmaxf(hi, __shfl_xor(hi, m, NL)); }
-    }
-    const float sc = hi > lo ? bump / (hi - lo) : 0.f;
-    for (int i = l; i < n; i += NL) h[i] = (h[i] - lo) * sc;
-    adr += n;
-  }
-}
-__global__ void hb_domain_rand_kernel(const DevModel M, const DomainRand D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset) {
-  const int e = (blockIdx.x * blockDim.x + threadIdx.x) / kDrawLanes, l = threadIdx.x % kDrawLanes;
-  if (e >= n_env || (mask && !mask[e])) return;
-  domain_draw<kDrawLanes>(M, D, dr + (size_t)e * stride, env_offset + e, episode[e], l);
-}
-
-// value through a delay ring: push x as item k, return item k - d (filler before the ring has d items)
-__device__ __forceinline__ float ring_delay(float* ring, int stride, int k, int d, float x, float filler) {
-  ring[(size_t)(k % kDelaySlots) * stride] = x;
-  if (d == 0) return x;
-  return k >= d ? ring[(size_t)((k - d) % kDelaySlots) * stride] : filler;
-}
-
-// CPUEnv._apply_action + _apply_external_forces (cpu_env.py:612-674) for one env per thread.
-// action == nullptr: the reference's step(None), which re-applies the current controls without noise.
-__global__ void hb_action_env_kernel(const DevModel M, const EnvRand R, const EnvRandState S, const float* action, float* prev, float* latest, float* ctrl,
-                                     const int* episode, const float* state, const uint8_t* mask, int n_env, int env_offset) {
-  // (sixteen lanes per env: the actuators lane-strided, the push schedule on the env's first lane)
-  const int e = (blockIdx.x * blockDim.x + threadIdx.x) / 16, l = threadIdx.x % 16;
-  if (e >= n_env || (mask && !mask[e])) return;
-  const int nu = M.nu, ge = env_offset + e, ep = episode[e];
-  const int k = S.k_act[e], d = S.delay[4 * e];
-  const unsigned kk = R.frozen_noise ? 0u : (unsigned)k;
-  for (int i = l; i < nu; i += 16) {
-    const size_t ai = (size_t)e * nu + i;
-    float a = action ? action[ai] : ctrl[ai];
-    if (action && R.action_noise > 0.f) a += R.factor * R.action_noise * rng_normal(R.seed, ge, ep, kk, RS_ACTION, i);
-    const float out = ring_delay(S.fifo_act + ((size_t)e * kDelaySlots) * nu + i, nu, k, d, a, 0.f);
-    prev[ai] = latest[ai];
-    latest[ai] = out;
-    ctrl[ai] = out;
-  }
-  if (l != 0) return;
-  S.k_act[e] = k + 1;
-  if (R.push_enabled && S.xfrc) {
-    float* p = S.push + 8 * (size_t)e;
-    float* xf = S.xfrc + (size_t)e * M.nbody * 6;
-    const float time = state[(size_t)e * M.nstate];
-    if (time >= p[0] + p[1]) {  // window over (or first step): clear the old force, schedule the next push
-      const unsigned ev = (unsigned)p[6];
-      int body = (int)p[5];
-      if (body > 0 && body < M.nbody) { xf[6 * body] = 0.f; xf[6 * body + 1] = 0.f; }
-      p[0] = time + R.push_min_interval + rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 0) * (R.push_max_interval - R.push_min_interval);
-      p[1] = R.push_min_duration + rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 1) * (R.push_max_duration - R.push_min_duration);
-      p[2] = R.factor * (R.push_min_force + rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 2) * (R.push_max_force - R.push_min_force));
-      float dx = 2.f * rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 3) - 1.f, dy = 2.f * rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 4) - 1.f;
-      const float n = sqrtf(dx * dx + dy * dy);  // never 0: the uniforms are odd multiples of 2^-24
-      p[3] = dx / n; p[4] = dy / n;
-      body = 1 + min(M.nbody - 2, (int)(rng_uniform(R.seed, ge, ep, ev, RS_PUSH, 5) * (float)(M.nbody - 1)));
-      p[5] = (float)body;
-      p[6] = (float)(ev + 1);
-    }
-    if (time > p[0] && time < p[0] + p[1]) {
-      const int body = (int)p[5];
-      xf[6 * body] = p[3] * p[2];
-      xf[6 * body + 1] = p[4] * p[2];
-    }
-  }
-}
-
-// CPUEnv._get_obs's noise and delay lines (cpu_env.py:465-545) applied in place to the true observation o
-// env adapter: observation, the 27-DoF analogue of CPUEnv._get_obs (cpu_env.py:465-571):
-// [hinge/slide qpos, hinge/slide qvel, root angular velocity, gravity direction in the root body frame]
-// (lane l of nl cooperating lanes writes entries l, l + nl, ... of each part)
-__device__ __forceinline__ Q4 obs_root_quat(const DevModel& M, const float* s) {
-  const int da = M.obs_root_dofadr;
-  return da >= 0 ? ldq(s + 1 + M.jnt_qposadr[M.dof_jntid[da]] + 3) : Q4{1.f, 0.f, 0.f, 0.f};
-}
-__device__ __forceinline__ void compute_obs(const DevModel& M, const float* s, float* o, int l = 0, int nl = 1) {
-  const float* qpos = s + 1;
-  const float* qvel = s + 1 + M.nq;
-  const int nj = (M.nobs - 6) / 2;
-  for (int i = l; i < nj; i += nl) { o[i] = qpos[M.jnt_qposadr[M.obs_jnt[i]]]; o[nj + i] = qvel[M.jnt_dofadr[M.obs_jnt[i]]]; }
-  const int da = M.obs_root_dofadr;
-  // gravity direction in the torso frame: R(q)^T (0,0,-1)  (cpu_env.py:510-519)
-  float m[9];
-  q2mat(m, qnormalize(obs_root_quat(M, s)));
-  for (int c = l; c < 3; c += nl) { o[2 * nj + c] = da >= 0 ? qvel[da + 3 + c] : 0.f; o[2 * nj + 3 + c] = -m[6 + c]; }
-}
-
-// the same observation through CPUEnv's sensor model (cpu_env.py:465-571): noise on every reading, each group of readings delayed by
-// its own number of control steps (rings of kDelaySlots past readings)
-__device__ __forceinline__ void envrand_observe(const DevModel& M, const EnvRand& R, const EnvRandState& S, int e, int env_global, int ep, const float* s, float* o, int l = 0,
-                                                int nl = 1) {
-  const float* qpos = s + 1;
-  const float* qvel = s + 1 + M.nq;
-  const int k = S.k_obs[e];
-  const unsigned kk = R.frozen_noise ? 0u : (unsigned)k;
-  const int nj = (M.nobs - 6) / 2;
-  const int dj = S.delay[4 * e + 1], dg = S.delay[4 * e + 2], dv = S.delay[4 * e + 3];
-  float* rj = S.fifo_joint + ((size_t)e * kDelaySlots) * 2 * nj;
-  for (int i = l; i < nj; i += nl) {
-    const float a = qpos[M.jnt_qposadr[M.obs_jnt[i]]] + R.factor * R.joint_angle_noise * rng_normal(R.seed, env_global, ep, kk, RS_JOINT_POS, i);
-    const float v = qvel[M.jnt_dofadr[M.obs_jnt[i]]] + R.factor * R.joint_velocity_noise * rng_normal(R.seed, env_global, ep, kk, RS_JOINT_VEL, i);
-    o[i] = ring_delay(rj + i, 2 * nj, k, dj, a, 0.f);
-    o[nj + i] = ring_delay(rj + nj + i, 2 * nj, k, dj, v, 0.f);
-  }
-  if (l < 3) {  // (the three components of the gyro and of the gravity direction: lanes 0..2, or one lane all three)
-    const int da = M.obs_root_dofadr;
-    // gravity direction from the noisy, re-normalised torso quaternion (Rotation.from_quat normalises)
-    Q4 q = obs_root_quat(M, s);
-    q.w += R.factor * R.imu_noise * rng_normal(R.seed, env_global, ep, kk, RS_IMU, 0);
-    q.x += R.factor * R.imu_noise * rng_normal(R.seed, env_global, ep, kk, RS_IMU, 1);
-    q.y += R.factor * R.imu_noise * rng_normal(R.seed, env_global, ep, kk, RS_IMU, 2);
-    q.z += R.factor * R.imu_noise * rng_normal(R.seed, env_global, ep, kk, RS_IMU, 3);
-    float m[9];
-    q2mat(m, qnormalize(q));
-    float* rg = S.fifo_gyro + ((size_t)e * kDelaySlots) * 3;
-    float* rv = S.fifo_grav + ((size_t)e * kDelaySlots) * 3;
-    for (int c = l; c < 3; c += nl) {
-      const float w = (da >= 0 ? qvel[da + 3 + c] : 0.f) + R.factor * R.gyro_noise * rng_normal(R.seed, env_global, ep, kk, RS_GYRO, c);
-      o[2 * nj + c] = ring_delay(rg + c, 3, k, dg, w, 0.f);
-      o[2 * nj + 3 + c] = ring_delay(rv + c, 3, k, dv, -m[6 + c], c == 2 ? -1.f : 0.f);
-    }
-  }
-  if (l == 0) S.k_obs[e] = k + 1;
-}
-
-__global__ void hb_obs_kernel(const DevModel M, const float* state, float* obs, int n_env) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_env) return;
-  compute_obs(M, state + (size_t)e * M.nstate, obs + (size_t)e * M.nobs);
-}
-
-// CPUEnv._apply_action bookkeeping (cpu_env.py:656-674): previous <- latest, latest <- action, ctrl <- action
-__global__ void hb_action_kernel(const float* action, float* prev, float* latest, float* ctrl, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  prev[i] = latest[i];
-  float a = action[i];
-  latest[i] = a;
-  ctrl[i] = a;
-}
-
-__device__ __forceinline__ float scaled_exp(float x) { return expf(-x / 0.5f); }  // reward_functions.py:17-19
-
-// standupReward (reward_functions.py:247-374) + observation + termination + auto-reset.  kEnvLanes lanes per env, 256 / kEnvLanes
-// envs per block (it was one thread per env: 37 us of serial work on 32 CUs for 4096 envs, a fifth of VecEnv.step_torch's GPU time).
-// The env's state record is staged in LDS (one coalesced pass instead of a strided read per thread); sums over joints, actuators
-// and symmetry pairs are lane-strided partial sums reduced over the env's lanes; an auto-reset writes the new state into the same
-// LDS copy (every lane the joints it owns), so that the observation of the new episode is read from it after the block barrier.
-constexpr int kEnvLanes = 16;
-__device__ __forceinline__ float env_lane_sum(float x) {
-#pragma unroll
-  for (int m = kEnvLanes / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, kEnvLanes);
-  return x;
-}
-__global__ __launch_bounds__(256) void hb_env_kernel(const DevModel M, const EnvConfig cfg, const EnvRand R, const EnvRandState S, float* state, const float* qfrc, const int* counts,
-                              float* prev, float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated,
-                              uint8_t* truncated, const uint8_t* mask, int observe, const DomainRand D, float* dr, int dr_stride, int n_env, int env_offset) {
-  extern __shared__ float sh_state[];
-  const int grp = threadIdx.x / kEnvLanes, l = threadIdx.x % kEnvLanes;
-  const int e = blockIdx.x * (256 / kEnvLanes) + grp;
-  const bool active = e < n_env && (!mask || mask[e]);
-  const int nsp = (M.nstate + 3) & ~3;
-  float* ls = sh_state + grp * nsp;
-  float* s = state + (size_t)(active ? e : 0) * M.nstate;
-  if (active) for (int i = l; i < M.nstate; i += kEnvLanes) ls[i] = s[i];
-  __syncthreads();
-  bool reset = false;
-  if (active) {
-    const float* qpos = ls + 1;
-    const float* qvel = ls + 1 + M.nq;
-    const int da = M.obs_root_dofadr;
-    // root height and the gravity direction in the torso frame (every lane)
-    Q4 q = {1.f, 0.f, 0.f, 0.f};
-    float z = 0.f;
-    if (da >= 0) { const int qa = M.jnt_qposadr[M.dof_jntid[da]]; q = qnormalize(ldq(qpos + qa + 3)); z = qpos[qa + 2]; }
-    float m[9];
-    q2mat(m, q);
-    const float g[3] = {-m[6], -m[7], -m[8]};
-    float r = 0.f;
-    // horizontal velocity
-    float vx = da >= 0 ? qvel[da] : 0.f, vy = da >= 0 ? qvel[da + 1] : 0.f;
-    float dvx = vx - cfg.target_velocity[0], dvy = vy - cfg.target_velocity[1];
-    r += cfg.w_hvel * scaled_exp(dvx * dvx + dvy * dvy);
-    // upright: |g_local - (0,0,-1)|^2
-    r += cfg.w_upright * scaled_exp(g[0] * g[0] + g[1] * g[1] + (g[2] + 1.f) * (g[2] + 1.f));
-    // torso height: linear ramp min_z -> target_z, clamped (numpy.interp)
-    float t = (z - cfg.min_z) / fmaxf(cfg.target_z - cfg.min_z, 1e-9f);
-    r += cfg.w_height * fminf(fmaxf(t, 0.f), 1.f);
-    // joint torques on the scalar joints' dofs
-    {
-      float acc = 0.f, n = 0.f;
-      for (int j = l; j < M.njnt; j += kEnvLanes)
-        if (M.jnt_type[j] >= 2) {
-          float x = fmaxf(fabsf(qfrc[(size_t)e * M.nv + M.jnt_dofadr[j]]) - cfg.safe_torque, 0.f);
-          acc += scaled_exp(x * x);
-          n += 1.f;
-        }
-      acc = env_lane_sum(acc); n = env_lane_sum(n);
-      if (n > 0.f) r += cfg.w_torque * acc / n;
-    }
-    // control change / regularisation / symmetry on the (scaled) actions
-    const float* pa = prev + (size_t)e * M.nu;
-    const float* la = latest + (size_t)e * M.nu;
-    const float inv = 1.f / cfg.action_scale;
-    if (M.nu > 0) {
-      float chg = 0.f, reg = 0.f;
-      for (int i = l; i < M.nu; i += kEnvLanes) {
-        float d = (la[i] - pa[i]) * inv * cfg.control_frequency;
-        chg += scaled_exp(d * d);
-        float a = la[i] * inv;
-        reg += scaled_exp(a * a);
-      }
-      chg = env_lane_sum(chg); reg = env_lane_sum(reg);
-      r += cfg.w_ctrl_change * chg / (float)M.nu + cfg.w_ctrl_reg * reg / (float)M.nu;
-    }
-    if (cfg.n_equal + cfg.n_opposite > 0) {
-      float sym = 0.f;
-      for (int k = l; k < cfg.n_equal + cfg.n_opposite; k += kEnvLanes) {
-        const bool eq = k < cfg.n_equal;
-        const int a0 = eq ? cfg.equal_pairs[k][0] : cfg.opposite_pairs[k - cfg.n_equal][0], a1 = eq ? cfg.equal_pairs[k][1] : cfg.opposite_pairs[k - cfg.n_equal][1];
-        const float d = (eq ? la[a0] - la[a1] : la[a0] + la[a1]) * inv;
-        sym += scaled_exp(d * d);
-      }
-      sym = env_lane_sum(sym);
-      r += cfg.w_symmetry * sym / (float)(cfg.n_equal + cfg.n_opposite);
-    }
-    if (cfg.w_vvel != 0.f) { const float vz = da >= 0 ? qvel[da + 2] : 0.f; r += cfg.w_vvel * scaled_exp(vz * vz); }  // vertical_velocity_penalty
-    if (counts[kCountStride * e + 4]) r += cfg.self_collision_penalty;
-    const bool upright = fmaxf(fabsf(g[0]), fabsf(g[1])) < cfg.upright_tol;
-    const bool timeup = cfg.max_time > 0.f && ls[0] >= cfg.max_time;
-    bool term, trunc;
-    if (cfg.reward_kind == 1) {  // controlInputReward: fall = terminal (with the terminal reward), time limit = truncation
-      term = !upright || z < cfg.min_z_grounded;
-      trunc = timeup;
-    } else {                     // standupReward: time limit = terminal, standing up = truncation ("is_success")
-      term = timeup;
-      trunc = z >= cfg.target_z && upright;
-    }
-    if (term) r = cfg.terminal_reward;
-    if (l == 0) { reward[e] = r; terminated[e] = term ? 1 : 0; truncated[e] = trunc ? 1 : 0; }
-    reset = (term || trunc) && cfg.auto_reset;
-  }
-  const bool rand_on = S.k_obs != nullptr;
-  int ep = active ? episode[e] : 0;
-  __syncthreads();  // (every lane has read the old state and the old episode number)
-  if (reset) {
-    // CPUEnv.reset for this env; the perturbation index advances with the episode count
-    ep += 1;
-    reset_state(M, ls, qpos_src, cfg.reset_perturb, env_offset + e, ep, cfg.reset_quat_perturb, l, kEnvLanes);
-    for (int i = l; i < M.nu; i += kEnvLanes) { prev[(size_t)e * M.nu + i] = 0.f; latest[(size_t)e * M.nu + i] = 0.f; }
-    if (l == 0) {
-      episode[e] = ep;
-      status[e] = 0;
-      if (rand_on) envrand_begin_episode(M, R, S, e, env_offset + e, ep);
-    }
-    static_assert(kEnvLanes == kDrawLanes, "the env kernel draws an episode's model parameters with all lanes of the env");
-    if (dr) domain_draw<kDrawLanes>(M, D, dr + (size_t)e * dr_stride, env_offset + e, ep, l);
-  }
-  __threadfence_block();
-  __syncthreads();  // the new state (LDS) and the new episode's delays (global, written by lane 0) are visible to the env's lanes
-  if (active) {
-    if (reset) for (int i = l; i < M.nstate; i += kEnvLanes) s[i] = ls[i];
-    float* o = obs + (size_t)e * M.nobs;
-    if (rand_on && observe) envrand_observe(M, R, S, e, env_offset + e, ep, ls, o, l, kEnvLanes);
-    else compute_obs(M, ls, o, l, kEnvLanes);
-  }
-}
-
-// hb_env_reset's collision test (cpu_env.py:411-414): envs of the mask that collide (mode 1: any contact, mode 2:
-// self-contact) or ended in their settle step stay in the mask, get a new episode number and are counted
-__global__ void hb_reset_check_kernel(const int* counts, const uint8_t* terminated, const uint8_t* truncated, uint8_t* mask, int* episode, int* pending, int mode,
-                                      int n_env) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_env || !mask[e]) return;
-  const bool hit = mode == 1 ? counts[kCountStride * e] > 0 : counts[kCountStride * e + 4] != 0;
-  if (hit || terminated[e] || truncated[e]) { episode[e]++; atomicAdd(pending, 1); }
-  else mask[e] = 0;
-}
-
-
-// One dense layer of the policy MLP on the matrix cores: Y[M][N] = act(X[M][K] W[K][N] + b[N]).
-// One wave per 32x32 output tile, K swept two columns per v_mfma_f32_32x32x2_f32 (exact f32); the X tile
-// is staged through LDS (row stride K+1: conflict-free A-operand reads), W streams from L2 coalesced.
-__global__ __launch_bounds__(kGroup) void hb_mlp_layer_kernel(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act) {
-  extern __shared__ float xs[];
-  const int lane = threadIdx.x, m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-  const int ks = K + 1;
-  for (int idx = lane; idx < 32 * K; idx += kGroup) {
-    const int r = idx / K, c = idx - r * K;
-    xs[r * ks + c] = (m0 + r < Mrows) ? X[(size_t)(m0 + r) * K + c] : 0.f;
-  }
-  __syncthreads();
-  const int col = lane & 31, half = lane >> 5;
-  const bool nvld = n0 + col < N;
-  f32x16 D;
-#pragma unroll
-  for (int r = 0; r < 16; r++) D[r] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 2) {
-    const int k = k0 + half;
-    const float a = k < K ? xs[col * ks + k] : 0.f;
-    const float bv = (nvld && k < K) ? W[(size_t)k * N + n0 + col] : 0.f;
-    D = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, D, 0, 0, 0);
-  }
-  const float bn = nvld ? bias[n0 + col] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (row < Mrows && nvld) {
-      float v = D[r] + bn;
-      Y[(size_t)row * N + n0 + col] = act ? tanhf(v) : v;
-    }
-  }
-}
-
-// The whole policy in one launch: observation -> every MLP layer -> controls, for 16 envs per block (4096 envs = 256
-// blocks: one per CU; f32 MFMA throughput per CU is the bound, so the batch is spread over the whole chip).
-// Activations never leave LDS (two ping-pong tiles of 16 rows); eight waves share the 16-column output tiles of a
-// layer, each sweeping K four columns per v_mfma_f32_16x16x4_f32 (exact f32) with the A operand from LDS and the
-// B operand from weights pre-packed on the host in operand order (one coalesced 256-byte wave load per MFMA:
-// wp[tile][k/4][lane] = W[4(k/4) + lane/16][16 tile + lane%16]).  A layer with fewer than eight tiles (the
-// nu-wide output layer) splits K across the idle waves instead; the partial tiles are summed in a fixed order
-// (deterministic, no atomics).
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(512) void hb_policy_kernel(const DevModel M, const PolicyDesc pd, const float* state, float* ctrl, int n_env) {
-  extern __shared__ float sm[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * 16, ldx = pd.ldx;
-  float* cur = sm;
-  float* nxt = sm + 16 * ldx;
-  float* part = sm + 32 * ldx;  // [8][16][16] partial tiles
-  // observation tile: 32 threads per env row gather the copied entries through the gather table (independent loads,
-  // all in flight at once), one thread per row derives the gravity direction from the root quaternion
-  {
-    const int row = tid >> 5, sub = tid & 31;
-    float* o = cur + row * ldx;
-    const bool live = m0 + row < n_env;
-    const float* s = state + (size_t)(m0 + row) * M.nstate;
-    const int ncopy = M.nobs - 3;
-    for (int k = sub; k < ncopy; k += 32) {
-      const int src = M.obs_src[k];
-      o[k] = (live && src >= 0) ? s[src] : 0.f;
-    }
-    if (sub == 0) {
-      Q4 q = {1.f, 0.f, 0.f, 0.f};
-      if (live && M.obs_root_qadr >= 0) q = qnormalize(ldq(s + 1 + M.obs_root_qadr + 3));
-      float mm[9];
-      q2mat(mm, q);
-      o[ncopy] = live ? -mm[6] : 0.f; o[ncopy + 1] = live ? -mm[7] : 0.f; o[ncopy + 2] = live ? -mm[8] : 0.f;
-      for (int k = M.nobs; k < M.nobs + 3; k++) o[k] = 0.f;  // K is swept four at a time: the pad columns must be finite
-    }
-  }
-  __syncthreads();
-  const int col = lane & 15, quad = lane >> 4;  // A: row = col, k offset = quad;  B: k offset = quad, column = col;  D: rows 4 quad + r, column col
-  for (int l = 0; l < pd.nl; l++) {
-    const int K = pd.sizes[l], N = pd.sizes[l + 1], KK = (K + 3) / 4, ntile = (N + 15) / 16;
-    const bool last = l + 1 == pd.nl;
-    int S = 1;  // K slices per tile
-    while (S * 2 * ntile <= 8) S *= 2;
-    const float* wp = pd.w[l];
-    const float* bias = pd.b[l];
-    if (!last && tid < 48) nxt[(tid / 3) * ldx + N + tid % 3] = 0.f;  // pad columns of the next layer's input
-    for (int it = wave; it < ntile * S; it += 8) {
-      const int nt = it / S, sl = it - nt * S;
-      const int kb = KK * sl / S, ke = KK * (sl + 1) / S;
-      f32x4v D = {0.f, 0.f, 0.f, 0.f};
-      const float* ap = cur + col * ldx + quad;
-      const float* bp = wp + (size_t)nt * KK * 64 + lane;
-      int kk = kb;
-      for (; kk + 8 <= ke; kk += 8) {  // eight operand pairs in flight per batch of MFMAs
-        float a[8], w[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) { a[u] = ap[4 * (kk + u)]; w[u] = bp[(size_t)(kk + u) * 64]; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) D = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w[u], D, 0, 0, 0);
-      }
-      for (; kk < ke; kk++) D = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk], bp[(size_t)kk * 64], D, 0, 0, 0);
-      const int n = nt * 16 + col;
-      if (S == 1) {
-        const float bn = n < N ? bias[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = 4 * quad + r;
-          if (n < N) {
-            const float v = tanhf(D[r] + bn);
-            if (!last) nxt[row * ldx + n] = v;
-            else if (m0 + row < n_env) ctrl[(size_t)(m0 + row) * N + n] = v;
-          }
-        }
-      } else {
-        float* pp = part + it * 256;
-#pragma unroll
-        for (int r = 0; r < 4; r++) pp[(4 * quad + r) * 16 + col] = D[r];
-      }
-    }
-    __syncthreads();
-    if (S > 1) {
-      for (int idx = tid; idx < ntile * 256; idx += 512) {
-        const int nt = idx >> 8, rc = idx & 255, row = rc >> 4, n = nt * 16 + (rc & 15);
-        if (n < N) {
-          float v = bias[n];
-          for (int sl = 0; sl < S; sl++) v += part[(nt * S + sl) * 256 + rc];
-          v = tanhf(v);
-          if (!last) nxt[row * ldx + n] = v;
-          else if (m0 + row < n_env) ctrl[(size_t)(m0 + row) * N + n] = v;
-        }
-      }
-      __syncthreads();
-    }
-    float* t = cur; cur = nxt; nxt = t;
-  }
-}
-
-// The same policy without LDS and inside 64 VGPRs: four waves per block of sixteen envs, activations ping-pong through an L2-resident
-// scratch (the waves of a block share the CU's vector L1).  Two step-kernel waves per SIMD leave 64 VGPRs, six wave slots and no LDS:
-// blocks of THIS kernel run beside them (measured: 6 us slower beside a chip full of step waves than alone), where the LDS variant
-// (33 KB per block) waits for two step blocks of a CU to retire (config 4, pipelined: its 10 us became 43).
-// Activations are stored in the A-operand order of v_mfma_f32_16x16x4_f32 - element (env row, k) at [k / 4][k % 4][row] - so that a
-// k-step's operand is one contiguous 256-byte wave load like the host-packed weights (row-major rows 260 floats apart cost sixteen
-// cache lines per load: 52 us for 4096 envs).
-// (amdgpu_num_vgpr counts per half of the unified register file: 32 -> 64 registers in all, tools/kernel_resources.sh; with 48 - what
-// is left beside two 232-register waves - the kernel spills 23 values and the loop runs 3.10e7 instead of 3.20e7 env-steps/s)
-__attribute__((amdgpu_num_vgpr(32))) __global__ __launch_bounds__(256) void hb_policy_lean_kernel(const DevModel M, const PolicyDesc pd, const float* state, float* ctrl,
-                                                                                                  float* act, int n_env) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * 16, ldx = pd.ldx;
-  float* cur = act + (size_t)blockIdx.x * 32 * ldx;  // [ldx / 4][4][16]
-  float* nxt = cur + 16 * ldx;
-  {
-    const int row = tid & 15, sub = tid >> 4;  // sixteen threads per observation column stride, consecutive threads = consecutive rows
-    const bool live = m0 + row < n_env;
-    const float* s = state + (size_t)(live ? m0 + row : 0) * M.nstate;
-    const int ncopy = M.nobs - 3;
-    for (int k = sub; k < ncopy; k += 16) {
-      const int src = M.obs_src[k];
-      cur[(k >> 2) * 64 + (k & 3) * 16 + row] = (live && src >= 0) ? s[src] : 0.f;
-    }
-    if (sub == 0) {
-      Q4 q = {1.f, 0.f, 0.f, 0.f};
-      if (live && M.obs_root_qadr >= 0) q = qnormalize(ldq(s + 1 + M.obs_root_qadr + 3));
-      // third row of the rotation matrix of q (q2mat's m[6..8])
-      const float m6 = 2.f * (q.x * q.z - q.w * q.y), m7 = 2.f * (q.y * q.z + q.w * q.x), m8 = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
-      const float g3[3] = {live ? -m6 : 0.f, live ? -m7 : 0.f, live ? -m8 : 0.f};
-      for (int c = 0; c < 3; c++) { const int k = ncopy + c; cur[(k >> 2) * 64 + (k & 3) * 16 + row] = g3[c]; }
-      for (int k = M.nobs; k < ((M.nobs + 3) & ~3); k++) cur[(k >> 2) * 64 + (k & 3) * 16 + row] = 0.f;  // K is swept four at a time: the pad columns must be finite
-    }
-  }
-  __syncthreads();
-  const int col = lane & 15, quad = lane >> 4;  // B: k offset = quad, column = col;  D: rows 4 quad + r, column col
-  for (int l = 0; l < pd.nl; l++) {
-    const int K = pd.sizes[l], N = pd.sizes[l + 1], KK = (K + 3) / 4, ntile = (N + 15) / 16;
-    const bool last = l + 1 == pd.nl;
-    const float* wp = pd.w[l];
-    const float* bias = pd.b[l];
-    if (!last && tid < 16 * (((N + 3) & ~3) - N)) { const int k = N + tid / 16; nxt[(k >> 2) * 64 + (k & 3) * 16 + (tid & 15)] = 0.f; }  // pad columns of the next layer's input
-    // two output tiles per wave and pass: they share the A operand, and their accumulators are two independent MFMA chains
-    for (int nt = 2 * wave; nt < ntile; nt += 8) {
-      const bool two = nt + 1 < ntile;
-      f32x4v D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
-      const float* ap = cur + lane;
-      const float* bp0 = wp + (size_t)nt * KK * 64 + lane;
-      const float* bp1 = bp0 + (two ? (size_t)KK * 64 : 0);
-      int kk = 0;
-      for (; kk + 4 <= KK; kk += 4) {  // four k-steps of operands in flight per batch of MFMAs (measured: three are slower; loading the next batch under this one's MFMAs changes nothing)
-        float a[4], w0[4], w1[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = ap[(kk + u) * 64]; w0[u] = bp0[(kk + u) * 64]; w1[u] = bp1[(kk + u) * 64]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w0[u], D0, 0, 0, 0);
-          D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w1[u], D1, 0, 0, 0);
-        }
-      }
-      for (; kk < KK; kk++) {
-        const float a = ap[kk * 64];
-        D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp0[kk * 64], D0, 0, 0, 0);
-        D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp1[kk * 64], D1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        if (h == 1 && !two) break;
-        const int n = (nt + h) * 16 + col;
-        const float bn = n < N ? bias[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = 4 * quad + r;
-          if (n < N) {
-            const float v = tanhf((h ? D1[r] : D0[r]) + bn);
-            if (!last) nxt[(n >> 2) * 64 + (n & 3) * 16 + row] = v;
-            else if (m0 + row < n_env) ctrl[(size_t)(m0 + row) * N + n] = v;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    float* t = cur; cur = nxt; nxt = t;
-  }
-}
-
-// Probe for hb_batch_pipeline: one wave that idles for `ticks` of the 100 MHz wall clock (bounded by the sleep count as well) and
-// records when it began and ended.  Two of these on two streams overlap in time exactly when the streams own different hardware queues.
-__global__ __launch_bounds__(64) void hb_probe_spin_kernel(unsigned long long* out, unsigned ticks) {
-  const unsigned long long t0 = wall_clock64();
-  unsigned long long t = t0;
-  for (int guard = 0; guard < 2048 && t - t0 < ticks; guard++) {
-    __builtin_amdgcn_s_sleep(64);
-    t = wall_clock64();
-  }
-  if (threadIdx.x == 0) { out[0] = t0; out[1] = t; }
-}
-// Heavy-first dispatch order for the next launch: counting sort of the envs by the cost proxy of their
-// last step (constraint rows x solver sweeps, counts[4e+3]), most expensive first (LPT scheduling of
-// the 4096 blocks over the resident slots).  One block; the order inside a cost bin is arbitrary,
-// which cannot change results (envs are independent).
-__global__ __launch_bounds__(1024) void hb_order_kernel(const int* counts, int* order, int* keys, int e0, int n, int slot, int shift) {
-  // sorts envs e0 .. e0+n-1 into order[e0 .. e0+n-1], most expensive first; cost = counts[env][slot] >> shift, 256 bins
-  __shared__ int hist[256];
-  __shared__ int base[256];
-  const int tid = threadIdx.x;
-  if (tid < 256) hist[tid] = 0;
-  __syncthreads();
-  for (int e = e0 + tid; e < e0 + n; e += blockDim.x) {
-    int key = min(255, counts[kCountStride * e + slot] >> shift);
-    keys[e] = key;  // read ONCE: the slow lane of two-lane stepping may be writing counts beside this kernel, and a key that changed
-                    // between the two passes would leave an env out of the permutation
-    atomicAdd(&hist[255 - key], 1);  // bin 0 = most expensive
-  }
-  __syncthreads();
-  // exclusive prefix sum of the 256 bins (Hillis-Steele on 256 threads: 8 rounds instead of a 256-step serial loop
-  // on one thread, which was most of this kernel's 9 us on the critical path of every fourth step)
-  if (tid < 256) base[tid] = hist[tid];
-  __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    int v = 0;
-    if (tid < 256 && tid >= o) v = base[tid - o];
-    __syncthreads();
-    if (tid < 256) base[tid] += v;
-    __syncthreads();
-  }
-  if (tid < 256) base[tid] += e0 - hist[tid];  // inclusive -> exclusive, offset by the segment start
-  __syncthreads();
-  for (int e = e0 + tid; e < e0 + n; e += blockDim.x) {
-    const int key = keys[e];
-    order[atomicAdd(&base[255 - key], 1)] = e;
-  }
-}
-
-// benchmark controls: ctrl[t][e][i] = 2*H(1+t0+t+1000*(env_offset+e), i+2) - 1  (testspeed.cc:64-80)
-__global__ void hb_halton_ctrl_kernel(float* out, int T, int n_env, int nu, int t0, int env_offset) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)T * n_env * nu;
-  if (idx >= total) return;
-  int i = (int)(idx % nu);
-  size_t r = idx / nu;
-  int e = (int)(r % n_env), t = (int)(r / n_env);
-  out[idx] = 2.f * halton(1 + t0 + t + 1000 * (env_offset + e), i + 2) - 1.f;
-}
-
-// ------------------------------------------------------------------------------------------
-// host-callable launchers (declared in hb_launch.hpp)
-}  // namespace hb
-
-#include "hb_launch.hpp"
-
-namespace hb {
-
 // the lean instantiations apply when the launch has none of the optional inputs / outputs (HB_LEAN=0: never)
 static bool lean_launch(const BatchPtrs& P, bool with_qfrc = false) {
   static const bool lean_on = !(getenv("HB_LEAN") && atoi(getenv("HB_LEAN")) == 0);
@@ -4012,11 +2017,7 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
     if (P.qpos_out) Q.qpos_out = P.qpos_out + (size_t)t * P.n_env * P.stage.nq;
     if (P.qvel_out) Q.qvel_out = P.qvel_out + (size_t)t * P.n_env * P.stage.nv;
     if (P.sensor_out) Q.sensor_out = P.sensor_out + (size_t)t * P.n_env * P.sensor_stride;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(hb_pose_kernel, dim3(P.nblk), dim3(kGroup), (size_t)P.stage.pose_lds, stream, M_dev, Q);
-    if (Q.stage.no_mesh) hipLaunchKernelGGL(hb_narrow_prim_kernel, dim3(P.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
-    else hipLaunchKernelGGL(hb_narrow_kernel, dim3(P.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_pose_narrow(M_dev, Q, stream);  // (hb_narrow.hip)
     if (e != hipSuccess) return e;
     if (variant == 1 && Q.stage.defer) {
       // the step kernel without the portal-search code; the full one then takes the (rare) env-steps whose qacc came out bad
@@ -4061,108 +2062,6 @@ hipError_t launch_step_slow(const DevModel* M_dev, int lds_floats, const BatchPt
 hipError_t launch_step_small(const DevModel* M_small, int lds_floats, const BatchPtrs& P, hipStream_t stream) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(hb_step_small_kernel, dim3(P.nblk), dim3(kGroup), (size_t)lds_floats * sizeof(float), stream, M_small, P, 1);
-  return hipGetLastError();
-}
-hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,
-                        int env_offset, hipStream_t stream, float quat_perturb) {
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, status, mask, qpos_src, episode, n_env, perturb, env_offset, quat_perturb);
-  return hipGetLastError();
-}
-hipError_t launch_envrand_reset(const DevModel& M, const EnvRand& R, const EnvRandState& S, const int* episode, const uint8_t* mask, int n_env, int env_offset,
-                                hipStream_t stream) {
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_envrand_reset_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, M, R, S, episode, mask, n_env, env_offset);
-  return hipGetLastError();
-}
-hipError_t launch_action_env(const DevModel& M, const EnvRand& R, const EnvRandState& S, const float* action, float* prev, float* latest, float* ctrl,
-                             const int* episode, const float* state, const uint8_t* mask, int n_env, int env_offset, hipStream_t stream) {
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_action_env_kernel, dim3((n_env + 15) / 16), dim3(256), 0, stream, M, R, S, action, prev, latest, ctrl, episode, state, mask, n_env,
-                     env_offset);
-  return hipGetLastError();
-}
-hipError_t launch_reset_check(const int* counts, const uint8_t* terminated, const uint8_t* truncated, uint8_t* mask, int* episode, int* pending, int mode, int n_env,
-                              hipStream_t stream) {
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_reset_check_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, counts, terminated, truncated, mask, episode, pending, mode, n_env);
-  return hipGetLastError();
-}
-hipError_t launch_obs(const DevModel& M, const float* state, float* obs, int n_env, hipStream_t stream) {
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_obs_kernel, dim3((n_env + 255) / 256), dim3(256), 0, stream, M, state, obs, n_env);
-  return hipGetLastError();
-}
-hipError_t launch_action(const float* action, float* prev, float* latest, float* ctrl, int n, hipStream_t stream) {
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_action_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, action, prev, latest, ctrl, n);
-  return hipGetLastError();
-}
-hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, const EnvRand& R, const EnvRandState& S, float* state, const float* qfrc, const int* counts, float* prev,
-                      float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
-                      const uint8_t* mask, int observe, const DomainRand& D, float* dr, int dr_stride, int n_env, int env_offset, hipStream_t stream) {
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  const int per_block = 256 / kEnvLanes;
-  hipLaunchKernelGGL(hb_env_kernel, dim3((n_env + per_block - 1) / per_block), dim3(256), (size_t)per_block * ((M.nstate + 3) & ~3) * sizeof(float), stream, M, cfg, R, S, state, qfrc, counts, prev, latest, qpos_src, episode, status, obs,
-                     reward, terminated, truncated, mask, observe, D, dr, dr_stride, n_env, env_offset);
-  return hipGetLastError();
-}
-hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset,
-                              hipStream_t stream) {
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_domain_rand_kernel, dim3((n_env + 256 / kDrawLanes - 1) / (256 / kDrawLanes)), dim3(256), 0, stream, M, D, dr, stride, episode, mask, n_env, env_offset);
-  return hipGetLastError();
-}
-hipError_t launch_probe_spin(unsigned long long* out, unsigned ticks, hipStream_t stream) {
-  hipLaunchKernelGGL(hb_probe_spin_kernel, dim3(1), dim3(64), 0, stream, out, ticks);
-  return hipGetLastError();
-}
-hipError_t launch_order(const int* counts, int* order, int n_env, int e0, int n, hipStream_t stream, int slot, int shift) {
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_order_kernel, dim3(1), dim3(1024), 0, stream, counts, order, order + n_env, e0, n, slot, shift);
-  return hipGetLastError();
-}
-hipError_t launch_mlp_layer(const float* X, const float* W, const float* bias, float* Y, int Mrows, int K, int N, int act, hipStream_t stream) {
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_mlp_layer_kernel, dim3((Mrows + 31) / 32, (N + 31) / 32), dim3(kGroup), (size_t)32 * (K + 1) * sizeof(float), stream, X, W, bias, Y, Mrows, K, N, act);
-  return hipGetLastError();
-}
-hipError_t launch_policy_lean(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, float* act, int n_env, hipStream_t stream) {
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_policy_lean_kernel, dim3((n_env + 15) / 16), dim3(256), 0, stream, M, pd, state, ctrl, act, n_env);
-  return hipGetLastError();
-}
-hipError_t launch_policy(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, int n_env, hipStream_t stream) {
-  const size_t shmem = ((size_t)32 * pd.ldx + 8 * 256) * sizeof(float);
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_policy_kernel, dim3((n_env + 15) / 16), dim3(512), shmem, stream, M, pd, state, ctrl, n_env);
-  return hipGetLastError();
-}
-hipError_t launch_halton_ctrl(float* out, int T, int n_env, int nu, int t0, int env_offset, hipStream_t stream) {
-  size_t total = (size_t)T * n_env * nu;
-  (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  hipLaunchKernelGGL(hb_halton_ctrl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, out, T, n_env, nu, t0, env_offset);
-  return hipGetLastError();
-}
-hipError_t launch_stand_cost(const float* rows, int H, int n_env, const StandTask& K, const int* status, float* total, float* costs, hipStream_t stream) {
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_stand_cost_kernel, dim3((n_env + 127) / 128), dim3(128), 0, stream, rows, H, n_env, K, status, total, costs);
-  return hipGetLastError();
-}
-hipError_t launch_walk_cost(const float* rows, int H, int n_env, const WalkTask& K, const int* status, float* total, float* costs, hipStream_t stream) {
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_walk_cost_kernel, dim3((n_env + 63) / 64), dim3(64), 0, stream, rows, H, n_env, K, status, total, costs);
-  return hipGetLastError();
-}
-hipError_t launch_cost_terms(const float* residual, int n, int nres, const CostSpec& K, float* terms, float* cost, hipStream_t stream) {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(hb_cost_terms_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, residual, n, nres, K, terms, cost);
-  return hipGetLastError();
-}
-hipError_t launch_spline_tape(const DevModel& M, const float* knots, const float* times, int P, int interp, float time0, float dt, int T, int n_env, float* tape, hipStream_t stream) {
-  (void)hipGetLastError();
-  const size_t total = (size_t)T * n_env * M.nu;
-  hipLaunchKernelGGL(hb_spline_tape_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, M, knots, times, P, interp, time0, dt, T, n_env, tape);
   return hipGetLastError();
 }
 hipError_t set_step_lds_limit(int bytes) {

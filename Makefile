@@ -3,7 +3,7 @@ HIPCC ?= hipcc
 ARCH ?= gfx950
 CSRC := humanoid_mujoco_amd/csrc
 HOST_SRCS := $(CSRC)/hb_api.cpp $(CSRC)/mjcf.cpp $(CSRC)/setconst.cpp $(CSRC)/model_io.cpp $(CSRC)/mesh.cpp
-HIP_SRCS := $(CSRC)/hb_step.hip $(CSRC)/hb_narrow.hip $(CSRC)/hb_env.hip
+HIP_SRCS := $(CSRC)/hb_step.hip $(CSRC)/hb_step_duo.hip $(CSRC)/hb_narrow.hip $(CSRC)/hb_env.hip
 HDRS := $(wildcard $(CSRC)/*.hpp) include/hb.h
 LIB := humanoid_mujoco_amd/libhb.so
 FLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-result -ffp-contract=on -fno-slp-vectorize -fno-vectorize $(EXTRA)

@@ -655,6 +655,7 @@ struct hb_batch {
   std::vector<hipEvent_t> tev;  // pairs
   int tev_used = 0;
   long long launch_count = 0;
+  const char* last_kernel = "";  // hb_last_kernel
   int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
   int* d_order2 = nullptr;  // the same for the narrowphase launch of a staged step
   int order_mode = 0;       // 0: none yet, 1: one permutation of the whole batch, 2: one permutation per pipe segment
@@ -795,7 +796,7 @@ int launch_segment(hb_batch* b, BatchPtrs P, int nsteps, const Segment& sg, int 
   // a whole-batch permutation would mix segments: a segment only uses the order of its own envs
   P.order = (b->schedule && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2)) ? b->d_order : nullptr;
   P.order2 = (P.order && b->stage.result) ? b->d_order2 : nullptr;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, nsteps, sg.st));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, nsteps, sg.st)); b->last_kernel = last_step_kernel();
   if (reorder) HB_HIP(launch_order(b->d_counts, b->d_order, b->n_env, sg.lo, sg.hi - sg.lo, sg.st));
   if (reorder && b->stage.result) HB_HIP(launch_order(b->d_counts, b->d_order2, b->n_env, sg.lo, sg.hi - sg.lo, sg.st, /*slot=*/7, /*shift=*/0));
   return HB_OK;
@@ -1349,7 +1350,7 @@ int hb_forward(hb_batch* b, const float* ctrl) {
   else if (n) HB_HIP(hipMemsetAsync(ctrl_for_write(b), 0, n * sizeof(float), main_stream(b)));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b)));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b))); b->last_kernel = last_step_kernel();
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
 }
@@ -1833,7 +1834,7 @@ static int rollout_rows(hb_batch* b, const float* ctrl, int H, const hb_sensor_s
   F.ctrl = b->d_ctrl + (H > 1 ? (size_t)(H - 2) * N * nu : 0); F.ctrl_mode = 0; F.integrate = 0;
   F.sensor_out = b->d_sensor_out + (size_t)(H - 1) * N * *stride;
   F.blk0 = 0; F.nblk = N;
-  HB_HIP(launch_step(b->D.d_dm, dm.variant, dm.solver, dm.nv, dm.lds_floats, F, 1, main_stream(b)));
+  HB_HIP(launch_step(b->D.d_dm, dm.variant, dm.solver, dm.nv, dm.lds_floats, F, 1, main_stream(b))); b->last_kernel = last_step_kernel();
   return HB_OK;
 }
 
@@ -1977,7 +1978,7 @@ int hb_sensors(hb_batch* b, const float* ctrl, const hb_sensor_spec* spec, float
   P.ctrl = b->d_ctrl; P.ctrl_mode = 0; P.integrate = 0;
   int rc = sensor_setup(b, spec, 1, P);
   if (rc != HB_OK) return rc;
-  HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b)));
+  HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, 1, main_stream(b))); b->last_kernel = last_step_kernel();
   HB_HIP(hipMemcpyAsync(sensor_out, b->d_sensor_out, (size_t)b->n_env * P.sensor_stride * sizeof(float), hipMemcpyDeviceToHost, main_stream(b)));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   return HB_OK;
@@ -2506,6 +2507,8 @@ int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch, int* kcycles)
   }
   return HB_OK;
 }
+
+const char* hb_last_kernel(const hb_batch* b) { return b ? b->last_kernel : ""; }
 
 int hb_get_lanes(hb_batch* b, int* lane) {
   if (!b) return HB_EINVAL;

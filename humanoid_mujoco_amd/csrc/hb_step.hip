@@ -1974,6 +1974,14 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_h27_kernel(const D
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 0, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
 
+// every step-kernel launch leaves its kernel's name behind (hb_last_kernel: tests and bench.py name the kernel they measured by what the
+// library says it launched, not by a literal)
+static thread_local const char* g_last_step_kernel = "";
+const char* last_step_kernel() { return g_last_step_kernel; }
+#define HB_STEP_LAUNCH(kernel, ...) do { g_last_step_kernel = #kernel; hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
+// two envs per wave (hb_step_duo.hip) for the lean single-step launches of the 27-dof humanoid's PGS kernel; HB_DUO=0: one env per wave
+static bool duo_on() { static const bool on = !(getenv("HB_DUO") && atoi(getenv("HB_DUO")) == 0); return on; }
+
 // the lean instantiations apply when the launch has none of the optional inputs / outputs (HB_LEAN=0: never)
 static bool lean_launch(const BatchPtrs& P, bool with_qfrc = false) {
   static const bool lean_on = !(getenv("HB_LEAN") && atoi(getenv("HB_LEAN")) == 0);
@@ -1982,25 +1990,26 @@ static bool lean_launch(const BatchPtrs& P, bool with_qfrc = false) {
 }
 static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int solver, int nv, size_t shmem, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  if (variant == 2 && nv <= 20) hipLaunchKernelGGL(hb_step_newton_big20_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-  else if (variant == 2) hipLaunchKernelGGL(hb_step_newton_big28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-  else if (variant == 1) hipLaunchKernelGGL(hb_step_gen_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-  else if (variant == 3) hipLaunchKernelGGL(hb_step_gen_big_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  if (variant == 2 && nv <= 20) HB_STEP_LAUNCH(hb_step_newton_big20_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (variant == 2) HB_STEP_LAUNCH(hb_step_newton_big28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (variant == 1) HB_STEP_LAUNCH(hb_step_gen_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (variant == 3) HB_STEP_LAUNCH(hb_step_gen_big_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (solver == 2 && nv <= 28) {
-    if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) hipLaunchKernelGGL(hb_step_newton28_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-    else if (nsteps == 1 && lean_launch(P)) hipLaunchKernelGGL(hb_step_newton28_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-    else if (lean_launch(P, true)) hipLaunchKernelGGL(hb_step_newton28_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-    else hipLaunchKernelGGL(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) HB_STEP_LAUNCH(hb_step_newton28_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (nsteps == 1 && lean_launch(P)) HB_STEP_LAUNCH(hb_step_newton28_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (lean_launch(P, true)) HB_STEP_LAUNCH(hb_step_newton28_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else HB_STEP_LAUNCH(hb_step_newton28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   }
-  else if (solver == 2) hipLaunchKernelGGL(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (solver == 2) HB_STEP_LAUNCH(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (nv <= 28) {
-    if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) hipLaunchKernelGGL(hb_step_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-    else if (nsteps == 1 && lean_launch(P)) hipLaunchKernelGGL(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-    else if (lean_launch(P, true) && (P.lean_ok & 2)) hipLaunchKernelGGL(hb_step_h27_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-    else if (lean_launch(P, true)) hipLaunchKernelGGL(hb_step_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-    else hipLaunchKernelGGL(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2) && duo_on()) { g_last_step_kernel = "hb_step_duo_kernel"; return launch_step_duo(M_dev, P, stream); }
+    else if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) HB_STEP_LAUNCH(hb_step_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (nsteps == 1 && lean_launch(P)) HB_STEP_LAUNCH(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (lean_launch(P, true) && (P.lean_ok & 2)) HB_STEP_LAUNCH(hb_step_h27_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else if (lean_launch(P, true)) HB_STEP_LAUNCH(hb_step_lean_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+    else HB_STEP_LAUNCH(hb_step_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   }
-  else hipLaunchKernelGGL(hb_step32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else HB_STEP_LAUNCH(hb_step32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   return hipGetLastError();
 }
 
@@ -2021,24 +2030,24 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
     if (e != hipSuccess) return e;
     if (variant == 1 && Q.stage.defer) {
       // the step kernel without the portal-search code; the full one then takes the (rare) env-steps whose qacc came out bad
-      if (lean_launch(Q) && (Q.lean_ok & 2)) hipLaunchKernelGGL(hb_step_gen_fast_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
-      else if (lean_launch(Q)) hipLaunchKernelGGL(hb_step_gen_fast_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
-      else hipLaunchKernelGGL(hb_step_gen_fast_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
+      if (lean_launch(Q) && (Q.lean_ok & 2)) HB_STEP_LAUNCH(hb_step_gen_fast_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
+      else if (lean_launch(Q)) HB_STEP_LAUNCH(hb_step_gen_fast_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
+      else HB_STEP_LAUNCH(hb_step_gen_fast_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       Q.stage.rerun = 1;
     } else if (variant == 3 && Q.stage.dm_fast) {
       // PGS: the one-group kernel (63 rows, 24 contacts, two waves per SIMD) first; the kPgsNefcMax-row kernel then steps what it defers
-      hipLaunchKernelGGL(hb_step_gen_fast1_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      HB_STEP_LAUNCH(hb_step_gen_fast1_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       Q.stage.rerun = 1;
     } else if (variant == 2 && Q.stage.dm_fast) {
       // most env-steps fit the one-group Newton instantiation (two waves per SIMD); the four-group kernel then steps the rest
-      if (nv <= 20 && lean_launch(Q) && (Q.lean_ok & 4)) hipLaunchKernelGGL(hb_step_newton_gen20_team_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
-      else if (nv <= 20 && lean_launch(Q)) hipLaunchKernelGGL(hb_step_newton_gen20_lean_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
-      else if (nv <= 20) hipLaunchKernelGGL(hb_step_newton_gen20_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
-      else hipLaunchKernelGGL(hb_step_newton_gen28_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      if (nv <= 20 && lean_launch(Q) && (Q.lean_ok & 4)) HB_STEP_LAUNCH(hb_step_newton_gen20_team_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      else if (nv <= 20 && lean_launch(Q)) HB_STEP_LAUNCH(hb_step_newton_gen20_lean_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      else if (nv <= 20) HB_STEP_LAUNCH(hb_step_newton_gen20_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
+      else HB_STEP_LAUNCH(hb_step_newton_gen28_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
       Q.stage.rerun = 1;
@@ -2056,12 +2065,12 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
 }
 hipError_t launch_step_slow(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int blocks, int nseg, hipStream_t stream) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_step_slow_kernel, dim3(blocks, nseg), dim3(kGroup), (size_t)lds_floats * sizeof(float), stream, M_dev, P, 1);
+  HB_STEP_LAUNCH(hb_step_slow_kernel, dim3(blocks, nseg), dim3(kGroup), (size_t)lds_floats * sizeof(float), stream, M_dev, P, 1);
   return hipGetLastError();
 }
 hipError_t launch_step_small(const DevModel* M_small, int lds_floats, const BatchPtrs& P, hipStream_t stream) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_step_small_kernel, dim3(P.nblk), dim3(kGroup), (size_t)lds_floats * sizeof(float), stream, M_small, P, 1);
+  HB_STEP_LAUNCH(hb_step_small_kernel, dim3(P.nblk), dim3(kGroup), (size_t)lds_floats * sizeof(float), stream, M_small, P, 1);
   return hipGetLastError();
 }
 hipError_t set_step_lds_limit(int bytes) {

@@ -147,6 +147,7 @@ def lib():
     L.hb_get_status.argtypes = [vp, vp]
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
     L.hb_get_lanes.argtypes = [vp, vp]
+    L.hb_last_kernel.argtypes = [vp]; L.hb_last_kernel.restype = ctypes.c_char_p
     L.hb_get_collision_counts.argtypes = [vp, vp, vp, vp]
     L.hb_batch_segments.argtypes = [vp]
     L.hb_diag_enable.argtypes = [vp, ci]
@@ -417,6 +418,10 @@ class Batch:
         a, b, c = (np.zeros(self.n_env, dtype=np.int32) for _ in range(3))
         _check(lib().hb_get_counts(self._h, _ptr(a), _ptr(b), _ptr(c)), "hb_get_counts")
         return a, b, c
+
+    def last_kernel(self):
+        """name of the step kernel the batch's last step / rollout / forward launch ran (include/hb.h: hb_last_kernel)"""
+        return lib().hb_last_kernel(self._h).decode()
 
     def lanes(self):
         """1 per env currently in the slow lane of two-lane stepping (include/hb.h: hb_get_lanes); all zero when it is off."""

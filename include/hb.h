@@ -321,6 +321,11 @@ int hb_get_status(hb_batch* b, int* status);
 /* Per-env counters of the last step: ncon, nefc, solver iterations (mjData.ncon/nefc/
  * solver_niter, mjdata.h:196-201) — what testspeed.cc:97-98 accumulates. */
 int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter);
+/* Name of the step kernel the batch's last step / rollout / forward launch ran ("hb_step_duo_kernel", "hb_step_h27_q_kernel", ...; ""
+ * before the first).  Which instantiation a launch takes depends on the model's solver and sizes and on the optional inputs / outputs
+ * the call asked for: the parity tests assert that the kernel they checked is the kernel the benchmark times, and
+ * bench.py names the kernel of its roofline object by this string.  The pointer stays valid for the life of the library. */
+const char* hb_last_kernel(const hb_batch* b);
 /* Narrowphase work of the last step of each env, for models that collide through mesh hulls or height fields (the staged step:
  * DESIGN.md 3.6): nwork = work items (a candidate pair that passed the broadphase, or one prism of a height-field pair's sub-grid),
  * nsearch = those of them that needed a portal search (mjc_Convex / mjc_ConvexHField: libccd MPR), kcycles = shader clock cycles / 1024

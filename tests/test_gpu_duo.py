@@ -1,0 +1,191 @@
+"""Two envs per wave (hb_step_duo_kernel, csrc/hb_step_duo.hip): the kernel the plain step API - and with it bench.py's timed loop - runs
+for the 27-dof humanoid with the PGS solver.
+
+The golden parity test of tests/test_gpu_parity.py enables the diagnostic read-outs, and a launch with any optional output takes the
+full one-env kernel (hb_step_kernel).  Here the SAME 128 golden states go through the plain step, so that what is compared with the
+fp64 oracle's fixture (oracle/mjstep_oracle.c via tools/make_golden.py; one-step tolerances as stated in tests/test_gpu_parity.py) is
+the timed kernel itself - asserted by name through hb_last_kernel - and the duo kernel is held bit-identical to the one-env kernels on
+every path it has: two envs packed at lanes 0 / 32, a heavy env packed in front of a light one, one env at a time (more than 12
+contacts, rows beyond the packed capacity), an odd env count, the heavy-first order, pipelined segments, the reset paths of mj_check*.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import GOLDEN, HUMANOID_HBM
+
+pytestmark = pytest.mark.gpu
+DUO = "hb_step_duo_kernel"
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "humanoid27_steps.npz"))
+
+
+def pack_state(g, idx):
+    return np.concatenate([g["time"][idx, None], g["qpos"][idx], g["qvel"][idx], g["warm"][idx]], axis=1)
+
+
+def test_golden_states_through_the_timed_kernel(hbmod, humanoid_model, gpu, golden):
+    g = golden
+    n = len(g["env"])
+    for order in (np.arange(n), np.arange(n)[::-1], np.random.default_rng(0).permutation(n)):  # different partners in the wave
+        b = hbmod.Batch(humanoid_model, n, gpu)
+        b.set_state(hbmod.STATE_INTEGRATION, pack_state(g, order))
+        b.step(g["ctrl"][order].astype(np.float32))
+        assert b.last_kernel() == DUO
+        q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
+        ncon, nefc, niter = b.counts()
+        assert not b.status().any()
+        assert np.array_equal(ncon, g["ncon"][order]) and np.array_equal(nefc, g["nefc"][order])
+        # PGS sweep counts: the fp64 oracle's wherever its convergence test is not within rounding of the threshold (fp32 sweeps that stop
+        # one sweep earlier or later there are the one-env kernel's too: the next test holds the two kernels bit-identical)
+        off = niter != g["niter"][order]
+        assert off.sum() <= 2 and np.abs(niter - g["niter"][order]).max() <= 1, (off.sum(), niter[off], g["niter"][order][off])
+        dq = np.abs(q - g["qpos1"][order]) / np.maximum(1.0, np.abs(g["qpos1"][order]))
+        assert dq.max() <= 4e-5, dq.max()
+        vs = np.maximum(1.0, np.abs(g["qvel1"][order]).max(axis=1, keepdims=True))
+        assert (np.abs(v - g["qvel1"][order]) / vs).max() <= 4e-4
+        # qacc_warmstart of the new state is the step's qacc
+        a = b.get_state(hbmod.STATE_WARMSTART).astype(np.float64)
+        as_ = np.maximum(1.0, np.abs(g["qacc"][order]).max(axis=1, keepdims=True))
+        assert (np.abs(a - g["qacc"][order]) / as_).max() <= 4e-4
+        assert np.allclose(b.time, g["time"][order] + 0.005, atol=1e-5)
+        b.close()
+
+
+def _reference_step(hbmod, m, gpu, state, ctrl):
+    """the same step through the full one-env kernel (a launch that asks for the diagnostics takes hb_step_kernel)"""
+    r = hbmod.Batch(m, len(state), gpu)
+    r.diag_enable(True)
+    r.set_state(hbmod.STATE_INTEGRATION, state)
+    r.step(ctrl)
+    assert r.last_kernel() == "hb_step_kernel"
+    out = r.get_state(hbmod.STATE_INTEGRATION), r.counts(), r.status()
+    r.close()
+    return out
+
+
+def test_duo_is_bit_identical_to_the_one_env_kernel(hbmod, humanoid_model, gpu):
+    """benchmark workload, fallen humanoids: single steps through the duo kernel against the full kernel from the same states, for an
+    even and an odd env count, with and without the heavy-first order, unpipelined and in three segments"""
+    m = humanoid_model
+    rng = np.random.default_rng(7)
+    for n, pipe in ((512, False), (385, False), (1024, True)):
+        b = hbmod.Batch(m, n, gpu)
+        b.reset(perturb=True)
+        b.rollout_halton(300)
+        if pipe:
+            b.pipeline(3)
+        for t in range(12):  # (the heavy-first order is re-sorted every fourth call)
+            st = b.get_state(hbmod.STATE_INTEGRATION)
+            ctrl = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
+            b.step(ctrl)
+            assert b.last_kernel() == DUO
+            want, wcounts, wstatus = _reference_step(hbmod, m, gpu, st, ctrl)
+            got = b.get_state(hbmod.STATE_INTEGRATION)
+            assert np.array_equal(got, want), (n, t, np.abs(got - want).max())
+            for x, y in zip(b.counts(), wcounts):
+                assert np.array_equal(x, y)
+        b.close()
+
+
+def _collapsed_states(hbmod, m, gpu, n):
+    """the collapsed regime of profiles/r01_soak_1e10.txt: humanoids dropped from a crouch with their limbs driven into the floor - many
+    contacts and limit rows at once"""
+    b = hbmod.Batch(m, n, gpu)
+    b.reset(perturb=True)
+    rng = np.random.default_rng(11)
+    b.rollout_halton(150)
+    ctrl = np.sign(rng.uniform(-1, 1, size=(n, m.nu))).astype(np.float32)  # saturated actuators
+    for _ in range(60):
+        b.step(ctrl)
+    st = b.get_state(hbmod.STATE_INTEGRATION)
+    b.close()
+    return st, ctrl
+
+
+def test_heavy_env_steps_take_the_packed_and_the_one_at_a_time_paths(hbmod, humanoid_model, gpu):
+    """env-steps above 31 rows: packed in front of their partner's rows when both fit the wave's 64 row lanes, else one env at a time -
+    bit-identical to the one-env kernel either way.  The states are chosen so that both paths occur (asserted on the row counts)."""
+    m = humanoid_model
+    n = 2048
+    st, ctrl = _collapsed_states(hbmod, m, gpu, n)
+    want, (ncon, nefc, niter), wstatus = _reference_step(hbmod, m, gpu, st, ctrl)
+    # partners as the kernel pairs them without an order: env e with env n - 1 - e
+    heavy = nefc > 31
+    partner = nefc[::-1]
+    packed = heavy & (((np.maximum(nefc, partner) + 1 + 3) & ~3) + np.minimum(nefc, partner) + 1 <= 64) & (partner <= 31)
+    alone = (nefc + partner + 2 > 64) | ((nefc > 31) & (partner > 31))
+    print("\nrows: max %d, env-steps above 31 rows %d (packed with their partner %d), waves stepped one env at a time %d, max contacts %d"
+          % (nefc.max(), heavy.sum(), packed.sum(), alone.sum() // 2, ncon.max()))
+    assert heavy.sum() >= 8 and packed.sum() >= 1
+    b = hbmod.Batch(m, n, gpu)
+    b.set_state(hbmod.STATE_INTEGRATION, st)
+    b.step(ctrl)
+    assert b.last_kernel() == DUO
+    got = b.get_state(hbmod.STATE_INTEGRATION)
+    bad = np.flatnonzero((got != want).any(axis=1))
+    assert bad.size == 0, (bad[:8], nefc[bad[:8]], partner[bad[:8]])
+    for x, y in zip(b.counts(), (ncon, nefc, niter)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(b.status(), wstatus)
+    # a heavy env beside a heavy env: force the one-env-at-a-time path by pairing the heaviest envs with each other
+    idx = np.argsort(-nefc)[:64]
+    pair_state = np.concatenate([st[idx], st[idx][::-1]])  # env k's partner is env 127 - k: the same heavy states mirrored
+    pair_ctrl = np.concatenate([ctrl[idx], ctrl[idx][::-1]])
+    want2, counts2, _ = _reference_step(hbmod, m, gpu, pair_state, pair_ctrl)
+    c = hbmod.Batch(m, len(pair_state), gpu)
+    c.set_state(hbmod.STATE_INTEGRATION, pair_state)
+    c.step(pair_ctrl)
+    assert c.last_kernel() == DUO
+    assert np.array_equal(c.get_state(hbmod.STATE_INTEGRATION), want2)
+    for x, y in zip(c.counts(), counts2):
+        assert np.array_equal(x, y)
+    assert (counts2[1][:64] + counts2[1][:64][::-1] + 2 > 64).any()  # at least one wave could not pack its two envs
+    b.close(); c.close()
+
+
+def test_bad_states_reset_inside_a_shared_wave(hbmod, humanoid_model, gpu):
+    """mj_checkPos / mj_checkVel / mj_checkAcc in one env of a wave: that env is reset (and, for a bad qacc, runs mj_forward a second time)
+    while its partner steps normally - same bits, same warning bits as the one-env kernel"""
+    m = humanoid_model
+    n = 64
+    b = hbmod.Batch(m, n, gpu)
+    b.reset(perturb=True)
+    b.rollout_halton(250)
+    st = b.get_state(hbmod.STATE_INTEGRATION)
+    nq, nv = m.nq, m.nv
+    st[3, 1 + 5] = np.nan              # BADQPOS
+    st[10, 1 + nq + 7] = np.inf        # BADQVEL
+    st[17, 1 + nq + 2] = 3e9           # a velocity that overflows the accelerations: BADQACC
+    st[n - 1 - 17, 1 + nq + 4] = 3e9   # ... and its partner in the same wave as well
+    st[40, 1 + nq:1 + nq + nv] = 2e9
+    ctrl = np.random.default_rng(3).uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
+    want, wcounts, wstatus = _reference_step(hbmod, m, gpu, st, ctrl)
+    b.set_state(hbmod.STATE_INTEGRATION, st)
+    b.step(ctrl)
+    assert b.last_kernel() == DUO
+    assert np.array_equal(b.status(), wstatus) and (wstatus != 0).sum() >= 4
+    got = b.get_state(hbmod.STATE_INTEGRATION)
+    assert np.array_equal(got, want), np.flatnonzero((got != want).any(axis=1))
+    for x, y in zip(b.counts(), wcounts):
+        assert np.array_equal(x, y)
+    b.close()
+
+
+def test_halton_controls_and_hb_duo_switch(hbmod, humanoid_model, gpu):
+    """the benchmark's on-device Halton controls through the duo kernel (ctrl mode 2) equal the rollout kernel's"""
+    m = humanoid_model
+    n = 256
+    a = hbmod.Batch(m, n, gpu); b = hbmod.Batch(m, n, gpu)
+    a.reset(perturb=True, env_offset=1000); b.reset(perturb=True, env_offset=1000)
+    a.rollout_halton(40, 0, 1000)             # one launch, LEAN = 2 kernel with the step loop
+    assert a.last_kernel() == "hb_step_h27_q_kernel"
+    for t in range(40):
+        b.rollout_halton(1, t, 1000)          # single steps: the duo kernel
+    assert b.last_kernel() == DUO
+    assert np.array_equal(a.get_state(hbmod.STATE_INTEGRATION), b.get_state(hbmod.STATE_INTEGRATION))
+    a.close(); b.close()

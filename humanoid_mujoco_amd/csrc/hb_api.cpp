@@ -656,6 +656,7 @@ struct hb_batch {
   int tev_used = 0;
   long long launch_count = 0;
   const char* last_kernel = "";  // hb_last_kernel
+  int duo = getenv("HB_DUO") ? atoi(getenv("HB_DUO")) : 1;  // two envs per wave: 0 never, 1 where it pays, 2 always (hb_batch_duo)
   int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
   int* d_order2 = nullptr;  // the same for the narrowphase launch of a staged step
   int order_mode = 0;       // 0: none yet, 1: one permutation of the whole batch, 2: one permutation per pipe segment
@@ -734,6 +735,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
   if (const char* sp = getenv("HB_STOP_PHASE")) P.stop_phase = atoi(sp);
 #endif
   P.stage = b->stage;
+  P.duo = b->duo;
   const bool sized_on = !(getenv("HB_SIZED") && atoi(getenv("HB_SIZED")) == 0);
   P.lean_ok = (b->D.dm.disableflags == 0 ? 1 : 0) | (b->D.sized_h27 && sized_on ? 2 : 0) | (b->D.sized_team && sized_on ? 4 : 0);
   if (b->diag) P.stage.dm_fast = nullptr;  // the diagnostic buffers are laid out for the kernel of the model's own variant
@@ -2509,6 +2511,11 @@ int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch, int* kcycles)
 }
 
 const char* hb_last_kernel(const hb_batch* b) { return b ? b->last_kernel : ""; }
+int hb_batch_duo(hb_batch* b, int mode) {
+  if (!b || mode < 0 || mode > 2) return HB_EINVAL;
+  b->duo = mode;
+  return HB_OK;
+}
 
 int hb_get_lanes(hb_batch* b, int* lane) {
   if (!b) return HB_EINVAL;

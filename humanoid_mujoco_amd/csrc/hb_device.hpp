@@ -383,6 +383,7 @@ struct BatchPtrs {
   int lean_ok;                // bit 0: the model's options allow the lean instantiations (mjOption.disableflags == 0); bit 1: its sizes and LDS
                               // layout are kSizedHumanoid27's (the size-specialised instantiations); bit 2: its fast layout is kSizedTeamV1's
   int stop_phase;             // diagnostic builds only: 0 = off (HB_STOP_PHASE in the environment, read at every launch)
+  int duo;                    // host side only (launch_step): two envs per wave 0 never, 1 where it pays, 2 always (hb_batch_duo)
   StageBufs stage;
 };
 

@@ -544,6 +544,95 @@ __device__ __forceinline__ void sym_factor_mfma(f32x16 X, f32x16& T, f32x16& S, 
   }
 }
 
+// Two independent problems side by side (two envs per wave, hb_step_duo.hip): the pivot chains of the two eliminations do not depend on
+// each other, so pair b of the one is issued into the latencies of pair b of the other (readlane - rcp - fma - swap - MFMA - MFMA).  Per
+// problem the arithmetic is sym_factor_mfma's / sym_solve_mfma's, statement for statement.
+template <int NP>
+__device__ __forceinline__ void sym_factor_mfma_x2(f32x16 Xa, f32x16 Xb, f32x16& Ta, f32x16& Sa, f32x16& Tb, f32x16& Sb, int lane) {
+  const int li = lane & 31, half = lane >> 5;
+  const bool up = half != 0;
+  const int q = li - 4 * half;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { Ta[r] = q == crow(r) ? 1.f : 0.f; Sa[r] = 1.f; Tb[r] = Ta[r]; Sb[r] = 1.f; }
+  const float lik = (float)(li - half);
+#pragma unroll
+  for (int b = 0; b < NP; b++) {
+    const int k0 = 2 * b, r0 = (k0 & 3) + 4 * (k0 >> 3), h0 = (k0 >> 2) & 1, L0 = 32 * h0;
+    const float below = __builtin_amdgcn_fmed3f(lik - (float)k0, 0.f, 1.f);
+#define HB_FACTOR_PAIR(X, T, S)                                                                                                   \
+    {                                                                                                                             \
+      const float rowa = X[r0], rowb = X[r0 + 1], ta = T[r0], tb = T[r0 + 1];                                                     \
+      const float d0 = fmaxf(rdlane(rowa, L0 + k0), HB_MINVAL);                                                                   \
+      const float inv0 = __builtin_amdgcn_rcpf(d0);                                                                               \
+      const float m = rdlane(rowb, L0 + k0) * inv0;                                                                               \
+      const float rowb1 = __builtin_fmaf(-m, rowa, rowb), tb1 = __builtin_fmaf(-m, ta, tb);                                       \
+      const float d1 = fmaxf(rdlane(rowb1, L0 + k0 + 1), HB_MINVAL);                                                              \
+      const float inv1 = __builtin_amdgcn_rcpf(d1);                                                                               \
+      const u32x2 sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(rowa), __float_as_uint(rowb1), false, false);            \
+      const u32x2 st = __builtin_amdgcn_permlane32_swap(__float_as_uint(ta), __float_as_uint(tb1), false, false);                \
+      const float vb = __uint_as_float(h0 ? sx.y : sx.x), vt = __uint_as_float(h0 ? st.y : st.x);                                 \
+      const float va = -(vb * (up ? inv1 : inv0)) * below;                                                                        \
+      X = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, X, 0, 0, 0);                                                               \
+      T = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vt, T, 0, 0, 0);                                                               \
+      if (half == h0) { S[r0] = __builtin_amdgcn_rsqf(d0); S[r0 + 1] = __builtin_amdgcn_rsqf(d1); }                               \
+    }
+    HB_FACTOR_PAIR(Xa, Ta, Sa)
+    HB_FACTOR_PAIR(Xb, Tb, Sb)
+#undef HB_FACTOR_PAIR
+  }
+}
+
+template <int NP>
+__device__ __forceinline__ void sym_solve_mfma_x2(f32x16 Xa, f32x16 Xb, float ga, float gb, float& xa, float& xb, int lane) {
+  const int li = lane & 31, half = lane >> 5;
+  const bool up = half != 0;
+  {
+    const float e31 = li == 31 ? 1.f : 0.f;
+    Xa = __builtin_amdgcn_mfma_f32_32x32x2f32(up ? ga : e31, up ? e31 : ga, Xa, 0, 0, 0);
+    Xb = __builtin_amdgcn_mfma_f32_32x32x2f32(up ? gb : e31, up ? e31 : gb, Xb, 0, 0, 0);
+  }
+  f32x16 Ta, Za, Tb, Zb;
+  const int q = li - 4 * half;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { Ta[r] = q == crow(r) ? 1.f : 0.f; Za[r] = 0.f; Tb[r] = Ta[r]; Zb[r] = 0.f; }
+  const float lik = (float)(li - half);
+#pragma unroll
+  for (int b = 0; b < NP; b++) {
+    const int k0 = 2 * b, r0 = (k0 & 3) + 4 * (k0 >> 3), h0 = (k0 >> 2) & 1, L0 = 32 * h0;
+    const float below = __builtin_amdgcn_fmed3f(lik - (float)k0, 0.f, 1.f);
+#define HB_SOLVE_PAIR(X, T, Z)                                                                                                    \
+    {                                                                                                                             \
+      const float rowa = X[r0], rowb = X[r0 + 1], ta = T[r0], tb = T[r0 + 1];                                                     \
+      const float inv0 = __builtin_amdgcn_rcpf(fmaxf(rdlane(rowa, L0 + k0), HB_MINVAL));                                          \
+      const float m = rdlane(rowb, L0 + k0) * inv0;                                                                               \
+      const float rowb1 = __builtin_fmaf(-m, rowa, rowb), tb1 = __builtin_fmaf(-m, ta, tb);                                       \
+      const float inv1 = __builtin_amdgcn_rcpf(fmaxf(rdlane(rowb1, L0 + k0 + 1), HB_MINVAL));                                     \
+      const u32x2 sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(rowa), __float_as_uint(rowb1), false, false);            \
+      const u32x2 st = __builtin_amdgcn_permlane32_swap(__float_as_uint(ta), __float_as_uint(tb1), false, false);                \
+      const float vb = __uint_as_float(h0 ? sx.y : sx.x), vt = __uint_as_float(h0 ? st.y : st.x);                                 \
+      const float va = -(vb * (up ? inv1 : inv0)) * below;                                                                        \
+      X = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, X, 0, 0, 0);                                                               \
+      T = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vt, T, 0, 0, 0);                                                               \
+      const float z0 = rdlane(rowa, L0 + 31) * inv0, z1 = rdlane(rowb1, L0 + 31) * inv1;                                          \
+      if (half == h0) { Z[r0] = z0; Z[r0 + 1] = z1; }                                                                             \
+    }
+    HB_SOLVE_PAIR(Xa, Ta, Za)
+    HB_SOLVE_PAIR(Xb, Tb, Zb)
+#undef HB_SOLVE_PAIR
+  }
+#define HB_SOLVE_OUT(T, Z, out_)                                                                                                    \
+  {                                                                                                                               \
+    float p = 0.f, p1 = 0.f;                                                                                                      \
+    _Pragma("unroll") for (int r = 0; r < 16; r += 2) { p = __builtin_fmaf(T[r], Z[r], p); p1 = __builtin_fmaf(T[r + 1], Z[r + 1], p1); } \
+    p += p1;                                                                                                                      \
+    const u32x2 sp = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);                      \
+    out_ = p + __uint_as_float(up ? sp.x : sp.y);                                                                                 \
+  }
+  HB_SOLVE_OUT(Ta, Za, xa)
+  HB_SOLVE_OUT(Tb, Zb, xb)
+#undef HB_SOLVE_OUT
+}
+
 // W[c][row] = T[row][c] * S(row): lane (c, half) owns four runs of four consecutive rows: four 16-byte stores
 __device__ __forceinline__ void store_w_rows(float* W, int stride, const f32x16& T, const f32x16& S, int lane) {
   float* p = W + (lane & 31) * stride + 4 * (lane >> 5);

@@ -1979,8 +1979,22 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevMo
 static thread_local const char* g_last_step_kernel = "";
 const char* last_step_kernel() { return g_last_step_kernel; }
 #define HB_STEP_LAUNCH(kernel, ...) do { g_last_step_kernel = #kernel; hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
-// two envs per wave (hb_step_duo.hip) for the lean single-step launches of the 27-dof humanoid's PGS kernel; HB_DUO=0: one env per wave
-static bool duo_on() { static const bool on = !(getenv("HB_DUO") && atoi(getenv("HB_DUO")) == 0); return on; }
+// Two envs per wave (hb_step_duo.hip) for the lean launches of the 27-dof humanoid's PGS kernel - where it pays.  A duo wave takes ~ 1.6 x as
+// long as a one-env wave and holds two envs: 25 % more env-steps per wave-cycle.  But a single-step launch lasts as long as its slowest
+// wave, and the batch-wide barrier between step calls is hidden only while the launches in flight hold more waves than the chip has
+// slots (8 per CU for both kernels): 4096 envs are two rounds of one-env waves (the second hides the first one's tail) but exactly ONE
+// round of duo waves - 92 against 78 us per step on MI355X; from 8192 envs on the duo kernel wins, 124 against 148 us
+// (profiles/r04_duo_sizes.txt).  A rollout launch has no barrier between steps: duo as soon as the batch fills the chip.
+// BatchPtrs::duo (hb_batch_duo; HB_DUO in the environment is a new batch's default): 0 never, 1 where it pays, 2 always.
+static int wave_slots() {
+  static const int slots = [] { int dev = 0, cus = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; return 8 * cus; }();
+  return slots;
+}
+static bool duo_pays(const BatchPtrs& P, int nsteps) {
+  if (P.duo == 0) return false;
+  if (P.duo == 2) return true;
+  return nsteps == 1 ? 2 * P.n_env >= 5 * wave_slots() : P.n_env >= 2 * wave_slots();
+}
 
 // the lean instantiations apply when the launch has none of the optional inputs / outputs (HB_LEAN=0: never)
 static bool lean_launch(const BatchPtrs& P, bool with_qfrc = false) {
@@ -2002,7 +2016,7 @@ static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int sol
   }
   else if (solver == 2) HB_STEP_LAUNCH(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (nv <= 28) {
-    if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2) && duo_on()) { g_last_step_kernel = "hb_step_duo_kernel"; return launch_step_duo(M_dev, P, stream); }
+    if (lean_launch(P) && (P.lean_ok & 2) && duo_pays(P, nsteps)) { g_last_step_kernel = nsteps == 1 ? "hb_step_duo_kernel" : "hb_step_duo_q_kernel"; return launch_step_duo(M_dev, P, nsteps, stream); }
     else if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) HB_STEP_LAUNCH(hb_step_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (nsteps == 1 && lean_launch(P)) HB_STEP_LAUNCH(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (lean_launch(P, true) && (P.lean_ok & 2)) HB_STEP_LAUNCH(hb_step_h27_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);

@@ -35,6 +35,7 @@ constexpr int kCsD = 29;     // row stride of C: 28 dof columns + one pad (odd: 
 constexpr int kWsD = 28;     // row stride of W: 16-byte aligned rows of 28
 constexpr int kNCh = 12;     // contacts per env while two envs share the wave (24 = kNconMax when one env is stepped alone)
 constexpr int kMetaSlots = 11;
+constexpr int kDuoAnti = 16;  // heaviest dispatch slots of a launch that are paired with the lightest (the others: with their neighbour)
 // per-row meta slots (the one-env kernel's, without its two unused ones)
 enum { E_POS = 0, E_MARGIN, E_SOLREF0, E_SOLREF1, E_IMP0, E_IMP1, E_IMP2, E_IMP3, E_IMP4, E_DA, E_MU2 };
 // contact record: the one-env kernel's 17 floats, then the dof masks of the two bodies
@@ -86,6 +87,24 @@ __device__ __forceinline__ f32x16 load_sym_env(DevModelRef M, const float* s_qM,
   return X;
 }
 
+// both envs' matrices with one fetch of the sixteen table words
+template <int WHICH>
+__device__ __forceinline__ void load_sym_env2(DevModelRef M, const float* qMa, const float* Hda, const float* qMb, const float* Hdb, int lane0, f32x16& Xa, f32x16& Xb) {
+  int lane;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0));
+  int e[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) e[r] = M.mdense_c[r * 64 + lane];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { Xa[r] = qMa[e[r]]; Xb[r] = qMb[e[r]]; }
+  if constexpr (WHICH == 1) {
+    const int li = lane & 31, q = li - 4 * (lane >> 5);
+    const float ha = li < NV ? Hda[li] : 1.f, hb_ = li < NV ? Hdb[li] : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { Xa[r] = q == crow(r) ? ha : Xa[r]; Xb[r] = q == crow(r) ? hb_ : Xb[r]; }
+  }
+}
+
 // W[c][row] = T[row][c] * S(row), rows and columns 0..27 only (stride kWsD): store_w_rows without the identity padding
 __device__ __forceinline__ void store_w28(float* W, const f32x16& T, const f32x16& S, int lane) {
   const int c = lane & 31, half = lane >> 5;
@@ -108,19 +127,32 @@ __device__ __forceinline__ float dot28(const float* row, const float* v) {
 
 }  // namespace duo
 
-__global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* Mp, const BatchPtrs P) {
+// MULTI = 0: one step (the step API); 1: nsteps steps with the state on chip in between (the rollouts: every wave advances its two envs through
+// all of them, no batch-wide barrier between steps)
+template <int MULTI>
+__device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P, int nsteps_in) {
   using namespace duo;
+  const int nsteps = MULTI ? nsteps_in : 1;
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
   extern __shared__ float lds[];
   const int lane0 = threadIdx.x;
   int lane = lane0;
   const int npairs = (P.nblk + 1) >> 1;
   if ((int)blockIdx.x >= npairs) return;
-  // the wave's two envs: dispatch slots b and nblk - 1 - b of the launch (with the heavy-first order the costliest env of the launch
-  // shares its wave with the cheapest: the packed sweeps of a wave cost the SUM of its envs' row updates)
-  const int slotA = P.blk0 + (int)blockIdx.x, slotB = P.blk0 + P.nblk - 1 - (int)blockIdx.x;
+  // The wave's two envs.  The sweeps of two envs run side by side and last as long as the longer one, so envs of like cost share a wave:
+  // neighbours in the heavy-first order (slots 2 j, 2 j + 1).  Only the kDuoAnti costliest slots of the launch take the cheapest ones as
+  // partners: an env above 31 rows packs its rows in front of a light partner's, while two of them in one wave would have to be stepped
+  // one after the other.
+  int slotA, slotB;
+  {
+    const int kAnti = min(kDuoAnti, P.nblk >> 2), b = (int)blockIdx.x;
+    if (b < kAnti) { slotA = b; slotB = P.nblk - 1 - b; }
+    else { slotA = kAnti + 2 * (b - kAnti); slotB = slotA + 1 < P.nblk - kAnti ? slotA + 1 : -1; }
+    slotA += P.blk0;
+    if (slotB >= 0) slotB += P.blk0;
+  }
   const int envA = P.order ? P.order[slotA] : slotA;
-  const int envB = slotB > slotA ? (P.order ? P.order[slotB] : slotB) : -1;
+  const int envB = slotB >= 0 ? (P.order ? P.order[slotB] : slotB) : -1;
   const int h = lane0 >> 5;
   const int env = h ? envB : envA;  // (the lane's env for everything lane-parallel; -1: no second env in this wave)
 
@@ -141,13 +173,10 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
   {
     const bool have = env >= 0;
     const float* gs = P.state + (size_t)(have ? env : 0) * NSTATE;
-    float cp = 0.f, tq = 0.f, tv = 0.f, tw = 0.f;
-    // (one step: ctrl[e][nu] - mode 0, or the first slice of ctrl[t][e][nu] - mode 1; mode 2: the benchmark's on-device Halton controls)
-    if (have && l0 < NU) cp = P.ctrl_mode == 2 ? 2.f * halton(1 + P.t0 + 1000 * (P.env_offset + env), l0 + 2) - 1.f : P.ctrl[(size_t)env * NU + l0];
+    float tq = 0.f, tv = 0.f, tw = 0.f;
     if (have) time = gs[0];
     if (have && l0 < NQ) tq = gs[1 + l0];
     if (have && l0 < NV) { tv = gs[1 + NQ + l0]; tw = gs[1 + NQ + NV + l0]; }
-    if (l0 < NU) s_ctrl[l0] = cp;
     if (l0 < NQ) s_qpos[l0] = tq;
     if (l0 < 28) { s_qvel[l0] = tv; s_warm[l0] = tw; s_v0[l0] = 0.f; s_v2[l0] = 0.f; }
     // pads behind the sparse matrix (zero, one: what the dense views read outside the sparsity pattern / beyond nv)
@@ -161,9 +190,23 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
   }
   gsync();
 
+#ifdef HB_STAMPS
+  unsigned long long stamps_[16] = {0};
+#endif
+  // controls of step t: ctrl[e][nu] (mode 0), ctrl[t][e][nu] (mode 1), or the benchmark's on-device Halton sequence (mode 2); those of step
+  // t + 1 are requested at the top of step t (an HBM round trip that would otherwise open every step)
+  auto ctrl_of = [&](int t) -> float {
+    if (!(env >= 0 && l0 < NU)) return 0.f;
+    if (P.ctrl_mode == 2) return 2.f * halton(1 + P.t0 + t + 1000 * (P.env_offset + env), l0 + 2) - 1.f;
+    return P.ctrl[(P.ctrl_mode == 1 ? (size_t)t * P.n_env * NU : 0) + (size_t)env * NU + l0];
+  };
+  float ctrl_pf = ctrl_of(0);
   int status = 0;            // per lane = per env (identical in the lanes of a half)
   bool ctrl_zeroed = false;  // the env's pass runs on reset data (mj_resetData zeroes ctrl): per half
   bool redo = false;         // the env's pass is the second mj_forward of a step whose first one gave a bad qacc: per half
+  for (int step = 0; step < nsteps; step++) {
+  if (l0 < NU) s_ctrl[l0] = ctrl_pf;
+  if (MULTI && step + 1 < nsteps && P.ctrl_mode != 0) ctrl_pf = ctrl_of(step + 1);
   unsigned todo = envB >= 0 ? 3u : 1u;  // envs of the wave still to be stepped (bit 0: A, bit 1: B)
   bool serial = false;       // one env at a time from now on
   while (todo) {
@@ -193,6 +236,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
     if (geoml) { pf_gbody = M.geom_bodyid[l]; pf_gpos = ld3(M.geom_pos + 3 * l); pf_gquat = ldq(M.geom_quat + 4 * l); }
     float4 pf_dA = {0.f, 0.f, 0.f, 0.f}, pf_dB = pf_dA;
     if (dofl) { pf_dA = M.drec[3 * l]; pf_dB = M.drec[3 * l + 1]; }
+    HB_STAMP(0);
     // ---------------------------------------------------------------- mj_checkPos / mj_checkVel
     {
       bool badp = false, badv = false;
@@ -211,6 +255,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
     }
     gsync();
 
+    HB_STAMP(1);
     // ---------------------------------------------------------------- mj_kinematics
     if (on && l == 0) {
       st3(s_xpq, {0.f, 0.f, 0.f}); stq(s_xpq + 4, {1.f, 0.f, 0.f, 0.f}); st3(s_xipos, {0.f, 0.f, 0.f});
@@ -292,6 +337,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
       st3(s_xipos + 3 * myb, mypos + mrot(mat, {ip.x, ip.y, ip.z}));
     }
     gsync();
+    HB_STAMP(2);
     // geoms: world position and z axis
     if (geoml) {
       const int g = l, b = pf_gbody;
@@ -363,6 +409,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
       s_tenlen[t] = len;
     }
     gsync();
+    HB_STAMP(3);
     // ---------------------------------------------------------------- mj_comVel + mj_rne forward pass
     float lv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, la[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (bl) {
@@ -458,6 +505,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
       }
       gsync();
     }
+    HB_STAMP(4);
     // ---------------------------------------------------------------- qM from the composite inertias
     float4 pf_bA = {0.f, 0.f, 0.f, 0.f}, pf_bB = pf_bA, pf_bC = pf_bA, pf_a0 = pf_bA, pf_a1 = pf_bA, pf_a2 = pf_bA, pf_a3 = pf_bA;
     if (dofl) { pf_bA = M.drec[3 * l]; pf_bB = M.drec[3 * l + 1]; pf_bC = M.drec[3 * l + 2]; }
@@ -489,6 +537,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
       }
     }
     gsync();
+    HB_STAMP(5);
     // ---------------------------------------------------------------- qfrc_bias, mj_passive, mj_fwdActuation -> qfrc_smooth
     if (dofl) {
       const int d = l;
@@ -517,6 +566,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
     }
     gsync();
 
+    HB_STAMP(6);
     // ================================================================ constraint arrays from here on (alias the dynamics scratch)
     // contact record s of the lane's env: slots 0..11 in its own block, 12..23 (an env stepped alone) in the other env's
     auto con_rec = [&](int s) -> float* { return (s < kNCh ? E : lds + (1 - h) * kEnvF) + o_con + (s < kNCh ? s : s - kNCh) * kConStride; };
@@ -622,6 +672,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
     bool selfc = false;
     if (l < ncon) selfc = M.pair_self[pairid] != 0;
 
+    HB_STAMP(7);
     // ---------------------------------------------------------------- mj_makeConstraint: count, place, write
     // (a) limit candidates: 2 per limited joint / tendon in constraint order, 32 per round
     constexpr int kLimRounds = (NLIM + H - 1) / H;
@@ -794,6 +845,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
     if (on && l < kCsD) s_C[(rbase + nefc) * kCsD + l] = l < NV ? s_smooth[l] : 0.f;
     gsync();
 
+    HB_STAMP(8);
     // ---------------------------------------------------------------- per-row quantities (lane = packed row)
     const bool lolane = lane < split;
     const int renv = lolane ? envLo : 1 - envLo;     // the env of this row lane
@@ -834,17 +886,26 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
       aref = -Bc * vel - K * imp * (pos - margin);
     }
     gsync();
+    HB_STAMP(9);
     // ---------------------------------------------------------------- W = L^-1 D^-1/2 per env; C = J W (rows and the qfrc_smooth rows)
-    for (int e = 0; e < 2; e++) {
-      if (!((act >> e) & 1u)) continue;
+    {
       int lw;
       asm volatile("v_mov_b32 %0, %1" : "=v"(lw) : "v"(lane0));
-      float* EE = lds + e * kEnvF;
-      f32x16 T, S;
-      sym_factor_mfma<14>(load_sym_env<0>(M, EE + o_qM, EE + o_Hd, lw), T, S, lw);
-      store_w28(EE + o_W, T, S, lw);
+      if (both) {  // the two eliminations side by side: each fills the other's pivot latencies
+        f32x16 Xa, Xb, Ta, Sa, Tb, Sb;
+        load_sym_env2<0>(M, lds + o_qM, lds + o_Hd, lds + kEnvF + o_qM, lds + kEnvF + o_Hd, lw, Xa, Xb);
+        sym_factor_mfma_x2<14>(Xa, Xb, Ta, Sa, Tb, Sb, lw);
+        store_w28(lds + o_W, Ta, Sa, lw);
+        store_w28(lds + kEnvF + o_W, Tb, Sb, lw);
+      } else {
+        float* EE = lds + ((act >> 1) & 1u) * kEnvF;
+        f32x16 T, S;
+        sym_factor_mfma<14>(load_sym_env<0>(M, EE + o_qM, EE + o_Hd, lw), T, S, lw);
+        store_w28(EE + o_W, T, S, lw);
+      }
     }
     gsync();
+    HB_STAMP(10);
     // packed rows of env e (incl. its qfrc_smooth row): [lo_e, hi_e]
     const int pLo0 = 0, pLo1 = nLo, pHi0 = split, pHi1 = split + nHi;  // low env: [0, nLo]; high env: [split, split + nHi]
     {
@@ -889,6 +950,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
       }
     }
     gsync();
+    HB_STAMP(11);
     // ---------------------------------------------------------------- efc_b, AR = C C^T + diag(R) (mj_projectConstraint), block diagonal over the envs
     const float* yv = s_C + ysrow * kCsD;
     float ar[kNefcMax];
@@ -960,6 +1022,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
         if (32 + ra + 4 < kNefcMax) ar[32 + ra + 4] = __uint_as_float(s1.y);
       }
     }
+    HB_STAMP(12);
     // ---------------------------------------------------------------- mj_fwdConstraint: warm start + PGS over the packed rows
     // sums over the rows of each env: the one-env kernel's wave_sum on the lanes that env's rows would have there
     const bool aligned = !both || split == 32;
@@ -981,7 +1044,83 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
       }
     };
     int niterLo = 0, niterHi = 0;
-    {
+    if (both && split == 32) {
+      // Both envs at most 31 rows, env A's on lanes 0.., env B's on lanes 32..: the two Gauss-Seidel sweeps run SIDE BY SIDE - row i of
+      // both envs in one row step (every lane proposes; the turn-holders of the two halves are read out by two v_readlane, each half
+      // takes its own).  The two dependency chains share their instructions: one row step serves two envs.  Per env the arithmetic,
+      // and its order, is the one-env sweep's.
+      float arS[31];  // the lane's AR column over the rows of its own env
+#pragma unroll
+      for (int i = 0; i < 31; i++) arS[i] = h ? ar[32 + i] : ar[i];
+      const float nAinv = -1.f / Aii;
+      float arf = 0.f;
+      const int nmax2 = max(nLo, nHi);
+      {
+        const float jar = jw - aref;
+        force = (rowact && jar < 0.f) ? -Dd * jar : 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          if (c * 4 < nmax2) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (c * 4 + r < 31) { const float fa = rdlane(force, c * 4 + r), fb = rdlane(force, 32 + c * 4 + r); arf += arS[c * 4 + r] * (h ? fb : fa); }
+          }
+        }
+        float cLo, cHi;
+        env_sums(rowact ? force * (0.5f * arf + bvec) : 0.f, cLo, cHi);
+        const float cost = h ? cHi : cLo;
+        if (cost > 0.f) { force = 0.f; arf = 0.f; }
+      }
+      float res = rowact ? bvec + arf : 0.f;
+      const int max_sweeps = M.iterations;
+      const float pgs_tol = M.tolerance, pgs_scale = M.pgs_scale;
+      bool liveLo = nLo > 0 && max_sweeps > 0, liveHi = nHi > 0 && max_sweeps > 0;
+      const bool sweptLo = liveLo, sweptHi = liveHi;
+      float force_out = force;
+      while (liveLo || liveHi) {
+        int ne;
+        {
+          const int a = max(liveLo ? nLo : 0, liveHi ? nHi : 0);
+          asm volatile("s_mov_b32 %0, %1" : "=s"(ne) : "s"(a));
+        }
+        const float nforce = -force, res0 = res;
+        int dl = 0;
+#define HB_PGS_ROW2(i)                                                               \
+  if ((i) < 31) {                                                                    \
+    const float d_ = fmaxf(res * nAinv, nforce);                                     \
+    const int da_ = __builtin_amdgcn_readlane(__float_as_int(d_), (i));              \
+    const int db_ = __builtin_amdgcn_readlane(__float_as_int(d_), 32 + (i));         \
+    res = __builtin_fmaf(arS[(i) < 31 ? (i) : 0], __int_as_float(h ? db_ : da_), res); \
+    dl = hb_writelane(da_, (i), dl);                                                 \
+    dl = hb_writelane(db_, 32 + (i), dl);                                            \
+  }
+#define HB_PGS_CHUNK2(c) if ((c) * 4 >= ne) break; HB_PGS_ROW2((c) * 4) HB_PGS_ROW2((c) * 4 + 1) HB_PGS_ROW2((c) * 4 + 2) HB_PGS_ROW2((c) * 4 + 3)
+        do {
+          HB_PGS_CHUNK2(0) HB_PGS_CHUNK2(1) HB_PGS_CHUNK2(2) HB_PGS_CHUNK2(3) HB_PGS_CHUNK2(4) HB_PGS_CHUNK2(5) HB_PGS_CHUNK2(6) HB_PGS_CHUNK2(7)
+        } while (0);
+#undef HB_PGS_CHUNK2
+#undef HB_PGS_ROW2
+        const float delta = __int_as_float(dl);
+        force += delta;
+        float iLo, iHi;
+        env_sums(delta * (res0 + res), iLo, iHi);
+        if (liveLo) {
+          niterLo++;
+          if (-0.5f * iLo * pgs_scale < pgs_tol || niterLo >= max_sweeps) {
+            liveLo = false;
+            if (!h) { force_out = force; res = 0.f; force = 0.f; }  // rows of a finished env are inert from here on
+          }
+        }
+        if (liveHi) {
+          niterHi++;
+          if (-0.5f * iHi * pgs_scale < pgs_tol || niterHi >= max_sweeps) {
+            liveHi = false;
+            if (h) { force_out = force; res = 0.f; force = 0.f; }
+          }
+        }
+      }
+      force = (h ? sweptHi : sweptLo) ? force_out : force;
+    } else {
       const float nAinv = -1.f / Aii;
       float arf = 0.f;
       const int ne_all = both ? (nHi > 0 ? pHi1 : nLo) : nLo;  // packed rows in use: [0, ne_all)
@@ -1060,6 +1199,7 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
       force = (lolane ? sweptLo : sweptHi) ? force_out : force;
     }
     const int niter = (h == envLo) ? niterLo : niterHi;  // per lane = per env
+    HB_STAMP(13);
     // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = W (y + s)
     {
       const float fz = rowact ? force : 0.f;
@@ -1101,16 +1241,25 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
     if (fin) ctrl_zeroed = false;
     if (fin && l == 0) { int* c = P.counts + kCountStride * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; c[3] = nefc * (niter + 4); c[4] = selfcol; }
 
+    HB_STAMP(14);
     // ---------------------------------------------------------------- mj_Euler: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint
     if (fin && l < NV) s_warm[l] = s_v0[l];  // qacc_warmstart <- qacc
     const unsigned finm = act & ~again;
     if (eulerdamp) {
-      for (int e = 0; e < 2; e++) {
-        if (!((finm >> e) & 1u)) continue;
-        int le;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(le) : "v"(lane0));
-        float* EE = lds + e * kEnvF;
-        const int li = le & 31;
+      int le;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(le) : "v"(lane0));
+      const int li = le & 31;
+      if (finm == 3u) {
+        float* EA = lds; float* EB = lds + kEnvF;
+        const float rhsa = li < NV ? M.timestep * M.dof_damping[li] * (EA + o_v0)[li] : 0.f;
+        const float rhsb = li < NV ? M.timestep * M.dof_damping[li] * (EB + o_v0)[li] : 0.f;
+        float xa, xb;
+        f32x16 Xa, Xb;
+        load_sym_env2<1>(M, EA + o_qM, EA + o_Hd, EB + o_qM, EB + o_Hd, le, Xa, Xb);
+        sym_solve_mfma_x2<14>(Xa, Xb, rhsa, rhsb, xa, xb, le);
+        if (le < NV) { (EA + o_v2)[le] = (EA + o_v0)[le] - xa; (EB + o_v2)[le] = (EB + o_v0)[le] - xb; }
+      } else if (finm) {
+        float* EE = lds + ((finm >> 1) & 1u) * kEnvF;
         const float rhs = li < NV ? M.timestep * M.dof_damping[li] * (EE + o_v0)[li] : 0.f;
         const float x = sym_solve_mfma<14>(load_sym_env<1>(M, EE + o_qM, EE + o_Hd, le), rhs, le);
         if (le < NV) (EE + o_v2)[le] = (EE + o_v0)[le] - x;
@@ -1137,22 +1286,32 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* 
     }
     if (fin) time += hstep;
     gsync();
-    // ---- state out
-    if (fin) {
-      float* gs = P.state + (size_t)env * NSTATE;
-      if (l == 0) gs[0] = time;
-      if (l < NQ) gs[1 + l] = s_qpos[l];
-      if (l < NV) { gs[1 + NQ + l] = s_qvel[l]; gs[1 + NQ + NV + l] = s_warm[l]; }
-      if (status && l == 0) atomicOr(P.status + env, status);
-    }
+#ifdef HB_STAMPS
+    HB_STAMP(15);
+    if (lane == 0 && P.stamps) for (int i = 0; i < 16; i++) { P.stamps[(size_t)envA * 16 + i] = stamps_[i]; if (envB >= 0) P.stamps[(size_t)envB * 16 + i] = stamps_[i]; }
+#endif
     todo &= ~finm;
+  }
+  }
+  // ---- state out
+  if (env >= 0) {
+    float* gs = P.state + (size_t)env * NSTATE;
+    if (l0 == 0) gs[0] = time;
+    if (l0 < NQ) gs[1 + l0] = s_qpos[l0];
+    if (l0 < NV) { gs[1 + NQ + l0] = s_qvel[l0]; gs[1 + NQ + NV + l0] = s_warm[l0]; }
+    if (status && l0 == 0) atomicOr(P.status + env, status);
   }
 }
 
+__global__ __launch_bounds__(kGroup, 2) void hb_step_duo_kernel(const DevModel* Mp, const BatchPtrs P) { step_duo<0>(Mp, P, 1); }
+// the rollouts' kernel: the step loop inside (hb_rollout_dev / hb_rollout_halton without optional outputs)
+__global__ __launch_bounds__(kGroup, 2) void hb_step_duo_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_duo<1>(Mp, P, nsteps); }
+
 // lean single-step launches of the 27-dof humanoid's PGS kernel, two envs per wave (launch_step_kernel, hb_step.hip)
-hipError_t launch_step_duo(const DevModel* M_dev, const BatchPtrs& P, hipStream_t stream) {
+hipError_t launch_step_duo(const DevModel* M_dev, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(hb_step_duo_kernel, dim3((P.nblk + 1) / 2), dim3(kGroup), (size_t)duo::kLdsF * sizeof(float), stream, M_dev, P);
+  if (nsteps == 1) hipLaunchKernelGGL(hb_step_duo_kernel, dim3((P.nblk + 1) / 2), dim3(kGroup), (size_t)duo::kLdsF * sizeof(float), stream, M_dev, P);
+  else hipLaunchKernelGGL(hb_step_duo_q_kernel, dim3((P.nblk + 1) / 2), dim3(kGroup), (size_t)duo::kLdsF * sizeof(float), stream, M_dev, P, nsteps);
   return hipGetLastError();
 }
 

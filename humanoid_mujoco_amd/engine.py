@@ -148,6 +148,7 @@ def lib():
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
     L.hb_get_lanes.argtypes = [vp, vp]
     L.hb_last_kernel.argtypes = [vp]; L.hb_last_kernel.restype = ctypes.c_char_p
+    L.hb_batch_duo.argtypes = [vp, ci]
     L.hb_get_collision_counts.argtypes = [vp, vp, vp, vp]
     L.hb_batch_segments.argtypes = [vp]
     L.hb_diag_enable.argtypes = [vp, ci]
@@ -418,6 +419,10 @@ class Batch:
         a, b, c = (np.zeros(self.n_env, dtype=np.int32) for _ in range(3))
         _check(lib().hb_get_counts(self._h, _ptr(a), _ptr(b), _ptr(c)), "hb_get_counts")
         return a, b, c
+
+    def duo(self, mode=1):
+        """two envs per wave for the lean launches of the 27-dof humanoid's PGS kernel: 0 never, 1 where it pays (default), 2 always"""
+        _check(lib().hb_batch_duo(self._h, int(mode)), "hb_batch_duo")
 
     def last_kernel(self):
         """name of the step kernel the batch's last step / rollout / forward launch ran (include/hb.h: hb_last_kernel)"""

@@ -326,6 +326,12 @@ int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter);
  * the call asked for: the parity tests assert that the kernel they checked is the kernel the benchmark times, and
  * bench.py names the kernel of its roofline object by this string.  The pointer stays valid for the life of the library. */
 const char* hb_last_kernel(const hb_batch* b);
+/* Two envs per wavefront (csrc/hb_step_duo.hip): the lean launches of the 27-dof humanoid's PGS kernel - the plain step
+ * API and the rollouts without optional outputs - can run hb_step_duo_kernel / hb_step_duo_q_kernel, bit-identical to the one-env
+ * kernels.  mode 1 (default; HB_DUO in the environment at hb_batch_create overrides): where it pays - step calls of batches from 2.5 x
+ * the chip's wave slots on (5120 envs on MI355X), rollouts from 2 x; 0: never; 2: always.  Replaces nothing of the reference:
+ * mj_step has no such knob (mujoco.h:120). */
+int hb_batch_duo(hb_batch* b, int mode);
 /* Narrowphase work of the last step of each env, for models that collide through mesh hulls or height fields (the staged step:
  * DESIGN.md 3.6): nwork = work items (a candidate pair that passed the broadphase, or one prism of a height-field pair's sub-grid),
  * nsearch = those of them that needed a portal search (mjc_Convex / mjc_ConvexHField: libccd MPR), kcycles = shader clock cycles / 1024

@@ -33,6 +33,7 @@ def test_golden_states_through_the_timed_kernel(hbmod, humanoid_model, gpu, gold
     n = len(g["env"])
     for order in (np.arange(n), np.arange(n)[::-1], np.random.default_rng(0).permutation(n)):  # different partners in the wave
         b = hbmod.Batch(humanoid_model, n, gpu)
+        b.duo(2)  # (by default a batch this small takes the one-env kernel: include/hb.h, hb_batch_duo)
         b.set_state(hbmod.STATE_INTEGRATION, pack_state(g, order))
         b.step(g["ctrl"][order].astype(np.float32))
         assert b.last_kernel() == DUO
@@ -75,8 +76,10 @@ def test_duo_is_bit_identical_to_the_one_env_kernel(hbmod, humanoid_model, gpu):
     rng = np.random.default_rng(7)
     for n, pipe in ((512, False), (385, False), (1024, True)):
         b = hbmod.Batch(m, n, gpu)
+        b.duo(2)
         b.reset(perturb=True)
         b.rollout_halton(300)
+        assert b.last_kernel() == "hb_step_duo_q_kernel"
         if pipe:
             b.pipeline(3)
         for t in range(12):  # (the heavy-first order is re-sorted every fourth call)
@@ -90,6 +93,20 @@ def test_duo_is_bit_identical_to_the_one_env_kernel(hbmod, humanoid_model, gpu):
             for x, y in zip(b.counts(), wcounts):
                 assert np.array_equal(x, y)
         b.close()
+
+
+def partners(n, anti=16):
+    """env -> the env it shares its wave with (-1: none), as hb_step_duo_kernel pairs the dispatch slots of an n-env launch without a
+    heavy-first order: the first `anti` slots with the last ones, the others with their neighbour (csrc/hb_step_duo.hip: kDuoAnti)"""
+    k = min(anti, n >> 2)
+    p = np.full(n, -1)
+    for e in range(n):
+        if e < k or e >= n - k:
+            p[e] = n - 1 - e
+        else:
+            q = e + 1 if (e - k) % 2 == 0 else e - 1
+            p[e] = q if q < n - k else -1
+    return p
 
 
 def _collapsed_states(hbmod, m, gpu, n):
@@ -114,15 +131,16 @@ def test_heavy_env_steps_take_the_packed_and_the_one_at_a_time_paths(hbmod, huma
     n = 2048
     st, ctrl = _collapsed_states(hbmod, m, gpu, n)
     want, (ncon, nefc, niter), wstatus = _reference_step(hbmod, m, gpu, st, ctrl)
-    # partners as the kernel pairs them without an order: env e with env n - 1 - e
     heavy = nefc > 31
-    partner = nefc[::-1]
+    pidx = partners(n)
+    partner = np.where(pidx >= 0, nefc[pidx], 0)
     packed = heavy & (((np.maximum(nefc, partner) + 1 + 3) & ~3) + np.minimum(nefc, partner) + 1 <= 64) & (partner <= 31)
     alone = (nefc + partner + 2 > 64) | ((nefc > 31) & (partner > 31))
     print("\nrows: max %d, env-steps above 31 rows %d (packed with their partner %d), waves stepped one env at a time %d, max contacts %d"
           % (nefc.max(), heavy.sum(), packed.sum(), alone.sum() // 2, ncon.max()))
     assert heavy.sum() >= 8 and packed.sum() >= 1
     b = hbmod.Batch(m, n, gpu)
+    b.duo(2)
     b.set_state(hbmod.STATE_INTEGRATION, st)
     b.step(ctrl)
     assert b.last_kernel() == DUO
@@ -133,18 +151,19 @@ def test_heavy_env_steps_take_the_packed_and_the_one_at_a_time_paths(hbmod, huma
         assert np.array_equal(x, y)
     assert np.array_equal(b.status(), wstatus)
     # a heavy env beside a heavy env: force the one-env-at-a-time path by pairing the heaviest envs with each other
-    idx = np.argsort(-nefc)[:64]
-    pair_state = np.concatenate([st[idx], st[idx][::-1]])  # env k's partner is env 127 - k: the same heavy states mirrored
-    pair_ctrl = np.concatenate([ctrl[idx], ctrl[idx][::-1]])
+    idx = np.argsort(-nefc)[:128]  # (whatever the pairing: every env's partner is one of the heaviest)
+    pair_state, pair_ctrl = st[idx], ctrl[idx]
     want2, counts2, _ = _reference_step(hbmod, m, gpu, pair_state, pair_ctrl)
     c = hbmod.Batch(m, len(pair_state), gpu)
+    c.duo(2)
     c.set_state(hbmod.STATE_INTEGRATION, pair_state)
     c.step(pair_ctrl)
     assert c.last_kernel() == DUO
     assert np.array_equal(c.get_state(hbmod.STATE_INTEGRATION), want2)
     for x, y in zip(c.counts(), counts2):
         assert np.array_equal(x, y)
-    assert (counts2[1][:64] + counts2[1][:64][::-1] + 2 > 64).any()  # at least one wave could not pack its two envs
+    p2 = partners(len(idx))
+    assert (counts2[1] + counts2[1][p2] + 2 > 64).any()  # at least one wave could not pack its two envs
     b.close(); c.close()
 
 
@@ -154,6 +173,7 @@ def test_bad_states_reset_inside_a_shared_wave(hbmod, humanoid_model, gpu):
     m = humanoid_model
     n = 64
     b = hbmod.Batch(m, n, gpu)
+    b.duo(2)
     b.reset(perturb=True)
     b.rollout_halton(250)
     st = b.get_state(hbmod.STATE_INTEGRATION)
@@ -176,16 +196,40 @@ def test_bad_states_reset_inside_a_shared_wave(hbmod, humanoid_model, gpu):
     b.close()
 
 
-def test_halton_controls_and_hb_duo_switch(hbmod, humanoid_model, gpu):
-    """the benchmark's on-device Halton controls through the duo kernel (ctrl mode 2) equal the rollout kernel's"""
+def test_rollouts_through_the_duo_kernel_and_the_default_choice(hbmod, humanoid_model, gpu):
+    """hb_step_duo_q_kernel (the step loop inside, state on chip between steps) against the one-env rollout kernel: Halton controls
+    (ctrl mode 2), recorded control tapes (mode 1), single steps with Halton controls; and which kernel a batch takes by default"""
     m = humanoid_model
-    n = 256
-    a = hbmod.Batch(m, n, gpu); b = hbmod.Batch(m, n, gpu)
-    a.reset(perturb=True, env_offset=1000); b.reset(perturb=True, env_offset=1000)
-    a.rollout_halton(40, 0, 1000)             # one launch, LEAN = 2 kernel with the step loop
+    n, T = 256, 40
+    a = hbmod.Batch(m, n, gpu); b = hbmod.Batch(m, n, gpu); c = hbmod.Batch(m, n, gpu)
+    b.duo(2); c.duo(2)
+    for x in (a, b, c):
+        x.reset(perturb=True, env_offset=1000)
+    a.rollout_halton(T, 0, 1000)              # a batch this small: the one-env kernel with the step loop
     assert a.last_kernel() == "hb_step_h27_q_kernel"
-    for t in range(40):
-        b.rollout_halton(1, t, 1000)          # single steps: the duo kernel
-    assert b.last_kernel() == DUO
+    b.rollout_halton(T, 0, 1000)              # two envs per wave, the step loop inside
+    assert b.last_kernel() == "hb_step_duo_q_kernel"
+    for t in range(T):
+        c.rollout_halton(1, t, 1000)          # single steps
+    assert c.last_kernel() == DUO
+    sa = a.get_state(hbmod.STATE_INTEGRATION)
+    assert np.array_equal(sa, b.get_state(hbmod.STATE_INTEGRATION)) and np.array_equal(sa, c.get_state(hbmod.STATE_INTEGRATION))
+    for x, y in zip(a.counts(), b.counts()):
+        assert np.array_equal(x, y)
+    tape = np.random.default_rng(5).uniform(-1, 1, size=(T, n, m.nu)).astype(np.float32)
+    a.rollout(tape); b.rollout(tape)
+    assert a.last_kernel() == "hb_step_h27_q_kernel" and b.last_kernel() == "hb_step_duo_q_kernel"
     assert np.array_equal(a.get_state(hbmod.STATE_INTEGRATION), b.get_state(hbmod.STATE_INTEGRATION))
-    a.close(); b.close()
+    assert np.array_equal(a.status(), b.status())
+    a.close(); b.close(); c.close()
+    # the default: one env per wave for the step calls of the benchmark's 4096 envs (exactly one round of duo waves: DESIGN.md 3.8), two
+    # for its rollouts and for step calls from 2.5 x the chip's wave slots on
+    ctrl0 = np.zeros((1, m.nu), np.float32)
+    d = hbmod.Batch(m, 4096, gpu)
+    d.step(np.repeat(ctrl0, 4096, axis=0)); k_step = d.last_kernel()
+    d.rollout_halton(2); k_roll = d.last_kernel()
+    d.close()
+    e = hbmod.Batch(m, 8192, gpu)
+    e.step(np.repeat(ctrl0, 8192, axis=0)); k_big = e.last_kernel()
+    e.close()
+    assert (k_step, k_roll, k_big) == ("hb_step_h27_kernel", "hb_step_duo_q_kernel", DUO), (k_step, k_roll, k_big)

@@ -23,6 +23,10 @@ assert L.hb_get_stamps(b._h, st.ctypes.data_as(ctypes.c_void_p)) == 0
 d = np.diff(st.astype(np.int64), axis=1).astype(np.float64)
 names = ["ctrl+check", "kinematics", "geoms/com/cinert/cdof", "comVel+crb+rne tree passes", "qM", "factorM", "bias/passive/act", "collision", "makeConstraint",
          "row quantities", "half-solve", "b + AR", "PGS", "dual finish", "Euler+advance"]
+if b.last_kernel() == "hb_step_duo_kernel":  # two envs per wave: no factorM slot, the half solve in two parts; cycles are per WAVE = two env-steps
+    names = ["ctrl+check", "kinematics", "geoms/com/cinert/cdof", "comVel+crb+rne tree passes", "qM", "bias/passive/act", "collision", "makeConstraint",
+             "row quantities", "W = elimination of M (both envs)", "C = J W", "b + AR", "PGS", "dual finish + checkAcc", "Euler+advance"]
+    print("kernel: hb_step_duo_kernel (cycles per wave = per TWO env-steps)")
 tot = d.sum(1)
 print("model %s" % MODEL)
 print("envs %d; mean cycles per env-step (one wave) %.0f, median %.0f" % (N, tot.mean(), np.median(tot)))

@@ -49,8 +49,6 @@ struct DeviceModel {
   int fast_lds_floats = 0;
   bool sized_h27 = false;  // sizes and LDS layout equal kSizedHumanoid27's: the size-specialised step kernel applies
   bool sized_team = false; // the fast layout equals kSizedTeamV1's
-  DevModel* d_dm_small = nullptr;  // classic PGS models of dense order <= 28: the small layout (hb_step_small_kernel), else null
-  int small_lds_floats = 0;
   // observation order tables (device pointers): joint order and, when it exists, actuator order (hb_env_config.obs_actuator_order)
   const int *obs_jnt_joint = nullptr, *obs_src_joint = nullptr, *obs_jnt_act = nullptr, *obs_src_act = nullptr;
   bool has_act_order = false;
@@ -61,7 +59,6 @@ struct DeviceModel {
     if (d_qpos_src) (void)hipFree(d_qpos_src);
     if (d_dm) (void)hipFree(d_dm);
     if (d_dm_fast) (void)hipFree(d_dm_fast);
-    if (d_dm_small) (void)hipFree(d_dm_small);
   }
 };
 
@@ -173,7 +170,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   }
   if (m.nM > 1023) { err = "sparse mass matrix too large for the packed index tables"; return false; }
   // ---- LDS layout (a function of the variant: a variant-2 model also gets the variant-1 layout for its fast step kernel)
-  auto lay = [&](DevModel& dm, bool small = false) -> bool {
+  auto lay = [&](DevModel& dm) -> bool {
   int off = 0;
   auto take = [&](int n) { int o = off; off += (n + 3) & ~3; return o; };
   // row stride of C: 33 (K = 32 for the matrix cores plus a pad column); the big Newton layout stores J rows only as wide as its dense
@@ -207,13 +204,6 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
     dm.o_efc = take(32 * 36);
     dm.o_meta = take(dm.nefc_max * kMetaStride);
     dm.o_AR = take(dm.nefc_max * dm.nefc_max);
-  } else if (small) {
-    // the small instantiation of the classic PGS kernel (dense order 28, kSmallNefcMax rows, kSmallNconMax contacts): C, then the row
-    // meta (13 slots per row) with the contact records behind it - both dead when W (28 rows of 36: no padding rows) is built over them;
-    // the forces stay in registers and the damped Euler solve needs no W_H pair at this order
-    dm.o_C = take((kSmallNefcMax + 1) * dm.cstride);
-    dm.o_efc = take(std::max(((13 * kSmallNefcMax + 3) & ~3) + kSmallNconMax * kConStride, 28 * 36));
-    dm.o_con = dm.o_efc + ((13 * kSmallNefcMax + 3) & ~3);
   } else {
   dm.o_con = take(kNconMax * kConStride); dm.o_C = take((kNefcMax + 1) * dm.cstride);
   // per-row meta (13 slots x kNefcMax) is dead once the row quantities are in registers; W = L^-1 D^-1/2
@@ -225,7 +215,7 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   }
   if (dm.variant == 1) dm.o_meta = take(64 * kMetaStride);
   }
-  dm.o_force = small ? 0 : take(std::max(kGroup, dm.nefc_max));
+  dm.o_force = take(std::max(kGroup, dm.nefc_max));
   int endB = off;
   // xipos and scom/cdof are read while region B is being written (xfrc, Jacobians): keep xipos out of the alias
   dm.lds_floats = std::max(endA, endB);
@@ -556,15 +546,6 @@ bool build_device_model(const Model& m, DeviceModel& D, std::string& err) {
   // A variant-2 model (Newton on 256 rows in four register groups: one wave per SIMD) almost always has at most 63 rows and 24
   // contacts in a step: its staged step first runs the one-group Newton instantiation (two waves per SIMD) on the variant-1 LDS
   // layout and falls back to the four-group kernel for the envs that overflow (launch_step).  Same tables, other offsets.
-  // The classic PGS kernel of dense order <= 28 (the 27-dof humanoid) also gets the small layout: hb_step_small_kernel, three waves per SIMD
-  D.small_lds_floats = 0;
-  if (dm.variant == 0 && dm.solver == 0 && nv <= 28) {
-    DevModel sm = dm;
-    sm.ncon_max = kSmallNconMax; sm.nefc_max = kSmallNefcMax;
-    if (!lay(sm, true)) return false;
-    if (hipMalloc((void**)&D.d_dm_small, sizeof(DevModel)) != hipSuccess || hipMemcpy(D.d_dm_small, &sm, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMalloc failed for the device model"; return false; }
-    D.small_lds_floats = sm.lds_floats;
-  }
   {
     // the size-specialised kernel (hb_step_h27_kernel): the model's sizes and the layout just computed against the compile-time mirror
     const SizedModel z = dm.variant == 1 ? kSizedHumanoid27V1 : kSizedHumanoid27;
@@ -656,11 +637,12 @@ struct hb_batch {
   int tev_used = 0;
   long long launch_count = 0;
   const char* last_kernel = "";  // hb_last_kernel
-  int duo = getenv("HB_DUO") ? atoi(getenv("HB_DUO")) : 1;  // two envs per wave: 0 never, 1 where it pays, 2 always (hb_batch_duo)
+  // run-time choices between kernels / schedules that give the same results (hb_batch_tune, include/hb.h: HB_TUNE_*), indexed by knob
+  int tune[HB_TUNE_COUNT] = {getenv("HB_DUO") ? atoi(getenv("HB_DUO")) : 1, 1, 1, 1, 1, 1, 1, 4, 1};
   int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
   int* d_order2 = nullptr;  // the same for the narrowphase launch of a staged step
   int order_mode = 0;       // 0: none yet, 1: one permutation of the whole batch, 2: one permutation per pipe segment
-  bool schedule = getenv("HB_NO_SCHEDULE") == nullptr;  // heavy-first dispatch order (experiments can switch it off)
+  bool schedule = true;  // heavy-first dispatch order (HB_TUNE_SCHEDULE)
   // Pipelined stepping (hb_batch_pipeline): the batch is cut into npipe fixed env segments, each stepped by
   // its own launch on its own stream.  Envs are independent, so segment c of step t+1 only has to follow
   // segment c of step t: the tail of one step (its slowest envs) overlaps the head of the next.  `stream`
@@ -673,25 +655,6 @@ struct hb_batch {
   hipEvent_t ev_fork = nullptr, ev_pipe[kPipes] = {};
   int join_error = 0;
   bool main_dirty = true;  // work was enqueued on `stream` since the pipes last forked from it
-  // Two-lane stepping of the classic PGS kernel (launch_steps): the small kernel (three waves per SIMD) steps the fast lane on the
-  // segment's stream; an env whose step overflows that kernel's rows or contacts is flagged in d_lane and stepped - that step and the ones
-  // after it - by the full kernel on the segment's SLOW stream, which runs beside the next steps' small launches and is never waited for
-  // except at a rebalance point (every lane_window-th step of a segment: the small kernel waits for the slow lane and tries every env again).
-  int* d_lane = nullptr;           // [n_env] 0: fast lane, else slow lane (the tag of the call that moved it); null: two-lane stepping off
-  int* d_lane_list = nullptr;      // [n_env] per-segment lists of slow envs (segment c's at its first env), -1: empty slot
-  int* d_lane_count = nullptr;     // [kPipes] entries in each segment's list
-  int* d_lane_done = nullptr;      // [n_env] tag of the last step completed for a slow env
-  int* d_lane_win = nullptr;       // [n_env] window in whose list the env was last entered
-  hipStream_t slow = nullptr;      // ONE stream for the slow lane (with the batch's stream and two pipes: the runtime's four hardware queues)
-  hipEvent_t ev_fast[kPipes] = {}, ev_slow = nullptr;
-  bool slow_pending = false;       // ev_slow holds a slow launch
-  hipEvent_t ev_win[kPipes][2] = {};  // per segment and window parity: the last slow launch of that window
-  bool win_pending[kPipes][2] = {};
-  LaneRing* lane_ring = nullptr;   // device: the calls the GPU has got to and their controls (what the slow lane catches up with)
-  bool slow_forked = false;        // slow launches in flight that the batch's stream has not been ordered behind
-  int lane_nseg = 0;               // segment count of the last two-lane call (a change re-joins everything first)
-  long long lane_calls = 0;
-  int lane_window = 32;
 };
 
 namespace {
@@ -720,6 +683,16 @@ int ensure_ctrl(hb_batch* b, size_t floats) {
   return HB_OK;
 }
 
+// the staged step's buffers as this launch sees them (HB_TUNE_STAGED / FASTPASS / NARROW_PRIM switch parts of it off: all null = the fused step)
+StageBufs staged(const hb_batch* b) {
+  StageBufs sb = b->stage;
+  if (!b->tune[HB_TUNE_STAGED]) { sb = StageBufs{}; return sb; }
+  if (!b->tune[HB_TUNE_FASTPASS]) { sb.defer = nullptr; sb.dm_fast = nullptr; sb.fast_lds = 0; }
+  if (!b->tune[HB_TUNE_NARROW_PRIM]) sb.no_mesh = 0;
+  return sb;
+}
+bool staged_on(const hb_batch* b) { return b->stage.result && b->tune[HB_TUNE_STAGED]; }
+
 BatchPtrs make_ptrs(hb_batch* b) {
   BatchPtrs P;
   memset(&P, 0, sizeof P);
@@ -727,17 +700,17 @@ BatchPtrs make_ptrs(hb_batch* b) {
   if (b->diag) { P.diag_qacc = b->d_diag_qacc; P.diag_force = b->d_diag_force; P.diag_contact = b->d_diag_contact; }
   P.n_env = b->n_env;
   P.integrate = 1;
-  if (b->schedule && b->order_mode) { P.order = b->d_order; P.order2 = b->stage.result ? b->d_order2 : nullptr; }
+  if (b->schedule && b->order_mode) { P.order = b->d_order; P.order2 = staged_on(b) ? b->d_order2 : nullptr; }
   P.blk0 = 0; P.nblk = b->n_env;
   P.dr = b->d_dr; P.dr_stride = b->dr_stride;
   P.stamps = b->d_stamps;
 #ifdef HB_STAMPS
   if (const char* sp = getenv("HB_STOP_PHASE")) P.stop_phase = atoi(sp);
 #endif
-  P.stage = b->stage;
-  P.duo = b->duo;
-  const bool sized_on = !(getenv("HB_SIZED") && atoi(getenv("HB_SIZED")) == 0);
-  P.lean_ok = (b->D.dm.disableflags == 0 ? 1 : 0) | (b->D.sized_h27 && sized_on ? 2 : 0) | (b->D.sized_team && sized_on ? 4 : 0);
+  P.stage = staged(b);
+  P.duo = b->tune[HB_TUNE_DUO];
+  const bool sized_on = b->tune[HB_TUNE_SIZED] != 0;
+  P.lean_ok = (b->D.dm.disableflags == 0 && b->tune[HB_TUNE_LEAN] ? 1 : 0) | (b->D.sized_h27 && sized_on ? 2 : 0) | (b->D.sized_team && sized_on ? 4 : 0);
   if (b->diag) P.stage.dm_fast = nullptr;  // the diagnostic buffers are laid out for the kernel of the model's own variant
   if (b->xfrc_std > 0.f && b->d_xfrc) {
     const double rate = b->xfrc_rate > 0.f ? std::exp(-b->model->m.timestep / b->xfrc_rate) : 0.0;  // trajectory.cc:149-150
@@ -750,11 +723,7 @@ BatchPtrs make_ptrs(hb_batch* b) {
 
 // order `stream` behind every pipe (no-op unless steps are in flight on the pipes)
 void join_pipes(hb_batch* b) {
-  if (b->slow_forked || b->forked) b->main_dirty = true;  // the batch's stream now carries the join: the next fork must carry it to the pipes
-  if (b->slow_forked) {  // the slow lane's launches (every slow stream that has one outstanding)
-    if (b->slow_pending && hipStreamWaitEvent(b->stream, b->ev_slow, 0) != hipSuccess) b->join_error = 1;
-    b->slow_forked = false;
-  }
+  if (b->forked) b->main_dirty = true;  // the batch's stream now carries the join: the next fork must carry it to the pipes
   if (!b->forked) return;
   for (int c = 0; c < b->npipe; c++) {
     if (hipEventRecord(b->ev_pipe[c], b->pipe[c]) != hipSuccess || hipStreamWaitEvent(b->stream, b->ev_pipe[c], 0) != hipSuccess) b->join_error = 1;
@@ -769,7 +738,7 @@ hipStream_t main_stream(hb_batch* b) {
 }
 
 // heavy-first re-sort every N-th step call (HB_REORDER_PERIOD overrides, for experiments)
-int reorder_period() { static const int p = [] { const char* e = getenv("HB_REORDER_PERIOD"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }(); return p; }
+int reorder_period(const hb_batch* b) { return b->tune[HB_TUNE_REORDER_PERIOD] < 1 ? 1 : b->tune[HB_TUNE_REORDER_PERIOD]; }
 // number of segments the next step call is cut into (1: one launch on the batch's stream)
 int segment_count(const hb_batch* b) { return (b->npipe > 1 && !b->time_steps && b->n_env >= 64 * b->npipe) ? b->npipe : 1; }
 struct Segment { int lo, hi; hipStream_t st; };
@@ -797,10 +766,10 @@ int launch_segment(hb_batch* b, BatchPtrs P, int nsteps, const Segment& sg, int 
   P.blk0 = sg.lo; P.nblk = sg.hi - sg.lo;
   // a whole-batch permutation would mix segments: a segment only uses the order of its own envs
   P.order = (b->schedule && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2)) ? b->d_order : nullptr;
-  P.order2 = (P.order && b->stage.result) ? b->d_order2 : nullptr;
+  P.order2 = (P.order && staged_on(b)) ? b->d_order2 : nullptr;
   HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, nsteps, sg.st)); b->last_kernel = last_step_kernel();
   if (reorder) HB_HIP(launch_order(b->d_counts, b->d_order, b->n_env, sg.lo, sg.hi - sg.lo, sg.st));
-  if (reorder && b->stage.result) HB_HIP(launch_order(b->d_counts, b->d_order2, b->n_env, sg.lo, sg.hi - sg.lo, sg.st, /*slot=*/7, /*shift=*/0));
+  if (reorder && staged_on(b)) HB_HIP(launch_order(b->d_counts, b->d_order2, b->n_env, sg.lo, sg.hi - sg.lo, sg.st, /*slot=*/7, /*shift=*/0));
   return HB_OK;
 }
 // `refreshed`: the launch rewrote the permutations itself (launch_step's in-rollout refresh of a staged multi-step launch sorts the slots
@@ -810,107 +779,10 @@ void steps_enqueued(hb_batch* b, int nseg, bool reorder, bool refreshed = false)
   b->launch_count++;
 }
 
-// Two-lane stepping applies to single-step launches of a classic PGS model of dense order <= 28 that write nothing before the
-// overflow tests of the small kernel (no rollout noise, no sensor read-out, no diagnostics, no masked stepping).
-bool two_lane_ok(const hb_batch* b, const BatchPtrs& P, int nsteps) {
-  return b->d_lane && b->npipe <= 4 && nsteps == 1 && P.integrate && !b->diag && !P.sensor_out && !(P.xfrc_scale > 0.f) && !P.env_mask && !P.stamps;
-}
-constexpr int kSlowBlocks = 128;  // workgroups per segment of the slow lane's launch (they walk the list: a handful of envs per step in the benchmark's regime)
-// phase of segment c inside its window at the current call (windows are staggered across the segments), and the window's index
-long long lane_phase(const hb_batch* b, int c, int nseg) { return (b->lane_calls + (long long)c * b->lane_window / nseg) % b->lane_window; }
-long long lane_windex(const hb_batch* b, int c, int nseg) { return (b->lane_calls + (long long)c * b->lane_window / nseg) / b->lane_window; }
-// one segment's small-kernel launch of a two-lane step (the slow lane's launch follows once, for all segments: launch_steps)
-int launch_segment_two_lane(hb_batch* b, BatchPtrs P, const Segment& sg, int c, int nseg, bool reorder) {
-  P.blk0 = sg.lo; P.nblk = sg.hi - sg.lo;
-  P.order = (b->schedule && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2)) ? b->d_order : nullptr;
-  P.order2 = nullptr;
-  P.lane_seg = c;
-  const bool rebalance = lane_phase(b, c, nseg) == 0;  // a new window of this segment: a new list (the other parity's)
-  if (rebalance) {
-    const int par = P.lane_par[c];
-    // the list of this parity was last walked by the slow launches of the window before the previous one: long finished, but nothing
-    // else orders them before the memset below
-    if (b->win_pending[c][par]) HB_HIP(hipStreamWaitEvent(sg.st, b->ev_win[c][par], 0));
-    HB_HIP(hipMemsetAsync(b->d_lane_count + 4 * par + c, 0, sizeof(int), sg.st));
-    HB_HIP(hipMemsetAsync(b->d_lane_list + (size_t)par * b->n_env + sg.lo, 0xff, (size_t)(sg.hi - sg.lo) * sizeof(int), sg.st));
-  }
-  P.lane_mode = rebalance ? 2 : 1;
-  HB_HIP(launch_step_small(b->D.d_dm_small, b->D.small_lds_floats, P, sg.st));
-  HB_HIP(hipEventRecord(b->ev_fast[c], sg.st));
-  if (reorder) HB_HIP(launch_order(b->d_counts, b->d_order, b->n_env, sg.lo, sg.hi - sg.lo, sg.st));
-  return HB_OK;
-}
-
 int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
   const int nseg = segment_count(b);
-  if (two_lane_ok(b, P, nsteps)) {
-    if (b->lane_nseg != nseg) {
-      // segment boundaries moved: everything behind the batch's stream first, and every env back to the fast lane (the lists are per segment)
-      hipStream_t ms = main_stream(b);
-      HB_HIP(hipMemsetAsync(b->d_lane, 0, (size_t)b->n_env * sizeof(int), ms));
-      HB_HIP(hipMemsetAsync(b->d_lane_win, 0, (size_t)b->n_env * sizeof(int), ms));
-      HB_HIP(hipMemsetAsync(b->d_lane_list, 0xff, (size_t)2 * b->n_env * sizeof(int), ms));
-      HB_HIP(hipMemsetAsync(b->d_lane_count, 0, 8 * sizeof(int), ms));
-      HB_HIP(hipMemsetAsync(b->lane_ring, 0, sizeof(LaneRing), ms));
-      b->lane_nseg = nseg; b->lane_calls = 0;
-      memset(b->win_pending, 0, sizeof b->win_pending);
-    }
-    const bool sample = nseg == 1 && b->time_steps && (b->launch_count % 8 == 0) && b->tev_used + 2 <= (int)b->tev.size();
-    const bool reorder = b->schedule && (b->launch_count % reorder_period() == 0);
-    // (one segment: the launch goes on the batch's own stream, which after the re-join above has no pipes in flight - and must not wait
-    // for the slow lane, so no join here)
-    int rc = nseg > 1 ? fork_pipes(b, nseg) : HB_OK;
-    if (rc != HB_OK) return rc;
-    if (sample) HB_HIP(hipEventRecord(b->tev[b->tev_used], b->stream));
-    P.lane = b->d_lane; P.lane_list = b->d_lane_list; P.lane_count = b->d_lane_count; P.lane_done = b->d_lane_done; P.lane_win = b->d_lane_win;
-    P.lane_ring = b->lane_ring;  // (written by the small launches themselves as the GPU gets to them)
-    P.n_env_total = b->n_env;
-    P.lane_tag = (int)(1 + b->lane_calls % 0x3fffffff);
-    for (int c = 0; c < nseg; c++) {
-      const Segment sg = segment(b, c, nseg);
-      P.lane_lo[c] = sg.lo; P.lane_n[c] = sg.hi - sg.lo;
-      P.lane_par[c] = (int)(lane_windex(b, c, nseg) & 1);
-      P.lane_wid[c] = (int)(1 + lane_windex(b, c, nseg) % 0x3fffffff);
-      P.lane_limit[c] = (int)(P.lane_tag + (b->lane_window - 1 - lane_phase(b, c, nseg)));  // the last tag of the segment's current window
-    }
-    for (int c = 0; c < nseg; c++) {
-      rc = launch_segment_two_lane(b, P, segment(b, c, nseg), c, nseg, reorder);
-      if (rc != HB_OK) return rc;
-    }
-    if (sample) { HB_HIP(hipEventRecord(b->tev[b->tev_used + 1], b->stream)); b->tev_used += 2; }
-    // The slow lane: ONE launch for all segments on its own stream - after this step's small launches (which may have added envs) and, by
-    // stream order, after the slow lane's earlier launches.  Nothing waits for it but a join.
-    const int slow_blocks = kSlowBlocks;
-    {
-      if (!b->slow) {
-        // a stream of its own PRIORITY class: the runtime maps ordinary streams round robin onto four hardware queues, and the slow lane
-        // sharing a queue with a pipe would serialise behind that pipe's small launches; streams created with a priority get queues of
-        // their own (seen in the kernel trace's queue ids)
-        static const int prio = getenv("HB_SLOW_PRIO") ? atoi(getenv("HB_SLOW_PRIO")) : -1;
-        int lo = 0, hi = 0;
-        if (prio == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&b->slow, hipStreamNonBlocking, prio < 0 ? hi : lo) != hipSuccess) {
-          (void)hipGetLastError();
-          HB_HIP(hipStreamCreateWithFlags(&b->slow, hipStreamNonBlocking));
-        }
-      }
-      for (int c = 0; c < nseg; c++) HB_HIP(hipStreamWaitEvent(b->slow, b->ev_fast[c], 0));
-      BatchPtrs S = P;
-      S.lane_mode = 3; S.order = nullptr; S.order2 = nullptr; S.blk0 = 0; S.nblk = b->n_env;
-      HB_HIP(launch_step_slow(b->D.d_dm, b->D.dm.lds_floats, S, std::min(std::max(1, b->n_env / nseg), slow_blocks), nseg, b->slow));
-      HB_HIP(hipEventRecord(b->ev_slow, b->slow));
-      // the last slow launch that walks a window's list: what the memset of that list two windows on is ordered behind
-      for (int c = 0; c < nseg; c++)
-        if (lane_phase(b, c, nseg) == b->lane_window - 1) { HB_HIP(hipEventRecord(b->ev_win[c][P.lane_par[c]], b->slow)); b->win_pending[c][P.lane_par[c]] = true; }
-      b->slow_pending = true;
-      b->slow_forked = true;
-    }
-    b->lane_calls++;
-    steps_enqueued(b, nseg, reorder);
-    return HB_OK;
-  }
-  if (b->slow_forked) (void)main_stream(b);  // a full-kernel launch steps every env: behind the slow lane first
   const bool sample = nseg == 1 && b->time_steps && (b->launch_count % 8 == 0) && b->tev_used + 2 <= (int)b->tev.size();
-  const bool reorder = b->schedule && (b->launch_count % reorder_period() == 0);
+  const bool reorder = b->schedule && (b->launch_count % reorder_period(b) == 0);
   int rc = fork_pipes(b, nseg);
   if (rc != HB_OK) return rc;
   if (sample) HB_HIP(hipEventRecord(b->tev[b->tev_used], b->stream));
@@ -920,7 +792,7 @@ int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
   }
   if (sample) { HB_HIP(hipEventRecord(b->tev[b->tev_used + 1], b->stream)); b->tev_used += 2; }
   // (the condition of launch_step's refresh: staged, ordered, at least one (t & 7) == 7 with a step behind it)
-  const bool refreshed = b->stage.result && b->D.dm.variant != 0 && b->schedule && nsteps > 8 && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2);
+  const bool refreshed = staged_on(b) && b->D.dm.variant != 0 && b->schedule && nsteps > 8 && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2);
   steps_enqueued(b, nseg, reorder, refreshed);
   return HB_OK;
 }
@@ -1124,7 +996,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
   const DevModel& dm = b->D.dm;
   bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) == hipSuccess;
-  // (the pipes' streams are created when hb_batch_pipeline asks for them and the slow lane's at its first launch: the runtime maps streams
+  // (the pipes' streams are created when hb_batch_pipeline asks for them: the runtime maps streams
   // onto four hardware queues, and streams that share one serialise - a batch should not own more streams than it uses)
   ok = ok && hipMalloc((void**)&b->d_state, (size_t)n_env * dm.nstate * sizeof(float)) == hipSuccess;
   ok = ok && hipMalloc((void**)&b->d_status, (size_t)n_env * sizeof(int)) == hipSuccess;
@@ -1132,24 +1004,9 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
   ok = ok && hipMemset(b->d_counts, 0, (size_t)n_env * kCountStride * sizeof(int)) == hipSuccess;
   ok = ok && ensure_ctrl(b, (size_t)n_env * std::max(1, dm.nu)) == HB_OK;
   ok = ok && hipMalloc((void**)&b->d_order, (size_t)2 * n_env * sizeof(int)) == hipSuccess;  // the permutation | the sort keys of a pass
-  // two-lane stepping is OPT-IN (HB_TWO_LANE=1): measured on MI355X it loses to the full kernel on the benchmark's contact-rich regime
-  // (DESIGN.md 3.7), and wins only where env-steps of more than 31 rows are rarer than there
-  if (ok && b->D.d_dm_small && getenv("HB_TWO_LANE") && atoi(getenv("HB_TWO_LANE")) != 0) {
-    ok = hipMalloc((void**)&b->d_lane, (size_t)n_env * sizeof(int)) == hipSuccess && hipMemset(b->d_lane, 0, (size_t)n_env * sizeof(int)) == hipSuccess &&
-         hipMalloc((void**)&b->d_lane_list, (size_t)2 * n_env * sizeof(int)) == hipSuccess && hipMemset(b->d_lane_list, 0xff, (size_t)2 * n_env * sizeof(int)) == hipSuccess &&
-         hipMalloc((void**)&b->d_lane_count, 8 * sizeof(int)) == hipSuccess && hipMemset(b->d_lane_count, 0, 8 * sizeof(int)) == hipSuccess &&
-         hipMalloc((void**)&b->d_lane_done, (size_t)n_env * sizeof(int)) == hipSuccess && hipMemset(b->d_lane_done, 0, (size_t)n_env * sizeof(int)) == hipSuccess &&
-         hipMalloc((void**)&b->d_lane_win, (size_t)n_env * sizeof(int)) == hipSuccess && hipMemset(b->d_lane_win, 0, (size_t)n_env * sizeof(int)) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&b->ev_slow, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipMalloc((void**)&b->lane_ring, sizeof(LaneRing)) == hipSuccess && hipMemset(b->lane_ring, 0, sizeof(LaneRing)) == hipSuccess;
-    if (const char* w = getenv("HB_LANE_WINDOW")) b->lane_window = std::min(kLaneRing, std::max(1, atoi(w)));
-    for (int c = 0; c < hb_batch::kPipes && ok; c++)
-      ok = hipEventCreateWithFlags(&b->ev_fast[c], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_win[c][0], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&b->ev_win[c][1], hipEventDisableTiming) == hipSuccess;
-  }
   ok = ok && hipMalloc((void**)&b->d_order2, (size_t)2 * n_env * sizeof(int)) == hipSuccess;
-  // general variants: the staged step (pose -> narrowphase -> step kernels); HB_STAGED=0 keeps everything in the step kernel
-  if (dm.variant != 0 && !(getenv("HB_STAGED") && atoi(getenv("HB_STAGED")) == 0)) {
+  // general variants: the staged step (pose -> narrowphase -> step kernels); hb_batch_tune(HB_TUNE_STAGED, 0) keeps everything in the step kernel
+  if (dm.variant != 0) {
     StageBufs& sb = b->stage;
     ok = ok && hipMalloc((void**)&sb.geom, (size_t)n_env * std::max(1, dm.ngeom) * 10 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&sb.item, (size_t)n_env * kWorkMax * sizeof(int4)) == hipSuccess;
@@ -1159,9 +1016,9 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
     ok = ok && hipMalloc((void**)&sb.result, (size_t)n_env * kWorkMax * 4 * sizeof(float4)) == hipSuccess;
     ok = ok && hipMemset(sb.nwork, 0, (size_t)n_env * sizeof(int)) == hipSuccess;
     sb.nq = dm.nq; sb.nv = dm.nv; sb.nu = dm.nu;
-    sb.no_mesh = (b->model->m.nmesh == 0 && !(getenv("HB_NARROW_PRIM") && atoi(getenv("HB_NARROW_PRIM")) == 0)) ? 1 : 0;
+    sb.no_mesh = b->model->m.nmesh == 0 ? 1 : 0;
     sb.pose_lds = pose_lds_floats(dm.nq, dm.nbody, dm.ngeom) * (int)sizeof(float);
-    if ((dm.variant == 1 || b->D.d_dm_fast) && !(getenv("HB_FASTPASS") && atoi(getenv("HB_FASTPASS")) == 0)) {
+    if (dm.variant == 1 || b->D.d_dm_fast) {
       ok = ok && hipMalloc((void**)&sb.defer, (size_t)n_env * sizeof(int)) == hipSuccess;
       ok = ok && hipMemset(sb.defer, 0, (size_t)n_env * sizeof(int)) == hipSuccess;
       if (dm.variant == 2 || dm.variant == 3) { sb.dm_fast = b->D.d_dm_fast; sb.fast_lds = b->D.fast_lds_floats * (int)sizeof(float); }
@@ -1181,22 +1038,11 @@ static void envrand_free_fwd(hb_batch* b);
 void hb_batch_free(hb_batch* b) {
   if (!b) return;
   HB_IGN(hipSetDevice(b->device));
-  if (b->lane_ring && hb_debug()) {
-    LaneRing r;
-    HB_IGN(hipDeviceSynchronize());
-    if (hipMemcpy(&r, b->lane_ring, sizeof r, hipMemcpyDeviceToHost) == hipSuccess)
-      fprintf(stderr, "[hb] two-lane: %lld step calls since the last re-join, %d env-steps made by the slow lane\n", b->lane_calls, r.slow_steps);
-  }
   for (int c = 0; c < hb_batch::kPipes; c++) {
     if (b->pipe[c] && b->pipe[c] != b->stream) { HB_IGN(hipStreamSynchronize(b->pipe[c])); HB_IGN(hipStreamDestroy(b->pipe[c])); }
-    if (b->ev_fast[c]) HB_IGN(hipEventDestroy(b->ev_fast[c]));
-    for (int i = 0; i < 2; i++) if (b->ev_win[c][i]) HB_IGN(hipEventDestroy(b->ev_win[c][i]));
     if (b->ev_pipe[c]) HB_IGN(hipEventDestroy(b->ev_pipe[c]));
   }
   if (b->ev_fork) HB_IGN(hipEventDestroy(b->ev_fork));
-  if (b->slow) { HB_IGN(hipStreamSynchronize(b->slow)); HB_IGN(hipStreamDestroy(b->slow)); }
-  if (b->ev_slow) HB_IGN(hipEventDestroy(b->ev_slow));
-  if (b->lane_ring) HB_IGN(hipFree(b->lane_ring));
   if (b->stream) { HB_IGN(hipStreamSynchronize(b->stream)); HB_IGN(hipStreamDestroy(b->stream)); }
   for (auto e : b->tev) HB_IGN(hipEventDestroy(e));
   for (int i = 0; i < 4; i++) { if (b->d_mlp_w[i]) HB_IGN(hipFree(b->d_mlp_w[i])); if (b->d_mlp_b[i]) HB_IGN(hipFree(b->d_mlp_b[i])); if (b->d_mlp_wp[i]) HB_IGN(hipFree(b->d_mlp_wp[i])); }
@@ -1210,7 +1056,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
   void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nsearch, b->stage.nwork, b->stage.result, b->stage.defer, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_mask,
-                  b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_order2, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode, b->d_lane, b->d_lane_list, b->d_lane_count, b->d_lane_done, b->d_lane_win};
+                  b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_order2, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
 }
@@ -1230,14 +1076,9 @@ static int make_pipes(hb_batch* b, int n) {
   for (int c = 0; c < n; c++) {
     if (!b->pipe[c] && c == 0) b->pipe[0] = b->stream;
     if (!b->pipe[c]) {
-      // HB_PIPE_PRIO=1 (experiment, slower: 95 us per step for three segments): streams of different priorities.  ROCm keeps one pool
-      // of hardware queues per priority level
-      static const int prio_mode = getenv("HB_PIPE_PRIO") ? atoi(getenv("HB_PIPE_PRIO")) : 0;
-      int least = 0, greatest = 0;
-      hipDeviceGetStreamPriorityRange(&least, &greatest);
-      const int levels[hb_batch::kPipes] = {greatest, 0, least, 0, greatest, 0, least, 0};
-      const hipError_t e = prio_mode ? hipStreamCreateWithPriority(&b->pipe[c], hipStreamNonBlocking, levels[c])
-                                     : hipStreamCreateWithFlags(&b->pipe[c], hipStreamNonBlocking);
+      // (streams of different priorities - ROCm keeps one pool of hardware queues per priority level - were measured too: 95 us per step for three
+      // segments against 88)
+      const hipError_t e = hipStreamCreateWithFlags(&b->pipe[c], hipStreamNonBlocking);
       if (e != hipSuccess) return HB_ENOMEM;
     }
     if (!b->ev_pipe[c] && hipEventCreateWithFlags(&b->ev_pipe[c], hipEventDisableTiming) != hipSuccess) return HB_ENOMEM;
@@ -2419,8 +2260,8 @@ static int policy_forward(hb_batch* b, int lo, int hi, hipStream_t st, int seg =
     for (int l = 0; l <= b->mlp_layers; l++) { pd.sizes[l] = b->mlp_sizes[l]; widest = std::max(widest, b->mlp_sizes[l]); }
     for (int l = 0; l < b->mlp_layers; l++) { pd.w[l] = b->d_mlp_wp[l]; pd.b[l] = b->d_mlp_b[l]; }
     pd.ldx = widest + 4;  // + the K pad columns (K is swept four at a time); 16-row tiles
-    static const bool lean_ok = !(getenv("HB_POLICY_LEAN") && atoi(getenv("HB_POLICY_LEAN")) == 0);
-    static const bool lean_all = getenv("HB_POLICY_LEAN") && atoi(getenv("HB_POLICY_LEAN")) == 2;
+    const bool lean_ok = b->tune[HB_TUNE_POLICY_LEAN] != 0;
+    const bool lean_all = b->tune[HB_TUNE_POLICY_LEAN] == 2;
     if (lean_all && seg < 0) seg = 0;
     if (seg >= 0 && lean_ok && b->d_mlp_act)
       HB_HIP(launch_policy_lean(dm, pd, b->d_state + (size_t)lo * dm.nstate, ctrl_for_write(b) + (size_t)lo * dm.nu,
@@ -2458,7 +2299,7 @@ int hb_rollout_policy(hb_batch* b, int T, float* qpos_out_dev) {
   int rc = fork_pipes(b, nseg);
   if (rc != HB_OK) return rc;
   for (int t = 0; t < T; t++) {
-    const bool reorder = b->schedule && (b->launch_count % reorder_period() == 0);
+    const bool reorder = b->schedule && (b->launch_count % reorder_period(b) == 0);
     BatchPtrs P = make_ptrs(b);
     P.qfrc_out = nullptr;  // (the env adapter's read-out: nothing in this loop reads it, and without it the step launches are the lean kernels)
     P.ctrl = b->d_ctrl; P.ctrl_mode = 0;
@@ -2511,22 +2352,15 @@ int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch, int* kcycles)
 }
 
 const char* hb_last_kernel(const hb_batch* b) { return b ? b->last_kernel : ""; }
-int hb_batch_duo(hb_batch* b, int mode) {
-  if (!b || mode < 0 || mode > 2) return HB_EINVAL;
-  b->duo = mode;
-  return HB_OK;
-}
-
-int hb_get_lanes(hb_batch* b, int* lane) {
-  if (!b) return HB_EINVAL;
+int hb_batch_tune(hb_batch* b, int knob, int value) {
+  if (!b || knob < 0 || knob >= HB_TUNE_COUNT || value < 0) return HB_EINVAL;
+  if (knob == HB_TUNE_DUO && value > 2) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  HB_HIP(hipStreamSynchronize(main_stream(b)));
-  if (!b->d_lane) { if (lane) memset(lane, 0, (size_t)b->n_env * sizeof(int)); return 0; }
-  std::vector<int> h((size_t)b->n_env);
-  HB_HIP(hipMemcpy(h.data(), b->d_lane, h.size() * sizeof(int), hipMemcpyDeviceToHost));
-  int nslow = 0;
-  for (int e = 0; e < b->n_env; e++) { nslow += h[e] != 0; if (lane) lane[e] = h[e] != 0; }
-  return nslow;
+  (void)main_stream(b);  // the choice holds from the next launch on: whatever is in flight on the segments' streams is joined first
+  b->tune[knob] = value;
+  if (knob == HB_TUNE_SCHEDULE) { b->schedule = value != 0; b->order_mode = 0; }
+  if (knob == HB_TUNE_STAGED || knob == HB_TUNE_FASTPASS) b->order_mode = 0;
+  return HB_OK;
 }
 
 int hb_diag_enable(hb_batch* b, int on) {

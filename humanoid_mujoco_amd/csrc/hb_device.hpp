@@ -23,11 +23,6 @@ namespace hb {
 constexpr int kGroup = 64;      // lanes cooperating on one env (one wavefront)
 constexpr int kNconMax = 24;    // contact capacity per env (overflow -> HB_WARN_CONTACTFULL)
 constexpr int kNefcMax = 63;    // constraint-row capacity per env (overflow -> HB_WARN_CNSTRFULL); lane 63 / row 63 of C carries the extra right-hand side
-// the SMALL instantiation of the classic PGS kernel (hb_step_small_kernel): rows and contacts of 99.85 % of the benchmark's env-steps in
-// 168 registers and 12.6 KB of LDS, i.e. three waves per SIMD; an env-step that needs more moves its env to the slow lane (BatchPtrs::lane)
-constexpr int kSmallNefcMax = 31;
-constexpr int kSmallNconMax = 12;
-constexpr int kLaneRing = 64;   // step calls whose controls the slow lane can still reach (>= the rebalance window)
 // the general instantiations (mesh hulls, height-field prisms, condim 4 / 6: the reference's own robot) with the Newton solver hold
 // their rows in kBigGroups groups of 64 (lane l owns rows l, l + 64, ...): 256 rows, 48 contacts
 constexpr int kBigGroups = 4;
@@ -310,17 +305,6 @@ __host__ __device__ inline int pose_lds_floats(int nq, int nb, int ngeom) {
   return ((nq + 3) & ~3) + 12 * nb + 2 * ((3 * ngeom + 3) & ~3) + 4 * ngeom + kListMax * 5 + kWorkMax;
 }
 
-// What the slow lane of two-lane stepping needs to know about the step calls (device memory, written by the small kernel of each call
-// when it starts - in the order the GPU gets to the calls, however far ahead the host has enqueued): per segment the tag of the latest
-// call whose small launch has started, and by tag % kLaneRing the controls of the last kLaneRing calls.
-struct LaneRing {
-  int released[4];
-  int slow_steps, slow_blocks;  // statistics: env-steps the slow lane has made, blocks of its launches that found work
-  int t0[kLaneRing];
-  int mode[kLaneRing];
-  const float* ctrl[kLaneRing];
-};
-
 struct BatchPtrs {
   float* state;        // [n_env][nstate]
   const float* ctrl;   // [n_env][nu] or [T][n_env][nu]
@@ -359,26 +343,6 @@ struct BatchPtrs {
   unsigned long long sensor_submask[4];                          //   bit b: body b belongs to that subtree
   float sensor_subinv[4];                                        //   1 / subtree mass
   const unsigned char* env_mask;  // nullable [n_env]: envs with a zero byte are skipped by this launch
-  // Two-lane stepping of the classic PGS kernel (launch_steps in hb_api.cpp).  lane[e] != 0 puts env e in the SLOW lane
-  // (the value: tag = 1 + index of the step call that moved it there); lane_done[e] = tag of the last step completed for a slow env.
-  // lane_mode 1: the small kernel steps the fast-lane envs; an env whose step overflows its capacity goes to the slow lane (state
-  // untouched): lane_done[e] = lane_tag - 1, lane[e] = lane_tag, env appended to the segment's list.  2: the same at a REBALANCE point of
-  // the segment (a new window, a new list): a slow env whose slow lane has caught up (lane_done[e] == lane_tag - 1) is taken back and
-  // stepped here, one that has not is carried over into the new list.  3: hb_step_slow_kernel walks the lists (see there).
-  int* lane;        // nullable [n_env]
-  int* lane_done;   // [n_env]
-  int* lane_list;   // [2][n_env]: per window parity, the segments' lists (segment c's at lane_lo[c]; -1: empty slot)
-  int* lane_count;  // [2][4]: per window parity and segment, the entries appended since the window began
-  int lane_lo[4], lane_n[4];  // first env and env count of every segment
-  int lane_par[4];            // per segment: parity of its current window (which list / count)
-  int lane_wid[4];            // per segment: 1 + index of its current window
-  int* lane_win;              // [n_env] lane_wid of the window in whose list the env was last entered (an env is listed once per window)
-  int lane_limit[4];          // per segment: the last tag of its current window (the slow lane stops there: the next window's small launch
-                              // decides about every env itself)
-  int lane_seg;               // the segment this launch of the small kernel steps (the slow lane's launch covers all: blockIdx.y)
-  int lane_mode, lane_tag;
-  int n_env_total;            // (n_env of the batch: stride of the two lists)
-  LaneRing* lane_ring;        // the step calls the GPU has got to and their controls
   unsigned long long* stamps;  // diagnostic builds (-DHB_STAMPS) only: [n_env][16] s_memtime stamps of the last step
   int lean_ok;                // bit 0: the model's options allow the lean instantiations (mjOption.disableflags == 0); bit 1: its sizes and LDS
                               // layout are kSizedHumanoid27's (the size-specialised instantiations); bit 2: its fast layout is kSizedTeamV1's

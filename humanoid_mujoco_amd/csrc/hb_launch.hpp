@@ -4,10 +4,6 @@
 #include "hb_device.hpp"
 namespace hb {
 hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream);
-// the small instantiation of the classic PGS kernel on its own LDS layout (two-lane stepping: BatchPtrs::lane, lane_mode 1 / 2), one step
-hipError_t launch_step_small(const DevModel* M_small, int lds_floats, const BatchPtrs& P, hipStream_t stream);
-// the slow lane of two-lane stepping: `blocks` workgroups per segment walk the lists of P.lane_list with the full classic PGS instantiation (lane_mode 3)
-hipError_t launch_step_slow(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int blocks, int nseg, hipStream_t stream);
 // two envs per wave: a lean single-step launch of the 27-dof humanoid's PGS kernel (hb_step_duo.hip; chosen by launch_step)
 hipError_t launch_step_duo(const DevModel* M_dev, const BatchPtrs& P, int nsteps, hipStream_t stream);
 // name of the step kernel the last launch_step of this thread launched last (hb_last_kernel)

@@ -34,8 +34,8 @@ namespace hb {
 // flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
 // (sizes and LDS offsets: the model's, or - SIZED - the constants of kSizedHumanoid27, hb_device.hpp)
 #define HB_SZ(f) (SIZED ? (NDENSE == 20 ? kSizedTeamV1.f : COLL ? kSizedHumanoid27V1.f : kSizedHumanoid27.f) : M.f)
-template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int SMALL = 0, int LEAN = 0, int SIZED = 0>
-__device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps_in, int env_fixed = -1, int ring = -1) {
+template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int LEAN = 0, int SIZED = 0>
+__device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps_in) {
   const int nsteps = LEAN == 1 ? 1 : nsteps_in;  // (LEAN == 1 is launched for single steps only: the step API; rollouts take LEAN == 2)
   // LEAN (1 = a single step without the constraint-force read-out; 2 = any number of steps, read-out optional): a launch without the optional inputs and outputs (applied forces and their noise, constraint-force / sensor / trajectory
   // read-outs, diagnostics, per-env model parameters, an env mask; mj_step, not mj_forward) - known at compile time, so their tests,
@@ -54,11 +54,10 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   const int P_dr_stride = LEAN ? 0 : P.dr_stride;
   const unsigned char* const P_env_mask = LEAN ? nullptr : P.env_mask;
   const int P_integrate = LEAN ? 1 : P.integrate;
-  static_assert(SIZED == 0 || (NG == 1 && SMALL == 0 && ((NDENSE == 28 && (COLL == 0 || SOLVER == 0)) || (NDENSE == 20 && COLL == 1 && SOLVER == 2))), "the size-specialised instantiations: the humanoid (classic or variant-1 layout) and the robot (Newton, variant-1 layout)");
+  static_assert(SIZED == 0 || (NG == 1 && ((NDENSE == 28 && (COLL == 0 || SOLVER == 0)) || (NDENSE == 20 && COLL == 1 && SOLVER == 2))), "the size-specialised instantiations: the humanoid (classic or variant-1 layout) and the robot (Newton, variant-1 layout)");
   static_assert(NG == 1 || SOLVER == 2 || (COLL == 1 && NG == kPgsGroups && DEFER == 0), "PGS on more than one row group: the general variant's kPgsGroups instantiation");
-  static_assert(SMALL == 0 || (SOLVER == 0 && NDENSE <= 28 && COLL == 0 && NG == 1 && DEFER == 0), "the small instantiation: classic PGS kernel of dense order <= 28");
-  constexpr int kNR = SMALL ? kSmallNefcMax : (NG == 1 ? kNefcMax : 64 * NG);  // row capacity of this instantiation
-  constexpr int kNC = SMALL ? kSmallNconMax : (NG == 1 ? kNconMax : kBigNconMax);  // contact capacity
+  constexpr int kNR = NG == 1 ? kNefcMax : 64 * NG;  // row capacity of this instantiation
+  constexpr int kNC = NG == 1 ? kNconMax : kBigNconMax;  // contact capacity
   // the model tables are read through a constant-address-space pointer (not by-value kernel
   // arguments): the ~100 table pointers and every wave-uniform table entry are fetched on demand by
   // scalar loads through the scalar cache instead of living in (and spilling from) SGPRs
@@ -69,10 +68,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   extern __shared__ float lds[];
   const int lane0 = threadIdx.x;
   int lane = lane0;
-  bool coherent = env_fixed >= 0;  // (the slow lane's kernel; the small kernel sets it for an env it takes back from the slow lane)
-  if (env_fixed < 0 && (int)blockIdx.x >= P.nblk) return;
+  if ((int)blockIdx.x >= P.nblk) return;
   const int slot = P.blk0 + (int)blockIdx.x;
-  const int env = env_fixed >= 0 ? env_fixed : (P.order ? P.order[slot] : slot);  // (env_fixed: the slow lane's kernel names the env)
+  const int env = P.order ? P.order[slot] : slot;
   if (P_env_mask && !P_env_mask[env]) return;  // masked stepping (hb_env_reset's settle step)
   if constexpr (COLL != 0 && DEFER == 0) {
     if (P.stage.rerun) {  // second pass of a staged step: only the envs the fast pass deferred
@@ -81,52 +79,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       if (lane0 == 0) P.stage.defer[env] = 0;
     }
   }
-  // two-lane stepping (BatchPtrs::lane): the small kernel leaves the slow-lane envs to hb_step_slow_kernel
-  if constexpr (SMALL != 0) {
-    // the first block of a small launch tells the slow lane that the GPU has got to this call, and with which controls
-    if (blockIdx.x == 0 && lane0 == 0) {
-      const int r = P.lane_tag % kLaneRing;
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(P.lane_ring->ctrl + r), (unsigned long long)(uintptr_t)P.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(P.lane_ring->t0 + r, P.t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(P.lane_ring->mode + r, P.ctrl_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(P.lane_ring->released + P.lane_seg, P.lane_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const int slow = P.lane[env];
-    if (slow) {
-      // A slow env comes back to the fast lane at the first call at which its slow lane has caught up: lane_done[e] == lane_tag - 1 means
-      // every earlier step is complete, and the compare-and-swap to -lane_tag CLAIMS this call's step (the slow lane claims its steps the
-      // same way, so exactly one of the two steps the env for this call).  Otherwise the env stays slow; at the first call of a window
-      // (lane_mode 2: a new list) it is carried over into the new list.
-      int got = 0;
-      if (lane0 == 0) {
-        int expect = P.lane_tag - 1;
-        got = __hip_atomic_compare_exchange_strong(P.lane_done + env, &expect, -P.lane_tag, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-      }
-      got = uniform(got);
-      if (!got) {
-        if (P.lane_mode == 2 && lane0 == 0 && P.lane_win[env] != P.lane_wid[P.lane_seg]) {
-          P.lane_win[env] = P.lane_wid[P.lane_seg];
-          P.lane_list[P.lane_par[P.lane_seg] * P.n_env_total + P.lane_lo[P.lane_seg] + atomicAdd(P.lane_count + 4 * P.lane_par[P.lane_seg] + P.lane_seg, 1)] = env;
-        }
-        return;
-      }
-      coherent = true;  // the slow lane's stores of this env's state, not a stale cache line
-      if (lane0 == 0) P.lane[env] = 0;
-    }
-  }
-  // an env-step that overflows the small instantiation (nothing has been written at that point): to the slow lane
-  auto to_slow_lane = [&]() {
-    if (lane0 == 0) {
-      P.lane_done[env] = P.lane_tag - 1;  // (the fast lane has completed every step before this one)
-      P.lane[env] = P.lane_tag;
-      if (P.lane_win[env] != P.lane_wid[P.lane_seg]) {  // (an env that left and re-entered the slow lane inside a window is already listed)
-        P.lane_win[env] = P.lane_wid[P.lane_seg];
-        P.lane_list[P.lane_par[P.lane_seg] * P.n_env_total + P.lane_lo[P.lane_seg] + atomicAdd(P.lane_count + 4 * P.lane_par[P.lane_seg] + P.lane_seg, 1)] = env;
-      }
-    }
-  };
-  (void)to_slow_lane;
   // per-env model parameters (domain randomisation), nullable; offsets per DomainLayout
   const float* dr = P_dr ? P_dr + (size_t)env * P_dr_stride : nullptr;
   const DomainLayout DL = domain_layout(HB_SZ(nbody), HB_SZ(nv), HB_SZ(nlimcand), HB_SZ(nu), M.nhfielddata);
@@ -173,20 +125,12 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   // the controls of the first step are requested before the state, those of step t+1 at the top of step t:
   // an HBM round trip each (streamed, never cached) that would otherwise open every step
   float ctrl_pf = 0.f;
-  // (ring >= 0: the slow lane steps this env with the controls of an earlier step call)
   const float* ctrl_src = P.ctrl;
-  int ctrl_mode = P.ctrl_mode, ctrl_t0 = P.t0;
-  if (ring >= 0) {
-    ctrl_src = reinterpret_cast<const float*>((uintptr_t)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(P.lane_ring->ctrl + ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    ctrl_mode = __hip_atomic_load(P.lane_ring->mode + ring, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ctrl_t0 = __hip_atomic_load(P.lane_ring->t0 + ring, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  const int ctrl_mode = P.ctrl_mode, ctrl_t0 = P.t0;
   if (ctrl_mode != 2 && lane < HB_SZ(nu)) ctrl_pf = ctrl_src[(size_t)env * HB_SZ(nu) + lane];
   float* gstate = P.state + (size_t)env * HB_SZ(nstate);
-  // (coherent: the state record changes hands between the slow lane's kernel and a small launch running beside it - agent-scope accesses
-  // that go past the non-coherent caches, entry by entry; everywhere else ordinary loads and stores)
-  auto ld_state = [&](int i) -> float { return coherent ? __hip_atomic_load(gstate + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gstate[i]; };
-  auto st_state = [&](int i, float v) { if (coherent) __hip_atomic_store(gstate + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else gstate[i] = v; };
+  auto ld_state = [&](int i) -> float { return gstate[i]; };
+  auto st_state = [&](int i, float v) { gstate[i] = v; };
   float time = ld_state(0);
   for (int i = lane; i < nq; i += kGroup) s_qpos[i] = ld_state(1 + i);
   for (int i = lane; i < nv; i += kGroup) { s_qvel[i] = ld_state(1 + nq + i); s_warm[i] = ld_state(1 + nq + nv + i); }
@@ -788,7 +732,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         ncon += __popcll(b1) + __popcll(b2);
       }
       if (ncon > kNC) {
-        if constexpr (SMALL != 0) { to_slow_lane(); return; }  // more contacts than this instantiation holds
         status |= (1 << 1); ncon = kNC;
       }
     }
@@ -962,7 +905,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         nefc += __popcll(bal);
       }
       if (nefc > kNR) {
-        if constexpr (SMALL != 0) { to_slow_lane(); return; }
         status |= (1 << 2); nefc = kNR;
       }
     }
@@ -990,7 +932,6 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         c[C_FRIC] = fmaxf(1e-5f, dr ? fmaxf(M.pair_fricab[2 * pairid] * dr[DL.o_fric], M.pair_fricab[2 * pairid + 1]) : M.pair_friction[3 * pairid]);
       }
       if (__ballot(lane < ncon && incl && !fits)) {
-        if constexpr (SMALL != 0) { to_slow_lane(); return; }
         status |= (1 << 2);
       }
       // contacts are materialised in order; once one does not fit, none of the later ones does
@@ -1126,7 +1067,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       asm volatile("v_mov_b32 %0, %1" : "=v"(lw) : "v"(lane0));
       f32x16 T, S;
       sym_factor_mfma<NDENSE / 2>(load_sym_pairs<0>(M, s_qLD, lw), T, S, lw);
-      if (!SMALL || (lw & 31) < NDENSE) store_w_rows(s_W, kWs, T, S, lw);  // (the small layout has no room for the padding rows, and nothing reads them)
+      store_w_rows(s_W, kWs, T, S, lw);
       gsync();
     }
     if constexpr (NG == 1) {
@@ -1134,7 +1075,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       const int col = lane & 31, half = lane >> 5;
 #pragma unroll
       for (int I = 0; I < 2; I++) {
-        if (I == 0 || (!SMALL && nefc >= 32)) {
+        if (I == 0 || nefc >= 32) {
           const int arow = 32 * I + col;
           const float* Ap = s_C + arow * cs + half;
           const bool av = arow <= nefc;
@@ -1180,7 +1121,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       bvec = jas - aref;
       Aii = rowact ? diag + R : 1.f;
       const int col = lane & 31, half = lane >> 5;
-      const bool two = !SMALL && nefc > 32;  // rows 32..62 in use: all four tiles, else only tile (0,0)
+      const bool two = nefc > 32;  // rows 32..62 in use: all four tiles, else only tile (0,0)
       const bool v0 = col < nefc, v1 = 32 + col < nefc;
       const float* A0p = s_C + col * cs + half;
       const float* A1p = s_C + (32 + col) * cs + half;
@@ -1219,7 +1160,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         const int ra = (r & 3) + 8 * (r >> 2);
         const u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(X0[r]), __float_as_uint(Y0[r]), false, false);
         ar[ra] = __uint_as_float(s0.x);
-        if (ra + 4 < kNR) ar[ra + 4] = __uint_as_float(s0.y);  // (the small instantiation has no row 31)
+        if (ra + 4 < kNR) ar[ra + 4] = __uint_as_float(s0.y);
         const u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(X1[r]), __float_as_uint(Y1[r]), false, false);
         if (32 + ra < kNR) ar[32 + ra] = __uint_as_float(s1.x);
         if (32 + ra + 4 < kNR) ar[32 + ra + 4] = __uint_as_float(s1.y);
@@ -1293,25 +1234,15 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         if (improvement * pgs_scale < pgs_tol) break;
       }
     }
-    if constexpr (SMALL == 0) { if (lane < kNR) s_force[lane] = rowact ? force : 0.f; }
+    if (lane < kNR) s_force[lane] = rowact ? force : 0.f;
     gsync();
     HB_STAMP(13);
     // ---------------------------------------------------------------- dual finish: s = sum_i f_i C_i ; qacc = W (y + s)
     const bool want_qfrc = P_qfrc_out != nullptr;
-    if constexpr (SMALL != 0) {
-      // the forces straight out of their lanes (nefc is uniform): no LDS copy.  Every lane runs the loop - v_readlane reads lanes that a
-      // divergent region has switched off, and the value they hold must have been computed there
-      const float fz = rowact ? force : 0.f;
-      const int kc = lane < kCs ? lane : 0;
+    for (int k = lane; k < nv; k += kGroup) {
       float sacc = 0.f;
-      for (int i = 0; i < nefc; i++) sacc += rdlane(fz, i) * s_C[i * cs + kc];
-      if (lane < nv) s_v2[lane] = yv[lane] + sacc;  // y + s (nv <= 28: one pass)
-    } else {
-      for (int k = lane; k < nv; k += kGroup) {
-        float sacc = 0.f;
-        for (int i = 0; i < nefc; i++) sacc += s_force[i] * s_C[i * cs + k];
-        s_v2[k] = yv[k] + sacc;  // y + s
-      }
+      for (int i = 0; i < nefc; i++) sacc += s_force[i] * s_C[i * cs + k];
+      s_v2[k] = yv[k] + sacc;  // y + s
     }
     gsync();
     if (lane < nv) s_v0[lane] = dot32(s_W + lane * kWs, s_v2);
@@ -1902,53 +1833,11 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
 // (224 registers instead of the 229 the allocator would take - two values spilled - so that beside two of its waves a SIMD has 64
 // registers left: what the closed loop's policy kernel runs in, hb_policy_lean_kernel; amdgpu_num_vgpr counts per half of the file)
 __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28>(Mp, P, nsteps); }
-// the small instantiation (31 rows, 12 contacts: three waves per SIMD); single-step launches only - an overflowing env-step leaves without
-// having written anything, and the slow lane (hb_step_kernel, lane_mode 3) steps that env from then on
-__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 1>(Mp, P, nsteps); }
+__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 1>(Mp, P, nsteps); }
 // (the single-step lean kernel with the sizes and the LDS layout of the reference's 27-dof humanoid as constants)
-__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 1, 1>(Mp, P, nsteps); }
-__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_h27_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 2, 1>(Mp, P, nsteps); }
-__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 0, 2>(Mp, P, nsteps); }
-__global__ __launch_bounds__(kGroup, 3) void hb_step_small_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 1>(Mp, P, nsteps); }
-// The slow lane: a few blocks walk every segment's list of slow envs and step them with the full instantiation.  A slow env-step is
-// often the heavy kind (more than 31 rows: up to 50 sweeps over them, about 100 us against the 80 us period of the small launches), and a
-// launch lasts as long as its slowest block - so the slow lane is NOT in lock step with the fast one.  A slow env depends on nothing the
-// small launches do: lane_done[e] is the tag of the last step completed for it, and a block steps its env through ALL the step calls the
-// GPU has got to so far (LaneRing::released, with the controls of those calls) - also calls whose small launch started while it was
-// running.  An env that was heavy for a step or two catches up at the pace of its own light steps, and the small kernel takes it back at
-// the first call that finds it caught up; nothing ever waits for the slow lane but a join.
-// (A list entry a LATER small launch is writing beside this kernel shows as -1 or not at all: the next launch takes it.)
-__global__ __launch_bounds__(kGroup, 2) void hb_step_slow_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) {
-  const int seg = blockIdx.y;
-  const int* list = P.lane_list + P.lane_par[seg] * P.n_env_total + P.lane_lo[seg];
-  const int count = min(uniform(P.lane_count[4 * P.lane_par[seg] + seg]), P.lane_n[seg]);
-  for (int i = blockIdx.x; i < count; i += gridDim.x) {
-    const int e = uniform(list[i]);
-    if (e < 0) continue;
-    if (uniform(P.lane[e]) == 0) continue;
-    // step after step, each CLAIMED by compare-and-swap on lane_done[e] (t - 1 -> -t) and published when complete (-t -> t): the small
-    // kernel claims a step the same way when it takes the env back - whoever loses a claim leaves the env to the winner
-    for (;;) {
-      // (relaxed agent-scope accesses: they go past the non-coherent caches one word at a time; an acquire / release FENCE at agent
-      // scope would invalidate / write back the whole L2 of the XCD under the small launches' feet - measured: 250 instead of 90 us per step)
-      const int released = uniform(__hip_atomic_load(P.lane_ring->released + seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      int done = uniform(__hip_atomic_load(P.lane_done + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (done < 0 || done >= released || uniform(P.lane[e]) == 0) break;
-      int won = 0;
-      if (threadIdx.x == 0) {
-        int expect = done;
-        won = __hip_atomic_compare_exchange_strong(P.lane_done + e, &expect, -(done + 1), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-      }
-      if (!uniform(won)) break;
-      if (threadIdx.x == 0) atomicAdd(&P.lane_ring->slow_steps, 1);
-      step_body<0, 28>(Mp, P, nsteps, e, (done + 1) % kLaneRing);
-      gsync();
-      // every lane's (write-through, agent-scope) stores of the new state have left the wave before the flag does
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (threadIdx.x == 0) __hip_atomic_store(P.lane_done + e, done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
+__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 1, 1>(Mp, P, nsteps); }
+__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_h27_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 2, 1>(Mp, P, nsteps); }
+__attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) void hb_step_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 0, 1, 0, 2>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 32>(Mp, P, nsteps); }
 // General instantiations (mesh hulls, height-field prisms, condim 4 / 6): PGS on 63 rows (configs[4]: the 27-dof humanoid on terrain),
 // Newton on 256 rows (the reference's own robot, simulation/assets/world.xml: 18 dofs -> dense order 20; up to 28 dofs)
@@ -1965,13 +1854,13 @@ __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen28_kernel(const D
 // Newton instantiations: dense order 28 (nv <= 28: the 27-dof humanoid) and 32
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28>(Mp, P, nsteps); }
 // lean instantiations (step_body's LEAN: no optional inputs / outputs in the launch) of the kernels the plain step API spends its time in
-__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 1>(Mp, P, nsteps); }
-__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 1, 1>(Mp, P, nsteps); }
-__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 0, 2>(Mp, P, nsteps); }
-__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2, 0, 1>(Mp, P, nsteps); }
-__global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_team_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 0, 1, 1>(Mp, P, nsteps); }
-__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2, 0, 1, 1>(Mp, P, nsteps); }
-__global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 0, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 1, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton28_lean_q_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 0, 1, 0, 2>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_team_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 1, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_h27_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2, 1, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_lean_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 32>(Mp, P, nsteps); }
 
 // every step-kernel launch leaves its kernel's name behind (hb_last_kernel: tests and bench.py name the kernel they measured by what the
@@ -1984,7 +1873,7 @@ const char* last_step_kernel() { return g_last_step_kernel; }
 // wave, and the batch-wide barrier between step calls is hidden only while the launches in flight hold more waves than the chip has
 // slots (8 per CU for both kernels): 4096 envs are two rounds of one-env waves (the second hides the first one's tail) but exactly ONE
 // round of duo waves - 92 against 78 us per step on MI355X; from 8192 envs on the duo kernel wins, 124 against 148 us
-// (profiles/r04_duo_sizes.txt).  A rollout launch has no barrier between steps: duo as soon as the batch fills the chip.
+// (profiles/r04_duo_sizes.txt).  A rollout launch has no barrier between steps: duo as soon as the batch fills the chip twice over.
 // BatchPtrs::duo (hb_batch_duo; HB_DUO in the environment is a new batch's default): 0 never, 1 where it pays, 2 always.
 static int wave_slots() {
   static const int slots = [] { int dev = 0, cus = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; return 8 * cus; }();
@@ -1993,14 +1882,17 @@ static int wave_slots() {
 static bool duo_pays(const BatchPtrs& P, int nsteps) {
   if (P.duo == 0) return false;
   if (P.duo == 2) return true;
-  return nsteps == 1 ? 2 * P.n_env >= 5 * wave_slots() : P.n_env >= 2 * wave_slots();
+  if (nsteps > 1) return P.n_env >= 2 * wave_slots();
+  // (a launch that covers the whole batch is an unpipelined step call: nothing overlaps its tail anyway, and from 1.5 x the slots on one round
+  // of duo waves beats two rounds of one-env waves - 103 against 112 us at 4096 envs)
+  return P.nblk == P.n_env ? 2 * P.n_env >= 3 * wave_slots() : 2 * P.n_env >= 5 * wave_slots();
 }
 
 // the lean instantiations apply when the launch has none of the optional inputs / outputs (HB_LEAN=0: never)
 static bool lean_launch(const BatchPtrs& P, bool with_qfrc = false) {
   static const bool lean_on = !(getenv("HB_LEAN") && atoi(getenv("HB_LEAN")) == 0);
   return lean_on && (P.lean_ok & 1) && !P.xfrc && (with_qfrc || !P.qfrc_out) && !P.sensor_out && !P.qpos_out && !P.qvel_out && !P.diag_qacc && !P.diag_force && !P.diag_contact && !P.dr && !P.env_mask &&
-         P.integrate && !P.lane;
+         P.integrate;
 }
 static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int solver, int nv, size_t shmem, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
@@ -2076,16 +1968,6 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
     }
   }
   return hipSuccess;
-}
-hipError_t launch_step_slow(const DevModel* M_dev, int lds_floats, const BatchPtrs& P, int blocks, int nseg, hipStream_t stream) {
-  (void)hipGetLastError();
-  HB_STEP_LAUNCH(hb_step_slow_kernel, dim3(blocks, nseg), dim3(kGroup), (size_t)lds_floats * sizeof(float), stream, M_dev, P, 1);
-  return hipGetLastError();
-}
-hipError_t launch_step_small(const DevModel* M_small, int lds_floats, const BatchPtrs& P, hipStream_t stream) {
-  (void)hipGetLastError();
-  HB_STEP_LAUNCH(hb_step_small_kernel, dim3(P.nblk), dim3(kGroup), (size_t)lds_floats * sizeof(float), stream, M_small, P, 1);
-  return hipGetLastError();
 }
 hipError_t set_step_lds_limit(int bytes) {
   hipError_t e = hipFuncSetAttribute((const void*)hb_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -146,9 +146,8 @@ def lib():
     L.hb_get_obs.argtypes = [vp, vp, vp, vp, vp]
     L.hb_get_status.argtypes = [vp, vp]
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
-    L.hb_get_lanes.argtypes = [vp, vp]
     L.hb_last_kernel.argtypes = [vp]; L.hb_last_kernel.restype = ctypes.c_char_p
-    L.hb_batch_duo.argtypes = [vp, ci]
+    L.hb_batch_tune.argtypes = [vp, ci, ci]
     L.hb_get_collision_counts.argtypes = [vp, vp, vp, vp]
     L.hb_batch_segments.argtypes = [vp]
     L.hb_diag_enable.argtypes = [vp, ci]
@@ -420,21 +419,21 @@ class Batch:
         _check(lib().hb_get_counts(self._h, _ptr(a), _ptr(b), _ptr(c)), "hb_get_counts")
         return a, b, c
 
+    TUNE = {"duo": 0, "lean": 1, "sized": 2, "staged": 3, "fastpass": 4, "narrow_prim": 5, "schedule": 6, "reorder_period": 7, "policy_lean": 8}
+
+    def tune(self, **knobs):
+        """run-time choices between kernels / schedules that give the same results (include/hb.h: hb_batch_tune, HB_TUNE_*), e.g.
+        tune(duo=2, staged=0)"""
+        for k, v in knobs.items():
+            _check(lib().hb_batch_tune(self._h, self.TUNE[k], int(v)), "hb_batch_tune")
+
     def duo(self, mode=1):
         """two envs per wave for the lean launches of the 27-dof humanoid's PGS kernel: 0 never, 1 where it pays (default), 2 always"""
-        _check(lib().hb_batch_duo(self._h, int(mode)), "hb_batch_duo")
+        self.tune(duo=mode)
 
     def last_kernel(self):
         """name of the step kernel the batch's last step / rollout / forward launch ran (include/hb.h: hb_last_kernel)"""
         return lib().hb_last_kernel(self._h).decode()
-
-    def lanes(self):
-        """1 per env currently in the slow lane of two-lane stepping (include/hb.h: hb_get_lanes); all zero when it is off."""
-        a = np.zeros(self.n_env, dtype=np.int32)
-        rc = lib().hb_get_lanes(self._h, _ptr(a))
-        if rc < 0:
-            _check(rc, "hb_get_lanes")
-        return a
 
     def collision_counts(self, want_cycles=False):
         """(work items, portal searches[, narrowphase wave time in 1024-cycle units]) of every env's last step (general collision

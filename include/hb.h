@@ -326,25 +326,35 @@ int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter);
  * the call asked for: the parity tests assert that the kernel they checked is the kernel the benchmark times, and
  * bench.py names the kernel of its roofline object by this string.  The pointer stays valid for the life of the library. */
 const char* hb_last_kernel(const hb_batch* b);
-/* Two envs per wavefront (csrc/hb_step_duo.hip): the lean launches of the 27-dof humanoid's PGS kernel - the plain step
- * API and the rollouts without optional outputs - can run hb_step_duo_kernel / hb_step_duo_q_kernel, bit-identical to the one-env
- * kernels.  mode 1 (default; HB_DUO in the environment at hb_batch_create overrides): where it pays - step calls of batches from 2.5 x
- * the chip's wave slots on (5120 envs on MI355X), rollouts from 2 x; 0: never; 2: always.  Replaces nothing of the reference:
- * mj_step has no such knob (mujoco.h:120). */
-int hb_batch_duo(hb_batch* b, int mode);
+/* Run-time choices between kernels and schedules that give the SAME results (every one of them is held bit-identical to its alternative
+ * by a test): for the tests that compare them and for measurements.  Takes effect from the next launch on.  Nothing of the reference
+ * corresponds: mj_step (mujoco.h:120) has one code path.
+ *   HB_TUNE_DUO            two envs per wavefront for the lean launches of the 27-dof humanoid's PGS kernel (csrc/hb_step_duo.hip; DESIGN.md
+ *                          3.8): 1 (default) where it pays - pipelined step calls of batches from 2.5 x the chip's wave slots on (5120 envs on
+ *                          MI355X), unpipelined ones from 1.5 x (3072), rollouts from 2 x (4096); 0 never; 2 always
+ *   HB_TUNE_LEAN           1 (default): launches without optional inputs / outputs take the lean instantiations of step_body; 0: the full ones
+ *   HB_TUNE_SIZED          1 (default): models with the size signature of the 27-dof humanoid / the reference's robot take the kernels that
+ *                          have those sizes as constants; 0: the generic ones
+ *   HB_TUNE_STAGED         1 (default): models with mesh hulls / height fields step in stages (pose, narrowphase, step kernels: DESIGN.md
+ *                          3.6); 0: everything inside one step kernel
+ *   HB_TUNE_FASTPASS       1 (default): the staged step runs the one-group fast kernel first and the full one for what that defers; 0: full only
+ *   HB_TUNE_NARROW_PRIM    1 (default): a model without mesh geoms takes the narrowphase kernel that has no hull climb in it
+ *   HB_TUNE_SCHEDULE       1 (default): blocks are dispatched heavy-first (hb_order_kernel); 0: in env order
+ *   HB_TUNE_REORDER_PERIOD the heavy-first order is re-sorted every n-th step call (default 4)
+ *   HB_TUNE_POLICY_LEAN    hb_rollout_policy: 1 (default) the LDS-free policy kernel beside the other segments' step kernels when
+ *                          pipelined; 0 never; 2 always
+ * Environment variables the library reads (all others of earlier rounds are gone): HB_DEBUG (name failing HIP calls on stderr), HB_DUO
+ * (HB_TUNE_DUO's value for new batches), HB_BOX_CULL=0 (model tables without the oriented-box cull of portal-search pairs: a test),
+ * and in the diagnostic build (-DHB_STAMPS) HB_STOP_PHASE. */
+enum { HB_TUNE_DUO = 0, HB_TUNE_LEAN, HB_TUNE_SIZED, HB_TUNE_STAGED, HB_TUNE_FASTPASS, HB_TUNE_NARROW_PRIM, HB_TUNE_SCHEDULE, HB_TUNE_REORDER_PERIOD,
+       HB_TUNE_POLICY_LEAN, HB_TUNE_COUNT };
+int hb_batch_tune(hb_batch* b, int knob, int value);
 /* Narrowphase work of the last step of each env, for models that collide through mesh hulls or height fields (the staged step:
  * DESIGN.md 3.6): nwork = work items (a candidate pair that passed the broadphase, or one prism of a height-field pair's sub-grid),
  * nsearch = those of them that needed a portal search (mjc_Convex / mjc_ConvexHField: libccd MPR), kcycles = shader clock cycles / 1024
  * the env's narrowphase wave took (saturating at 255; the cost the heavy-first dispatch of that launch sorts by).  Zeros for other
  * models.  Any pointer may be NULL. */
 int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch, int* kcycles);
-
-/* Two-lane stepping (classic PGS models of dense order <= 28, i.e. the 27-dof humanoid): single-step calls run the
- * SMALL instantiation of the step kernel (31 rows, 12 contacts, three waves per SIMD) on the fast lane; an env whose step needs more
- * is stepped by the full kernel (63 rows, 24 contacts) on a slow lane beside it, until the next rebalance point.  Results are those of
- * the full kernel either way.  lane[e] (nullable) = 1 while env e is in the slow lane; returns the number of such envs (0 for a batch
- * without two-lane stepping; HB_TWO_LANE=0 in the environment at hb_batch_create switches it off), or a negative error. */
-int hb_get_lanes(hb_batch* b, int* lane);
 
 /* Diagnostics of the last step for parity tests (mjData.qacc, efc_force, contact[]; mjdata.h:
  * 362,376,427): enable once, then read after a step.  efc_force is [n_env][nefc_max];

@@ -226,10 +226,16 @@ def test_rollouts_through_the_duo_kernel_and_the_default_choice(hbmod, humanoid_
     # for its rollouts and for step calls from 2.5 x the chip's wave slots on
     ctrl0 = np.zeros((1, m.nu), np.float32)
     d = hbmod.Batch(m, 4096, gpu)
-    d.step(np.repeat(ctrl0, 4096, axis=0)); k_step = d.last_kernel()
+    d.step(np.repeat(ctrl0, 4096, axis=0)); k_unpiped = d.last_kernel()   # one launch per step call: one round of duo waves against two
+    d.pipeline(True)
+    d.step(np.repeat(ctrl0, 4096, axis=0)); k_step = d.last_kernel()      # env segments on their own streams: the benchmark's timed loop
     d.rollout_halton(2); k_roll = d.last_kernel()
     d.close()
     e = hbmod.Batch(m, 8192, gpu)
+    e.pipeline(True)
     e.step(np.repeat(ctrl0, 8192, axis=0)); k_big = e.last_kernel()
     e.close()
-    assert (k_step, k_roll, k_big) == ("hb_step_h27_kernel", "hb_step_duo_q_kernel", DUO), (k_step, k_roll, k_big)
+    f = hbmod.Batch(m, 2048, gpu)
+    f.step(np.repeat(ctrl0, 2048, axis=0)); k_small = f.last_kernel()
+    f.close()
+    assert (k_unpiped, k_step, k_roll, k_big, k_small) == (DUO, "hb_step_h27_kernel", "hb_step_duo_q_kernel", DUO, "hb_step_h27_kernel"), (k_unpiped, k_step, k_roll, k_big, k_small)

@@ -1,6 +1,6 @@
 """The staged step of the general collision path: pose kernel -> narrowphase kernel -> step kernel, with a fast
 first pass of the step kernel and the full kernel behind it for the env-steps the fast one defers.  Every arrangement must give
-what the single fused kernel gives (HB_STAGED=0), which the convex / terrain parity tests pin against the oracle."""
+what the single fused kernel gives (hb_batch_tune: HB_TUNE_STAGED = 0), which the convex / terrain parity tests pin against the oracle."""
 import os
 
 import numpy as np
@@ -14,13 +14,20 @@ TEAM_HBM = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "team_robot.hbm")
 TERRAIN_HBM = os.path.join(ROOT, "humanoid_mujoco_amd", "assets", "humanoid27_hfield.hbm")
 
 
+TUNE = {"HB_STAGED": "staged", "HB_FASTPASS": "fastpass"}
+
+
 def _batch(hbmod, model, n, gpu, **env):
-    """a batch created under the given HB_* switches (read at creation)"""
-    old = {k: os.environ.get(k) for k in env}
+    """a batch with the given run-time choices (include/hb.h: hb_batch_tune); HB_BOX_CULL is the one switch that is baked into the model
+    tables, i.e. read from the environment when the batch is created"""
+    old = {k: os.environ.get(k) for k in env if k not in TUNE}
     try:
         for k, v in env.items():
-            os.environ[k] = str(v)
-        return hbmod.Batch(model, n, gpu)
+            if k not in TUNE:
+                os.environ[k] = str(v)
+        b = hbmod.Batch(model, n, gpu)
+        b.tune(**{TUNE[k]: v for k, v in env.items() if k in TUNE})
+        return b
     finally:
         for k, v in old.items():
             if v is None:

@@ -2,7 +2,7 @@
 """Step-API throughput against the number of pipeline segments, every case in a process of its own (the
 stream -> hardware-queue assignment depends on what the process created before), each case repeated.
 Output: us per step of 4096 envs (segments in use); "segments 1" is hb_batch_pipeline's default (probe).
-Cases: GPU_MAX_HW_QUEUES, HB_PIPE_PRIO (segments on streams of different priorities), two-lane, scheduling knobs.
+Cases: GPU_MAX_HW_QUEUES, the scheduling knobs of hb_batch_tune (TUNE_<knob>=<value> in the child's environment).
 (Rounds 1-2 ran the segments on extra streams BESIDE the batch's own: gpurun_out/r03q/queues.txt, queues2.txt.)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,7 @@ npipe = int(sys.argv[1])
 m = hb.Model.load(os.path.join(%r, "humanoid_mujoco_amd", "assets", "humanoid27.hbm"))
 N, K, W = 4096, 400, 300
 b = hb.Batch(m, N, 0)
+b.tune(**{k[5:].lower(): int(v) for k, v in os.environ.items() if k.startswith("TUNE_")})
 ctrl = b.dev_alloc((K + W) * N * m.nu * 4)
 b.halton_ctrl_dev(K + W, 0, 0, ctrl)
 b.reset(perturb=True)
@@ -27,16 +28,10 @@ b.sync()
 dt = time.perf_counter() - t0
 print("%%.1f(%%d)" %% (1e6 * dt / K, b.segments))
 ''' % (ROOT, ROOT)
-cases = [("default", {}, (1, 2, 3, 4)), ("HB_PIPE_PRIO=1", {"HB_PIPE_PRIO": "1"}, (2, 3, 4)),
-         ("GPU_MAX_HW_QUEUES=8", {"GPU_MAX_HW_QUEUES": "8"}, (2, 3, 4, 5, 6, 8)),
-         ("GPU_MAX_HW_QUEUES=16", {"GPU_MAX_HW_QUEUES": "16"}, (2, 3, 4, 5, 6, 8)),
-         ("GPU_MAX_HW_QUEUES=8 HB_PIPE_PRIO=1", {"GPU_MAX_HW_QUEUES": "8", "HB_PIPE_PRIO": "1"}, (3, 4, 6))]
-cases += [("HB_NO_SCHEDULE=1", {"HB_NO_SCHEDULE": "1"}, (1, 2)), ("HB_REORDER_PERIOD=1", {"HB_REORDER_PERIOD": "1"}, (1,)),
-          ("HB_REORDER_PERIOD=2", {"HB_REORDER_PERIOD": "2"}, (1,)), ("HB_REORDER_PERIOD=8", {"HB_REORDER_PERIOD": "8"}, (1,)),
-          ("HB_REORDER_PERIOD=32", {"HB_REORDER_PERIOD": "32"}, (1,))]
-cases += [("HB_TWO_LANE=1", {"HB_TWO_LANE": "1"}, (0, 2, 3)), ("HB_TWO_LANE=1 GPU_MAX_HW_QUEUES=8", {"HB_TWO_LANE": "1", "GPU_MAX_HW_QUEUES": "8"}, (0, 2, 3)),
-          ("HB_TWO_LANE=1 HB_LANE_WINDOW=16", {"HB_TWO_LANE": "1", "HB_LANE_WINDOW": "16"}, (0, 2, 3)),
-          ("HB_TWO_LANE=1 HB_SLOW_PRIO=0", {"HB_TWO_LANE": "1", "HB_SLOW_PRIO": "0"}, (0, 2, 3))]
+cases = [("default", {}, (1, 2, 3, 4)), ("GPU_MAX_HW_QUEUES=8", {"GPU_MAX_HW_QUEUES": "8"}, (2, 3, 4, 5, 6, 8)),
+         ("GPU_MAX_HW_QUEUES=16", {"GPU_MAX_HW_QUEUES": "16"}, (2, 3, 4, 5, 6, 8))]
+cases += [("TUNE_SCHEDULE=0", {"TUNE_SCHEDULE": "0"}, (1, 2)), ("TUNE_REORDER_PERIOD=1", {"TUNE_REORDER_PERIOD": "1"}, (1,)),
+          ("TUNE_REORDER_PERIOD=8", {"TUNE_REORDER_PERIOD": "8"}, (1,)), ("TUNE_DUO=2", {"TUNE_DUO": "2"}, (0, 1, 2, 3)), ("TUNE_DUO=0", {"TUNE_DUO": "0"}, (0, 1, 3))]
 if len(sys.argv) > 1: cases = [c for c in cases if c[0] in sys.argv[1:]]
 for name, extra, pipes in cases:
     for npipe in pipes:

@@ -16,9 +16,6 @@ timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smok
 echo "== bench" | tee -a $OUT/progress.log
 timeout -k 10 600 python bench.py --steps 1000 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/progress.log
 cat $OUT/bench.json
-echo "== two-lane stepping (opt-in): the same bench line with HB_TWO_LANE=1, and the small kernel's residency sweep" | tee -a $OUT/progress.log
-HB_TWO_LANE=1 HB_DEBUG=1 timeout -k 10 300 python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-rollout --no-newton --no-team > $OUT/bench_two_lane.json 2> $OUT/bench_two_lane.err; echo "two-lane bench rc=$?" | tee -a $OUT/progress.log
-timeout -k 10 200 python tools/gpu_small_kernel_occupancy.py > $OUT/small_kernel_occupancy.txt 2>&1
 echo "== testspeed (C++ host)" | tee -a $OUT/progress.log
 timeout -k 10 300 ./build/hb_testspeed humanoid_mujoco_amd/assets/humanoid27.hbm 1000 4096 > $OUT/testspeed.log 2>&1; echo "testspeed rc=$?" | tee -a $OUT/progress.log
 cat $OUT/testspeed.log
@@ -37,7 +34,7 @@ timeout -k 10 600 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_I
 timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/prof_mfma -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline > $OUT/prof_mfma.log 2>&1; echo "mfma rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_pipeline_sweep.py > $OUT/pipeline_sweep.txt 2>&1; echo "sweep rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_phase_profile.py 4096 > $OUT/phase_profile.txt 2>&1; echo "phase rc=$?" | tee -a $OUT/progress.log
-timeout -k 10 200 python tools/gpu_phase_profile.py 4096 humanoid27_hfield.hbm > $OUT/phase_config5.txt 2>&1; timeout -k 10 200 python tools/gpu_phase_profile.py 4096 team_robot.hbm > $OUT/phase_team.txt 2>&1; HB_STAGED=0 timeout -k 10 200 python tools/gpu_phase_profile.py 4096 team_robot.hbm > $OUT/phase_team_fused.txt 2>&1; timeout -k 10 400 python tools/gpu_pipeline_queues.py default GPU_MAX_HW_QUEUES=8 GPU_MAX_HW_QUEUES=16 > $OUT/pipeline_queues.txt 2>&1; timeout -k 10 900 bash tools/gpu_phase_instructions.sh $OUT/phase_inst > $OUT/phase_instructions.txt 2>&1
+timeout -k 10 200 python tools/gpu_phase_profile.py 4096 humanoid27_hfield.hbm > $OUT/phase_config5.txt 2>&1; timeout -k 10 200 python tools/gpu_phase_profile.py 4096 team_robot.hbm > $OUT/phase_team.txt 2>&1; timeout -k 10 400 python tools/gpu_pipeline_queues.py default GPU_MAX_HW_QUEUES=8 GPU_MAX_HW_QUEUES=16 > $OUT/pipeline_queues.txt 2>&1; timeout -k 10 900 bash tools/gpu_phase_instructions.sh $OUT/phase_inst > $OUT/phase_instructions.txt 2>&1
 timeout -k 10 200 python tools/gpu_parity_report.py > $OUT/parity_report.txt 2>&1; timeout -k 10 200 python tools/gpu_parity_report.py newton > $OUT/parity_report_newton.txt 2>&1; echo "parity rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace_newton -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-rollout --no-pipeline > $OUT/prof_trace_newton.log 2>&1; echo "newton trace rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 300 python tools/gpu_soak.py > $OUT/soak.txt 2>&1; timeout -k 10 300 python tools/gpu_soak_pipelined.py 100000 > $OUT/soak_pipelined.txt 2>&1; timeout -k 10 200 python tools/gpu_config4_physics_only.py > $OUT/config4_physics_only.txt 2>&1; timeout -k 10 300 python tools/gpu_soak.py newton > $OUT/soak_newton.txt 2>&1; timeout -k 10 200 python tools/gpu_vecenv_bench.py > $OUT/vecenv.txt 2>&1; timeout -k 10 200 python tools/gpu_pgs_fit.py > $OUT/pgs_fit.txt 2>&1; timeout -k 10 200 python tools/gpu_config4.py > $OUT/config4.txt 2>&1; timeout -k 10 200 python tools/gpu_config5.py > $OUT/config5.txt 2>&1; timeout -k 10 300 python tools/gpu_team_bench.py > $OUT/team_bench.txt 2>&1; timeout -k 10 300 python tools/gpu_planner_bench.py > $OUT/planner.txt 2>&1; timeout -k 10 300 python tools/gpu_drift_nocontact.py > $OUT/drift_nocontact.txt 2>&1; timeout -k 10 300 python tools/gpu_mpc_demo.py 4096 > $OUT/mpc_demo.txt 2>&1; timeout -k 10 300 python tools/gpu_latency.py > $OUT/latency.txt 2>&1; timeout -k 10 300 python tools/gpu_newton_bench.py > $OUT/newton_bench.txt 2>&1; timeout -k 10 200 python tools/gpu_newton_bench.py --phases > $OUT/newton_phases.txt 2>&1; timeout -k 10 200 python tools/gpu_newton_bench.py --probe > $OUT/newton_sections.txt 2>&1; echo "configs rc=$?" | tee -a $OUT/progress.log

@@ -237,6 +237,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def gather(obj):
+        """every rank's value on rank 0 (a list in rank order); None on the other ranks"""
+        if dist is None:
+            return [obj]
+        out = [None] * world if rank == 0 else None
+        dist.gather_object(obj, out, dst=0)
+        return out
+
     K, W, PRE = args.steps, args.warmup, max(0, args.preroll)
     n_env = args.envs_per_gpu
     lo, hi = shard_range(n_env * world, world, rank)
@@ -245,11 +253,14 @@ def main():
     if args.dry_run:
         if dist is not None:
             dist.barrier()
-        elapsed = reduce_max(1e-3 * (1 + rank))
+        own = 1e-3 * (1 + rank)
+        elapsed = reduce_max(own)
+        ranks = gather({"rank": rank, "elapsed_s": own, "device": "dry-run", "segments": 0, "envs": [lo, hi]})
         if dist is not None:
             dist.barrier()
         if rank == 0:
             print(json.dumps({"metric": "env-steps/sec (whole node), 27-DoF humanoid, 4096 envs/GPU", "dry_run": True, "value": None, "n_gpus": world,
+                              "ranks_seen": dist.get_world_size() if dist is not None else 1, "ranks": ranks,
                               "steps": K, "warmup": W, "max_over_ranks_s": elapsed, "shard_of_last_rank": list(shard_range(n_env * world, world, world - 1))}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -297,16 +308,21 @@ def main():
         batch.step_dev(ctrl + t * stride)
     region_ms = batch.timer_stop()  # HIP events around the whole timed region on the batch's stream (joins the segments); also drains it
     batch.sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_own = elapsed = time.perf_counter() - t0
+    timed_kernel = batch.last_kernel()  # what the library says the timed loop's launches ran (include/hb.h: hb_last_kernel)
     if dist is not None:
         elapsed = reduce_max(elapsed)
         dist.barrier()
+    ranks = gather({"rank": rank, "elapsed_s": elapsed_own, "value": n_env * K / elapsed_own, "device": batch.device_name(), "segments": nseg, "envs": [lo, hi],
+                    "kernel": timed_kernel})
     status = batch.status()
     nc, ne, ni = batch.counts()
 
     # Roofline leg: the dominant kernel as ONE launch per step (all 4096 envs), unpipelined, continuing from
     # the state the timed loop left; HIP events around KR back-to-back launches on the launch stream.
     batch.pipeline(False)
+    # (the library picks the kernel of a step call by the launch's shape: hold it to the one the timed loop ran)
+    batch.tune(duo=2 if timed_kernel == "hb_step_duo_kernel" else 0)
     KR = min(K, 200)
     for t in range(5):
         batch.step_dev(ctrl + (W + min(t, K - 1)) * stride)
@@ -315,6 +331,8 @@ def main():
     for t in range(KR):
         batch.step_dev(ctrl + (W + t) * stride)
     launch_us = 1e3 * batch.timer_stop() / KR
+    roofline_kernel = batch.last_kernel()
+    batch.tune(duo=1)
 
     # Second measurement, reported beside `value`: the same K steps as ONE hb_rollout_dev launch (state
     # resident on chip, each env advancing through its own K steps without a per-step batch barrier) —
@@ -328,6 +346,7 @@ def main():
         batch.rollout_dev(ctrl + W * stride, K)
         batch.sync()
         elapsed_rollout = time.perf_counter() - t1
+        rollout_kernel = batch.last_kernel()
     if dist is not None and elapsed_rollout is not None:
         elapsed_rollout = reduce_max(elapsed_rollout)
         dist.barrier()
@@ -418,6 +437,7 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ranks_seen": dist.get_world_size() if dist is not None else 1, "ranks": ranks,
             "config": {"workload": "configs[1]: %d parallel humanoid envs per GPU, Halton random actions, fp32, PGS<=50 iters tol 1e-8, dt 0.005, one mj_step of every env per "
                                    "hb_step_dev call%s; every env pre-rolled %d untimed steps from the perturbed reset (steady regime: fallen humanoids, ~10 constraint rows), "
                                    "then %d warm-up and %d timed steps"
@@ -426,8 +446,13 @@ def main():
                        "sharding": "env blocks by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                         "kernel": "hb_step_h27_kernel", "avg_launch_us": launch_us, "launches": KR,
-                         "launch_shape": "%d blocks x 64 lanes, one env per block, unpipelined leg" % n_env,
+                         "kernel": roofline_kernel, "avg_launch_us": launch_us, "launches": KR,
+                         "launch_shape": ("%d blocks x 64 lanes, two envs per block, unpipelined leg" % ((n_env + 1) // 2)) if "duo" in roofline_kernel
+                                         else "%d blocks x 64 lanes, one env per block, unpipelined leg" % n_env,
+                         # the launches the TIMED loop makes: the same kernel, cut into env segments on their own streams
+                         "timed_shape": {"kernel": timed_kernel, "segments": nseg, "envs_per_segment": [n_env * (c + 1) // nseg - n_env * c // nseg for c in range(nseg)],
+                                         "ms_per_step": 1e3 * elapsed / K,
+                                         "segment_launch_us_from_profile": (traffic or {}).get("segment_launch_us")},
                          "timed_region_ms_per_step": region_ms / K,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_env,
                          "note": "path is latency/VALU bound, not HBM bound (SURVEY.md §8d); see DESIGN.md"},
@@ -445,12 +470,13 @@ def main():
                 out["roofline"]["profile_avg_launch_us"] = 1e-3 * traffic["avg_launch_ns_kernel_trace"]
         if elapsed_rollout is not None:
             out["rollout"] = {"value": n_env * world * K / elapsed_rollout, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed_rollout / K,
+                              "kernel": rollout_kernel,
                               "what": "same K steps as one hb_rollout_dev launch per GPU (no per-step batch barrier; testspeed.cc shape)"}
         if newton is not None:
             out["newton"] = newton
         if team is not None:
             out["team_robot"] = team
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:  # (one number per box: rank 0, whatever N)
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"].update(probe_libmujoco())
         print(json.dumps(out), flush=True)

@@ -2352,6 +2352,13 @@ int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch, int* kcycles)
 }
 
 const char* hb_last_kernel(const hb_batch* b) { return b ? b->last_kernel : ""; }
+int hb_batch_device_name(const hb_batch* b, char* out, int cap) {
+  if (!b || !out || cap < 2) return HB_EINVAL;
+  hipDeviceProp_t prop;
+  HB_HIP(hipGetDeviceProperties(&prop, b->device));
+  snprintf(out, (size_t)cap, "%s (%s, %d CUs) #%d", prop.name, prop.gcnArchName, prop.multiProcessorCount, b->device);
+  return HB_OK;
+}
 int hb_batch_tune(hb_batch* b, int knob, int value) {
   if (!b || knob < 0 || knob >= HB_TUNE_COUNT || value < 0) return HB_EINVAL;
   if (knob == HB_TUNE_DUO && value > 2) return HB_EINVAL;

@@ -1925,6 +1925,7 @@ static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int sol
 hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, int lds_floats, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   const size_t shmem = (size_t)lds_floats * sizeof(float);
   if (variant == 0 || !P.stage.result) return launch_step_kernel(M_dev, variant, solver, nv, shmem, P, nsteps, stream);
+  const char* fast_name = nullptr;  // (a staged step is named after its fast-pass kernel: the one that steps almost every env)
   for (int t = 0; t < nsteps; t++) {
     BatchPtrs Q = P;
     Q.t0 = P.t0 + t;
@@ -1941,12 +1942,14 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
       else HB_STEP_LAUNCH(hb_step_gen_fast_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, Q, 1);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
+      fast_name = g_last_step_kernel;
       Q.stage.rerun = 1;
     } else if (variant == 3 && Q.stage.dm_fast) {
       // PGS: the one-group kernel (63 rows, 24 contacts, two waves per SIMD) first; the kPgsNefcMax-row kernel then steps what it defers
       HB_STEP_LAUNCH(hb_step_gen_fast1_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
+      fast_name = g_last_step_kernel;
       Q.stage.rerun = 1;
     } else if (variant == 2 && Q.stage.dm_fast) {
       // most env-steps fit the one-group Newton instantiation (two waves per SIMD); the four-group kernel then steps the rest
@@ -1956,6 +1959,7 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
       else HB_STEP_LAUNCH(hb_step_newton_gen28_kernel, dim3(P.nblk), dim3(kGroup), (size_t)Q.stage.fast_lds, stream, Q.stage.dm_fast, Q, 1);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
+      fast_name = g_last_step_kernel;
       Q.stage.rerun = 1;
     }
     e = launch_step_kernel(M_dev, variant, solver, nv, shmem, Q, 1, stream);
@@ -1967,6 +1971,7 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
       if (e != hipSuccess) return e;
     }
   }
+  if (fast_name) g_last_step_kernel = fast_name;
   return hipSuccess;
 }
 hipError_t set_step_lds_limit(int bytes) {

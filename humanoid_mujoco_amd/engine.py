@@ -148,6 +148,7 @@ def lib():
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
     L.hb_last_kernel.argtypes = [vp]; L.hb_last_kernel.restype = ctypes.c_char_p
     L.hb_batch_tune.argtypes = [vp, ci, ci]
+    L.hb_batch_device_name.argtypes = [vp, cp, ci]
     L.hb_get_collision_counts.argtypes = [vp, vp, vp, vp]
     L.hb_batch_segments.argtypes = [vp]
     L.hb_diag_enable.argtypes = [vp, ci]
@@ -430,6 +431,11 @@ class Batch:
     def duo(self, mode=1):
         """two envs per wave for the lean launches of the 27-dof humanoid's PGS kernel: 0 never, 1 where it pays (default), 2 always"""
         self.tune(duo=mode)
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        _check(lib().hb_batch_device_name(self._h, buf, 256), "hb_batch_device_name")
+        return buf.value.decode()
 
     def last_kernel(self):
         """name of the step kernel the batch's last step / rollout / forward launch ran (include/hb.h: hb_last_kernel)"""

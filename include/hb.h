@@ -326,6 +326,9 @@ int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter);
  * the call asked for: the parity tests assert that the kernel they checked is the kernel the benchmark times, and
  * bench.py names the kernel of its roofline object by this string.  The pointer stays valid for the life of the library. */
 const char* hb_last_kernel(const hb_batch* b);
+/* "<device name> (<gfx arch>, <n> CUs) #<index>" of the GPU the batch lives on: what every rank of a multi-GPU bench.py run reports about
+ * itself (the reference's testspeed.cc prints its thread count: sample/testspeed.cc:203-210). */
+int hb_batch_device_name(const hb_batch* b, char* out, int cap);
 /* Run-time choices between kernels and schedules that give the SAME results (every one of them is held bit-identical to its alternative
  * by a test): for the tests that compare them and for measurements.  Takes effect from the next launch on.  Nothing of the reference
  * corresponds: mj_step (mujoco.h:120) has one code path.

@@ -1,11 +1,8 @@
 """Two envs per wave (hb_step_duo_kernel, csrc/hb_step_duo.hip): the kernel the plain step API - and with it bench.py's timed loop - runs
 for the 27-dof humanoid with the PGS solver.
 
-The golden parity test of tests/test_gpu_parity.py enables the diagnostic read-outs, and a launch with any optional output takes the
-full one-env kernel (hb_step_kernel).  Here the SAME 128 golden states go through the plain step, so that what is compared with the
-fp64 oracle's fixture (oracle/mjstep_oracle.c via tools/make_golden.py; one-step tolerances as stated in tests/test_gpu_parity.py) is
-the timed kernel itself - asserted by name through hb_last_kernel - and the duo kernel is held bit-identical to the one-env kernels on
-every path it has: two envs packed at lanes 0 / 32, a heavy env packed in front of a light one, one env at a time (more than 12
+tests/test_gpu_timed_kernels.py puts the 128 golden states of the fp64 oracle through it (and through the one-env kernel), by name.
+Here the duo kernel is held bit-identical to the one-env kernels on every path it has: two envs packed at lanes 0 / 32, a heavy env packed in front of a light one, one env at a time (more than 12
 contacts, rows beyond the packed capacity), an odd env count, the heavy-first order, pipelined segments, the reset paths of mj_check*.
 """
 import os
@@ -26,35 +23,6 @@ def golden():
 
 def pack_state(g, idx):
     return np.concatenate([g["time"][idx, None], g["qpos"][idx], g["qvel"][idx], g["warm"][idx]], axis=1)
-
-
-def test_golden_states_through_the_timed_kernel(hbmod, humanoid_model, gpu, golden):
-    g = golden
-    n = len(g["env"])
-    for order in (np.arange(n), np.arange(n)[::-1], np.random.default_rng(0).permutation(n)):  # different partners in the wave
-        b = hbmod.Batch(humanoid_model, n, gpu)
-        b.duo(2)  # (by default a batch this small takes the one-env kernel: include/hb.h, hb_batch_duo)
-        b.set_state(hbmod.STATE_INTEGRATION, pack_state(g, order))
-        b.step(g["ctrl"][order].astype(np.float32))
-        assert b.last_kernel() == DUO
-        q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
-        ncon, nefc, niter = b.counts()
-        assert not b.status().any()
-        assert np.array_equal(ncon, g["ncon"][order]) and np.array_equal(nefc, g["nefc"][order])
-        # PGS sweep counts: the fp64 oracle's wherever its convergence test is not within rounding of the threshold (fp32 sweeps that stop
-        # one sweep earlier or later there are the one-env kernel's too: the next test holds the two kernels bit-identical)
-        off = niter != g["niter"][order]
-        assert off.sum() <= 2 and np.abs(niter - g["niter"][order]).max() <= 1, (off.sum(), niter[off], g["niter"][order][off])
-        dq = np.abs(q - g["qpos1"][order]) / np.maximum(1.0, np.abs(g["qpos1"][order]))
-        assert dq.max() <= 4e-5, dq.max()
-        vs = np.maximum(1.0, np.abs(g["qvel1"][order]).max(axis=1, keepdims=True))
-        assert (np.abs(v - g["qvel1"][order]) / vs).max() <= 4e-4
-        # qacc_warmstart of the new state is the step's qacc
-        a = b.get_state(hbmod.STATE_WARMSTART).astype(np.float64)
-        as_ = np.maximum(1.0, np.abs(g["qacc"][order]).max(axis=1, keepdims=True))
-        assert (np.abs(a - g["qacc"][order]) / as_).max() <= 4e-4
-        assert np.allclose(b.time, g["time"][order] + 0.005, atol=1e-5)
-        b.close()
 
 
 def _reference_step(hbmod, m, gpu, state, ctrl):

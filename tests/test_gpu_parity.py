@@ -624,6 +624,7 @@ def test_heightfield_terrain_humanoid_config5(hbmod, gpu):
     b = hbmod.Batch(m, n, gpu)
     b.set_state(hbmod.STATE_INTEGRATION, np.array(states))
     b.step(np.array(ctrls, dtype=np.float32))
+    assert b.last_kernel() == "hb_step_gen_fast_h27_kernel"  # the staged step's sized fast kernel: what the configs[4] measurement times
     q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
     nc, ne, ni = b.counts()
     assert not b.status().any()

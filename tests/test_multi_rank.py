@@ -97,6 +97,10 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 7 and out["warmup"] == 3 and out["dry_run"] is True
     assert out["max_over_ranks_s"] == 2e-3                  # MAX over ranks of (1 + rank) ms
     assert out["shard_of_last_rank"] == [4096, 8192]        # env blocks by rank
+    # what the 8-GPU record needs of every rank: how many ranks the process group really had, and per rank its own time, device and env block
+    assert out["ranks_seen"] == 2 and [r["rank"] for r in out["ranks"]] == [0, 1]
+    assert [r["elapsed_s"] for r in out["ranks"]] == [1e-3, 2e-3] and [r["envs"] for r in out["ranks"]] == [[0, 4096], [4096, 8192]]
+    assert all("device" in r and "segments" in r for r in out["ranks"])
 
 
 def test_bench_under_a_launcher_keeps_the_launchers_world():

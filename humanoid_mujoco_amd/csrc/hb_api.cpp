@@ -587,6 +587,7 @@ struct hb_batch {
   hipStream_t stream = nullptr;
   float *d_state = nullptr, *d_ctrl = nullptr, *d_xfrc = nullptr, *d_diag_qacc = nullptr, *d_diag_force = nullptr, *d_diag_contact = nullptr;
   float *d_obs = nullptr, *d_reward = nullptr;
+  float* d_term_obs = nullptr;  // [n_env][nobs] observations of the states episodes ended in (hb_env_terminal_obs), null until asked for
   uint8_t *d_term = nullptr, *d_trunc = nullptr, *d_mask = nullptr;
   int *d_status = nullptr, *d_counts = nullptr;
   size_t ctrl_cap = 0;  // floats
@@ -1055,7 +1056,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_dr) HB_IGN(hipFree(b->d_dr));
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
-  void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nsearch, b->stage.nwork, b->stage.result, b->stage.defer, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_mask,
+  void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nsearch, b->stage.nwork, b->stage.result, b->stage.defer, b->d_term_obs, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_mask,
                   b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_order2, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
@@ -1886,7 +1887,7 @@ static int env_eval(hb_batch* b, bool allow_reset, bool observe, const uint8_t* 
   EnvRandState S = b->rs;
   if (!b->rand_on) memset(&S, 0, sizeof S);
   HB_HIP(launch_env(b->D.dm, cfg, b->env_rand, S, b->d_state, b->d_qfrc, b->d_counts, b->d_prev, b->d_latest, src, b->d_episode, b->d_status, d_obs, d_reward,
-                    d_term, d_trunc, mask, observe ? 1 : 0, b->dom_rand, b->d_dr, b->dr_stride, b->n_env, b->env_offset, main_stream(b)));
+                    d_term, d_trunc, mask, observe ? 1 : 0, b->dom_rand, b->d_dr, b->dr_stride, b->n_env, b->env_offset, main_stream(b), observe ? b->d_term_obs : nullptr));
   return HB_OK;
 }
 
@@ -2185,6 +2186,22 @@ static int env_step_host(hb_batch* b, const float* action, int n_substeps, float
     HB_HIP(hipMemcpyAsync(truncated, b->d_trunc, n, hipMemcpyDeviceToHost, main_stream(b)));
   }
   if (wait) HB_HIP(hipStreamSynchronize(main_stream(b)));
+  return HB_OK;
+}
+int hb_env_terminal_obs(hb_batch* b, float* terminal_obs) {
+  if (!b) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipSetDevice(b->device));
+  const size_t bytes = (size_t)b->n_env * b->D.dm.nobs * sizeof(float);
+  if (!b->d_term_obs) {  // first call: from the next hb_env_step on the env kernel records them
+    if (hipMalloc((void**)&b->d_term_obs, bytes) != hipSuccess) return HB_ENOMEM;
+    HB_HIP(hipMemsetAsync(b->d_term_obs, 0, bytes, main_stream(b)));
+  }
+  if (terminal_obs) {
+    HB_HIP(hipMemcpyAsync(terminal_obs, b->d_term_obs, bytes, hipMemcpyDeviceToHost, main_stream(b)));
+    HB_HIP(hipStreamSynchronize(main_stream(b)));
+  }
   return HB_OK;
 }
 int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated) {

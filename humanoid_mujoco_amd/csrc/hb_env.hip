@@ -465,7 +465,7 @@ __device__ __forceinline__ float env_lane_sum(float x) {
 }
 __global__ __launch_bounds__(256) void hb_env_kernel(const DevModel M, const EnvConfig cfg, const EnvRand R, const EnvRandState S, float* state, const float* qfrc, const int* counts,
                               float* prev, float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated,
-                              uint8_t* truncated, const uint8_t* mask, int observe, const DomainRand D, float* dr, int dr_stride, int n_env, int env_offset) {
+                              uint8_t* truncated, const uint8_t* mask, int observe, const DomainRand D, float* dr, int dr_stride, int n_env, int env_offset, float* term_obs) {
   extern __shared__ float sh_state[];
   const int grp = threadIdx.x / kEnvLanes, l = threadIdx.x % kEnvLanes;
   const int e = blockIdx.x * (256 / kEnvLanes) + grp;
@@ -553,6 +553,14 @@ __global__ __launch_bounds__(256) void hb_env_kernel(const DevModel M, const Env
   }
   const bool rand_on = S.k_obs != nullptr;
   int ep = active ? episode[e] : 0;
+  // the observation of the state an episode ENDS in, before the env is reset in place: what stable-baselines3's VecEnv hands the learner as
+  // infos[i]["terminal_observation"] (DummyVecEnv.step_wait; SAC / PPO bootstrap from it when the episode was truncated) - the same sensor
+  // model, noise and delays as any other observation of that episode (CPUEnv.step returns self._get_obs() before anything resets)
+  if (reset && term_obs) {
+    float* to = term_obs + (size_t)e * M.nobs;
+    if (rand_on && observe) envrand_observe(M, R, S, e, env_offset + e, ep, ls, to, l, kEnvLanes);
+    else compute_obs(M, ls, to, l, kEnvLanes);
+  }
   __syncthreads();  // (every lane has read the old state and the old episode number)
   if (reset) {
     // CPUEnv.reset for this env; the perturbation index advances with the episode count
@@ -903,11 +911,11 @@ hipError_t launch_action(const float* action, float* prev, float* latest, float*
 }
 hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, const EnvRand& R, const EnvRandState& S, float* state, const float* qfrc, const int* counts, float* prev,
                       float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
-                      const uint8_t* mask, int observe, const DomainRand& D, float* dr, int dr_stride, int n_env, int env_offset, hipStream_t stream) {
+                      const uint8_t* mask, int observe, const DomainRand& D, float* dr, int dr_stride, int n_env, int env_offset, hipStream_t stream, float* term_obs) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   const int per_block = 256 / kEnvLanes;
   hipLaunchKernelGGL(hb_env_kernel, dim3((n_env + per_block - 1) / per_block), dim3(256), (size_t)per_block * ((M.nstate + 3) & ~3) * sizeof(float), stream, M, cfg, R, S, state, qfrc, counts, prev, latest, qpos_src, episode, status, obs,
-                     reward, terminated, truncated, mask, observe, D, dr, dr_stride, n_env, env_offset);
+                     reward, terminated, truncated, mask, observe, D, dr, dr_stride, n_env, env_offset, term_obs);
   return hipGetLastError();
 }
 hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset,

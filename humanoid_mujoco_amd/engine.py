@@ -148,6 +148,7 @@ def lib():
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
     L.hb_last_kernel.argtypes = [vp]; L.hb_last_kernel.restype = ctypes.c_char_p
     L.hb_batch_tune.argtypes = [vp, ci, ci]
+    L.hb_env_terminal_obs.argtypes = [vp, vp]
     L.hb_batch_device_name.argtypes = [vp, cp, ci]
     L.hb_get_collision_counts.argtypes = [vp, vp, vp, vp]
     L.hb_batch_segments.argtypes = [vp]
@@ -711,6 +712,16 @@ class Batch:
         if not copy:
             return pin["o"], pin["r"], pin["te"].view(bool), pin["tr"].view(bool)
         return pin["o"].copy(), pin["r"].copy(), pin["te"].astype(bool), pin["tr"].astype(bool)
+
+    def env_terminal_obs(self, fetch=True):
+        """[n_env, nobs] observations of the states episodes ended in (include/hb.h: hb_env_terminal_obs); fetch=False only switches the
+        recording on"""
+        if not fetch:
+            _check(lib().hb_env_terminal_obs(self._h, None), "hb_env_terminal_obs")
+            return None
+        out = np.zeros((self.n_env, self.model.nobs), dtype=np.float32)
+        _check(lib().hb_env_terminal_obs(self._h, _ptr(out)), "hb_env_terminal_obs")
+        return out
 
     def env_step_dev(self, action_ptr, obs_ptr, reward_ptr, terminated_ptr, truncated_ptr, n_substeps=1):
         """hb_env_step_dev: device pointers (e.g. torch tensors' data_ptr()), asynchronous on the batch's stream: a policy on

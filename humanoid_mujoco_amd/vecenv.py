@@ -1,14 +1,51 @@
-"""VecEnv-shaped adapter over the env entry points of libhb.so.
+"""stable-baselines3 VecEnv contract over the env entry points of libhb.so.
 
-Replaces the stack ``DummyVecEnv([CPUEnv, ...])`` the reference trains and benchmarks with
-(rl/train.py:123-136, simulation/benchmark.py:37-53, env contract simulation/cpu_env.py:374-416,676-693):
-``reset() -> obs[N, nobs]`` and ``step(actions[N, nu]) -> (obs, reward[N], terminated[N], truncated[N], infos)``
-with finished envs reset in place (SB3 VecEnv semantics) and ``set_attr("randomization_factor", x)``
-(rl/randomization_adaptation_callback.py:53-54).  All arithmetic is in the HIP kernels.
+Replaces the stack ``DummyVecEnv([CPUEnv, ...])`` the reference trains and benchmarks with (rl/train.py:123-136,169-232,
+simulation/benchmark.py:37-53; env contract simulation/cpu_env.py:374-416,676-693).  What SB3's learners and callbacks use of a VecEnv:
+  ``reset() -> obs[N, nobs]``
+  ``step_async(actions)``, ``step_wait() -> (obs, rewards, dones, infos)`` and ``step(actions)`` = the two in a row, finished envs reset
+      in place; ``infos`` is a list of N dicts, and for an env that finished this step
+          infos[i]["terminal_observation"]  the observation of the state the episode ended in (DummyVecEnv.step_wait; SAC / PPO bootstrap
+                                            from it),
+          infos[i]["TimeLimit.truncated"]   = truncated and not terminated (the learner bootstraps only then),
+          infos[i]["is_success"]            (cpu_env.py:688-689: the env's `truncated` - in standupReward that IS success);
+  ``num_envs``, ``observation_space`` / ``action_space`` (Box-like: low, high, shape, dtype, sample(), contains()), ``get_attr``,
+  ``set_attr`` (rl/randomization_adaptation_callback.py:53-54 sets "randomization_factor"), ``env_method``, ``seed``, ``env_is_wrapped``,
+  ``close``.
+``step_arrays(actions) -> (obs, reward, terminated, truncated, infos)`` is the array form (gymnasium's vector-env tuple, infos a dict of
+arrays) for callers that do not want N dicts per step; ``step_torch`` keeps everything on the GPU.  All arithmetic is in the HIP kernels.
 """
 import numpy as np
 
 from .engine import WARN_BADQACC, WARN_BADQPOS, WARN_BADQVEL, WARN_CNSTRFULL, WARN_CONTACTFULL, Batch, Model
+
+
+class Box:
+    """what SB3 reads of a gymnasium.spaces.Box (gymnasium is not a dependency of this package): cpu_env.py:56-63"""
+
+    def __init__(self, low, high, shape, dtype=np.float32, seed=0):
+        self.low = np.full(shape, low, dtype=dtype)
+        self.high = np.full(shape, high, dtype=dtype)
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
+        self._rng = np.random.default_rng(seed)
+
+    def sample(self):
+        return self._rng.uniform(self.low, self.high).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    def seed(self, seed=None):
+        self._rng = np.random.default_rng(seed)
+        return [seed]
+
+    def __repr__(self):
+        return "Box(%g, %g, %r, %s)" % (float(self.low.flat[0]), float(self.high.flat[0]), self.shape, self.dtype.name)
+
+
+_NO_INFO = {}  # (shared by the envs that did not finish an episode this step: SB3 copies an info dict before it adds to one)
 
 
 class VecEnv:
@@ -48,6 +85,11 @@ class VecEnv:
         self.action_shape = (self.model.nu,)
         self.observation_shape = (self.model.nobs,)
         self.action_low, self.action_high = -1.0, 1.0
+        self.action_space = Box(-1.0, 1.0, self.action_shape, seed=seed)
+        self.observation_space = Box(-10.0, 10.0, self.observation_shape, seed=seed)
+        self.seed_value = int(seed)
+        self.render_mode = None
+        self.batch.env_terminal_obs(fetch=False)  # the env kernel records the observation an episode ends in (hb_env_terminal_obs)
 
     @property
     def randomization_factor(self):
@@ -61,7 +103,16 @@ class VecEnv:
         self.domain.factor = float(self.cfg.reset_perturb)
         self.batch.env_domain_randomize(self.domain if self.domain.factor > 0 else None)
 
-    def set_attr(self, name, value):
+    ATTRS = ("randomization_factor", "num_envs", "n_substeps", "reward_kind", "max_time", "seed_value", "render_mode")
+
+    def get_attr(self, name, indices=None):
+        """VecEnv.get_attr: the attribute of every (selected) env - all envs of a batch share their parameters"""
+        if name not in self.ATTRS:
+            raise AttributeError(name)
+        v = getattr(self.cfg, name) if name in ("reward_kind", "max_time") else getattr(self, name)
+        return [v] * len(self._indices(indices))
+
+    def set_attr(self, name, value, indices=None):
         if name != "randomization_factor":
             raise AttributeError(name)
         self.cfg.reset_perturb = float(np.clip(value, 0.0, 1.0))
@@ -70,6 +121,33 @@ class VecEnv:
             self._apply_realism()
         if self.domain is not None:
             self._apply_domain()
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        """VecEnv.env_method: the per-env methods SB3's tooling calls on CPUEnv: its reward / termination functions are the batch's"""
+        if method_name == "get_wrapper_attr":
+            return self.get_attr(args[0], indices)
+        raise AttributeError("env method %r: the envs of a batch live on the GPU (hb_env_*), not in Python objects" % method_name)
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * len(self._indices(indices))
+
+    def seed(self, seed=None):
+        """VecEnv.seed: env i is seeded seed + i in SB3; here the counter-based generators take (seed, global env index) themselves"""
+        self.seed_value = int(0 if seed is None else seed)
+        for r in (self.realism, self.domain):
+            if r is not None:
+                r.seed = self.seed_value
+        if self.realism is not None:
+            self._apply_realism()
+        if self.domain is not None:
+            self._apply_domain()
+        self.action_space.seed(self.seed_value)
+        return [self.seed_value + i for i in range(self.num_envs)]
+
+    def _indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        return [indices] if isinstance(indices, int) else list(indices)
 
     def reset(self):
         return self.batch.env_reset()
@@ -80,14 +158,30 @@ class VecEnv:
         self._pending = True
 
     def step_wait(self):
-        """VecEnv.step_wait: the results of the step_async before it"""
+        """VecEnv.step_wait: (obs, rewards, dones, infos) of the step_async before it, infos a list of dicts (module docstring)"""
         assert getattr(self, "_pending", False), "step_wait without step_async"
         self._pending = False
         self.batch.sync()
-        return self._finish(*self.batch.env_step_result(getattr(self, "copy_outputs", True)))
+        return self._sb3(*self._finish(*self.batch.env_step_result(getattr(self, "copy_outputs", True))))
 
     def step(self, actions):
+        """VecEnv.step = step_async + step_wait"""
+        self.step_async(actions)
+        return self.step_wait()
+
+    def step_arrays(self, actions):
+        """the same step as arrays: (obs, reward, terminated, truncated, infos) with infos a dict of arrays"""
         return self._finish(*self.batch.env_step(actions, self.n_substeps, copy=getattr(self, "copy_outputs", True)))
+
+    def _sb3(self, obs, rew, term, trunc, arr):
+        done = arr["done"]
+        infos = [_NO_INFO] * self.num_envs
+        if done.any():
+            tobs = self.batch.env_terminal_obs()  # one more transfer, only on the steps an episode ends
+            for i in np.flatnonzero(done):
+                infos[i] = {"terminal_observation": tobs[i].copy(), "TimeLimit.truncated": bool(trunc[i] and not term[i]), "is_success": bool(trunc[i]),
+                            "warnings": int(arr["warnings"][i])}
+        return obs, rew, done, infos
 
     def _finish(self, obs, rew, term, trunc):
         done = term | trunc

@@ -485,6 +485,14 @@ int hb_env_reset(hb_batch* b, float* obs);
  * (uint8_t*)(reward + n_env), truncated == terminated + n_env; page-locked for a DMA transfer: hb_host_alloc) gets them in ONE
  * device-to-host transfer, anyone else in four. */
 int hb_env_step(hb_batch* b, const float* action, int n_substeps, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated);
+/* The observations of the states episodes ENDED in.  hb_env_step resets a finished env in place and reports the first observation of its
+ * new episode; stable-baselines3's vectorised envs (the reference trains through DummyVecEnv: rl/train.py:134-136) keep the last
+ * observation of the old one as infos[i]["terminal_observation"], and its off-policy learners bootstrap from it when the episode was
+ * truncated - which in the reference's standupReward is the SUCCESS case (reward_functions.py:371-372, cpu_env.py:686-693).  The first call
+ * (terminal_obs may be NULL) switches the recording on; from the next hb_env_step on, row e of the [n_env][nobs] table is rewritten
+ * whenever env e finishes an episode (same sensor model, noise and delays as that episode's other observations) and keeps its value
+ * otherwise.  With a non-NULL pointer the table is copied to the host (after the steps enqueued so far). */
+int hb_env_terminal_obs(hb_batch* b, float* terminal_obs);
 /* The same, enqueued only: VecEnv.step_async of the reference's training loop (stable-baselines3 VecEnv: step_async() then
  * step_wait(); rl/train.py:134-136 builds a DummyVecEnv whose step() is that pair).  The action buffer must stay untouched and the
  * output buffers unread until hb_batch_sync(b) returns (= step_wait); page-locked buffers (hb_host_alloc) make the copies truly

@@ -36,7 +36,7 @@ def test_env_step_matches_reference_reward(hbmod, humanoid_model, gpu, solver):
     for t in range(60):
         act = rng.uniform(-1.2, 1.2, size=(n, m.nu)).astype(np.float32)
         st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
-        obs, rew, term, trunc, info = env.step(act)
+        obs, rew, term, trunc, info = env.step_arrays(act)
         st1 = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
         assert not term.any()
         for e in range(n):
@@ -65,10 +65,10 @@ def test_time_limit_terminates_and_auto_resets(hbmod, humanoid_model, gpu):
     env.reset()
     zeros = np.zeros((n, m.nu), np.float32)
     for t in range(4):
-        obs, rew, term, trunc, info = env.step(zeros)
+        obs, rew, term, trunc, info = env.step_arrays(zeros)
         assert not term.any() and not trunc.any()
     q_before = env.batch.qpos
-    obs, rew, term, trunc, info = env.step(zeros)
+    obs, rew, term, trunc, info = env.step_arrays(zeros)
     assert term.all() and np.allclose(rew, -100.0)
     # reset in place: time back to zero, a fresh perturbed start, and the returned obs belongs to the new episode
     assert np.allclose(env.batch.time, 0.0)
@@ -79,7 +79,7 @@ def test_time_limit_terminates_and_auto_resets(hbmod, humanoid_model, gpu):
     # a second episode starts from a different perturbation than the first
     first = env.batch.qpos.copy()
     for t in range(5):
-        obs, rew, term, trunc, info = env.step(zeros)
+        obs, rew, term, trunc, info = env.step_arrays(zeros)
     assert term.all()
     assert not np.allclose(env.batch.qpos, first)
 
@@ -89,7 +89,7 @@ def test_success_truncation_and_randomization_factor(hbmod, humanoid_model, gpu)
     env = hbmod.VecEnv(m, 4, gpu, randomization_factor=0.0, max_time=0.0)
     env.reset()
     assert np.allclose(env.batch.qpos, m.array("qpos0").astype(np.float32)[None])  # no perturbation at factor 0
-    obs, rew, term, trunc, info = env.step(np.zeros((4, m.nu), np.float32))
+    obs, rew, term, trunc, info = env.step_arrays(np.zeros((4, m.nu), np.float32))
     assert trunc.all() and info["is_success"].all()  # standing upright above target height == success (reward_functions.py:371-372)
     env.set_attr("randomization_factor", 0.5)
     env.reset()
@@ -115,7 +115,7 @@ def test_device_resident_step_matches_host_step(hbmod, humanoid_model, gpu):
     rng = np.random.default_rng(0)
     for t in range(40):
         act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
-        o1, r1, te1, tr1, _ = a.step(act)
+        o1, r1, te1, tr1, _ = a.step_arrays(act)
         o2, r2, te2, tr2 = b.step_torch(torch.from_numpy(act).cuda())
         assert np.array_equal(o1, o2.cpu().numpy()) and np.array_equal(r1, r2.cpu().numpy())
         assert np.array_equal(te1, te2.cpu().numpy()) and np.array_equal(tr1, tr2.cpu().numpy())
@@ -137,8 +137,8 @@ def test_step_outputs_as_views_and_through_scattered_buffers(hbmod, humanoid_mod
     flags = 0
     for t in range(60):
         act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
-        o1, r1, te1, tr1, _ = envs[0].step(act)
-        o2, r2, te2, tr2, _ = envs[1].step(act)
+        o1, r1, te1, tr1, _ = envs[0].step_arrays(act)
+        o2, r2, te2, tr2, _ = envs[1].step_arrays(act)
         assert L.hb_env_step(envs[2].batch._h, act.ctypes.data_as(ctypes.c_void_p), 1, o3.ctypes.data_as(ctypes.c_void_p), r3.ctypes.data_as(ctypes.c_void_p),
                              te3.ctypes.data_as(ctypes.c_void_p), tr3.ctypes.data_as(ctypes.c_void_p)) == 0
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(te1, te2) and np.array_equal(tr1, tr2)
@@ -161,12 +161,12 @@ def test_step_async_then_step_wait_equals_step(hbmod, humanoid_model, gpu):
     rng = np.random.default_rng(2)
     for t in range(70):
         act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
-        o1, r1, te1, tr1, i1 = a.step(act)
+        o1, r1, te1, tr1, i1 = a.step_arrays(act)
         b.step_async(act)
         _ = float(np.linalg.norm(rng.normal(size=(64, 64)) @ rng.normal(size=(64, 64))))  # the host is free in between
-        o2, r2, te2, tr2, i2 = b.step_wait()
-        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(te1, te2) and np.array_equal(tr1, tr2)
-        assert np.array_equal(i1["done"], i2["done"])
+        o2, r2, d2, i2 = b.step_wait()  # (stable-baselines3's tuple: obs, rewards, dones, infos - a list of dicts)
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(te1 | tr1, d2)
+        assert np.array_equal(i1["done"], d2) and [("terminal_observation" in x) for x in i2] == list(d2)
     with pytest.raises(AssertionError):
         b.step_wait()
     a.close(); b.close()
@@ -180,12 +180,12 @@ def test_vecenv_reports_warning_bits(hbmod, humanoid_model, gpu):
     env.warning_period = 1  # read the bits back at every step (the default refreshes them every 16th: they are sticky)
     env.reset()
     act = np.zeros((n, humanoid_model.nu), np.float32)
-    _, _, _, _, info = env.step(act)
+    _, _, _, _, info = env.step_arrays(act)
     assert info["warnings"].shape == (n,) and not info["warnings"].any() and not info["overflow"].any()
     st = env.batch.get_state(hbmod.STATE_INTEGRATION)
     st[4, 3] = np.nan
     env.batch.set_state(hbmod.STATE_INTEGRATION, st)
-    obs, rew, _, _, info = env.step(act)
+    obs, rew, _, _, info = env.step_arrays(act)
     assert info["warnings"][4] & hbmod.WARN_BADQPOS and not np.delete(info["warnings"], 4).any()
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
     assert env.warning_counts() == {"contact_full": 0, "constraint_full": 0, "bad_qpos": 1, "bad_qvel": 0, "bad_qacc": 0}

@@ -38,7 +38,7 @@ def test_noise_and_delay_lines_match_numpy(hbmod, humanoid_model, gpu):
     rng = np.random.default_rng(0)
     for t in range(T):
         act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
-        obs, rew, term, trunc, info = env.step(act)
+        obs, rew, term, trunc, info = env.step_arrays(act)
         st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
         for e in range(n):
             ref = refs[e].observe(st[e, 1:1 + m.nq], st[e, 1 + m.nq:1 + m.nq + m.nv])
@@ -56,8 +56,8 @@ def test_action_delay_is_a_pure_shift(hbmod, humanoid_model, gpu):
     rng = np.random.default_rng(1)
     tape = rng.uniform(-1, 1, size=(T, n, m.nu)).astype(np.float32)
     for t in range(T):
-        env.step(tape[t])
-        plain.step(tape[t - d] if t >= d else np.zeros((n, m.nu), np.float32))
+        env.step_arrays(tape[t])
+        plain.step_arrays(tape[t - d] if t >= d else np.zeros((n, m.nu), np.float32))
         assert np.array_equal(env.batch.get_state(hbmod.STATE_INTEGRATION), plain.batch.get_state(hbmod.STATE_INTEGRATION)), t
 
 
@@ -69,7 +69,7 @@ def test_noise_statistics_and_frozen_mode(hbmod, humanoid_model, gpu):
     env.reset()
     errs = []
     for t in range(T):
-        obs, *_ = env.step(zeros)
+        obs, *_ = env.step_arrays(zeros)
         true, *_ = env.batch.obs(want_reward=False)
         errs.append(obs - true)
     errs = np.array(errs)  # [T, n, 48]
@@ -82,8 +82,8 @@ def test_noise_statistics_and_frozen_mode(hbmod, humanoid_model, gpu):
     env2, _ = make_env(hbmod, m, 16, gpu, seed=5, min_delay=0.0, max_delay=0.0, frozen_noise=1, imu_noise=0.0)
     env2.reset()
     z16 = np.zeros((16, m.nu), np.float32)
-    e1 = env2.step(z16)[0] - env2.batch.obs(want_reward=False)[0]
-    e2 = env2.step(z16)[0] - env2.batch.obs(want_reward=False)[0]
+    e1 = env2.step_arrays(z16)[0] - env2.batch.obs(want_reward=False)[0]
+    e2 = env2.step_arrays(z16)[0] - env2.batch.obs(want_reward=False)[0]
     assert np.abs(e1[:, :45]).max() > 1e-3 and np.allclose(e1[:, :45], e2[:, :45], atol=2e-6)
 
 
@@ -97,7 +97,7 @@ def test_push_schedule_matches_numpy(hbmod, humanoid_model, gpu):
     seen = 0
     for t in range(T):
         time = env.batch.time.copy()
-        env.step(zeros)
+        env.step_arrays(zeros)
         xf = env.batch.get_state(STATE_XFRC).reshape(n, 17, 6)
         for e in range(n):
             want = refs[e].push_update(np.float32(time[e]))
@@ -124,7 +124,7 @@ def test_control_input_reward_semantics(hbmod, humanoid_model, gpu):
     for t in range(14):
         act = rng.uniform(-1.5, 1.5, size=(n, m.nu)).astype(np.float32)
         st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
-        obs, rew, term, trunc, info = env.step(act)
+        obs, rew, term, trunc, info = env.step_arrays(act)
         st1 = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
         for e in range(n):
             o.reset()
@@ -142,7 +142,7 @@ def test_control_input_reward_semantics(hbmod, humanoid_model, gpu):
     q = b.get_state(hbmod.STATE_QPOS, dtype=np.float64)
     q[:, 3:7] = np.array([0.7071, 0.7071, 0.0, 0.0])  # lying on the side
     b.set_state(hbmod.STATE_QPOS, q.astype(np.float32))
-    obs, rew, term, trunc, info = env.step(np.zeros((n, m.nu), np.float32))
+    obs, rew, term, trunc, info = env.step_arrays(np.zeros((n, m.nu), np.float32))
     assert term.all() and np.allclose(rew, cfg.terminal_reward)
 
 
@@ -168,7 +168,7 @@ def test_reset_until_collision_free(hbmod, humanoid_model, gpu):
     env2.reset()
     plain0 = hbmod.VecEnv(m, n, gpu, randomization_factor=0.0, auto_reset=0, max_time=0.0, target_z=10.0)
     plain0.reset()
-    plain0.step(np.zeros((n, m.nu), np.float32))
+    plain0.step_arrays(np.zeros((n, m.nu), np.float32))
     assert np.array_equal(env2.batch.get_state(hbmod.STATE_INTEGRATION), plain0.batch.get_state(hbmod.STATE_INTEGRATION))
 
 
@@ -243,7 +243,7 @@ def test_domain_randomization_draws_and_physics(hbmod, humanoid_model, gpu):
     for t in range(12):
         act = rng.uniform(-1, 1, size=(n, m.nu)).astype(np.float32)
         st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
-        env.step(act)
+        env.step_arrays(act)
         q1 = b.qpos
         for e in range(n):
             o.marr("body_mass")[:] = mass[e]
@@ -287,7 +287,7 @@ def test_domain_randomization_redraws_per_episode_and_switches_off(hbmod, humano
     assert np.abs(p0[0] - p0[1]).max() > 1e-4  # envs differ
     zeros = np.zeros((n, m.nu), np.float32)
     for t in range(3):
-        obs, rew, term, trunc, info = env.step(zeros)
+        obs, rew, term, trunc, info = env.step_arrays(zeros)
     assert term.all()
     p1 = env.batch.env_domain_params().copy()
     assert np.abs(p1 - p0).max() > 1e-4 and np.isfinite(p1).all()  # new episode, new draw
@@ -335,7 +335,7 @@ def test_floor_heightmap_randomization(hbmod, gpu):
         take = t > 60 and t % 12 == 0
         if take:
             st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
-        env.step(zero)
+        env.step_arrays(zero)
         if take:
             q = b.qpos.astype(np.float64)
             nc, ne, _ = b.counts()

@@ -75,7 +75,7 @@ def test_team_step_reward_and_observation_match_the_reference_formula(hbmod, gpu
     for t in range(150):
         act = (rng.uniform(-1, 1, (n, m.nu)) * (0.3 if t % 2 else 1.0)).astype(np.float32)
         st = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
-        obs, rew, term, trunc, info = env.step(act)
+        obs, rew, term, trunc, info = env.step_arrays(act)
         st1 = b.get_state(hbmod.STATE_INTEGRATION, dtype=np.float64)
         assert not term.any() and not info["warnings"].any()
         for e in range(0, n, 3):
@@ -115,6 +115,6 @@ def test_team_domain_randomisation_sets_the_motor_gains(hbmod, gpu):
     assert gain.min() >= 1.5 - 1e-6 and gain.max() <= 2.5 + 1e-6 and gain.std() > 0.2
     assert np.abs(frc[:, :, 0] + 1).max() <= 0.05 + 1e-6 and np.abs(frc[:, :, 1] - 1).max() <= 0.05 + 1e-6
     # and the physics uses them: one step with full command from rest, the hinge accelerations scale with the drawn gains
-    obs, rew, term, trunc, info = env.step(np.ones((n, nu), np.float32))
+    obs, rew, term, trunc, info = env.step_arrays(np.ones((n, nu), np.float32))
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
     env.close()

@@ -21,11 +21,11 @@ for label, kw in (("plain", {}), ("plain, outputs as views of the transfer recor
     env.copy_outputs = not views
     env.reset()
     for t in range(20):
-        env.step(acts[t % 8])
+        env.step_arrays(acts[t % 8])
     t0 = time.perf_counter()
     done = 0
     for t in range(T):
-        obs, rew, term, trunc, info = env.step(acts[t % 8])
+        obs, rew, term, trunc, info = env.step_arrays(acts[t % 8])
         done += int(info["done"].sum())
     dt = time.perf_counter() - t0
     print("VecEnv.step (%s): %d envs x %d steps in %.3f s -> %.3e env-steps/s (%.0f us/step, host round trip included); %d episodes ended"

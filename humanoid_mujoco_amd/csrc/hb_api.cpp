@@ -587,6 +587,7 @@ struct hb_batch {
   hipStream_t stream = nullptr;
   float *d_state = nullptr, *d_ctrl = nullptr, *d_xfrc = nullptr, *d_diag_qacc = nullptr, *d_diag_force = nullptr, *d_diag_contact = nullptr;
   float *d_obs = nullptr, *d_reward = nullptr;
+  int* d_seen = nullptr;        // [n_env] warning bits of episodes that ended since the last hb_env_warnings
   float* d_term_obs = nullptr;  // [n_env][nobs] observations of the states episodes ended in (hb_env_terminal_obs), null until asked for
   uint8_t *d_term = nullptr, *d_trunc = nullptr, *d_mask = nullptr;
   int *d_status = nullptr, *d_counts = nullptr;
@@ -1056,7 +1057,7 @@ void hb_batch_free(hb_batch* b) {
   if (b->d_dr) HB_IGN(hipFree(b->d_dr));
   if (b->d_rmask) HB_IGN(hipFree(b->d_rmask));
   if (b->d_pending) HB_IGN(hipFree(b->d_pending));
-  void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nsearch, b->stage.nwork, b->stage.result, b->stage.defer, b->d_term_obs, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_mask,
+  void* ptrs[] = {b->stage.geom, b->stage.item, b->stage.nsearch, b->stage.nwork, b->stage.result, b->stage.defer, b->d_term_obs, b->d_seen, b->d_state, b->d_ctrl, b->d_xfrc, b->d_diag_qacc, b->d_diag_force, b->d_diag_contact, b->d_obs, b->d_mask,
                   b->d_status, b->d_counts, b->d_qpos_out, b->d_qvel_out, b->d_task_out, b->d_knots, b->d_order, b->d_order2, b->d_prev, b->d_latest, b->d_qfrc, b->d_action, b->d_episode};
   for (void* p : ptrs) if (p) HB_IGN(hipFree(p));
   delete b;
@@ -1131,7 +1132,9 @@ int hb_batch_pipeline(hb_batch* b, int on) {
       bad = pipes_conflict(b, want);
     }
     for (hipStream_t s : spare) if (s) HB_IGN(hipStreamDestroy(s));
+    if (bad == -2) return HB_ENODEVICE;  // the probe itself failed (a HIP error, not a shared queue): an error, not a quiet two segments
     if (bad != -1) want = 2;
+    if (hb_debug()) fprintf(stderr, "[hb] hb_batch_pipeline: %d env segments (%s)\n", want, bad == -1 ? "every segment stream has a hardware queue of its own" : "two of three segment streams share a hardware queue");
   }
   b->npipe = want;
   b->order_mode = 0;            // segment boundaries changed: per-segment permutations are stale
@@ -1864,7 +1867,8 @@ static int env_alloc(hb_batch* b) {
   size_t nu = std::max(1, dm.nu);
   if (hipMalloc((void**)&b->d_prev, n * nu * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_latest, n * nu * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&b->d_action, n * nu * sizeof(float)) != hipSuccess || hipMalloc((void**)&b->d_qfrc, n * dm.nv * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&b->d_episode, n * sizeof(int)) != hipSuccess) return HB_ENOMEM;
+      hipMalloc((void**)&b->d_episode, n * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->d_seen, n * sizeof(int)) != hipSuccess) return HB_ENOMEM;
+  HB_HIP(hipMemset(b->d_seen, 0, n * sizeof(int)));
   HB_HIP(hipMemset(b->d_prev, 0, n * nu * sizeof(float)));
   HB_HIP(hipMemset(b->d_latest, 0, n * nu * sizeof(float)));
   HB_HIP(hipMemset(b->d_qfrc, 0, n * dm.nv * sizeof(float)));
@@ -1887,7 +1891,7 @@ static int env_eval(hb_batch* b, bool allow_reset, bool observe, const uint8_t* 
   EnvRandState S = b->rs;
   if (!b->rand_on) memset(&S, 0, sizeof S);
   HB_HIP(launch_env(b->D.dm, cfg, b->env_rand, S, b->d_state, b->d_qfrc, b->d_counts, b->d_prev, b->d_latest, src, b->d_episode, b->d_status, d_obs, d_reward,
-                    d_term, d_trunc, mask, observe ? 1 : 0, b->dom_rand, b->d_dr, b->dr_stride, b->n_env, b->env_offset, main_stream(b), observe ? b->d_term_obs : nullptr));
+                    d_term, d_trunc, mask, observe ? 1 : 0, b->dom_rand, b->d_dr, b->dr_stride, b->n_env, b->env_offset, main_stream(b), observe ? b->d_term_obs : nullptr, b->d_seen));
   return HB_OK;
 }
 
@@ -2337,6 +2341,21 @@ int hb_get_status(hb_batch* b, int* status) {
   HB_HIP(hipSetDevice(b->device));
   HB_HIP(hipStreamSynchronize(main_stream(b)));
   HB_HIP(hipMemcpy(status, b->d_status, (size_t)b->n_env * sizeof(int), hipMemcpyDeviceToHost));
+  return HB_OK;
+}
+
+int hb_env_warnings(hb_batch* b, int* warnings) {
+  if (!b || !warnings) return HB_EINVAL;
+  int rc = env_alloc(b);
+  if (rc != HB_OK) return rc;
+  HB_HIP(hipSetDevice(b->device));
+  hipStream_t st = main_stream(b);
+  std::vector<int> seen((size_t)b->n_env);
+  HB_HIP(hipMemcpyAsync(warnings, b->d_status, seen.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+  HB_HIP(hipMemcpyAsync(seen.data(), b->d_seen, seen.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+  HB_HIP(hipMemsetAsync(b->d_seen, 0, seen.size() * sizeof(int), st));
+  HB_HIP(hipStreamSynchronize(st));
+  for (size_t e = 0; e < seen.size(); e++) warnings[e] |= seen[e];
   return HB_OK;
 }
 

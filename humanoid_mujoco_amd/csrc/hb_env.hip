@@ -465,7 +465,7 @@ __device__ __forceinline__ float env_lane_sum(float x) {
 }
 __global__ __launch_bounds__(256) void hb_env_kernel(const DevModel M, const EnvConfig cfg, const EnvRand R, const EnvRandState S, float* state, const float* qfrc, const int* counts,
                               float* prev, float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated,
-                              uint8_t* truncated, const uint8_t* mask, int observe, const DomainRand D, float* dr, int dr_stride, int n_env, int env_offset, float* term_obs) {
+                              uint8_t* truncated, const uint8_t* mask, int observe, const DomainRand D, float* dr, int dr_stride, int n_env, int env_offset, float* term_obs, int* seen) {
   extern __shared__ float sh_state[];
   const int grp = threadIdx.x / kEnvLanes, l = threadIdx.x % kEnvLanes;
   const int e = blockIdx.x * (256 / kEnvLanes) + grp;
@@ -569,6 +569,7 @@ __global__ __launch_bounds__(256) void hb_env_kernel(const DevModel M, const Env
     for (int i = l; i < M.nu; i += kEnvLanes) { prev[(size_t)e * M.nu + i] = 0.f; latest[(size_t)e * M.nu + i] = 0.f; }
     if (l == 0) {
       episode[e] = ep;
+      if (seen) seen[e] |= status[e];  // (the warning bits of the episode that ends here stay readable: hb_env_warnings)
       status[e] = 0;
       if (rand_on) envrand_begin_episode(M, R, S, e, env_offset + e, ep);
     }
@@ -911,11 +912,11 @@ hipError_t launch_action(const float* action, float* prev, float* latest, float*
 }
 hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, const EnvRand& R, const EnvRandState& S, float* state, const float* qfrc, const int* counts, float* prev,
                       float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
-                      const uint8_t* mask, int observe, const DomainRand& D, float* dr, int dr_stride, int n_env, int env_offset, hipStream_t stream, float* term_obs) {
+                      const uint8_t* mask, int observe, const DomainRand& D, float* dr, int dr_stride, int n_env, int env_offset, hipStream_t stream, float* term_obs, int* seen) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
   const int per_block = 256 / kEnvLanes;
   hipLaunchKernelGGL(hb_env_kernel, dim3((n_env + per_block - 1) / per_block), dim3(256), (size_t)per_block * ((M.nstate + 3) & ~3) * sizeof(float), stream, M, cfg, R, S, state, qfrc, counts, prev, latest, qpos_src, episode, status, obs,
-                     reward, terminated, truncated, mask, observe, D, dr, dr_stride, n_env, env_offset, term_obs);
+                     reward, terminated, truncated, mask, observe, D, dr, dr_stride, n_env, env_offset, term_obs, seen);
   return hipGetLastError();
 }
 hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset,

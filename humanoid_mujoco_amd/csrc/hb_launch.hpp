@@ -22,7 +22,7 @@ hipError_t launch_obs(const DevModel& M, const float* state, float* obs, int n_e
 hipError_t launch_action(const float* action, float* prev, float* latest, float* ctrl, int n, hipStream_t stream);
 hipError_t launch_env(const DevModel& M, const EnvConfig& cfg, const EnvRand& R, const EnvRandState& S, float* state, const float* qfrc, const int* counts, float* prev,
                       float* latest, const float* qpos_src, int* episode, int* status, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
-                      const uint8_t* mask, int observe, const DomainRand& D, float* dr, int dr_stride, int n_env, int env_offset, hipStream_t stream, float* term_obs = nullptr);
+                      const uint8_t* mask, int observe, const DomainRand& D, float* dr, int dr_stride, int n_env, int env_offset, hipStream_t stream, float* term_obs = nullptr, int* seen = nullptr);
 hipError_t launch_domain_rand(const DevModel& M, const DomainRand& D, float* dr, int stride, const int* episode, const uint8_t* mask, int n_env, int env_offset,
                               hipStream_t stream);
 hipError_t launch_policy(const DevModel& M, const PolicyDesc& pd, const float* state, float* ctrl, int n_env, hipStream_t stream);

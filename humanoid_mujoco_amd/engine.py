@@ -149,6 +149,7 @@ def lib():
     L.hb_last_kernel.argtypes = [vp]; L.hb_last_kernel.restype = ctypes.c_char_p
     L.hb_batch_tune.argtypes = [vp, ci, ci]
     L.hb_env_terminal_obs.argtypes = [vp, vp]
+    L.hb_env_warnings.argtypes = [vp, vp]
     L.hb_batch_device_name.argtypes = [vp, cp, ci]
     L.hb_get_collision_counts.argtypes = [vp, vp, vp, vp]
     L.hb_batch_segments.argtypes = [vp]
@@ -697,21 +698,33 @@ class Batch:
                                        te=out.array[ob + rb:ob + rb + n], tr=out.array[ob + rb + n:], off=(0, ob, ob + rb, ob + rb + n))
         a = np.asarray(action, dtype=np.float32)
         assert a.shape == (self.n_env, self.model.nu), a.shape
+        if getattr(self, "_env_pending", False):  # a step enqueued with wait=False may still be reading the action buffer / writing the outputs
+            self.sync()
+            self._env_pending = False
         pin["a"].array[...] = a
         base, off = pin["out"].ptr, pin["off"]
         fn = lib().hb_env_step_async if wait is False else lib().hb_env_step
         _check(fn(self._h, ctypes.c_void_p(pin["a"].ptr), int(n_substeps), ctypes.c_void_p(base + off[0]), ctypes.c_void_p(base + off[1]),
                   ctypes.c_void_p(base + off[2]), ctypes.c_void_p(base + off[3])), "hb_env_step")
         if wait is False:
+            self._env_pending = True
             return None
         return self.env_step_result(copy)
 
     def env_step_result(self, copy=True):
         """the outputs of the last env_step (after env_step(..., wait=False): call sync() first)"""
-        pin = self._env_pin
+        pin = getattr(self, "_env_pin", None)
+        if pin is None:
+            raise HbError("env_step_result before any env_step")
         if not copy:
             return pin["o"], pin["r"], pin["te"].view(bool), pin["tr"].view(bool)
         return pin["o"].copy(), pin["r"].copy(), pin["te"].astype(bool), pin["tr"].astype(bool)
+
+    def env_warnings(self):
+        """HB_WARN_* bits every env has raised since the previous call, across in-place resets (include/hb.h: hb_env_warnings)"""
+        w = np.zeros(self.n_env, dtype=np.int32)
+        _check(lib().hb_env_warnings(self._h, _ptr(w)), "hb_env_warnings")
+        return w
 
     def env_terminal_obs(self, fetch=True):
         """[n_env, nobs] observations of the states episodes ended in (include/hb.h: hb_env_terminal_obs); fetch=False only switches the

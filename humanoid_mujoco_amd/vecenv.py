@@ -185,14 +185,14 @@ class VecEnv:
 
     def _finish(self, obs, rew, term, trunc):
         done = term | trunc
-        # "warnings": the per-env HB_WARN_* bits (mjData.warning, mjdata.h:54-65) accumulated since the env's last reset:
-        # a contact or constraint-row overflow (rows were dropped for that env-step) or a bad-state reset is visible to
-        # the training loop instead of silently changing that env's physics
-        # (read back every `warning_period`-th step, default 16 - the bits are sticky until the env's reset, so nothing is lost in between -
-        # and not every step: the read is one more stream synchronisation and device-to-host copy on the host-action path)
+        # "warnings": the per-env HB_WARN_* bits (mjData.warning, mjdata.h:54-65): a contact or constraint-row overflow (rows were dropped for
+        # that env-step) or a bad-state reset is visible to the training loop instead of silently changing that env's physics.  Polled every
+        # `warning_period`-th step (default 16: the poll is one more stream synchronisation and device-to-host copy on the host-action path)
+        # through hb_env_warnings, which also keeps the bits of episodes that ended - and were reset in place - between two polls: nothing is
+        # lost, a bit is reported at the poll after it was raised.  A fresh array at every poll.
         self._steps = getattr(self, "_steps", 0) + 1
         if getattr(self, "_warn", None) is None or self._steps % max(1, int(getattr(self, "warning_period", 16))) == 0:
-            self._warn = self.batch.status()
+            self._warn = self.batch.env_warnings()
         w = self._warn
         infos = {"is_success": trunc.copy(), "done": done, "warnings": w,  # cpu_env.py:688-689
                  "overflow": (w & (WARN_CONTACTFULL | WARN_CNSTRFULL)) != 0}

@@ -318,6 +318,10 @@ int hb_get_obs(hb_batch* b, float* obs, float* reward, uint8_t* terminated, uint
 /* Per-env status bits (HB_WARN_*), accumulated since the last hb_reset; replaces polling
  * mjData.warning (mujoco_mpc/mjpc/utilities.cc:787-799 CheckWarnings). */
 int hb_get_status(hb_batch* b, int* status);
+/* The same for a training loop that resets finished envs in place (hb_env_step with auto_reset): hb_get_status is cleared by an env's reset,
+ * so a warning of an episode that ended before the next poll would be lost.  warnings[e] = the bits env e has raised since the previous
+ * call of this function, in whatever episodes; the call clears what finished episodes left behind. */
+int hb_env_warnings(hb_batch* b, int* warnings);
 /* Per-env counters of the last step: ncon, nefc, solver iterations (mjData.ncon/nefc/
  * solver_niter, mjdata.h:196-201) — what testspeed.cc:97-98 accumulates. */
 int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter);

@@ -190,3 +190,22 @@ def test_vecenv_reports_warning_bits(hbmod, humanoid_model, gpu):
     assert np.isfinite(obs).all() and np.isfinite(rew).all()
     assert env.warning_counts() == {"contact_full": 0, "constraint_full": 0, "bad_qpos": 1, "bad_qvel": 0, "bad_qacc": 0}
     env.close()
+    # an episode that raises a warning and ENDS (reset in place) before the next poll: hb_get_status has been cleared by the reset, the
+    # poll still reports the bit - once
+    env = hbmod.VecEnv(humanoid_model, n, gpu, max_time=2.5 * humanoid_model.opt.timestep, target_z=10.0)  # three-step episodes
+    env.warning_period = 8
+    env.reset()
+    env.step_arrays(act)  # (the first step polls)
+    st = env.batch.get_state(hbmod.STATE_INTEGRATION)
+    st[2, 3] = np.nan
+    env.batch.set_state(hbmod.STATE_INTEGRATION, st)
+    for t in range(6):
+        _, _, _, _, info = env.step_arrays(act)  # steps 2 .. 7: the planted env is flagged at step 2 and reset (time limit) soon after
+        assert not info["warnings"].any()        # (not polled yet)
+    assert not (env.batch.status() & hbmod.WARN_BADQPOS).any()  # the reset has cleared the sticky word
+    _, _, _, _, info = env.step_arrays(act)      # step 8: the poll
+    assert info["warnings"][2] & hbmod.WARN_BADQPOS and not np.delete(info["warnings"], 2).any()
+    for t in range(8):
+        _, _, _, _, info = env.step_arrays(act)
+    assert not info["warnings"].any()            # reported once
+    env.close()

@@ -127,6 +127,7 @@ bool compile_mjcf_string(const std::string& xml, Model& m, std::string& err);
 // mesh.cpp — STL reader and convex hull (the vertices MuJoCo's mesh collision uses)
 bool read_stl_vertices(const std::string& path, std::vector<double>& pts, std::string& err);
 bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull, std::string& err, std::vector<int>* tris = nullptr);
+bool mesh_mass_properties(const std::vector<double>& verts, const std::vector<int>& tris, double& volume, double com[3], double inertia[6]);
 // setconst.cpp — mj_setConst products (mujoco.h:221) computed in fp64 on the host
 bool set_const(Model& m, std::string& err);
 // model_io.cpp — ".hbm" text serialisation (replaces mj_saveModel/mj_loadModel, mujoco.h:159-163)

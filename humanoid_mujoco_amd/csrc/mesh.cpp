@@ -208,6 +208,38 @@ static bool hull_once(const std::vector<double>& pts, const std::vector<double>&
   return true;
 }
 
+// Volume, centre of mass and inertia tensor about the centre of mass (unit density; xx, yy, zz, xy, xz, yz) of the solid bounded by a
+// closed, outward-oriented triangle surface: the sum over the signed tetrahedra (origin, a, b, c) of the closed-form tetrahedron
+// integrals.  This is what MuJoCo's compiler derives a mesh geom's mass, inertial frame and inertia from (the reference's robot:
+// simulation/assets/humanoid.xml:22-93 gives its mesh geoms no size, world.xml:18 its defaults); it integrates over the mesh's own
+// faces, this compiler over the faces of the convex hull it keeps - the same solid for a convex mesh, the hull's for any other.
+bool mesh_mass_properties(const std::vector<double>& v, const std::vector<int>& tris, double& volume, double com[3], double inertia[6]) {
+  // second moments about the origin: integral of x_i x_j over a tetrahedron (0, a, b, c) = det / 120 * (sum over vertex pairs incl. equal ones)
+  double vol = 0, m1[3] = {0, 0, 0}, m2[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  // (integrated about a point inside the solid: the first vertex - smaller cancellations than about a far-away file origin)
+  const double o[3] = {v[0], v[1], v[2]};
+  for (size_t t = 0; t + 2 < tris.size(); t += 3) {
+    double a[3], b[3], c[3];
+    for (int i = 0; i < 3; i++) { a[i] = v[3 * tris[t] + i] - o[i]; b[i] = v[3 * tris[t + 1] + i] - o[i]; c[i] = v[3 * tris[t + 2] + i] - o[i]; }
+    const double det = a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+    vol += det / 6;
+    for (int i = 0; i < 3; i++) m1[i] += det / 24 * (a[i] + b[i] + c[i]);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        m2[i][j] += det / 120 * (2 * (a[i] * a[j] + b[i] * b[j] + c[i] * c[j]) + a[i] * b[j] + b[i] * a[j] + a[i] * c[j] + c[i] * a[j] + b[i] * c[j] + c[i] * b[j]);
+  }
+  if (!(vol > 0)) return false;
+  volume = vol;
+  double cl[3];
+  for (int i = 0; i < 3; i++) { cl[i] = m1[i] / vol; com[i] = o[i] + cl[i]; }
+  // central second moments, then the inertia tensor
+  double c2[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c2[i][j] = m2[i][j] - vol * cl[i] * cl[j];
+  inertia[0] = c2[1][1] + c2[2][2]; inertia[1] = c2[0][0] + c2[2][2]; inertia[2] = c2[0][0] + c2[1][1];
+  inertia[3] = -c2[0][1]; inertia[4] = -c2[0][2]; inertia[5] = -c2[1][2];
+  return true;
+}
+
 // Vertices of an STL file (binary, or ASCII "solid ... vertex x y z"), duplicates removed, in first-appearance order.
 bool read_stl_vertices(const std::string& path, std::vector<double>& pts, std::string& err) {
   std::ifstream f(path, std::ios::binary);

@@ -36,7 +36,9 @@ struct Ctx {
   std::map<std::string, DefaultClass> classes;
   std::map<std::string, std::string> hfield_names;  // name -> index (as string)
   std::map<std::string, int> mesh_names;            // name -> mesh id
-  std::vector<double> mesh_center;                  // per mesh: centre of its hull's bounding box in the file's coordinates (the hull is stored relative to it)
+  std::vector<double> mesh_center;                  // per mesh: centre of mass of its hull in the file's coordinates (the hull is stored relative to it ...
+  std::vector<double> mesh_quat;                    //   ... in its principal axes of inertia: their orientation in the file's frame, 4 per mesh)
+  std::vector<double> mesh_volume, mesh_inertia;    // per mesh: volume; principal moments at unit density (3 per mesh, descending)
   std::vector<double> mesh_rbound;                  // per mesh: largest vertex distance from that centre
   std::string basedir, meshdir;
   Model* m = nullptr;
@@ -176,7 +178,7 @@ struct GeomTmp {
   int type;
   double size[3], pos[3], quat[4];
   double mass, inertia[3];  // principal, in geom frame
-  bool inertia_unknown = false;  // a mesh geom that would have to supply mass and inertia (MuJoCo derives them from the mesh volume)
+  double mesh_volume = 0, mesh_inertia[3] = {0, 0, 0};  // a mesh geom: its hull's volume and principal moments at unit density
 };
 
 // mass and principal inertia of a primitive at given density (or explicit mass)
@@ -187,12 +189,12 @@ void geom_inertia(GeomTmp& g, double density, double mass_attr) {
   else if (g.type == GEOM_CAPSULE) vol = PI * r * r * (2 * h) + 4.0 / 3.0 * PI * r * r * r;
   else if (g.type == GEOM_CYLINDER) vol = PI * r * r * (2 * h);
   else vol = 0;
-  // a mesh's mass, centre of mass and inertia come from its volume in MuJoCo; this compiler keeps only the hull's vertices, so a mesh
-  // geom can take part in a body's inertia only through the body's <inertial> (finish_body_inertia turns the flag into an error)
-  g.inertia_unknown = g.type == GEOM_MESH && (mass_attr > 0 || (mass_attr < 0 && density > 0));
+  // (a mesh geom: volume and principal moments of its hull, in whose centre-of-mass / principal frame the geom already sits: compile_geom)
+  if (g.type == GEOM_MESH) vol = g.mesh_volume;
   double mass = mass_attr >= 0 ? mass_attr : density * vol;
   g.mass = mass;
   g.inertia[0] = g.inertia[1] = g.inertia[2] = 0;
+  if (g.type == GEOM_MESH && vol > 0) for (int i = 0; i < 3; i++) g.inertia[i] = mass / vol * g.mesh_inertia[i];
   if (g.type == GEOM_SPHERE) {
     g.inertia[0] = g.inertia[1] = g.inertia[2] = 0.4 * mass * r * r;
   } else if (g.type == GEOM_CAPSULE) {
@@ -265,16 +267,21 @@ bool add_geom(Ctx& c, const XmlNode& n, int body, const std::string& childclass,
   if (type == GEOM_CAPSULE && (g.size[0] <= 0 || g.size[1] <= 0)) return c.fail("mjcf: capsule needs radius and half-length in " + a.where);
   int dataid = -1;
   if (type == GEOM_MESH) {
-    // MuJoCo collides a mesh geom through the convex hull of its mesh (mesh.cpp).  The hull is stored relative to the centre of
-    // its bounding box; that offset goes into the geom's position (MuJoCo re-centres on the mesh's centre of mass and aligns with
-    // its principal axes instead: the same surface in world coordinates)
+    // MuJoCo collides a mesh geom through the convex hull of its mesh (mesh.cpp), and its compiler re-centres a mesh on its centre of mass
+    // and aligns it with its principal axes of inertia; the offset and the rotation go into the geom's frame (same surface in world
+    // coordinates; what moves is the frame origin - the interior point of the MPR portal search - and the geom's inertial frame)
     std::string mn = a.str("mesh");
     auto it = c.mesh_names.find(mn);
     if (it == c.mesh_names.end()) return c.fail("mjcf: unknown mesh '" + mn + "' in " + a.where);
     dataid = it->second;
-    double off[3];
+    double off[3], q[4];
     hm::rot_vec_quat(off, &c.mesh_center[3 * dataid], g.quat);
     for (int i = 0; i < 3; i++) g.pos[i] += off[i];
+    hm::mul_quat(q, g.quat, &c.mesh_quat[4 * dataid]);
+    hm::normalize4(q);
+    memcpy(g.quat, q, sizeof q);
+    g.mesh_volume = c.mesh_volume[dataid];
+    for (int i = 0; i < 3; i++) g.mesh_inertia[i] = c.mesh_inertia[3 * dataid + i];
     g.size[0] = g.size[1] = g.size[2] = 0;
   }
   if (type == GEOM_HFIELD) {
@@ -427,11 +434,6 @@ bool finish_body_inertia(Ctx& c, int body, BodyBuild& bb) {
     memcpy(ipos, bb.ipos, sizeof ipos); memcpy(iquat, bb.iquat, sizeof iquat);
     mass = bb.mass; memcpy(inertia, bb.inertia, sizeof inertia);
   } else {
-    if (body > 0)
-      for (auto& g : bb.geoms)
-        if (g.inertia_unknown)
-          return c.fail("mjcf: body '" + m.body_name[body] + "' has no <inertial> and a mesh geom that would have to supply mass and inertia: "
-                        "mesh-derived inertia is not implemented (give the body an <inertial>, or the geom mass=\"0\" / density=\"0\")");
     std::vector<GeomTmp*> sel;
     for (auto& g : bb.geoms) if (g.mass > 0) sel.push_back(&g);
     if (sel.size() == 1) {
@@ -608,15 +610,49 @@ bool read_mesh(Ctx& c, const XmlNode& n) {
   for (size_t i = 0; i < pts.size(); i++) pts[i] *= sc[i % 3];
   std::vector<int> hull, tris;
   if (!convex_hull_vertices(pts, hull, c.err, &tris)) { c.err += " in " + a.where; return false; }
-  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-  for (int v : hull) for (int i = 0; i < 3; i++) { lo[i] = std::min(lo[i], pts[3 * v + i]); hi[i] = std::max(hi[i], pts[3 * v + i]); }
-  double cen[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])}, rb = 0;
+  // the hull's volume, centre of mass and principal axes of inertia (signed tetrahedra over its faces: mesh.cpp); the stored vertices are
+  // relative to that frame
+  std::vector<double> hv;
+  for (int v : hull) for (int i = 0; i < 3; i++) hv.push_back(pts[3 * v + i]);
+  double vol = 0, cen[3], I6[6], rb = 0;
+  if (!mesh_mass_properties(hv, tris, vol, cen, I6)) return c.fail("mjcf: mesh hull has no volume in " + a.where);
+  double Rm[9], w3[3];
+  {
+    const double I[9] = {I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]};
+    double w[3], V[9];
+    hm::eig3(I, w, V);
+    int idx[3] = {0, 1, 2};  // moments descending, right-handed axes (as finish_body_inertia orders a body's)
+    for (int i = 0; i < 3; i++) for (int j = i + 1; j < 3; j++) if (w[idx[j]] > w[idx[i]]) std::swap(idx[i], idx[j]);
+    for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) Rm[3 * r + k] = V[3 * r + idx[k]];
+    double c0[3] = {Rm[0], Rm[3], Rm[6]}, c1[3] = {Rm[1], Rm[4], Rm[7]}, c2[3];
+    hm::cross(c2, c0, c1);
+    Rm[2] = c2[0]; Rm[5] = c2[1]; Rm[8] = c2[2];
+    for (int k = 0; k < 3; k++) w3[k] = w[idx[k]];
+    // (a tensor that is diagonal to rounding - a box, a symmetric part: the eigenvectors of equal or nearly equal moments are arbitrary -
+    // takes the file's axes, permuted into descending order, moments equal to 1e-12 counted as equal)
+    const double offd = std::fabs(I6[3]) + std::fabs(I6[4]) + std::fabs(I6[5]), tr = I6[0] + I6[1] + I6[2];
+    if (offd <= 1e-12 * tr) {
+      int pm[3] = {0, 1, 2};
+      for (int i = 0; i < 3; i++) for (int j = i + 1; j < 3; j++) if (I6[pm[j]] > I6[pm[i]] + 1e-12 * tr) std::swap(pm[i], pm[j]);
+      for (int i = 0; i < 9; i++) Rm[i] = 0.0;
+      Rm[3 * pm[0] + 0] = 1.0; Rm[3 * pm[1] + 1] = 1.0;
+      double c0[3] = {Rm[0], Rm[3], Rm[6]}, c1[3] = {Rm[1], Rm[4], Rm[7]}, c2[3];
+      hm::cross(c2, c0, c1);
+      Rm[2] = c2[0]; Rm[5] = c2[1]; Rm[8] = c2[2];
+      for (int k = 0; k < 3; k++) w3[k] = I6[pm[k]];
+    }
+  }
+  double mq[4];
+  hm::mat2quat(mq, Rm);
+  hm::normalize4(mq);
   c.mesh_names[name] = m.nmesh;
   m.mesh_name.push_back(name);
   m.mesh_vertadr.push_back(m.nmeshvert);
   m.mesh_vertnum.push_back((int)hull.size());
   for (int v : hull) {
-    double q[3] = {pts[3 * v] - cen[0], pts[3 * v + 1] - cen[1], pts[3 * v + 2] - cen[2]};
+    const double d[3] = {pts[3 * v] - cen[0], pts[3 * v + 1] - cen[1], pts[3 * v + 2] - cen[2]};
+    double q[3];  // R' d: coordinates along the principal axes
+    for (int k = 0; k < 3; k++) q[k] = Rm[k] * d[0] + Rm[3 + k] * d[1] + Rm[6 + k] * d[2];
     rb = std::max(rb, hm::norm3(q));
     push3(m.mesh_vert, q);
   }
@@ -632,6 +668,9 @@ bool read_mesh(Ctx& c, const XmlNode& n) {
     }
   }
   push3(c.mesh_center, cen);
+  for (int i = 0; i < 4; i++) c.mesh_quat.push_back(mq[i]);
+  c.mesh_volume.push_back(vol);
+  for (int i = 0; i < 3; i++) c.mesh_inertia.push_back(w3[i]);
   c.mesh_rbound.push_back(rb);
   m.nmeshvert += (int)hull.size();
   m.nmesh++;

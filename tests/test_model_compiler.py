@@ -167,11 +167,6 @@ def test_multi_tree_weld_and_options(hbmod, tmp_path):
     ("<mujoco><worldbody><body></worldbody></mujoco>", "mismatched"),
     ("<mujoco><option solver='CG'/><worldbody/></mujoco>", "PGS"),
     ("<notmujoco/>", "root element"),
-    # a mesh geom that would have to supply a body's mass and inertia (MuJoCo takes them from the mesh volume): refused, never a
-    # silent point mass - alone, beside a primitive geom, and with an explicit mass
-    ("<mujoco><asset><mesh name='m' vertex='0 0 0 1 0 0 0 1 0 0 0 1'/></asset><worldbody><body><joint/><geom type='mesh' mesh='m'/></body></worldbody></mujoco>", "mesh-derived inertia"),
-    ("<mujoco><asset><mesh name='m' vertex='0 0 0 1 0 0 0 1 0 0 0 1'/></asset><worldbody><body><joint/><geom size='0.1'/><geom type='mesh' mesh='m'/></body></worldbody></mujoco>", "mesh-derived inertia"),
-    ("<mujoco><asset><mesh name='m' vertex='0 0 0 1 0 0 0 1 0 0 0 1'/></asset><worldbody><body><joint/><geom type='mesh' mesh='m' mass='2'/></body></worldbody></mujoco>", "mesh-derived inertia"),
 ])
 def test_compile_errors_are_reported_not_fatal(hbmod, xml, frag):
     with pytest.raises(hbmod.HbError) as e:
@@ -180,7 +175,7 @@ def test_compile_errors_are_reported_not_fatal(hbmod, xml, frag):
 
 
 def test_mesh_and_cylinder_geoms_in_the_inertia_of_a_body(hbmod):
-    """With an <inertial> (as every body of the reference's robot has) or with density 0 a mesh geom compiles; a cylinder contributes its
+    """A mesh geom beside an <inertial> (as every body of the reference's robot has) or with density 0; a cylinder contributes its
     closed-form mass and inertia like the other primitives (m = rho pi r^2 2h, Ixx = m (3 r^2 + (2h)^2) / 12, Izz = m r^2 / 2)."""
     mesh = "<asset><mesh name='m' vertex='0 0 0 1 0 0 0 1 0 0 0 1'/></asset>"
     a = hbmod.Model.from_xml_string("<mujoco>%s<worldbody><body><joint/><inertial pos='0 0 0' mass='1' diaginertia='1 1 1'/><geom type='mesh' mesh='m'/></body></worldbody></mujoco>" % mesh)
@@ -191,6 +186,69 @@ def test_mesh_and_cylinder_geoms_in_the_inertia_of_a_body(hbmod):
     mass = 1000 * np.pi * 0.04 * 1.0
     assert abs(c.array("body_mass")[1] - mass) < 1e-9
     assert np.allclose(c.array("body_inertia").reshape(-1, 3)[1], [mass * (3 * 0.04 + 1.0) / 12, mass * (3 * 0.04 + 1.0) / 12, mass * 0.04 / 2], rtol=1e-12)
+
+
+def _mesh_body(hbmod, verts, extra="", geom_attr=""):
+    v = " ".join("%r" % float(x) for x in np.asarray(verts, float).ravel())
+    xml = ("<mujoco><asset><mesh name='m' vertex='%s'/></asset><worldbody><body pos='0 0 1'><joint type='free'/>%s<geom type='mesh' mesh='m' %s/></body></worldbody></mujoco>"
+           % (v, extra, geom_attr))
+    return hbmod.Model.from_xml_string(xml)
+
+
+def _box(lo, hi):
+    return [[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]
+
+
+def test_mesh_mass_properties_closed_forms(hbmod):
+    """MuJoCo derives a mesh geom's mass, inertial frame and inertia from the mesh volume, and stores the mesh about its centre of mass in
+    its principal axes (the geoms of simulation/assets/humanoid.xml:22-93, defaults world.xml:18).  csrc/mesh.cpp: signed tetrahedra over
+    the hull's faces; closed forms for a cube, an off-centre box, a tetrahedron - volume, centroid and principal moments to 1e-12 - and a
+    body WITHOUT <inertial> gets them (it was an error before)."""
+    rho = 1000.0
+    # cube of edge 0.2 centred at (0.3, -0.1, 0.05) in the mesh file's coordinates
+    c0 = np.array([0.3, -0.1, 0.05])
+    m = _mesh_body(hbmod, _box(c0 - 0.1, c0 + 0.1))
+    mass = rho * 0.2 ** 3
+    assert abs(m.array("body_mass")[1] - mass) < 1e-12 * mass
+    assert np.allclose(m.array("body_ipos")[3:6], c0, atol=1e-15) and np.allclose(m.array("geom_pos")[0:3], c0, atol=1e-15)
+    assert np.allclose(m.array("body_inertia")[3:6], mass * 0.2 ** 2 / 6, rtol=1e-12)
+    verts = m.array("mesh_vert").reshape(-1, 3)
+    assert len(verts) == 8 and np.allclose(np.sort(np.abs(verts), axis=None), 0.1, atol=1e-15)  # stored about the centre of mass
+    # off-centre box 0.4 x 0.2 x 0.1 with its corner at the file's origin: centroid at the half extents, principal moments m (b^2 + c^2) / 12
+    # descending - i.e. about z, y, x - and the mesh stored in THAT frame (the long edge along the last principal axis)
+    a_, b_, c_ = 0.4, 0.2, 0.1
+    m = _mesh_body(hbmod, _box((0, 0, 0), (a_, b_, c_)))
+    mass = rho * a_ * b_ * c_
+    want = np.array([mass * (a_ ** 2 + b_ ** 2) / 12, mass * (a_ ** 2 + c_ ** 2) / 12, mass * (b_ ** 2 + c_ ** 2) / 12])
+    assert abs(m.array("body_mass")[1] - mass) < 1e-12 * mass
+    assert np.allclose(m.array("body_ipos")[3:6], [a_ / 2, b_ / 2, c_ / 2], atol=1e-15)
+    assert np.allclose(m.array("body_inertia")[3:6], want, rtol=1e-12)
+    verts = m.array("mesh_vert").reshape(-1, 3)
+    assert np.allclose(np.abs(verts).max(axis=0), [c_ / 2, b_ / 2, a_ / 2], atol=1e-14)
+    # the geom frame maps the stored vertices back onto the file's box
+    q = m.array("geom_quat")[0:4]
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    back = verts @ R.T + m.array("geom_pos")[0:3]
+    assert np.allclose(np.sort(back, axis=0), np.sort(np.array(_box((0, 0, 0), (a_, b_, c_))), axis=0), atol=1e-14)
+    # the unit right tetrahedron: volume 1 / 6, centroid (1/4, 1/4, 1/4), inertia tensor about the centroid with eigenvalues 1/80 * (1, 1, 2/... )
+    m = _mesh_body(hbmod, [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    mass = rho / 6
+    assert abs(m.array("body_mass")[1] - mass) < 1e-12 * mass and np.allclose(m.array("body_ipos")[3:6], 0.25, atol=1e-15)
+    # closed form: central second moments of the unit right tetrahedron are V * (3/80) on the diagonal and V * (-1/80) off it, so the
+    # inertia tensor is V * [[6, 1, 1], [1, 6, 1], [1, 1, 6]] / 80: eigenvalues V * 8 / 80 (axis (1, 1, 1)) and V * 5 / 80 (twice)
+    assert np.allclose(m.array("body_inertia")[3:6], [mass * 8 / 80, mass * 5 / 80, mass * 5 / 80], rtol=1e-12)
+    # an explicit mass scales the moments; a second geom on the body composes as for primitives
+    m = _mesh_body(hbmod, _box(c0 - 0.1, c0 + 0.1), geom_attr="mass='2'")
+    assert m.array("body_mass")[1] == 2.0 and np.allclose(m.array("body_inertia")[3:6], 2.0 * 0.04 / 6, rtol=1e-12)
+    m = _mesh_body(hbmod, _box(c0 - 0.1, c0 + 0.1), extra="<geom size='0.05' pos='-0.3 0 0'/>")
+    ms = rho * 4 / 3 * np.pi * 0.05 ** 3
+    mc = rho * 0.008
+    assert abs(m.array("body_mass")[1] - (ms + mc)) < 1e-12
+    assert np.allclose(m.array("body_ipos")[3:6], (mc * c0 + ms * np.array([-0.3, 0, 0])) / (ms + mc), atol=1e-14)
+    # the free body's mass matrix from the oracle: diag(m, m, m, principal moments) in the inertial frame
+    # (qM of a single free body: translation block m I, rotation block the inertia in the body's own frame)
 
 
 def test_load_errors(hbmod, tmp_path):

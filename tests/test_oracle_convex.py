@@ -63,7 +63,17 @@ def _hull_of(hbmod, pts):
     m = hbmod.Model.from_xml_string(xml)
     v = m.array("mesh_vert").reshape(-1, 3)
     gp = m.array("geom_pos").reshape(-1, 3)[0]
-    return v + gp, float(m.array("geom_rbound")[0])  # back in the file's coordinates (the geom carries the bounding-box centre)
+    w, x, y, z = m.array("geom_quat").reshape(-1, 4)[0]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    # back in the file's coordinates: the hull is stored about its centre of mass in its principal axes, the geom carries that frame
+    return v @ R.T + gp, float(m.array("geom_rbound")[0]), gp
+
+
+def _volume_about(_, cen, hull, pts):
+    """the hull's volume as the sum of |tetrahedra| from the frame origin the compiler chose: equals the volume iff that point is inside"""
+    tri = pts[hull.simplices]
+    return np.abs(np.einsum("ij,ij->i", tri[:, 0] - cen, np.cross(tri[:, 1] - cen, tri[:, 2] - cen))).sum() / 6
 
 
 def test_convex_hull_matches_scipy_and_brute_force_support(hbmod):
@@ -74,16 +84,17 @@ def test_convex_hull_matches_scipy_and_brute_force_support(hbmod):
         pts = rng.normal(size=(n, 3)) * rng.uniform(0.05, 2.0, 3)
         if trial == 5:
             pts /= np.linalg.norm(pts, axis=1, keepdims=True)  # every point on the sphere: all of them are hull vertices
-        hv, rb = _hull_of(hbmod, pts)
+        hv, rb, cen = _hull_of(hbmod, pts)
         want = pts[np.sort(ConvexHull(pts).vertices)]
         assert len(hv) == len(want) and np.allclose(np.sort(hv, axis=0), np.sort(want, axis=0), atol=1e-12)
         dirs = rng.normal(size=(200, 3))
         assert np.allclose((hv @ dirs.T).max(0), (pts @ dirs.T).max(0), atol=1e-12)  # the support function is that of the point cloud
-        cen = 0.5 * (hv.min(0) + hv.max(0))
-        assert abs(rb - np.linalg.norm(hv - cen, axis=1).max()) < 1e-12
+        assert abs(rb - np.linalg.norm(hv - cen, axis=1).max()) < 1e-12  # the bounding sphere about the frame origin: the hull's centre of mass
+        hull = ConvexHull(pts)
+        assert abs(hull.volume - _volume_about(hv[np.argsort(np.lexsort(hv.T))], cen, hull, pts)) < 1e-9 * hull.volume
     # interior and duplicate points are dropped; a cube keeps its 8 corners
     pts = np.vstack([CUBE, CUBE * 0.5, CUBE, [[0, 0, 0]]])
-    hv, _ = _hull_of(hbmod, pts)
+    hv, _, _ = _hull_of(hbmod, pts)
     assert len(hv) == 8 and np.allclose(np.sort(hv, axis=0), np.sort(CUBE, axis=0))
 
 
@@ -158,12 +169,26 @@ def test_team_robot_compiles_with_its_hulls(hbmod):
     names = ["torso", "left_forearm_pitch_link", "left_knee_pitch_link"]
     vadr, vnum, verts = m.array("mesh_vertadr").astype(int), m.array("mesh_vertnum").astype(int), m.array("mesh_vert").reshape(-1, 3)
     for k, nm in [(0, names[0]), (3, names[1]), (6, names[2])]:
-        b = open(os.path.join(REFERENCE, "simulation/assets/humanoid_urdf", nm + ".stl"), "rb").read()
+        path = os.path.join(REFERENCE, "simulation/assets/humanoid_urdf", nm + ".stl")
+        b = open(path, "rb").read()
         n = struct.unpack("<I", b[80:84])[0]
         raw = np.frombuffer(b[84:], dtype=np.uint8).reshape(n, 50)[:, 12:48].copy().view("<f4").reshape(-1, 3).astype(np.float64)
         hv = verts[vadr[k]:vadr[k] + vnum[k]]
-        cen = 0.5 * (raw.min(0) + raw.max(0))
-        assert np.allclose((hv @ dirs.T).max(0), ((raw - cen) @ dirs.T).max(0), atol=1e-9)
+        # the mesh's frame (centre of mass, principal axes of its hull) as a geom at the body origin carries it
+        one = hbmod.Model.from_xml_string('<mujoco><asset><mesh name="m" file="%s"/></asset><worldbody><body><freejoint/><inertial pos="0 0 0" mass="1" '
+                                          'diaginertia="1 1 1"/><geom type="mesh" mesh="m"/></body></worldbody></mujoco>' % path)
+        com = one.array("geom_pos")[0:3]
+        w, x, y, z = one.array("geom_quat")[0:4]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        assert np.allclose(one.array("mesh_vert").reshape(-1, 3), hv, atol=0)
+        assert np.allclose((hv @ dirs.T).max(0), (((raw - com) @ R) @ dirs.T).max(0), atol=1e-9)  # hull support == raw STL support
+        from scipy.spatial import ConvexHull
+        hull = ConvexHull(raw)
+        tri = raw[hull.simplices]
+        cen_vol = (np.einsum("i,ij->j", np.abs(np.einsum("ij,ij->i", tri[:, 0] - raw.mean(0), np.cross(tri[:, 1] - raw.mean(0), tri[:, 2] - raw.mean(0)))),
+                             (tri.sum(1) + raw.mean(0)) / 4)) / np.abs(np.einsum("ij,ij->i", tri[:, 0] - raw.mean(0), np.cross(tri[:, 1] - raw.mean(0), tri[:, 2] - raw.mean(0)))).sum()
+        assert np.allclose(com, cen_vol, atol=1e-9)  # ... about the centre of mass of the hull (scipy's triangulation of the same hull)
         assert vnum[k] < 400
 
 
@@ -351,7 +376,7 @@ def test_reference_green_screen_world_compiles_and_stands_on_its_plane(hbmod, tm
     m.save(p)
     o = Oracle(p)
     o.reset()
-    for _ in range(1200):
+    for _ in range(2000):  # (a foot flips over once more at about step 1200 before everything is at rest)
         o.step()
     assert o.ncon >= 4 and np.abs(o.qvel).max() < 0.01
     mass = o.marr("body_mass").sum()
@@ -375,7 +400,10 @@ def test_hull_of_a_subdivided_float32_box_is_closed(hbmod):
     xml = ('<mujoco><asset><mesh name="m" vertex="%s"/></asset><worldbody><body><freejoint/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/>'
            '<geom type="mesh" mesh="m"/></body></worldbody></mujoco>' % " ".join("%.9g" % v for v in pts.reshape(-1)))
     m = hbmod.Model.from_xml_string(xml)
-    hv = m.array("mesh_vert").reshape(-1, 3) + m.array("geom_pos").reshape(-1, 3)[0]
+    w, x, y, z = m.array("geom_quat").reshape(-1, 4)[0]
+    Rg = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    hv = m.array("mesh_vert").reshape(-1, 3) @ Rg.T + m.array("geom_pos").reshape(-1, 3)[0]  # the geom's frame: centre of mass, principal axes
     assert 8 <= len(hv) <= len(pts)
     nbradr, nbrnum, nbr = m.array("mesh_nbradr").astype(int), m.array("mesh_nbrnum").astype(int), m.array("mesh_nbr").astype(int)
     assert (nbrnum >= 3).all()

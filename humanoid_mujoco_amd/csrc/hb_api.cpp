@@ -953,6 +953,13 @@ int hb_options_set(hb_model* h, const hb_options* o) {
   return HB_OK;
 }
 
+int hb_model_pair_order(hb_model* h, int order) {
+  if (!h) return HB_EINVAL;
+  if (order == 0 || order == 1) sort_pairs(h->m, order);
+  else if (order != -1) return HB_EINVAL;
+  return h->m.pair_order;
+}
+
 int hb_model_name2id(const hb_model* h, const char* kind, const char* name) {
   if (!h || !kind || !name) return -1;
   const Model& m = h->m;

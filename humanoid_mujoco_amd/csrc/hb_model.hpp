@@ -81,6 +81,11 @@ struct Model {
   // ---- names
   std::vector<std::string> body_name, jnt_name, geom_name, tendon_name, actuator_name, key_name, mesh_name;
 
+  // Order of the candidate collision pairs = order in which mj_collision emits contacts (it changes nothing physical, but PGS cut at a
+  // finite sweep count depends on it: DESIGN.md 2).  1 (what the MJCF compiler writes): body pairs ascending, inside a body pair the geoms of
+  // the first body, then those of the second - the structure of MuJoCo's collision driver, which runs its broadphase over BODIES and then
+  // walks the geoms of every body pair.  0: geom pairs ascending (rounds 1-3 of this engine; .hbm files without the field).
+  int pair_order = 0;
   std::string pair_unsupported;  // compile time only: why a colliding geom pair cannot be simulated (empty: all pairs have colliders)
 
   // ---- field visitor used by serialisation (model_io.cpp): f(name, member) for every field
@@ -91,7 +96,7 @@ struct Model {
     HB_F(timestep); HB_F(impratio); HB_F(tolerance);
     f("gravity", gravity, 3);
     HB_F(integrator); HB_F(cone); HB_F(solver); HB_F(iterations); HB_F(disableflags);
-    HB_F(meaninertia); HB_F(ls_iterations); HB_F(ls_tolerance);
+    HB_F(meaninertia); HB_F(ls_iterations); HB_F(ls_tolerance); HB_F(pair_order);
     HB_F(body_parentid); HB_F(body_rootid); HB_F(body_weldid); HB_F(body_jntnum); HB_F(body_jntadr);
     HB_F(body_dofnum); HB_F(body_dofadr); HB_F(body_geomnum); HB_F(body_geomadr); HB_F(body_depth);
     HB_F(body_pos); HB_F(body_quat); HB_F(body_ipos); HB_F(body_iquat); HB_F(body_mass);
@@ -127,6 +132,8 @@ bool compile_mjcf_string(const std::string& xml, Model& m, std::string& err);
 // mesh.cpp — STL reader and convex hull (the vertices MuJoCo's mesh collision uses)
 bool read_stl_vertices(const std::string& path, std::vector<double>& pts, std::string& err);
 bool convex_hull_vertices(const std::vector<double>& pts, std::vector<int>& hull, std::string& err, std::vector<int>* tris = nullptr);
+// re-orders the candidate pair list in place (Model::pair_order)
+void sort_pairs(Model& m, int order);
 bool mesh_mass_properties(const std::vector<double>& verts, const std::vector<int>& tris, double& volume, double com[3], double inertia[6]);
 // setconst.cpp — mj_setConst products (mujoco.h:221) computed in fp64 on the host
 bool set_const(Model& m, std::string& err);

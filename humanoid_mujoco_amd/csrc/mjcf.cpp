@@ -12,6 +12,8 @@
 #include "hb_model.hpp"
 #include "hmath.hpp"
 #include "xml_mini.hpp"
+#include <algorithm>
+#include <array>
 #include <cstring>
 #include <fstream>
 #include <set>
@@ -799,6 +801,24 @@ bool read_actuators(Ctx& c, const XmlNode& n) {
   return c.err.empty();
 }
 
+}  // namespace
+void sort_pairs(Model& m, int order) {
+  std::vector<int> idx(m.pair_geom1.size());
+  for (size_t i = 0; i < idx.size(); i++) idx[i] = (int)i;
+  auto key = [&](int p) {
+    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    const int lo = std::min(g1, g2), hi = std::max(g1, g2);
+    if (order == 0) return std::array<int, 4>{lo, hi, 0, 0};
+    const int b1 = m.geom_bodyid[lo], b2 = m.geom_bodyid[hi];  // (geoms are numbered body by body: the lower geom sits on the lower body)
+    return b1 <= b2 ? std::array<int, 4>{b1, b2, lo, hi} : std::array<int, 4>{b2, b1, hi, lo};
+  };
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(a) < key(b); });
+  veci g1(idx.size()), g2(idx.size());
+  for (size_t i = 0; i < idx.size(); i++) { g1[i] = m.pair_geom1[idx[i]]; g2[i] = m.pair_geom2[idx[i]]; }
+  m.pair_geom1.swap(g1); m.pair_geom2.swap(g2);
+  m.pair_order = order ? 1 : 0;
+}
+namespace {
 void build_pairs(Model& m) {
   m.pair_geom1.clear(); m.pair_geom2.clear();
   bool filterparent = !(m.disableflags & DSBL_FILTERPARENT);
@@ -826,6 +846,7 @@ void build_pairs(Model& m) {
       m.pair_geom2.push_back(b);
     }
   m.npair = (int)m.pair_geom1.size();
+  sort_pairs(m, 1);
 }
 
 void expand_includes(XmlNode& n, const std::string& basedir, std::string& err, int depth) {

@@ -148,6 +148,7 @@ def lib():
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
     L.hb_last_kernel.argtypes = [vp]; L.hb_last_kernel.restype = ctypes.c_char_p
     L.hb_batch_tune.argtypes = [vp, ci, ci]
+    L.hb_model_pair_order.argtypes = [vp, ci]
     L.hb_env_terminal_obs.argtypes = [vp, vp]
     L.hb_env_warnings.argtypes = [vp, vp]
     L.hb_batch_device_name.argtypes = [vp, cp, ci]
@@ -285,6 +286,14 @@ class Model:
                 setattr(o, k, v)
         _check(lib().hb_options_set(self._h, ctypes.byref(o)), "hb_options_set")
         self._read_sizes()  # (the solver selects the instantiation: contact and row capacities follow it)
+
+    def pair_order(self, order=-1):
+        """contact order of mj_collision (include/hb.h: hb_model_pair_order): 1 body pairs first (the compiler's default), 0 geom pairs
+        ascending; -1: query.  Returns the order in force."""
+        rc = lib().hb_model_pair_order(self._h, int(order))
+        if rc < 0:
+            _check(rc, "hb_model_pair_order")
+        return rc
 
     def name2id(self, kind, name):
         return lib().hb_model_name2id(self._h, kind.encode(), name.encode())

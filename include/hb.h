@@ -91,6 +91,14 @@ int hb_model_sizes(const hb_model* m, hb_sizes* out);
  * opt.timestep).  Options are copied into a batch at hb_batch_create. */
 int hb_options_get(const hb_model* m, hb_options* out);
 int hb_options_set(hb_model* m, const hb_options* in);
+/* The order in which mj_collision emits contacts = the order of the model's candidate geom pairs.  Physically irrelevant, but PGS cut at a
+ * finite sweep count depends on it (up to 4e-2 in qacc on the benchmark workload at 50 sweeps, 3e-14 for converged Newton:
+ * profiles/r03_contact_order.txt).  order 1 (what the MJCF compiler writes): body pairs ascending, then the geoms of the first and of the
+ * second body - MuJoCo's collision driver enumerates body pairs, then the geoms inside a pair (the documented structure of
+ * engine_collision_driver; the pinned MuJoCo 3.1.4 is not in the reference tree to check the details against); order 0: geom pairs
+ * ascending (this engine's rounds 1-3, and .hbm files written then).  -1: query.  Returns the order in force.  Call before
+ * hb_batch_create. */
+int hb_model_pair_order(hb_model* m, int order);
 /* mj_name2id (mujoco.h:516) for kind in {"body","joint","geom","actuator","tendon","key"}; -1 if absent. */
 int hb_model_name2id(const hb_model* m, const char* kind, const char* name);
 /* Copies a named fp64 model array (mjModel field name, e.g. "body_mass", "qpos0") into out[cap];

@@ -84,3 +84,49 @@ def test_newton_golden_states_through_the_plain_step(hbmod, gpu, golden):
     # Newton stops on a gradient norm: fp32 reaches the floor of that test an iteration or two away from fp64 on a few states
     assert niter.max() <= 30 and np.abs(niter - it_o).max() <= 3 and (niter != it_o).mean() <= 0.25, (np.abs(niter - it_o).max(), (niter != it_o).mean())
     b.close()
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_one_step_parity_in_both_contact_orders(hbmod, gpu, tmp_path, order):
+    """hb_model_pair_order: body-pair-major (1: what the compiler writes, MuJoCo's collision-driver structure) and geom-major (0: rounds 1-3)
+    contact order.  The device mirrors whichever the model carries: one step from oracle states of the benchmark's steady regime (fallen
+    humanoids: self collisions, several bodies on the floor) against the oracle on the same ordering - contacts in the same ORDER (geom
+    ids row by row), same counts, qacc / forces to the one-step tolerances.  (profiles/r04_contact_order_modes.txt: how rarely the two
+    orders differ on this model, and by how much.)"""
+    m = hbmod.Model.load(HUMANOID_HBM)
+    assert m.pair_order() == 1 and m.pair_order(order) == order
+    p = str(tmp_path / ("order%d.hbm" % order))
+    m.save(p)
+    o = Oracle(p)
+    states, ctrls = [], []
+    for e in (1, 4, 6):
+        o.init_env(e)
+        for t in range(700):
+            c = o.ctrl_env(t, e)
+            o.ctrl[:] = c
+            if t >= 300 and t % 8 == 0:
+                states.append(np.concatenate([[o.time], o.qpos, o.qvel, o.qacc_warmstart])); ctrls.append(c.copy())
+            o.step()
+    n = len(states)
+    st = np.array(states).astype(np.float32).astype(np.float64)
+    ct = np.array(ctrls, dtype=np.float32)
+    b = hbmod.Batch(m, n, gpu)
+    b.diag_enable(True)
+    b.set_state(hbmod.STATE_INTEGRATION, st)
+    b.step(ct)
+    a, f, con = b.qacc().astype(np.float64), b.efc_force().astype(np.float64), b.contacts()
+    ncon, nefc, _ = b.counts()
+    multi = 0
+    for k in range(n):
+        o.qpos[:] = st[k, 1:1 + m.nq]; o.qvel[:] = st[k, 1 + m.nq:1 + m.nq + m.nv]; o.qacc_warmstart[:] = st[k, 1 + m.nq + m.nv:]; o.ctrl[:] = ct[k]
+        o.forward()
+        cs = o.contacts()
+        assert (o.ncon, o.nefc) == (ncon[k], nefc[k])
+        assert [(int(con[k, i, 14]), int(con[k, i, 15])) for i in range(o.ncon)] == [(c["geom1"], c["geom2"]) for c in cs]
+        multi += int(o.ncon >= 4)
+        assert np.abs(a[k] - o.qacc).max() / max(1.0, np.abs(o.qacc).max()) <= 4e-4
+        if o.nefc:
+            fo = o.efc_force[:o.nefc]
+            assert np.abs(f[k, :o.nefc] - fo).max() / max(1.0, np.abs(fo).max()) <= 4e-4
+    assert multi >= 20
+    b.close()

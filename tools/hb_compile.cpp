@@ -1,5 +1,5 @@
 // hb_compile — compile an MJCF file to the .hbm text model (host only, no GPU needed).
-// usage: hb_compile in.xml out.hbm [--solver PGS|Newton] [--iterations N] [--timestep h]
+// usage: hb_compile in.xml out.hbm [--solver PGS|Newton] [--iterations N] [--timestep h] [--pair-order body|geom]
 // (the options override mjOption after compilation: the committed benchmark model carries the benchmark's PGS / 50)
 #include "../humanoid_mujoco_amd/csrc/hb_model.hpp"
 #include <cstdio>
@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
       else { fprintf(stderr, "error: unknown solver %s\n", argv[i + 1]); return 2; }
     } else if (!strcmp(argv[i], "--iterations")) m.iterations = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--timestep")) m.timestep = atof(argv[i + 1]);
+    else if (!strcmp(argv[i], "--pair-order")) hb::sort_pairs(m, !strcmp(argv[i + 1], "geom") ? 0 : 1);
     else { fprintf(stderr, "error: unknown option %s\n", argv[i]); return 2; }
   }
   if (!hb::save_hbm(m, argv[2], err)) { fprintf(stderr, "error: %s\n", err.c_str()); return 1; }

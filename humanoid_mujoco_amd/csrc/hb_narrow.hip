@@ -159,18 +159,31 @@ __global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, 
 // there are as many of them as the chip holds at once; packing the searches of all envs densely into waves (a prefix sum over the
 // per-env counts, 64 / 16 / 4 searches per wave, one kernel per kind of search) measured slower: a wave's time is set by its
 // longest search and the divergence between its lanes, not by how many lanes it has.
-template <int MESH>
+// PAIR = 1: TWO envs per wave (lanes 0..31: one env's searches, 32..63: the other's; thirty-two searches of each per chunk).  A wave's time is
+// the latency of one portal search - a chain of dependent fp64 operations and table loads - plus a little for every further search that
+// runs beside it (55 k cycles + 5 k per search on the lying robot, profiles/r04_team_counters.json: 2.7 of 64 lanes active per vector
+// instruction with one env per wave).  Half the waves, each a quarter longer: an unpipelined step of 4096 robots takes 233 us instead of
+// 267.  But the launch then is ONE round of waves and lasts as long as its slowest (a hull - hull search of 200 k cycles), which pipelined
+// segments no longer hide: 226 us against 212 - so launch_pose_narrow takes this form only for a launch that covers its whole batch
+// (profiles/r04_narrow_pairs.txt).
+template <int MESH, int PAIR = 0>
 __device__ __forceinline__ void narrow_body(const DevModel* Mp, const BatchPtrs& P) {
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
   const int lane = threadIdx.x;
   // heavy first (BatchPtrs::order2: the envs of this launch sorted by the time their wave took in an earlier step): the launch ends
   // when its slowest wave does, and a slow wave that starts in the last round ends late
-  const int chunk = (int)blockIdx.x / P.nblk, slot = P.blk0 + (int)blockIdx.x % P.nblk;
-  const int env = P.order2 ? P.order2[slot] : slot;
+  constexpr int kPer = PAIR ? 32 : kGroup;  // searches of an env per chunk
+  const int nslot = PAIR ? (P.nblk + 1) >> 1 : P.nblk;
+  const int chunk = (int)blockIdx.x / nslot, pr = (int)blockIdx.x % nslot;
+  const int half = PAIR ? lane >> 5 : 0, l = PAIR ? lane & 31 : lane;
+  const int slot = P.blk0 + (PAIR ? 2 * pr + half : pr);
+  const bool live = !PAIR || 2 * pr + half < P.nblk;
+  const int env = live ? (P.order2 ? P.order2[slot] : slot) : 0;
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-  const int n1 = P.stage.nsearch[2 * env], n2 = P.stage.nsearch[2 * env + 1];
-  const int j = chunk * kGroup + lane;
-  if (chunk * kGroup >= n1 + n2) { if (chunk == 0 && lane == 0) P.counts[kCountStride * (size_t)env + 7] = 0; return; }
+  const int n1 = live ? P.stage.nsearch[2 * env] : 0, n2 = live ? P.stage.nsearch[2 * env + 1] : 0;
+  const int j = chunk * kPer + l;
+  if (chunk == 0 && l == 0 && live) P.counts[kCountStride * (size_t)env + 7] = 0;
+  if (!__any(chunk * kPer < n1 + n2)) return;
   const bool have = j < n1 + n2;
   int4 it = {env, 0, 1 << 16, 0};
   if (have) it = P.stage.item[(size_t)env * kWorkMax + (j < n1 ? j : kWorkMax - 1 - (j - n1))];
@@ -190,16 +203,25 @@ __device__ __forceinline__ void narrow_body(const DevModel* Mp, const BatchPtrs&
     R[2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
     R[3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(p)};
   }
-  if (chunk == 0 && lane == 0) P.counts[kCountStride * (size_t)env + 7] = (int)min(255ull, (__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+  // (the cost the heavy-first order of the next launches sorts by: the time of the env's - first - wave)
+  if (chunk == 0 && l == 0 && live) P.counts[kCountStride * (size_t)env + 7] = (int)min(255ull, (__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 __global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<1>(Mp, P); }
 // a model without mesh geoms (configs[4]: capsules and spheres over the height field's prisms): no hull climb in the kernel
 __global__ __launch_bounds__(kGroup, 3) void hb_narrow_prim_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<0>(Mp, P); }
+// two envs per wave (narrow_body's PAIR): the unpipelined launches
+__global__ __launch_bounds__(kGroup, 2) void hb_narrow2_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<1, 1>(Mp, P); }
+__global__ __launch_bounds__(kGroup, 3) void hb_narrow2_prim_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<0, 1>(Mp, P); }
 
 hipError_t launch_pose_narrow(const DevModel* M_dev, const BatchPtrs& Q, hipStream_t stream) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(hb_pose_kernel, dim3(Q.nblk), dim3(kGroup), (size_t)Q.stage.pose_lds, stream, M_dev, Q);
-  if (Q.stage.no_mesh) hipLaunchKernelGGL(hb_narrow_prim_kernel, dim3(Q.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
+  const bool pairs = Q.nblk == Q.n_env && Q.n_env >= 512;  // a launch that covers its whole batch: nothing overlaps its tail anyway
+  if (pairs) {
+    const dim3 grid(((Q.nblk + 1) / 2) * (kWorkMax / 32));
+    if (Q.stage.no_mesh) hipLaunchKernelGGL(hb_narrow2_prim_kernel, grid, dim3(kGroup), 0, stream, M_dev, Q);
+    else hipLaunchKernelGGL(hb_narrow2_kernel, grid, dim3(kGroup), 0, stream, M_dev, Q);
+  } else if (Q.stage.no_mesh) hipLaunchKernelGGL(hb_narrow_prim_kernel, dim3(Q.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
   else hipLaunchKernelGGL(hb_narrow_kernel, dim3(Q.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
   return hipGetLastError();
 }

@@ -1,7 +1,8 @@
+mkdir -p ${OUT:-gpurun_out/duo_sizes}
 for n in 2048 4096 8192 16384 32768; do
   for duo in 1 0; do
-    HB_DUO=$duo timeout -k 10 200 python bench.py --steps 300 --warmup 20 --envs-per-gpu $n --no-cpu-baseline --no-team --no-newton --no-rollout > gpurun_out/r04h/b_${n}_$duo.json 2> gpurun_out/r04h/b_${n}_$duo.err
+    HB_DUO=$duo timeout -k 10 200 python bench.py --steps 300 --warmup 20 --envs-per-gpu $n --no-cpu-baseline --no-team --no-newton --no-rollout > ${OUT:-gpurun_out/duo_sizes}/b_${n}_$duo.json 2> ${OUT:-gpurun_out/duo_sizes}/b_${n}_$duo.err
     python -c "
-import json; d=json.load(open('gpurun_out/r04h/b_${n}_$duo.json')); print('envs $n duo $duo: %.3e env-steps/s, %.1f us/step pipelined, %.1f us unpipelined launch' % (d['value'], 1e3*d['ms_per_step'], d['roofline']['avg_launch_us']))"
+import json; d=json.load(open('${OUT:-gpurun_out/duo_sizes}/b_${n}_$duo.json')); print('envs $n duo $duo: %.3e env-steps/s, %.1f us/step pipelined, %.1f us unpipelined launch' % (d['value'], 1e3*d['ms_per_step'], d['roofline']['avg_launch_us']))"
   done
 done

@@ -10,6 +10,7 @@ import humanoid_mujoco_amd as hb
 m = hb.Model.load(os.path.join(ROOT, "humanoid_mujoco_amd", "assets", sys.argv[2] if len(sys.argv) > 2 else "humanoid27.hbm"))
 N = 4096
 b = hb.Batch(m, N, 0)
+b.tune(duo=int(os.environ.get("PHASE_DUO", "0")))  # 2: hb_step_duo_kernel (two envs per wave), 0: hb_step_h27_kernel
 b.reset(perturb=True)
 b.rollout_halton(600)
 b.sync()

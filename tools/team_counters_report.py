@@ -2,7 +2,7 @@
 """Per-kernel summary of tools/gpu_team_counters.sh's rocprofv3 passes (means over the steady single-step launches)."""
 import collections, csv, glob, json, os, sys
 out = sys.argv[1]
-KERNELS = ("hb_narrow_kernel", "hb_narrow_prim_kernel", "hb_pose_kernel", "hb_step_newton_gen20_team_kernel", "hb_step_newton_big20_kernel")
+KERNELS = tuple(sys.argv[2:]) or ("hb_narrow_kernel", "hb_narrow2_kernel", "hb_narrow_prim_kernel", "hb_pose_kernel", "hb_step_newton_gen20_team_kernel", "hb_step_newton_big20_kernel")
 
 
 def short(name):
@@ -13,17 +13,20 @@ def short(name):
 
 
 res = collections.defaultdict(dict)
+GRID = int(os.environ.get("REPORT_GRID", "0"))  # only dispatches of this grid size (threads), e.g. the unpipelined single-step launches
 tr = glob.glob(os.path.join(out, "trace", "*kernel_trace.csv")) or glob.glob(os.path.join(out, "trace", "*", "*kernel_trace.csv"))
 if tr:
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(tr[0])):
         k = short(r["Kernel_Name"])
         if k:
+            if GRID and int(r.get("Grid_Size") or r["Grid_Size_X"]) != GRID:
+                continue
             d[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     for k, v in d.items():
         v = sorted(v)[: max(1, len(v) - 1)]  # (the 150-step settle launch of the rollout is not a per-step launch)
         res[k]["launches"] = len(v); res[k]["avg_us"] = 1e-3 * sum(v) / len(v)
-for sub in ("sq", "valu", "mem", "hbm"):
+for sub in ("sq", "valu", "mem", "hbm", "mfma"):
     fs = glob.glob(os.path.join(out, sub, "*counter_collection.csv")) or glob.glob(os.path.join(out, sub, "*", "*counter_collection.csv"))
     if not fs:
         continue
@@ -32,6 +35,8 @@ for sub in ("sq", "valu", "mem", "hbm"):
     for r in csv.DictReader(open(fs[0])):
         k = short(r["Kernel_Name"])
         if k:
+            if GRID and int(r["Grid_Size"]) != GRID:
+                continue
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = {x: r[x] for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "LDS_Block_Size", "Grid_Size", "Workgroup_Size") if x in r}
     for k, cs in agg.items():
@@ -50,6 +55,10 @@ for k, r in res.items():
         for c in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
             if c in r:
                 r[c.lower() + "_frac_of_wave_cycles"] = r[c] / r["SQ_WAVE_CYCLES"]
+    if r.get("SQ_INSTS_VALU_MFMA_MOPS_F32") is not None and r.get("SQ_BUSY_CU_CYCLES"):
+        r["mfma_busy_frac_of_busy_cu_cycles"] = r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / r["SQ_BUSY_CU_CYCLES"]
+    if r.get("SQ_ACTIVE_INST_VALU") and r.get("SQ_BUSY_CU_CYCLES"):
+        r["valu_pipe_busy_frac"] = r["SQ_ACTIVE_INST_VALU"] / r["SQ_BUSY_CU_CYCLES"]
     if "FETCH_SIZE" in r:
         r["hbm_bytes_per_launch"] = {"fetch_raw": 1024 * r["FETCH_SIZE"], "fetch_x2_gfx950": 2048 * r["FETCH_SIZE"], "write": 1024 * r.get("WRITE_SIZE", 0)}
 print(json.dumps(res, indent=1, sort_keys=True))

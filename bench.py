@@ -202,6 +202,8 @@ def main():
     ap.add_argument("--no-newton", action="store_true", help="skip the third measurement (same workload with the reference's default solver, Newton)")
     ap.add_argument("--no-team", action="store_true", help="skip the fourth measurement (the reference's own robot, assets/team_robot.hbm)")
     ap.add_argument("--no-pipeline", action="store_true", help="time the unpipelined step API (one launch per step) as `value`")
+    ap.add_argument("--duo", type=int, default=None, choices=(0, 1, 2), help="two envs per wave (hb_batch_tune HB_TUNE_DUO): 1 where it pays (default), 0 never, 2 always - the "
+                    "counter passes of tools/gpu_round.sh hold the unpipelined launches to one kernel with it")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction only, no GPU work (CPU rehearsal of the N>1 path with HB_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
 
@@ -275,6 +277,8 @@ def main():
         ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(ndev))
         device = local_rank % max(1, ndev.value)
     batch = hb.Batch(model, n_env, device)  # raises without a GPU: no CPU fallback
+    duo_default = args.duo if args.duo is not None else int(os.environ.get("HB_DUO", "1"))
+    batch.tune(duo=duo_default)
     nu = model.nu
     # controls for every timed step live in HBM, generated there (testspeed.cc:64-80); step indices continue behind the pre-roll
     ctrl = batch.dev_alloc((K + W) * n_env * nu * 4)
@@ -332,7 +336,7 @@ def main():
         batch.step_dev(ctrl + (W + t) * stride)
     launch_us = 1e3 * batch.timer_stop() / KR
     roofline_kernel = batch.last_kernel()
-    batch.tune(duo=1)
+    batch.tune(duo=duo_default)
 
     # Second measurement, reported beside `value`: the same K steps as ONE hb_rollout_dev launch (state
     # resident on chip, each env advancing through its own K steps without a per-step batch barrier) —
@@ -404,6 +408,24 @@ def main():
                 "mean_newton_iterations": float(tni.mean()), "portal_searches_per_env": float(tns.mean()), "envs_with_warnings": int((tb.status() != 0).sum()),
                 "what": "the reference's own robot (assets/team_robot.hbm: 18 dofs, 9 mesh hulls, condim 6, 8 x 8 height field, Newton), %d envs, staged step "
                         "(pose, narrowphase, step kernels), same step API and pipelining as `value`" % n_env}
+        team["kernel"] = tb.last_kernel()
+        # roofline of the robot's dominant kernel, the narrowphase launch (48 % of its step): per env-step it reads the geoms' world poses
+        # (40 B x 13 geoms) and its work items (16 B each) and writes one result record per item (64 B); times and lane utilisation from
+        # the committed rocprofv3 passes (tools/gpu_team_counters.sh), not from this run
+        try:
+            tc = json.load(open(os.path.join(ROOT, "profiles", "team_counters_latest.json")))
+            nk = tc.get("hb_narrow_kernel") or {}
+            algo = n_env * (40 * tm.ngeom + (16 + 64) * float(tnw.mean()))
+            if nk.get("avg_us"):
+                team["roofline"] = {"bound": "hbm", "kernel": "hb_narrow_kernel", "achieved": algo / (nk["avg_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": algo / (nk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": nk["avg_us"], "algorithmic_bytes_per_launch": algo,
+                                    "traffic": (nk.get("hbm_bytes_per_launch") or {}).get("fetch_x2_gfx950", 0) + (nk.get("hbm_bytes_per_launch") or {}).get("write", 0) or None,
+                                    "active_lanes_per_valu_instruction": nk.get("active_lanes_per_valu_instruction"),
+                                    "wait_inst_frac_of_wave_cycles": nk.get("sq_wait_inst_any_frac_of_wave_cycles"),
+                                    "note": "a portal search is one dependent chain of fp64 operations and table loads per lane: latency x wave slots bound, 2.7 of 64 lanes active (DESIGN.md 3.6)",
+                                    "source": "committed profile, not this run: profiles/team_counters_latest.json (tools/gpu_team_counters.sh)"}
+        except Exception:
+            pass
         tb.dev_free(tctrl)
         tb.close()
         # the same at the batch size that fills the chip under the narrowphase's latency chain (the robot against the batch size)

@@ -13,6 +13,7 @@ def is_step(name):
     """the benchmark's single-step launches: the size-specialised lean instantiation of the PGS step kernel (hb_step_lean_kernel for other models; hb_step_kernel before they existed, and in
     launches that carry an optional input or output)"""
     return "hb_step_h27_kernel(" in name or "hb_step_lean_kernel(" in name or "hb_step_kernel(" in name
+    # (hb_step_duo_kernel, two envs per wave, has its own passes: tools/gpu_duo_counters.sh -> profiles/<round>_counters_duo.json)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
@@ -112,6 +113,10 @@ if fv:
 json.dump(out, open(os.path.join(dst, rnd + "_counters.json"), "w"), indent=1)
 if "valu_issue_frac_of_peak" in out and os.path.exists(os.path.join(dst, "traffic_latest.json")):
     latest = json.load(open(os.path.join(dst, "traffic_latest.json")))
+    # the launches of the TIMED loop: env segments (grids smaller than the whole batch) of the same kernel, from the kernel trace of the bench command
+    seg = {g: v for g, v in by_grid.items() if g != full and len(v) >= 10}
+    if seg:
+        latest["segment_launch_us"] = {str(g // 64) + " envs": 1e-3 * sum(v) / len(v) for g, v in sorted(seg.items())}
     latest["valu_issue_frac_of_peak"] = out["valu_issue_frac_of_peak"]
     latest["avg_launch_ns_kernel_trace"] = avg_ns
     if "hbm" in out:
@@ -142,7 +147,7 @@ if tn:
     st2 = glob.glob(os.path.join(src, "prof_trace_newton", "*", "*_kernel_stats.csv"))
     if st2:
         shutil.copy(st2[0], os.path.join(dst, rnd + "_kernel_stats_solvers.csv"))
-for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("pipeline_sweep.txt", rnd + "_pipeline_sweep.txt"), ("vecenv.txt", rnd + "_vecenv.txt"), ("soak.txt", rnd + "_soak.txt"), ("soak_newton.txt", rnd + "_soak_newton.txt"), ("pgs_fit.txt", rnd + "_pgs_fit.txt"), ("planner.txt", rnd + "_planner.txt"), ("mpc_demo.txt", rnd + "_mpc_demo.txt"), ("latency.txt", rnd + "_latency.txt"), ("drift_nocontact.txt", rnd + "_drift_nocontact.txt"), ("parity_report_newton.txt", rnd + "_parity_report_newton.txt"), ("newton_bench.txt", rnd + "_newton_bench.txt"), ("newton_phases.txt", rnd + "_newton_phases.txt"), ("newton_sections.txt", rnd + "_newton_sections.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("testspeed_newton.log", rnd + "_testspeed_newton.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt"), ("team_bench.txt", rnd + "_team_bench.txt"), ("phase_config5.txt", rnd + "_phase_config5.txt"), ("phase_team.txt", rnd + "_phase_team.txt"), ("phase_team_fused.txt", rnd + "_phase_team_fused.txt"), ("pipeline_queues.txt", rnd + "_pipeline_queues.txt"), ("phase_instructions.txt", rnd + "_phase_instructions.txt"), ("soak_pipelined.txt", rnd + "_soak_pipelined.txt"), ("config4_physics_only.txt", rnd + "_config4_physics_only.txt"), ("testspeed_stages.log", rnd + "_testspeed_stages.txt"), ("testspeed_team.log", rnd + "_testspeed_team.txt"), ("team_short.txt", rnd + "_team_short.txt"), ("bench_two_lane.json", rnd + "_bench_two_lane.json"), ("small_kernel_occupancy.txt", rnd + "_small_kernel_occupancy.txt"),
+for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("pipeline_sweep.txt", rnd + "_pipeline_sweep.txt"), ("vecenv.txt", rnd + "_vecenv.txt"), ("soak.txt", rnd + "_soak.txt"), ("soak_newton.txt", rnd + "_soak_newton.txt"), ("pgs_fit.txt", rnd + "_pgs_fit.txt"), ("planner.txt", rnd + "_planner.txt"), ("mpc_demo.txt", rnd + "_mpc_demo.txt"), ("latency.txt", rnd + "_latency.txt"), ("drift_nocontact.txt", rnd + "_drift_nocontact.txt"), ("parity_report_newton.txt", rnd + "_parity_report_newton.txt"), ("newton_bench.txt", rnd + "_newton_bench.txt"), ("newton_phases.txt", rnd + "_newton_phases.txt"), ("newton_sections.txt", rnd + "_newton_sections.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("testspeed_newton.log", rnd + "_testspeed_newton.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt"), ("team_bench.txt", rnd + "_team_bench.txt"), ("phase_config5.txt", rnd + "_phase_config5.txt"), ("phase_team.txt", rnd + "_phase_team.txt"), ("phase_team_fused.txt", rnd + "_phase_team_fused.txt"), ("pipeline_queues.txt", rnd + "_pipeline_queues.txt"), ("phase_instructions.txt", rnd + "_phase_instructions.txt"), ("soak_pipelined.txt", rnd + "_soak_pipelined.txt"), ("config4_physics_only.txt", rnd + "_config4_physics_only.txt"), ("testspeed_stages.log", rnd + "_testspeed_stages.txt"), ("testspeed_team.log", rnd + "_testspeed_team.txt"), ("team_short.txt", rnd + "_team_short.txt"), ("duo_sizes.txt", rnd + "_duo_sizes.txt"), ("vecenv_sb3.txt", rnd + "_vecenv_sb3.txt"), ("step_latency_dist.txt", rnd + "_step_latency_dist.txt"),
                 ("prof_team/t_kernel_stats.csv", rnd + "_kernel_stats_team.csv"), ("prof_config5/t_kernel_stats.csv", rnd + "_kernel_stats_config5.csv")):
     p = os.path.join(src, f)
     if os.path.exists(p):

@@ -5,7 +5,7 @@
 OUT=$1; export HB_DUO=$2; K=$3; export REPORT_GRID=$4
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline"
+B="python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo $HB_DUO"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > $OUT/trace.txt 2>&1; echo "trace rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq -o t -- $B > $OUT/sq.txt 2>&1; echo "sq rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/valu -o t -- $B > $OUT/valu.txt 2>&1; echo "valu rc=$?"

@@ -24,14 +24,14 @@ timeout -k 10 300 ./build/hb_testspeed_stamps humanoid_mujoco_amd/assets/humanoi
 echo "== rocprofv3 kernel trace" | tee -a $OUT/progress.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- python3 bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-rollout --no-newton --no-team > $OUT/prof_trace.log 2>&1; echo "trace rc=$?" | tee -a $OUT/progress.log
 echo "== rocprofv3 pmc FETCH" | tee -a $OUT/progress.log
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline > $OUT/prof_fetch.log 2>&1; echo "fetch rc=$?" | tee -a $OUT/progress.log
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline > $OUT/prof_write.log 2>&1; echo "write rc=$?" | tee -a $OUT/progress.log
-timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/prof_sq -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline > $OUT/prof_sq.log 2>&1; echo "sq rc=$?" | tee -a $OUT/progress.log
-timeout -k 10 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_lds -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline > $OUT/prof_lds.log 2>&1; echo "lds rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_fetch.log 2>&1; echo "fetch rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_write.log 2>&1; echo "write rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/prof_sq -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_sq.log 2>&1; echo "sq rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_lds -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_lds.log 2>&1; echo "lds rc=$?" | tee -a $OUT/progress.log
 # real lane utilisation of the VALU instructions (SQ_INSTS_VALU counts a wave instruction whatever its EXEC mask): thread-cycles over
 # instruction-cycles = active lanes per VALU instruction (63.7 on the full-wave kernels of the same pass) - collect_profiles.py
-timeout -k 10 600 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/prof_valu -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline > $OUT/prof_valu.log 2>&1; echo "valu rc=$?" | tee -a $OUT/progress.log
-timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/prof_mfma -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline > $OUT/prof_mfma.log 2>&1; echo "mfma rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 600 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/prof_valu -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_valu.log 2>&1; echo "valu rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/prof_mfma -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_mfma.log 2>&1; echo "mfma rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_pipeline_sweep.py > $OUT/pipeline_sweep.txt 2>&1; echo "sweep rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_phase_profile.py 4096 > $OUT/phase_profile.txt 2>&1; echo "phase rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_phase_profile.py 4096 humanoid27_hfield.hbm > $OUT/phase_config5.txt 2>&1; timeout -k 10 200 python tools/gpu_phase_profile.py 4096 team_robot.hbm > $OUT/phase_team.txt 2>&1; timeout -k 10 400 python tools/gpu_pipeline_queues.py default GPU_MAX_HW_QUEUES=8 GPU_MAX_HW_QUEUES=16 > $OUT/pipeline_queues.txt 2>&1; timeout -k 10 900 bash tools/gpu_phase_instructions.sh $OUT/phase_inst > $OUT/phase_instructions.txt 2>&1

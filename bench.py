@@ -7,11 +7,16 @@ state and controls already resident in HBM.  Before anything is timed every env 
 PREROLL (600) untimed steps of the same workload, so that a short timed window (the driver runs
 --steps 20) samples the steady regime — the humanoids on the floor, about ten constraint rows per
 env — and not the contact-free fall that follows the reset.  The CPU leg times the same window.
-The timed loop runs with hb_batch_pipeline on: each call enqueues the batch as three env segments on
-three streams (two if they cannot have a hardware queue each), so the slow tail of one step overlaps the next (same results,
-tests/test_gpu_parity.py::test_pipelined_stepping_is_bit_identical).  The roofline object is
-measured on a second, unpipelined leg (one 4096-block launch per step, HIP events on the launch
-stream) so that it is a per-launch figure comparable with the rocprofv3 kernel trace.
+The timed loop runs with hb_batch_pipeline on.  Its K hb_step_dev calls are enqueued back to back, nothing else in between - the
+reference's own loop, mj_step after mj_step (simulation/mujoco/sample/testspeed.cc:93-96) - and for this workload the library runs such
+calls as launches of up to 256 steps of the two-envs-per-wave kernel, step t on the controls of call t (include/hb.h: hb_step_dev;
+same states bit for bit, tests/test_gpu_fold.py): no env waits for the batch's slowest one between steps.  The roofline object is then
+those launches themselves: they run one after the other on the batch's stream, so the HIP events around the timed region divided by
+their number (hb_batch_step_launches) is the launch duration the rocprofv3 kernel trace shows.  Where the library does not fold (fewer
+envs, other models, --duo 0, --no-pipeline) each call enqueues the batch as three env segments on three streams, so that the slow tail
+of one step overlaps the next (tests/test_gpu_parity.py::test_pipelined_stepping_is_bit_identical), and the roofline object is measured
+on a second, unpipelined leg (one launch per step, HIP events on the launch stream) - which is always run and reported as
+roofline.single_step.
 
 Launching.  `python3 bench.py --gpus N`: with WORLD_SIZE unset the parent process — before it makes
 any HIP or torch call — starts N children of itself, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
@@ -179,12 +184,16 @@ def cpu_baseline(target_seconds=12.0):
             "mean_nefc": st["mean_nefc"]}
 
 
-def load_traffic():
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (or None)."""
+def load_traffic(kernel=None):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (or None).  The file's top level is the one-env-per-wave
+    single-step kernel's (hb_step_h27_kernel, as in rounds 1-3); "by_kernel" holds the passes of the other kernels the timed loop can run."""
     p = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p))
+            d = json.load(open(p))
+            if kernel and kernel in d.get("by_kernel", {}):
+                return d["by_kernel"][kernel]
+            return None if (kernel and d.get("kernel", "hb_step_h27_kernel") != kernel) else d
         except Exception:
             return None
     return None
@@ -204,6 +213,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="time the unpipelined step API (one launch per step) as `value`")
     ap.add_argument("--duo", type=int, default=None, choices=(0, 1, 2), help="two envs per wave (hb_batch_tune HB_TUNE_DUO): 1 where it pays (default), 0 never, 2 always - the "
                     "counter passes of tools/gpu_round.sh hold the unpipelined launches to one kernel with it")
+    ap.add_argument("--fold", type=int, default=None, help="most hb_step_dev calls the library may run as one launch (hb_batch_tune HB_TUNE_FOLD; default: the library's, 256); "
+                    "1 = one launch per call on three env segments, the timed loop of rounds 1-3")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / reduction only, no GPU work (CPU rehearsal of the N>1 path with HB_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
 
@@ -279,6 +290,8 @@ def main():
     batch = hb.Batch(model, n_env, device)  # raises without a GPU: no CPU fallback
     duo_default = args.duo if args.duo is not None else int(os.environ.get("HB_DUO", "1"))
     batch.tune(duo=duo_default)
+    if args.fold is not None:
+        batch.tune(fold=args.fold)
     nu = model.nu
     # controls for every timed step live in HBM, generated there (testspeed.cc:64-80); step indices continue behind the pre-roll
     ctrl = batch.dev_alloc((K + W) * n_env * nu * 4)
@@ -306,6 +319,7 @@ def main():
     for t in range(W):
         batch.step_dev(ctrl + t * stride)
     barrier()
+    launches0 = batch.step_launches()
     batch.timer_start()
     t0 = time.perf_counter()
     for t in range(W, W + K):
@@ -314,19 +328,24 @@ def main():
     batch.sync()
     elapsed_own = elapsed = time.perf_counter() - t0
     timed_kernel = batch.last_kernel()  # what the library says the timed loop's launches ran (include/hb.h: hb_last_kernel)
+    # the library runs step calls enqueued back to back as one launch of up to 256 steps where that pays (include/hb.h: hb_step_dev)
+    timed_launches = batch.step_launches() - launches0
+    folded = 0 < timed_launches < K
     if dist is not None:
         elapsed = reduce_max(elapsed)
         dist.barrier()
-    ranks = gather({"rank": rank, "elapsed_s": elapsed_own, "value": n_env * K / elapsed_own, "device": batch.device_name(), "segments": nseg, "envs": [lo, hi],
-                    "kernel": timed_kernel})
+    ranks = gather({"rank": rank, "elapsed_s": elapsed_own, "value": n_env * K / elapsed_own, "device": batch.device_name(), "segments": 1 if folded else nseg, "envs": [lo, hi],
+                    "kernel": timed_kernel, "launches": timed_launches})
     status = batch.status()
     nc, ne, ni = batch.counts()
 
     # Roofline leg: the dominant kernel as ONE launch per step (all 4096 envs), unpipelined, continuing from
     # the state the timed loop left; HIP events around KR back-to-back launches on the launch stream.
+    # (When the timed loop's calls were folded into multi-step launches, those launches ARE the roofline object's - they run back to back
+    # on the batch's stream, inside the HIP events of the timed region - and this leg is reported beside them as `single_step`.)
     batch.pipeline(False)
     # (the library picks the kernel of a step call by the launch's shape: hold it to the one the timed loop ran)
-    batch.tune(duo=2 if timed_kernel == "hb_step_duo_kernel" else 0)
+    batch.tune(duo=2 if "duo" in timed_kernel else 0)
     KR = min(K, 200)
     for t in range(5):
         batch.step_dev(ctrl + (W + min(t, K - 1)) * stride)
@@ -452,8 +471,24 @@ def main():
 
     if rank == 0:
         value = n_env * world * K / elapsed
-        achieved = ALGO_BYTES_PER_ENV_STEP * n_env / (launch_us * 1e-6) / 1e9
-        traffic = load_traffic()
+        single_step = {"kernel": roofline_kernel, "avg_launch_us": launch_us, "launches": KR,
+                       "achieved": ALGO_BYTES_PER_ENV_STEP * n_env / (launch_us * 1e-6) / 1e9,
+                       "launch_shape": ("%d blocks x 64 lanes, two envs per block, one step per launch, unpipelined" % ((n_env + 1) // 2)) if "duo" in roofline_kernel
+                                       else "%d blocks x 64 lanes, one env per block, one step per launch, unpipelined" % n_env}
+        if folded:
+            steps_per_launch = K / timed_launches
+            roofline_kernel = timed_kernel
+            launch_us = 1e3 * region_ms / timed_launches
+            algo_per_launch = ALGO_BYTES_PER_ENV_STEP * n_env * steps_per_launch
+            KR = timed_launches
+            launch_shape = "%d blocks x 64 lanes, two envs per block, %s steps per launch (the timed loop's hb_step_dev calls, folded), one launch after the other on the batch's stream" % (
+                (n_env + 1) // 2, ("%d" % steps_per_launch) if steps_per_launch == int(steps_per_launch) else ("%.1f" % steps_per_launch))
+        else:
+            steps_per_launch = 1
+            algo_per_launch = ALGO_BYTES_PER_ENV_STEP * n_env
+            launch_shape = single_step["launch_shape"] + " leg"
+        achieved = algo_per_launch / (launch_us * 1e-6) / 1e9
+        traffic = load_traffic(roofline_kernel)
         out = {
             "metric": "env-steps/sec (whole node), 27-DoF humanoid, 4096 envs/GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -463,20 +498,23 @@ def main():
             "config": {"workload": "configs[1]: %d parallel humanoid envs per GPU, Halton random actions, fp32, PGS<=50 iters tol 1e-8, dt 0.005, one mj_step of every env per "
                                    "hb_step_dev call%s; every env pre-rolled %d untimed steps from the perturbed reset (steady regime: fallen humanoids, ~10 constraint rows), "
                                    "then %d warm-up and %d timed steps"
-                                   % (n_env, (" (pipelined: %d env segments on %d streams)" % (nseg, nseg)) if pipelined else "", PRE, W, K),
+                                   % (n_env, (" (the %d calls enqueued back to back, which the library ran as %d launches of the two-envs-per-wave kernel: include/hb.h hb_step_dev)" % (K, timed_launches)) if folded
+                                      else (" (pipelined: %d env segments on %d streams)" % (nseg, nseg)) if pipelined else "", PRE, W, K),
                        "model": "27-DoF humanoid (assets/humanoid27.hbm)", "envs_per_gpu": n_env, "global_envs": n_env * world, "preroll_steps": PRE,
                        "sharding": "env blocks by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                         "kernel": roofline_kernel, "avg_launch_us": launch_us, "launches": KR,
-                         "launch_shape": ("%d blocks x 64 lanes, two envs per block, unpipelined leg" % ((n_env + 1) // 2)) if "duo" in roofline_kernel
-                                         else "%d blocks x 64 lanes, one env per block, unpipelined leg" % n_env,
-                         # the launches the TIMED loop makes: the same kernel, cut into env segments on their own streams
-                         "timed_shape": {"kernel": timed_kernel, "segments": nseg, "envs_per_segment": [n_env * (c + 1) // nseg - n_env * c // nseg for c in range(nseg)],
-                                         "ms_per_step": 1e3 * elapsed / K,
-                                         "segment_launch_us_from_profile": (traffic or {}).get("segment_launch_us")},
+                         "traffic": ((traffic or {}).get("hbm_bytes_per_step") * steps_per_launch) if (traffic or {}).get("hbm_bytes_per_step") else (traffic or {}).get("hbm_bytes_per_launch"),
+                         "kernel": roofline_kernel, "avg_launch_us": launch_us, "launches": KR, "steps_per_launch": steps_per_launch,
+                         "launch_shape": launch_shape,
+                         # the launches the TIMED loop makes
+                         "timed_shape": ({"kernel": timed_kernel, "launches": timed_launches, "steps_per_launch": steps_per_launch, "segments": 1, "ms_per_step": 1e3 * elapsed / K,
+                                          "what": "the roofline object's own launches: HIP events around the timed region / launches"} if folded else
+                                         {"kernel": timed_kernel, "launches": timed_launches, "segments": nseg, "envs_per_segment": [n_env * (c + 1) // nseg - n_env * c // nseg for c in range(nseg)],
+                                          "ms_per_step": 1e3 * elapsed / K,
+                                          "segment_launch_us_from_profile": (traffic or {}).get("segment_launch_us")}),
+                         "single_step": single_step,
                          "timed_region_ms_per_step": region_ms / K,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_env,
+                         "algorithmic_bytes_per_launch": algo_per_launch,
                          "note": "path is latency/VALU bound, not HBM bound (SURVEY.md §8d); see DESIGN.md"},
             "state_check": {"envs_with_warnings": int((status != 0).sum()), "mean_ncon": float(nc.mean()), "mean_nefc": float(ne.mean()),
                             "mean_pgs_iters": float(ni.mean())},
@@ -490,6 +528,8 @@ def main():
                     out["roofline"][k] = traffic[k]
             if "avg_launch_ns_kernel_trace" in traffic:  # (the profile's own launch time: `achieved` of that run, for comparison with this one)
                 out["roofline"]["profile_avg_launch_us"] = 1e-3 * traffic["avg_launch_ns_kernel_trace"]
+            if "us_per_step_kernel_trace" in traffic:  # (multi-step launches: the kernel trace's duration of the timed launches / their steps)
+                out["roofline"]["profile_us_per_step"] = traffic["us_per_step_kernel_trace"]
         if elapsed_rollout is not None:
             out["rollout"] = {"value": n_env * world * K / elapsed_rollout, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed_rollout / K,
                               "kernel": rollout_kernel,

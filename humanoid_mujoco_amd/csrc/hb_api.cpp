@@ -640,7 +640,11 @@ struct hb_batch {
   long long launch_count = 0;
   const char* last_kernel = "";  // hb_last_kernel
   // run-time choices between kernels / schedules that give the same results (hb_batch_tune, include/hb.h: HB_TUNE_*), indexed by knob
-  int tune[HB_TUNE_COUNT] = {getenv("HB_DUO") ? atoi(getenv("HB_DUO")) : 1, 1, 1, 1, 1, 1, 1, 4, 1};
+  int tune[HB_TUNE_COUNT] = {getenv("HB_DUO") ? atoi(getenv("HB_DUO")) : 1, 1, 1, 1, 1, 1, 1, 4, 1, kFoldMax};
+  // hb_step_dev calls not launched yet (fold_steps): the launch parameters they share, and the controls of each
+  BatchPtrs fold_P;
+  const float* fold_ctrl[kFoldMax] = {};
+  int fold_n = 0;
   int* d_order = nullptr;   // heavy-first dispatch order (hb_order_kernel), valid once a step has run
   int* d_order2 = nullptr;  // the same for the narrowphase launch of a staged step
   int order_mode = 0;       // 0: none yet, 1: one permutation of the whole batch, 2: one permutation per pipe segment
@@ -733,7 +737,9 @@ void join_pipes(hb_batch* b) {
   b->forked = false;
 }
 // the batch's stream, ordered behind all enqueued steps: every use of the stream outside launch_steps goes through here
+int flush_steps(hb_batch* b);
 hipStream_t main_stream(hb_batch* b) {
+  if (b->fold_n && flush_steps(b) != HB_OK) b->join_error = 1;  // (hb_batch_sync reports it)
   join_pipes(b);
   b->main_dirty = true;  // the caller is about to enqueue something the next step's launches must follow
   return b->stream;
@@ -781,10 +787,12 @@ void steps_enqueued(hb_batch* b, int nseg, bool reorder, bool refreshed = false)
   b->launch_count++;
 }
 
-int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
-  const int nseg = segment_count(b);
+int launch_steps_now(hb_batch* b, BatchPtrs& P, int nsteps, int ncalls = 1) {
+  // a launch of several steps has no batch-wide barrier between its steps: nothing for segments to overlap, and three launches that each
+  // bring their own rounds of waves fill the chip worse than one (4096 envs, 64 steps: 103 us per step against 71, profiles/r04_fold_sizes.txt)
+  const int nseg = (b->D.dm.variant == 0 && nsteps >= 5) ? 1 : segment_count(b);
   const bool sample = nseg == 1 && b->time_steps && (b->launch_count % 8 == 0) && b->tev_used + 2 <= (int)b->tev.size();
-  const bool reorder = b->schedule && (b->launch_count % reorder_period(b) == 0);
+  const bool reorder = b->schedule && (ncalls >= reorder_period(b) || b->launch_count % reorder_period(b) == 0);
   int rc = fork_pipes(b, nseg);
   if (rc != HB_OK) return rc;
   if (sample) HB_HIP(hipEventRecord(b->tev[b->tev_used], b->stream));
@@ -797,6 +805,51 @@ int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps) {
   const bool refreshed = staged_on(b) && b->D.dm.variant != 0 && b->schedule && nsteps > 8 && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2);
   steps_enqueued(b, nseg, reorder, refreshed);
   return HB_OK;
+}
+
+// Step calls enqueued back to back run as ONE launch.  hb_step_dev is asynchronous: until the caller synchronises, reads something or
+// enqueues other work (all of which pass main_stream), nobody can tell K launches of one step from one launch of K steps - except the clock:
+// a launch of one step lasts as long as its slowest env and the next one waits for it, a launch of K steps lets every wave run on into
+// its envs' next step (the rollout kernels: no batch-wide barrier, and the two-envs-per-wave kernel pays from 4096 envs on instead of
+// 5120).  So a plain step call whose multi-step launch takes that kernel is held back (its launch parameters and its control pointer) until one
+// of: kFoldMax steps are held, a call with other parameters arrives, anything touches the batch's stream.  The held calls then run as
+// one multi-step launch whose step t reads the controls of call t (BatchPtrs::ctrl_tab, ctrl_mode 3).  Results are bit-identical to
+// the unfolded launches (tests/test_gpu_fold.py); HB_TUNE_FOLD = 1 switches it off.
+// Only for a PIPELINED batch: its caller has already taken on the one obligation this adds - hb_batch_join (or fetching the stream again)
+// before enqueueing work of its own on the batch's stream behind step calls (include/hb.h: hb_batch_pipeline).  An unpipelined batch
+// keeps its plain stream semantics: every call is launched when it is made.
+int flush_steps(hb_batch* b) {
+  if (!b->fold_n) return HB_OK;
+  BatchPtrs P = b->fold_P;
+  const int n = b->fold_n;
+  b->fold_n = 0;  // (first: the launch below passes fork_pipes / join_pipes, never main_stream, but nothing may re-enter with steps held)
+  HB_HIP(hipSetDevice(b->device));
+  bool same = true;
+  for (int t = 1; t < n; t++) same = same && b->fold_ctrl[t] == b->fold_ctrl[0];
+  if (same) { P.ctrl = b->fold_ctrl[0]; P.ctrl_mode = 0; }  // (one call, with or without substeps: exactly the launch it always was)
+  else { P.ctrl = nullptr; P.ctrl_mode = 3; for (int t = 0; t < n; t++) P.ctrl_tab[t] = b->fold_ctrl[t]; }
+  return launch_steps_now(b, P, n, n);
+}
+int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps, bool foldable = false) {
+  const int cap = std::min(b->tune[HB_TUNE_FOLD], kFoldMax);
+#ifdef HB_STAMPS
+  foldable = false;  // (the diagnostic build samples single launches)
+#endif
+  foldable = foldable && b->npipe > 1 && cap > 1 && nsteps <= cap && P.ctrl_mode == 0 && !b->time_steps && !b->diag && !P.stamps && P.xfrc_scale == 0.f &&
+             multi_step_takes_duo(b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, P);
+  if (!foldable) {
+    const int rc = flush_steps(b);
+    return rc != HB_OK ? rc : launch_steps_now(b, P, nsteps);
+  }
+  BatchPtrs key = P;
+  key.ctrl = nullptr;
+  if (b->fold_n && (memcmp(&key, &b->fold_P, sizeof key) != 0 || b->fold_n + nsteps > cap)) {
+    const int rc = flush_steps(b);
+    if (rc != HB_OK) return rc;
+  }
+  if (!b->fold_n) b->fold_P = key;
+  for (int t = 0; t < nsteps; t++) b->fold_ctrl[b->fold_n++] = P.ctrl;
+  return b->fold_n >= cap ? flush_steps(b) : HB_OK;
 }
 
 // field offsets of the per-env state record for a state spec
@@ -1046,6 +1099,7 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
 static void envrand_free_fwd(hb_batch* b);
 void hb_batch_free(hb_batch* b) {
   if (!b) return;
+  b->fold_n = 0;  // (step calls nobody will read the results of)
   HB_IGN(hipSetDevice(b->device));
   for (int c = 0; c < hb_batch::kPipes; c++) {
     if (b->pipe[c] && b->pipe[c] != b->stream) { HB_IGN(hipStreamSynchronize(b->pipe[c])); HB_IGN(hipStreamDestroy(b->pipe[c])); }
@@ -1117,7 +1171,7 @@ static int pipes_conflict(hb_batch* b, int n) {
 int hb_batch_pipeline(hb_batch* b, int on) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  join_pipes(b);
+  (void)main_stream(b);
   if (on < 0 || on > hb_batch::kPipes) return HB_EINVAL;
   // 1: default segment count.  Measured on MI355X, 4096 envs, us per step (tools/gpu_pipeline_queues.py, every case a fresh process):
   // 2 segments 92, 3 segments 88, 4 segments 87 with GPU_MAX_HW_QUEUES >= 5 and 142 without, 5 and more 107 - 170 however many queues
@@ -1151,7 +1205,7 @@ int hb_batch_segments(const hb_batch* b) { return b ? segment_count(b) : HB_EINV
 int hb_batch_join(hb_batch* b) {
   if (!b) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
-  join_pipes(b);
+  (void)main_stream(b);  // (launches the step calls held back, then joins the segments' streams)
   return b->join_error ? HB_ENODEVICE : HB_OK;
 }
 
@@ -1182,7 +1236,7 @@ int hb_step_dev(hb_batch* b, const float* ctrl_dev, int n_substeps) {
   HB_HIP(hipSetDevice(b->device));
   BatchPtrs P = make_ptrs(b);
   P.ctrl = ctrl_dev; P.ctrl_mode = 0;
-  return launch_steps(b, P, n_substeps);
+  return launch_steps(b, P, n_substeps, /*foldable=*/true);
 }
 
 int hb_step(hb_batch* b, const float* ctrl, int n_substeps) {
@@ -2394,7 +2448,16 @@ int hb_get_collision_counts(hb_batch* b, int* nwork, int* nsearch, int* kcycles)
   return HB_OK;
 }
 
-const char* hb_last_kernel(const hb_batch* b) { return b ? b->last_kernel : ""; }
+const char* hb_last_kernel(hb_batch* b) {
+  if (!b) return "";
+  if (b->fold_n && flush_steps(b) != HB_OK) b->join_error = 1;  // (step calls held back: launched now, so that the name is theirs)
+  return b->last_kernel;
+}
+long long hb_batch_step_launches(hb_batch* b) {
+  if (!b) return HB_EINVAL;
+  if (b->fold_n && flush_steps(b) != HB_OK) b->join_error = 1;
+  return b->launch_count;
+}
 int hb_batch_device_name(const hb_batch* b, char* out, int cap) {
   if (!b || !out || cap < 2) return HB_EINVAL;
   hipDeviceProp_t prop;
@@ -2405,6 +2468,7 @@ int hb_batch_device_name(const hb_batch* b, char* out, int cap) {
 int hb_batch_tune(hb_batch* b, int knob, int value) {
   if (!b || knob < 0 || knob >= HB_TUNE_COUNT || value < 0) return HB_EINVAL;
   if (knob == HB_TUNE_DUO && value > 2) return HB_EINVAL;
+  if (knob == HB_TUNE_FOLD && (value < 1 || value > kFoldMax)) return HB_EINVAL;
   HB_HIP(hipSetDevice(b->device));
   (void)main_stream(b);  // the choice holds from the next launch on: whatever is in flight on the segments' streams is joined first
   b->tune[knob] = value;
@@ -2446,7 +2510,7 @@ void* hb_dev_alloc(hb_batch* b, uint64_t bytes) {
 void hb_dev_free(hb_batch* b, void* p) {
   if (!b || !p) return;
   HB_IGN(hipSetDevice(b->device));
-  HB_IGN(hipStreamSynchronize(main_stream(b)));
+  HB_IGN(hipStreamSynchronize(main_stream(b)));  // (step calls held back, fold_steps, may read the buffer: launched and waited for)
   HB_IGN(hipFree(p));
 }
 void* hb_host_alloc(uint64_t bytes) {

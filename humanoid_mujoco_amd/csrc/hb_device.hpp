@@ -305,6 +305,8 @@ __host__ __device__ inline int pose_lds_floats(int nq, int nb, int ngeom) {
   return ((nq + 3) & ~3) + 12 * nb + 2 * ((3 * ngeom + 3) & ~3) + 4 * ngeom + kListMax * 5 + kWorkMax;
 }
 
+// most step calls one launch executes (the calls the host enqueued back to back, hb_api.cpp fold_steps)
+constexpr int kFoldMax = 256;
 struct BatchPtrs {
   float* state;        // [n_env][nstate]
   const float* ctrl;   // [n_env][nu] or [T][n_env][nu]
@@ -321,7 +323,7 @@ struct BatchPtrs {
   float* diag_contact; // nullable [n_env][kNconMax][kDiagConStride]
   int n_env;
   int blk0, nblk;      // this launch covers dispatch slots blk0 .. blk0+nblk-1 (one block each) of the batch
-  int ctrl_mode;       // 0: ctrl[e][nu] held for all steps; 1: ctrl[t][e][nu]; 2: on-device Halton
+  int ctrl_mode;       // 0: ctrl[e][nu] held for all steps; 1: ctrl[t][e][nu]; 2: on-device Halton; 3: ctrl_tab[t][e][nu]
   int t0, env_offset;  // Halton indexing
   int integrate;       // 1: mj_step, 0: mj_forward only
   // heavy-first block scheduling (nullable): slot s takes env = order[s], a permutation sorted by
@@ -347,6 +349,7 @@ struct BatchPtrs {
   int lean_ok;                // bit 0: the model's options allow the lean instantiations (mjOption.disableflags == 0); bit 1: its sizes and LDS
                               // layout are kSizedHumanoid27's (the size-specialised instantiations); bit 2: its fast layout is kSizedTeamV1's
   int stop_phase;             // diagnostic builds only: 0 = off (HB_STOP_PHASE in the environment, read at every launch)
+  const float* ctrl_tab[kFoldMax];  // ctrl_mode 3: step t of this launch is the step call whose [n_env][nu] controls these are (hb_api.cpp: fold_steps)
   int duo;                    // host side only (launch_step): two envs per wave 0 never, 1 where it pays, 2 always (hb_batch_duo)
   StageBufs stage;
 };

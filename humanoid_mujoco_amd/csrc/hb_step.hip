@@ -125,8 +125,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   // the controls of the first step are requested before the state, those of step t+1 at the top of step t:
   // an HBM round trip each (streamed, never cached) that would otherwise open every step
   float ctrl_pf = 0.f;
-  const float* ctrl_src = P.ctrl;
+  // (ctrl_mode 3: step calls the host folded into this launch, BatchPtrs::ctrl_tab - multi-step instantiations only)
   const int ctrl_mode = P.ctrl_mode, ctrl_t0 = P.t0;
+  const float* ctrl_src = (LEAN != 1 && ctrl_mode == 3) ? P.ctrl_tab[0] : P.ctrl;
   if (ctrl_mode != 2 && lane < HB_SZ(nu)) ctrl_pf = ctrl_src[(size_t)env * HB_SZ(nu) + lane];
   float* gstate = P.state + (size_t)env * HB_SZ(nstate);
   auto ld_state = [&](int i) -> float { return gstate[i]; };
@@ -184,10 +185,11 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       int idx = 1 + ctrl_t0 + step + 1000 * (P.env_offset + env);
       for (int i = lane; i < HB_SZ(nu); i += kGroup) s_ctrl[i] = 2.f * halton(idx, i + 2) - 1.f;
     } else {
-      const float* c = ctrl_src + (ctrl_mode == 1 ? (size_t)step * P.n_env * HB_SZ(nu) : 0) + (size_t)env * HB_SZ(nu);
+      const float* c = ((LEAN != 1 && ctrl_mode == 3) ? P.ctrl_tab[step] : ctrl_src + (ctrl_mode == 1 ? (size_t)step * P.n_env * HB_SZ(nu) : 0)) + (size_t)env * HB_SZ(nu);
       if (lane < HB_SZ(nu)) s_ctrl[lane] = ctrl_pf;
       for (int i = lane + kGroup; i < HB_SZ(nu); i += kGroup) s_ctrl[i] = c[i];
       if (ctrl_mode == 1 && step + 1 < nsteps && lane < HB_SZ(nu)) ctrl_pf = c[(size_t)P.n_env * HB_SZ(nu) + lane];
+      if (LEAN != 1 && ctrl_mode == 3 && step + 1 < nsteps && lane < HB_SZ(nu)) ctrl_pf = P.ctrl_tab[step + 1][(size_t)env * HB_SZ(nu) + lane];
     }
     // ---------------------------------------------------------------- mj_checkPos / mj_checkVel
     {
@@ -1888,11 +1890,15 @@ static bool duo_pays(const BatchPtrs& P, int nsteps) {
   return P.nblk == P.n_env ? 2 * P.n_env >= 3 * wave_slots() : 2 * P.n_env >= 5 * wave_slots();
 }
 
-// the lean instantiations apply when the launch has none of the optional inputs / outputs (HB_LEAN=0: never)
+// the lean instantiations apply when the launch has none of the optional inputs / outputs (BatchPtrs::lean_ok bit 0, HB_TUNE_LEAN)
 static bool lean_launch(const BatchPtrs& P, bool with_qfrc = false) {
-  static const bool lean_on = !(getenv("HB_LEAN") && atoi(getenv("HB_LEAN")) == 0);
-  return lean_on && (P.lean_ok & 1) && !P.xfrc && (with_qfrc || !P.qfrc_out) && !P.sensor_out && !P.qpos_out && !P.qvel_out && !P.diag_qacc && !P.diag_force && !P.diag_contact && !P.dr && !P.env_mask &&
+  return (P.lean_ok & 1) && !P.xfrc && (with_qfrc || !P.qfrc_out) && !P.sensor_out && !P.qpos_out && !P.qvel_out && !P.diag_qacc && !P.diag_force && !P.diag_contact && !P.dr && !P.env_mask &&
          P.integrate;
+}
+// would a launch of several steps with these parameters take the two-envs-per-wave kernel?  (hb_api.cpp folds step calls into one launch
+// when it does: a multi-step launch of one-env waves is no faster than pipelined single steps - profiles/r04_fold_sizes.txt)
+bool multi_step_takes_duo(int variant, int solver, int nv, const BatchPtrs& P) {
+  return variant == 0 && solver != 2 && nv <= 28 && lean_launch(P) && (P.lean_ok & 2) && duo_pays(P, 2);
 }
 static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int solver, int nv, size_t shmem, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error

@@ -193,11 +193,12 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
 #ifdef HB_STAMPS
   unsigned long long stamps_[16] = {0};
 #endif
-  // controls of step t: ctrl[e][nu] (mode 0), ctrl[t][e][nu] (mode 1), or the benchmark's on-device Halton sequence (mode 2); those of step
+  // controls of step t: ctrl[e][nu] (mode 0), ctrl[t][e][nu] (mode 1), ctrl_tab[t][e][nu] (mode 3), or the benchmark's on-device Halton sequence (mode 2); those of step
   // t + 1 are requested at the top of step t (an HBM round trip that would otherwise open every step)
   auto ctrl_of = [&](int t) -> float {
     if (!(env >= 0 && l0 < NU)) return 0.f;
     if (P.ctrl_mode == 2) return 2.f * halton(1 + P.t0 + t + 1000 * (P.env_offset + env), l0 + 2) - 1.f;
+    if (MULTI && P.ctrl_mode == 3) return P.ctrl_tab[t][(size_t)env * NU + l0];  // step calls folded into this launch
     return P.ctrl[(P.ctrl_mode == 1 ? (size_t)t * P.n_env * NU : 0) + (size_t)env * NU + l0];
   };
   float ctrl_pf = ctrl_of(0);

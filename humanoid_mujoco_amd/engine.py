@@ -147,6 +147,7 @@ def lib():
     L.hb_get_status.argtypes = [vp, vp]
     L.hb_get_counts.argtypes = [vp, vp, vp, vp]
     L.hb_last_kernel.argtypes = [vp]; L.hb_last_kernel.restype = ctypes.c_char_p
+    L.hb_batch_step_launches.argtypes = [vp]; L.hb_batch_step_launches.restype = ctypes.c_longlong
     L.hb_batch_tune.argtypes = [vp, ci, ci]
     L.hb_model_pair_order.argtypes = [vp, ci]
     L.hb_env_terminal_obs.argtypes = [vp, vp]
@@ -431,7 +432,7 @@ class Batch:
         _check(lib().hb_get_counts(self._h, _ptr(a), _ptr(b), _ptr(c)), "hb_get_counts")
         return a, b, c
 
-    TUNE = {"duo": 0, "lean": 1, "sized": 2, "staged": 3, "fastpass": 4, "narrow_prim": 5, "schedule": 6, "reorder_period": 7, "policy_lean": 8}
+    TUNE = {"duo": 0, "lean": 1, "sized": 2, "staged": 3, "fastpass": 4, "narrow_prim": 5, "schedule": 6, "reorder_period": 7, "policy_lean": 8, "fold": 9}
 
     def tune(self, **knobs):
         """run-time choices between kernels / schedules that give the same results (include/hb.h: hb_batch_tune, HB_TUNE_*), e.g.
@@ -447,6 +448,10 @@ class Batch:
         buf = ctypes.create_string_buffer(256)
         _check(lib().hb_batch_device_name(self._h, buf, 256), "hb_batch_device_name")
         return buf.value.decode()
+
+    def step_launches(self):
+        """number of step launches so far (include/hb.h: hb_batch_step_launches)"""
+        return int(lib().hb_batch_step_launches(self._h))
 
     def last_kernel(self):
         """name of the step kernel the batch's last step / rollout / forward launch ran (include/hb.h: hb_last_kernel)"""

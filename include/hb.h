@@ -126,7 +126,8 @@ int hb_batch_sync(hb_batch* b);
  * (envs are independent: results are identical to the unpipelined launch).  The internal streams fork
  * from the batch's stream at every step call and are joined back by the next hb_* call of any other
  * kind.  A caller that enqueues its OWN work on hb_batch_stream() after step calls must call
- * hb_batch_join first (or fetch the stream again); callers that only use hb_* functions need nothing. */
+ * hb_batch_join first (or fetch the stream again); callers that only use hb_* functions need nothing.
+ * A pipelined batch also folds hb_step_dev calls made back to back into one launch (see hb_step_dev): the same rule covers it. */
 int hb_batch_pipeline(hb_batch* b, int on);
 /* Number of env segments step calls are cut into at the moment (1: unpipelined). */
 int hb_batch_segments(const hb_batch* b);
@@ -142,6 +143,13 @@ int hb_reset(hb_batch* b, const uint8_t* mask, int keyframe, int perturb, int en
  * simulation/cpu_env.py:683-684, simulation/mujoco/sample/testspeed.cc:93-96).
  * ctrl: env-major [n_env][nu] float32, applied for n_substeps consecutive steps. */
 int hb_step(hb_batch* b, const float* ctrl, int n_substeps);
+/* The same with the controls already in device memory, asynchronous: the call returns at once, its results are there after hb_batch_sync
+ * or behind anything enqueued on hb_batch_stream later, and ctrl_dev must stay allocated and untouched until then.  On a PIPELINED batch
+ * (hb_batch_pipeline) whose multi-step launches take the two-envs-per-wave kernel (HB_TUNE_DUO: the 27-dof humanoid's PGS configuration from
+ * 4096 envs on), calls made back to back - nothing else of the batch's API in between - are executed as ONE kernel launch of up to
+ * HB_TUNE_FOLD steps, step t reading the controls of call t: no env waits for the batch's slowest one between steps (4096 envs on MI355X:
+ * 71 us per step against 78).  The states are bit-identical to one launch per call; the work starts when HB_TUNE_FOLD steps are held or
+ * when any other hb_* call of the batch (hb_batch_sync, hb_batch_stream, hb_batch_join, a read) arrives. */
 int hb_step_dev(hb_batch* b, const float* ctrl_dev, int n_substeps);
 
 /* Replaces the open-loop rollout loops (mujoco_mpc/mjpc/trajectory.cc:141-179,
@@ -337,7 +345,11 @@ int hb_get_counts(hb_batch* b, int* ncon, int* nefc, int* niter);
  * before the first).  Which instantiation a launch takes depends on the model's solver and sizes and on the optional inputs / outputs
  * the call asked for: the parity tests assert that the kernel they checked is the kernel the benchmark times, and
  * bench.py names the kernel of its roofline object by this string.  The pointer stays valid for the life of the library. */
-const char* hb_last_kernel(const hb_batch* b);
+const char* hb_last_kernel(hb_batch* b);
+/* How many times the batch has launched its step kernel(s) so far - the launches of one call's env segments (hb_batch_pipeline) count as
+ * one, a staged step's kernels as one, hb_step_dev calls folded into one launch as one: bench.py divides its timed region by the
+ * difference to get the launch duration its roofline object quotes.  Step calls still held back are launched first. */
+long long hb_batch_step_launches(hb_batch* b);
 /* "<device name> (<gfx arch>, <n> CUs) #<index>" of the GPU the batch lives on: what every rank of a multi-GPU bench.py run reports about
  * itself (the reference's testspeed.cc prints its thread count: sample/testspeed.cc:203-210). */
 int hb_batch_device_name(const hb_batch* b, char* out, int cap);
@@ -358,11 +370,13 @@ int hb_batch_device_name(const hb_batch* b, char* out, int cap);
  *   HB_TUNE_REORDER_PERIOD the heavy-first order is re-sorted every n-th step call (default 4)
  *   HB_TUNE_POLICY_LEAN    hb_rollout_policy: 1 (default) the LDS-free policy kernel beside the other segments' step kernels when
  *                          pipelined; 0 never; 2 always
+ *   HB_TUNE_FOLD           hb_step_dev calls enqueued back to back run as ONE launch of up to this many steps (default and maximum 256; 1:
+ *                          every call its own launch).  See hb_step_dev.
  * Environment variables the library reads (all others of earlier rounds are gone): HB_DEBUG (name failing HIP calls on stderr), HB_DUO
  * (HB_TUNE_DUO's value for new batches), HB_BOX_CULL=0 (model tables without the oriented-box cull of portal-search pairs: a test),
  * and in the diagnostic build (-DHB_STAMPS) HB_STOP_PHASE. */
 enum { HB_TUNE_DUO = 0, HB_TUNE_LEAN, HB_TUNE_SIZED, HB_TUNE_STAGED, HB_TUNE_FASTPASS, HB_TUNE_NARROW_PRIM, HB_TUNE_SCHEDULE, HB_TUNE_REORDER_PERIOD,
-       HB_TUNE_POLICY_LEAN, HB_TUNE_COUNT };
+       HB_TUNE_POLICY_LEAN, HB_TUNE_FOLD, HB_TUNE_COUNT };
 int hb_batch_tune(hb_batch* b, int knob, int value);
 /* Narrowphase work of the last step of each env, for models that collide through mesh hulls or height fields (the staged step:
  * DESIGN.md 3.6): nwork = work items (a candidate pair that passed the broadphase, or one prism of a height-field pair's sub-grid),

@@ -1,0 +1,124 @@
+"""Step calls enqueued back to back run as ONE launch (include/hb.h: hb_step_dev, HB_TUNE_FOLD; csrc/hb_api.cpp: fold_steps).
+
+The reference steps a thread's envs in a loop with nothing between the steps (simulation/mujoco/sample/testspeed.cc:93-96: mj_step
+after mj_step); hb_step_dev is asynchronous, so K calls in a row are the same thing to the caller as one launch of K steps - which
+has no batch-wide barrier between the steps.  Held here: the folded launches give bit-identical states, counts and status to one
+launch per call, for every pattern of calls that folds or has to stop folding."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N = 512  # (three segments of a pipelined batch: 170 / 171 envs, an odd number for the two-envs-per-wave kernel)
+T = 150
+
+
+def _ctrl(hbmod, b, nu, t0=7):
+    p = b.dev_alloc(T * N * nu * 4)
+    b.halton_ctrl_dev(T, t0, 0, p)
+    return p, N * nu * 4
+
+
+def _everything(hbmod, b):
+    return (b.get_state(hbmod.STATE_INTEGRATION),) + tuple(b.counts()) + (b.status(),)
+
+
+def _same(x, y):
+    return all(np.array_equal(a, c) for a, c in zip(x, y))
+
+
+@pytest.mark.parametrize("duo,pipelined,kernel", [(2, 1, "hb_step_duo_q_kernel"), (2, 2, "hb_step_duo_q_kernel"), (0, 1, "hb_step_h27_kernel"), (2, 0, "hb_step_duo_kernel")])
+def test_folded_step_calls_are_bit_identical(hbmod, humanoid_model, gpu, duo, pipelined, kernel):
+    """(an unpipelined batch does not fold: its caller was never asked to join before using the batch's stream - include/hb.h; nor does one
+    whose multi-step launch runs one env per wave: that is no faster than pipelined single steps)"""
+    m = humanoid_model
+    got = []
+    for fold in (1, 64):
+        folds = fold > 1 and duo == 2 and pipelined
+        b = hbmod.Batch(m, N, gpu)
+        b.tune(duo=duo, fold=fold)
+        b.reset(perturb=True)
+        b.pipeline(pipelined)
+        ctrl, stride = _ctrl(hbmod, b, m.nu)
+        for t in range(T):  # 150 calls: two full launches of 64 steps and one of 22
+            b.step_dev(ctrl + t * stride)
+        b.sync()
+        assert b.last_kernel() == (kernel if folds else kernel.replace("_q_kernel", "_kernel"))
+        got.append(_everything(hbmod, b))
+        b.dev_free(ctrl)
+        b.close()
+    assert _same(got[0], got[1])
+    assert got[0][1].max() >= 3  # contacts were there: fallen humanoids
+
+
+def test_fold_stops_where_it_has_to(hbmod, humanoid_model, gpu):
+    """reads, writes into the control buffer through the batch's API, substeps, the host-control step and a rollout between the calls"""
+    m = humanoid_model
+    rng = np.random.default_rng(3)
+    host_ctrl = rng.uniform(-1, 1, (N, m.nu)).astype(np.float32)
+    got = []
+    for fold in (1, 256, 5):
+        b = hbmod.Batch(m, N, gpu)
+        b.tune(fold=fold, duo=2)
+        b.reset(perturb=True)
+        b.pipeline(True)
+        ctrl, stride = _ctrl(hbmod, b, m.nu)
+        one = b.dev_alloc(stride)
+        mid = []
+        for t in range(40):
+            b.step_dev(ctrl + t * stride)
+        mid.append(b.get_state(hbmod.STATE_INTEGRATION))       # a read in the middle
+        for t in range(40, 60):                                  # the closed-loop pattern: ONE buffer, rewritten between the calls
+            b.halton_ctrl_dev(1, 7 + t, 0, one)
+            b.step_dev(one)
+        for t in range(60, 70):
+            b.step_dev(ctrl + t * stride, 3)                     # substeps: the same controls three steps long
+        b.step(host_ctrl)                                        # host controls (synchronous)
+        for t in range(70, 80):
+            b.step_dev(ctrl + t * stride)
+        b.rollout_halton(9, 500)                                 # another kind of launch behind held step calls
+        for t in range(80, 90):
+            b.step_dev(ctrl + t * stride)
+        mid.append(b.counts()[0])
+        for t in range(90, 100):
+            b.step_dev(ctrl + t * stride)
+        b.tune(reorder_period=2)                                 # a knob turned between step calls
+        for t in range(100, 110):
+            b.step_dev(ctrl + t * stride)
+        b.sync()
+        got.append(tuple(mid) + _everything(hbmod, b))
+        b.dev_free(ctrl); b.dev_free(one)
+        b.close()
+    assert _same(got[0], got[1]) and _same(got[0], got[2])
+
+
+def test_callers_own_work_on_the_batch_stream_between_folded_calls(hbmod, humanoid_model, gpu):
+    """the rule of a pipelined batch (include/hb.h: hb_batch_pipeline): hb_batch_join, then the caller's own work on the batch's stream.  Here a
+    torch copy rewrites ONE control buffer between the step calls, on a stream handle fetched once"""
+    torch = pytest.importorskip("torch")
+    m = humanoid_model
+    dev = torch.device("cuda", gpu)
+    rng = np.random.default_rng(5)
+    seq = torch.from_numpy(rng.uniform(-1, 1, (30, N, m.nu)).astype(np.float32)).to(dev)
+    torch.cuda.synchronize(dev)
+    b = hbmod.Batch(m, N, gpu)
+    b.tune(duo=2)
+    b.reset(perturb=True)
+    b.pipeline(True)
+    ref = hbmod.Batch(m, N, gpu)
+    ref.tune(fold=1, duo=2)
+    ref.reset(perturb=True)
+    ref.pipeline(True)
+    buf = torch.zeros((N, m.nu), dtype=torch.float32, device=dev)
+    s = torch.cuda.ExternalStream(b.stream, device=dev)
+    for t in range(30):
+        b.join()
+        with torch.cuda.stream(s):
+            buf.copy_(seq[t])
+        b.step_dev(buf.data_ptr())
+        if t % 3 == 0:
+            b.step_dev(buf.data_ptr())  # and two calls in a row on the same controls
+            ref.step_dev(seq[t].data_ptr())
+        ref.step_dev(seq[t].data_ptr())
+    b.sync(); ref.sync()
+    assert np.array_equal(b.get_state(hbmod.STATE_INTEGRATION), ref.get_state(hbmod.STATE_INTEGRATION))
+    b.close(); ref.close()

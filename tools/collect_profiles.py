@@ -111,6 +111,57 @@ if fv:
             out["valu_useful_lane_ops_per_s"] = out["valu_lane_ops_per_s"] * util
             out["valu_useful_frac_of_peak"] = out["valu_useful_lane_ops_per_s"] / 78.6e12
 json.dump(out, open(os.path.join(dst, rnd + "_counters.json"), "w"), indent=1)
+
+
+def timed_kernel_profile():
+    """The kernel bench.py's timed loop runs since its step calls are folded: hb_step_duo_q_kernel, launches of up to 256 steps of the two-envs-per-wave
+    kernel.  PMC passes: `bench.py --steps 256 --warmup 5 --no-rollout --no-newton --no-team` - the process' LAST dispatch of that kernel is the
+    timed loop's one launch of 256 steps (before it: the pre-roll's 600 steps and the warm-up's 5; the single-step leg behind it runs
+    hb_step_duo_kernel).  Kernel trace: the bench command itself (--steps 1000: the last ceil(1000 / 256) dispatches)."""
+    name, steps, waves = "hb_step_duo_q_kernel(", 256, 2048
+    q = {}
+    for d in ("prof_q_fetch", "prof_q_write", "prof_q_sq", "prof_q_lds", "prof_q_mfma", "prof_q_valu"):
+        fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+        if not fs:
+            continue
+        rows = [r for r in csv.DictReader(open(fs[0])) if name in r["Kernel_Name"]]
+        if not rows:
+            continue
+        last = max(int(r["Dispatch_Id"]) for r in rows)
+        for r in rows:
+            if int(r["Dispatch_Id"]) == last:
+                q[r["Counter_Name"]] = q.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                q["_meta"] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+    res = {"kernel": "hb_step_duo_q_kernel", "pmc_launch": "%d blocks x 64 lanes (two envs each), %d steps in the launch" % (waves, steps), "counters_of_that_launch": q}
+    if trace:
+        rows = [(int(r["Dispatch_Id"]) if "Dispatch_Id" in r else i, float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+                for i, r in enumerate(csv.DictReader(open(trace[0]))) if name in r["Kernel_Name"]]
+        rows.sort()
+        K, n = 1000, 4  # (tools/gpu_round.sh: --steps 1000 = launches of 256, 256, 256, 232 steps)
+        if len(rows) >= n + 2:
+            t = [x for _, x in rows[-n:]]
+            res["kernel_trace"] = {"timed_launches": n, "steps": K, "launch_ns": t, "avg_launch_ns": sum(t) / n, "us_per_step": 1e-3 * sum(t) / K}
+    if "FETCH_SIZE" in q and "WRITE_SIZE" in q:
+        fetch, write = q["FETCH_SIZE"] * 1024, q["WRITE_SIZE"] * 1024
+        res["hbm"] = {"fetch_bytes_raw_per_step": fetch / steps, "write_bytes_per_step": write / steps, "hbm_bytes_per_step": (2 * fetch + write) / steps,
+                      "algorithmic_bytes_per_step": 748 * n_env, "note": "FETCH_SIZE doubled per the gfx950 correction; the launch's counters / its 256 steps"}
+    if "SQ_INSTS_VALU" in q and "SQ_WAVES" in q:
+        res["per_env_step"] = {k: q[k] / (2.0 * q["SQ_WAVES"] * steps) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                                                                                 "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_MFMA") if k in q}
+    if "SQ_THREAD_CYCLES_VALU" in q and q.get("SQ_ACTIVE_INST_VALU"):
+        res["active_lanes_per_valu_instruction"] = q["SQ_THREAD_CYCLES_VALU"] / q["SQ_ACTIVE_INST_VALU"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in q and q.get("SQ_BUSY_CU_CYCLES"):
+        res["mfma_busy_frac"] = q["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * q["SQ_BUSY_CU_CYCLES"])
+    if "SQ_ACTIVE_INST_VALU" in q and q.get("SQ_BUSY_CU_CYCLES"):
+        res["valu_pipe_busy_frac"] = q["SQ_ACTIVE_INST_VALU"] / q["SQ_BUSY_CU_CYCLES"]
+    if "SQ_WAIT_INST_ANY" in q and q.get("SQ_WAVE_CYCLES"):
+        res["sq_wait_inst_any_frac_of_wave_cycles"] = q["SQ_WAIT_INST_ANY"] / q["SQ_WAVE_CYCLES"]
+    return res if (q or "kernel_trace" in res) else None
+
+
+tk = timed_kernel_profile()
+if tk:
+    json.dump(tk, open(os.path.join(dst, rnd + "_counters_timed_kernel.json"), "w"), indent=1)
 if "valu_issue_frac_of_peak" in out and os.path.exists(os.path.join(dst, "traffic_latest.json")):
     latest = json.load(open(os.path.join(dst, "traffic_latest.json")))
     # the launches of the TIMED loop: env segments (grids smaller than the whole batch) of the same kernel, from the kernel trace of the bench command
@@ -132,6 +183,25 @@ if "valu_issue_frac_of_peak" in out and os.path.exists(os.path.join(dst, "traffi
         # 4 x ACTIVE / (4 x BUSY_CU cycles).  Whole unpipelined launch, its ragged tail included; 85 MFMAs per wave come on top (mfma_busy_frac)
         latest["valu"]["pipe_busy_frac"] = counters["SQ_ACTIVE_INST_VALU"]["mean"] / counters["SQ_BUSY_CU_CYCLES"]["mean"]
         latest["valu"]["instructions_per_wave"] = counters["SQ_INSTS_VALU"]["mean"] / counters["SQ_WAVES"]["mean"]
+    latest["kernel"] = "hb_step_h27_kernel"
+    if tk:
+        e = {"source": "profiles/%s_counters_timed_kernel.json (rocprofv3 --pmc passes of `bench.py --steps 256`, the timed loop's one launch of 256 steps; tools/gpu_round.sh)" % rnd}
+        if "hbm" in tk:
+            e["hbm_bytes_per_step"] = tk["hbm"]["hbm_bytes_per_step"]; e["fetch_bytes_raw_per_step"] = tk["hbm"]["fetch_bytes_raw_per_step"]; e["write_bytes_per_step"] = tk["hbm"]["write_bytes_per_step"]
+        if "kernel_trace" in tk:
+            e["us_per_step_kernel_trace"] = tk["kernel_trace"]["us_per_step"]; e["avg_launch_ns_kernel_trace"] = tk["kernel_trace"]["avg_launch_ns"]
+        if "per_env_step" in tk and "active_lanes_per_valu_instruction" in tk and "kernel_trace" in tk:
+            issued = tk["per_env_step"]["SQ_INSTS_VALU"] * n_env * 64 / (tk["kernel_trace"]["us_per_step"] * 1e-6)
+            util = min(1.0, tk["active_lanes_per_valu_instruction"] / 64.0)
+            e["valu_issue_frac_of_peak"] = issued / 78.6e12
+            e["valu"] = {"bound": "valu", "issued_lane_ops_per_s": issued, "active_lane_fraction": util, "achieved": issued * util, "peak": 78.6e12, "unit": "fp32 lane-op/s",
+                         "frac": issued * util / 78.6e12, "instructions_per_env_step": tk["per_env_step"]["SQ_INSTS_VALU"],
+                         "note": "SQ_INSTS_VALU x 64 x (active lanes / 64) of the 256-step launch / its duration in the kernel trace; peak = 157.3 TFLOP/s / 2 flop per fma"}
+            if "valu_pipe_busy_frac" in tk:
+                e["valu"]["pipe_busy_frac"] = tk["valu_pipe_busy_frac"]
+        if "mfma_busy_frac" in tk:
+            e["mfma_busy_frac"] = tk["mfma_busy_frac"]
+        latest.setdefault("by_kernel", {})["hb_step_duo_q_kernel"] = e
     json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 # second kernel trace (bench.py --no-pipeline with its Newton leg): every hb_* kernel's 4096-block launches
 tn = glob.glob(os.path.join(src, "prof_trace_newton", "*", "*_kernel_trace.csv"))
@@ -147,7 +217,7 @@ if tn:
     st2 = glob.glob(os.path.join(src, "prof_trace_newton", "*", "*_kernel_stats.csv"))
     if st2:
         shutil.copy(st2[0], os.path.join(dst, rnd + "_kernel_stats_solvers.csv"))
-for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("pipeline_sweep.txt", rnd + "_pipeline_sweep.txt"), ("vecenv.txt", rnd + "_vecenv.txt"), ("soak.txt", rnd + "_soak.txt"), ("soak_newton.txt", rnd + "_soak_newton.txt"), ("pgs_fit.txt", rnd + "_pgs_fit.txt"), ("planner.txt", rnd + "_planner.txt"), ("mpc_demo.txt", rnd + "_mpc_demo.txt"), ("latency.txt", rnd + "_latency.txt"), ("drift_nocontact.txt", rnd + "_drift_nocontact.txt"), ("parity_report_newton.txt", rnd + "_parity_report_newton.txt"), ("newton_bench.txt", rnd + "_newton_bench.txt"), ("newton_phases.txt", rnd + "_newton_phases.txt"), ("newton_sections.txt", rnd + "_newton_sections.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("testspeed_newton.log", rnd + "_testspeed_newton.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt"), ("team_bench.txt", rnd + "_team_bench.txt"), ("phase_config5.txt", rnd + "_phase_config5.txt"), ("phase_team.txt", rnd + "_phase_team.txt"), ("phase_team_fused.txt", rnd + "_phase_team_fused.txt"), ("pipeline_queues.txt", rnd + "_pipeline_queues.txt"), ("phase_instructions.txt", rnd + "_phase_instructions.txt"), ("soak_pipelined.txt", rnd + "_soak_pipelined.txt"), ("config4_physics_only.txt", rnd + "_config4_physics_only.txt"), ("testspeed_stages.log", rnd + "_testspeed_stages.txt"), ("testspeed_team.log", rnd + "_testspeed_team.txt"), ("team_short.txt", rnd + "_team_short.txt"), ("duo_sizes.txt", rnd + "_duo_sizes.txt"), ("vecenv_sb3.txt", rnd + "_vecenv_sb3.txt"), ("step_latency_dist.txt", rnd + "_step_latency_dist.txt"),
+for f, name in (("phase_profile.txt", rnd + "_phase_profile.txt"), ("parity_report.txt", rnd + "_parity_report.txt"), ("config4.txt", rnd + "_config4.txt"), ("config5.txt", rnd + "_config5.txt"), ("pipeline_sweep.txt", rnd + "_pipeline_sweep.txt"), ("vecenv.txt", rnd + "_vecenv.txt"), ("soak.txt", rnd + "_soak.txt"), ("soak_newton.txt", rnd + "_soak_newton.txt"), ("pgs_fit.txt", rnd + "_pgs_fit.txt"), ("planner.txt", rnd + "_planner.txt"), ("mpc_demo.txt", rnd + "_mpc_demo.txt"), ("latency.txt", rnd + "_latency.txt"), ("drift_nocontact.txt", rnd + "_drift_nocontact.txt"), ("parity_report_newton.txt", rnd + "_parity_report_newton.txt"), ("newton_bench.txt", rnd + "_newton_bench.txt"), ("newton_phases.txt", rnd + "_newton_phases.txt"), ("newton_sections.txt", rnd + "_newton_sections.txt"), ("bench.json", rnd + "_bench.json"), ("testspeed.log", rnd + "_testspeed.txt"), ("testspeed_newton.log", rnd + "_testspeed_newton.txt"), ("pytest_gpu.log", rnd + "_pytest_gpu.txt"), ("smoke.log", rnd + "_smoke.txt"), ("team_bench.txt", rnd + "_team_bench.txt"), ("phase_config5.txt", rnd + "_phase_config5.txt"), ("phase_team.txt", rnd + "_phase_team.txt"), ("phase_team_fused.txt", rnd + "_phase_team_fused.txt"), ("pipeline_queues.txt", rnd + "_pipeline_queues.txt"), ("phase_instructions.txt", rnd + "_phase_instructions.txt"), ("soak_pipelined.txt", rnd + "_soak_pipelined.txt"), ("config4_physics_only.txt", rnd + "_config4_physics_only.txt"), ("testspeed_stages.log", rnd + "_testspeed_stages.txt"), ("testspeed_team.log", rnd + "_testspeed_team.txt"), ("team_short.txt", rnd + "_team_short.txt"), ("duo_sizes.txt", rnd + "_duo_sizes.txt"), ("vecenv_sb3.txt", rnd + "_vecenv_sb3.txt"), ("step_latency_dist.txt", rnd + "_step_latency_dist.txt"), ("fold_sizes.txt", rnd + "_fold_sizes_now.txt"),
                 ("prof_team/t_kernel_stats.csv", rnd + "_kernel_stats_team.csv"), ("prof_config5/t_kernel_stats.csv", rnd + "_kernel_stats_config5.csv")):
     p = os.path.join(src, f)
     if os.path.exists(p):

@@ -19,6 +19,7 @@ ctrl = b.dev_alloc((K + W) * N * m.nu * 4)
 b.halton_ctrl_dev(K + W, 0, 0, ctrl)
 b.reset(perturb=True)
 b.pipeline(npipe)
+b.tune(fold=1)  # (this is about one launch per call)
 stride = N * m.nu * 4
 for t in range(W): b.step_dev(ctrl + t * stride)
 b.sync()

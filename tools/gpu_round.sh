@@ -32,12 +32,20 @@ timeout -k 10 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST
 # instruction-cycles = active lanes per VALU instruction (63.7 on the full-wave kernels of the same pass) - collect_profiles.py
 timeout -k 10 600 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/prof_valu -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_valu.log 2>&1; echo "valu rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/prof_mfma -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_mfma.log 2>&1; echo "mfma rc=$?" | tee -a $OUT/progress.log
+# the kernel the timed loop runs (its step calls folded: hb_step_duo_q_kernel): the same passes on `bench.py --steps 256`, whose timed loop is ONE launch of 256 steps
+QARGS="--steps 256 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_q_fetch -- python3 bench.py $QARGS > $OUT/prof_q_fetch.log 2>&1; echo "q fetch rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_q_write -- python3 bench.py $QARGS > $OUT/prof_q_write.log 2>&1; echo "q write rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/prof_q_sq -- python3 bench.py $QARGS > $OUT/prof_q_sq.log 2>&1; echo "q sq rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_q_lds -- python3 bench.py $QARGS > $OUT/prof_q_lds.log 2>&1; echo "q lds rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 300 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/prof_q_valu -- python3 bench.py $QARGS > $OUT/prof_q_valu.log 2>&1; echo "q valu rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/prof_q_mfma -- python3 bench.py $QARGS > $OUT/prof_q_mfma.log 2>&1; echo "q mfma rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_pipeline_sweep.py > $OUT/pipeline_sweep.txt 2>&1; echo "sweep rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_phase_profile.py 4096 > $OUT/phase_profile.txt 2>&1; echo "phase rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_phase_profile.py 4096 humanoid27_hfield.hbm > $OUT/phase_config5.txt 2>&1; timeout -k 10 200 python tools/gpu_phase_profile.py 4096 team_robot.hbm > $OUT/phase_team.txt 2>&1; timeout -k 10 400 python tools/gpu_pipeline_queues.py default GPU_MAX_HW_QUEUES=8 GPU_MAX_HW_QUEUES=16 > $OUT/pipeline_queues.txt 2>&1; timeout -k 10 900 bash tools/gpu_phase_instructions.sh $OUT/phase_inst > $OUT/phase_instructions.txt 2>&1
 timeout -k 10 200 python tools/gpu_parity_report.py > $OUT/parity_report.txt 2>&1; timeout -k 10 200 python tools/gpu_parity_report.py newton > $OUT/parity_report_newton.txt 2>&1; echo "parity rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace_newton -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-rollout --no-pipeline > $OUT/prof_trace_newton.log 2>&1; echo "newton trace rc=$?" | tee -a $OUT/progress.log
-timeout -k 10 300 python tools/gpu_soak.py > $OUT/soak.txt 2>&1; timeout -k 10 300 python tools/gpu_soak_pipelined.py 100000 > $OUT/soak_pipelined.txt 2>&1; timeout -k 10 200 python tools/gpu_config4_physics_only.py > $OUT/config4_physics_only.txt 2>&1; timeout -k 10 300 python tools/gpu_soak.py newton > $OUT/soak_newton.txt 2>&1; timeout -k 10 200 python tools/gpu_vecenv_bench.py > $OUT/vecenv.txt 2>&1; timeout -k 10 200 python tools/gpu_pgs_fit.py > $OUT/pgs_fit.txt 2>&1; timeout -k 10 200 python tools/gpu_config4.py > $OUT/config4.txt 2>&1; timeout -k 10 200 python tools/gpu_config5.py > $OUT/config5.txt 2>&1; timeout -k 10 300 python tools/gpu_team_bench.py > $OUT/team_bench.txt 2>&1; timeout -k 10 300 python tools/gpu_planner_bench.py > $OUT/planner.txt 2>&1; timeout -k 10 300 python tools/gpu_drift_nocontact.py > $OUT/drift_nocontact.txt 2>&1; timeout -k 10 300 python tools/gpu_mpc_demo.py 4096 > $OUT/mpc_demo.txt 2>&1; timeout -k 10 300 python tools/gpu_latency.py > $OUT/latency.txt 2>&1; timeout -k 10 300 python tools/gpu_newton_bench.py > $OUT/newton_bench.txt 2>&1; timeout -k 10 200 python tools/gpu_newton_bench.py --phases > $OUT/newton_phases.txt 2>&1; timeout -k 10 200 python tools/gpu_newton_bench.py --probe > $OUT/newton_sections.txt 2>&1; echo "configs rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 300 python tools/gpu_soak.py > $OUT/soak.txt 2>&1; timeout -k 10 300 python tools/gpu_soak_pipelined.py 100000 > $OUT/soak_pipelined.txt 2>&1; timeout -k 10 200 python tools/gpu_config4_physics_only.py > $OUT/config4_physics_only.txt 2>&1; timeout -k 10 300 python tools/gpu_soak.py newton > $OUT/soak_newton.txt 2>&1; timeout -k 10 200 python tools/gpu_vecenv_bench.py > $OUT/vecenv.txt 2>&1; timeout -k 10 200 python tools/gpu_pgs_fit.py > $OUT/pgs_fit.txt 2>&1; timeout -k 10 200 python tools/gpu_config4.py > $OUT/config4.txt 2>&1; timeout -k 10 200 python tools/gpu_config5.py > $OUT/config5.txt 2>&1; timeout -k 10 300 python tools/gpu_team_bench.py > $OUT/team_bench.txt 2>&1; timeout -k 10 300 python tools/gpu_planner_bench.py > $OUT/planner.txt 2>&1; timeout -k 10 300 python tools/gpu_drift_nocontact.py > $OUT/drift_nocontact.txt 2>&1; timeout -k 10 300 python tools/gpu_mpc_demo.py 4096 > $OUT/mpc_demo.txt 2>&1; timeout -k 10 300 python tools/gpu_latency.py > $OUT/latency.txt 2>&1; timeout -k 10 300 python tools/gpu_fold_sizes.py > $OUT/fold_sizes.txt 2>&1; timeout -k 10 300 python tools/gpu_newton_bench.py > $OUT/newton_bench.txt 2>&1; timeout -k 10 200 python tools/gpu_newton_bench.py --phases > $OUT/newton_phases.txt 2>&1; timeout -k 10 200 python tools/gpu_newton_bench.py --probe > $OUT/newton_sections.txt 2>&1; echo "configs rc=$?" | tee -a $OUT/progress.log
 # kernel split of a staged step: the reference's own robot and the terrain humanoid (configs[4])
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_team -o t -- python3 tools/gpu_team_short.py > $OUT/team_short.txt 2>&1; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_config5 -o t -- python3 tools/gpu_team_short.py 8192 humanoid27_hfield.hbm > $OUT/config5_short.txt 2>&1; echo "staged traces rc=$?" | tee -a $OUT/progress.log
 find $OUT -name "*.csv" | head -40

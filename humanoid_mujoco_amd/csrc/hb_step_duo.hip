@@ -1078,22 +1078,40 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
       bool liveLo = nLo > 0 && max_sweeps > 0, liveHi = nHi > 0 && max_sweeps > 0;
       const bool sweptLo = liveLo, sweptHi = liveHi;
       float force_out = force;
-      while (liveLo || liveHi) {
+      // while BOTH envs sweep: one row step = row i of both (7 VALU: mul, max, two v_readlane, the half's pick, fma, and ONE v_cndmask under the
+      // mask {i, 32 + i} that keeps the two turn-holders' steps - they are the d_ of those very lanes)
+      while (liveLo && liveHi) {
         int ne;
         {
-          const int a = max(liveLo ? nLo : 0, liveHi ? nHi : 0);
+          const int a = max(nLo, nHi);
           asm volatile("s_mov_b32 %0, %1" : "=s"(ne) : "s"(a));
         }
         const float nforce = -force, res0 = res;
-        int dl = 0;
+        float dl = 0.f;
+        unsigned long long turn_ = 0x0000000100000001ull;  // the lanes whose turn it is: row 0 of both envs
 #define HB_PGS_ROW2(i)                                                               \
   if ((i) < 31) {                                                                    \
     const float d_ = fmaxf(res * nAinv, nforce);                                     \
-    const int da_ = __builtin_amdgcn_readlane(__float_as_int(d_), (i));              \
-    const int db_ = __builtin_amdgcn_readlane(__float_as_int(d_), 32 + (i));         \
-    res = __builtin_fmaf(arS[(i) < 31 ? (i) : 0], __int_as_float(h ? db_ : da_), res); \
-    dl = hb_writelane(da_, (i), dl);                                                 \
-    dl = hb_writelane(db_, 32 + (i), dl);                                            \
+    int da_, db_;                                                                    \
+    unsigned long long ex_;                                                          \
+    /* res += arS[i] * (the step of row i of the lane's own env): the two steps stay in scalar registers and each half takes its own */ \
+    /* under its half of EXEC (a v_cndmask between two scalars would cost two more VALU moves: one scalar operand per instruction). */ \
+    /* The turn-holders' mask {i, 32 + i} walks up one bit per row (thirty-one 64-bit constants would live in scalar registers, and */ \
+    /* spill).  One asm statement, ordered so that no VALU instruction reads a scalar register within two instructions of the */      \
+    /* statement's start or of the v_readlane that wrote it: the compiler's hazard recogniser does not look inside. */                 \
+    asm volatile("s_mov_b64 %[t], exec\n\t"                                          \
+                 "v_readlane_b32 %[a], %[d], %[ia]\n\t"                              \
+                 "v_readlane_b32 %[b], %[d], %[ib]\n\t"                              \
+                 "v_cndmask_b32_e64 %[dl], %[dl], %[d], %[turn]\n\t"                 \
+                 "s_lshl_b64 %[turn], %[turn], 1\n\t"                                \
+                 "s_mov_b64 exec, %[lo]\n\t"                                         \
+                 "v_fmac_f32_e32 %[r], %[a], %[ar]\n\t"                              \
+                 "s_mov_b64 exec, %[hi]\n\t"                                         \
+                 "v_fmac_f32_e32 %[r], %[b], %[ar]\n\t"                              \
+                 "s_mov_b64 exec, %[t]"                                               \
+                 : [r] "+v"(res), [dl] "+v"(dl), [turn] "+s"(turn_), [a] "=&s"(da_), [b] "=&s"(db_), [t] "=&s"(ex_) \
+                 : [d] "v"(d_), [ar] "v"(arS[(i) < 31 ? (i) : 0]), [ia] "n"(i), [ib] "n"(32 + (i)), [lo] "s"(0x00000000ffffffffull), [hi] "s"(0xffffffff00000000ull) \
+                 : "scc");                                                           \
   }
 #define HB_PGS_CHUNK2(c) if ((c) * 4 >= ne) break; HB_PGS_ROW2((c) * 4) HB_PGS_ROW2((c) * 4 + 1) HB_PGS_ROW2((c) * 4 + 2) HB_PGS_ROW2((c) * 4 + 3)
         do {
@@ -1101,25 +1119,54 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
         } while (0);
 #undef HB_PGS_CHUNK2
 #undef HB_PGS_ROW2
-        const float delta = __int_as_float(dl);
+        const float delta = dl;
         force += delta;
         float iLo, iHi;
         env_sums(delta * (res0 + res), iLo, iHi);
-        if (liveLo) {
-          niterLo++;
-          if (-0.5f * iLo * pgs_scale < pgs_tol || niterLo >= max_sweeps) {
-            liveLo = false;
-            if (!h) { force_out = force; res = 0.f; force = 0.f; }  // rows of a finished env are inert from here on
-          }
+        niterLo++; niterHi++;
+        if (-0.5f * iLo * pgs_scale < pgs_tol || niterLo >= max_sweeps) {
+          liveLo = false;
+          if (!h) { force_out = force; res = 0.f; force = 0.f; }  // rows of a finished env are inert from here on
         }
-        if (liveHi) {
-          niterHi++;
-          if (-0.5f * iHi * pgs_scale < pgs_tol || niterHi >= max_sweeps) {
-            liveHi = false;
-            if (h) { force_out = force; res = 0.f; force = 0.f; }
-          }
+        if (-0.5f * iHi * pgs_scale < pgs_tol || niterHi >= max_sweeps) {
+          liveHi = false;
+          if (h) { force_out = force; res = 0.f; force = 0.f; }
         }
       }
+      // ONE env still sweeps (the wave sweeps max(sA, sB) times: 29 against a mean of 20 per env): the one-env kernel's row step (5 VALU) on that
+      // env's lanes.  The other half's lanes ride along: their res takes garbage, their step stays 0 and their forces are in force_out.
+#define HB_PGS_ROW1(base, i)                                                         \
+  if ((i) < 31) {                                                                    \
+    const float d_ = fmaxf(res * nAinv, nforce);                                     \
+    const int di_ = __builtin_amdgcn_readlane(__float_as_int(d_), (base) + (i));     \
+    res = __builtin_fmaf(arS[(i) < 31 ? (i) : 0], __int_as_float(di_), res);         \
+    dl = hb_writelane(di_, (base) + (i), dl);                                        \
+  }
+#define HB_PGS_CHUNK1(base, c) if ((c) * 4 >= ne) break; HB_PGS_ROW1(base, (c) * 4) HB_PGS_ROW1(base, (c) * 4 + 1) HB_PGS_ROW1(base, (c) * 4 + 2) HB_PGS_ROW1(base, (c) * 4 + 3)
+#define HB_PGS_TAIL(base, live, n_, niter_, mine)                                    \
+      while (live) {                                                                 \
+        int ne;                                                                      \
+        asm volatile("s_mov_b32 %0, %1" : "=s"(ne) : "s"(n_));                       \
+        const float nforce = -force, res0 = res;                                     \
+        int dl = 0;                                                                  \
+        do {                                                                         \
+          HB_PGS_CHUNK1(base, 0) HB_PGS_CHUNK1(base, 1) HB_PGS_CHUNK1(base, 2) HB_PGS_CHUNK1(base, 3) HB_PGS_CHUNK1(base, 4) HB_PGS_CHUNK1(base, 5) HB_PGS_CHUNK1(base, 6) HB_PGS_CHUNK1(base, 7) \
+        } while (0);                                                                 \
+        const float delta = __int_as_float(dl);                                      \
+        force += delta;                                                              \
+        float iLo, iHi;                                                              \
+        env_sums((mine) ? delta * (res0 + res) : 0.f, iLo, iHi);                     \
+        niter_++;                                                                    \
+        if (-0.5f * ((base) ? iHi : iLo) * pgs_scale < pgs_tol || niter_ >= max_sweeps) { \
+          live = false;                                                              \
+          if (mine) force_out = force;                                               \
+        }                                                                            \
+      }
+      HB_PGS_TAIL(0, liveLo, nLo, niterLo, !h)
+      HB_PGS_TAIL(32, liveHi, nHi, niterHi, h)
+#undef HB_PGS_TAIL
+#undef HB_PGS_CHUNK1
+#undef HB_PGS_ROW1
       force = (h ? sweptHi : sweptLo) ? force_out : force;
     } else {
       const float nAinv = -1.f / Aii;

@@ -47,6 +47,16 @@ def steady(v):
     return [x for x in v if x <= 5 * med] if med > 0 else v
 
 
+# (since the timed loop's calls are folded, the bench command's own trace holds no one-env single-step launches: tools/gpu_round.sh traces
+# `bench.py --no-pipeline --duo 0 --fold 1` for them)
+trace1 = glob.glob(os.path.join(src, "prof_trace_h27", "*", "*_kernel_trace.csv"))
+if trace1 and not by_grid.get(full):
+    for row in csv.DictReader(open(trace1[0])):
+        if is_step(row["Kernel_Name"]):
+            by_grid[int(row.get("Grid_Size") or row["Grid_Size_X"])].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    st1 = glob.glob(os.path.join(src, "prof_trace_h27", "*", "*_kernel_stats.csv"))
+    if st1:
+        shutil.copy(st1[0], os.path.join(dst, rnd + "_kernel_stats_h27.csv"))
 by_grid = collections.defaultdict(list, {g: steady(v) for g, v in by_grid.items()})
 if by_grid.get(full):
     avg_ns = sum(by_grid[full]) / len(by_grid[full]); calls = len(by_grid[full])
@@ -120,7 +130,7 @@ def timed_kernel_profile():
     hb_step_duo_kernel).  Kernel trace: the bench command itself (--steps 1000: the last ceil(1000 / 256) dispatches)."""
     name, steps, waves = "hb_step_duo_q_kernel(", 256, 2048
     q = {}
-    for d in ("prof_q_fetch", "prof_q_write", "prof_q_sq", "prof_q_lds", "prof_q_mfma", "prof_q_valu"):
+    for d in ("prof_q_fetch", "prof_q_write", "prof_q_sq", "prof_q_lds", "prof_q_mfma", "prof_q_valu", "prof_q_icache"):
         fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
         if not fs:
             continue
@@ -128,10 +138,13 @@ def timed_kernel_profile():
         if not rows:
             continue
         last = max(int(r["Dispatch_Id"]) for r in rows)
+        one = {}
         for r in rows:
             if int(r["Dispatch_Id"]) == last:
-                q[r["Counter_Name"]] = q.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                one[r["Counter_Name"]] = one.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                 q["_meta"] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+        for k, v in one.items():
+            q.setdefault(k, v)  # (a counter collected in two passes: the first pass' reading)
     res = {"kernel": "hb_step_duo_q_kernel", "pmc_launch": "%d blocks x 64 lanes (two envs each), %d steps in the launch" % (waves, steps), "counters_of_that_launch": q}
     if trace:
         rows = [(int(r["Dispatch_Id"]) if "Dispatch_Id" in r else i, float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
@@ -154,6 +167,8 @@ def timed_kernel_profile():
         res["mfma_busy_frac"] = q["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * q["SQ_BUSY_CU_CYCLES"])
     if "SQ_ACTIVE_INST_VALU" in q and q.get("SQ_BUSY_CU_CYCLES"):
         res["valu_pipe_busy_frac"] = q["SQ_ACTIVE_INST_VALU"] / q["SQ_BUSY_CU_CYCLES"]
+    if "SQC_ICACHE_MISSES" in q and q.get("SQC_ICACHE_REQ"):
+        res["icache_miss_frac_of_requests"] = q["SQC_ICACHE_MISSES"] / q["SQC_ICACHE_REQ"]
     if "SQ_WAIT_INST_ANY" in q and q.get("SQ_WAVE_CYCLES"):
         res["sq_wait_inst_any_frac_of_wave_cycles"] = q["SQ_WAIT_INST_ANY"] / q["SQ_WAVE_CYCLES"]
     return res if (q or "kernel_trace" in res) else None

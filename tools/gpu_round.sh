@@ -23,6 +23,8 @@ timeout -k 10 300 ./build/hb_testspeed humanoid_mujoco_amd/assets/humanoid27.hbm
 timeout -k 10 300 ./build/hb_testspeed_stamps humanoid_mujoco_amd/assets/humanoid27.hbm 300 4096 > $OUT/testspeed_stages.log 2>&1; timeout -k 10 300 ./build/hb_testspeed humanoid_mujoco_amd/assets/team_robot.hbm 500 4096 > $OUT/testspeed_team.log 2>&1
 echo "== rocprofv3 kernel trace" | tee -a $OUT/progress.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- python3 bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-rollout --no-newton --no-team > $OUT/prof_trace.log 2>&1; echo "trace rc=$?" | tee -a $OUT/progress.log
+# the one-env-per-wave single-step kernel (hb_step_h27_kernel: batches below 4096 envs, closed loops), one launch per step: its launch durations for the PMC passes below
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace_h27 -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 --fold 1 > $OUT/prof_trace_h27.log 2>&1; echo "trace h27 rc=$?" | tee -a $OUT/progress.log
 echo "== rocprofv3 pmc FETCH" | tee -a $OUT/progress.log
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_fetch.log 2>&1; echo "fetch rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 > $OUT/prof_write.log 2>&1; echo "write rc=$?" | tee -a $OUT/progress.log
@@ -40,6 +42,8 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
 timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_q_lds -- python3 bench.py $QARGS > $OUT/prof_q_lds.log 2>&1; echo "q lds rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 300 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/prof_q_valu -- python3 bench.py $QARGS > $OUT/prof_q_valu.log 2>&1; echo "q valu rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/prof_q_mfma -- python3 bench.py $QARGS > $OUT/prof_q_mfma.log 2>&1; echo "q mfma rc=$?" | tee -a $OUT/progress.log
+# (waves of a 256-step launch drift apart: does the instruction cache still hold what 8 waves per CU are running?)
+timeout -k 10 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/prof_q_icache -- python3 bench.py $QARGS > $OUT/prof_q_icache.log 2>&1; echo "q icache rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_pipeline_sweep.py > $OUT/pipeline_sweep.txt 2>&1; echo "sweep rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_phase_profile.py 4096 > $OUT/phase_profile.txt 2>&1; echo "phase rc=$?" | tee -a $OUT/progress.log
 timeout -k 10 200 python tools/gpu_phase_profile.py 4096 humanoid27_hfield.hbm > $OUT/phase_config5.txt 2>&1; timeout -k 10 200 python tools/gpu_phase_profile.py 4096 team_robot.hbm > $OUT/phase_team.txt 2>&1; timeout -k 10 400 python tools/gpu_pipeline_queues.py default GPU_MAX_HW_QUEUES=8 GPU_MAX_HW_QUEUES=16 > $OUT/pipeline_queues.txt 2>&1; timeout -k 10 900 bash tools/gpu_phase_instructions.sh $OUT/phase_inst > $OUT/phase_instructions.txt 2>&1

@@ -135,7 +135,12 @@ __device__ __forceinline__ void climb_eval(const float4 (&q)[kMeshChunk], Climb&
 // corrupt tables or non-finite directions, where a kernel that never ends would take the device with it)
 constexpr int kClimbMax = 1024;
 __device__ __forceinline__ void climb(const CObj& o, Climb& c) {
-  for (int guard = 0; guard < kClimbMax; guard++) {
+#ifdef HB_NARROW_DIAG
+  const int rounds_max = min(kClimbMax, g_mpr_limit[1]);
+#else
+  constexpr int rounds_max = kClimbMax;
+#endif
+  for (int guard = 0; guard < rounds_max; guard++) {
     const int adr = c.link >> 8, nch = c.link & 255;
     bool moved = false;
     V3 nb = c.best;
@@ -227,96 +232,140 @@ __device__ __forceinline__ bool mpr_reach_tolerance(const CSup& P1, const CSup& 
   const double d = fmin(fmin(dv4 - dot(P1.v, dir), dv4 - dot(P2.v, dir)), dv4 - dot(P3.v, dir));
   return ccd_eq(d, tol) || d < tol;
 }
+// (which portal vertex v4 replaces is data: written as a store through a chosen pointer the three vertices live in scratch memory, a
+// round trip through the cache hierarchy on every use; as selects they stay in registers)
+__device__ __forceinline__ V3d pick(bool c, V3d a, V3d b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 __device__ __forceinline__ void mpr_expand_portal(const CSup& P0, CSup& P1, CSup& P2, CSup& P3, const CSup& v4) {
   const V3d v4v0 = cross(v4.v, P0.v);
-  if (dot(P1.v, v4v0) > 0.0) { if (dot(P2.v, v4v0) > 0.0) P1 = v4; else P3 = v4; }
-  else { if (dot(P3.v, v4v0) > 0.0) P2 = v4; else P1 = v4; }
+  const bool a = dot(P1.v, v4v0) > 0.0, b = dot(P2.v, v4v0) > 0.0, c = dot(P3.v, v4v0) > 0.0;
+  const bool to1 = a ? b : !c, to2 = !a && c, to3 = a && !b;
+  P1.v = pick(to1, v4.v, P1.v); P1.v1 = pick(to1, v4.v1, P1.v1);
+  P2.v = pick(to2, v4.v, P2.v); P2.v1 = pick(to2, v4.v1, P2.v1);
+  P3.v = pick(to3, v4.v, P3.v); P3.v1 = pick(to3, v4.v1, P3.v1);
 }
 
-// ccdMPRPenetration: true (and depth, dir from obj1 into obj2, pos) when the objects intersect
+// ccdMPRPenetration: true (and depth, dir from obj1 into obj2, pos) when the objects intersect.
+// libccd's three loops (discoverPortal, refinePortal, findPenetration: the oracle's mpr_penetration has them as written there) run here
+// as ONE loop around ONE support call, the lane's place in the algorithm kept in `state`: a wave runs a different test in every lane,
+// and lanes inside different loops of the original would execute those loops one after the other (the wave's time the sum over the
+// loops of the slowest lane in each); with one loop it is the number of support calls of the longest test.  Per lane the statements,
+// their order and their operands are the original's.
 template <int MESH = 1>
 __device__ __forceinline__ bool mpr_penetration(const CObj& o1, const CObj& o2, int max_iterations, double tolerance, float& depth_out, V3& pdir_out, V3& pos_out) {
-  CSup P0, P1, P2, P3, v4;
+  CSup P0, P1, P2, P3;
   const V3d origin = {0.0, 0.0, 0.0};
-  double depth;
-  V3d pdir, pos;
+  P1.v = origin; P1.v1 = origin; P2 = P1; P3 = P1;
   // ---- discoverPortal
   P0.v1 = ccd_center(o1);
   P0.v = P0.v1 - ccd_center(o2);
   if (ccd_eq(P0.v.x, 0.0) && ccd_eq(P0.v.y, 0.0) && ccd_eq(P0.v.z, 0.0)) P0.v.x += HB_CCD_EPS * 10.0;
   V3d dir = normalized(P0.v * -1.0);
-  P1 = mpr_support<MESH>(o1, o2, dir);
-  double dt = dot(P1.v, dir);
-  if (ccd_is_zero(dt) || dt < 0.0) return false;
-  dir = cross(P0.v, P1.v);
-  if (ccd_is_zero(dot(dir, dir))) {
-    pos_out = narrow(P1.v1 - P1.v * 0.5);  // 0.5 (v1 + v2), v2 = v1 - v
-    if (ccd_eq(P1.v.x, 0.0) && ccd_eq(P1.v.y, 0.0) && ccd_eq(P1.v.z, 0.0)) { depth_out = 0.f; pdir_out = {0.f, 0.f, 0.f}; return true; }  // touching
-    double n;
-    pdir_out = narrow(normalized(P1.v, &n));
-    depth_out = (float)n;
-    return true;
-  }
-  dir = normalized(dir);
-  P2 = mpr_support<MESH>(o1, o2, dir);
-  dt = dot(P2.v, dir);
-  if (ccd_is_zero(dt) || dt < 0.0) return false;
-  dir = normalized(cross(P1.v - P0.v, P2.v - P0.v));
-  if (dot(dir, P0.v) > 0.0) { const CSup t = P1; P1 = P2; P2 = t; dir = dir * -1.0; }
-  for (int guard = 0;; guard++) {
-    if (guard > 1000) return false;
-    P3 = mpr_support<MESH>(o1, o2, dir);
-    dt = dot(P3.v, dir);
-    if (ccd_is_zero(dt) || dt < 0.0) return false;
-    bool cont = false;
-    dt = dot(cross(P1.v, P3.v), P0.v);
-    if (dt < 0.0 && !ccd_is_zero(dt)) { P2 = P3; cont = true; }
-    if (!cont) {
-      dt = dot(cross(P3.v, P2.v), P0.v);
-      if (dt < 0.0 && !ccd_is_zero(dt)) { P1 = P3; cont = true; }
-    }
-    if (!cont) break;
-    dir = normalized(cross(P1.v - P0.v, P2.v - P0.v));
-  }
-  // ---- refinePortal
-  for (int guard = 0;; guard++) {
-    if (guard > 1000) return false;
+  enum { S_P1 = 0, S_P2, S_DISCOVER, S_REFINE, S_FIND, S_DONE };
+  int state = S_P1;
+  int count = 0;  // iterations of the loop the lane is in (discover / refine: libccd's guard; find: `it`)
+  bool hit = false;
+  // the head of refinePortal's loop: the portal's direction; leaves for findPenetration when the origin is on its outer side
+  auto refine_head = [&]() {
     dir = mpr_portal_dir(P1, P2, P3);
-    dt = dot(dir, P1.v);
-    if (ccd_is_zero(dt) || dt > 0.0) break;
-    v4 = mpr_support<MESH>(o1, o2, dir);
-    dt = dot(v4.v, dir);
-    if (!(ccd_is_zero(dt) || dt > 0.0) || mpr_reach_tolerance(P1, P2, P3, v4, dir, tolerance)) return false;
-    mpr_expand_portal(P0, P1, P2, P3, v4);
-  }
-  // ---- findPenetr
-  for (int it = 0;; it++) {
-    dir = mpr_portal_dir(P1, P2, P3);
-    v4 = mpr_support<MESH>(o1, o2, dir);
-    if (mpr_reach_tolerance(P1, P2, P3, v4, dir, tolerance) || it > max_iterations) {
-      const V3d w = closest_on_triangle(origin, P1.v, P2.v, P3.v);
-      depth = sqrt(dot(w, w));
-      if (ccd_is_zero(depth)) pdir = origin;
-      else pdir = normalized(w);
-      // findPos: barycentric coordinates of the origin in the portal tetrahedron
-      dir = mpr_portal_dir(P1, P2, P3);
-      double b0 = dot(cross(P1.v, P2.v), P3.v), b1 = dot(cross(P3.v, P2.v), P0.v), b2 = dot(cross(P0.v, P1.v), P3.v), b3 = dot(cross(P2.v, P1.v), P0.v);
-      double sum = b0 + b1 + b2 + b3;
-      if (ccd_is_zero(sum) || sum < 0.0) {
-        b0 = 0.0;
-        b1 = dot(cross(P2.v, P3.v), dir); b2 = dot(cross(P3.v, P1.v), dir); b3 = dot(cross(P1.v, P2.v), dir);
-        sum = b1 + b2 + b3;
+    const double dt = dot(dir, P1.v);
+    if (ccd_is_zero(dt) || dt > 0.0) { state = S_FIND; count = 0; }  // (findPenetration starts from the same portal direction)
+  };
+#ifdef HB_NARROW_DIAG
+  int diag_calls = 0;
+#endif
+  while (state != S_DONE) {
+#ifdef HB_NARROW_DIAG
+    if (diag_calls++ >= g_mpr_limit[0]) break;
+#endif
+    const CSup s = mpr_support<MESH>(o1, o2, dir);
+    if (state == S_P1) {
+      P1 = s;
+      const double dt = dot(P1.v, dir);
+      if (ccd_is_zero(dt) || dt < 0.0) state = S_DONE;
+      else {
+        dir = cross(P0.v, P1.v);
+        if (ccd_is_zero(dot(dir, dir))) {
+          pos_out = narrow(P1.v1 - P1.v * 0.5);  // 0.5 (v1 + v2), v2 = v1 - v
+          if (ccd_eq(P1.v.x, 0.0) && ccd_eq(P1.v.y, 0.0) && ccd_eq(P1.v.z, 0.0)) { depth_out = 0.f; pdir_out = {0.f, 0.f, 0.f}; }  // touching
+          else {
+            double n;
+            pdir_out = narrow(normalized(P1.v, &n));
+            depth_out = (float)n;
+          }
+          hit = true;
+          state = S_DONE;
+        } else {
+          dir = normalized(dir);
+          state = S_P2;
+        }
       }
-      const double inv = 1.0 / sum;
-      // 0.5 (p1 + p2) with p2_i = v1_i - v_i
-      const V3d p1 = P0.v1 * b0 + P1.v1 * b1 + P2.v1 * b2 + P3.v1 * b3;
-      const V3d pv = P0.v * b0 + P1.v * b1 + P2.v * b2 + P3.v * b3;
-      pos = (p1 - pv * 0.5) * inv;
-      depth_out = (float)depth; pdir_out = narrow(pdir); pos_out = narrow(pos);
-      return true;
+    } else if (state == S_P2) {
+      P2 = s;
+      const double dt = dot(P2.v, dir);
+      if (ccd_is_zero(dt) || dt < 0.0) state = S_DONE;
+      else {
+        dir = normalized(cross(P1.v - P0.v, P2.v - P0.v));
+        if (dot(dir, P0.v) > 0.0) { const CSup t = P1; P1 = P2; P2 = t; dir = dir * -1.0; }
+        state = S_DISCOVER; count = 0;
+      }
+    } else if (state == S_DISCOVER) {
+      P3 = s;
+      double dt = dot(P3.v, dir);
+      if (ccd_is_zero(dt) || dt < 0.0) state = S_DONE;
+      else {
+        bool cont = false;
+        dt = dot(cross(P1.v, P3.v), P0.v);
+        if (dt < 0.0 && !ccd_is_zero(dt)) { P2 = P3; cont = true; }
+        if (!cont) {
+          dt = dot(cross(P3.v, P2.v), P0.v);
+          if (dt < 0.0 && !ccd_is_zero(dt)) { P1 = P3; cont = true; }
+        }
+        if (cont) {
+          dir = normalized(cross(P1.v - P0.v, P2.v - P0.v));
+          if (++count > 1000) state = S_DONE;
+        } else {
+          state = S_REFINE; count = 0;
+          refine_head();
+        }
+      }
+    } else if (state == S_REFINE) {
+      const double dt = dot(s.v, dir);
+      if (!(ccd_is_zero(dt) || dt > 0.0) || mpr_reach_tolerance(P1, P2, P3, s, dir, tolerance)) state = S_DONE;
+      else {
+        mpr_expand_portal(P0, P1, P2, P3, s);
+        if (++count > 1000) state = S_DONE;
+        else refine_head();
+      }
+    } else {  // S_FIND
+      if (mpr_reach_tolerance(P1, P2, P3, s, dir, tolerance) || count > max_iterations) {
+        const V3d w = closest_on_triangle(origin, P1.v, P2.v, P3.v);
+        const double depth = sqrt(dot(w, w));
+        const V3d pdir = ccd_is_zero(depth) ? origin : normalized(w);
+        // findPos: barycentric coordinates of the origin in the portal tetrahedron
+        dir = mpr_portal_dir(P1, P2, P3);
+        double b0 = dot(cross(P1.v, P2.v), P3.v), b1 = dot(cross(P3.v, P2.v), P0.v), b2 = dot(cross(P0.v, P1.v), P3.v), b3 = dot(cross(P2.v, P1.v), P0.v);
+        double sum = b0 + b1 + b2 + b3;
+        if (ccd_is_zero(sum) || sum < 0.0) {
+          b0 = 0.0;
+          b1 = dot(cross(P2.v, P3.v), dir); b2 = dot(cross(P3.v, P1.v), dir); b3 = dot(cross(P1.v, P2.v), dir);
+          sum = b1 + b2 + b3;
+        }
+        const double inv = 1.0 / sum;
+        // 0.5 (p1 + p2) with p2_i = v1_i - v_i
+        const V3d p1 = P0.v1 * b0 + P1.v1 * b1 + P2.v1 * b2 + P3.v1 * b3;
+        const V3d pv = P0.v * b0 + P1.v * b1 + P2.v * b2 + P3.v * b3;
+        const V3d pos = (p1 - pv * 0.5) * inv;
+        depth_out = (float)depth; pdir_out = narrow(pdir); pos_out = narrow(pos);
+        hit = true;
+        state = S_DONE;
+      } else {
+        mpr_expand_portal(P0, P1, P2, P3, s);
+        count++;
+        dir = mpr_portal_dir(P1, P2, P3);
+      }
     }
-    mpr_expand_portal(P0, P1, P2, P3, v4);
   }
+  return hit;
 }
 
 // mjc_fixNormal: a sphere or capsule supplies its own surface normal at the contact point (oracle: fix_normal)

@@ -1,6 +1,14 @@
 // hb_narrow.hip - the staged step of the general variants: hb_pose_kernel (poses, broadphase, work items) and the narrowphase kernels
 // (one work item per lane).  See hb_step.hip for the step kernels that gather their results.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#ifdef HB_STAMPS
+// diagnostic build only (tools/gpu_narrow_limits.sh): HB_MPR_LIMIT="a,b" in the environment cuts every portal search off after a support
+// calls and every hull climb after b rounds - WRONG contacts, but the launch durations say where the narrowphase's time goes
+#define HB_NARROW_DIAG 1
+namespace hb { __device__ int g_mpr_limit[2] = {1 << 30, 1 << 30}; }
+#endif
 #include "hb_kcommon.hpp"
 #include "hb_collide.hpp"
 #include "hb_launch.hpp"
@@ -215,6 +223,17 @@ __global__ __launch_bounds__(kGroup, 3) void hb_narrow2_prim_kernel(const DevMod
 
 hipError_t launch_pose_narrow(const DevModel* M_dev, const BatchPtrs& Q, hipStream_t stream) {
   (void)hipGetLastError();
+#ifdef HB_NARROW_DIAG
+  static const bool limits_set = [] {
+    if (const char* e = getenv("HB_MPR_LIMIT")) {
+      int v[2] = {1 << 30, 1 << 30};
+      sscanf(e, "%d,%d", &v[0], &v[1]);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mpr_limit), v, sizeof v);
+    }
+    return true;
+  }();
+  (void)limits_set;
+#endif
   hipLaunchKernelGGL(hb_pose_kernel, dim3(Q.nblk), dim3(kGroup), (size_t)Q.stage.pose_lds, stream, M_dev, Q);
   const bool pairs = Q.nblk == Q.n_env && Q.n_env >= 512;  // a launch that covers its whole batch: nothing overlaps its tail anyway
   if (pairs) {

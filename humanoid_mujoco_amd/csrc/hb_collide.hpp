@@ -182,7 +182,7 @@ __device__ __forceinline__ int build_work_list(DevModelRef M, int lane, const fl
 // pass (3) for one work item: pair p (sub-item `sub` of the sub-grid rmin, cmin, ncols for a height-field pair) -> n contacts (0..2).
 // MODE 0: all of it.  MODE 1 (hb_pose_kernel): everything but the portal search; returns whether the item needs one (then n = 0).
 // MODE 2 (hb_narrow_kernel): an item MODE 1 said needs the portal search.
-template <int MODE, int MESH = 1>
+template <int MODE, int MESH = 1, int GROUP = 1>
 __device__ __forceinline__ int eval_work_item(DevModelRef M, const float* hdata_all, bool have, int p, int sub, int rmin, int cmin, int ncols, float loz,
                                               const float* s_gpos, const float* s_gaxis, const float* s_gquat, ConOut& co0, ConOut& co1, int& n, V3& hint) {
   float4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
@@ -285,7 +285,7 @@ __device__ __forceinline__ int eval_work_item(DevModelRef M, const float* hdata_
   if (mpr_kind) {
     float depth;
     V3 dir, vec;
-    const bool hit = mpr_penetration<MESH>(o1, o2, M.mpr_iterations, (double)M.mpr_tolerance, depth, dir, vec);
+    const bool hit = mpr_penetration<MESH, GROUP>(o1, o2, M.mpr_iterations, (double)M.mpr_tolerance, depth, dir, vec);
     if (mpr_kind == 1) {
       if (hit && depth >= 2.220446e-16f) {
         co0.dist = -depth;

@@ -180,39 +180,44 @@ __device__ __forceinline__ void narrow_body(const DevModel* Mp, const BatchPtrs&
   const int lane = threadIdx.x;
   // heavy first (BatchPtrs::order2: the envs of this launch sorted by the time their wave took in an earlier step): the launch ends
   // when its slowest wave does, and a slow wave that starts in the last round ends late
-  constexpr int kPer = PAIR ? 32 : kGroup;  // searches of an env per chunk
+  // a model with meshes: four lanes per search (hb_mpr.hpp: climb4), sixteen searches per wave; otherwise a lane per search
+  constexpr int G = MESH ? 4 : 1;
+  constexpr int kPer = (PAIR ? 32 : kGroup) / G;  // searches of an env per chunk
   const int nslot = PAIR ? (P.nblk + 1) >> 1 : P.nblk;
-  const int chunk = (int)blockIdx.x / nslot, pr = (int)blockIdx.x % nslot;
+  const int nwaves = (int)gridDim.x / nslot;  // waves per slot: wave c takes chunks c, c + nwaves, ... of its env(s)
+  const int pr = (int)blockIdx.x % nslot;
   const int half = PAIR ? lane >> 5 : 0, l = PAIR ? lane & 31 : lane;
   const int slot = P.blk0 + (PAIR ? 2 * pr + half : pr);
   const bool live = !PAIR || 2 * pr + half < P.nblk;
   const int env = live ? (P.order2 ? P.order2[slot] : slot) : 0;
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   const int n1 = live ? P.stage.nsearch[2 * env] : 0, n2 = live ? P.stage.nsearch[2 * env + 1] : 0;
-  const int j = chunk * kPer + l;
-  if (chunk == 0 && l == 0 && live) P.counts[kCountStride * (size_t)env + 7] = 0;
-  if (!__any(chunk * kPer < n1 + n2)) return;
-  const bool have = j < n1 + n2;
-  int4 it = {env, 0, 1 << 16, 0};
-  if (have) it = P.stage.item[(size_t)env * kWorkMax + (j < n1 ? j : kWorkMax - 1 - (j - n1))];
+  const bool first = (int)blockIdx.x / nslot == 0;
+  if (first && l == 0 && live) P.counts[kCountStride * (size_t)env + 7] = 0;
   const int ng = M.ngeom;
   const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
-  const int p = it.y & 0xffff, w = it.y >> 16;
   const float* g = P.stage.geom + (size_t)env * ng * 10;
   const float* hdata = P.dr ? P.dr + (size_t)env * P.dr_stride + DL.o_hfield : (const float*)M.hfield_data;
-  ConOut co0, co1;
-  int n;
-  V3 hint;
-  eval_work_item<2, MESH>(M, hdata, have, p, it.z & 0xffff, it.w & 0xffff, it.w >> 16, it.z >> 16, 0.f, g, g + 3 * ng, g + 6 * ng, co0, co1, n, hint);
-  if (have) {
-    float4* R = P.stage.result + ((size_t)env * kWorkMax + w) * 4;
-    R[0] = {co0.dist, co0.pos.x, co0.pos.y, co0.pos.z};
-    R[1] = {co0.n.x, co0.n.y, co0.n.z, __int_as_float(n)};
-    R[2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
-    R[3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(p)};
+  for (int chunk = (int)blockIdx.x / nslot; __any(chunk * kPer < n1 + n2); chunk += nwaves) {
+    const int j = chunk * kPer + l / G;
+    const bool have = j < n1 + n2;
+    int4 it = {env, 0, 1 << 16, 0};
+    if (have) it = P.stage.item[(size_t)env * kWorkMax + (j < n1 ? j : kWorkMax - 1 - (j - n1))];
+    const int p = it.y & 0xffff, w = it.y >> 16;
+    ConOut co0, co1;
+    int n;
+    V3 hint;
+    eval_work_item<2, MESH, G>(M, hdata, have, p, it.z & 0xffff, it.w & 0xffff, it.w >> 16, it.z >> 16, 0.f, g, g + 3 * ng, g + 6 * ng, co0, co1, n, hint);
+    if (have && (l & (G - 1)) == 0) {
+      float4* R = P.stage.result + ((size_t)env * kWorkMax + w) * 4;
+      R[0] = {co0.dist, co0.pos.x, co0.pos.y, co0.pos.z};
+      R[1] = {co0.n.x, co0.n.y, co0.n.z, __int_as_float(n)};
+      R[2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
+      R[3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(p)};
+    }
   }
   // (the cost the heavy-first order of the next launches sorts by: the time of the env's - first - wave)
-  if (chunk == 0 && l == 0 && live) P.counts[kCountStride * (size_t)env + 7] = (int)min(255ull, (__builtin_amdgcn_s_memtime() - t_begin) >> 10);
+  if (first && l == 0 && live) P.counts[kCountStride * (size_t)env + 7] = (int)min(255ull, (__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 __global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<1>(Mp, P); }
 // a model without mesh geoms (configs[4]: capsules and spheres over the height field's prisms): no hull climb in the kernel
@@ -237,11 +242,13 @@ hipError_t launch_pose_narrow(const DevModel* M_dev, const BatchPtrs& Q, hipStre
   hipLaunchKernelGGL(hb_pose_kernel, dim3(Q.nblk), dim3(kGroup), (size_t)Q.stage.pose_lds, stream, M_dev, Q);
   const bool pairs = Q.nblk == Q.n_env && Q.n_env >= 512;  // a launch that covers its whole batch: nothing overlaps its tail anyway
   if (pairs) {
-    const dim3 grid(((Q.nblk + 1) / 2) * (kWorkMax / 32));
-    if (Q.stage.no_mesh) hipLaunchKernelGGL(hb_narrow2_prim_kernel, grid, dim3(kGroup), 0, stream, M_dev, Q);
-    else hipLaunchKernelGGL(hb_narrow2_kernel, grid, dim3(kGroup), 0, stream, M_dev, Q);
+    // (waves per pair of envs: a wave without searches left ends at once.  Meshes: four lanes per search, two waves hold sixteen searches per env -
+    // the reference's robot has at most eleven - and loop for more; without meshes a lane per search, a wave per 32 searches of each env)
+    const int slots = (Q.nblk + 1) / 2;
+    if (Q.stage.no_mesh) hipLaunchKernelGGL(hb_narrow2_prim_kernel, dim3(slots * (kWorkMax / 32)), dim3(kGroup), 0, stream, M_dev, Q);
+    else hipLaunchKernelGGL(hb_narrow2_kernel, dim3(slots * 2), dim3(kGroup), 0, stream, M_dev, Q);
   } else if (Q.stage.no_mesh) hipLaunchKernelGGL(hb_narrow_prim_kernel, dim3(Q.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
-  else hipLaunchKernelGGL(hb_narrow_kernel, dim3(Q.nblk * (kWorkMax / kGroup)), dim3(kGroup), 0, stream, M_dev, Q);
+  else hipLaunchKernelGGL(hb_narrow_kernel, dim3(Q.nblk * 2), dim3(kGroup), 0, stream, M_dev, Q);
   return hipGetLastError();
 }
 

@@ -693,7 +693,7 @@ int ensure_ctrl(hb_batch* b, size_t floats) {
 StageBufs staged(const hb_batch* b) {
   StageBufs sb = b->stage;
   if (!b->tune[HB_TUNE_STAGED]) { sb = StageBufs{}; return sb; }
-  if (!b->tune[HB_TUNE_FASTPASS]) { sb.defer = nullptr; sb.dm_fast = nullptr; sb.fast_lds = 0; }
+  if (!b->tune[HB_TUNE_FASTPASS]) { sb.defer = nullptr; sb.defer_list = nullptr; sb.defer_count = nullptr; sb.dm_fast = nullptr; sb.fast_lds = 0; }
   if (!b->tune[HB_TUNE_NARROW_PRIM]) sb.no_mesh = 0;
   return sb;
 }
@@ -1081,8 +1081,9 @@ hb_batch* hb_batch_create(const hb_model* m, int n_env, int device, char* err, i
     sb.no_mesh = b->model->m.nmesh == 0 ? 1 : 0;
     sb.pose_lds = pose_lds_floats(dm.nq, dm.nbody, dm.ngeom) * (int)sizeof(float);
     if (dm.variant == 1 || b->D.d_dm_fast) {
-      ok = ok && hipMalloc((void**)&sb.defer, (size_t)n_env * sizeof(int)) == hipSuccess;
-      ok = ok && hipMemset(sb.defer, 0, (size_t)n_env * sizeof(int)) == hipSuccess;
+      ok = ok && hipMalloc((void**)&sb.defer, (size_t)n_env * 3 * sizeof(int)) == hipSuccess;  // flags | list | counters (StageBufs)
+      ok = ok && hipMemset(sb.defer, 0, (size_t)n_env * 3 * sizeof(int)) == hipSuccess;
+      if (ok) { sb.defer_list = sb.defer + n_env; sb.defer_count = sb.defer + 2 * (size_t)n_env; }
       if (dm.variant == 2 || dm.variant == 3) { sb.dm_fast = b->D.d_dm_fast; sb.fast_lds = b->D.fast_lds_floats * (int)sizeof(float); }
       if (ok && sb.fast_lds > 64 * 1024) ok = set_step_lds_limit(sb.fast_lds) == hipSuccess;
     }

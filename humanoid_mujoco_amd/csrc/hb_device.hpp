@@ -252,6 +252,11 @@ struct StageBufs {
   const DevModel* dm_fast;  // null: no fast pass (not variant 2, or diagnostics on: their buffers have the big kernel's strides)
   int fast_lds;             // its dynamic LDS bytes
   int* defer;               // [n_env]
+  // the deferred envs of a launch as a list, so that the second pass is a handful of waves that loop over it instead of one wave per env
+  // that looks at its flag and leaves (4096 waves of the four-group kernel, one per SIMD: 18 us): defer_list[blk0 + k], k < defer_count[blk0]
+  // (blk0: the launch's first slot - every env segment has its own stretch and counter).  hb_pose_kernel zeroes the counter.
+  int* defer_list;
+  int* defer_count;
   int rerun;                // set by launch_step for the second pass
   int no_mesh;              // the model has no mesh geoms: the narrowphase launch is hb_narrow_prim_kernel
 };

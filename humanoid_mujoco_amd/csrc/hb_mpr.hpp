@@ -138,6 +138,8 @@ constexpr int kClimbMax = 1024;
 // the four loads and values records r and r + 4 of every chunk, then the four exchange their best (key: value, tie value, position in the
 // list - the order the one-lane scan takes records in) in two steps inside the quad and fetch the winner's record from the lane that
 // holds it.  A round is ~ 90 vector instructions instead of ~ 200, and the instructions of a wave serve sixteen tests.
+// (Tried on top, round 4, and dropped: the climbs of the two objects of a support call round by round side by side, their loads in flight
+// together - the narrowphase launch 84.7 -> 91.3 us: a hull against a hull is rare, and every other search paid for the second half.)
 __device__ __forceinline__ double quad_xchg(double v, bool far) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
   const int plo = far ? __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true);

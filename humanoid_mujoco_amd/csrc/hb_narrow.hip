@@ -24,6 +24,7 @@ __global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, 
   const int lane = threadIdx.x;
   if ((int)blockIdx.x >= P.nblk) return;
   const int env = P.blk0 + (int)blockIdx.x;
+  if (blockIdx.x == 0 && lane == 0 && P.stage.defer_count) P.stage.defer_count[P.blk0] = 0;  // (the list the step's fast pass fills for its second pass)
   if (P.env_mask && !P.env_mask[env]) { if (lane == 0) { P.stage.nwork[env] = 0; P.stage.nsearch[2 * env] = 0; P.stage.nsearch[2 * env + 1] = 0; } return; }
   const int nq = M.nq, nv = M.nv, nb = M.nbody, ng = M.ngeom;
   float* s_qpos = lds;
@@ -166,7 +167,10 @@ __global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, 
 // first, exactly as the fused step kernel would (eval_work_item).  The waves are mostly empty (an env has about nine searches), but
 // there are as many of them as the chip holds at once; packing the searches of all envs densely into waves (a prefix sum over the
 // per-env counts, 64 / 16 / 4 searches per wave, one kernel per kind of search) measured slower: a wave's time is set by its
-// longest search and the divergence between its lanes, not by how many lanes it has.
+// longest search and the divergence between its lanes, not by how many lanes it has.  Round 4 tried it again on top of the
+// four-lane searches and the one-loop portal search (a flat list filled by one atomicAdd per env in hb_pose_kernel, sixteen consecutive
+// searches per wave): the narrowphase launch stayed at 85 us - it lasts as long as its longest search, 170-190 k cycles - and the 4096
+// atomics on one counter cost the pose kernel 23 us.
 // PAIR = 1: TWO envs per wave (lanes 0..31: one env's searches, 32..63: the other's; thirty-two searches of each per chunk).  A wave's time is
 // the latency of one portal search - a chain of dependent fp64 operations and table loads - plus a little for every further search that
 // runs beside it (55 k cycles + 5 k per search on the lying robot, profiles/r04_team_counters.json: 2.7 of 64 lanes active per vector
@@ -198,7 +202,7 @@ __device__ __forceinline__ void narrow_body(const DevModel* Mp, const BatchPtrs&
   const DomainLayout DL = domain_layout(M.nbody, M.nv, M.nlimcand, M.nu, M.nhfielddata);
   const float* g = P.stage.geom + (size_t)env * ng * 10;
   const float* hdata = P.dr ? P.dr + (size_t)env * P.dr_stride + DL.o_hfield : (const float*)M.hfield_data;
-  for (int chunk = (int)blockIdx.x / nslot; __any(chunk * kPer < n1 + n2); chunk += nwaves) {
+  auto run_chunk = [&](int chunk) {
     const int j = chunk * kPer + l / G;
     const bool have = j < n1 + n2;
     int4 it = {env, 0, 1 << 16, 0};
@@ -215,16 +219,21 @@ __device__ __forceinline__ void narrow_body(const DevModel* Mp, const BatchPtrs&
       R[2] = {co1.dist, co1.pos.x, co1.pos.y, co1.pos.z};
       R[3] = {co1.n.x, co1.n.y, co1.n.z, __int_as_float(p)};
     }
+  };
+  if constexpr (G == 1) {  // (a wave per chunk: launch_pose_narrow; a loop here costs the kernel without the hull climb 50 more spilled registers)
+    if (__any((int)blockIdx.x / nslot * kPer < n1 + n2)) run_chunk((int)blockIdx.x / nslot);
+  } else {
+    for (int chunk = (int)blockIdx.x / nslot; __any(chunk * kPer < n1 + n2); chunk += nwaves) run_chunk(chunk);
   }
   // (the cost the heavy-first order of the next launches sorts by: the time of the env's - first - wave)
   if (first && l == 0 && live) P.counts[kCountStride * (size_t)env + 7] = (int)min(255ull, (__builtin_amdgcn_s_memtime() - t_begin) >> 10);
 }
 __global__ __launch_bounds__(kGroup, 2) void hb_narrow_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<1>(Mp, P); }
 // a model without mesh geoms (configs[4]: capsules and spheres over the height field's prisms): no hull climb in the kernel
-__global__ __launch_bounds__(kGroup, 3) void hb_narrow_prim_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<0>(Mp, P); }
+__global__ __launch_bounds__(kGroup, 2) void hb_narrow_prim_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<0>(Mp, P); }
 // two envs per wave (narrow_body's PAIR): the unpipelined launches
 __global__ __launch_bounds__(kGroup, 2) void hb_narrow2_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<1, 1>(Mp, P); }
-__global__ __launch_bounds__(kGroup, 3) void hb_narrow2_prim_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<0, 1>(Mp, P); }
+__global__ __launch_bounds__(kGroup, 2) void hb_narrow2_prim_kernel(const DevModel* Mp, const BatchPtrs P) { narrow_body<0, 1>(Mp, P); }
 
 hipError_t launch_pose_narrow(const DevModel* M_dev, const BatchPtrs& Q, hipStream_t stream) {
   (void)hipGetLastError();

@@ -34,8 +34,20 @@ namespace hb {
 // flagged as well, so that a fast instantiation carries no portal-search code at all (it costs the step kernel ~ 280 spilled registers).
 // (sizes and LDS offsets: the model's, or - SIZED - the constants of kSizedHumanoid27, hb_device.hpp)
 #define HB_SZ(f) (SIZED ? (NDENSE == 20 ? kSizedTeamV1.f : COLL ? kSizedHumanoid27V1.f : kSizedHumanoid27.f) : M.f)
+// the fast pass of a staged step hands an env to the second pass: its flag, and a place in the launch's list (StageBufs::defer_list)
+__device__ __forceinline__ void defer_env(const BatchPtrs& P, int env) {
+  P.stage.defer[env] = 1;
+  if (P.stage.defer_list) P.stage.defer_list[P.blk0 + atomicAdd(&P.stage.defer_count[P.blk0], 1)] = env;
+}
+// the second pass: a few waves that walk the list (any other launch: one wave per slot, as ever)
+#define HB_STEP_OR_RERUN(...)                                                                               \
+  do {                                                                                                      \
+    const bool rr_ = P.stage.rerun && P.stage.defer_list;                                                   \
+    const int n_ = rr_ ? P.stage.defer_count[P.blk0] : (int)gridDim.x;                                      \
+    for (int i_ = (int)blockIdx.x; i_ < n_; i_ += (int)gridDim.x) step_body<__VA_ARGS__>(Mp, P, nsteps, rr_ ? P.stage.defer_list[P.blk0 + i_] : -1); \
+  } while (0)
 template <int SOLVER, int NDENSE, int COLL = 0, int NG = 1, int DEFER = 0, int LEAN = 0, int SIZED = 0>
-__device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps_in) {
+__device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P, int nsteps_in, int env_in = -1) {
   const int nsteps = LEAN == 1 ? 1 : nsteps_in;  // (LEAN == 1 is launched for single steps only: the step API; rollouts take LEAN == 2)
   // LEAN (1 = a single step without the constraint-force read-out; 2 = any number of steps, read-out optional): a launch without the optional inputs and outputs (applied forces and their noise, constraint-force / sensor / trajectory
   // read-outs, diagnostics, per-env model parameters, an env mask; mj_step, not mj_forward) - known at compile time, so their tests,
@@ -68,9 +80,9 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   extern __shared__ float lds[];
   const int lane0 = threadIdx.x;
   int lane = lane0;
-  if ((int)blockIdx.x >= P.nblk) return;
+  if (env_in < 0 && (int)blockIdx.x >= P.nblk) return;
   const int slot = P.blk0 + (int)blockIdx.x;
-  const int env = P.order ? P.order[slot] : slot;
+  const int env = env_in >= 0 ? env_in : (P.order ? P.order[slot] : slot);  // (env_in: the second pass of a staged step walks the list of deferred envs)
   if (P_env_mask && !P_env_mask[env]) return;  // masked stepping (hb_env_reset's settle step)
   if constexpr (COLL != 0 && DEFER == 0) {
     if (P.stage.rerun) {  // second pass of a staged step: only the envs the fast pass deferred
@@ -808,7 +820,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
         if (__ballot(lane < ncon && incl && !fits)) status |= (1 << 2);
         if constexpr (DEFER == 1) {
           if (status & ((1 << 1) | (1 << 2))) {  // more contacts or rows than this instantiation holds: the four-group kernel steps this env
-            if (lane == 0) P.stage.defer[env] = 1;
+            if (lane == 0) defer_env(P, env);
             return;
           }
         }
@@ -1680,7 +1692,7 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
       for (int i = lane; i < nv; i += kGroup) bad |= !(fabsf(s_v0[i]) <= HB_MAXVAL);
       if (__any(bad)) {
         if constexpr (DEFER != 0) {  // the reset and the second forward pass (with a narrowphase of its own) are the four-group kernel's
-          if (lane == 0) P.stage.defer[env] = 1;
+          if (lane == 0) defer_env(P, env);
           return;
         }
         status |= (1 << 6);
@@ -1843,13 +1855,13 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ __launch_bounds__(kGroup, 2) vo
 __global__ __launch_bounds__(kGroup, 2) void hb_step32_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 32>(Mp, P, nsteps); }
 // General instantiations (mesh hulls, height-field prisms, condim 4 / 6): PGS on 63 rows (configs[4]: the 27-dof humanoid on terrain),
 // Newton on 256 rows (the reference's own robot, simulation/assets/world.xml: 18 dofs -> dense order 20; up to 28 dofs)
-__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 2) void hb_step_gen_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { HB_STEP_OR_RERUN(0, 28, 1, 1); }
 // PGS on kPgsNefcMax rows (AR in LDS: one env per CU) for condim 4 / 6 models, and the one-group fast pass that defers to it (variant 3)
-__global__ __launch_bounds__(kGroup, 1) void hb_step_gen_big_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, kPgsGroups>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 1) void hb_step_gen_big_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { HB_STEP_OR_RERUN(0, 28, 1, kPgsGroups); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast1_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_gen_fast_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<0, 28, 1, 1, 2>(Mp, P, nsteps); }  // staged step, fast pass
-__global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big20_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, kBigGroups>(Mp, P, nsteps); }
-__global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 1, kBigGroups>(Mp, P, nsteps); }
+__global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big20_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { HB_STEP_OR_RERUN(2, 20, 1, kBigGroups); }
+__global__ __launch_bounds__(kGroup, 1) void hb_step_newton_big28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { HB_STEP_OR_RERUN(2, 28, 1, kBigGroups); }
 // fast pass of a variant-2 model's staged step: Newton on one row group, general collision results, deferring what does not fit
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen20_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 20, 1, 1, 1>(Mp, P, nsteps); }
 __global__ __launch_bounds__(kGroup, 2) void hb_step_newton_gen28_kernel(const DevModel* Mp, const BatchPtrs P, int nsteps) { step_body<2, 28, 1, 1, 1>(Mp, P, nsteps); }
@@ -1902,10 +1914,13 @@ bool multi_step_takes_duo(int variant, int solver, int nv, const BatchPtrs& P) {
 }
 static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int solver, int nv, size_t shmem, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error
-  if (variant == 2 && nv <= 20) HB_STEP_LAUNCH(hb_step_newton_big20_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-  else if (variant == 2) HB_STEP_LAUNCH(hb_step_newton_big28_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-  else if (variant == 1) HB_STEP_LAUNCH(hb_step_gen_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
-  else if (variant == 3) HB_STEP_LAUNCH(hb_step_gen_big_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  // (the second pass of a staged step: kRerunWaves waves that walk the list of deferred envs - HB_STEP_OR_RERUN)
+  constexpr int kRerunWaves = 1024;  // (one per SIMD: the four-group kernels hold one wave per SIMD)
+  const int grid = (P.stage.rerun && P.stage.defer_list) ? (P.nblk < kRerunWaves ? P.nblk : kRerunWaves) : P.nblk;
+  if (variant == 2 && nv <= 20) HB_STEP_LAUNCH(hb_step_newton_big20_kernel, dim3(grid), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (variant == 2) HB_STEP_LAUNCH(hb_step_newton_big28_kernel, dim3(grid), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (variant == 1) HB_STEP_LAUNCH(hb_step_gen_kernel, dim3(grid), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
+  else if (variant == 3) HB_STEP_LAUNCH(hb_step_gen_big_kernel, dim3(grid), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (solver == 2 && nv <= 28) {
     if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) HB_STEP_LAUNCH(hb_step_newton28_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (nsteps == 1 && lean_launch(P)) HB_STEP_LAUNCH(hb_step_newton28_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);

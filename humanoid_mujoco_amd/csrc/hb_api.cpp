@@ -810,8 +810,9 @@ int launch_steps_now(hb_batch* b, BatchPtrs& P, int nsteps, int ncalls = 1) {
 // Step calls enqueued back to back run as ONE launch.  hb_step_dev is asynchronous: until the caller synchronises, reads something or
 // enqueues other work (all of which pass main_stream), nobody can tell K launches of one step from one launch of K steps - except the clock:
 // a launch of one step lasts as long as its slowest env and the next one waits for it, a launch of K steps lets every wave run on into
-// its envs' next step (the rollout kernels: no batch-wide barrier, and the two-envs-per-wave kernel pays from 4096 envs on instead of
-// 5120).  So a plain step call whose multi-step launch takes that kernel is held back (its launch parameters and its control pointer) until one
+// its envs' next step (the rollout kernels: no batch-wide barrier).  That pays when the launch's waves are all on the chip at once
+// (hb_step.hip: fold_pays - up to 2048 envs, 4096 for the models with the two-envs-per-wave kernel).  Such a step call is held back (its
+// launch parameters and its control pointer) until one
 // of: kFoldMax steps are held, a call with other parameters arrives, anything touches the batch's stream.  The held calls then run as
 // one multi-step launch whose step t reads the controls of call t (BatchPtrs::ctrl_tab, ctrl_mode 3).  Results are bit-identical to
 // the unfolded launches (tests/test_gpu_fold.py); HB_TUNE_FOLD = 1 switches it off.
@@ -836,7 +837,7 @@ int launch_steps(hb_batch* b, BatchPtrs& P, int nsteps, bool foldable = false) {
   foldable = false;  // (the diagnostic build samples single launches)
 #endif
   foldable = foldable && b->npipe > 1 && cap > 1 && nsteps <= cap && P.ctrl_mode == 0 && !b->time_steps && !b->diag && !P.stamps && P.xfrc_scale == 0.f &&
-             multi_step_takes_duo(b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, P);
+             fold_pays(b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, P);
   if (!foldable) {
     const int rc = flush_steps(b);
     return rc != HB_OK ? rc : launch_steps_now(b, P, nsteps);

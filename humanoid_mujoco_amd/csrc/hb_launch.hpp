@@ -8,7 +8,7 @@ hipError_t launch_step(const DevModel* M_dev, int variant, int solver, int nv, i
 hipError_t launch_step_duo(const DevModel* M_dev, const BatchPtrs& P, int nsteps, hipStream_t stream);
 // name of the step kernel the last launch_step of this thread launched last (hb_last_kernel)
 const char* last_step_kernel();
-bool multi_step_takes_duo(int variant, int solver, int nv, const BatchPtrs& P);
+bool fold_pays(int variant, int solver, int nv, const BatchPtrs& P);
 // the pose + narrowphase launches of one staged step (hb_narrow.hip)
 hipError_t launch_pose_narrow(const DevModel* M_dev, const BatchPtrs& Q, hipStream_t stream);
 hipError_t launch_reset(const DevModel& M, float* state, int* status, const uint8_t* mask, const float* qpos_src, const int* episode, int n_env, float perturb,

@@ -1896,7 +1896,9 @@ static int wave_slots() {
 static bool duo_pays(const BatchPtrs& P, int nsteps) {
   if (P.duo == 0) return false;
   if (P.duo == 2) return true;
-  if (nsteps > 1) return P.n_env >= 2 * wave_slots();
+  // a launch of several steps: as soon as one-env waves would need a second round (3072 envs: 65 us per step against 76; 2048 envs are
+  // one round of one-env waves: 42 against 56 - profiles/r04_fold_sizes_by_batch.txt)
+  if (nsteps > 1) return P.n_env > wave_slots();
   // (a launch that covers the whole batch is an unpipelined step call: nothing overlaps its tail anyway, and from 1.5 x the slots on one round
   // of duo waves beats two rounds of one-env waves - 103 against 112 us at 4096 envs)
   return P.nblk == P.n_env ? 2 * P.n_env >= 3 * wave_slots() : 2 * P.n_env >= 5 * wave_slots();
@@ -1907,10 +1909,17 @@ static bool lean_launch(const BatchPtrs& P, bool with_qfrc = false) {
   return (P.lean_ok & 1) && !P.xfrc && (with_qfrc || !P.qfrc_out) && !P.sensor_out && !P.qpos_out && !P.qvel_out && !P.diag_qacc && !P.diag_force && !P.diag_contact && !P.dr && !P.env_mask &&
          P.integrate;
 }
-// would a launch of several steps with these parameters take the two-envs-per-wave kernel?  (hb_api.cpp folds step calls into one launch
-// when it does: a multi-step launch of one-env waves is no faster than pipelined single steps - profiles/r04_fold_sizes.txt)
-bool multi_step_takes_duo(int variant, int solver, int nv, const BatchPtrs& P) {
-  return variant == 0 && solver != 2 && nv <= 28 && lean_launch(P) && (P.lean_ok & 2) && duo_pays(P, 2);
+// Does it pay to run step calls the host has enqueued back to back as ONE launch of several steps (hb_api.cpp: fold_steps)?  When all the
+// launch's waves are on the chip at once: then no wave waits for a slot while others run through their steps, and no env waits for the
+// batch's slowest one between steps.  One-env waves: up to 8 per CU (2048 envs on MI355X: 42 us per step against 64 for pipelined single
+// steps); two-envs-per-wave waves, for the models that have that kernel: up to twice as many envs (4096: 67 against 78).  Beyond one
+// round a multi-step launch is no faster than pipelined single steps, and slower when its last round is part empty (4608 envs: 104
+// against 85) - profiles/r04_fold_sizes_by_batch.txt.
+bool fold_pays(int variant, int solver, int nv, const BatchPtrs& P) {
+  if (variant != 0) return false;
+  if (P.n_env <= wave_slots()) return true;
+  const bool duo_kernel = solver != 2 && nv <= 28 && lean_launch(P) && (P.lean_ok & 2) && duo_pays(P, 2);
+  return duo_kernel && (P.n_env + 1) / 2 <= wave_slots();
 }
 static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int solver, int nv, size_t shmem, const BatchPtrs& P, int nsteps, hipStream_t stream) {
   (void)hipGetLastError();  // the result below must be this launch's, not an older call's sticky error

@@ -145,11 +145,12 @@ int hb_reset(hb_batch* b, const uint8_t* mask, int keyframe, int perturb, int en
 int hb_step(hb_batch* b, const float* ctrl, int n_substeps);
 /* The same with the controls already in device memory, asynchronous: the call returns at once, its results are there after hb_batch_sync
  * or behind anything enqueued on hb_batch_stream later, and ctrl_dev must stay allocated and untouched until then.  On a PIPELINED batch
- * (hb_batch_pipeline) whose multi-step launches take the two-envs-per-wave kernel (HB_TUNE_DUO: the 27-dof humanoid's PGS configuration from
- * 4096 envs on), calls made back to back - nothing else of the batch's API in between - are executed as ONE kernel launch of up to
- * HB_TUNE_FOLD steps, step t reading the controls of call t: no env waits for the batch's slowest one between steps (4096 envs on MI355X:
- * 71 us per step against 78).  The states are bit-identical to one launch per call; the work starts when HB_TUNE_FOLD steps are held or
- * when any other hb_* call of the batch (hb_batch_sync, hb_batch_stream, hb_batch_join, a read) arrives. */
+ * (hb_batch_pipeline) of a primitive-geometry model whose waves all fit on the chip at once (8 per CU: up to 2048 envs on MI355X, 4096
+ * for the models with the two-envs-per-wave kernel, HB_TUNE_DUO), calls made back to back - nothing else of the batch's API in between -
+ * are executed as ONE kernel launch of up to HB_TUNE_FOLD steps, step t reading the controls of call t: no env waits for the batch's
+ * slowest one between steps (MI355X: 2048 envs 42 us per step against 64, 4096 envs 67 against 78).  The states are bit-identical to one
+ * launch per call; the work starts when HB_TUNE_FOLD steps are held or when any other hb_* call of the batch (hb_batch_sync,
+ * hb_batch_stream, hb_batch_join, a read) arrives. */
 int hb_step_dev(hb_batch* b, const float* ctrl_dev, int n_substeps);
 
 /* Replaces the open-loop rollout loops (mujoco_mpc/mjpc/trajectory.cc:141-179,
@@ -358,7 +359,7 @@ int hb_batch_device_name(const hb_batch* b, char* out, int cap);
  * corresponds: mj_step (mujoco.h:120) has one code path.
  *   HB_TUNE_DUO            two envs per wavefront for the lean launches of the 27-dof humanoid's PGS kernel (csrc/hb_step_duo.hip; DESIGN.md
  *                          3.8): 1 (default) where it pays - pipelined step calls of batches from 2.5 x the chip's wave slots on (5120 envs on
- *                          MI355X), unpipelined ones from 1.5 x (3072), rollouts from 2 x (4096); 0 never; 2 always
+ *                          MI355X), unpipelined ones from 1.5 x (3072), launches of several steps from more than 1 x (2049); 0 never; 2 always
  *   HB_TUNE_LEAN           1 (default): launches without optional inputs / outputs take the lean instantiations of step_body; 0: the full ones
  *   HB_TUNE_SIZED          1 (default): models with the size signature of the 27-dof humanoid / the reference's robot take the kernels that
  *                          have those sizes as constants; 0: the generic ones

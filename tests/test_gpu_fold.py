@@ -26,14 +26,13 @@ def _same(x, y):
     return all(np.array_equal(a, c) for a, c in zip(x, y))
 
 
-@pytest.mark.parametrize("duo,pipelined,kernel", [(2, 1, "hb_step_duo_q_kernel"), (2, 2, "hb_step_duo_q_kernel"), (0, 1, "hb_step_h27_kernel"), (2, 0, "hb_step_duo_kernel")])
+@pytest.mark.parametrize("duo,pipelined,kernel", [(2, 1, "hb_step_duo_q_kernel"), (2, 2, "hb_step_duo_q_kernel"), (0, 1, "hb_step_h27_q_kernel"), (1, 3, "hb_step_h27_q_kernel"), (2, 0, "hb_step_duo_kernel")])
 def test_folded_step_calls_are_bit_identical(hbmod, humanoid_model, gpu, duo, pipelined, kernel):
-    """(an unpipelined batch does not fold: its caller was never asked to join before using the batch's stream - include/hb.h; nor does one
-    whose multi-step launch runs one env per wave: that is no faster than pipelined single steps)"""
+    """(an unpipelined batch does not fold: its caller was never asked to join before using the batch's stream - include/hb.h)"""
     m = humanoid_model
     got = []
     for fold in (1, 64):
-        folds = fold > 1 and duo == 2 and pipelined
+        folds = fold > 1 and pipelined
         b = hbmod.Batch(m, N, gpu)
         b.tune(duo=duo, fold=fold)
         b.reset(perturb=True)
@@ -48,6 +47,36 @@ def test_folded_step_calls_are_bit_identical(hbmod, humanoid_model, gpu, duo, pi
         b.close()
     assert _same(got[0], got[1])
     assert got[0][1].max() >= 3  # contacts were there: fallen humanoids
+
+
+def test_folded_calls_of_other_models_and_solvers(hbmod, gpu):
+    """every primitive-geometry model folds when its waves fit on the chip at once: the humanoid under Newton (hb_step_newton28_lean_q_kernel)
+    and a model without the humanoid's size signature, the particle of tests/golden/particle_task.hbm (the generic kernels)"""
+    import os
+    from oracle_lib import GOLDEN, HUMANOID_HBM
+    newton = hbmod.Model.load(HUMANOID_HBM)
+    newton.set_opt(solver=2, iterations=100)
+    particle = hbmod.Model.load(os.path.join(GOLDEN, "particle_task.hbm"))
+    for m, kernel in ((newton, "hb_step_newton28_lean_q_kernel"), (particle, None)):
+        got, names, launches = [], [], []
+        for fold in (1, 256):
+            b = hbmod.Batch(m, N, gpu)
+            b.tune(fold=fold)
+            b.reset(perturb=True)
+            b.pipeline(True)
+            p = b.dev_alloc(T * N * max(m.nu, 1) * 4)
+            b.halton_ctrl_dev(T, 3, 0, p)
+            n0 = b.step_launches()
+            for t in range(T):
+                b.step_dev(p + t * N * m.nu * 4)
+            b.sync()
+            launches.append(b.step_launches() - n0)
+            names.append(b.last_kernel())
+            got.append(_everything(hbmod, b))
+            b.dev_free(p)
+            b.close()
+        assert _same(got[0], got[1])
+        assert launches == [T, 1] and (kernel is None or names[1] == kernel), (launches, names)
 
 
 def test_fold_stops_where_it_has_to(hbmod, humanoid_model, gpu):

@@ -47,8 +47,10 @@ def run(kind, K, seg, duo):
 
 print("%d envs; us per step (median of 15)" % N)
 print("%-8s %4s %9s %4s %10s  %s" % ("kind", "K", "segments", "duo", "us/step", "kernel"))
-for duo in ((1,) if os.environ.get("SOLVER") == "newton" else (1, 0)):
-    for K in (5, 20, 64, 256):
+DUOS = tuple(int(x) for x in os.environ["DUO"].split(",")) if os.environ.get("DUO") else ((1,) if os.environ.get("SOLVER") == "newton" else (1, 0))
+KS = tuple(int(x) for x in os.environ["KS"].split(",")) if os.environ.get("KS") else (5, 20, 64, 256)
+for duo in DUOS:
+    for K in KS:
         for kind, seg in (("calls", 3), ("folded64", 3), ("folded256", 3), ("rollout", 0), ("rollout", 3)):
             us, k = run(kind, K, seg, duo)
             print("%-8s %4d %9d %4d %10.1f  %s" % (kind, K, max(seg, 1), duo, us, k), flush=True)

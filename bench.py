@@ -433,15 +433,17 @@ def main():
         # the committed rocprofv3 passes (tools/gpu_team_counters.sh), not from this run
         try:
             tc = json.load(open(os.path.join(ROOT, "profiles", "team_counters_latest.json")))
-            nk = tc.get("hb_narrow_kernel") or {}
+            # (the committed passes run unpipelined launches, which take the two-envs-per-wave form of the same kernel body: hb_narrow2_kernel)
+            nkname = "hb_narrow_kernel" if tc.get("hb_narrow_kernel") else "hb_narrow2_kernel"
+            nk = tc.get(nkname) or {}
             algo = n_env * (40 * tm.ngeom + (16 + 64) * float(tnw.mean()))
             if nk.get("avg_us"):
-                team["roofline"] = {"bound": "hbm", "kernel": "hb_narrow_kernel", "achieved": algo / (nk["avg_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                team["roofline"] = {"bound": "hbm", "kernel": nkname, "achieved": algo / (nk["avg_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": algo / (nk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": nk["avg_us"], "algorithmic_bytes_per_launch": algo,
                                     "traffic": (nk.get("hbm_bytes_per_launch") or {}).get("fetch_x2_gfx950", 0) + (nk.get("hbm_bytes_per_launch") or {}).get("write", 0) or None,
                                     "active_lanes_per_valu_instruction": nk.get("active_lanes_per_valu_instruction"),
                                     "wait_inst_frac_of_wave_cycles": nk.get("sq_wait_inst_any_frac_of_wave_cycles"),
-                                    "note": "a portal search is one dependent chain of fp64 operations and table loads per lane: latency x wave slots bound, 2.7 of 64 lanes active (DESIGN.md 3.6)",
+                                    "note": "four lanes per portal search, sixteen searches per wave; the launch lasts as long as its longest search - a chain of dependent fp64 operations and hull-table loads (DESIGN.md 3.6)",
                                     "source": "committed profile, not this run: profiles/team_counters_latest.json (tools/gpu_team_counters.sh)"}
         except Exception:
             pass

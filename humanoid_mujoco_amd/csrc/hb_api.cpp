@@ -656,6 +656,7 @@ struct hb_batch {
   // before anything else is enqueued on it.
   static constexpr int kPipes = 8;  // most segments; npipe of them in use (streams are created when first asked for)
   int npipe = 0;                    // 0: unpipelined
+  int probed_segments = 0;          // what hb_batch_pipeline(b, 1)'s probe of the segment streams found (0: not probed yet); the streams are kept, so is the answer
   bool forked = false;
   hipStream_t pipe[kPipes] = {};
   hipEvent_t ev_fork = nullptr, ev_pipe[kPipes] = {};
@@ -1182,7 +1183,8 @@ int hb_batch_pipeline(hb_batch* b, int on) {
   int want = on == 1 ? 3 : on;
   int rc = make_pipes(b, want);
   if (rc != HB_OK) return rc;
-  if (on == 1) {
+  if (on == 1 && b->probed_segments) want = b->probed_segments;  // (probed before on these very streams: no second probe, the same shape every time)
+  else if (on == 1) {
     // a stream that shares its queue is replaced by a fresh one (the runtime deals queues out in turn: the next stream lands on another
     // one) while the old one still holds its place; a few tries, then two segments
     hipStream_t spare[4] = {};
@@ -1197,6 +1199,7 @@ int hb_batch_pipeline(hb_batch* b, int on) {
     for (hipStream_t s : spare) if (s) HB_IGN(hipStreamDestroy(s));
     if (bad == -2) return HB_ENODEVICE;  // the probe itself failed (a HIP error, not a shared queue): an error, not a quiet two segments
     if (bad != -1) want = 2;
+    b->probed_segments = want;
     if (hb_debug()) fprintf(stderr, "[hb] hb_batch_pipeline: %d env segments (%s)\n", want, bad == -1 ? "every segment stream has a hardware queue of its own" : "two of three segment streams share a hardware queue");
   }
   b->npipe = want;

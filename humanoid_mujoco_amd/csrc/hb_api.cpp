@@ -757,6 +757,8 @@ Segment segment(hb_batch* b, int c, int nseg) {
 }
 // fork: the pipes see everything enqueued on the batch's stream so far (controls written there, resets, ...)
 int fork_pipes(hb_batch* b, int nseg) {
+  // (step calls held back - fold_steps - come first whoever launches next; flush_steps itself gets here with nothing held any more)
+  if (b->fold_n) { const int rc = flush_steps(b); if (rc != HB_OK) return rc; }
   if (nseg == 1) { join_pipes(b); return HB_OK; }
   // (nothing enqueued on the batch's stream since the last fork: the pipes already follow all of it, and a marker on a stream that
   // shares a hardware queue with a busy one would wait behind that one's work)

@@ -18,6 +18,13 @@ def _ctrl(hbmod, b, nu, t0=7):
     return p, N * nu * 4
 
 
+def _policy(m):
+    rng = np.random.default_rng(11)
+    sizes = [m.nobs, 32, m.nu]
+    return ([(0.2 * rng.standard_normal((sizes[i], sizes[i + 1]))).astype(np.float32) for i in range(2)],
+            [(0.1 * rng.standard_normal(sizes[i + 1])).astype(np.float32) for i in range(2)])
+
+
 def _everything(hbmod, b):
     return (b.get_state(hbmod.STATE_INTEGRATION),) + tuple(b.counts()) + (b.status(),)
 
@@ -90,6 +97,7 @@ def test_fold_stops_where_it_has_to(hbmod, humanoid_model, gpu):
         b.tune(fold=fold, duo=2)
         b.reset(perturb=True)
         b.pipeline(True)
+        b.set_policy_mlp(*_policy(m))
         ctrl, stride = _ctrl(hbmod, b, m.nu)
         one = b.dev_alloc(stride)
         mid = []
@@ -105,6 +113,9 @@ def test_fold_stops_where_it_has_to(hbmod, humanoid_model, gpu):
         for t in range(70, 80):
             b.step_dev(ctrl + t * stride)
         b.rollout_halton(9, 500)                                 # another kind of launch behind held step calls
+        for t in range(76, 80):
+            b.step_dev(ctrl + t * stride)
+        b.rollout_policy(3)                                      # the closed loop launches its segments itself (fork_pipes): held calls first
         for t in range(80, 90):
             b.step_dev(ctrl + t * stride)
         mid.append(b.counts()[0])

@@ -171,21 +171,21 @@ __global__ __launch_bounds__(kGroup, 4) void hb_pose_kernel(const DevModel* Mp, 
 // four-lane searches and the one-loop portal search (a flat list filled by one atomicAdd per env in hb_pose_kernel, sixteen consecutive
 // searches per wave): the narrowphase launch stayed at 85 us - it lasts as long as its longest search, 170-190 k cycles - and the 4096
 // atomics on one counter cost the pose kernel 23 us.
-// PAIR = 1: TWO envs per wave (lanes 0..31: one env's searches, 32..63: the other's; thirty-two searches of each per chunk).  A wave's time is
-// the latency of one portal search - a chain of dependent fp64 operations and table loads - plus a little for every further search that
-// runs beside it (55 k cycles + 5 k per search on the lying robot, profiles/r04_team_counters.json: 2.7 of 64 lanes active per vector
-// instruction with one env per wave).  Half the waves, each a quarter longer: an unpipelined step of 4096 robots takes 233 us instead of
-// 267.  But the launch then is ONE round of waves and lasts as long as its slowest (a hull - hull search of 200 k cycles), which pipelined
-// segments no longer hide: 226 us against 212 - so launch_pose_narrow takes this form only for a launch that covers its whole batch
-// (profiles/r04_narrow_pairs.txt).
+// A model with meshes (MESH = 1): FOUR lanes per search (hb_mpr.hpp: climb4 - the four share the rounds of a hull climb), sixteen searches per
+// wave; without meshes a lane per search.  Where that came from: the diagnostic build's HB_MPR_LIMIT (tools/gpu_narrow_limits.sh,
+// profiles/r04_narrow_limits.txt) showed the launch VALU-bound at 4.6 active lanes, 10 us per support call allowed, 8 of them the climb.
+// PAIR = 1: TWO envs per wave (lanes 0..31: one env's searches, 32..63: the other's).  Half the waves, each a little longer: the unpipelined
+// step of 4096 robots 267 -> 233 us with one lane per search (profiles/r04_narrow_pairs.txt), and with four lanes per search the launch is
+// 84 us in this form (profiles/r04_team_counters.json: 11.7 active lanes per vector instruction).  The launch then is ONE round of waves and
+// lasts as long as its slowest; for pipelined segments the two forms measure the same (169 us per step of 4096 robots), and
+// launch_pose_narrow takes the pair form for a launch that covers its whole batch.
 template <int MESH, int PAIR = 0>
 __device__ __forceinline__ void narrow_body(const DevModel* Mp, const BatchPtrs& P) {
   DevModelRef M = *(const DevModel HB_CONST*)(uintptr_t)Mp;
   const int lane = threadIdx.x;
   // heavy first (BatchPtrs::order2: the envs of this launch sorted by the time their wave took in an earlier step): the launch ends
   // when its slowest wave does, and a slow wave that starts in the last round ends late
-  // a model with meshes: four lanes per search (hb_mpr.hpp: climb4), sixteen searches per wave; otherwise a lane per search
-  constexpr int G = MESH ? 4 : 1;
+  constexpr int G = MESH ? 4 : 1;  // lanes per search
   constexpr int kPer = (PAIR ? 32 : kGroup) / G;  // searches of an env per chunk
   const int nslot = PAIR ? (P.nblk + 1) >> 1 : P.nblk;
   const int nwaves = (int)gridDim.x / nslot;  // waves per slot: wave c takes chunks c, c + nwaves, ... of its env(s)

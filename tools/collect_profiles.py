@@ -217,6 +217,18 @@ if "valu_issue_frac_of_peak" in out and os.path.exists(os.path.join(dst, "traffi
         if "mfma_busy_frac" in tk:
             e["mfma_busy_frac"] = tk["mfma_busy_frac"]
         latest.setdefault("by_kernel", {})["hb_step_duo_q_kernel"] = e
+    # the single-step form of the same kernel body (unpipelined step calls from 3072 envs, the closed loops): tools/gpu_duo_counters.sh's report, if it has been copied
+    pd = os.path.join(dst, rnd + "_counters_duo.json")
+    if os.path.exists(pd):
+        dk = json.load(open(pd)).get("hb_step_duo_kernel", {})
+        hb_ = dk.get("hbm_bytes_per_launch")
+        if hb_:
+            latest.setdefault("by_kernel", {})["hb_step_duo_kernel"] = {
+                "source": "profiles/%s_counters_duo.json (tools/gpu_duo_counters.sh: rocprofv3 --pmc passes of `bench.py --no-pipeline --duo 2`, FETCH_SIZE and WRITE_SIZE in passes of their own)" % rnd,
+                "hbm_bytes_per_launch": hb_["fetch_x2_gfx950"] + hb_["write"], "fetch_bytes_raw": hb_["fetch_raw"], "write_bytes": hb_["write"],
+                "avg_launch_ns_kernel_trace": 1e3 * dk.get("avg_us", 0.0),
+                "valu": {"bound": "valu", "instructions_per_wave": dk.get("per_wave", {}).get("SQ_INSTS_VALU"),
+                         "active_lane_fraction": (dk.get("active_lanes_per_valu_instruction") or 0.0) / 64.0, "pipe_busy_frac": dk.get("valu_pipe_busy_frac")}}
     json.dump(latest, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 # second kernel trace (bench.py --no-pipeline with its Newton leg): every hb_* kernel's 4096-block launches
 tn = glob.glob(os.path.join(src, "prof_trace_newton", "*", "*_kernel_trace.csv"))

@@ -11,5 +11,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
 timeout -k 10 300 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/valu -o t -- $B > $OUT/valu.txt 2>&1; echo "valu rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $OUT/mem -o t -- $B > $OUT/mem.txt 2>&1; echo "mem rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/mfma -o t -- $B > $OUT/mfma.txt 2>&1; echo "mfma rc=$?"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d $OUT/hbm -o t -- $B > $OUT/hbm.txt 2>&1; echo "hbm rc=$?"
+# (FETCH_SIZE and WRITE_SIZE in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes: together the profiler aborts)
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/hbm -o t -- $B > $OUT/hbm.txt 2>&1; echo "hbm fetch rc=$?"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/hbmw -o t -- $B > $OUT/hbmw.txt 2>&1; echo "hbm write rc=$?"
 python3 tools/team_counters_report.py $OUT $K | tee $OUT/report.txt

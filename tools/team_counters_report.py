@@ -26,7 +26,7 @@ if tr:
     for k, v in d.items():
         v = sorted(v)[: max(1, len(v) - 1)]  # (the 150-step settle launch of the rollout is not a per-step launch)
         res[k]["launches"] = len(v); res[k]["avg_us"] = 1e-3 * sum(v) / len(v)
-for sub in ("sq", "valu", "mem", "hbm", "mfma"):
+for sub in ("sq", "valu", "mem", "hbm", "hbmw", "mfma"):
     fs = glob.glob(os.path.join(out, sub, "*counter_collection.csv")) or glob.glob(os.path.join(out, sub, "*", "*counter_collection.csv"))
     if not fs:
         continue

@@ -528,10 +528,15 @@ def main():
             for k in ("valu_issue_frac_of_peak", "mfma_busy_frac", "valu"):
                 if k in traffic:
                     out["roofline"][k] = traffic[k]
-            if "avg_launch_ns_kernel_trace" in traffic:  # (the profile's own launch time: `achieved` of that run, for comparison with this one)
-                out["roofline"]["profile_avg_launch_us"] = 1e-3 * traffic["avg_launch_ns_kernel_trace"]
-            if "us_per_step_kernel_trace" in traffic:  # (multi-step launches: the kernel trace's duration of the timed launches / their steps)
-                out["roofline"]["profile_us_per_step"] = traffic["us_per_step_kernel_trace"]
+            # (the profile's own launch time: `achieved` of that run, for comparison with this one.  Multi-step launches: the committed traces
+            # are of the default command (250 steps per launch) and of the driver's (`--steps 20`: one launch of 20 steps, which ends on
+            # its slowest wave): the one whose launches are shaped like this run's)
+            prof = traffic.get("driver_cmd") if (traffic.get("driver_cmd") and steps_per_launch <= 2 * traffic["driver_cmd"].get("steps_per_launch", 20)) else traffic
+            if "avg_launch_ns_kernel_trace" in prof:
+                out["roofline"]["profile_avg_launch_us"] = 1e-3 * prof["avg_launch_ns_kernel_trace"]
+            if "us_per_step_kernel_trace" in prof:  # (the kernel trace's duration of the timed launches / their steps)
+                out["roofline"]["profile_us_per_step"] = prof["us_per_step_kernel_trace"]
+                out["roofline"]["profile_steps_per_launch"] = prof.get("steps_per_launch", prof.get("steps_per_launch_kernel_trace"))
         if elapsed_rollout is not None:
             out["rollout"] = {"value": n_env * world * K / elapsed_rollout, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed_rollout / K,
                               "kernel": rollout_kernel,

@@ -154,6 +154,15 @@ def timed_kernel_profile():
         if len(rows) >= n + 2:
             t = [x for _, x in rows[-n:]]
             res["kernel_trace"] = {"timed_launches": n, "steps": K, "launch_ns": t, "avg_launch_ns": sum(t) / n, "us_per_step": 1e-3 * sum(t) / K}
+    # the driver's command: `bench.py --gpus 1 --steps 20 --warmup 5` - its timed loop is the process' last dispatch of the kernel, 20 steps
+    td = glob.glob(os.path.join(src, "prof_trace_driver", "*", "*_kernel_trace.csv"))
+    if td:
+        rows = sorted((int(r["Dispatch_Id"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) for r in csv.DictReader(open(td[0])) if name in r["Kernel_Name"])
+        if len(rows) >= 3:
+            res["kernel_trace_driver_cmd"] = {"command": "bench.py --gpus 1 --steps 20 --warmup 5", "timed_launches": 1, "steps": 20, "launch_ns": rows[-1][1], "us_per_step": 1e-3 * rows[-1][1] / 20}
+        sd = glob.glob(os.path.join(src, "prof_trace_driver", "*", "*_kernel_stats.csv"))
+        if sd:
+            shutil.copy(sd[0], os.path.join(dst, rnd + "_kernel_stats_driver_cmd.csv"))
     if "FETCH_SIZE" in q and "WRITE_SIZE" in q:
         fetch, write = q["FETCH_SIZE"] * 1024, q["WRITE_SIZE"] * 1024
         res["hbm"] = {"fetch_bytes_raw_per_step": fetch / steps, "write_bytes_per_step": write / steps, "hbm_bytes_per_step": (2 * fetch + write) / steps,
@@ -205,6 +214,9 @@ if "valu_issue_frac_of_peak" in out and os.path.exists(os.path.join(dst, "traffi
             e["hbm_bytes_per_step"] = tk["hbm"]["hbm_bytes_per_step"]; e["fetch_bytes_raw_per_step"] = tk["hbm"]["fetch_bytes_raw_per_step"]; e["write_bytes_per_step"] = tk["hbm"]["write_bytes_per_step"]
         if "kernel_trace" in tk:
             e["us_per_step_kernel_trace"] = tk["kernel_trace"]["us_per_step"]; e["avg_launch_ns_kernel_trace"] = tk["kernel_trace"]["avg_launch_ns"]
+            e["steps_per_launch_kernel_trace"] = tk["kernel_trace"]["steps"] / tk["kernel_trace"]["timed_launches"]
+        if "kernel_trace_driver_cmd" in tk:  # (a single launch of 20 steps: what `bench.py --steps 20` times)
+            e["driver_cmd"] = {"us_per_step_kernel_trace": tk["kernel_trace_driver_cmd"]["us_per_step"], "avg_launch_ns_kernel_trace": tk["kernel_trace_driver_cmd"]["launch_ns"], "steps_per_launch": 20}
         if "per_env_step" in tk and "active_lanes_per_valu_instruction" in tk and "kernel_trace" in tk:
             issued = tk["per_env_step"]["SQ_INSTS_VALU"] * n_env * 64 / (tk["kernel_trace"]["us_per_step"] * 1e-6)
             util = min(1.0, tk["active_lanes_per_valu_instruction"] / 64.0)

@@ -23,6 +23,8 @@ timeout -k 10 300 ./build/hb_testspeed humanoid_mujoco_amd/assets/humanoid27.hbm
 timeout -k 10 300 ./build/hb_testspeed_stamps humanoid_mujoco_amd/assets/humanoid27.hbm 300 4096 > $OUT/testspeed_stages.log 2>&1; timeout -k 10 300 ./build/hb_testspeed humanoid_mujoco_amd/assets/team_robot.hbm 500 4096 > $OUT/testspeed_team.log 2>&1
 echo "== rocprofv3 kernel trace" | tee -a $OUT/progress.log
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- python3 bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-rollout --no-newton --no-team > $OUT/prof_trace.log 2>&1; echo "trace rc=$?" | tee -a $OUT/progress.log
+# the driver's own command (--steps 20 --warmup 5: its timed loop is ONE launch of 20 steps, which ends on its slowest wave - a different shape from the 250-step launches above)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace_driver -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-rollout --no-newton --no-team > $OUT/prof_trace_driver.log 2>&1; echo "trace driver cmd rc=$?" | tee -a $OUT/progress.log
 # the one-env-per-wave single-step kernel (hb_step_h27_kernel: batches below 4096 envs, closed loops), one launch per step: its launch durations for the PMC passes below
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace_h27 -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-rollout --no-newton --no-team --no-pipeline --duo 0 --fold 1 > $OUT/prof_trace_h27.log 2>&1; echo "trace h27 rc=$?" | tee -a $OUT/progress.log
 echo "== rocprofv3 pmc FETCH" | tee -a $OUT/progress.log

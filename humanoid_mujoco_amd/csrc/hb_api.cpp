@@ -1205,7 +1205,7 @@ int hb_batch_pipeline(hb_batch* b, int on) {
     if (hb_debug()) fprintf(stderr, "[hb] hb_batch_pipeline: %d env segments (%s)\n", want, bad == -1 ? "every segment stream has a hardware queue of its own" : "two of three segment streams share a hardware queue");
   }
   b->npipe = want;
-  b->order_mode = 0;            // segment boundaries changed: per-segment permutations are stale
+  if (b->order_mode == 2) b->order_mode = 0;  // segment boundaries changed: per-segment permutations are stale (one of the whole batch stays good for unsegmented launches)
   return HB_OK;
 }
 int hb_batch_segments(const hb_batch* b) { return b ? segment_count(b) : HB_EINVAL; }

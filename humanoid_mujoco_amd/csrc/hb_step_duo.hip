@@ -143,9 +143,14 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
   // neighbours in the heavy-first order (slots 2 j, 2 j + 1).  Only the kDuoAnti costliest slots of the launch take the cheapest ones as
   // partners: an env above 31 rows packs its rows in front of a light partner's, while two of them in one wave would have to be stepped
   // one after the other.
+  // A launch of SEVERAL steps (MULTI) is one round of waves that lasts as long as its heaviest pair's total, and how heavy an env is persists
+  // (rows x sweeps summed over 256 steps: 16 % spread between envs, single ones at 2.5 x the mean) while the sweeps of a pair cost the same
+  // whoever the partner is: so there every env takes the one from the other end of the order - the order being by the envs' AVERAGE cost
+  // over the previous launch (below: counts[3]).  Modelled on 256 recorded steps (tools/gpu_pair_balance.py, profiles/r04_pair_balance.txt):
+  // heaviest pair / mean pair 1.38 with neighbours, 1.18 with opposite ends.
   int slotA, slotB;
   {
-    const int kAnti = min(kDuoAnti, P.nblk >> 2), b = (int)blockIdx.x;
+    const int kAnti = MULTI ? (P.nblk >> 1) : min(kDuoAnti, P.nblk >> 2), b = (int)blockIdx.x;
     if (b < kAnti) { slotA = b; slotB = P.nblk - 1 - b; }
     else { slotA = kAnti + 2 * (b - kAnti); slotB = slotA + 1 < P.nblk - kAnti ? slotA + 1 : -1; }
     slotA += P.blk0;
@@ -203,6 +208,9 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
   };
   float ctrl_pf = ctrl_of(0);
   int status = 0;            // per lane = per env (identical in the lanes of a half)
+  int cost_sum = 0, cost_n = 0;  // the env's rows x sweeps over the steps of this launch
+  constexpr int kCostHistory = 64;
+  const int cost_prev = (MULTI && env >= 0) ? P.counts[kCountStride * (size_t)env + 3] : 0;
   bool ctrl_zeroed = false;  // the env's pass runs on reset data (mj_resetData zeroes ctrl): per half
   bool redo = false;         // the env's pass is the second mj_forward of a step whose first one gave a bad qacc: per half
   for (int step = 0; step < nsteps; step++) {
@@ -1287,7 +1295,10 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
     }
     const bool fin = on && !((again >> h) & 1u);  // the lane's env completes its step in this pass
     if (fin) ctrl_zeroed = false;
-    if (fin && l == 0) { int* c = P.counts + kCountStride * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; c[3] = nefc * (niter + 4); c[4] = selfcol; }
+    // (counts[3], what the heavy-first order sorts by: the step's rows x sweeps - in a launch of several steps their average, with what the
+    // env brought along weighing as much as kCostHistory steps: a launch of five steps does not forget what six hundred said)
+    if (fin) { cost_sum += nefc * (niter + 4); cost_n++; }
+    if (fin && l == 0) { int* c = P.counts + kCountStride * (size_t)env; c[0] = ncon; c[1] = nefc; c[2] = niter; c[3] = MULTI ? (cost_prev * kCostHistory + cost_sum) / (kCostHistory + cost_n) : nefc * (niter + 4); c[4] = selfcol; }
 
     HB_STAMP(14);
     // ---------------------------------------------------------------- mj_Euler: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint

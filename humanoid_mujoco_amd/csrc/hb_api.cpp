@@ -779,7 +779,9 @@ int launch_segment(hb_batch* b, BatchPtrs P, int nsteps, const Segment& sg, int 
   P.order = (b->schedule && (nseg == 1 ? b->order_mode != 0 : b->order_mode == 2)) ? b->d_order : nullptr;
   P.order2 = (P.order && staged_on(b)) ? b->d_order2 : nullptr;
   HB_HIP(launch_step(b->D.d_dm, b->D.dm.variant, b->D.dm.solver, b->D.dm.nv, b->D.dm.lds_floats, P, nsteps, sg.st)); b->last_kernel = last_step_kernel();
-  if (reorder) HB_HIP(launch_order(b->d_counts, b->d_order, b->n_env, sg.lo, sg.hi - sg.lo, sg.st));
+  // (the key of the counting sort is 8 bits of the cost: of a single step's rows x sweeps - up to ~ 1600 - the bits above the lowest three; of the
+  // AVERAGE over a launch of several steps, which the two-envs-per-wave kernel leaves behind and pairs its envs by - 180 .. 700 -, one bit more)
+  if (reorder) HB_HIP(launch_order(b->d_counts, b->d_order, b->n_env, sg.lo, sg.hi - sg.lo, sg.st, /*slot=*/3, /*shift=*/(nsteps >= 8 && b->D.dm.variant == 0) ? 2 : 3));
   if (reorder && staged_on(b)) HB_HIP(launch_order(b->d_counts, b->d_order2, b->n_env, sg.lo, sg.hi - sg.lo, sg.st, /*slot=*/7, /*shift=*/0));
   return HB_OK;
 }
@@ -795,7 +797,8 @@ int launch_steps_now(hb_batch* b, BatchPtrs& P, int nsteps, int ncalls = 1) {
   // bring their own rounds of waves fill the chip worse than one (4096 envs, 64 steps: 103 us per step against 71, profiles/r04_fold_sizes.txt)
   const int nseg = (b->D.dm.variant == 0 && nsteps >= 5) ? 1 : segment_count(b);
   const bool sample = nseg == 1 && b->time_steps && (b->launch_count % 8 == 0) && b->tev_used + 2 <= (int)b->tev.size();
-  const bool reorder = b->schedule && (ncalls >= reorder_period(b) || b->launch_count % reorder_period(b) == 0);
+  // (a launch of several steps is followed by its re-sort every time: it pairs its envs by the order, and one sort is nothing beside it)
+  const bool reorder = b->schedule && (ncalls >= reorder_period(b) || nsteps >= 8 || b->launch_count % reorder_period(b) == 0);
   int rc = fork_pipes(b, nseg);
   if (rc != HB_OK) return rc;
   if (sample) HB_HIP(hipEventRecord(b->tev[b->tev_used], b->stream));

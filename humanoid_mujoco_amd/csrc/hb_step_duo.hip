@@ -139,6 +139,9 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
   int lane = lane0;
   const int npairs = (P.nblk + 1) >> 1;
   if ((int)blockIdx.x >= npairs) return;
+#ifdef HB_STAMPS
+  const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
+#endif
   // The wave's two envs.  The sweeps of two envs run side by side and last as long as the longer one, so envs of like cost share a wave:
   // neighbours in the heavy-first order (slots 2 j, 2 j + 1).  Only the kDuoAnti costliest slots of the launch take the cheapest ones as
   // partners: an env above 31 rows packs its rows in front of a light partner's, while two of them in one wave would have to be stepped
@@ -214,6 +217,15 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
   bool ctrl_zeroed = false;  // the env's pass runs on reset data (mj_resetData zeroes ctrl): per half
   bool redo = false;         // the env's pass is the second mj_forward of a step whose first one gave a bad qacc: per half
   for (int step = 0; step < nsteps; step++) {
+  if constexpr (MULTI != 0) {
+    // The two waves of a SIMD are blocks half a round apart, and the SIMD favours the older one: over a 250-step launch the first half of
+    // the blocks took 32.5 M ticks, their SIMD-mates 37 M (tools/gpu_wave_ends.py) - and the launch lasts as long as its last wave.  So the
+    // two take the higher priority in turns, step by step.
+    // (tried on top: a constant high priority for the heaviest 1/32 or 1/128 of the pairs - the launch's critical path -: no better, 60.6 - 60.8 us per
+    // step against 60.5; no priorities at all: 61.1, and 67.8 against 65.9 for launches of 20 steps; the younger wave always high: 66.9)
+    if (((step & 1) == 0) == ((int)blockIdx.x < (npairs >> 1))) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
   if (l0 < NU) s_ctrl[l0] = ctrl_pf;
   if (MULTI && step + 1 < nsteps && P.ctrl_mode != 0) ctrl_pf = ctrl_of(step + 1);
   unsigned todo = envB >= 0 ? 3u : 1u;  // envs of the wave still to be stepped (bit 0: A, bit 1: B)
@@ -1352,6 +1364,17 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
     todo &= ~finm;
   }
   }
+#ifdef HB_STAMPS
+  // diagnostic build (tools/gpu_wave_ends.py): where the wave ran (HW_ID, XCC_ID), which block it was, and when it ended - slots 1..4 of the
+  // stamp record of its first env (the stage stamps of its last step stay in the others)
+  if (lane == 0 && P.stamps) {
+    unsigned hw = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = P.stamps + (size_t)envA * 16;
+    o[1] = hw; o[2] = xcc; o[3] = blockIdx.x; o[4] = __builtin_amdgcn_s_memtime(); o[5] = t_wave0;
+  }
+#endif
   // ---- state out
   if (env >= 0) {
     float* gs = P.state + (size_t)env * NSTATE;

@@ -167,6 +167,14 @@ __device__ __forceinline__ void step_body(const DevModel* Mp, const BatchPtrs& P
   bool ctrl_zeroed = false;  // this pass of the step runs on reset data
   bool redo = false;         // this pass is the second mj_forward of a step whose first one gave a bad qacc (mj_checkAcc)
   for (int step = 0; step < nsteps; step++) {
+    if constexpr (LEAN != 1) {
+      // a launch of several steps whose waves are all resident (hb_api.cpp folds step calls into such launches): the two waves of a SIMD are
+      // blocks half a round apart and the SIMD favours the older one, so they take the higher priority in turns (hb_step_duo.hip has the numbers)
+      if (nsteps > 1) {
+        if (((step & 1) == 0) == ((int)blockIdx.x < ((int)gridDim.x >> 1))) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+    }
     // re-materialise the lane id every step: keeps per-lane table addresses and loads inside the step
     // instead of hoisted out of the rollout loop into long-lived (spilled) registers
     asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0) : "memory");

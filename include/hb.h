@@ -148,7 +148,7 @@ int hb_step(hb_batch* b, const float* ctrl, int n_substeps);
  * (hb_batch_pipeline) of a primitive-geometry model whose waves all fit on the chip at once (8 per CU: up to 2048 envs on MI355X, 4096
  * for the models with the two-envs-per-wave kernel, HB_TUNE_DUO), calls made back to back - nothing else of the batch's API in between -
  * are executed as ONE kernel launch of up to HB_TUNE_FOLD steps, step t reading the controls of call t: no env waits for the batch's
- * slowest one between steps (MI355X: 2048 envs 42 us per step against 64, 4096 envs 64 against 78).  The states are bit-identical to one
+ * slowest one between steps (MI355X: 2048 envs 42 us per step against 64, 4096 envs 62 against 78).  The states are bit-identical to one
  * launch per call; the work starts when HB_TUNE_FOLD steps are held or when any other hb_* call of the batch (hb_batch_sync,
  * hb_batch_stream, hb_batch_join, a read) arrives. */
 int hb_step_dev(hb_batch* b, const float* ctrl_dev, int n_substeps);

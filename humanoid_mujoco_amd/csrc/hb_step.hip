@@ -1946,7 +1946,8 @@ static hipError_t launch_step_kernel(const DevModel* M_dev, int variant, int sol
   }
   else if (solver == 2) HB_STEP_LAUNCH(hb_step_newton32_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
   else if (nv <= 28) {
-    if (lean_launch(P) && (P.lean_ok & 2) && duo_pays(P, nsteps)) { g_last_step_kernel = nsteps == 1 ? "hb_step_duo_kernel" : "hb_step_duo_q_kernel"; return launch_step_duo(M_dev, P, nsteps, stream); }
+    // (the two-envs-per-wave kernels write the joint torques when asked: the env adapter's launches take them as well)
+    if (lean_launch(P, true) && (P.lean_ok & 2) && duo_pays(P, nsteps)) { g_last_step_kernel = nsteps == 1 ? "hb_step_duo_kernel" : "hb_step_duo_q_kernel"; return launch_step_duo(M_dev, P, nsteps, stream); }
     else if (nsteps == 1 && lean_launch(P) && (P.lean_ok & 2)) HB_STEP_LAUNCH(hb_step_h27_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (nsteps == 1 && lean_launch(P)) HB_STEP_LAUNCH(hb_step_lean_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);
     else if (lean_launch(P, true) && (P.lean_ok & 2)) HB_STEP_LAUNCH(hb_step_h27_q_kernel, dim3(P.nblk), dim3(kGroup), shmem, stream, M_dev, P, nsteps);

@@ -1286,6 +1286,13 @@ __device__ __forceinline__ void step_duo(const DevModel* Mp, const BatchPtrs& P,
     gsync();
     if (dofl) s_v0[l] = dot28(E + o_W + l * kWsD, s_v2);
     gsync();
+    // qfrc_smooth + qfrc_constraint = M qacc, for callers that read the joint torques (the env adapter's reward): the one-env kernel's sum, term for term
+    if (P.qfrc_out && on && dofl) {
+      float acc = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < 32; j++) acc = __builtin_fmaf(s_qM[M.mdense[j * 32 + l]], j < NV ? s_v0[j] : 0.f, acc);
+      P.qfrc_out[(size_t)env * NV + l] = acc;
+    }
     // mj_checkAcc (mujoco.h:307): a bad qacc resets the data and runs mj_forward again; the step then integrates that result
     unsigned again = 0u;  // envs of this pass that run a second forward pass
     {

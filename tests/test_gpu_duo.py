@@ -207,3 +207,40 @@ def test_rollouts_through_the_duo_kernel_and_the_default_choice(hbmod, humanoid_
     f.step(np.repeat(ctrl0, 2048, axis=0)); k_small = f.last_kernel()
     f.close()
     assert (k_unpiped, k_step, k_roll, k_big, k_small) == (DUO, "hb_step_h27_kernel", "hb_step_duo_q_kernel", DUO, "hb_step_h27_kernel"), (k_unpiped, k_step, k_roll, k_big, k_small)
+
+
+def test_env_adapter_steps_through_the_duo_kernel_read_the_same_torques(hbmod, humanoid_model, gpu):
+    """hb_env_step's launches ask for the joint torques (qfrc_smooth + qfrc_constraint = M qacc: the reward's torque term): the
+    two-envs-per-wave kernel writes them too, term for term the one-env kernel's sum - observations, rewards and episode ends identical"""
+    n, T = 256, 60
+    rng = np.random.default_rng(9)
+    acts = rng.uniform(-1, 1, (T, n, humanoid_model.nu)).astype(np.float32)
+    got, names = [], []
+    for duo in (0, 2):
+        env = hbmod.VecEnv(humanoid_model, n, gpu, realism=True, domain_randomization=True)
+        env.batch.tune(duo=duo)
+        out = [env.reset().copy()]
+        for t in range(T):
+            obs, rew, term, trunc, info = env.step_arrays(acts[t])
+            out += [obs.copy(), rew.copy(), term.copy(), trunc.copy()]
+        names.append(env.batch.last_kernel())
+        got.append(out)
+        env.close()
+    assert names == ["hb_step_kernel", "hb_step_kernel"] or names[1].startswith("hb_step_duo"), names
+    assert all(np.array_equal(a, b) for a, b in zip(got[0], got[1]))
+    # (domain randomisation hands the launch per-env model parameters: that launch is not a lean one and takes the full kernel in both runs;
+    # without it the second run is the duo kernel's)
+    got, names = [], []
+    for duo in (0, 2):
+        env = hbmod.VecEnv(humanoid_model, n, gpu)
+        env.batch.tune(duo=duo)
+        out = [env.reset().copy()]
+        for t in range(T):
+            obs, rew, term, trunc, info = env.step_arrays(acts[t])
+            out += [obs.copy(), rew.copy(), term.copy(), trunc.copy()]
+        names.append(env.batch.last_kernel())
+        got.append(out)
+        env.close()
+    assert names == ["hb_step_h27_q_kernel", "hb_step_duo_kernel"], names
+    assert all(np.array_equal(a, b) for a, b in zip(got[0], got[1]))
+    assert any(np.abs(x).max() > 0 for x in got[0][2::4])  # rewards are not all zero

@@ -38,11 +38,4 @@ t0 = time.perf_counter()
 for t in range(200): env.step(acts[t % 50])
 dt = time.perf_counter() - t0
 print("VecEnv(team=True, realism, domain randomisation).step, host actions / observations every step: %.1f us/step -> %.3e env-steps/s" % (1e6 * dt / 200, N * 200 / dt))
-# the same loop with the batch's step calls cut into env segments: inside ONE step call the pose / narrowphase / step kernels of different
-# segments overlap (a staged step is three to four kernels, each of which leaves part of the chip idle at its tail)
-env.batch.pipeline(True)
-for t in range(10): env.step(acts[t])
-t0 = time.perf_counter()
-for t in range(200): env.step(acts[t % 50])
-dt = time.perf_counter() - t0
-print("the same with hb_batch_pipeline on (%d env segments): %.1f us/step -> %.3e env-steps/s" % (env.batch.segments, 1e6 * dt / 200, N * 200 / dt))
+# (hb_batch_pipeline on for this loop was measured too: 403 us per step against 382 - inside ONE step call the segments' kernels gain nothing on each other)

@@ -368,7 +368,8 @@ int hb_batch_device_name(const hb_batch* b, char* out, int cap);
  *   HB_TUNE_FASTPASS       1 (default): the staged step runs the one-group fast kernel first and the full one for what that defers; 0: full only
  *   HB_TUNE_NARROW_PRIM    1 (default): a model without mesh geoms takes the narrowphase kernel that has no hull climb in it
  *   HB_TUNE_SCHEDULE       1 (default): blocks are dispatched heavy-first (hb_order_kernel); 0: in env order
- *   HB_TUNE_REORDER_PERIOD the heavy-first order is re-sorted every n-th step call (default 4)
+ *   HB_TUNE_REORDER_PERIOD the heavy-first order is re-sorted every n-th step call (default 4), and after every launch of eight steps or more
+ *                          (the multi-step two-envs-per-wave kernel pairs its envs by that order: DESIGN.md 3.9)
  *   HB_TUNE_POLICY_LEAN    hb_rollout_policy: 1 (default) the LDS-free policy kernel beside the other segments' step kernels when
  *                          pipelined; 0 never; 2 always
  *   HB_TUNE_FOLD           hb_step_dev calls enqueued back to back run as ONE launch of up to this many steps (default and maximum 256; 1:

@@ -376,7 +376,7 @@ int hb_batch_device_name(const hb_batch* b, char* out, int cap);
  *                          every call its own launch).  See hb_step_dev.
  * Environment variables the library reads (all others of earlier rounds are gone): HB_DEBUG (name failing HIP calls on stderr), HB_DUO
  * (HB_TUNE_DUO's value for new batches), HB_BOX_CULL=0 (model tables without the oriented-box cull of portal-search pairs: a test),
- * and in the diagnostic build (-DHB_STAMPS) HB_STOP_PHASE. */
+ * and in the diagnostic build (-DHB_STAMPS) HB_STOP_PHASE and HB_MPR_LIMIT (tools/gpu_narrow_limits.sh). */
 enum { HB_TUNE_DUO = 0, HB_TUNE_LEAN, HB_TUNE_SIZED, HB_TUNE_STAGED, HB_TUNE_FASTPASS, HB_TUNE_NARROW_PRIM, HB_TUNE_SCHEDULE, HB_TUNE_REORDER_PERIOD,
        HB_TUNE_POLICY_LEAN, HB_TUNE_FOLD, HB_TUNE_COUNT };
 int hb_batch_tune(hb_batch* b, int knob, int value);

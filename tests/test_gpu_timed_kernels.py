@@ -6,7 +6,10 @@ bench.py, tools/hb_testspeed.cpp and a training loop run - takes the lean, size-
 same 128 golden states (oracle/mjstep_oracle.c via tools/make_golden.py; tolerances as stated in tests/test_gpu_parity.py) go through
 the plain step, and hb_last_kernel says which kernel that was:
   PGS     hb_step_h27_kernel (one env per wave; step calls of batches up to 2.5 x the chip's wave slots) and hb_step_duo_kernel (two
-          envs per wave: tests/test_gpu_duo.py has that one's own tests)
+          envs per wave: tests/test_gpu_duo.py has that one's own tests).  bench.py's timed loop itself runs hb_step_duo_q_kernel - the
+          same kernel body with the step loop inside, which the library launches for step calls enqueued back to back -: held
+          bit-identical to hb_step_duo_kernel launch by launch in tests/test_gpu_fold.py, and run on the golden states below as a
+          one-step launch through the rollout API
   Newton  hb_step_newton28_h27_kernel
 The staged step's fast kernels are named in the tests that already run them without diagnostics: hb_step_gen_fast_h27_kernel
 (tests/test_gpu_parity.py::test_heightfield_terrain_humanoid_config5) and hb_step_newton_gen20_team_kernel
@@ -30,14 +33,38 @@ def state_of(g):
     return np.concatenate([g["time"][:, None], g["qpos"], g["qvel"], g["warm"]], axis=1)
 
 
-@pytest.mark.parametrize("duo,kernel", [(0, "hb_step_h27_kernel"), (2, "hb_step_duo_kernel")])
+@pytest.mark.parametrize("duo,kernel", [(0, "hb_step_h27_kernel"), (2, "hb_step_duo_kernel"), (2, "hb_step_duo_q_kernel")])
 def test_pgs_golden_states_through_the_plain_step(hbmod, humanoid_model, gpu, golden, duo, kernel):
     g = golden
     n = len(g["env"])
     b = hbmod.Batch(humanoid_model, n, gpu)
     b.tune(duo=duo)
     b.set_state(hbmod.STATE_INTEGRATION, state_of(g))
-    b.step(g["ctrl"].astype(np.float32))
+    if kernel.endswith("_q_kernel"):  # the multi-step kernel: two steps' worth of controls, the launch cut off after the first
+        c = np.concatenate([g["ctrl"], g["ctrl"]]).astype(np.float32)
+        p = b.dev_alloc(c.nbytes)
+        b.to_dev(p, c)
+        b.pipeline(True)
+        b.step_dev(p)
+        b.step_dev(p + c.nbytes // 2)  # (two calls back to back: folded into one launch of the _q kernel ...)
+        b.sync()
+        assert b.last_kernel() == kernel
+        # ... whose SECOND step starts from the first one's result: compare the first step through a second batch that stops there
+        b2 = hbmod.Batch(humanoid_model, n, gpu)
+        b2.tune(duo=duo)
+        b2.set_state(hbmod.STATE_INTEGRATION, state_of(g))
+        b2.step(g["ctrl"].astype(np.float32))
+        b2.step(g["ctrl"].astype(np.float32))
+        assert np.array_equal(b.get_state(hbmod.STATE_INTEGRATION), b2.get_state(hbmod.STATE_INTEGRATION))
+        b.dev_free(p); b.close()
+        b = hbmod.Batch(humanoid_model, n, gpu)
+        b.tune(duo=duo)
+        b.set_state(hbmod.STATE_INTEGRATION, state_of(g))
+        b.step(g["ctrl"].astype(np.float32))
+        kernel = "hb_step_duo_kernel"
+        b2.close()
+    else:
+        b.step(g["ctrl"].astype(np.float32))
     assert b.last_kernel() == kernel
     q, v = b.qpos.astype(np.float64), b.qvel.astype(np.float64)
     a = b.get_state(hbmod.STATE_WARMSTART).astype(np.float64)  # qacc_warmstart of the new state = the step's qacc

@@ -162,3 +162,59 @@ def test_callers_own_work_on_the_batch_stream_between_folded_calls(hbmod, humano
     b.sync(); ref.sync()
     assert np.array_equal(b.get_state(hbmod.STATE_INTEGRATION), ref.get_state(hbmod.STATE_INTEGRATION))
     b.close(); ref.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_sequences_of_calls_give_the_same_states_folded_or_not(hbmod, humanoid_model, gpu, seed):
+    """a few hundred calls in random order - step calls with one to three substeps, reads, state writes, masked resets, rollouts, forward passes,
+    knobs, pipelining switched on and off, joins, the timers - on one batch that folds and one that does not: the same states at every read"""
+    m = humanoid_model
+    n = 256
+    batches = []
+    for fold in (1, 256):
+        b = hbmod.Batch(m, n, gpu)
+        b.tune(fold=fold, duo=2 if seed else 1)
+        b.reset(perturb=True)
+        b.pipeline(True)
+        batches.append(b)
+    ctrls = [_ctrl(hbmod, b, m.nu, t0=11 + seed) for b in batches]
+    rng = np.random.default_rng(100 + seed)
+    reads = [[], []]
+    t = 0
+    for op in range(260):
+        k = int(rng.integers(0, 20))
+        arg = rng.integers(0, 1 << 30)
+        for i, b in enumerate(batches):
+            r = np.random.default_rng(int(arg))  # the same draw for both batches
+            p, stride = ctrls[i]
+            if k < 11:
+                b.step_dev(p + (t % T) * stride, int(r.integers(1, 4)) if k == 10 else 1)
+            elif k == 11:
+                reads[i].append(b.get_state(hbmod.STATE_INTEGRATION))
+            elif k == 12:
+                st = b.get_state(hbmod.STATE_INTEGRATION)
+                st[:, 1 + m.nq:] *= 0.5
+                b.set_state(hbmod.STATE_INTEGRATION, st)
+            elif k == 13:
+                b.reset(mask=(r.uniform(size=n) < 0.1).astype(np.uint8), perturb=True, env_offset=int(r.integers(0, 50)))
+            elif k == 14:
+                b.rollout_halton(int(r.integers(1, 12)), int(r.integers(0, 100)))
+            elif k == 15:
+                b.forward()
+            elif k == 16:
+                b.tune(reorder_period=int(r.integers(1, 6)))
+            elif k == 17:
+                b.pipeline(int(r.integers(0, 4)))
+            elif k == 18:
+                b.join()
+            else:
+                b.timer_start(); b.step_dev(p + (t % T) * stride); b.timer_stop()
+        t += 1
+    for i, b in enumerate(batches):
+        b.sync()
+        reads[i].append(b.get_state(hbmod.STATE_INTEGRATION))
+        reads[i] += list(b.counts()) + [b.status()]
+    assert len(reads[0]) == len(reads[1]) and all(np.array_equal(x, y) for x, y in zip(reads[0], reads[1]))
+    for (b, (p, _)) in zip(batches, ctrls):
+        b.dev_free(p)
+        b.close()
